@@ -1,0 +1,252 @@
+"""Oracle (test infrastructure): primal-dual interior-point NLP solver, full-space sparse form.
+
+The reference hands its NLPs to IPOPT through CasADi (`opti.solver("ipopt", ...)`,
+`vehicle_follower.py:356-368`; un-pinned, absent here).  This file restates IPOPT's
+published algorithm (Waechter & Biegler, "On the implementation of an interior-point
+filter line-search algorithm for large-scale nonlinear programming", Math. Prog. 106,
+2006) in the simplified, fully deterministic form that the HIP kernel implements
+(DESIGN.md "CFZ-IPM"):
+
+  kept from the paper   barrier problem and primal-dual equations (eq. 3-4), optimality
+                        error E_mu with s_d/s_c scaling (eq. 5-6), filter line search (sec. 2.3),
+                        monotone barrier update
+                        (eq. 7) with kappa_eps/kappa_mu/theta_mu, fraction-to-the-boundary
+                        (eq. 15), primal/dual step sizes (eq. 14), multiplier safeguard
+                        (eq. 16), initial-point push (sec. 3.6), slack reformulation of
+                        inequalities, termination on tol + constr_viol_tol + dual_inf_tol +
+                        compl_inf_tol, mu floor = min(tol,compl_inf_tol)/(kappa_eps+1).
+  replaced              exact Hessian + inertia correction -> Gauss-Newton Hessian (PSD, so with
+                        the barrier terms the reduced system is positive definite by
+                        construction; `hessian="exact"` keeps the paper's form for the planning
+                        NLPs, whose objective has no state curvature);
+                        restoration phase and second-order correction -> none (a failed line search is
+                        reported as status 2; `VehicleFollower.step` then applies the reference's
+                        own shift fallback, vehicle_follower.py:501-524); the filter keeps at most
+                        `filter_cap` entries.
+
+It works on the whole KKT matrix with a general sparse LU, i.e. it shares no linear
+algebra with the structure-exploiting kernel; agreement of iterates between the two is
+the check that the block elimination + Riccati recursion in the kernel is a correct
+factorisation of the same Newton system.
+"""
+from dataclasses import dataclass
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+@dataclass
+class IpmOptions:
+    tol: float = 1e-2  # vehicle_follower.py:362
+    constr_viol_tol: float = 1e-2  # :363
+    max_iter: int = 600  # :364
+    dual_inf_tol: float = 1.0  # IPOPT default
+    compl_inf_tol: float = 1e-4  # IPOPT default
+    mu_init: float = 0.1
+    kappa_eps: float = 10.0
+    kappa_mu: float = 0.2
+    theta_mu: float = 1.5
+    tau_min: float = 0.99
+    bound_push: float = 1e-2
+    bound_frac: float = 1e-2
+    s_max: float = 100.0
+    kappa_sigma: float = 1e10
+    eta_phi: float = 1e-8
+    gamma_theta: float = 1e-5
+    gamma_phi: float = 1e-8
+    delta_sw: float = 1.0
+    s_theta: float = 1.1
+    s_phi: float = 2.3
+    filter_cap: int = 16
+    max_backtrack: int = 25
+    reg_primal: float = 1e-8
+    reg_dual: float = 1e-9
+    hessian: str = "gn"  # "gn" (kernel's choice) or "exact" (needs nlp.hess_exact; planning NLPs)
+    curv_kappa: float = 1e-8  # exact Hessian: inertia-free curvature test d'(W+Sigma)d >= kappa d'd
+
+
+STATUS_OK, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NAN = 0, 1, 2, 3
+
+
+def push_to_interior(x, xl, xu, opt: IpmOptions):
+    """IPOPT sec. 3.6 initial-point projection."""
+    x = x.copy()
+    hasl, hasu = np.isfinite(xl), np.isfinite(xu)
+    both = hasl & hasu
+    pl = np.where(hasl, opt.bound_push * np.maximum(1.0, np.abs(np.where(hasl, xl, 0.0))), 0.0)
+    pu = np.where(hasu, opt.bound_push * np.maximum(1.0, np.abs(np.where(hasu, xu, 0.0))), 0.0)
+    width = np.where(both, xu - xl, np.inf)
+    pl = np.where(both, np.minimum(pl, opt.bound_frac * width), pl)
+    pu = np.where(both, np.minimum(pu, opt.bound_frac * width), pu)
+    x = np.where(hasl, np.maximum(x, xl + pl), x)
+    x = np.where(hasu, np.minimum(x, xu - pu), x)
+    return x
+
+
+def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
+    """Returns dict(X, nu, zl, zu, status, iters, mu, err, f)."""
+    xl, xu = nlp.xl, nlp.xu
+    hasl, hasu = np.isfinite(xl), np.isfinite(xu)
+    n, m = nlp.n, nlp.m
+    x = push_to_interior(np.asarray(X0, float), xl, xu, opt)
+    zl = np.where(hasl, 1.0, 0.0)
+    zu = np.where(hasu, 1.0, 0.0)
+    nu = np.zeros(m)
+    mu = opt.mu_init
+    mu_floor = min(opt.tol, opt.compl_inf_tol) / (opt.kappa_eps + 1.0)
+    filt, filt_mu = None, None
+    delta_w_last = 0.0
+    theta_min = theta_max = None
+    status = STATUS_MAXITER
+    nb = int(hasl.sum() + hasu.sum())
+
+    def dist(xx):
+        dl = np.where(hasl, xx - np.where(hasl, xl, 0.0), 1.0)
+        du = np.where(hasu, np.where(hasu, xu, 0.0) - xx, 1.0)
+        return dl, du
+
+    def barrier_obj(xx, mu_):
+        dl, du = dist(xx)
+        if (dl <= 0).any() or (du <= 0).any():
+            return np.inf
+        return nlp.f(xx) - mu_ * (np.log(dl[hasl]).sum() + np.log(du[hasu]).sum())
+
+    it = 0
+    err0 = np.inf
+    for it in range(opt.max_iter + 1):
+        g = nlp.grad(x)
+        c, J = nlp._cons_jac(x, True)
+        dl, du = dist(x)
+        if theta_min is None:
+            th0 = np.abs(c).sum()
+            theta_min, theta_max = 1e-4 * max(1.0, th0), 1e4 * max(1.0, th0)
+        # ---- optimality error (paper eq. 5) -----------------------------------------
+        r_dual = g + J.T @ nu - zl + zu
+        s_d = max(opt.s_max, (np.abs(nu).sum() + zl.sum() + zu.sum()) / max(m + nb, 1)) / opt.s_max
+        s_c = max(opt.s_max, (zl.sum() + zu.sum()) / max(nb, 1)) / opt.s_max
+        dual_inf = np.abs(r_dual).max()
+        cviol = np.abs(c).max() if m else 0.0
+        compl_l, compl_u = dl * zl * hasl, du * zu * hasu
+
+        def compl_err(mu_):
+            a = np.abs(compl_l - mu_)[hasl].max() if hasl.any() else 0.0
+            b = np.abs(compl_u - mu_)[hasu].max() if hasu.any() else 0.0
+            return max(a, b)
+
+        def E(mu_):
+            return max(dual_inf / s_d, cviol, compl_err(mu_) / s_c)
+
+        err0 = E(0.0)
+        if not np.isfinite(err0):
+            status = STATUS_NAN
+            break
+        if trace is not None:
+            trace.append(dict(it=it, mu=mu, err0=err0, dual_inf=dual_inf, cviol=cviol, compl=compl_err(0.0),
+                              f=nlp.f(x), x=x.copy(), nu=nu.copy(), zl=zl.copy(), zu=zu.copy()))
+        if (
+            err0 <= opt.tol
+            and dual_inf <= opt.dual_inf_tol
+            and cviol <= opt.constr_viol_tol
+            and compl_err(0.0) <= opt.compl_inf_tol
+        ):
+            status = STATUS_OK
+            break
+        if it == opt.max_iter:
+            break
+        # ---- barrier update (paper eq. 7) ---------------------------------------------
+        while mu > mu_floor and E(mu) <= opt.kappa_eps * mu:
+            mu = max(mu_floor, min(opt.kappa_mu * mu, mu**opt.theta_mu))
+        tau = max(opt.tau_min, 1.0 - mu)
+        # ---- Newton step on the primal-dual equations (paper eq. 11-13) ---------------
+        sig = zl / dl * hasl + zu / du * hasu
+        gphi = g - mu / dl * hasl + mu / du * hasu  # gradient of the barrier objective
+        rhs = -np.concatenate([gphi + J.T @ nu, c])
+        if opt.hessian == "gn":
+            H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
+            K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
+            sol = spla.splu(K).solve(rhs)
+            dx, dnu = sol[:n], sol[n:]
+        else:
+            # exact Hessian; IPOPT's inertia correction (paper sec. 3.1) restated with the
+            # inertia-free curvature test of Chiang & Zavala (2016): raise delta_w until
+            # the step sees positive curvature.
+            W = nlp.hess_exact(x, nu) + sp.diags(sig)
+            trial_delta = 0.0
+            while True:
+                H = W + (trial_delta + opt.reg_primal) * sp.eye(n)
+                K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
+                sol = spla.splu(K).solve(rhs)
+                dx, dnu = sol[:n], sol[n:]
+                if float(dx @ (H @ dx)) >= opt.curv_kappa * float(dx @ dx) and np.isfinite(sol).all():
+                    break
+                trial_delta = 1e-4 if trial_delta == 0.0 else (max(delta_w_last / 3.0, 1e-4) if trial_delta < 0 else trial_delta * 8.0)
+                if trial_delta > 1e20:
+                    break
+            delta_w_last = trial_delta if trial_delta > 0 else delta_w_last
+        dzl = (mu / dl - zl - zl / dl * dx) * hasl
+        dzu = (mu / du - zu + zu / du * dx) * hasu
+        # ---- fraction to the boundary (paper eq. 15) -----------------------------------
+        a_pri = 1.0
+        neg = hasl & (dx < 0)
+        if neg.any():
+            a_pri = min(a_pri, (-tau * dl[neg] / dx[neg]).min())
+        pos = hasu & (dx > 0)
+        if pos.any():
+            a_pri = min(a_pri, (tau * du[pos] / dx[pos]).min())
+        a_dual = 1.0
+        neg = hasl & (dzl < 0)
+        if neg.any():
+            a_dual = min(a_dual, (-tau * zl[neg] / dzl[neg]).min())
+        neg = hasu & (dzu < 0)
+        if neg.any():
+            a_dual = min(a_dual, (-tau * zu[neg] / dzu[neg]).min())
+        # ---- filter line search (paper sec. 2.3, Algorithm A steps A-5.*) ------------------
+        theta = np.abs(c).sum()
+        phi0 = barrier_obj(x, mu)
+        dphi = float(gphi @ dx)
+        if filt is None or filt_mu != mu:  # the filter is re-initialised for every barrier problem
+            filt, filt_mu = [], mu
+        alpha = a_pri
+        accepted = False
+        for _ in range(opt.max_backtrack):
+            xt = x + alpha * dx
+            th_t = np.abs(nlp.cons(xt)).sum()
+            ph_t = barrier_obj(xt, mu)
+            ok = np.isfinite(ph_t) and np.isfinite(th_t) and th_t <= theta_max
+            if ok:
+                for th_f, ph_f in filt:
+                    if th_t >= th_f and ph_t >= ph_f:
+                        ok = False
+                        break
+            f_type = False
+            if ok:
+                switching = (
+                    theta <= theta_min
+                    and dphi < 0.0
+                    and alpha * (-dphi) ** opt.s_phi > opt.delta_sw * theta**opt.s_theta
+                )
+                if switching:
+                    f_type = True
+                    ok = ph_t <= phi0 + opt.eta_phi * alpha * dphi
+                else:
+                    ok = th_t <= (1.0 - opt.gamma_theta) * theta or ph_t <= phi0 - opt.gamma_phi * theta
+            if ok:
+                accepted = True
+                break
+            alpha *= 0.5
+        if not accepted:
+            status = STATUS_LINESEARCH
+            break
+        if not f_type:
+            filt.append(((1.0 - opt.gamma_theta) * theta, phi0 - opt.gamma_phi * theta))
+            if len(filt) > opt.filter_cap:
+                filt.pop(0)
+        x = xt
+        nu = nu + alpha * dnu
+        zl = zl + a_dual * dzl
+        zu = zu + a_dual * dzu
+        # ---- multiplier safeguard (paper eq. 16) ----------------------------------------
+        dl, du = dist(x)
+        zl = np.where(hasl, np.clip(zl, mu / (opt.kappa_sigma * dl), opt.kappa_sigma * mu / dl), 0.0)
+        zu = np.where(hasu, np.clip(zu, mu / (opt.kappa_sigma * du), opt.kappa_sigma * mu / du), 0.0)
+    return dict(X=x, nu=nu, zl=zl, zu=zu, status=status, iters=it, mu=mu, err=err0, f=nlp.f(x))
