@@ -1,0 +1,544 @@
+/* TEST INFRASTRUCTURE ONLY -- plain-C, single-thread port of the MPC-step solver.
+ *
+ * PARITY UNPINNED (see oracle/__init__.py).  This file restates, per problem instance and
+ * with scalar loops, the same algorithm the HIP kernel runs (DESIGN.md "CFZ-IPM"):
+ *   NLP        reference confrez/control/vehicle_follower.py:146-368 (setup_controller), with
+ *              the OBCA duals eliminated into closed-form separation certificates
+ *              (oracle/mpc_nlp.py: block_separation / certificate_duals)
+ *   dynamics   reference confrez/control/dynamic_model.py:5-58 (RK4, M sub-steps)
+ *   solver     oracle/ipm.py (interior point, filter line search) with the Newton system
+ *              solved by slack elimination + Riccati recursion instead of a sparse LU
+ * It is the `cpu_baseline` ("port") of bench.py and the iterate-level reference of the
+ * kernel tests.  The product library never links or calls it.
+ *
+ * Build: gcc -O2 -fPIC -shared -o oracle/_build/libcfz_port.so oracle/cfz_port.c -lm
+ */
+#include <math.h>
+#include <string.h>
+
+#define MAXN 64
+#define MAXB 16
+#define NP 7
+
+typedef struct {
+  int N, n_obs, n_nbr, rk_substeps, max_iter;
+  double dt, wb, dmin;
+  double g[4];
+  double bounds[12];  /* lo,hi for x,y,v,delta,a,w */
+  double weights[6];  /* x,y,psi,a,(v w)^2,delta */
+  double A_obs[MAXB][4][2], b_obs[MAXB][4], V_obs[MAXB][4][2];
+  /* solver options (oracle/ipm.py IpmOptions) */
+  double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu,
+      tau_min, bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw,
+      s_theta, s_phi, reg_primal;
+  int filter_cap, max_backtrack;
+} cfz_port_spec;
+
+typedef struct {
+  double p[MAXN][NP], sg[MAXN][MAXB];              /* primal: stage vars, slacks */
+  double nuc[MAXN][MAXB], zs[MAXN][MAXB];          /* block multipliers, slack bound multipliers */
+  double zl[MAXN][6], zu[MAXN][6];                 /* box multipliers */
+  double pi0[5], pi[MAXN][5];                      /* initial-state and dynamics multipliers */
+} iterate;
+
+static const int BCOL[6] = {0, 1, 3, 4, 5, 6}; /* bounded columns of p */
+static const double GB[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+
+/* ---------------------------------------------------------------- dynamics */
+static void f_ct(const double z[5], const double u[2], double wb, double out[5]) {
+  out[0] = z[3] * cos(z[2]);
+  out[1] = z[3] * sin(z[2]);
+  out[2] = z[3] / wb * tan(z[4]);
+  out[3] = u[0];
+  out[4] = u[1];
+}
+
+/* f and its action on a sensitivity pair (Sz 5x5, Su 5x2) */
+static void f_ct_sens(const double z[5], const double u[2], double wb, const double Sz[5][5],
+                      const double Su[5][2], double f[5], double fz[5][5], double fu[5][2]) {
+  double c = cos(z[2]), s = sin(z[2]), t = tan(z[4]), v = z[3];
+  f[0] = v * c; f[1] = v * s; f[2] = v / wb * t; f[3] = u[0]; f[4] = u[1];
+  double j02 = -v * s, j03 = c, j12 = v * c, j13 = s, j23 = t / wb, j24 = v / wb * (1.0 + t * t);
+  for (int q = 0; q < 5; ++q) {
+    fz[0][q] = j02 * Sz[2][q] + j03 * Sz[3][q];
+    fz[1][q] = j12 * Sz[2][q] + j13 * Sz[3][q];
+    fz[2][q] = j23 * Sz[3][q] + j24 * Sz[4][q];
+    fz[3][q] = 0.0; fz[4][q] = 0.0;
+  }
+  for (int q = 0; q < 2; ++q) {
+    fu[0][q] = j02 * Su[2][q] + j03 * Su[3][q];
+    fu[1][q] = j12 * Su[2][q] + j13 * Su[3][q];
+    fu[2][q] = j23 * Su[3][q] + j24 * Su[4][q];
+    fu[3][q] = (q == 0); fu[4][q] = (q == 1);
+  }
+}
+
+static void rk4(const double z[5], const double u[2], double dt, double wb, int M, double out[5]) {
+  double h = dt / M, zk[5], a1[5], a2[5], a3[5], a4[5], tmp[5];
+  memcpy(zk, z, sizeof zk);
+  for (int m = 0; m < M; ++m) {
+    f_ct(zk, u, wb, a1);
+    for (int i = 0; i < 5; ++i) tmp[i] = zk[i] + h * a1[i] / 2;
+    f_ct(tmp, u, wb, a2);
+    for (int i = 0; i < 5; ++i) tmp[i] = zk[i] + h * a2[i] / 2;
+    f_ct(tmp, u, wb, a3);
+    for (int i = 0; i < 5; ++i) tmp[i] = zk[i] + h * a3[i];
+    f_ct(tmp, u, wb, a4);
+    for (int i = 0; i < 5; ++i) zk[i] = zk[i] + h / 6 * (a1[i] + 2 * a2[i] + 2 * a3[i] + a4[i]);
+  }
+  memcpy(out, zk, sizeof zk);
+}
+
+static void rk4_sens(const double z[5], const double u[2], double dt, double wb, int M, double out[5],
+                     double A[5][5], double B[5][2]) {
+  double h = dt / M, zk[5], Sz[5][5], Su[5][2];
+  memcpy(zk, z, sizeof zk);
+  memset(Sz, 0, sizeof Sz); memset(Su, 0, sizeof Su);
+  for (int i = 0; i < 5; ++i) Sz[i][i] = 1.0;
+  for (int m = 0; m < M; ++m) {
+    double a[4][5], az[4][5][5], au[4][5][2], zt[5], Tz[5][5], Tu[5][2];
+    f_ct_sens(zk, u, wb, Sz, Su, a[0], az[0], au[0]);
+    for (int st = 1; st < 4; ++st) {
+      double w = (st == 3) ? h : h / 2;
+      for (int i = 0; i < 5; ++i) {
+        zt[i] = zk[i] + w * a[st - 1][i];
+        for (int q = 0; q < 5; ++q) Tz[i][q] = Sz[i][q] + w * az[st - 1][i][q];
+        for (int q = 0; q < 2; ++q) Tu[i][q] = Su[i][q] + w * au[st - 1][i][q];
+      }
+      f_ct_sens(zt, u, wb, Tz, Tu, a[st], az[st], au[st]);
+    }
+    for (int i = 0; i < 5; ++i) {
+      zk[i] += h / 6 * (a[0][i] + 2 * a[1][i] + 2 * a[2][i] + a[3][i]);
+      for (int q = 0; q < 5; ++q) Sz[i][q] += h / 6 * (az[0][i][q] + 2 * az[1][i][q] + 2 * az[2][i][q] + az[3][i][q]);
+      for (int q = 0; q < 2; ++q) Su[i][q] += h / 6 * (au[0][i][q] + 2 * au[1][i][q] + 2 * au[2][i][q] + au[3][i][q]);
+    }
+  }
+  memcpy(out, zk, sizeof zk); memcpy(A, Sz, sizeof Sz); memcpy(B, Su, sizeof Su);
+}
+
+/* ---------------------------------------------------------------- separation certificates */
+/* polygon (A,b,V) vs body rectangle at (x,y,psi); returns sep, grad[3], cert = kind*16+face*4+vertex */
+static double block_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
+                        double psi, const double g[4], double grad[3], int *cert) {
+  double c = cos(psi), s = sin(psi);
+  double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  double W[4][2], dW[4][2]; /* world body vertices and their psi-derivatives */
+  for (int v = 0; v < 4; ++v) {
+    W[v][0] = x + c * BV[v][0] - s * BV[v][1];
+    W[v][1] = y + s * BV[v][0] + c * BV[v][1];
+    dW[v][0] = -s * BV[v][0] - c * BV[v][1];
+    dW[v][1] = c * BV[v][0] - s * BV[v][1];
+  }
+  double best = 0.0; int have = 0;
+  for (int i = 0; i < 4; ++i) {
+    int vm = 0; double dm = 0.0;
+    for (int v = 0; v < 4; ++v) {
+      double d = W[v][0] * A[i][0] + W[v][1] * A[i][1] - b[i];
+      if (v == 0 || d < dm) { dm = d; vm = v; }
+    }
+    if (!have || dm > best) {
+      have = 1; best = dm;
+      grad[0] = A[i][0]; grad[1] = A[i][1]; grad[2] = A[i][0] * dW[vm][0] + A[i][1] * dW[vm][1];
+      *cert = 16 + 4 * i + vm;
+    }
+  }
+  for (int k = 0; k < 4; ++k) {
+    double nx = c * GB[k][0] - s * GB[k][1], ny = s * GB[k][0] + c * GB[k][1];
+    double dnx = -s * GB[k][0] - c * GB[k][1], dny = c * GB[k][0] - s * GB[k][1];
+    int vm = 0; double dm = 0.0;
+    for (int v = 0; v < 4; ++v) {
+      double d = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[k];
+      if (v == 0 || d < dm) { dm = d; vm = v; }
+    }
+    if (dm > best) {
+      best = dm;
+      grad[0] = -nx; grad[1] = -ny; grad[2] = dnx * (V[vm][0] - x) + dny * (V[vm][1] - y);
+      *cert = 32 + 4 * k + vm;
+    }
+  }
+  return best;
+}
+
+static void nbr_polygon(const double *nbr, int N, int o, int k, const double g[4], double A[4][2], double b[4],
+                        double V[4][2]) {
+  double xo = nbr[(o * 3 + 0) * N + k], yo = nbr[(o * 3 + 1) * N + k], po = nbr[(o * 3 + 2) * N + k];
+  double c = cos(po), s = sin(po);
+  double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  for (int i = 0; i < 4; ++i) {
+    A[i][0] = c * GB[i][0] - s * GB[i][1];
+    A[i][1] = s * GB[i][0] + c * GB[i][1];
+    b[i] = A[i][0] * xo + A[i][1] * yo + g[i];
+    V[i][0] = xo + c * BV[i][0] - s * BV[i][1];
+    V[i][1] = yo + s * BV[i][0] + c * BV[i][1];
+  }
+}
+
+static void eval_blocks(const cfz_port_spec *sp, const double *nbr, const double p[][NP], double sep[][MAXB],
+                        double grad[][MAXB][3], int cert[][MAXB]) {
+  int nb = sp->n_obs + sp->n_nbr;
+  for (int k = 0; k < sp->N; ++k)
+    for (int j = 0; j < nb; ++j) {
+      double gr[3]; int ce;
+      if (j < sp->n_obs) {
+        sep[k][j] = block_sep(sp->A_obs[j], sp->b_obs[j], sp->V_obs[j], p[k][0], p[k][1], p[k][2], sp->g, gr, &ce);
+      } else {
+        double A[4][2], b[4], V[4][2];
+        nbr_polygon(nbr, sp->N, j - sp->n_obs, k, sp->g, A, b, V);
+        sep[k][j] = block_sep(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, gr, &ce);
+      }
+      if (grad) { grad[k][j][0] = gr[0]; grad[k][j][1] = gr[1]; grad[k][j][2] = gr[2]; }
+      if (cert) cert[k][j] = ce;
+    }
+}
+
+/* ---------------------------------------------------------------- objective */
+static double stage_cost(const cfz_port_spec *sp, const double *ref, int k, const double p[NP]) {
+  const double *w = sp->weights; int N = sp->N;
+  double ex = p[0] - ref[0 * N + k], ey = p[1] - ref[1 * N + k], ep = p[2] - ref[2 * N + k];
+  return w[0] * ex * ex + w[1] * ey * ey + w[2] * ep * ep + w[3] * p[5] * p[5] + w[4] * p[3] * p[3] * p[6] * p[6] +
+         w[5] * p[4] * p[4];
+}
+static void stage_grad(const cfz_port_spec *sp, const double *ref, int k, const double p[NP], double gr[NP]) {
+  const double *w = sp->weights; int N = sp->N;
+  gr[0] = 2 * w[0] * (p[0] - ref[0 * N + k]);
+  gr[1] = 2 * w[1] * (p[1] - ref[1 * N + k]);
+  gr[2] = 2 * w[2] * (p[2] - ref[2 * N + k]);
+  gr[3] = 2 * w[4] * p[3] * p[6] * p[6];
+  gr[4] = 2 * w[5] * p[4];
+  gr[5] = 2 * w[3] * p[5];
+  gr[6] = 2 * w[4] * p[3] * p[3] * p[6];
+}
+
+/* theta = |c|_1 and barrier objective at a trial point (p, sg); returns 0 if outside bounds */
+static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr,
+                       const double p[][NP], const double sg[][MAXB], double mu, double *theta, double *phi) {
+  int N = sp->N, nb = sp->n_obs + sp->n_nbr;
+  double th = 0.0, ph = 0.0, lg = 0.0;
+  static double sep[MAXN][MAXB];
+  for (int k = 0; k < N; ++k) {
+    for (int q = 0; q < 6; ++q) {
+      double dl = p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - p[k][BCOL[q]];
+      if (!(dl > 0.0) || !(du > 0.0)) return 0;
+      lg += log(dl) + log(du);
+    }
+    for (int j = 0; j < nb; ++j) {
+      if (!(sg[k][j] > 0.0)) return 0;
+      lg += log(sg[k][j]);
+    }
+    ph += stage_cost(sp, ref, k, p[k]);
+  }
+  for (int i = 0; i < 5; ++i) th += fabs(p[0][i] - x0[i]);
+  for (int k = 0; k + 1 < N; ++k) {
+    double F[5];
+    rk4(p[k], p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, F);
+    for (int i = 0; i < 5; ++i) th += fabs(F[i] - p[k + 1][i]);
+  }
+  eval_blocks(sp, nbr, p, sep, 0, 0);
+  for (int k = 0; k < N; ++k)
+    for (int j = 0; j < nb; ++j) th += fabs(sep[k][j] - sp->dmin - sg[k][j]);
+  *theta = th; *phi = ph - mu * lg;
+  return isfinite(th) && isfinite(*phi);
+}
+
+/* ---------------------------------------------------------------- small dense helpers */
+static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *out) {
+  /* out = M^{-1} rhs for nr right-hand sides stored as rhs[2][nr] (row-major) via Cholesky */
+  double l00 = sqrt(M[0][0]), l10 = M[1][0] / l00, l11 = sqrt(M[1][1] - l10 * l10);
+  for (int q = 0; q < nr; ++q) {
+    double y0 = rhs[0 * nr + q] / l00, y1 = (rhs[1 * nr + q] - l10 * y0) / l11;
+    double x1 = y1 / l11, x0 = (y0 - l10 * x1) / l00;
+    out[0 * nr + q] = x0; out[1 * nr + q] = x1;
+  }
+}
+
+/* ---------------------------------------------------------------- the solver */
+/* p_io: [N][7] warm start in (x,y,psi,v,delta,a,w per stage), solution out.
+ * stats: [0]=iters [1]=status(0 ok,1 maxiter,2 linesearch,3 nan) ; fstats: [0]=f [1]=err [2]=mu
+ * trace (optional): per iteration 4 doubles (mu, err0, cviol, dual_inf) then p[N][7] -> stride 4+7N */
+int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
+                   double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap) {
+  const int N = sp->N, nb = sp->n_obs + sp->n_nbr;
+  if (N > MAXN || N < 2 || nb > MAXB) return -1;
+  static iterate it, dt_; /* step stored in an `iterate` too */
+  static double sep[MAXN][MAXB], gra[MAXN][MAXB][3], cj[MAXN][MAXB];
+  static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
+  static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
+  static double Kk[MAXN][2][5], kf[MAXN][2];
+  static double pt[MAXN][NP], sgt[MAXN][MAXB];
+  double filt[64][2]; int nfilt = 0; double filt_mu = -1.0;
+  double theta_min = -1.0, theta_max = -1.0;
+  const double mu_floor = fmin(sp->tol, sp->compl_inf_tol) / (sp->kappa_eps + 1.0);
+  double mu = sp->mu_init;
+  int status = 1, iter = 0;
+  double err0 = INFINITY;
+  const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb);
+
+  /* ---- initial point: slacks from the un-pushed warm start, then push everything inside */
+  for (int k = 0; k < N; ++k) for (int i = 0; i < NP; ++i) it.p[k][i] = p_io[k * NP + i];
+  eval_blocks(sp, nbr, it.p, sep, 0, 0);
+  for (int k = 0; k < N; ++k) {
+    for (int q = 0; q < 6; ++q) {
+      double lo = sp->bounds[2 * q], hi = sp->bounds[2 * q + 1];
+      double pl = fmin(sp->bound_push * fmax(1.0, fabs(lo)), sp->bound_frac * (hi - lo));
+      double pu = fmin(sp->bound_push * fmax(1.0, fabs(hi)), sp->bound_frac * (hi - lo));
+      double v = it.p[k][BCOL[q]];
+      v = fmax(v, lo + pl); v = fmin(v, hi - pu);
+      it.p[k][BCOL[q]] = v; it.zl[k][q] = 1.0; it.zu[k][q] = 1.0;
+    }
+    for (int j = 0; j < nb; ++j) {
+      it.sg[k][j] = fmax(sep[k][j] - sp->dmin, sp->bound_push);
+      it.zs[k][j] = 1.0; it.nuc[k][j] = 0.0;
+    }
+    for (int i = 0; i < 5; ++i) it.pi[k][i] = 0.0;
+  }
+  for (int i = 0; i < 5; ++i) it.pi0[i] = 0.0;
+
+  for (iter = 0; iter <= sp->max_iter; ++iter) {
+    /* ---- evaluate ----------------------------------------------------------------- */
+    int cert[MAXN][MAXB];
+    eval_blocks(sp, nbr, it.p, sep, gra, cert);
+    double cviol = 0.0, theta = 0.0;
+    for (int i = 0; i < 5; ++i) { double r = it.p[0][i] - x0[i]; cviol = fmax(cviol, fabs(r)); theta += fabs(r); }
+    for (int k = 0; k + 1 < N; ++k) {
+      rk4_sens(it.p[k], it.p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, Fk[k], Ak[k], Bk[k]);
+      for (int i = 0; i < 5; ++i) { dk[k][i] = Fk[k][i] - it.p[k + 1][i]; cviol = fmax(cviol, fabs(dk[k][i])); theta += fabs(dk[k][i]); }
+    }
+    for (int k = 0; k < N; ++k)
+      for (int j = 0; j < nb; ++j) { cj[k][j] = sep[k][j] - sp->dmin - it.sg[k][j]; cviol = fmax(cviol, fabs(cj[k][j])); theta += fabs(cj[k][j]); }
+    if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+    /* dual infeasibility, multiplier sums, complementarity */
+    double dual_inf = 0.0, sum_nu = 0.0, sum_z = 0.0, fval = 0.0;
+    double cmp0 = 0.0, cmpmu = 0.0; /* max |d*z - 0| and max |d*z - mu| */
+    for (int i = 0; i < 5; ++i) sum_nu += fabs(it.pi0[i]);
+    for (int k = 0; k < N; ++k) {
+      double gr[NP], r[NP];
+      stage_grad(sp, ref, k, it.p[k], gr);
+      fval += stage_cost(sp, ref, k, it.p[k]);
+      for (int i = 0; i < NP; ++i) r[i] = gr[i];
+      for (int j = 0; j < nb; ++j) {
+        for (int q = 0; q < 3; ++q) r[q] += gra[k][j][q] * it.nuc[k][j];
+        dual_inf = fmax(dual_inf, fabs(-it.nuc[k][j] - it.zs[k][j]));
+        sum_nu += fabs(it.nuc[k][j]); sum_z += it.zs[k][j];
+        double cz = it.sg[k][j] * it.zs[k][j];
+        cmp0 = fmax(cmp0, fabs(cz)); cmpmu = fmax(cmpmu, fabs(cz - mu));
+      }
+      if (k + 1 < N) {
+        for (int i = 0; i < 5; ++i) {
+          sum_nu += fabs(it.pi[k][i]);
+          for (int q = 0; q < 5; ++q) r[q] += Ak[k][i][q] * it.pi[k][i];
+          for (int q = 0; q < 2; ++q) r[5 + q] += Bk[k][i][q] * it.pi[k][i];
+        }
+      }
+      if (k == 0) for (int i = 0; i < 5; ++i) r[i] += it.pi0[i];
+      else for (int i = 0; i < 5; ++i) r[i] -= it.pi[k - 1][i];
+      for (int q = 0; q < 6; ++q) {
+        r[BCOL[q]] += -it.zl[k][q] + it.zu[k][q];
+        sum_z += it.zl[k][q] + it.zu[k][q];
+        double dl = it.p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - it.p[k][BCOL[q]];
+        cmp0 = fmax(cmp0, fmax(fabs(dl * it.zl[k][q]), fabs(du * it.zu[k][q])));
+        cmpmu = fmax(cmpmu, fmax(fabs(dl * it.zl[k][q] - mu), fabs(du * it.zu[k][q] - mu)));
+      }
+      for (int i = 0; i < NP; ++i) dual_inf = fmax(dual_inf, fabs(r[i]));
+    }
+    double s_d = fmax(sp->s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp->s_max;
+    double s_c = fmax(sp->s_max, sum_z / (double)n_bnd) / sp->s_max;
+    err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
+    if (trace && iter < trace_cap) {
+      double *tr = trace + (size_t)iter * (4 + NP * N);
+      tr[0] = mu; tr[1] = err0; tr[2] = cviol; tr[3] = dual_inf;
+      for (int k = 0; k < N; ++k) for (int i = 0; i < NP; ++i) tr[4 + k * NP + i] = it.p[k][i];
+    }
+    if (!isfinite(err0)) { status = 3; break; }
+    if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
+    if (iter == sp->max_iter) break;
+    /* ---- barrier update ------------------------------------------------------------- */
+    while (mu > mu_floor) {
+      /* complementarity error against the current mu has to be recomputed for each candidate mu */
+      double cm = 0.0;
+      for (int k = 0; k < N; ++k) {
+        for (int j = 0; j < nb; ++j) cm = fmax(cm, fabs(it.sg[k][j] * it.zs[k][j] - mu));
+        for (int q = 0; q < 6; ++q) {
+          double dl = it.p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - it.p[k][BCOL[q]];
+          cm = fmax(cm, fmax(fabs(dl * it.zl[k][q] - mu), fabs(du * it.zu[k][q] - mu)));
+        }
+      }
+      double emu = fmax(dual_inf / s_d, fmax(cviol, cm / s_c));
+      if (emu <= sp->kappa_eps * mu) mu = fmax(mu_floor, fmin(sp->kappa_mu * mu, pow(mu, sp->theta_mu)));
+      else break;
+    }
+    (void)cmpmu;
+    double tau = fmax(sp->tau_min, 1.0 - mu);
+    /* ---- condensed stage QP ----------------------------------------------------------- */
+    double dphi = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const double *w = sp->weights; const double *p = it.p[k];
+      memset(H[k], 0, sizeof H[k]);
+      stage_grad(sp, ref, k, p, gphi[k]);
+      H[k][0][0] = 2 * w[0]; H[k][1][1] = 2 * w[1]; H[k][2][2] = 2 * w[2]; H[k][4][4] = 2 * w[5]; H[k][5][5] = 2 * w[3];
+      H[k][3][3] = 2 * w[4] * p[6] * p[6]; H[k][6][6] = 2 * w[4] * p[3] * p[3];
+      H[k][3][6] = H[k][6][3] = 2 * w[4] * p[3] * p[6];
+      for (int i = 0; i < NP; ++i) H[k][i][i] += sp->reg_primal;
+      for (int q = 0; q < 6; ++q) {
+        double dl = p[BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - p[BCOL[q]];
+        H[k][BCOL[q]][BCOL[q]] += it.zl[k][q] / dl + it.zu[k][q] / du;
+        gphi[k][BCOL[q]] += -mu / dl + mu / du;
+      }
+      for (int i = 0; i < NP; ++i) gk[k][i] = gphi[k][i];
+      for (int j = 0; j < nb; ++j) {
+        double S = it.zs[k][j] / it.sg[k][j] + sp->reg_primal;
+        double coef = S * cj[k][j] - mu / it.sg[k][j];
+        for (int a = 0; a < 3; ++a) {
+          gk[k][a] += gra[k][j][a] * coef;
+          for (int b = 0; b < 3; ++b) H[k][a][b] += S * gra[k][j][a] * gra[k][j][b];
+        }
+      }
+    }
+    /* ---- Riccati backward: value function 0.5 dz'P_k dz + p_k'dz kept for every stage ------- */
+    static double Ps[MAXN][5][5], ps[MAXN][5];
+    {
+      int k = N - 1; /* terminal stage: its inputs a,w are costed but drive no dynamics */
+      double R2[2][2] = {{H[k][5][5], H[k][5][6]}, {H[k][6][5], H[k][6][6]}};
+      double rhs[2][6], sol[2][6];
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[k][5 + a][q]; rhs[a][5] = gk[k][5 + a]; }
+      sym2_solve(R2, &rhs[0][0], 6, &sol[0][0]);
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) Ps[k][i][q] = H[k][i][q] + H[k][5][i] * Kk[k][0][q] + H[k][6][i] * Kk[k][1][q];
+        ps[k][i] = gk[k][i] + H[k][5][i] * kf[k][0] + H[k][6][i] * kf[k][1];
+      }
+    }
+    for (int k = N - 2; k >= 0; --k) {
+      double PA[5][5], PB[5][2], Pd[5];
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Ak[k][r][q]; PA[i][q] = s; }
+        for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Bk[k][r][q]; PB[i][q] = s; }
+        double s = ps[k + 1][i]; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * dk[k][r]; Pd[i] = s;
+      }
+      double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
+      for (int a = 0; a < 2; ++a) {
+        for (int b = 0; b < 2; ++b) { double s = H[k][5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PB[r][b]; Huu[a][b] = s; }
+        for (int q = 0; q < 5; ++q) { double s = H[k][5 + a][q]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PA[r][q]; Hux[a][q] = s; }
+        double s = gk[k][5 + a]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * Pd[r]; hu[a] = s;
+      }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) { double s = H[k][i][q]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * PA[r][q]; Hxx[i][q] = s; }
+        double s = gk[k][i]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * Pd[r]; hx[i] = s;
+      }
+      double rhs[2][6], sol[2][6];
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
+      sym2_solve(Huu, &rhs[0][0], 6, &sol[0][0]);
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) Ps[k][i][q] = Hxx[i][q] + Hux[0][i] * Kk[k][0][q] + Hux[1][i] * Kk[k][1][q];
+        ps[k][i] = hx[i] + Hux[0][i] * kf[k][0] + Hux[1][i] * kf[k][1];
+      }
+      for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { double s = 0.5 * (Ps[k][i][q] + Ps[k][q][i]); Ps[k][i][q] = Ps[k][q][i] = s; }
+    }
+    /* ---- forward sweep: dp, new multipliers ------------------------------------------------ */
+    for (int i = 0; i < 5; ++i) dt_.p[0][i] = x0[i] - it.p[0][i];
+    for (int k = 0; k < N; ++k) {
+      for (int a = 0; a < 2; ++a) { double s = kf[k][a]; for (int q = 0; q < 5; ++q) s += Kk[k][a][q] * dt_.p[k][q]; dt_.p[k][5 + a] = s; }
+      if (k + 1 < N)
+        for (int i = 0; i < 5; ++i) {
+          double s = dk[k][i];
+          for (int q = 0; q < 5; ++q) s += Ak[k][i][q] * dt_.p[k][q];
+          for (int q = 0; q < 2; ++q) s += Bk[k][i][q] * dt_.p[k][5 + q];
+          dt_.p[k + 1][i] = s;
+        }
+    }
+    for (int i = 0; i < 5; ++i) { double s = ps[0][i]; for (int q = 0; q < 5; ++q) s += Ps[0][i][q] * dt_.p[0][q]; dt_.pi0[i] = -s - it.pi0[i]; }
+    for (int k = 0; k + 1 < N; ++k)
+      for (int i = 0; i < 5; ++i) { double s = ps[k + 1][i]; for (int q = 0; q < 5; ++q) s += Ps[k + 1][i][q] * dt_.p[k + 1][q]; dt_.pi[k][i] = s - it.pi[k][i]; }
+    /* ---- slack / multiplier steps, fraction to the boundary ----------------------------------- */
+    double a_pri = 1.0, a_dual = 1.0;
+    for (int k = 0; k < N; ++k) {
+      for (int i = 0; i < NP; ++i) dphi += gphi[k][i] * dt_.p[k][i];
+      for (int j = 0; j < nb; ++j) {
+        double ds = cj[k][j]; for (int a = 0; a < 3; ++a) ds += gra[k][j][a] * dt_.p[k][a];
+        double S = it.zs[k][j] / it.sg[k][j] + sp->reg_primal;
+        dt_.sg[k][j] = ds;
+        dt_.nuc[k][j] = S * ds - mu / it.sg[k][j] - it.nuc[k][j];
+        dt_.zs[k][j] = mu / it.sg[k][j] - it.zs[k][j] - it.zs[k][j] / it.sg[k][j] * ds;
+        dphi += -mu / it.sg[k][j] * ds;
+        if (ds < 0.0) a_pri = fmin(a_pri, -tau * it.sg[k][j] / ds);
+        if (dt_.zs[k][j] < 0.0) a_dual = fmin(a_dual, -tau * it.zs[k][j] / dt_.zs[k][j]);
+      }
+      for (int q = 0; q < 6; ++q) {
+        double dx = dt_.p[k][BCOL[q]];
+        double dl = it.p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - it.p[k][BCOL[q]];
+        dt_.zl[k][q] = mu / dl - it.zl[k][q] - it.zl[k][q] / dl * dx;
+        dt_.zu[k][q] = mu / du - it.zu[k][q] + it.zu[k][q] / du * dx;
+        if (dx < 0.0) a_pri = fmin(a_pri, -tau * dl / dx);
+        if (dx > 0.0) a_pri = fmin(a_pri, tau * du / dx);
+        if (dt_.zl[k][q] < 0.0) a_dual = fmin(a_dual, -tau * it.zl[k][q] / dt_.zl[k][q]);
+        if (dt_.zu[k][q] < 0.0) a_dual = fmin(a_dual, -tau * it.zu[k][q] / dt_.zu[k][q]);
+      }
+    }
+    /* ---- filter line search ---------------------------------------------------------------- */
+    double phi0;
+    {
+      double th_dummy;
+      if (!merit_terms(sp, x0, ref, nbr, it.p, it.sg, mu, &th_dummy, &phi0)) { status = 3; break; }
+    }
+    if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
+    double alpha = a_pri; int accepted = 0, f_type = 0;
+    for (int bt = 0; bt < sp->max_backtrack; ++bt) {
+      for (int k = 0; k < N; ++k) {
+        for (int i = 0; i < NP; ++i) pt[k][i] = it.p[k][i] + alpha * dt_.p[k][i];
+        for (int j = 0; j < nb; ++j) sgt[k][j] = it.sg[k][j] + alpha * dt_.sg[k][j];
+      }
+      double th_t, ph_t;
+      int ok = merit_terms(sp, x0, ref, nbr, pt, sgt, mu, &th_t, &ph_t) && th_t <= theta_max;
+      if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = 0; break; }
+      f_type = 0;
+      if (ok) {
+        int sw = theta <= theta_min && dphi < 0.0 && alpha * pow(-dphi, sp->s_phi) > sp->delta_sw * pow(theta, sp->s_theta);
+        if (sw) { f_type = 1; ok = ph_t <= phi0 + sp->eta_phi * alpha * dphi; }
+        else ok = th_t <= (1.0 - sp->gamma_theta) * theta || ph_t <= phi0 - sp->gamma_phi * theta;
+      }
+      if (ok) { accepted = 1; break; }
+      alpha *= 0.5;
+    }
+    if (!accepted) { status = 2; break; }
+    if (!f_type) {
+      if (nfilt == sp->filter_cap) { memmove(filt, filt + 1, sizeof(double) * 2 * (nfilt - 1)); nfilt--; }
+      filt[nfilt][0] = (1.0 - sp->gamma_theta) * theta; filt[nfilt][1] = phi0 - sp->gamma_phi * theta; nfilt++;
+    }
+    /* ---- update ------------------------------------------------------------------------------ */
+    for (int i = 0; i < 5; ++i) it.pi0[i] += alpha * dt_.pi0[i];
+    for (int k = 0; k < N; ++k) {
+      for (int i = 0; i < NP; ++i) it.p[k][i] = pt[k][i];
+      if (k + 1 < N) for (int i = 0; i < 5; ++i) it.pi[k][i] += alpha * dt_.pi[k][i];
+      for (int j = 0; j < nb; ++j) {
+        it.sg[k][j] = sgt[k][j];
+        it.nuc[k][j] += alpha * dt_.nuc[k][j];
+        double z = it.zs[k][j] + a_dual * dt_.zs[k][j];
+        it.zs[k][j] = fmin(fmax(z, mu / (sp->kappa_sigma * it.sg[k][j])), sp->kappa_sigma * mu / it.sg[k][j]);
+      }
+      for (int q = 0; q < 6; ++q) {
+        double dl = it.p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - it.p[k][BCOL[q]];
+        double z = it.zl[k][q] + a_dual * dt_.zl[k][q];
+        it.zl[k][q] = fmin(fmax(z, mu / (sp->kappa_sigma * dl)), sp->kappa_sigma * mu / dl);
+        z = it.zu[k][q] + a_dual * dt_.zu[k][q];
+        it.zu[k][q] = fmin(fmax(z, mu / (sp->kappa_sigma * du)), sp->kappa_sigma * mu / du);
+      }
+    }
+  }
+  /* ---- output ---------------------------------------------------------------------------------- */
+  int cert[MAXN][MAXB];
+  eval_blocks(sp, nbr, it.p, sep, 0, cert);
+  double fval = 0.0;
+  for (int k = 0; k < N; ++k) {
+    fval += stage_cost(sp, ref, k, it.p[k]);
+    for (int i = 0; i < NP; ++i) p_io[k * NP + i] = it.p[k][i];
+    for (int j = 0; j < nb; ++j) {
+      if (sep_out) sep_out[k * nb + j] = sep[k][j];
+      if (cert_out) cert_out[k * nb + j] = cert[k][j];
+    }
+  }
+  stats[0] = iter; stats[1] = status;
+  fstats[0] = fval; fstats[1] = err0; fstats[2] = mu;
+  return 0;
+}
+
+int cfz_port_sizeof_spec(void) { return (int)sizeof(cfz_port_spec); }

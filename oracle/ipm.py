@@ -60,7 +60,7 @@ class IpmOptions:
     filter_cap: int = 16
     max_backtrack: int = 25
     reg_primal: float = 1e-8
-    reg_dual: float = 1e-9
+    reg_dual: float = 0.0
     hessian: str = "gn"  # "gn" (kernel's choice) or "exact" (needs nlp.hess_exact; planning NLPs)
     curv_kappa: float = 1e-8  # exact Hessian: inertia-free curvature test d'(W+Sigma)d >= kappa d'd
 

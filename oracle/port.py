@@ -1,0 +1,83 @@
+"""Oracle (test infrastructure): ctypes binding of the plain-C port `oracle/cfz_port.c`."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .ipm import IpmOptions
+from .mpc_nlp import MpcSpec, polytope_vertices
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libcfz_port.so")
+MAXB = 16
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cfz_port.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _LIB, src, "-lm"])
+    return _LIB
+
+
+class _Spec(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("n_obs", C.c_int), ("n_nbr", C.c_int), ("rk_substeps", C.c_int), ("max_iter", C.c_int),
+        ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
+        ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
+        ("A_obs", C.c_double * (MAXB * 8)), ("b_obs", C.c_double * (MAXB * 4)), ("V_obs", C.c_double * (MAXB * 8)),
+    ] + [(k, C.c_double) for k in (
+        "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
+        "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split()
+    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int)]
+
+
+def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
+    s = _Spec()
+    s.N, s.n_obs, s.n_nbr, s.rk_substeps, s.max_iter = spec.N, spec.n_obs, spec.n_nbr, spec.rk_substeps, opt.max_iter
+    s.dt, s.wb, s.dmin = spec.dt, spec.wb, spec.dmin
+    s.g[:] = list(spec.g)
+    s.bounds[:] = list(spec.bounds)
+    s.weights[:] = list(spec.weights)
+    A = np.zeros((MAXB, 4, 2)); b = np.zeros((MAXB, 4)); V = np.zeros((MAXB, 4, 2))
+    for j in range(spec.n_obs):
+        A[j], b[j] = spec.A_obs[j], spec.b_obs[j]
+        V[j] = polytope_vertices(spec.A_obs[j], spec.b_obs[j])[0]
+    s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel()); s.V_obs[:] = list(V.ravel())
+    for k in ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
+              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split():
+        setattr(s, k, getattr(opt, k))
+    s.filter_cap, s.max_backtrack = opt.filter_cap, opt.max_backtrack
+    return s
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        assert _lib.cfz_port_sizeof_spec() == C.sizeof(_Spec), "struct layout mismatch"
+    return _lib
+
+
+def solve(spec: MpcSpec, x0, ref, nbr, warm_p, opt: IpmOptions = IpmOptions(), trace_cap=0):
+    """warm_p [N,7] -> dict(p [N,7], sep [N,nb], cert [N,nb], iters, status, f, err, mu, trace)."""
+    lib = _load()
+    N, nb = spec.N, spec.n_blk
+    cs = make_spec(spec, opt)
+    p = np.ascontiguousarray(warm_p, dtype=np.float64).copy()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    nbr = np.ascontiguousarray(nbr if spec.n_nbr else np.zeros(1), dtype=np.float64)
+    sep = np.zeros((N, nb)); cert = np.zeros((N, nb), dtype=np.int32)
+    stats = np.zeros(2, dtype=np.int32); fst = np.zeros(3)
+    trace = np.zeros((max(trace_cap, 1), 4 + 7 * N))
+    dp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.cfz_port_solve(C.byref(cs), dp(x0), dp(ref), dp(nbr), dp(p), dp(sep), dp(cert), dp(stats), dp(fst),
+                            dp(trace) if trace_cap else None, C.c_int(trace_cap))
+    assert rc == 0
+    return dict(p=p, sep=sep, cert=cert, iters=int(stats[0]), status=int(stats[1]), f=fst[0], err=fst[1], mu=fst[2],
+                trace=trace[: min(trace_cap, stats[0] + 1)])
