@@ -1,0 +1,391 @@
+// cfz_engine.hip -- libconfrez_hip.so: gfx950 kernels and the C ABI of include/confrez_hip.h.
+//
+// Kernels
+//   solve_kernel   one 64-lane workgroup (one wavefront) per MPC-step NLP; iterate, stage data
+//                  and reduction scratch in LDS (cfz_solver.inl); parameters, warm start and
+//                  solution are the only global-memory traffic (8*(5 + 3N + 3N n_nbr + 2*7N) B
+//                  per instance).
+//   loop_prep      closed loop: parameters and shifted warm start of every vehicle from the
+//                  previous predictions (reference vehicle_follower.py:432-476, 636-637)
+//   loop_post      closed loop: read-back or shift fallback, plant integration, clock
+//                  (reference :484-563)
+// Host side: a handle owns all device buffers, one stream and two events.
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/confrez_hip.h"
+#include "cfz_solver.inl"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *what, hipError_t e = hipSuccess) {
+  g_err = what;
+  if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+  return -1;
+}
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(#call, e_); } while (0)
+
+struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
+
+__global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
+                                                   const double *ref, const double *nbr, double *zu, int32_t *status,
+                                                   int32_t *iters, double *stats, DualPtrs du) {
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int N = sp.N, no = sp.n_obs, nn = sp.n_nbr;
+  int oi[2]; double od[3];
+  cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (du.l) {
+    duo.l = du.l + (size_t)b * N * 4 * no; duo.mm = du.m + (size_t)b * N * 4 * no;
+    duo.lam_ij = du.lam_ij + (size_t)b * nn * N * 4; duo.lam_ji = du.lam_ji + (size_t)b * nn * N * 4;
+    duo.s = du.s + (size_t)b * nn * N * 2;
+  }
+  cfz::solve_instance(sp, x0 + (size_t)b * 5, ref + (size_t)b * 3 * N, nbr + (size_t)b * nn * 3 * N,
+                      zu + (size_t)b * 7 * N, smem, L, oi, od, duo);
+  if (threadIdx.x == 0) {
+    iters[b] = oi[0]; status[b] = oi[1];
+    stats[b * 3 + 0] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
+  }
+}
+
+// ---- closed loop ------------------------------------------------------------------------------
+// pred[S][V][7][N] last predictions, state[S][V][5], kidx[S] reference sample index.
+// One thread per (instance, stage).
+__global__ void loop_prep(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
+                          const double *pred, const double *state, double *x0, double *ref, double *nbr,
+                          double *zu) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)S * V * N) return;
+  const int k = (int)(tid % N);
+  const int b = (int)(tid / N);
+  const int s = b / V, v = b - s * V;
+  const int ka = (k + 1 < N) ? k + 1 : N - 1;  // _adv_onestep (:413-426)
+  if (k < 5) x0[b * 5 + k] = state[b * 5 + k];
+  int kr = kidx[s] + k; if (kr > T - 1) kr = T - 1;
+  for (int c = 0; c < 3; ++c) ref[((size_t)b * 3 + c) * N + k] = ref_table[((size_t)v * T + kr) * 3 + c];
+  for (int c = 0; c < 7; ++c) zu[((size_t)b * 7 + c) * N + k] = pred[((size_t)b * 7 + c) * N + ka];
+  int o = 0;
+  for (int u = 0; u < V; ++u) {
+    if (u == v) continue;
+    const size_t bo = (size_t)s * V + u;
+    for (int c = 0; c < 3; ++c) nbr[(((size_t)b * (V - 1) + o) * 3 + c) * N + k] = pred[(bo * 7 + c) * N + ka];
+    ++o;
+  }
+}
+
+// One thread per instance: accept the solution or shift the old prediction, integrate the plant.
+__global__ void loop_post(int S, int V, int N, double dt, double wb, int plant_substeps, const int32_t *status,
+                          const double *zu, double *pred, double *state, int32_t *kidx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S * V) return;
+  double *pb = pred + (size_t)b * 7 * N;
+  if (status[b] == 0) {
+    for (int i = 0; i < 7 * N; ++i) pb[i] = zu[(size_t)b * 7 * N + i];
+  } else {
+    for (int c = 0; c < 7; ++c)
+      for (int k = 0; k + 1 < N; ++k) pb[c * N + k] = pb[c * N + k + 1];
+  }
+  double z[5], out[5];
+  for (int i = 0; i < 5; ++i) z[i] = state[b * 5 + i];
+  cfz::rk4_step<false>(z, pb[5 * N], pb[6 * N], dt, wb, plant_substeps, out, nullptr);
+  for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
+  if (b % V == 0) kidx[b / V] += 1;
+}
+
+// first prediction = the reference itself, inputs and v, delta zero (:399-400); state = ref + noise
+__global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
+                          const double *noise, double *pred, double *state) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)S * V * N) return;
+  const int k = (int)(tid % N);
+  const int b = (int)(tid / N);
+  const int s = b / V, v = b - s * V;
+  int kr = kidx[s] + k; if (kr > T - 1) kr = T - 1;
+  for (int c = 0; c < 7; ++c)
+    pred[((size_t)b * 7 + c) * N + k] = (c < 3) ? ref_table[((size_t)v * T + kr) * 3 + c] : 0.0;
+  if (k == 0)
+    for (int c = 0; c < 5; ++c)
+      state[b * 5 + c] = ((c < 3) ? ref_table[((size_t)v * T + kidx[s]) * 3 + c] : 0.0) + (noise ? noise[b * 5 + c] : 0.0);
+}
+
+}  // namespace
+
+struct cfz_handle {
+  int device = 0, max_batch = 0;
+  cfz::KSpec ks;
+  cfz::Lay lay;
+  size_t lds_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  // per-instance buffers
+  double *x0 = nullptr, *ref = nullptr, *nbr = nullptr, *zu = nullptr, *stats = nullptr;
+  int32_t *status = nullptr, *iters = nullptr;
+  double *l = nullptr, *m = nullptr, *lam_ij = nullptr, *lam_ji = nullptr, *s = nullptr;
+  // closed loop
+  int S = 0, T = 0;
+  double *ref_table = nullptr, *pred = nullptr, *state = nullptr;
+  int32_t *kidx = nullptr;
+};
+
+namespace {
+
+// vertices of {A p <= b} for a bounded quadrilateral, faces paired in index order
+bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
+  int n = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j) {
+      const double det = A[i][0] * A[j][1] - A[i][1] * A[j][0];
+      if (std::fabs(det) < 1e-9) continue;
+      const double px = (b[i] * A[j][1] - A[i][1] * b[j]) / det, py = (A[i][0] * b[j] - b[i] * A[j][0]) / det;
+      bool in = true;
+      for (int q = 0; q < 4; ++q) in = in && (A[q][0] * px + A[q][1] * py <= b[q] + 1e-9);
+      if (in) { if (n == 4) return false; V[n][0] = px; V[n][1] = py; ++n; }
+    }
+  return n == 4;
+}
+
+int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr, double *zu,
+                 int32_t *status, int32_t *iters, double *stats, bool duals, hipStream_t st) {
+  DualPtrs du = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
+  HIP_OK(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(64), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
+                     iters, stats, du);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(h->ev1, st));
+  return 0;
+}
+
+int check(cfz_handle *h, int B) {
+  if (!h) return fail("null handle");
+  if (B < 1 || B > h->max_batch) return fail("batch size out of range");
+  HIP_OK(hipSetDevice(h->device));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cfz_last_error(void) { return g_err.c_str(); }
+
+void cfz_default_spec(cfz_spec *s) {
+  memset(s, 0, sizeof *s);
+  s->N = 30; s->n_obs = 0; s->n_nbr = 0; s->rk_substeps = 4;
+  s->dt = 0.1; s->wb = 2.5; s->dmin = 0.05;
+  const double g[4] = {3.3, 0.9, 0.6, 0.9};
+  const double bd[12] = {2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0};
+  const double w[6] = {100, 100, 100, 1, 1, 1};
+  memcpy(s->g, g, sizeof g); memcpy(s->bounds, bd, sizeof bd); memcpy(s->weights, w, sizeof w);
+}
+
+void cfz_default_options(cfz_options *o) {
+  memset(o, 0, sizeof *o);
+  o->max_iter = 600; o->max_backtrack = 25; o->filter_cap = 16;
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->dual_inf_tol = 1.0; o->compl_inf_tol = 1e-4;
+  o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99;
+  o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
+  o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
+  o->reg_primal = 1e-8;
+}
+
+int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out) {
+  if (!spec || !out) return fail("null argument");
+  cfz_options od;
+  if (!opt) { cfz_default_options(&od); opt = &od; }
+  if (spec->N < 2 || spec->N > CFZ_MAX_N) return fail("N out of range");
+  if (spec->n_obs < 0 || spec->n_obs > CFZ_MAX_OBS || spec->n_nbr < 0 || spec->n_nbr > CFZ_MAX_NBR)
+    return fail("n_obs / n_nbr out of range");
+  if (spec->N > 64) return fail("N > 64 lanes is not supported by the one-wavefront kernel");
+  if (max_batch < 1) return fail("max_batch must be positive");
+  if (opt->filter_cap < 1 || opt->filter_cap > 32) return fail("filter_cap must be in 1..32");
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev == 0) return fail("no HIP device: libconfrez_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  HIP_OK(hipSetDevice(device));
+
+  cfz_handle *h = new cfz_handle();
+  h->device = device; h->max_batch = max_batch;
+  cfz::KSpec &k = h->ks;
+  memset(&k, 0, sizeof k);
+  k.N = spec->N; k.n_obs = spec->n_obs; k.n_nbr = spec->n_nbr; k.rk_substeps = spec->rk_substeps;
+  k.max_iter = opt->max_iter; k.max_backtrack = opt->max_backtrack; k.filter_cap = opt->filter_cap;
+  k.dt = spec->dt; k.wb = spec->wb; k.dmin = spec->dmin;
+  memcpy(k.g, spec->g, sizeof k.g); memcpy(k.bounds, spec->bounds, sizeof k.bounds);
+  memcpy(k.weights, spec->weights, sizeof k.weights);
+  for (int j = 0; j < spec->n_obs; ++j) {
+    memcpy(k.A_obs[j], spec->A_obs[j], sizeof k.A_obs[j]); memcpy(k.b_obs[j], spec->b_obs[j], sizeof k.b_obs[j]);
+    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], k.V_obs[j])) { delete h; return fail("obstacle is not a bounded quadrilateral"); }
+  }
+  k.tol = opt->tol; k.constr_viol_tol = opt->constr_viol_tol; k.dual_inf_tol = opt->dual_inf_tol;
+  k.compl_inf_tol = opt->compl_inf_tol; k.mu_init = opt->mu_init; k.kappa_eps = opt->kappa_eps;
+  k.kappa_mu = opt->kappa_mu; k.theta_mu = opt->theta_mu; k.tau_min = opt->tau_min; k.bound_push = opt->bound_push;
+  k.bound_frac = opt->bound_frac; k.s_max = opt->s_max; k.kappa_sigma = opt->kappa_sigma; k.eta_phi = opt->eta_phi;
+  k.gamma_theta = opt->gamma_theta; k.gamma_phi = opt->gamma_phi; k.delta_sw = opt->delta_sw;
+  k.s_theta = opt->s_theta; k.s_phi = opt->s_phi; k.reg_primal = opt->reg_primal;
+  h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
+  h->lds_bytes = (size_t)h->lay.total * sizeof(double);
+  if (h->lds_bytes > 160 * 1024) { delete h; return fail("problem does not fit the 160 KiB LDS of one CU"); }
+  if (h->lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
+  }
+  const size_t B = (size_t)max_batch, N = (size_t)k.N, no = (size_t)k.n_obs, nn = (size_t)k.n_nbr;
+  HIP_OK(hipStreamCreate(&h->stream));
+  HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));
+  HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
+  HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
+  HIP_OK(hipMalloc(&h->stats, B * 3 * 8)); HIP_OK(hipMalloc(&h->status, B * 4)); HIP_OK(hipMalloc(&h->iters, B * 4));
+  HIP_OK(hipMalloc(&h->l, (B * N * 4 * no + 1) * 8)); HIP_OK(hipMalloc(&h->m, (B * N * 4 * no + 1) * 8));
+  HIP_OK(hipMalloc(&h->lam_ij, (B * nn * N * 4 + 1) * 8)); HIP_OK(hipMalloc(&h->lam_ji, (B * nn * N * 4 + 1) * 8));
+  HIP_OK(hipMalloc(&h->s, (B * nn * N * 2 + 1) * 8));
+  HIP_OK(hipMemset(h->status, 0, B * 4)); HIP_OK(hipMemset(h->iters, 0, B * 4));
+  *out = h;
+  return 0;
+}
+
+int cfz_destroy(cfz_handle *h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
+                  h->ref_table, h->pred, h->state, h->kidx};
+  for (void *p : bufs) if (p) hipFree(p);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int cfz_max_batch(const cfz_handle *h) { return h ? h->max_batch : 0; }
+
+int cfz_mpc_set_params(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr) {
+  if (check(h, B)) return -1;
+  if (!x0 || !ref || (h->ks.n_nbr && !nbr)) return fail("null parameter array");
+  const size_t N = h->ks.N, nn = h->ks.n_nbr;
+  HIP_OK(hipMemcpyAsync(h->x0, x0, (size_t)B * 5 * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->ref, ref, (size_t)B * 3 * N * 8, hipMemcpyHostToDevice, h->stream));
+  if (nn) HIP_OK(hipMemcpyAsync(h->nbr, nbr, (size_t)B * nn * 3 * N * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cfz_mpc_set_warm(cfz_handle *h, int B, const double *zu) {
+  if (check(h, B)) return -1;
+  if (!zu) return fail("null warm start");
+  HIP_OK(hipMemcpyAsync(h->zu, zu, (size_t)B * 7 * h->ks.N * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cfz_mpc_solve(cfz_handle *h, int B) {
+  if (check(h, B)) return -1;
+  if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, true, h->stream)) return -1;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int cfz_mpc_get(cfz_handle *h, int B, double *zu, double *l, double *m, double *lam_ij, double *lam_ji, double *s) {
+  if (check(h, B)) return -1;
+  const size_t N = h->ks.N, no = h->ks.n_obs, nn = h->ks.n_nbr, b = (size_t)B;
+  if (zu) HIP_OK(hipMemcpy(zu, h->zu, b * 7 * N * 8, hipMemcpyDeviceToHost));
+  if (l && no) HIP_OK(hipMemcpy(l, h->l, b * N * 4 * no * 8, hipMemcpyDeviceToHost));
+  if (m && no) HIP_OK(hipMemcpy(m, h->m, b * N * 4 * no * 8, hipMemcpyDeviceToHost));
+  if (lam_ij && nn) HIP_OK(hipMemcpy(lam_ij, h->lam_ij, b * nn * N * 4 * 8, hipMemcpyDeviceToHost));
+  if (lam_ji && nn) HIP_OK(hipMemcpy(lam_ji, h->lam_ji, b * nn * N * 4 * 8, hipMemcpyDeviceToHost));
+  if (s && nn) HIP_OK(hipMemcpy(s, h->s, b * nn * N * 2 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double *cost, double *kkt_err, double *min_sep) {
+  if (check(h, B)) return -1;
+  if (status) HIP_OK(hipMemcpy(status, h->status, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (iters) HIP_OK(hipMemcpy(iters, h->iters, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (cost || kkt_err || min_sep) {
+    std::vector<double> st((size_t)B * 3);
+    HIP_OK(hipMemcpy(st.data(), h->stats, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+      if (cost) cost[b] = st[b * 3];
+      if (kkt_err) kkt_err[b] = st[b * 3 + 1];
+      if (min_sep) min_sep[b] = st[b * 3 + 2];
+    }
+  }
+  return 0;
+}
+
+double cfz_last_solve_ms(const cfz_handle *h) { return h ? (double)h->last_ms : -1.0; }
+
+int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double *d_ref, const double *d_nbr,
+                         double *d_zu, int32_t *d_status, int32_t *d_iters, double *d_stats, void *stream) {
+  if (check(h, B)) return -1;
+  if (!d_x0 || !d_ref || !d_zu || !d_status || !d_iters || !d_stats) return fail("null device pointer");
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  return launch_solve(h, B, d_x0, d_ref, d_nbr ? d_nbr : h->nbr, d_zu, d_status, d_iters, d_stats, false, st);
+}
+
+int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const int32_t *k0, const double *noise) {
+  if (!h) return fail("null handle");
+  const int V = h->ks.n_nbr + 1, N = h->ks.N;
+  if (S < 1 || (long)S * V > h->max_batch) return fail("S * (n_nbr+1) exceeds max_batch");
+  if (T < 1 || !ref_table || !k0) return fail("bad reference table");
+  HIP_OK(hipSetDevice(h->device));
+  for (void *p : {(void *)h->ref_table, (void *)h->pred, (void *)h->state, (void *)h->kidx}) if (p) hipFree(p);
+  h->ref_table = h->pred = h->state = nullptr; h->kidx = nullptr;
+  h->S = S; h->T = T;
+  const size_t B = (size_t)S * V;
+  HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 3 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
+  HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
+  HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 3 * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
+  double *dn = nullptr;
+  if (noise) { HIP_OK(hipMalloc(&dn, B * 5 * 8)); HIP_OK(hipMemcpy(dn, noise, B * 5 * 8, hipMemcpyHostToDevice)); }
+  const long nt = (long)B * N;
+  hipLaunchKernelGGL(loop_seed, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, S, V, N, T, h->ref_table,
+                     h->kidx, dn, h->pred, h->state);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (dn) hipFree(dn);
+  return 0;
+}
+
+int cfz_loop_step(cfz_handle *h) {
+  if (!h || !h->pred) return fail("cfz_loop_init has not been called");
+  HIP_OK(hipSetDevice(h->device));
+  const int V = h->ks.n_nbr + 1, N = h->ks.N, S = h->S, B = S * V;
+  const long nt = (long)B * N;
+  hipLaunchKernelGGL(loop_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, S, V, N, h->T, h->ref_table,
+                     h->kidx, h->pred, h->state, h->x0, h->ref, h->nbr, h->zu);
+  HIP_OK(hipGetLastError());
+  if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, false, h->stream)) return -1;
+  hipLaunchKernelGGL(loop_post, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, S, V, N, h->ks.dt, h->ks.wb, 100,
+                     h->status, h->zu, h->pred, h->state, h->kidx);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters) {
+  if (!h || !h->pred) return fail("cfz_loop_init has not been called");
+  HIP_OK(hipSetDevice(h->device));
+  const size_t B = (size_t)h->S * (h->ks.n_nbr + 1), N = h->ks.N;
+  if (state) HIP_OK(hipMemcpy(state, h->state, B * 5 * 8, hipMemcpyDeviceToHost));
+  if (pred) HIP_OK(hipMemcpy(pred, h->pred, B * 7 * N * 8, hipMemcpyDeviceToHost));
+  if (status) HIP_OK(hipMemcpy(status, h->status, B * 4, hipMemcpyDeviceToHost));
+  if (iters) HIP_OK(hipMemcpy(iters, h->iters, B * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,783 @@
+// cfz_solver.inl -- one MPC-step NLP solved by one wavefront.
+//
+// Included by cfz_engine.hip (gfx950 device code: one 64-lane workgroup per problem instance,
+// iterate and stage data in LDS) and by tests/emu/cfz_emu.cpp (same source, lanes run as a
+// loop, so the kernel logic can be checked and sanitised on a CPU).  Not a CPU fallback: the
+// product library only ever contains the device build.
+//
+// NLP: reference confrez/control/vehicle_follower.py:146-368 with the OBCA duals eliminated
+// into closed-form separation certificates; dynamics confrez/control/dynamic_model.py:5-58;
+// algorithm DESIGN.md "CFZ-IPM" (interior point, filter line search, slack elimination +
+// Riccati recursion).  Work split inside the wavefront:
+//   blocks    (stage k, obstacle/neighbour j) tasks strided over the 64 lanes
+//   dynamics  RK4 + forward sensitivities, one stage per lane
+//   assembly  condensed stage Hessian / gradient, one stage per lane
+//   Riccati   backward / forward / costate sweeps on lane 0 (30 dependent steps)
+//   step      slack and multiplier steps, fraction-to-boundary minima, one stage per lane
+//
+// Conventions: code inside CFZ_LANES(lane){...}CFZ_END runs once per lane and may only write
+// lane-private locals or workspace cells it owns; everything outside runs uniformly (every
+// lane computes the same value from the workspace).  Cross-lane sums/maxima go through the
+// `red` slots of the workspace.
+
+#ifndef CFZ_SOLVER_INL
+#define CFZ_SOLVER_INL
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CFZ_FN __host__ __device__ __forceinline__
+#else
+#define CFZ_FN static inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZ_LANES(lane) { const int lane = (int)threadIdx.x;
+#define CFZ_END } __syncthreads();
+#else
+#define CFZ_LANES(lane) for (int lane = 0; lane < 64; ++lane) {
+#define CFZ_END }
+#endif
+
+namespace cfz {
+
+constexpr int kNP = 7;      // x y psi v delta a w
+constexpr int kRed = 8;     // reduction slots
+constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
+
+// Everything the kernel needs besides per-instance data (plain old data, passed by value).
+struct KSpec {
+  int N, n_obs, n_nbr, rk_substeps;
+  int max_iter, max_backtrack, filter_cap, pad0;
+  double dt, wb, dmin;
+  double g[4], bounds[12], weights[6];
+  double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
+  double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
+      bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
+      reg_primal;
+};
+
+// Workspace layout (offsets in doubles) for one instance.
+struct Lay {
+  int N, nb;
+  int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
+  int dp, dsg, dpi0, dpi;                   // step
+  int cj, gra, ab, d, hc, gk, kk;           // stage data
+  int ref, nb4, x0, filt, red, total;
+};
+
+CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
+  Lay L; int o = 0;
+  L.N = N; L.nb = nb;
+  L.p = o; o += N * kNP;
+  L.sg = o; o += N * nb; L.nuc = o; o += N * nb; L.zs = o; o += N * nb;
+  L.zl = o; o += N * 6; L.zu = o; o += N * 6;
+  L.pi0 = o; o += 5; L.pi = o; o += N * 5;
+  L.dp = o; o += N * kNP; L.dsg = o; o += N * nb; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
+  L.cj = o; o += N * nb; L.gra = o; o += N * nb * 3;
+  L.ab = o; o += N * 15; L.d = o; o += N * 5;
+  L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
+  L.ref = o; o += 3 * N; L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
+  L.filt = o; o += 64; L.red = o; o += kRed * 64;
+  L.total = o;
+  return L;
+}
+
+// bounded columns of p: x y v delta a w  (psi is free)
+CFZ_FN int bcol(int q) { return q < 2 ? q : q + 1; }
+
+// ------------------------------------------------------------------------------ reductions
+CFZ_FN double red_sum(const double *m, const Lay &L, int slot) {
+  double s = 0.0;
+  for (int i = 0; i < 64; ++i) s += m[L.red + slot * 64 + i];
+  return s;
+}
+CFZ_FN double red_max(const double *m, const Lay &L, int slot) {
+  double s = m[L.red + slot * 64];
+  for (int i = 1; i < 64; ++i) s = fmax(s, m[L.red + slot * 64 + i]);
+  return s;
+}
+CFZ_FN double red_min(const double *m, const Lay &L, int slot) {
+  double s = m[L.red + slot * 64];
+  for (int i = 1; i < 64; ++i) s = fmin(s, m[L.red + slot * 64 + i]);
+  return s;
+}
+
+// ------------------------------------------------------------------------------ dynamics
+// RK4 (M sub-steps) of the kinematic bicycle.  The state rows v, delta integrate exactly
+// (v+ = v + a t, delta+ = delta + w t) and x, y never feed back, so only the sensitivities of
+// (x, y, psi) with respect to (psi0, v0, delta0, a, w) are propagated: S[3][5].
+template <bool SENS>
+CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb, int M, double out[5],
+                     double S[3][5]) {
+  const double h = dt / M;
+  double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
+  if (SENS) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 5; ++c) S[r][c] = 0.0;
+    S[2][0] = 1.0;
+  }
+  double tsub = 0.0;  // time since the start of the interval: dv/da = ddelta/dw = tsub
+  for (int m = 0; m < M; ++m) {
+    double ax = 0, ay = 0, ap = 0;  // weighted stage sums
+    double AS[3][5];
+    if (SENS)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 5; ++c) AS[r][c] = 0.0;
+    double kx = 0, ky = 0, kp = 0;  // previous stage derivative
+    double KS[3][5];
+    if (SENS)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 5; ++c) KS[r][c] = 0.0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+      const double wsum = (st == 0 || st == 3) ? 1.0 : 2.0;
+      const double ps = psi + wprev * kp, vs = v + wprev * a, ds = de + wprev * w;
+      const double c = cos(ps), s = sin(ps), t = tan(ds);
+      const double fx = vs * c, fy = vs * s, fp = vs / wb * t;
+      if (SENS) {
+        // stage point sensitivities: psi row from S/KS, v and delta rows analytic
+        const double tau = tsub + wprev;
+        const double j24 = vs / wb * (1.0 + t * t), j23 = t / wb;
+        double NS[3][5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          const double dps = S[2][q] + wprev * KS[2][q];
+          const double dvs = (q == 1) ? 1.0 : ((q == 3) ? tau : 0.0);
+          const double dds = (q == 2) ? 1.0 : ((q == 4) ? tau : 0.0);
+          NS[0][q] = -vs * s * dps + c * dvs;
+          NS[1][q] = vs * c * dps + s * dvs;
+          NS[2][q] = j23 * dvs + j24 * dds;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int q = 0; q < 5; ++q) { KS[r][q] = NS[r][q]; AS[r][q] += wsum * NS[r][q]; }
+      }
+      kx = fx; ky = fy; kp = fp;
+      ax += wsum * fx; ay += wsum * fy; ap += wsum * fp;
+    }
+    x += h / 6 * ax; y += h / 6 * ay; psi += h / 6 * ap;
+    v += h * a; de += h * w;
+    if (SENS)
+      for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 5; ++q) S[r][q] += h / 6 * AS[r][q];
+    tsub += h;
+  }
+  out[0] = x; out[1] = y; out[2] = psi; out[3] = v; out[4] = de;
+}
+
+// ------------------------------------------------------------------------------ separation certificates
+// Separation of polygon (A,b,V) from the body rectangle at (x,y,psi): max over the 8 face
+// normals of the min over the other polygon's vertices.  cert = kind*16 + face*4 + vertex,
+// kind 1 = polygon face / body vertex, kind 2 = body face / polygon vertex.  Strict
+// comparisons in candidate order (ties keep the first).
+template <bool GRAD>
+CFZ_FN double block_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
+                        double psi, const double g[4], double grad[3], int *cert) {
+  const double c = cos(psi), s = sin(psi);
+  const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  const double GB[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+  double W[4][2], dW[4][2];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    dW[v][0] = -s * BV[v][0] - c * BV[v][1];
+    dW[v][1] = c * BV[v][0] - s * BV[v][1];
+    W[v][0] = x + dW[v][1];
+    W[v][1] = y - dW[v][0];
+  }
+  double best = 0.0; int bc = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int vm = 0; double dm = W[0][0] * A[i][0] + W[0][1] * A[i][1] - b[i];
+#pragma unroll
+    for (int v = 1; v < 4; ++v) {
+      const double d = W[v][0] * A[i][0] + W[v][1] * A[i][1] - b[i];
+      if (d < dm) { dm = d; vm = v; }
+    }
+    if (i == 0 || dm > best) {
+      best = dm; bc = 16 + 4 * i + vm;
+      if (GRAD) {
+        grad[0] = A[i][0]; grad[1] = A[i][1];
+        double g2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (v == vm) g2 = A[i][0] * dW[v][0] + A[i][1] * dW[v][1];
+        grad[2] = g2;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double nx = c * GB[k][0] - s * GB[k][1], ny = s * GB[k][0] + c * GB[k][1];
+    int vm = 0; double dm = (V[0][0] - x) * nx + (V[0][1] - y) * ny - g[k];
+#pragma unroll
+    for (int v = 1; v < 4; ++v) {
+      const double d = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[k];
+      if (d < dm) { dm = d; vm = v; }
+    }
+    if (dm > best) {
+      best = dm; bc = 32 + 4 * k + vm;
+      if (GRAD) {
+        const double dnx = -s * GB[k][0] - c * GB[k][1], dny = c * GB[k][0] - s * GB[k][1];
+        grad[0] = -nx; grad[1] = -ny;
+        double g2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (v == vm) g2 = dnx * (V[v][0] - x) + dny * (V[v][1] - y);
+        grad[2] = g2;
+      }
+    }
+  }
+  if (cert) *cert = bc;
+  return best;
+}
+
+// polygon of block j at stage k: static obstacle from the spec, neighbour from its pose
+CFZ_FN void block_polygon(const KSpec &sp, const double *m, const Lay &L, int k, int j, double A[4][2], double b[4],
+                          double V[4][2]) {
+  if (j < sp.n_obs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      A[i][0] = sp.A_obs[j][i][0]; A[i][1] = sp.A_obs[j][i][1]; b[i] = sp.b_obs[j][i];
+      V[i][0] = sp.V_obs[j][i][0]; V[i][1] = sp.V_obs[j][i][1];
+    }
+  } else {
+    const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+    const double xo = q[0], yo = q[1], co = q[2], so = q[3];
+    const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
+    A[0][0] = co; A[0][1] = so; A[1][0] = -so; A[1][1] = co;
+    A[2][0] = -co; A[2][1] = -so; A[3][0] = so; A[3][1] = -co;
+    b[0] = A[0][0] * xo + A[0][1] * yo + g0; b[1] = A[1][0] * xo + A[1][1] * yo + g1;
+    b[2] = A[2][0] * xo + A[2][1] * yo + g2; b[3] = A[3][0] * xo + A[3][1] * yo + g3;
+    const double BV[4][2] = {{g0, g1}, {-g2, g1}, {-g2, -g3}, {g0, -g3}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      V[i][0] = xo + co * BV[i][0] - so * BV[i][1];
+      V[i][1] = yo + so * BV[i][0] + co * BV[i][1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ objective pieces
+CFZ_FN double stage_cost(const KSpec &sp, const double *ref, int k, const double p[kNP]) {
+  const double *w = sp.weights; const int N = sp.N;
+  const double ex = p[0] - ref[k], ey = p[1] - ref[N + k], ep = p[2] - ref[2 * N + k];
+  return w[0] * ex * ex + w[1] * ey * ey + w[2] * ep * ep + w[3] * p[5] * p[5] + w[4] * p[3] * p[3] * p[6] * p[6] +
+         w[5] * p[4] * p[4];
+}
+CFZ_FN void stage_grad(const KSpec &sp, const double *ref, int k, const double p[kNP], double gr[kNP]) {
+  const double *w = sp.weights; const int N = sp.N;
+  gr[0] = 2 * w[0] * (p[0] - ref[k]);
+  gr[1] = 2 * w[1] * (p[1] - ref[N + k]);
+  gr[2] = 2 * w[2] * (p[2] - ref[2 * N + k]);
+  gr[3] = 2 * w[4] * p[3] * p[6] * p[6];
+  gr[4] = 2 * w[5] * p[4];
+  gr[5] = 2 * w[3] * p[5];
+  gr[6] = 2 * w[4] * p[3] * p[3] * p[6];
+}
+
+// dense views of the compact stage storage
+CFZ_FN void load_AB(const double *m, const Lay &L, int k, double dt, double A[5][5], double B[5][2]) {
+  const double *s = m + L.ab + k * 15;
+  for (int i = 0; i < 5; ++i) {
+    for (int q = 0; q < 5; ++q) A[i][q] = (i == q) ? 1.0 : 0.0;
+    B[i][0] = 0.0; B[i][1] = 0.0;
+  }
+  for (int r = 0; r < 3; ++r) {
+    A[r][2] = s[r * 5 + 0]; A[r][3] = s[r * 5 + 1]; A[r][4] = s[r * 5 + 2];
+    B[r][0] = s[r * 5 + 3]; B[r][1] = s[r * 5 + 4];
+  }
+  B[3][0] = dt; B[4][1] = dt;
+}
+CFZ_FN void load_H(const double *m, const Lay &L, int k, double H[kNP][kNP]) {
+  const double *h = m + L.hc + k * 11;
+  for (int i = 0; i < kNP; ++i)
+    for (int q = 0; q < kNP; ++q) H[i][q] = 0.0;
+  for (int i = 0; i < kNP; ++i) H[i][i] = h[i];
+  H[0][1] = H[1][0] = h[7]; H[0][2] = H[2][0] = h[8]; H[1][2] = H[2][1] = h[9]; H[3][6] = H[6][3] = h[10];
+}
+CFZ_FN void sym2_solve6(const double M[2][2], const double rhs[2][6], double out[2][6]) {
+  const double l00 = sqrt(M[0][0]), l10 = M[1][0] / l00, l11 = sqrt(M[1][1] - l10 * l10);
+  for (int q = 0; q < 6; ++q) {
+    const double y0 = rhs[0][q] / l00, y1 = (rhs[1][q] - l10 * y0) / l11;
+    const double x1 = y1 / l11;
+    out[0][q] = (y0 - l10 * x1) / l00; out[1][q] = x1;
+  }
+}
+
+// ------------------------------------------------------------------------------ trial-point evaluation
+// theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lanes write partials
+// into red slots 0 (theta), 1 (phi without the log terms), 2 (sum of logs), 3 (1 if infeasible).
+CFZ_FN void merit_partials(const KSpec &sp, double *m, const Lay &L, double alpha, int lane) {
+  const int N = sp.N, nb = L.nb;
+  double th = 0.0, ph = 0.0, lg = 0.0, bad = 0.0;
+  for (int t = lane; t < N * nb; t += 64) {
+    const int k = t / nb, j = t - k * nb;
+    const double x = m[L.p + k * kNP + 0] + alpha * m[L.dp + k * kNP + 0];
+    const double y = m[L.p + k * kNP + 1] + alpha * m[L.dp + k * kNP + 1];
+    const double ps = m[L.p + k * kNP + 2] + alpha * m[L.dp + k * kNP + 2];
+    const double sg = m[L.sg + t] + alpha * m[L.dsg + t];
+    double A[4][2], b[4], V[4][2];
+    block_polygon(sp, m, L, k, j, A, b, V);
+    const double sep = block_sep<false>(A, b, V, x, y, ps, sp.g, nullptr, nullptr);
+    th += fabs(sep - sp.dmin - sg);
+    if (!(sg > 0.0)) bad = 1.0; else lg += log(sg);
+  }
+  if (lane < N) {
+    const int k = lane;
+    double pt[kNP];
+    for (int i = 0; i < kNP; ++i) pt[i] = m[L.p + k * kNP + i] + alpha * m[L.dp + k * kNP + i];
+    for (int q = 0; q < 6; ++q) {
+      const double dl = pt[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pt[bcol(q)];
+      if (!(dl > 0.0) || !(du > 0.0)) bad = 1.0; else lg += log(dl) + log(du);
+    }
+    ph += stage_cost(sp, m + L.ref, k, pt);
+    if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
+    if (k + 1 < N) {
+      double F[5];
+      rk4_step<false>(pt, pt[5], pt[6], sp.dt, sp.wb, sp.rk_substeps, F, nullptr);
+      for (int i = 0; i < 5; ++i)
+        th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
+    }
+  }
+  m[L.red + 0 * 64 + lane] = th; m[L.red + 1 * 64 + lane] = ph;
+  m[L.red + 2 * 64 + lane] = lg; m[L.red + 3 * 64 + lane] = bad;
+}
+
+// ------------------------------------------------------------------------------ the solver
+// x0[5], ref[3][N], nbr[n_nbr][3][N], zu[7][N] (warm start in, solution out) in global memory;
+// m = this instance's workspace (LDS on the device).  out: iters,status ; cost,err,min_sep.
+// dual_out (optional): l,m [N][4 n_obs], lam_ij, lam_ji [n_nbr][N][4], s [n_nbr][N][2].
+struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; };
+
+CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *refg, const double *nbrg, double *zu,
+                           double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo) {
+  const int N = sp.N, nb = L.nb, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
+  const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb);
+  const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
+
+  // ---- load parameters, initial point ---------------------------------------------------
+  CFZ_LANES(lane)
+    for (int i = lane; i < 3 * N; i += 64) m[L.ref + i] = refg[i];
+    for (int t = lane; t < N * n_nbr; t += 64) {
+      const int k = t / n_nbr, o = t - k * n_nbr;
+      const double po = nbrg[(o * 3 + 2) * N + k];
+      double *q = m + L.nb4 + t * 4;
+      q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
+    }
+    if (lane < 5) { m[L.x0 + lane] = x0g[lane]; m[L.pi0 + lane] = 0.0; }
+    for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
+    for (int i = lane; i < N * 5; i += 64) m[L.pi + i] = 0.0;
+  CFZ_END
+  CFZ_LANES(lane)
+    // slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
+    for (int t = lane; t < N * nb; t += 64) {
+      const int k = t / nb, j = t - k * nb;
+      double A[4][2], b[4], V[4][2];
+      block_polygon(sp, m, L, k, j, A, b, V);
+      const double sep = block_sep<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], m[L.p + k * kNP + 2],
+                                          sp.g, nullptr, nullptr);
+      m[L.sg + t] = fmax(sep - sp.dmin, sp.bound_push);
+      m[L.zs + t] = 1.0; m[L.nuc + t] = 0.0;
+    }
+  CFZ_END
+  CFZ_LANES(lane)
+    if (lane < N) {
+      for (int q = 0; q < 6; ++q) {
+        const double lo = sp.bounds[2 * q], hi = sp.bounds[2 * q + 1];
+        const double pl = fmin(sp.bound_push * fmax(1.0, fabs(lo)), sp.bound_frac * (hi - lo));
+        const double pu = fmin(sp.bound_push * fmax(1.0, fabs(hi)), sp.bound_frac * (hi - lo));
+        double v = m[L.p + lane * kNP + bcol(q)];
+        v = fmax(v, lo + pl); v = fmin(v, hi - pu);
+        m[L.p + lane * kNP + bcol(q)] = v;
+        m[L.zl + lane * 6 + q] = 1.0; m[L.zu + lane * 6 + q] = 1.0;
+      }
+    }
+  CFZ_END
+
+  double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
+  int nfilt = 0, status = 1, iter = 0;
+
+  for (iter = 0; iter <= sp.max_iter; ++iter) {
+    // ---- evaluate blocks and dynamics at the current point --------------------------------
+    CFZ_LANES(lane)
+      double cmax = 0.0, csum = 0.0;
+      for (int t = lane; t < N * nb; t += 64) {
+        const int k = t / nb, j = t - k * nb;
+        double A[4][2], b[4], V[4][2], gr[3];
+        block_polygon(sp, m, L, k, j, A, b, V);
+        const double sep = block_sep<true>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], m[L.p + k * kNP + 2],
+                                           sp.g, gr, nullptr);
+        const double c = sep - sp.dmin - m[L.sg + t];
+        m[L.cj + t] = c; m[L.gra + t * 3] = gr[0]; m[L.gra + t * 3 + 1] = gr[1]; m[L.gra + t * 3 + 2] = gr[2];
+        cmax = fmax(cmax, fabs(c)); csum += fabs(c);
+      }
+      if (lane == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
+      if (lane + 1 < N) {
+        const int k = lane;
+        double F[5], S[3][5];
+        const double *pk = m + L.p + k * kNP;
+        rk4_step<true>(pk, pk[5], pk[6], sp.dt, sp.wb, sp.rk_substeps, F, S);
+        for (int r = 0; r < 3; ++r) for (int q = 0; q < 5; ++q) m[L.ab + k * 15 + r * 5 + q] = S[r][q];
+        for (int i = 0; i < 5; ++i) {
+          const double d = F[i] - m[L.p + (k + 1) * kNP + i];
+          m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
+        }
+      }
+      m[L.red + 0 * 64 + lane] = cmax; m[L.red + 1 * 64 + lane] = csum;
+    CFZ_END
+    const double cviol = red_max(m, L, 0), theta = red_sum(m, L, 1);
+    if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+    // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
+    CFZ_LANES(lane)
+      double dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, fv = 0.0, lg = 0.0;
+      if (lane == 0) for (int i = 0; i < 5; ++i) snu += fabs(m[L.pi0 + i]);
+      if (lane < N) {
+        const int k = lane;
+        const double *pk = m + L.p + k * kNP;
+        double r[kNP];
+        stage_grad(sp, m + L.ref, k, pk, r);
+        fv = stage_cost(sp, m + L.ref, k, pk);
+        for (int j = 0; j < nb; ++j) {
+          const int t = k * nb + j;
+          const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
+          r[0] += m[L.gra + t * 3] * nu; r[1] += m[L.gra + t * 3 + 1] * nu; r[2] += m[L.gra + t * 3 + 2] * nu;
+          dinf = fmax(dinf, fabs(-nu - zs));
+          snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lg += log(sg);
+        }
+        if (k + 1 < N) {
+          double A[5][5], B[5][2];
+          load_AB(m, L, k, sp.dt, A, B);
+          for (int i = 0; i < 5; ++i) {
+            const double pi = m[L.pi + k * 5 + i];
+            snu += fabs(pi);
+            for (int q = 0; q < 5; ++q) r[q] += A[i][q] * pi;
+            r[5] += B[i][0] * pi; r[6] += B[i][1] * pi;
+          }
+        }
+        if (k == 0) for (int i = 0; i < 5; ++i) r[i] += m[L.pi0 + i];
+        else for (int i = 0; i < 5; ++i) r[i] -= m[L.pi + (k - 1) * 5 + i];
+        for (int q = 0; q < 6; ++q) {
+          const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
+          r[bcol(q)] += -zl + zu_; sz += zl + zu_;
+          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          c0 = fmax(c0, fmax(fabs(dl * zl), fabs(du * zu_)));
+          lg += log(dl) + log(du);
+        }
+        for (int i = 0; i < kNP; ++i) dinf = fmax(dinf, fabs(r[i]));
+      }
+      m[L.red + 0 * 64 + lane] = dinf; m[L.red + 1 * 64 + lane] = snu; m[L.red + 2 * 64 + lane] = sz;
+      m[L.red + 3 * 64 + lane] = c0; m[L.red + 4 * 64 + lane] = fv; m[L.red + 5 * 64 + lane] = lg;
+    CFZ_END
+    const double dual_inf = red_max(m, L, 0), sum_nu = red_sum(m, L, 1), sum_z = red_sum(m, L, 2);
+    const double cmp0 = red_max(m, L, 3), fval = red_sum(m, L, 4), logsum = red_sum(m, L, 5);
+    const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max;
+    const double s_c = fmax(sp.s_max, sum_z / (double)n_bnd) / sp.s_max;
+    err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
+    fval_last = fval;
+    if (!isfinite(err0)) { status = 3; break; }
+    if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
+    if (iter == sp.max_iter) break;
+    // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
+    while (mu > mu_floor) {
+      CFZ_LANES(lane)
+        double cm = 0.0;
+        if (lane < N) {
+          const int k = lane;
+          for (int j = 0; j < nb; ++j) cm = fmax(cm, fabs(m[L.sg + k * nb + j] * m[L.zs + k * nb + j] - mu));
+          for (int q = 0; q < 6; ++q) {
+            const double v = m[L.p + k * kNP + bcol(q)];
+            cm = fmax(cm, fmax(fabs((v - sp.bounds[2 * q]) * m[L.zl + k * 6 + q] - mu),
+                               fabs((sp.bounds[2 * q + 1] - v) * m[L.zu + k * 6 + q] - mu)));
+          }
+        }
+        m[L.red + 0 * 64 + lane] = cm;
+      CFZ_END
+      const double emu = fmax(dual_inf / s_d, fmax(cviol, red_max(m, L, 0) / s_c));
+      if (emu <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
+      else break;
+    }
+    const double tau = fmax(sp.tau_min, 1.0 - mu);
+    // ---- condensed stage QP: H_k (compact), g_k ---------------------------------------------------
+    CFZ_LANES(lane)
+      if (lane < N) {
+        const int k = lane;
+        const double *w = sp.weights; const double *pk = m + L.p + k * kNP;
+        double g[kNP], h[11];
+        stage_grad(sp, m + L.ref, k, pk, g);
+        h[0] = 2 * w[0]; h[1] = 2 * w[1]; h[2] = 2 * w[2]; h[3] = 2 * w[4] * pk[6] * pk[6]; h[4] = 2 * w[5];
+        h[5] = 2 * w[3]; h[6] = 2 * w[4] * pk[3] * pk[3]; h[7] = 0.0; h[8] = 0.0; h[9] = 0.0;
+        h[10] = 2 * w[4] * pk[3] * pk[6];
+        for (int i = 0; i < kNP; ++i) h[i] += sp.reg_primal;
+        for (int q = 0; q < 6; ++q) {
+          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          h[bcol(q)] += m[L.zl + k * 6 + q] / dl + m[L.zu + k * 6 + q] / du;
+          g[bcol(q)] += -mu / dl + mu / du;
+        }
+        for (int j = 0; j < nb; ++j) {
+          const int t = k * nb + j;
+          const double sg = m[L.sg + t], S = m[L.zs + t] / sg + sp.reg_primal;
+          const double coef = S * m[L.cj + t] - mu / sg;
+          const double a0 = m[L.gra + t * 3], a1 = m[L.gra + t * 3 + 1], a2 = m[L.gra + t * 3 + 2];
+          g[0] += a0 * coef; g[1] += a1 * coef; g[2] += a2 * coef;
+          h[0] += S * a0 * a0; h[1] += S * a1 * a1; h[2] += S * a2 * a2;
+          h[7] += S * a0 * a1; h[8] += S * a0 * a2; h[9] += S * a1 * a2;
+        }
+        for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
+        for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];
+      }
+    CFZ_END
+    // ---- Riccati: backward gains, forward step, costates (lane 0) ------------------------------------
+    CFZ_LANES(lane)
+      if (lane == 0) {
+        double P[5][5], pv[5], H[kNP][kNP];
+        {
+          const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
+          load_H(m, L, k, H);
+          const double *gk = m + L.gk + k * kNP;
+          const double R2[2][2] = {{H[5][5], H[5][6]}, {H[6][5], H[6][6]}};
+          double rhs[2][6], sol[2][6];
+          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[5 + a][q]; rhs[a][5] = gk[5 + a]; }
+          sym2_solve6(R2, rhs, sol);
+          double *K = m + L.kk + k * 12;
+          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) K[a * 5 + q] = -sol[a][q]; K[10 + a] = -sol[a][5]; }
+          for (int i = 0; i < 5; ++i) {
+            for (int q = 0; q < 5; ++q) P[i][q] = H[i][q] + H[5][i] * K[q] + H[6][i] * K[5 + q];
+            pv[i] = gk[i] + H[5][i] * K[10] + H[6][i] * K[11];
+          }
+        }
+        for (int k = N - 2; k >= 0; --k) {
+          double A[5][5], B[5][2], PA[5][5], PB[5][2], Pd[5];
+          load_AB(m, L, k, sp.dt, A, B); load_H(m, L, k, H);
+          const double *gk = m + L.gk + k * kNP, *dk = m + L.d + k * 5;
+          for (int i = 0; i < 5; ++i) {
+            for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += P[i][r] * A[r][q]; PA[i][q] = s; }
+            for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += P[i][r] * B[r][q]; PB[i][q] = s; }
+            double s = pv[i]; for (int r = 0; r < 5; ++r) s += P[i][r] * dk[r]; Pd[i] = s;
+          }
+          double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
+          for (int a = 0; a < 2; ++a) {
+            for (int b = 0; b < 2; ++b) { double s = H[5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += B[r][a] * PB[r][b]; Huu[a][b] = s; }
+            for (int q = 0; q < 5; ++q) { double s = H[5 + a][q]; for (int r = 0; r < 5; ++r) s += B[r][a] * PA[r][q]; Hux[a][q] = s; }
+            double s = gk[5 + a]; for (int r = 0; r < 5; ++r) s += B[r][a] * Pd[r]; hu[a] = s;
+          }
+          for (int i = 0; i < 5; ++i) {
+            for (int q = 0; q < 5; ++q) { double s = H[i][q]; for (int r = 0; r < 5; ++r) s += A[r][i] * PA[r][q]; Hxx[i][q] = s; }
+            double s = gk[i]; for (int r = 0; r < 5; ++r) s += A[r][i] * Pd[r]; hx[i] = s;
+          }
+          double rhs[2][6], sol[2][6];
+          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
+          sym2_solve6(Huu, rhs, sol);
+          double *K = m + L.kk + k * 12;
+          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) K[a * 5 + q] = -sol[a][q]; K[10 + a] = -sol[a][5]; }
+          for (int i = 0; i < 5; ++i) {
+            for (int q = 0; q < 5; ++q) P[i][q] = Hxx[i][q] + Hux[0][i] * K[q] + Hux[1][i] * K[5 + q];
+            pv[i] = hx[i] + Hux[0][i] * K[10] + Hux[1][i] * K[11];
+          }
+          for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { const double s = 0.5 * (P[i][q] + P[q][i]); P[i][q] = P[q][i] = s; }
+        }
+        // forward sweep
+        double *dp = m + L.dp;
+        for (int i = 0; i < 5; ++i) dp[i] = m[L.x0 + i] - m[L.p + i];
+        // multiplier of the initial-state row from the value function at stage 0
+        for (int i = 0; i < 5; ++i) { double s = pv[i]; for (int q = 0; q < 5; ++q) s += P[i][q] * dp[q]; m[L.dpi0 + i] = -s - m[L.pi0 + i]; }
+        for (int k = 0; k < N; ++k) {
+          const double *K = m + L.kk + k * 12;
+          for (int a = 0; a < 2; ++a) { double s = K[10 + a]; for (int q = 0; q < 5; ++q) s += K[a * 5 + q] * dp[k * kNP + q]; dp[k * kNP + 5 + a] = s; }
+          if (k + 1 < N) {
+            double A[5][5], B[5][2];
+            load_AB(m, L, k, sp.dt, A, B);
+            for (int i = 0; i < 5; ++i) {
+              double s = m[L.d + k * 5 + i];
+              for (int q = 0; q < 5; ++q) s += A[i][q] * dp[k * kNP + q];
+              s += B[i][0] * dp[k * kNP + 5] + B[i][1] * dp[k * kNP + 6];
+              dp[(k + 1) * kNP + i] = s;
+            }
+          }
+        }
+        // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows)
+        double lam[5] = {0, 0, 0, 0, 0};
+        for (int k = N - 1; k >= 1; --k) {
+          load_H(m, L, k, H);
+          double nl[5];
+          for (int i = 0; i < 5; ++i) {
+            double s = m[L.gk + k * kNP + i];
+            for (int q = 0; q < kNP; ++q) s += H[i][q] * dp[k * kNP + q];
+            nl[i] = s;
+          }
+          if (k + 1 < N) {
+            double A[5][5], B[5][2];
+            load_AB(m, L, k, sp.dt, A, B);
+            for (int i = 0; i < 5; ++i) for (int r = 0; r < 5; ++r) nl[i] += A[r][i] * lam[r];
+          }
+          for (int i = 0; i < 5; ++i) { lam[i] = nl[i]; m[L.dpi + (k - 1) * 5 + i] = nl[i] - m[L.pi + (k - 1) * 5 + i]; }
+        }
+      }
+    CFZ_END
+    // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
+    CFZ_LANES(lane)
+      double apri = 1.0, adual = 1.0, dphi = 0.0;
+      if (lane < N) {
+        const int k = lane;
+        const double *pk = m + L.p + k * kNP, *dpk = m + L.dp + k * kNP;
+        double g[kNP];
+        stage_grad(sp, m + L.ref, k, pk, g);
+        for (int q = 0; q < 6; ++q) {
+          const double dx = dpk[bcol(q)];
+          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
+          g[bcol(q)] += -mu / dl + mu / du;
+          const double dzl = mu / dl - zl - zl / dl * dx, dzu = mu / du - zu_ + zu_ / du * dx;
+          if (dx < 0.0) apri = fmin(apri, -tau * dl / dx);
+          if (dx > 0.0) apri = fmin(apri, tau * du / dx);
+          if (dzl < 0.0) adual = fmin(adual, -tau * zl / dzl);
+          if (dzu < 0.0) adual = fmin(adual, -tau * zu_ / dzu);
+        }
+        for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
+        for (int j = 0; j < nb; ++j) {
+          const int t = k * nb + j;
+          const double sg = m[L.sg + t], zs = m[L.zs + t];
+          const double ds = m[L.cj + t] + m[L.gra + t * 3] * dpk[0] + m[L.gra + t * 3 + 1] * dpk[1] + m[L.gra + t * 3 + 2] * dpk[2];
+          m[L.dsg + t] = ds;
+          const double dzs = mu / sg - zs - zs / sg * ds;
+          dphi += -mu / sg * ds;
+          if (ds < 0.0) apri = fmin(apri, -tau * sg / ds);
+          if (dzs < 0.0) adual = fmin(adual, -tau * zs / dzs);
+        }
+      }
+      m[L.red + 0 * 64 + lane] = apri; m[L.red + 1 * 64 + lane] = adual; m[L.red + 2 * 64 + lane] = dphi;
+    CFZ_END
+    const double a_pri = red_min(m, L, 0), a_dual = red_min(m, L, 1), dphi = red_sum(m, L, 2);
+    // ---- filter line search --------------------------------------------------------------------------------
+    const double phi0 = fval - mu * logsum;
+    if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
+    double alpha = a_pri; int accepted = 0, f_type = 0;
+    for (int bt = 0; bt < sp.max_backtrack; ++bt) {
+      CFZ_LANES(lane)
+        merit_partials(sp, m, L, alpha, lane);
+      CFZ_END
+      const double th_t = red_sum(m, L, 0), ph_t = red_sum(m, L, 1) - mu * red_sum(m, L, 2);
+      int ok = (red_max(m, L, 3) == 0.0) && isfinite(th_t) && isfinite(ph_t) && th_t <= theta_max;
+      if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= m[L.filt + 2 * q] && ph_t >= m[L.filt + 2 * q + 1]) { ok = 0; break; }
+      f_type = 0;
+      if (ok) {
+        const int sw = theta <= theta_min && dphi < 0.0 && alpha * pow(-dphi, sp.s_phi) > sp.delta_sw * pow(theta, sp.s_theta);
+        if (sw) { f_type = 1; ok = ph_t <= phi0 + sp.eta_phi * alpha * dphi; }
+        else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
+      }
+      if (ok) { accepted = 1; break; }
+      alpha *= 0.5;
+    }
+    if (!accepted) { status = 2; break; }
+    if (!f_type) {
+      CFZ_LANES(lane)
+        if (lane == 0) {
+          int n = nfilt;
+          if (n == sp.filter_cap) { for (int q = 0; q + 1 < n; ++q) { m[L.filt + 2 * q] = m[L.filt + 2 * q + 2]; m[L.filt + 2 * q + 1] = m[L.filt + 2 * q + 3]; } n--; }
+          m[L.filt + 2 * n] = (1.0 - sp.gamma_theta) * theta; m[L.filt + 2 * n + 1] = phi0 - sp.gamma_phi * theta;
+        }
+      CFZ_END
+      nfilt = (nfilt == sp.filter_cap) ? nfilt : nfilt + 1;
+    }
+    // ---- update ------------------------------------------------------------------------------------------------
+    CFZ_LANES(lane)
+      if (lane < 5) m[L.pi0 + lane] += alpha * m[L.dpi0 + lane];
+      if (lane < N) {
+        const int k = lane;
+        double *pk = m + L.p + k * kNP; const double *dpk = m + L.dp + k * kNP;
+        for (int q = 0; q < 6; ++q) {
+          const double dx = dpk[bcol(q)];
+          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
+          const double dzl = mu / dl - zl - zl / dl * dx, dzu = mu / du - zu_ + zu_ / du * dx;
+          const double xn = pk[bcol(q)] + alpha * dx;
+          const double dln = xn - sp.bounds[2 * q], dun = sp.bounds[2 * q + 1] - xn;
+          m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mu / (sp.kappa_sigma * dln)), sp.kappa_sigma * mu / dln);
+          m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mu / (sp.kappa_sigma * dun)), sp.kappa_sigma * mu / dun);
+        }
+        for (int j = 0; j < nb; ++j) {
+          const int t = k * nb + j;
+          const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t];
+          const double S = zs / sg + sp.reg_primal;
+          const double dnu = S * ds - mu / sg - m[L.nuc + t];
+          const double dzs = mu / sg - zs - zs / sg * ds;
+          const double sgn = sg + alpha * ds;
+          m[L.sg + t] = sgn; m[L.nuc + t] += alpha * dnu;
+          m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, mu / (sp.kappa_sigma * sgn)), sp.kappa_sigma * mu / sgn);
+        }
+        for (int i = 0; i < kNP; ++i) pk[i] += alpha * dpk[i];
+        if (k + 1 < N) for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] += alpha * m[L.dpi + k * 5 + i];
+      }
+    CFZ_END
+  }
+
+  // ---- write back: trajectory, separations, dual certificates ---------------------------------------------------
+  CFZ_LANES(lane)
+    for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
+    double smin = INFINITY;
+    for (int t = lane; t < N * nb; t += 64) {
+      const int k = t / nb, j = t - k * nb;
+      double A[4][2], b[4], V[4][2]; int cert;
+      block_polygon(sp, m, L, k, j, A, b, V);
+      const double psi = m[L.p + k * kNP + 2];
+      const double sep = block_sep<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, nullptr, &cert);
+      smin = fmin(smin, sep);
+      if (duo.l) {
+        const int kind = cert >> 4, f = (cert >> 2) & 3;
+        const double c = cos(psi), s = sin(psi);
+        double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
+        if (j < n_obs) {
+          if (kind == 1) {  // n = A_f ; G' mu = -R' n
+            lam[f] = 1.0;
+            const double mx = -(c * A[f][0] + s * A[f][1]), my = -(-s * A[f][0] + c * A[f][1]);
+            muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
+          } else {  // n = -R G_f ; A' lam = n from the two obstacle faces through vertex v
+            muv[f] = 1.0;
+            const int v = cert & 3;
+            const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+            const double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
+            // the two faces active at vertex v: those with |A_i.V_v - b_i| smallest
+            int i0 = 0, i1 = 1; double r0 = INFINITY, r1 = INFINITY;
+            for (int i = 0; i < 4; ++i) {
+              const double r = fabs(A[i][0] * V[v][0] + A[i][1] * V[v][1] - b[i]);
+              if (r < r0) { r1 = r0; i1 = i0; r0 = r; i0 = i; } else if (r < r1) { r1 = r; i1 = i; }
+            }
+            const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
+            const double det = A[ia][0] * A[ib][1] - A[ib][0] * A[ia][1];
+            lam[ia] = fmax((A[ib][1] * nx - A[ib][0] * ny) / det, 0.0);
+            lam[ib] = fmax((-A[ia][1] * nx + A[ia][0] * ny) / det, 0.0);
+          }
+          for (int i = 0; i < 4; ++i) { duo.l[k * 4 * n_obs + 4 * j + i] = lam[i]; duo.mm[k * 4 * n_obs + 4 * j + i] = muv[i]; }
+        } else {
+          const int o = j - n_obs;
+          const double *q = m + L.nb4 + (k * n_nbr + o) * 4;
+          const double co = q[2], so = q[3];
+          double wx, wy;  // separating direction from this vehicle to the other
+          const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+          if (kind == 1) {  // a face of the OTHER vehicle: w = -Ro G_f, mu = e_f, lam = posneg(R' w)
+            wx = -(co * gx - so * gy); wy = -(so * gx + co * gy);
+            muv[f] = 1.0;
+            const double lx = c * wx + s * wy, ly = -s * wx + c * wy;
+            lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
+          } else {  // a face of this vehicle: w = R G_f, lam = e_f, mu = posneg(-Ro' w)
+            wx = c * gx - s * gy; wy = s * gx + c * gy;
+            lam[f] = 1.0;
+            const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);
+            muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
+          }
+          for (int i = 0; i < 4; ++i) { duo.lam_ij[(o * N + k) * 4 + i] = lam[i]; duo.lam_ji[(o * N + k) * 4 + i] = muv[i]; }
+          // s = -A_this' lam = -R G' lam   (vehicle_follower.py:350)
+          const double glx = lam[0] - lam[2], gly = lam[1] - lam[3];
+          duo.s[(o * N + k) * 2 + 0] = -(c * glx - s * gly);
+          duo.s[(o * N + k) * 2 + 1] = -(s * glx + c * gly);
+        }
+      }
+    }
+    m[L.red + 0 * 64 + lane] = smin;
+  CFZ_END
+  out_d[0] = fval_last; out_d[1] = err0; out_d[2] = red_min(m, L, 0);
+  out_i[0] = iter; out_i[1] = status;
+}
+
+}  // namespace cfz
+#endif  // CFZ_SOLVER_INL

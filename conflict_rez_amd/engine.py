@@ -1,0 +1,239 @@
+"""ctypes binding of libconfrez_hip.so (C ABI: include/confrez_hip.h).
+
+This is the only place the Python package touches the solver.  There is no CPU fallback:
+if the HIP library is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconfrez_hip.so")
+MAX_OBS, MAX_NBR, MAX_N = 8, 7, 64
+
+STATUS_NAMES = {0: "converged", 1: "iteration limit", 2: "line search failed", 3: "non-finite iterate"}
+
+
+class _CSpec(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("n_obs", C.c_int32), ("n_nbr", C.c_int32), ("rk_substeps", C.c_int32),
+        ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
+        ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
+        ("A_obs", C.c_double * (MAX_OBS * 8)), ("b_obs", C.c_double * (MAX_OBS * 4)),
+    ]
+
+
+_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "reserved")
+_OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
+             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split()
+
+
+class _COptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in _OPT_INTS] + [(k, C.c_double) for k in _OPT_DBLS]
+
+
+@dataclass
+class ProblemSpec:
+    """Constants of the MPC-step NLP (`cfz_spec`); defaults are the reference's
+    (`VehicleFollower.setup_controller`, `VehicleBody`, `VehicleConfig`, `GeofenceRegion`)."""
+
+    N: int = 30
+    dt: float = 0.1
+    n_nbr: int = 3
+    A_obs: np.ndarray = field(default_factory=lambda: np.zeros((0, 4, 2)))
+    b_obs: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))
+    g: np.ndarray = field(default_factory=lambda: np.array([3.3, 0.9, 0.6, 0.9]))
+    wb: float = 2.5
+    bounds: np.ndarray = field(
+        default_factory=lambda: np.array([2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0])
+    )
+    dmin: float = 0.05
+    weights: np.ndarray = field(default_factory=lambda: np.array([100.0, 100, 100, 1, 1, 1]))
+    rk_substeps: int = 4
+
+    @property
+    def n_obs(self):
+        return int(np.asarray(self.A_obs).shape[0])
+
+    @classmethod
+    def from_objects(cls, obstacles, vehicle_body, vehicle_config, region, n_nbr, N=30, dt=0.1, dmin=0.05):
+        """From the reference-style objects (`Polytope` list, `VehicleBody`, `VehicleConfig`, `GeofenceRegion`)."""
+        vc, r = vehicle_config, region
+        return cls(
+            N=N, dt=dt, n_nbr=n_nbr, dmin=dmin, wb=vehicle_body.wb, g=np.asarray(vehicle_body.b, float),
+            A_obs=np.stack([o.A for o in obstacles]) if obstacles else np.zeros((0, 4, 2)),
+            b_obs=np.stack([o.b for o in obstacles]) if obstacles else np.zeros((0, 4)),
+            bounds=np.array([r.x_min, r.x_max, r.y_min, r.y_max, vc.v_min, vc.v_max, vc.delta_min, vc.delta_max,
+                             vc.a_min, vc.a_max, vc.w_delta_min, vc.w_delta_max], float),
+        )
+
+    def to_c(self):
+        if self.n_obs > MAX_OBS or self.n_nbr > MAX_NBR or self.N > MAX_N:
+            raise ValueError("problem exceeds the engine's compiled limits")
+        s = _CSpec()
+        s.N, s.n_obs, s.n_nbr, s.rk_substeps = self.N, self.n_obs, self.n_nbr, self.rk_substeps
+        s.dt, s.wb, s.dmin = self.dt, self.wb, self.dmin
+        s.g[:] = [float(v) for v in self.g]
+        s.bounds[:] = [float(v) for v in self.bounds]
+        s.weights[:] = [float(v) for v in self.weights]
+        A = np.zeros((MAX_OBS, 4, 2)); b = np.zeros((MAX_OBS, 4))
+        if self.n_obs:
+            A[: self.n_obs], b[: self.n_obs] = self.A_obs, self.b_obs
+        s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel())
+        return s
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libconfrez_hip.so and declares the prototypes of include/confrez_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). conflict_rez_amd has no CPU solver."
+        )
+    lib = C.CDLL(path)
+    vp, i32p = C.c_void_p, C.c_void_p
+    lib.cfz_last_error.restype = C.c_char_p
+    lib.cfz_default_spec.argtypes = [C.POINTER(_CSpec)]
+    lib.cfz_default_options.argtypes = [C.POINTER(_COptions)]
+    lib.cfz_create.argtypes = [C.POINTER(_CSpec), C.POINTER(_COptions), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.cfz_destroy.argtypes = [vp]
+    lib.cfz_max_batch.argtypes = [vp]
+    lib.cfz_mpc_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.cfz_mpc_set_warm.argtypes = [vp, C.c_int, vp]
+    lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
+    lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.cfz_mpc_stats.argtypes = [vp, C.c_int, i32p, i32p, vp, vp, vp]
+    lib.cfz_last_solve_ms.argtypes = [vp]
+    lib.cfz_last_solve_ms.restype = C.c_double
+    lib.cfz_mpc_solve_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cfz_loop_init.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.cfz_loop_step.argtypes = [vp]
+    lib.cfz_loop_get.argtypes = [vp, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+EXPORTS = (
+    "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_mpc_set_params cfz_mpc_set_warm "
+    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_loop_init cfz_loop_step "
+    "cfz_loop_get cfz_last_error"
+).split()
+
+
+def default_options(**overrides):
+    lib = load_library()
+    o = _COptions()
+    lib.cfz_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise ValueError(f"expected array of shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+class Engine:
+    """One batched solver instance on one GPU (a `cfz_handle`)."""
+
+    def __init__(self, spec: ProblemSpec, max_batch: int, device: int = 0, **options):
+        self.lib = load_library()
+        self.spec = spec
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        cs, co = spec.to_c(), default_options(**options)
+        if self.lib.cfz_create(C.byref(cs), C.byref(co), int(device), self.max_batch, C.byref(self._h)) != 0:
+            raise RuntimeError("cfz_create: " + self.lib.cfz_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.cfz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: " + self.lib.cfz_last_error().decode())
+
+    # ---- host-buffer path ------------------------------------------------------------------
+    def solve(self, x0, ref, nbr, zu, want_duals=True):
+        """x0 [B,5], ref [B,3,N], nbr [B,n_nbr,3,N], zu [B,7,N] (warm start) ->
+        dict(zu, status, iters, cost, kkt_err, min_sep[, l, m, lam_ij, lam_ji, s], solve_ms)."""
+        sp = self.spec
+        N, no, nn = sp.N, sp.n_obs, sp.n_nbr
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.shape[0]
+        x0 = _f64(x0, (B, 5)); ref = _f64(ref, (B, 3, N)); zu = _f64(zu, (B, 7, N))
+        nbr = _f64(nbr, (B, nn, 3, N)) if nn else None
+        self._ck(self.lib.cfz_mpc_set_params(self._h, B, _ptr(x0), _ptr(ref), _ptr(nbr)), "cfz_mpc_set_params")
+        self._ck(self.lib.cfz_mpc_set_warm(self._h, B, _ptr(zu)), "cfz_mpc_set_warm")
+        self._ck(self.lib.cfz_mpc_solve(self._h, B), "cfz_mpc_solve")
+        out = dict(zu=np.empty((B, 7, N)), status=np.empty(B, np.int32), iters=np.empty(B, np.int32),
+                   cost=np.empty(B), kkt_err=np.empty(B), min_sep=np.empty(B))
+        if want_duals:
+            out.update(l=np.zeros((B, N, 4 * no)), m=np.zeros((B, N, 4 * no)), lam_ij=np.zeros((B, nn, N, 4)),
+                       lam_ji=np.zeros((B, nn, N, 4)), s=np.zeros((B, nn, N, 2)))
+        self._ck(self.lib.cfz_mpc_get(self._h, B, _ptr(out["zu"]), _ptr(out.get("l")), _ptr(out.get("m")),
+                                      _ptr(out.get("lam_ij")), _ptr(out.get("lam_ji")), _ptr(out.get("s"))), "cfz_mpc_get")
+        self._ck(self.lib.cfz_mpc_stats(self._h, B, _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["cost"]),
+                                        _ptr(out["kkt_err"]), _ptr(out["min_sep"])), "cfz_mpc_stats")
+        out["solve_ms"] = self.last_solve_ms()
+        return out
+
+    def last_solve_ms(self):
+        return float(self.lib.cfz_last_solve_ms(self._h))
+
+    # ---- device-pointer path (torch tensors or any object with data_ptr()) --------------------
+    def solve_device(self, B, d_x0, d_ref, d_nbr, d_zu, d_status, d_iters, d_stats, stream=None):
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        self._ck(self.lib.cfz_mpc_solve_device(self._h, int(B), ptr(d_x0), ptr(d_ref), ptr(d_nbr), ptr(d_zu),
+                                               ptr(d_status), ptr(d_iters), ptr(d_stats),
+                                               None if stream is None else C.c_void_p(int(stream))), "cfz_mpc_solve_device")
+
+    # ---- batched closed loop ------------------------------------------------------------------------
+    def loop_init(self, ref_table, k0, noise=None):
+        """ref_table [V,T,3], k0 int32 [S], noise [S,V,5] or None."""
+        V = self.spec.n_nbr + 1
+        ref_table = np.ascontiguousarray(ref_table, dtype=np.float64)
+        T = ref_table.shape[1]
+        ref_table = _f64(ref_table, (V, T, 3))
+        k0 = np.ascontiguousarray(k0, dtype=np.int32)
+        S = k0.shape[0]
+        if noise is not None:
+            noise = _f64(noise, (S, V, 5))
+        self._S, self._V = S, V
+        self._ck(self.lib.cfz_loop_init(self._h, S, T, _ptr(ref_table), _ptr(k0), _ptr(noise)), "cfz_loop_init")
+
+    def loop_step(self):
+        self._ck(self.lib.cfz_loop_step(self._h), "cfz_loop_step")
+
+    def loop_get(self):
+        S, V, N = self._S, self._V, self.spec.N
+        out = dict(state=np.empty((S, V, 5)), pred=np.empty((S, V, 7, N)), status=np.empty((S, V), np.int32),
+                   iters=np.empty((S, V), np.int32))
+        self._ck(self.lib.cfz_loop_get(self._h, _ptr(out["state"]), _ptr(out["pred"]), _ptr(out["status"]),
+                                       _ptr(out["iters"])), "cfz_loop_get")
+        return out

@@ -28,7 +28,10 @@ _UPPER_WALL_X = (3, 4, 5, 7, 8, 10)
 _LOWER_WALL_X = (3, 4, 5, 7, 9, 10)
 ACTIONS = ((0, 0.0), (1, -np.pi / 4), (1, 0.0), (1, np.pi / 4), (-1, -np.pi / 4), (-1, 0.0), (-1, np.pi / 4))
 
-DEFAULT_ORDER = [0, 2, 1, 3]
+# default priority and initial waits: the combination for which the four tube plans stay clear of
+# each other in continuous space (see tests/golden/make_fixtures.py)
+DEFAULT_ORDER = [1, 0, 2, 3]
+DEFAULT_DELAYS = [2, 0, 0, 0]
 
 AGENT_CONFIGS = (
     {"init_state": {"front": (6, 8), "back": (6, 7)}, "goal": {"front": (12, 6), "back": (11, 6)}},
@@ -118,7 +121,10 @@ def generate_strategy(n_vehicles=4, order=None, start_delays=None, horizon=48):
         # vehicles whose start blocks another's goal slot go first; fall back to any feasible priority
         from itertools import permutations
 
-        for cand in [DEFAULT_ORDER[:n_vehicles]] + [list(p) for p in permutations(range(n_vehicles))]:
+        if start_delays is None:
+            start_delays = DEFAULT_DELAYS[:n_vehicles]
+        first = [i for i in DEFAULT_ORDER if i < n_vehicles]
+        for cand in [first] + [list(p) for p in permutations(range(n_vehicles))]:
             try:
                 return generate_strategy(n_vehicles, cand, start_delays, horizon)
             except RuntimeError:

@@ -1,0 +1,129 @@
+/* confrez_hip.h -- C ABI of libconfrez_hip.so, the MI355X (gfx950) engine behind the
+ * collision-free planning hot path of XuShenLZ/conflict_rez.
+ *
+ * The reference has no FFI: its seam is the CasADi call `opti.solve()` inside
+ * `VehicleFollower.step` (confrez/control/vehicle_follower.py:428-563).  Every entry point
+ * below names the reference statements it stands in for.  All arrays are contiguous fp64
+ * (int32 where stated), instance-major: the leading index is the problem instance
+ * b in [0, B).  Host-pointer calls copy in/out during the call and retain nothing;
+ * `_device` calls take HIP device pointers and enqueue on the handle's stream.
+ *
+ * Return value: 0 on success, <0 on an API error (cfz_last_error() explains).  Solver
+ * outcomes are per instance, in `status`:
+ *   0 converged | 1 iteration limit | 2 line search failed | 3 non-finite iterate
+ * The reference turns any non-zero outcome into a Python exception that `step()` catches
+ * to apply its shift fallback (vehicle_follower.py:478-524); the Python shim does the same.
+ *
+ * A handle is not thread-safe (the reference is single-threaded).
+ */
+#ifndef CONFREZ_HIP_H
+#define CONFREZ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFZ_MAX_OBS 8   /* static obstacles (reference: 6, compute_sets.py:259-330) */
+#define CFZ_MAX_NBR 7   /* neighbouring vehicles (reference: 3) */
+#define CFZ_MAX_N 64    /* horizon stages (reference: 30, vehicle_follower.py:146) */
+
+/* Constants of the MPC-step NLP: what `setup_controller(dt, N, dmin)` bakes into the CasADi
+ * graph (vehicle_follower.py:146-368). */
+typedef struct cfz_spec {
+  int32_t N;           /* horizon stages                       :146 */
+  int32_t n_obs;       /* static obstacles, 4 half-planes each :152-156 */
+  int32_t n_nbr;       /* other vehicles                       :303 */
+  int32_t rk_substeps; /* RK4 sub-steps M of dynamic_model.py:30 (reference 4) */
+  double dt;           /*                                      :146 */
+  double wb;           /* wheelbase, vehicle_types.py:19 */
+  double dmin;         /* clearance                            :146 */
+  double g[4];         /* body rectangle lf, w/2, lr, w/2 (rows +x,+y,-x,-y), vehicle_types.py:65-71 */
+  double bounds[12];   /* lo,hi of x, y, v, delta, a, w        :204-240 */
+  double weights[6];   /* (x-xr)^2,(y-yr)^2,(psi-psir)^2,a^2,(v w)^2,delta^2   :263-271 */
+  double A_obs[CFZ_MAX_OBS][4][2]; /* unit outward normals     :280-290 */
+  double b_obs[CFZ_MAX_OBS][4];
+} cfz_spec;
+
+/* Stopping rule and interior-point constants: `opti.solver("ipopt", p_opts, s_opts)`
+ * (vehicle_follower.py:356-368) plus the IPOPT defaults that call leaves untouched. */
+typedef struct cfz_options {
+  int32_t max_iter;       /* :364 600 */
+  int32_t max_backtrack;  /* line-search halvings before status 2 */
+  int32_t filter_cap;     /* filter entries kept per barrier problem */
+  int32_t reserved;
+  double tol;             /* :362 1e-2 */
+  double constr_viol_tol; /* :363 1e-2 */
+  double dual_inf_tol;    /* IPOPT default 1 */
+  double compl_inf_tol;   /* IPOPT default 1e-4 */
+  double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max, kappa_sigma;
+  double eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi, reg_primal;
+} cfz_options;
+
+typedef struct cfz_handle cfz_handle;
+
+void cfz_default_spec(cfz_spec *spec);       /* reference constants, no obstacles */
+void cfz_default_options(cfz_options *opt);  /* reference s_opts + IPOPT defaults */
+
+/* Builds the solver for one NLP structure on `device` for up to `max_batch` instances.
+ * Replaces the graph construction half of setup_controller (:165-368). */
+int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out);
+int cfz_destroy(cfz_handle *h);
+int cfz_max_batch(const cfz_handle *h);
+
+/* opti.set_value(current_x..current_delta, current_ref_*, p_other_pred[*]) (:432-456).
+ * x0[B][5]; ref[B][3][N] rows x,y,psi; nbr[B][n_nbr][3][N] (already advanced by the caller
+ * as `_adv_onestep` does, :445-455). */
+int cfz_mpc_set_params(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr);
+
+/* opti.set_initial(x..w) (:466-473).  zu[B][7][N] rows x,y,psi,v,delta,a,w.  The dual
+ * initial guesses of :458-464,:475-476 are not taken: the engine eliminates the OBCA duals
+ * and rebuilds them from the poses (DESIGN.md "Certificate elimination"). */
+int cfz_mpc_set_warm(cfz_handle *h, int B, const double *zu);
+
+/* sol = opti.solve() (:479): runs the batched solver and blocks until done. */
+int cfz_mpc_solve(cfz_handle *h, int B);
+
+/* sol.value(...) (:484-500).  Any output pointer may be NULL.
+ * zu[B][7][N]; l,m [B][N][4*n_obs]; lam_ij,lam_ji [B][n_nbr][N][4]; s [B][n_nbr][N][2]. */
+int cfz_mpc_get(cfz_handle *h, int B, double *zu, double *l, double *m, double *lam_ij, double *lam_ji, double *s);
+
+/* sol.stats() (:481): per-instance outcome.  Any pointer may be NULL.
+ * status,iters int32[B]; cost, kkt_err (scaled optimality error E_0), min_sep fp64[B]. */
+int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double *cost, double *kkt_err,
+                  double *min_sep);
+
+/* Milliseconds the last cfz_mpc_solve / cfz_loop_step spent in its solver kernel (HIP events
+ * on the handle's stream). */
+double cfz_last_solve_ms(const cfz_handle *h);
+
+/* ---- device-resident path ------------------------------------------------------------- */
+/* Same as set_params + set_warm + solve + get(zu) on HIP device pointers, asynchronous on
+ * `stream` (a hipStream_t; NULL = the handle's own stream).  d_status/d_iters int32[B],
+ * d_stats fp64[B][3] = cost, kkt_err, min_sep.  d_zu is read as the warm start and overwritten
+ * with the solution. */
+int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double *d_ref, const double *d_nbr,
+                         double *d_zu, int32_t *d_status, int32_t *d_iters, double *d_stats, void *stream);
+
+/* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
+ * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
+ * ref_table[V][T][3]: each vehicle's planned reference sampled every dt (what get_current_ref
+ * :370-404 interpolates); scenario s starts at sample k0[s].
+ * cfz_loop_init sets state = ref_table[v][k0] + noise[s][v][5] (x,y,psi,v,delta) and the first
+ * prediction = the reference itself with v,delta,a,w = 0 (:399-400).
+ * cfz_loop_step does one iteration for all scenarios, entirely on the device:
+ *   neighbours' predictions copied first (get_others_pred :636-637, Jacobi), every vehicle's
+ *   step(): parameters + shifted warm start (:432-476), solve (:479), read-back or shift
+ *   fallback (:484-524), clock += dt (:526), plant integration over dt with (a0,w0) (:528-543). */
+int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const int32_t *k0, const double *noise);
+int cfz_loop_step(cfz_handle *h);
+/* state[S][V][5], pred[S][V][7][N], status int32[S][V] of the last step; NULL to skip. */
+int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters);
+
+const char *cfz_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONFREZ_HIP_H */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "mpc_golden.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def ospec(golden):
+    from oracle.mpc_nlp import MpcSpec
+
+    return MpcSpec(A_obs=golden["A_obs"], b_obs=golden["b_obs"], n_nbr=3)

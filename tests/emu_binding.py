@@ -1,0 +1,74 @@
+"""ctypes binding of the test-only CPU build of the kernel source (tests/emu/cfz_emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(ROOT, "tests", "_build", "libcfz_emu.so")
+_OPTS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
+         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split()
+
+
+class KSpec(C.Structure):
+    _fields_ = [(k, C.c_int) for k in "N n_obs n_nbr rk_substeps max_iter max_backtrack filter_cap pad0".split()] + [
+        ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
+        ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
+        ("A_obs", C.c_double * 64), ("b_obs", C.c_double * 32), ("V_obs", C.c_double * 64),
+    ] + [(k, C.c_double) for k in _OPTS]
+
+
+def build(force=False, sanitize=False):
+    srcs = [os.path.join(ROOT, "tests", "emu", "cfz_emu.cpp"),
+            os.path.join(ROOT, "conflict_rez_amd", "csrc", "cfz_solver.inl")]
+    lib = _LIB.replace(".so", "_asan.so") if sanitize else _LIB
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        flags = ["-O1", "-g", "-fsanitize=address,undefined"] if sanitize else ["-O2"]
+        subprocess.check_call(["g++", *flags, "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", lib, srcs[0]])
+    return lib
+
+
+def make_kspec(spec, opt):
+    """spec: oracle.mpc_nlp.MpcSpec, opt: oracle.ipm.IpmOptions"""
+    from oracle.mpc_nlp import polytope_vertices
+
+    s = KSpec()
+    s.N, s.n_obs, s.n_nbr, s.rk_substeps = spec.N, spec.n_obs, spec.n_nbr, spec.rk_substeps
+    s.max_iter, s.max_backtrack, s.filter_cap = opt.max_iter, opt.max_backtrack, opt.filter_cap
+    s.dt, s.wb, s.dmin = spec.dt, spec.wb, spec.dmin
+    s.g[:] = list(spec.g); s.bounds[:] = list(spec.bounds); s.weights[:] = list(spec.weights)
+    A = np.zeros((8, 4, 2)); b = np.zeros((8, 4)); V = np.zeros((8, 4, 2))
+    for j in range(spec.n_obs):
+        A[j], b[j] = spec.A_obs[j], spec.b_obs[j]
+        V[j] = polytope_vertices(spec.A_obs[j], spec.b_obs[j])[0]
+    s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel()); s.V_obs[:] = list(V.ravel())
+    for k in _OPTS:
+        setattr(s, k, getattr(opt, k))
+    return s
+
+
+_lib = None
+
+
+def solve(spec, opt, x0, ref, nbr, zu, want_duals=True):
+    """zu [7,N] warm start -> dict(zu, iters, status, cost, err, min_sep, l, m, lam_ij, lam_ji, s)."""
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        assert _lib.cfz_emu_sizeof_kspec() == C.sizeof(KSpec)
+    N, no, nn = spec.N, spec.n_obs, spec.n_nbr
+    ks = make_kspec(spec, opt)
+    zu = np.ascontiguousarray(zu, dtype=np.float64).copy()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64); ref = np.ascontiguousarray(ref, dtype=np.float64)
+    nbr = np.ascontiguousarray(nbr if nn else np.zeros(1), dtype=np.float64)
+    oi = np.zeros(2, dtype=np.int32); od = np.zeros(3)
+    l = np.zeros((N, 4 * no)); m = np.zeros((N, 4 * no))
+    lij = np.zeros((nn, N, 4)); lji = np.zeros((nn, N, 4)); s = np.zeros((nn, N, 2))
+    dp = lambda a: a.ctypes.data_as(C.c_void_p)
+    dd = (lambda a: dp(a)) if want_duals else (lambda a: None)
+    rc = _lib.cfz_emu_solve(C.byref(ks), dp(x0), dp(ref), dp(nbr), dp(zu), dp(oi), dp(od), dd(l), dd(m), dd(lij), dd(lji), dd(s))
+    assert rc > 0
+    return dict(zu=zu, iters=int(oi[0]), status=int(oi[1]), cost=od[0], err=od[1], min_sep=od[2], l=l, m=m, lam_ij=lij,
+                lam_ji=lji, s=s, lds_doubles=rc)

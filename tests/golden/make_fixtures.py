@@ -1,0 +1,120 @@
+"""Generates the committed fixtures of tests/golden/ (run from the repo root:
+`python tests/golden/make_fixtures.py`).
+
+  pytypes_fields.json   field names / defaults of the reference's importable struct modules
+                        (needs /root/reference; skipped when absent)
+  refs_4v.npz           synthetic 4-vehicle strategy (conflict_rez_amd.strategy) and, per vehicle,
+                        the reference trajectory of the reference's `state_ws` NLP
+                        (vehicle.py:99-231, tube constraints, dt = 0.1) solved by the oracle
+                        (oracle/plan_nlp.py + oracle/ipm.py, exact Hessian), sampled every dt
+  mpc_golden.npz        MPC-step instances (inputs) and their solutions by the full-KKT numpy
+                        oracle (oracle/ipm.py on oracle/mpc_nlp.py)
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from conflict_rez_amd import strategy as strat  # noqa: E402
+from conflict_rez_amd.control.compute_sets import (  # noqa: E402
+    compute_obstacles, compute_sets, interp_along_sets)
+from conflict_rez_amd.vehicle_types import VehicleBody  # noqa: E402
+from oracle import ipm  # noqa: E402
+from oracle.mpc_nlp import MpcNlp, MpcSpec  # noqa: E402
+from oracle.plan_nlp import StateWsNlp  # noqa: E402
+
+
+def pytypes_fields():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        print("reference not present: pytypes_fields.json left as is")
+        return
+    sys.path.insert(0, ref)
+    import dataclasses
+    import importlib
+
+    out = {}
+    for mod, names in (("confrez.pytypes", ["Position", "VehicleActuation", "BodyLinearVelocity", "BodyAngularVelocity",
+                                             "BodyLinearAcceleration", "BodyAngularAcceleration", "OrientationEuler",
+                                             "OrientationQuaternion", "ParametricPose", "ParametricVelocity", "VehicleState",
+                                             "VehiclePrediction"]),
+                       ("confrez.vehicle_types", ["VehicleConfig", "VehicleBody"]),
+                       ("confrez.obstacle_types", ["GeofenceRegion"])):
+        m = importlib.import_module(mod)
+        for n in names:
+            inst = getattr(m, n)()
+            out[n] = {f.name: (getattr(inst, f.name) if isinstance(getattr(inst, f.name), (int, float, type(None))) else
+                               type(getattr(inst, f.name)).__name__) for f in dataclasses.fields(inst)}
+    vb = importlib.import_module("confrez.vehicle_types").VehicleBody()
+    out["VehicleBody.A"] = np.asarray(vb.A).tolist()
+    out["VehicleBody.b"] = np.asarray(vb.b).tolist()
+    out["VehicleBody.V"] = np.asarray(vb.V).tolist()
+    with open(os.path.join(HERE, "pytypes_fields.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    sys.path.remove(ref)
+
+
+def refs_4v():
+    hist = strat.generate_strategy(4)
+    vb = VehicleBody()
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, vb, 30)
+    agents = sorted(hist)
+    trajs = []
+    for a in agents:
+        tube = [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]]
+        p = paths[a]
+        nlp = StateWsNlp(p[0], tube, final_heading=None, shrink_tube=0.5)
+        res = ipm.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2]), ipm.IpmOptions(max_iter=300, hessian="exact"))
+        assert res["status"] == 0, (a, res["status"])
+        s = nlp.unpack(res["X"])
+        trajs.append(np.stack([s["x"], s["y"], s["psi"], s["v"], s["delta"], s["a"], s["w"]], 1))
+        print(a, "state_ws iters", res["iters"], "f %.4f" % res["f"], "T", len(s["x"]))
+    T = max(len(t) for t in trajs)
+    table = np.stack([np.concatenate([t, np.repeat(t[-1:], T - len(t), 0)], 0) for t in trajs])  # [V,T,7]
+    table[:, :, 3:] = np.where(np.arange(T)[None, :, None] < np.array([len(t) for t in trajs])[:, None, None], table[:, :, 3:], 0.0)
+    cells = {a: np.array([[*s["front"], *s["back"]] for s in hist[a]], dtype=np.int32) for a in agents}
+    np.savez_compressed(os.path.join(HERE, "refs_4v.npz"), table=table, lengths=np.array([len(t) for t in trajs]),
+                        **{"cells_" + a: cells[a] for a in agents})
+    return table
+
+
+def mpc_golden(table):
+    obs = compute_obstacles()
+    spec = MpcSpec(A_obs=np.stack([o.A for o in obs]), b_obs=np.stack([o.b for o in obs]), n_nbr=3)
+    N, V, T = spec.N, table.shape[0], table.shape[1]
+    rng = np.random.default_rng(7)
+    X0, REF, NBR, ZU, SOL, META = [], [], [], [], [], []
+    for case in range(12):
+        v = case % V
+        k0 = int(rng.integers(0, T - 40))
+        idx = np.minimum(k0 + np.arange(N), T - 1)
+        ref = table[v, idx, :3].T.copy()
+        x0 = np.array([*table[v, k0, :3], table[v, k0, 3], table[v, k0, 4]]) + rng.normal(0, [0.05, 0.05, 0.02, 0.05, 0.0])
+        others = [u for u in range(V) if u != v]
+        nbr = np.stack([table[u, np.minimum(idx + 1, T - 1), :3].T for u in others])
+        zu = np.concatenate([ref, np.zeros((4, N))], 0)
+        nlp = MpcNlp(spec, x0, ref, nbr)
+        warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
+        res = ipm.solve(nlp, nlp.pack(warm))
+        sol = nlp.unpack(res["X"])
+        X0.append(x0), REF.append(ref), NBR.append(nbr), ZU.append(zu)
+        SOL.append(np.stack([sol[k] for k in ("x", "y", "psi", "v", "delta", "a", "w")]))
+        META.append([res["status"], res["iters"], res["f"], sol["sep"].min()])
+        print("case", case, "vehicle", v, "k0", k0, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"],
+              "min sep %.4f" % sol["sep"].min())
+    np.savez_compressed(os.path.join(HERE, "mpc_golden.npz"), x0=np.array(X0), ref=np.array(REF), nbr=np.array(NBR),
+                        zu=np.array(ZU), sol=np.array(SOL), meta=np.array(META), A_obs=spec.A_obs, b_obs=spec.b_obs)
+
+
+if __name__ == "__main__":
+    pytypes_fields()
+    mpc_golden(refs_4v())
