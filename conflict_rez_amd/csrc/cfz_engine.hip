@@ -71,7 +71,7 @@ __global__ void loop_prep(int S, int V, int N, int T, const double *ref_table, c
   const int ka = (k + 1 < N) ? k + 1 : N - 1;  // _adv_onestep (:413-426)
   if (k < 5) x0[b * 5 + k] = state[b * 5 + k];
   int kr = kidx[s] + k; if (kr > T - 1) kr = T - 1;
-  for (int c = 0; c < 3; ++c) ref[((size_t)b * 3 + c) * N + k] = ref_table[((size_t)v * T + kr) * 3 + c];
+  for (int c = 0; c < 3; ++c) ref[((size_t)b * 3 + c) * N + k] = ref_table[((size_t)v * T + kr) * 7 + c];
   for (int c = 0; c < 7; ++c) zu[((size_t)b * 7 + c) * N + k] = pred[((size_t)b * 7 + c) * N + ka];
   int o = 0;
   for (int u = 0; u < V; ++u) {
@@ -101,7 +101,8 @@ __global__ void loop_post(int S, int V, int N, double dt, double wb, int plant_s
   if (b % V == 0) kidx[b / V] += 1;
 }
 
-// first prediction = the reference itself, inputs and v, delta zero (:399-400); state = ref + noise
+// first prediction = the planned trajectory at the horizon times, as get_current_ref seeds it
+// (:397-400); state = planned state at k0 + noise
 __global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
                           const double *noise, double *pred, double *state) {
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,11 +111,10 @@ __global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, c
   const int b = (int)(tid / N);
   const int s = b / V, v = b - s * V;
   int kr = kidx[s] + k; if (kr > T - 1) kr = T - 1;
-  for (int c = 0; c < 7; ++c)
-    pred[((size_t)b * 7 + c) * N + k] = (c < 3) ? ref_table[((size_t)v * T + kr) * 3 + c] : 0.0;
+  for (int c = 0; c < 7; ++c) pred[((size_t)b * 7 + c) * N + k] = ref_table[((size_t)v * T + kr) * 7 + c];
   if (k == 0)
     for (int c = 0; c < 5; ++c)
-      state[b * 5 + c] = ((c < 3) ? ref_table[((size_t)v * T + kidx[s]) * 3 + c] : 0.0) + (noise ? noise[b * 5 + c] : 0.0);
+      state[b * 5 + c] = ref_table[((size_t)v * T + kidx[s]) * 7 + c] + (noise ? noise[b * 5 + c] : 0.0);
 }
 
 }  // namespace
@@ -345,9 +345,9 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   h->ref_table = h->pred = h->state = nullptr; h->kidx = nullptr;
   h->S = S; h->T = T;
   const size_t B = (size_t)S * V;
-  HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 3 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
+  HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 7 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
   HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
-  HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 3 * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
   double *dn = nullptr;
   if (noise) { HIP_OK(hipMalloc(&dn, B * 5 * 8)); HIP_OK(hipMemcpy(dn, noise, B * 5 * 8, hipMemcpyHostToDevice)); }

@@ -59,24 +59,26 @@ struct KSpec {
 
 // Workspace layout (offsets in doubles) for one instance.
 struct Lay {
-  int N, nb;
+  int N, nb, nr;                            // stages, blocks per stage, rows per stage (2 per block)
   int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
   int dp, dsg, dpi0, dpi;                   // step
   int cj, gra, ab, d, hc, gk, kk;           // stage data
-  int ref, nb4, x0, filt, red, total;
+  int sel, ref, nb4, x0, filt, red, total;
 };
 
 CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   Lay L; int o = 0;
-  L.N = N; L.nb = nb;
+  const int nr = 2 * nb;
+  L.N = N; L.nb = nb; L.nr = nr;
   L.p = o; o += N * kNP;
-  L.sg = o; o += N * nb; L.nuc = o; o += N * nb; L.zs = o; o += N * nb;
+  L.sg = o; o += N * nr; L.nuc = o; o += N * nr; L.zs = o; o += N * nr;
   L.zl = o; o += N * 6; L.zu = o; o += N * 6;
   L.pi0 = o; o += 5; L.pi = o; o += N * 5;
-  L.dp = o; o += N * kNP; L.dsg = o; o += N * nb; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
-  L.cj = o; o += N * nb; L.gra = o; o += N * nb * 3;
+  L.dp = o; o += N * kNP; L.dsg = o; o += N * nr; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
+  L.cj = o; o += N * nr; L.gra = o; o += N * nr * 3;
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
+  L.sel = o; o += N * nb;  // working set codes, stored as doubles
   L.ref = o; o += 3 * N; L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
   L.filt = o; o += 64; L.red = o; o += kRed * 64;
   L.total = o;
@@ -169,67 +171,93 @@ CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb
 }
 
 // ------------------------------------------------------------------------------ separation certificates
-// Separation of polygon (A,b,V) from the body rectangle at (x,y,psi): max over the 8 face
-// normals of the min over the other polygon's vertices.  cert = kind*16 + face*4 + vertex,
-// kind 1 = polygon face / body vertex, kind 2 = body face / polygon vertex.  Strict
-// comparisons in candidate order (ties keep the first).
+// A block (stage k, obstacle or neighbour j) is certified along a face normal: "every vertex of
+// one polygon lies at least dmin outside face f of the other".  kind 1 = polygon face / body
+// vertices, kind 2 = body face / polygon vertices.  The working set of a block is the face and
+// the two vertices whose rows are imposed: sel = kind*64 + face*16 + vA*4 + vB, vA < vB.
+constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
+
 template <bool GRAD>
-CFZ_FN double block_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
-                        double psi, const double g[4], double grad[3], int *cert) {
+CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
+                        double c, double s, const double g[4], int kind, int f, double d[4], double gr[4][3]) {
+  if (kind == 1) {
+    const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+    double ax = 0.0, ay = 0.0, bf = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i == f) { ax = A[i][0]; ay = A[i][1]; bf = b[i]; }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double dwx = -s * BV[v][0] - c * BV[v][1], dwy = c * BV[v][0] - s * BV[v][1];
+      d[v] = (x + dwy) * ax + (y - dwx) * ay - bf;
+      if (GRAD) { gr[v][0] = ax; gr[v][1] = ay; gr[v][2] = ax * dwx + ay * dwy; }
+    }
+  } else {
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    double gf = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i == f) gf = g[i];
+    const double nx = c * gx - s * gy, ny = s * gx + c * gy, dnx = -s * gx - c * gy, dny = c * gx - s * gy;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      d[v] = (V[v][0] - x) * nx + (V[v][1] - y) * ny - gf;
+      if (GRAD) { gr[v][0] = -nx; gr[v][1] = -ny; gr[v][2] = dnx * (V[v][0] - x) + dny * (V[v][1] - y); }
+    }
+  }
+}
+
+CFZ_FN double pick4(const double d[4], int v) {
+  double r = d[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i == v) r = d[i];
+  return r;
+}
+
+CFZ_FN int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
+                       const double g[4], int prev) {
   const double c = cos(psi), s = sin(psi);
-  const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
-  const double GB[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
-  double W[4][2], dW[4][2];
+  const int pk = prev >> 6, pf = (prev >> 4) & 3;
+  double best = 0.0, prev_val = 0.0, d[4];
+  int have = 0, bk = 0, bf = 0, have_prev = 0;
+  for (int kind = 1; kind <= 2; ++kind)
+    for (int f = 0; f < 4; ++f) {
+      vertex_dist<false>(A, b, V, x, y, c, s, g, kind, f, d, nullptr);
+      const double val = fmin(fmin(d[0], d[1]), fmin(d[2], d[3]));
+      if (prev && kind == pk && f == pf) { prev_val = val; have_prev = 1; }
+      if (!have || val > best) { have = 1; best = val; bk = kind; bf = f; }
+    }
+  if (have_prev && prev_val >= best - kHyst) { bk = pk; bf = pf; }
+  vertex_dist<false>(A, b, V, x, y, c, s, g, bk, bf, d, nullptr);
+  int v0 = 0;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    dW[v][0] = -s * BV[v][0] - c * BV[v][1];
-    dW[v][1] = c * BV[v][0] - s * BV[v][1];
-    W[v][0] = x + dW[v][1];
-    W[v][1] = y - dW[v][0];
+  for (int v = 1; v < 4; ++v) if (d[v] < pick4(d, v0)) v0 = v;
+  const int n1 = (v0 + 1) & 3, n2 = (v0 + 3) & 3;
+  const double d0 = pick4(d, v0), dn1 = pick4(d, n1), dn2 = pick4(d, n2);
+  int v1 = (dn1 < dn2) ? n1 : ((dn2 < dn1) ? n2 : (n1 < n2 ? n1 : n2));
+  if (prev && bk == pk && bf == pf) {
+    const int oa = (prev >> 2) & 3, ob = prev & 3;
+    const double da = pick4(d, oa), db = pick4(d, ob);
+    if (fmin(da, db) <= d0 + 1e-12 && fmax(da, db) <= pick4(d, v1) + kHyst) { v0 = oa; v1 = ob; }
   }
-  double best = 0.0; int bc = 0;
+  const int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
+  return bk * 64 + bf * 16 + va * 4 + vb;
+}
+
+// values (and gradients wrt x,y,psi) of the two rows of working set `sel`
+template <bool GRAD>
+CFZ_FN void rows_for(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
+                     const double g[4], int sel, double sep[2], double grad[2][3]) {
+  const double c = cos(psi), s = sin(psi);
+  double d[4], gr[4][3];
+  vertex_dist<GRAD>(A, b, V, x, y, c, s, g, sel >> 6, (sel >> 4) & 3, d, gr);
+  const int va = (sel >> 2) & 3, vb = sel & 3;
+  sep[0] = pick4(d, va); sep[1] = pick4(d, vb);
+  if (GRAD) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int vm = 0; double dm = W[0][0] * A[i][0] + W[0][1] * A[i][1] - b[i];
-#pragma unroll
-    for (int v = 1; v < 4; ++v) {
-      const double d = W[v][0] * A[i][0] + W[v][1] * A[i][1] - b[i];
-      if (d < dm) { dm = d; vm = v; }
-    }
-    if (i == 0 || dm > best) {
-      best = dm; bc = 16 + 4 * i + vm;
-      if (GRAD) {
-        grad[0] = A[i][0]; grad[1] = A[i][1];
-        double g2 = 0.0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) if (v == vm) g2 = A[i][0] * dW[v][0] + A[i][1] * dW[v][1];
-        grad[2] = g2;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double nx = c * GB[k][0] - s * GB[k][1], ny = s * GB[k][0] + c * GB[k][1];
-    int vm = 0; double dm = (V[0][0] - x) * nx + (V[0][1] - y) * ny - g[k];
-#pragma unroll
-    for (int v = 1; v < 4; ++v) {
-      const double d = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[k];
-      if (d < dm) { dm = d; vm = v; }
-    }
-    if (dm > best) {
-      best = dm; bc = 32 + 4 * k + vm;
-      if (GRAD) {
-        const double dnx = -s * GB[k][0] - c * GB[k][1], dny = c * GB[k][0] - s * GB[k][1];
-        grad[0] = -nx; grad[1] = -ny;
-        double g2 = 0.0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) if (v == vm) g2 = dnx * (V[v][0] - x) + dny * (V[v][1] - y);
-        grad[2] = g2;
-      }
+    for (int v = 0; v < 4; ++v) {
+      if (v == va) { grad[0][0] = gr[v][0]; grad[0][1] = gr[v][1]; grad[0][2] = gr[v][2]; }
+      if (v == vb) { grad[1][0] = gr[v][0]; grad[1][1] = gr[v][1]; grad[1][2] = gr[v][2]; }
     }
   }
-  if (cert) *cert = bc;
-  return best;
 }
 
 // polygon of block j at stage k: static obstacle from the spec, neighbour from its pose
@@ -316,12 +344,15 @@ CFZ_FN void merit_partials(const KSpec &sp, double *m, const Lay &L, double alph
     const double x = m[L.p + k * kNP + 0] + alpha * m[L.dp + k * kNP + 0];
     const double y = m[L.p + k * kNP + 1] + alpha * m[L.dp + k * kNP + 1];
     const double ps = m[L.p + k * kNP + 2] + alpha * m[L.dp + k * kNP + 2];
-    const double sg = m[L.sg + t] + alpha * m[L.dsg + t];
-    double A[4][2], b[4], V[4][2];
+    double A[4][2], b[4], V[4][2], sep[2];
     block_polygon(sp, m, L, k, j, A, b, V);
-    const double sep = block_sep<false>(A, b, V, x, y, ps, sp.g, nullptr, nullptr);
-    th += fabs(sep - sp.dmin - sg);
-    if (!(sg > 0.0)) bad = 1.0; else lg += log(sg);
+    rows_for<false>(A, b, V, x, y, ps, sp.g, (int)m[L.sel + t], sep, nullptr);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
+      th += fabs(sep[r] - sp.dmin - sg);
+      if (!(sg > 0.0)) bad = 1.0; else lg += log(sg);
+    }
   }
   if (lane < N) {
     const int k = lane;
@@ -352,8 +383,8 @@ struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; };
 
 CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *refg, const double *nbrg, double *zu,
                            double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo) {
-  const int N = sp.N, nb = L.nb, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
-  const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb);
+  const int N = sp.N, nb = L.nb, nr = L.nr, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
+  const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
 
   // ---- load parameters, initial point ---------------------------------------------------
@@ -369,16 +400,37 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
     for (int i = lane; i < N * 5; i += 64) m[L.pi + i] = 0.0;
   CFZ_END
+  // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
+  // than 2*constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
   CFZ_LANES(lane)
-    // slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
+    double worst = INFINITY;
+    if (lane < nb) {
+      double A[4][2], b[4], V[4][2], sep[2];
+      block_polygon(sp, m, L, 0, lane, A, b, V);
+      const int c0 = select_rows(A, b, V, m[L.x0], m[L.x0 + 1], m[L.x0 + 2], sp.g, 0);
+      rows_for<false>(A, b, V, m[L.x0], m[L.x0 + 1], m[L.x0 + 2], sp.g, c0, sep, nullptr);
+      worst = fmin(sep[0], sep[1]);
+    }
+    m[L.red + lane] = worst;
+  CFZ_END
+  if (red_min(m, L, 0) < sp.dmin - 2.0 * sp.constr_viol_tol) {
+    out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = red_min(m, L, 0);
+    return;
+  }
+  CFZ_LANES(lane)
+    // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
     for (int t = lane; t < N * nb; t += 64) {
       const int k = t / nb, j = t - k * nb;
-      double A[4][2], b[4], V[4][2];
+      double A[4][2], b[4], V[4][2], sep[2];
       block_polygon(sp, m, L, k, j, A, b, V);
-      const double sep = block_sep<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], m[L.p + k * kNP + 2],
-                                          sp.g, nullptr, nullptr);
-      m[L.sg + t] = fmax(sep - sp.dmin, sp.bound_push);
-      m[L.zs + t] = 1.0; m[L.nuc + t] = 0.0;
+      const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], psi = m[L.p + k * kNP + 2];
+      const int c0 = select_rows(A, b, V, x, y, psi, sp.g, 0);
+      m[L.sel + t] = (double)c0;
+      rows_for<false>(A, b, V, x, y, psi, sp.g, c0, sep, nullptr);
+      for (int r = 0; r < 2; ++r) {
+        m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
+        m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
+      }
     }
   CFZ_END
   CFZ_LANES(lane)
@@ -399,18 +451,50 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   int nfilt = 0, status = 1, iter = 0;
 
   for (iter = 0; iter <= sp.max_iter; ++iter) {
-    // ---- evaluate blocks and dynamics at the current point --------------------------------
+    // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
     CFZ_LANES(lane)
       double cmax = 0.0, csum = 0.0;
       for (int t = lane; t < N * nb; t += 64) {
         const int k = t / nb, j = t - k * nb;
-        double A[4][2], b[4], V[4][2], gr[3];
+        double A[4][2], b[4], V[4][2], sep[2], gr[2][3];
         block_polygon(sp, m, L, k, j, A, b, V);
-        const double sep = block_sep<true>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], m[L.p + k * kNP + 2],
-                                           sp.g, gr, nullptr);
-        const double c = sep - sp.dmin - m[L.sg + t];
-        m[L.cj + t] = c; m[L.gra + t * 3] = gr[0]; m[L.gra + t * 3 + 1] = gr[1]; m[L.gra + t * 3 + 2] = gr[2];
-        cmax = fmax(cmax, fabs(c)); csum += fabs(c);
+        const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], psi = m[L.p + k * kNP + 2];
+        int c1 = (int)m[L.sel + t];
+        if (iter > 0) {
+          const int c0 = c1;
+          c1 = select_rows(A, b, V, x, y, psi, sp.g, c0);
+          if (c1 != c0) m[L.sel + t] = (double)c1;
+          rows_for<true>(A, b, V, x, y, psi, sp.g, c1, sep, gr);
+          if (c1 != c0) {
+            // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
+            // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
+            const int same_face = (c0 >> 4) == (c1 >> 4);
+            const int ov0 = (c0 >> 2) & 3, ov1 = c0 & 3;
+            const double o_sg[2] = {m[L.sg + 2 * t], m[L.sg + 2 * t + 1]};
+            const double o_zs[2] = {m[L.zs + 2 * t], m[L.zs + 2 * t + 1]};
+            const double o_nu[2] = {m[L.nuc + 2 * t], m[L.nuc + 2 * t + 1]};
+            for (int r = 0; r < 2; ++r) {
+              const int nv = r == 0 ? ((c1 >> 2) & 3) : (c1 & 3);
+              const int src = same_face ? (nv == ov0 ? 0 : (nv == ov1 ? 1 : -1)) : -1;
+              if (src >= 0) {
+                m[L.sg + 2 * t + r] = src == 0 ? o_sg[0] : o_sg[1];
+                m[L.zs + 2 * t + r] = src == 0 ? o_zs[0] : o_zs[1];
+                m[L.nuc + 2 * t + r] = src == 0 ? o_nu[0] : o_nu[1];
+              } else {
+                const double sg = fmax(sep[r] - sp.dmin, sp.bound_push);
+                m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = mu / sg; m[L.nuc + 2 * t + r] = -mu / sg;
+              }
+            }
+          }
+        } else {
+          rows_for<true>(A, b, V, x, y, psi, sp.g, c1, sep, gr);
+        }
+        for (int r = 0; r < 2; ++r) {
+          const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
+          m[L.cj + 2 * t + r] = c;
+          m[L.gra + (2 * t + r) * 3] = gr[r][0]; m[L.gra + (2 * t + r) * 3 + 1] = gr[r][1]; m[L.gra + (2 * t + r) * 3 + 2] = gr[r][2];
+          cmax = fmax(cmax, fabs(c)); csum += fabs(c);
+        }
       }
       if (lane == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
       if (lane + 1 < N) {
@@ -438,8 +522,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         double r[kNP];
         stage_grad(sp, m + L.ref, k, pk, r);
         fv = stage_cost(sp, m + L.ref, k, pk);
-        for (int j = 0; j < nb; ++j) {
-          const int t = k * nb + j;
+        for (int j = 0; j < nr; ++j) {
+          const int t = k * nr + j;
           const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
           r[0] += m[L.gra + t * 3] * nu; r[1] += m[L.gra + t * 3 + 1] * nu; r[2] += m[L.gra + t * 3 + 2] * nu;
           dinf = fmax(dinf, fabs(-nu - zs));
@@ -484,7 +568,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         double cm = 0.0;
         if (lane < N) {
           const int k = lane;
-          for (int j = 0; j < nb; ++j) cm = fmax(cm, fabs(m[L.sg + k * nb + j] * m[L.zs + k * nb + j] - mu));
+          for (int j = 0; j < nr; ++j) cm = fmax(cm, fabs(m[L.sg + k * nr + j] * m[L.zs + k * nr + j] - mu));
           for (int q = 0; q < 6; ++q) {
             const double v = m[L.p + k * kNP + bcol(q)];
             cm = fmax(cm, fmax(fabs((v - sp.bounds[2 * q]) * m[L.zl + k * 6 + q] - mu),
@@ -514,8 +598,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           h[bcol(q)] += m[L.zl + k * 6 + q] / dl + m[L.zu + k * 6 + q] / du;
           g[bcol(q)] += -mu / dl + mu / du;
         }
-        for (int j = 0; j < nb; ++j) {
-          const int t = k * nb + j;
+        for (int j = 0; j < nr; ++j) {
+          const int t = k * nr + j;
           const double sg = m[L.sg + t], S = m[L.zs + t] / sg + sp.reg_primal;
           const double coef = S * m[L.cj + t] - mu / sg;
           const double a0 = m[L.gra + t * 3], a1 = m[L.gra + t * 3 + 1], a2 = m[L.gra + t * 3 + 2];
@@ -634,8 +718,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           if (dzu < 0.0) adual = fmin(adual, -tau * zu_ / dzu);
         }
         for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
-        for (int j = 0; j < nb; ++j) {
-          const int t = k * nb + j;
+        for (int j = 0; j < nr; ++j) {
+          const int t = k * nr + j;
           const double sg = m[L.sg + t], zs = m[L.zs + t];
           const double ds = m[L.cj + t] + m[L.gra + t * 3] * dpk[0] + m[L.gra + t * 3 + 1] * dpk[1] + m[L.gra + t * 3 + 2] * dpk[2];
           m[L.dsg + t] = ds;
@@ -695,8 +779,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mu / (sp.kappa_sigma * dln)), sp.kappa_sigma * mu / dln);
           m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mu / (sp.kappa_sigma * dun)), sp.kappa_sigma * mu / dun);
         }
-        for (int j = 0; j < nb; ++j) {
-          const int t = k * nb + j;
+        for (int j = 0; j < nr; ++j) {
+          const int t = k * nr + j;
           const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t];
           const double S = zs / sg + sp.reg_primal;
           const double dnu = S * ds - mu / sg - m[L.nuc + t];
@@ -717,10 +801,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     double smin = INFINITY;
     for (int t = lane; t < N * nb; t += 64) {
       const int k = t / nb, j = t - k * nb;
-      double A[4][2], b[4], V[4][2]; int cert;
+      double A[4][2], b[4], V[4][2], sep2[2];
       block_polygon(sp, m, L, k, j, A, b, V);
       const double psi = m[L.p + k * kNP + 2];
-      const double sep = block_sep<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, nullptr, &cert);
+      const int c1 = select_rows(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, (int)m[L.sel + t]);
+      rows_for<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, c1, sep2, nullptr);
+      const double sep = fmin(sep2[0], sep2[1]);
+      const int cert = (c1 >> 6) * 16 + ((c1 >> 4) & 3) * 4 + (sep2[0] <= sep2[1] ? ((c1 >> 2) & 3) : (c1 & 3));
       smin = fmin(smin, sep);
       if (duo.l) {
         const int kind = cert >> 4, f = (cert >> 2) & 3;

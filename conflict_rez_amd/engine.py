@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconfrez_hip.so")
 MAX_OBS, MAX_NBR, MAX_N = 8, 7, 64
 
-STATUS_NAMES = {0: "converged", 1: "iteration limit", 2: "line search failed", 3: "non-finite iterate"}
+STATUS_NAMES = {0: "converged", 1: "iteration limit", 2: "line search failed", 3: "non-finite iterate",
+                4: "measured state in collision (infeasible)"}
 
 
 class _CSpec(C.Structure):
@@ -215,11 +216,11 @@ class Engine:
 
     # ---- batched closed loop ------------------------------------------------------------------------
     def loop_init(self, ref_table, k0, noise=None):
-        """ref_table [V,T,3], k0 int32 [S], noise [S,V,5] or None."""
+        """ref_table [V,T,7] (x,y,psi,v,delta,a,w), k0 int32 [S], noise [S,V,5] or None."""
         V = self.spec.n_nbr + 1
         ref_table = np.ascontiguousarray(ref_table, dtype=np.float64)
         T = ref_table.shape[1]
-        ref_table = _f64(ref_table, (V, T, 3))
+        ref_table = _f64(ref_table, (V, T, 7))
         k0 = np.ascontiguousarray(k0, dtype=np.int32)
         S = k0.shape[0]
         if noise is not None:

@@ -49,7 +49,8 @@ def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 
 def mpc_batch_from_table(spec: ProblemSpec, table, k0, noise):
     """Host arrays of one cold MPC step for S scenarios x V vehicles, instance order [s][v]:
     x0 [B,5], ref [B,3,N], nbr [B,V-1,3,N], zu [B,7,N] (the first `step()` of every vehicle:
-    prediction = reference, neighbours' predictions = their references, all advanced by one)."""
+    prediction = the planned trajectory incl. v, delta, a, w as `get_current_ref` seeds it
+    (vehicle_follower.py:397-400), neighbours' predictions = theirs, all advanced by one)."""
     V, T, N = table.shape[0], table.shape[1], spec.N
     S = len(k0)
     B = S * V
@@ -57,14 +58,13 @@ def mpc_batch_from_table(spec: ProblemSpec, table, k0, noise):
     for s in range(S):
         idx = np.minimum(k0[s] + np.arange(N), T - 1)
         adv = np.minimum(np.arange(N) + 1, N - 1)
-        preds = table[:, idx, :3]  # [V,N,3]
+        preds = table[:, idx, :]  # [V,N,7]
         for v in range(V):
             b = s * V + v
-            x0[b, :3] = table[v, k0[s], :3]
-            x0[b] += noise[s, v]
-            ref[b] = preds[v].T
-            zu[b, :3] = preds[v][adv].T
+            x0[b] = table[v, k0[s], :5] + noise[s, v]
+            ref[b] = preds[v][:, :3].T
+            zu[b] = preds[v][adv].T
             others = [u for u in range(V) if u != v]
             for o, u in enumerate(others):
-                nbr[b, o] = preds[u][adv].T
+                nbr[b, o] = preds[u][adv][:, :3].T
     return x0, ref, nbr, zu

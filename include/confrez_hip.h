@@ -10,7 +10,8 @@
  *
  * Return value: 0 on success, <0 on an API error (cfz_last_error() explains).  Solver
  * outcomes are per instance, in `status`:
- *   0 converged | 1 iteration limit | 2 line search failed | 3 non-finite iterate
+ *   0 converged | 1 iteration limit | 2 line search failed | 3 non-finite iterate |
+ *   4 measured state already violates a collision row (NLP infeasible, nothing iterated)
  * The reference turns any non-zero outcome into a Python exception that `step()` catches
  * to apply its shift fallback (vehicle_follower.py:478-524); the Python shim does the same.
  *
@@ -108,10 +109,10 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
 
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
- * ref_table[V][T][3]: each vehicle's planned reference sampled every dt (what get_current_ref
- * :370-404 interpolates); scenario s starts at sample k0[s].
- * cfz_loop_init sets state = ref_table[v][k0] + noise[s][v][5] (x,y,psi,v,delta) and the first
- * prediction = the reference itself with v,delta,a,w = 0 (:399-400).
+ * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt
+ * (what get_current_ref :370-404 interpolates); scenario s starts at sample k0[s].
+ * cfz_loop_init sets state = ref_table[v][k0][0:5] + noise[s][v][5] and the first prediction =
+ * the plan at the horizon times (:397-400).
  * cfz_loop_step does one iteration for all scenarios, entirely on the device:
  *   neighbours' predictions copied first (get_others_pred :636-637, Jacobi), every vehicle's
  *   step(): parameters + shifted warm start (:432-476), solve (:479), read-back or shift

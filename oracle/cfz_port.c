@@ -18,6 +18,7 @@
 
 #define MAXN 64
 #define MAXB 16
+#define MAXR (2 * MAXB) /* constraint rows per stage: two per block */
 #define NP 7
 
 typedef struct {
@@ -35,8 +36,8 @@ typedef struct {
 } cfz_port_spec;
 
 typedef struct {
-  double p[MAXN][NP], sg[MAXN][MAXB];              /* primal: stage vars, slacks */
-  double nuc[MAXN][MAXB], zs[MAXN][MAXB];          /* block multipliers, slack bound multipliers */
+  double p[MAXN][NP], sg[MAXN][MAXR];              /* primal: stage vars, slacks (one per row) */
+  double nuc[MAXN][MAXR], zs[MAXN][MAXR];          /* row multipliers, slack bound multipliers */
   double zl[MAXN][6], zu[MAXN][6];                 /* box multipliers */
   double pi0[5], pi[MAXN][5];                      /* initial-state and dynamics multipliers */
 } iterate;
@@ -117,46 +118,56 @@ static void rk4_sens(const double z[5], const double u[2], double dt, double wb,
 }
 
 /* ---------------------------------------------------------------- separation certificates */
-/* polygon (A,b,V) vs body rectangle at (x,y,psi); returns sep, grad[3], cert = kind*16+face*4+vertex */
-static double block_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
-                        double psi, const double g[4], double grad[3], int *cert) {
+#define HYST 1e-3 /* m: a block keeps its separating face until another one is better by this much */
+
+/* signed distances of the 4 vertices of one polygon to face f of the other (+ gradients wrt x,y,psi).
+ * kind 1 = polygon face / body vertices, kind 2 = body face / polygon vertices. */
+static void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
+                        const double g[4], int kind, int f, double d[4], double gr[4][3]) {
   double c = cos(psi), s = sin(psi);
-  double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
-  double W[4][2], dW[4][2]; /* world body vertices and their psi-derivatives */
-  for (int v = 0; v < 4; ++v) {
-    W[v][0] = x + c * BV[v][0] - s * BV[v][1];
-    W[v][1] = y + s * BV[v][0] + c * BV[v][1];
-    dW[v][0] = -s * BV[v][0] - c * BV[v][1];
-    dW[v][1] = c * BV[v][0] - s * BV[v][1];
-  }
-  double best = 0.0; int have = 0;
-  for (int i = 0; i < 4; ++i) {
-    int vm = 0; double dm = 0.0;
+  if (kind == 1) {
+    double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
     for (int v = 0; v < 4; ++v) {
-      double d = W[v][0] * A[i][0] + W[v][1] * A[i][1] - b[i];
-      if (v == 0 || d < dm) { dm = d; vm = v; }
+      double wx = x + c * BV[v][0] - s * BV[v][1], wy = y + s * BV[v][0] + c * BV[v][1];
+      double dwx = -s * BV[v][0] - c * BV[v][1], dwy = c * BV[v][0] - s * BV[v][1];
+      d[v] = wx * A[f][0] + wy * A[f][1] - b[f];
+      if (gr) { gr[v][0] = A[f][0]; gr[v][1] = A[f][1]; gr[v][2] = A[f][0] * dwx + A[f][1] * dwy; }
     }
-    if (!have || dm > best) {
-      have = 1; best = dm;
-      grad[0] = A[i][0]; grad[1] = A[i][1]; grad[2] = A[i][0] * dW[vm][0] + A[i][1] * dW[vm][1];
-      *cert = 16 + 4 * i + vm;
-    }
-  }
-  for (int k = 0; k < 4; ++k) {
-    double nx = c * GB[k][0] - s * GB[k][1], ny = s * GB[k][0] + c * GB[k][1];
-    double dnx = -s * GB[k][0] - c * GB[k][1], dny = c * GB[k][0] - s * GB[k][1];
-    int vm = 0; double dm = 0.0;
+  } else {
+    double nx = c * GB[f][0] - s * GB[f][1], ny = s * GB[f][0] + c * GB[f][1];
+    double dnx = -s * GB[f][0] - c * GB[f][1], dny = c * GB[f][0] - s * GB[f][1];
     for (int v = 0; v < 4; ++v) {
-      double d = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[k];
-      if (v == 0 || d < dm) { dm = d; vm = v; }
-    }
-    if (dm > best) {
-      best = dm;
-      grad[0] = -nx; grad[1] = -ny; grad[2] = dnx * (V[vm][0] - x) + dny * (V[vm][1] - y);
-      *cert = 32 + 4 * k + vm;
+      d[v] = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[f];
+      if (gr) { gr[v][0] = -nx; gr[v][1] = -ny; gr[v][2] = dnx * (V[v][0] - x) + dny * (V[v][1] - y); }
     }
   }
-  return best;
+}
+
+/* working set of one block: sel = kind*64 + face*16 + vA*4 + vB (vA < vB); see oracle/mpc_nlp.py select_rows */
+static int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
+                       const double g[4], int prev) {
+  double best = 0.0, prev_val = 0.0, d[4];
+  int have = 0, bk = 0, bf = 0, have_prev = 0;
+  int pk = prev >> 6, pf = (prev >> 4) & 3;
+  for (int kind = 1; kind <= 2; ++kind)
+    for (int f = 0; f < 4; ++f) {
+      vertex_dist(A, b, V, x, y, psi, g, kind, f, d, 0);
+      double val = fmin(fmin(d[0], d[1]), fmin(d[2], d[3]));
+      if (prev && kind == pk && f == pf) { prev_val = val; have_prev = 1; }
+      if (!have || val > best) { have = 1; best = val; bk = kind; bf = f; }
+    }
+  if (have_prev && prev_val >= best - HYST) { bk = pk; bf = pf; }
+  vertex_dist(A, b, V, x, y, psi, g, bk, bf, d, 0);
+  int v0 = 0;
+  for (int v = 1; v < 4; ++v) if (d[v] < d[v0]) v0 = v;
+  int n1 = (v0 + 1) & 3, n2 = (v0 + 3) & 3, v1;
+  if (d[n1] < d[n2]) v1 = n1; else if (d[n2] < d[n1]) v1 = n2; else v1 = n1 < n2 ? n1 : n2;
+  if (prev && bk == pk && bf == pf) {
+    int oa = (prev >> 2) & 3, ob = prev & 3;
+    if (fmin(d[oa], d[ob]) <= d[v0] + 1e-12 && fmax(d[oa], d[ob]) <= d[v1] + HYST) { v0 = oa; v1 = ob; }
+  }
+  int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
+  return bk * 64 + bf * 16 + va * 4 + vb;
 }
 
 static void nbr_polygon(const double *nbr, int N, int o, int k, const double g[4], double A[4][2], double b[4],
@@ -173,21 +184,35 @@ static void nbr_polygon(const double *nbr, int N, int o, int k, const double g[4
   }
 }
 
-static void eval_blocks(const cfz_port_spec *sp, const double *nbr, const double p[][NP], double sep[][MAXB],
-                        double grad[][MAXB][3], int cert[][MAXB]) {
+static void block_polygon(const cfz_port_spec *sp, const double *nbr, int k, int j, double A[4][2], double b[4],
+                          double V[4][2]) {
+  if (j < sp->n_obs) { memcpy(A, sp->A_obs[j], 64); memcpy(b, sp->b_obs[j], 32); memcpy(V, sp->V_obs[j], 64); }
+  else nbr_polygon(nbr, sp->N, j - sp->n_obs, k, sp->g, A, b, V);
+}
+
+/* refresh the working set at poses p (x,y,psi of every stage); `sel` in/out */
+static void select_all(const cfz_port_spec *sp, const double *nbr, const double p[][NP], int sel[][MAXB]) {
   int nb = sp->n_obs + sp->n_nbr;
   for (int k = 0; k < sp->N; ++k)
     for (int j = 0; j < nb; ++j) {
-      double gr[3]; int ce;
-      if (j < sp->n_obs) {
-        sep[k][j] = block_sep(sp->A_obs[j], sp->b_obs[j], sp->V_obs[j], p[k][0], p[k][1], p[k][2], sp->g, gr, &ce);
-      } else {
-        double A[4][2], b[4], V[4][2];
-        nbr_polygon(nbr, sp->N, j - sp->n_obs, k, sp->g, A, b, V);
-        sep[k][j] = block_sep(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, gr, &ce);
-      }
-      if (grad) { grad[k][j][0] = gr[0]; grad[k][j][1] = gr[1]; grad[k][j][2] = gr[2]; }
-      if (cert) cert[k][j] = ce;
+      double A[4][2], b[4], V[4][2];
+      block_polygon(sp, nbr, k, j, A, b, V);
+      sel[k][j] = select_rows(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, sel[k][j]);
+    }
+}
+
+/* rows of the current working set: sep[k][2j+r], grad[k][2j+r][3] */
+static void eval_rows(const cfz_port_spec *sp, const double *nbr, const double p[][NP], int sel[][MAXB],
+                      double sep[][MAXR], double grad[][MAXR][3]) {
+  int nb = sp->n_obs + sp->n_nbr;
+  for (int k = 0; k < sp->N; ++k)
+    for (int j = 0; j < nb; ++j) {
+      double A[4][2], b[4], V[4][2], d[4], gr[4][3];
+      block_polygon(sp, nbr, k, j, A, b, V);
+      int c = sel[k][j], kind = c >> 6, f = (c >> 4) & 3, va = (c >> 2) & 3, vb = c & 3;
+      vertex_dist(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, kind, f, d, grad ? gr : 0);
+      sep[k][2 * j] = d[va]; sep[k][2 * j + 1] = d[vb];
+      if (grad) for (int q = 0; q < 3; ++q) { grad[k][2 * j][q] = gr[va][q]; grad[k][2 * j + 1][q] = gr[vb][q]; }
     }
 }
 
@@ -211,10 +236,11 @@ static void stage_grad(const cfz_port_spec *sp, const double *ref, int k, const 
 
 /* theta = |c|_1 and barrier objective at a trial point (p, sg); returns 0 if outside bounds */
 static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr,
-                       const double p[][NP], const double sg[][MAXB], double mu, double *theta, double *phi) {
-  int N = sp->N, nb = sp->n_obs + sp->n_nbr;
+                       const double p[][NP], const double sg[][MAXR], int sel[][MAXB], double mu, double *theta,
+                       double *phi) {
+  int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr); /* rows */
   double th = 0.0, ph = 0.0, lg = 0.0;
-  static double sep[MAXN][MAXB];
+  static double sep[MAXN][MAXR];
   for (int k = 0; k < N; ++k) {
     for (int q = 0; q < 6; ++q) {
       double dl = p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - p[k][BCOL[q]];
@@ -233,7 +259,7 @@ static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *
     rk4(p[k], p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, F);
     for (int i = 0; i < 5; ++i) th += fabs(F[i] - p[k + 1][i]);
   }
-  eval_blocks(sp, nbr, p, sep, 0, 0);
+  eval_rows(sp, nbr, p, sel, sep, 0);
   for (int k = 0; k < N; ++k)
     for (int j = 0; j < nb; ++j) th += fabs(sep[k][j] - sp->dmin - sg[k][j]);
   *theta = th; *phi = ph - mu * lg;
@@ -253,29 +279,54 @@ static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *
 
 /* ---------------------------------------------------------------- the solver */
 /* p_io: [N][7] warm start in (x,y,psi,v,delta,a,w per stage), solution out.
- * stats: [0]=iters [1]=status(0 ok,1 maxiter,2 linesearch,3 nan) ; fstats: [0]=f [1]=err [2]=mu
+ * stats: [0]=iters [1]=status(0 ok,1 maxiter,2 linesearch,3 nan,4 initial state in collision) ; fstats: [0]=f [1]=err [2]=mu
  * trace (optional): per iteration 4 doubles (mu, err0, cviol, dual_inf) then p[N][7] -> stride 4+7N */
 int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
                    double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap) {
-  const int N = sp->N, nb = sp->n_obs + sp->n_nbr;
-  if (N > MAXN || N < 2 || nb > MAXB) return -1;
+  const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
+  if (N > MAXN || N < 2 || nblk > MAXB) return -1;
   static iterate it, dt_; /* step stored in an `iterate` too */
-  static double sep[MAXN][MAXB], gra[MAXN][MAXB][3], cj[MAXN][MAXB];
+  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cj[MAXN][MAXR];
+  static int sel[MAXN][MAXB];
   static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
   static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
   static double Kk[MAXN][2][5], kf[MAXN][2];
-  static double pt[MAXN][NP], sgt[MAXN][MAXB];
+  static double pt[MAXN][NP], sgt[MAXN][MAXR];
   double filt[64][2]; int nfilt = 0; double filt_mu = -1.0;
   double theta_min = -1.0, theta_max = -1.0;
   const double mu_floor = fmin(sp->tol, sp->compl_inf_tol) / (sp->kappa_eps + 1.0);
   double mu = sp->mu_init;
   int status = 1, iter = 0;
   double err0 = INFINITY;
-  const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb);
+  const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb); /* nb counts rows here */
 
   /* ---- initial point: slacks from the un-pushed warm start, then push everything inside */
   for (int k = 0; k < N; ++k) for (int i = 0; i < NP; ++i) it.p[k][i] = p_io[k * NP + i];
-  eval_blocks(sp, nbr, it.p, sep, 0, 0);
+  memset(sel, 0, sizeof sel);
+  { /* the pose of stage 0 is fixed by z0 = x0: a collision row violated there cannot be repaired */
+    double p0[1][NP]; int s0[1][MAXB]; double r0[1][MAXR];
+    for (int i = 0; i < NP; ++i) p0[0][i] = (i < 5) ? x0[i] : 0.0;
+    memset(s0, 0, sizeof s0);
+    cfz_port_spec one = *sp; one.N = 1;
+    /* neighbour arrays are indexed with stride N, so evaluate stage 0 through the full-size helpers */
+    for (int j = 0; j < nblk; ++j) {
+      double A[4][2], b[4], V[4][2], d[4];
+      block_polygon(sp, nbr, 0, j, A, b, V);
+      s0[0][j] = select_rows(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, 0);
+      int c = s0[0][j];
+      vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0);
+      r0[0][j] = fmin(d[(c >> 2) & 3], d[c & 3]);
+      if (r0[0][j] < sp->dmin - 2.0 * sp->constr_viol_tol) {
+        stats[0] = 0; stats[1] = 4; fstats[0] = 0.0; fstats[1] = INFINITY; fstats[2] = sp->mu_init;
+        if (sep_out) for (int q = 0; q < N * nblk; ++q) sep_out[q] = 0.0;
+        if (cert_out) for (int q = 0; q < N * nblk; ++q) cert_out[q] = 0;
+        return 0;
+      }
+    }
+    (void)one;
+  }
+  select_all(sp, nbr, it.p, sel);
+  eval_rows(sp, nbr, it.p, sel, sep, 0);
   for (int k = 0; k < N; ++k) {
     for (int q = 0; q < 6; ++q) {
       double lo = sp->bounds[2 * q], hi = sp->bounds[2 * q + 1];
@@ -294,9 +345,33 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
   for (int i = 0; i < 5; ++i) it.pi0[i] = 0.0;
 
   for (iter = 0; iter <= sp->max_iter; ++iter) {
+    /* ---- working set: rows keep slack and multipliers while their (face, vertex) identity lasts */
+    if (iter > 0) {
+      static int old[MAXN][MAXB];
+      memcpy(old, sel, sizeof sel);
+      select_all(sp, nbr, it.p, sel);
+      eval_rows(sp, nbr, it.p, sel, sep, 0);
+      for (int k = 0; k < N; ++k)
+        for (int j = 0; j < nblk; ++j) {
+          int o = old[k][j], n_ = sel[k][j];
+          if (o == n_) continue;
+          int same_face = (o >> 4) == (n_ >> 4);
+          double vs[2][3] = {{it.sg[k][2 * j], it.zs[k][2 * j], it.nuc[k][2 * j]},
+                             {it.sg[k][2 * j + 1], it.zs[k][2 * j + 1], it.nuc[k][2 * j + 1]}};
+          int ov[2] = {(o >> 2) & 3, o & 3}, nv[2] = {(n_ >> 2) & 3, n_ & 3};
+          for (int r = 0; r < 2; ++r) {
+            int src = -1;
+            if (same_face) { if (nv[r] == ov[0]) src = 0; else if (nv[r] == ov[1]) src = 1; }
+            if (src >= 0) { it.sg[k][2 * j + r] = vs[src][0]; it.zs[k][2 * j + r] = vs[src][1]; it.nuc[k][2 * j + r] = vs[src][2]; }
+            else {
+              double sg = fmax(sep[k][2 * j + r] - sp->dmin, sp->bound_push);
+              it.sg[k][2 * j + r] = sg; it.zs[k][2 * j + r] = mu / sg; it.nuc[k][2 * j + r] = -mu / sg;
+            }
+          }
+        }
+    }
     /* ---- evaluate ----------------------------------------------------------------- */
-    int cert[MAXN][MAXB];
-    eval_blocks(sp, nbr, it.p, sep, gra, cert);
+    eval_rows(sp, nbr, it.p, sel, sep, gra);
     double cviol = 0.0, theta = 0.0;
     for (int i = 0; i < 5; ++i) { double r = it.p[0][i] - x0[i]; cviol = fmax(cviol, fabs(r)); theta += fabs(r); }
     for (int k = 0; k + 1 < N; ++k) {
@@ -478,7 +553,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
     double phi0;
     {
       double th_dummy;
-      if (!merit_terms(sp, x0, ref, nbr, it.p, it.sg, mu, &th_dummy, &phi0)) { status = 3; break; }
+      if (!merit_terms(sp, x0, ref, nbr, it.p, it.sg, sel, mu, &th_dummy, &phi0)) { status = 3; break; }
     }
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; int accepted = 0, f_type = 0;
@@ -488,7 +563,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
         for (int j = 0; j < nb; ++j) sgt[k][j] = it.sg[k][j] + alpha * dt_.sg[k][j];
       }
       double th_t, ph_t;
-      int ok = merit_terms(sp, x0, ref, nbr, pt, sgt, mu, &th_t, &ph_t) && th_t <= theta_max;
+      int ok = merit_terms(sp, x0, ref, nbr, pt, sgt, sel, mu, &th_t, &ph_t) && th_t <= theta_max;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = 0; break; }
       f_type = 0;
       if (ok) {
@@ -525,15 +600,16 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
     }
   }
   /* ---- output ---------------------------------------------------------------------------------- */
-  int cert[MAXN][MAXB];
-  eval_blocks(sp, nbr, it.p, sep, 0, cert);
+  select_all(sp, nbr, it.p, sel);
+  eval_rows(sp, nbr, it.p, sel, sep, 0);
   double fval = 0.0;
   for (int k = 0; k < N; ++k) {
     fval += stage_cost(sp, ref, k, it.p[k]);
     for (int i = 0; i < NP; ++i) p_io[k * NP + i] = it.p[k][i];
-    for (int j = 0; j < nb; ++j) {
-      if (sep_out) sep_out[k * nb + j] = sep[k][j];
-      if (cert_out) cert_out[k * nb + j] = cert[k][j];
+    for (int j = 0; j < nblk; ++j) {
+      int c = sel[k][j], near = sep[k][2 * j] <= sep[k][2 * j + 1] ? (c >> 2) & 3 : c & 3;
+      if (sep_out) sep_out[k * nblk + j] = fmin(sep[k][2 * j], sep[k][2 * j + 1]);
+      if (cert_out) cert_out[k * nblk + j] = (c >> 6) * 16 + ((c >> 4) & 3) * 4 + near;
     }
   }
   stats[0] = iter; stats[1] = status;

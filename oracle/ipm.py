@@ -114,6 +114,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
     it = 0
     err0 = np.inf
     for it in range(opt.max_iter + 1):
+        if it > 0 and hasattr(nlp, "new_iterate"):  # working-set NLPs refresh their rows here
+            x, zl, nu = nlp.new_iterate(x, zl, nu, mu, opt.bound_push)
         g = nlp.grad(x)
         c, J = nlp._cons_jac(x, True)
         dl, du = dist(x)

@@ -23,10 +23,13 @@ Two views of the same NLP are provided:
   reference NLP with the OBCA duals eliminated by partial maximisation (DESIGN.md
   "Certificate elimination"): for a fixed pose the duals of one (stage, obstacle) or
   (stage, neighbour) block only have to *exist*, and the best they can certify is the
-  separation of the two polygons, so each block collapses to one inequality
-        sep_j(x_k, y_k, psi_k) - dmin - sigma = 0,   sigma >= 0,
-  where sep_j is evaluated in closed form over the face normals of both polygons
-  (`block_separation`), and the duals l, m, lambda_ij, lambda_ji, s that certify it are
+  separation of the two polygons along a face normal, i.e. "every vertex of one polygon is
+  at least dmin outside the best face of the other".  Each block therefore collapses to
+  two smooth rows (the two vertices nearest to that face; the (face, vertex, vertex) working
+  set is chosen by `select_rows` at every accepted iterate and held fixed inside the line
+  search, so the merit function of one iteration is smooth)
+        sep_{j,r}(x_k, y_k, psi_k) - dmin - sigma_{j,r} = 0,   sigma_{j,r} >= 0,  r = 0,1
+  and the duals l, m, lambda_ij, lambda_ji, s that certify it are
   reconstructed on output (`certificate_duals`).  They satisfy every dual-variable
   constraint of the reference exactly (:289-290, :350-352) and the separation rows
   (:287, :348) whenever sep_j >= dmin.  Face normals only: near a corner-to-corner
@@ -166,31 +169,76 @@ def polytope_vertices(A, b):
     return np.array(V), np.array(adj)
 
 
-def block_separation(A, b, PV, t, psi, g, BV):
-    """Separation of polygon (A,b; vertices PV) from the body rectangle at pose (t,psi).
+HYST = 1e-3  # m: a block keeps its separating face until another one is better by this much
 
-    sep = max over the 8 face normals of (min over the other polygon's vertices of the signed
-    distance to that face).  Returns (sep, grad wrt (x,y,psi), (kind, face, vertex)) with
-    kind 1 = polygon face / body vertex, kind 2 = body face / polygon vertex.  Ties keep the
-    first candidate in the order polygon faces 0..3, body faces 0..3 (strict `>`).
-    """
+
+def vertex_distances(A, b, PV, t, psi, g, BV, kind, f):
+    """Signed distances of the 4 vertices of one polygon to face f of the other, and their
+    gradients wrt (x,y,psi).  kind 1 = polygon face / body vertices, 2 = body face / polygon vertices."""
     c, s = np.cos(psi), np.sin(psi)
     R = np.array([[c, -s], [s, c]])
     dR = np.array([[-s, -c], [c, -s]])
-    W = t + BV @ R.T
-    best = None
-    for i in range(4):
-        d = W @ A[i] - b[i]
-        v = int(np.argmin(d))
-        if best is None or d[v] > best[0]:
-            best = (d[v], np.array([A[i, 0], A[i, 1], A[i] @ (dR @ BV[v])]), (1, i, v))
-    for k in range(4):
-        nk = R @ G_BODY[k]
-        d = (PV - t) @ nk - g[k]
-        v = int(np.argmin(d))
-        if d[v] > best[0]:
-            best = (d[v], np.array([-nk[0], -nk[1], (dR @ G_BODY[k]) @ (PV[v] - t)]), (2, k, v))
-    return best
+    d = np.zeros(4)
+    gr = np.zeros((4, 3))
+    if kind == 1:
+        W = t + BV @ R.T
+        d = W @ A[f] - b[f]
+        for v in range(4):
+            gr[v] = [A[f, 0], A[f, 1], A[f] @ (dR @ BV[v])]
+    else:
+        nk = R @ G_BODY[f]
+        d = (PV - t) @ nk - g[f]
+        for v in range(4):
+            gr[v] = [-nk[0], -nk[1], (dR @ G_BODY[f]) @ (PV[v] - t)]
+    return d, gr
+
+
+def select_rows(A, b, PV, t, psi, g, BV, prev=0):
+    """Working set of one block: the separating face and the two vertices whose rows are imposed.
+
+    The separating direction is the face normal (8 candidates in the order polygon faces 0..3,
+    body faces 0..3) with the largest  min over the other polygon's vertices of the signed
+    vertex-face distance; the previous face is kept unless another beats it by more than HYST.
+    `min over vertices >= dmin` is imposed as one smooth row per vertex; only the nearest vertex
+    and the nearer of its two neighbours are kept (for a convex polygon the minimum sits on one
+    vertex or, when an edge is parallel to the face, on two adjacent ones).  Returns the code
+    sel = kind*64 + face*16 + vA*4 + vB with vA < vB (vertex indices: identity of the two rows).
+    """
+    best, bk, bf = None, 0, 0
+    pk, pf = (prev >> 6), (prev >> 4) & 3
+    prev_val = None
+    for kind in (1, 2):
+        for f in range(4):
+            d, _ = vertex_distances(A, b, PV, t, psi, g, BV, kind, f)
+            val = d.min()
+            if prev and kind == pk and f == pf:
+                prev_val = val
+            if best is None or val > best:
+                best, bk, bf = val, kind, f
+    if prev_val is not None and prev_val >= best - HYST:
+        bk, bf = pk, pf
+    d, _ = vertex_distances(A, b, PV, t, psi, g, BV, bk, bf)
+    v0 = int(np.argmin(d))
+    n1, n2 = (v0 + 1) % 4, (v0 + 3) % 4
+    if d[n1] < d[n2]:
+        v1 = n1
+    elif d[n2] < d[n1]:
+        v1 = n2
+    else:
+        v1 = min(n1, n2)
+    if prev and bk == pk and bf == pf:  # keep the old pair while it still holds the minimum
+        oa, ob = (prev >> 2) & 3, prev & 3
+        if min(d[oa], d[ob]) <= d[v0] + 1e-12 and max(d[oa], d[ob]) <= d[v1] + HYST:
+            v0, v1 = oa, ob
+    va, vb = min(v0, v1), max(v0, v1)
+    return bk * 64 + bf * 16 + va * 4 + vb
+
+
+def rows_for(A, b, PV, t, psi, g, BV, sel):
+    """Values and gradients of the two rows of working set `sel`: (sep[2], grad[2,3])."""
+    kind, f, va, vb = sel >> 6, (sel >> 4) & 3, (sel >> 2) & 3, sel & 3
+    d, gr = vertex_distances(A, b, PV, t, psi, g, BV, kind, f)
+    return d[[va, vb]], gr[[va, vb]]
 
 
 def _posneg(m):
@@ -236,9 +284,9 @@ def certificate_duals(A, adj, psi, cert, psi_other=None):
 class MpcNlp:
     """min f(X) s.t. c(X)=0, XL<=X<=XU for one vehicle's MPC step.
 
-    X layout, stage-major, per stage k (stride n_stage = 7 + n_obs + n_nbr):
-        [x y psi v delta a w | sigma_0 .. sigma_{n_blk-1}]      (obstacles first, then neighbours)
-    c layout: [z0 - x0 (5) | F(z_k,u_k) - z_{k+1}, k<N-1 (5 each) | per stage: sep_j - dmin - sigma_j]
+    X layout, stage-major, per stage k (stride 7 + 2 n_blk):
+        [x y psi v delta a w | sigma_{j,r}, row index 2 j + r]   (obstacles first, then neighbours)
+    c layout: [z0 - x0 (5) | F(z_k,u_k) - z_{k+1}, k<N-1 (5 each) | per stage: sep_{j,r} - dmin - sigma_{j,r}]
     """
 
     def __init__(self, spec: MpcSpec, x0, ref, nbr=None):
@@ -250,9 +298,10 @@ class MpcNlp:
         )
         N = spec.N
         self.nb = spec.n_obs + spec.n_nbr
-        self.ns = NP + self.nb
+        self.nr = 2 * self.nb  # constraint rows per stage
+        self.ns = NP + self.nr
         self.n = N * self.ns
-        self.m = 5 + 5 * (N - 1) + self.nb * N
+        self.m = 5 + 5 * (N - 1) + self.nr * N
         self.c_blk0 = 5 + 5 * (N - 1)
         xl = np.full((N, self.ns), -np.inf)
         xu = np.full((N, self.ns), np.inf)
@@ -266,6 +315,7 @@ class MpcNlp:
         self.PV = [p[0] for p in pv]
         self.adj = [p[1] for p in pv]
         self.BV = body_vertices(spec.g)
+        self.sel = np.zeros((N, self.nb), dtype=np.int64)  # working set, 0 = none yet
 
     # ---- blocks --------------------------------------------------------------------
     def neighbour_polygon(self, o, k):
@@ -275,22 +325,60 @@ class MpcNlp:
         A = G_BODY @ Ro.T
         return A, A @ to + self.spec.g, to + self.BV @ Ro.T
 
+    def polygon(self, k, j):
+        if j < self.spec.n_obs:
+            return self.spec.A_obs[j], self.spec.b_obs[j], self.PV[j]
+        return self.neighbour_polygon(j - self.spec.n_obs, k)
+
+    def select(self, P):
+        """Recomputes the working set at poses P [N,>=3]; returns the previous one."""
+        old = self.sel.copy()
+        for k in range(self.spec.N):
+            for j in range(self.nb):
+                A, b, PV = self.polygon(k, j)
+                self.sel[k, j] = select_rows(A, b, PV, P[k, 0:2], P[k, 2], self.spec.g, self.BV, int(old[k, j]))
+        return old
+
     def blocks(self, P):
-        """sep [N,nb], grad wrt (x,y,psi) [N,nb,3], certificates."""
+        """Rows of the current working set: sep [N,2 nb], grad wrt (x,y,psi) [N,2 nb,3]."""
         sp_ = self.spec
-        sep = np.zeros((sp_.N, self.nb))
-        gr = np.zeros((sp_.N, self.nb, 3))
-        cert = {}
+        sep = np.zeros((sp_.N, self.nr))
+        gr = np.zeros((sp_.N, self.nr, 3))
         for k in range(sp_.N):
-            t, psi = P[k, 0:2], P[k, 2]
-            for j in range(sp_.n_obs):
-                r = block_separation(sp_.A_obs[j], sp_.b_obs[j], self.PV[j], t, psi, sp_.g, self.BV)
-                sep[k, j], gr[k, j], cert[(k, j)] = r
-            for o in range(sp_.n_nbr):
-                A, b, PV = self.neighbour_polygon(o, k)
-                r = block_separation(A, b, PV, t, psi, sp_.g, self.BV)
-                sep[k, sp_.n_obs + o], gr[k, sp_.n_obs + o], cert[(k, sp_.n_obs + o)] = r
-        return sep, gr, cert
+            for j in range(self.nb):
+                A, b, PV = self.polygon(k, j)
+                sep[k, 2 * j : 2 * j + 2], gr[k, 2 * j : 2 * j + 2] = rows_for(
+                    A, b, PV, P[k, 0:2], P[k, 2], sp_.g, self.BV, int(self.sel[k, j]))
+        return sep, gr
+
+    def new_iterate(self, x, zl, nu, mu, bound_push):
+        """Hook of oracle/ipm.py, called with every accepted iterate: refresh the working set.
+        A row that keeps its (face, vertex) identity keeps slack and multipliers; a new row starts
+        at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z."""
+        N = self.spec.N
+        Xs = x.reshape(N, self.ns)
+        old = self.select(Xs)
+        if np.array_equal(old, self.sel):
+            return x, zl, nu
+        sep, _ = self.blocks(Xs)
+        Z = zl.reshape(N, self.ns)
+        NU = nu[self.c_blk0 :].reshape(N, self.nr)
+        for k, j in zip(*np.nonzero(old != self.sel)):
+            o, n_ = int(old[k, j]), int(self.sel[k, j])
+            same_face = (o >> 4) == (n_ >> 4)
+            keep = {}
+            if same_face:
+                keep = {(o >> 2) & 3: 0, o & 3: 1}
+            vals = [(Xs[k, NP + 2 * j + r], Z[k, NP + 2 * j + r], NU[k, 2 * j + r]) for r in range(2)]
+            for r, v in enumerate(((n_ >> 2) & 3, n_ & 3)):
+                if v in keep:
+                    sg, z, nn = vals[keep[v]]
+                else:
+                    sg = max(sep[k, 2 * j + r] - self.spec.dmin, bound_push)
+                    z = mu / sg
+                    nn = -z
+                Xs[k, NP + 2 * j + r], Z[k, NP + 2 * j + r], NU[k, 2 * j + r] = sg, z, nn
+        return x, zl, nu
 
     # ---- packing between reference layout and X ------------------------------------
     def pack(self, sol):
@@ -301,6 +389,8 @@ class MpcNlp:
         X = np.zeros((N, self.ns))
         for i, key in enumerate(("x", "y", "psi", "v", "delta", "a", "w")):
             X[:, i] = sol[key]
+        self.sel[:] = 0
+        self.select(X)
         X[:, NP:] = self.blocks(X)[0] - self.spec.dmin
         return X.ravel()
 
@@ -313,8 +403,15 @@ class MpcNlp:
         sol["lam_ij"] = np.zeros((sp_.n_nbr, N, 4))
         sol["lam_ji"] = np.zeros((sp_.n_nbr, N, 4))
         sol["s"] = np.zeros((sp_.n_nbr, N, 2))
-        sep, _, cert = self.blocks(Xs)
-        sol["sep"] = sep
+        self.select(Xs)
+        sep = self.blocks(Xs)[0]
+        sol["sep"] = np.minimum(sep[:, 0::2], sep[:, 1::2])  # separation of every block
+        cert = {}
+        for k in range(N):
+            for j in range(self.nb):
+                c_ = int(self.sel[k, j])
+                va, vb = (c_ >> 2) & 3, c_ & 3
+                cert[(k, j)] = (c_ >> 6, (c_ >> 4) & 3, va if sep[k, 2 * j] <= sep[k, 2 * j + 1] else vb)
         for k in range(N):
             psi = Xs[k, 2]
             R = rot(psi)
@@ -415,10 +512,10 @@ class MpcNlp:
                     for j in range(2):
                         add(r, base[:-1] + 5 + j, Fu[:, i, j])
                     add(r, base[1:] + i, -1.0)
-        sep, gr, _ = self.blocks(P)
+        sep, gr = self.blocks(P)
         kk = np.arange(N)
-        for j in range(self.nb):
-            r = self.c_blk0 + self.nb * kk + j
+        for j in range(self.nr):
+            r = self.c_blk0 + self.nr * kk + j
             cvec[r] = sep[:, j] - sp_.dmin - P[:, NP + j]
             for q in range(3):
                 add(r, base + q, gr[:, j, q])
@@ -429,3 +526,37 @@ class MpcNlp:
                 (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.m, self.n)
             )
         return cvec, J
+
+
+STATUS_INFEASIBLE_X0 = 4
+
+
+def initial_state_in_collision(nlp: "MpcNlp", tol):
+    """The pose of stage 0 is pinned to the measured state (vehicle_follower.py:194-196); if a
+    collision row is violated there by more than 2*tol the NLP has no feasible point (IPOPT
+    would end in restoration failure and `step()` in its fallback, :501-524)."""
+    sp_ = nlp.spec
+    for j in range(nlp.nb):
+        A, b, PV = nlp.polygon(0, j)
+        sel = select_rows(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, 0)
+        sep, _ = rows_for(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, sel)
+        if sep.min() < sp_.dmin - 2.0 * tol:
+            return True
+    return False
+
+
+def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None):
+    """One MPC-step solve by the full-KKT oracle.  zu [7,N] warm start (rows x,y,psi,v,delta,a,w).
+    Returns dict(zu [7,N], status, iters, f, sep [N,n_blk], sol (reference-layout dict))."""
+    from . import ipm
+
+    opt = opt or ipm.IpmOptions()
+    nlp = MpcNlp(spec, x0, ref, nbr)
+    zu = np.asarray(zu, float)
+    if initial_state_in_collision(nlp, opt.constr_viol_tol):
+        return dict(zu=zu.copy(), status=STATUS_INFEASIBLE_X0, iters=0, f=0.0, sep=None, sol=None)
+    warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
+    res = ipm.solve(nlp, nlp.pack(warm), opt, trace=trace)
+    sol = nlp.unpack(res["X"])
+    out = np.stack([sol[k] for k in ("x", "y", "psi", "v", "delta", "a", "w")])
+    return dict(zu=out, status=res["status"], iters=res["iters"], f=res["f"], sep=sol["sep"], sol=sol)

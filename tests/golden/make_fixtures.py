@@ -26,7 +26,7 @@ from conflict_rez_amd.control.compute_sets import (  # noqa: E402
     compute_obstacles, compute_sets, interp_along_sets)
 from conflict_rez_amd.vehicle_types import VehicleBody  # noqa: E402
 from oracle import ipm  # noqa: E402
-from oracle.mpc_nlp import MpcNlp, MpcSpec  # noqa: E402
+from oracle.mpc_nlp import MpcSpec, solve_mpc  # noqa: E402
 from oracle.plan_nlp import StateWsNlp  # noqa: E402
 
 
@@ -93,24 +93,24 @@ def mpc_golden(table):
     N, V, T = spec.N, table.shape[0], table.shape[1]
     rng = np.random.default_rng(7)
     X0, REF, NBR, ZU, SOL, META = [], [], [], [], [], []
-    for case in range(12):
+    for case in range(16):
         v = case % V
         k0 = int(rng.integers(0, T - 40))
         idx = np.minimum(k0 + np.arange(N), T - 1)
+        adv = np.minimum(idx + 1, T - 1)
         ref = table[v, idx, :3].T.copy()
-        x0 = np.array([*table[v, k0, :3], table[v, k0, 3], table[v, k0, 4]]) + rng.normal(0, [0.05, 0.05, 0.02, 0.05, 0.0])
+        x0 = table[v, k0, :5] + rng.normal(0, [0.05, 0.05, 0.02, 0.05, 0.0])
         others = [u for u in range(V) if u != v]
-        nbr = np.stack([table[u, np.minimum(idx + 1, T - 1), :3].T for u in others])
-        zu = np.concatenate([ref, np.zeros((4, N))], 0)
-        nlp = MpcNlp(spec, x0, ref, nbr)
-        warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
-        res = ipm.solve(nlp, nlp.pack(warm))
-        sol = nlp.unpack(res["X"])
+        nbr = np.stack([table[u, adv, :3].T for u in others])
+        zu = table[v, adv, :].T.copy()
+        if case >= 12:  # cold guess: poses only, as after a fallback
+            zu[3:] = 0.0
+        res = solve_mpc(spec, x0, ref, nbr, zu)
         X0.append(x0), REF.append(ref), NBR.append(nbr), ZU.append(zu)
-        SOL.append(np.stack([sol[k] for k in ("x", "y", "psi", "v", "delta", "a", "w")]))
-        META.append([res["status"], res["iters"], res["f"], sol["sep"].min()])
+        SOL.append(res["zu"])
+        META.append([res["status"], res["iters"], res["f"], res["sep"].min() if res["sep"] is not None else np.nan])
         print("case", case, "vehicle", v, "k0", k0, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"],
-              "min sep %.4f" % sol["sep"].min())
+              "min sep", META[-1][3])
     np.savez_compressed(os.path.join(HERE, "mpc_golden.npz"), x0=np.array(X0), ref=np.array(REF), nbr=np.array(NBR),
                         zu=np.array(ZU), sol=np.array(SOL), meta=np.array(META), A_obs=spec.A_obs, b_obs=spec.b_obs)
 

@@ -33,6 +33,7 @@ def test_golden_vectors(eng, golden):
     assert np.abs(out["zu"][ok] - golden["sol"][ok]).max() < TOL
     assert np.allclose(out["cost"][ok], meta[ok, 2], rtol=1e-9, atol=1e-9)
     assert np.allclose(out["min_sep"][ok], meta[ok, 3], atol=1e-7)
+    assert (out["status"] == 4).sum() == (meta[:, 0] == 4).sum() >= 1  # the infeasible-x0 fixture is detected
 
 
 def test_matches_c_port_on_seeded_batch(eng, ospec):
@@ -85,6 +86,7 @@ def test_full_batch_properties(eng):
     out = eng.solve(x0, ref, nbr, zu, want_duals=False)
     ok = out["status"] == 0
     assert ok.mean() > 0.8, ok.mean()
+    assert set(np.unique(out["status"])) <= {0, 1, 2, 4}
     z = out["zu"][ok]
     assert np.abs(z[:, :5, 0] - x0[ok]).max() < 1e-2  # initial-state row
     assert out["min_sep"][ok].min() > 0.05 - 1e-2  # every block separated by dmin (to constr_viol_tol)
@@ -105,7 +107,7 @@ def test_closed_loop_on_device(eng):
     table, _ = scenarios.load_reference_table()
     S, steps = 8, 5
     k0, noise = scenarios.sample_scenarios(S, table, seed=3)
-    eng.loop_init(table[:, :, :3], k0, noise)
+    eng.loop_init(table, k0, noise)
     for _ in range(steps):
         eng.loop_step()
     got = eng.loop_get()
