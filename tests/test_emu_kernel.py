@@ -1,0 +1,74 @@
+"""The kernel source itself (conflict_rez_amd/csrc/cfz_solver.inl), compiled for the CPU with the 64 lanes
+run as a loop (tests/emu/cfz_emu.cpp), against the oracle.  Checks the kernel's logic without a GPU; the GPU
+build of the same source is checked by tests/test_gpu_parity.py."""
+import ctypes as C
+import subprocess
+import sys
+
+import numpy as np
+
+import emu_binding as emu
+from oracle import ipm, port
+from oracle.mpc_nlp import reference_residuals
+
+
+def _sol(r):
+    z = r["zu"]
+    return dict(x=z[0], y=z[1], psi=z[2], v=z[3], delta=z[4], a=z[5], w=z[6], l=r["l"], m=r["m"],
+                lam_ij=r["lam_ij"], lam_ji=r["lam_ji"], s=r["s"])
+
+
+def test_kernel_source_matches_oracle_on_goldens(golden, ospec):
+    opt = ipm.IpmOptions()
+    meta = golden["meta"]
+    for b in range(len(golden["x0"])):
+        r = emu.solve(ospec, opt, golden["x0"][b], golden["ref"][b], golden["nbr"][b], golden["zu"][b])
+        assert r["status"] == int(meta[b, 0]) and r["iters"] == int(meta[b, 1]), b
+        if r["status"] == 0:
+            assert np.abs(r["zu"] - golden["sol"][b]).max() < 1e-8
+            assert np.isclose(r["cost"], meta[b, 2], rtol=1e-9) and np.isclose(r["min_sep"], meta[b, 3], atol=1e-8)
+            res = reference_residuals(ospec, golden["x0"][b], golden["ref"][b], golden["nbr"][b], _sol(r))
+            assert res["eq"] < 1e-2 and res["ineq"] < 1e-2 and res["bound"] == 0.0
+
+
+def test_kernel_source_other_shapes(ospec):
+    """n_nbr = 0 / n_obs = 4 (BASELINE.json config 2) and a short horizon: same answers as the C port."""
+    from conflict_rez_amd import scenarios
+    from oracle.mpc_nlp import MpcSpec
+
+    table, _ = scenarios.load_reference_table()
+    opt = ipm.IpmOptions()
+    for n_obs, n_nbr, N in ((4, 0, 30), (6, 1, 12), (0, 2, 8)):
+        sp = scenarios.parking_lot_spec(n_nbr=n_nbr, N=N, n_obs=n_obs)
+        osp = MpcSpec(N=N, dt=sp.dt, A_obs=sp.A_obs, b_obs=sp.b_obs, n_nbr=n_nbr)
+        k0, noise = scenarios.sample_scenarios(3, table, seed=4)
+        x0, ref, nbr, zu = scenarios.mpc_batch_from_table(sp, table[: n_nbr + 1], k0, noise[:, : n_nbr + 1])
+        for b in range(len(x0)):
+            r1 = port.solve(osp, x0[b], ref[b], nbr[b], zu[b].T, opt)
+            r2 = emu.solve(osp, opt, x0[b], ref[b], nbr[b], zu[b])
+            assert (r1["status"], r1["iters"]) == (r2["status"], r2["iters"])
+            if r1["status"] == 0:
+                assert np.abs(r1["p"].T - r2["zu"]).max() < 1e-8
+
+
+def test_kernel_source_under_sanitizers(golden, ospec, tmp_path):
+    """AddressSanitizer + UBSan on the CPU build of the kernel source (no GPU sanitizers on this pool)."""
+    lib = emu.build(sanitize=True)
+    code = f"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, {str(emu.ROOT)!r}); sys.path.insert(0, {str(emu.ROOT + '/tests')!r})
+import emu_binding as emu
+from oracle import ipm
+from oracle.mpc_nlp import MpcSpec
+d = np.load({str(emu.ROOT + '/tests/golden/mpc_golden.npz')!r})
+emu._lib = C.CDLL({lib!r})
+sp = MpcSpec(A_obs=d['A_obs'], b_obs=d['b_obs'], n_nbr=3)
+for b in (0, 7, 11):
+    r = emu.solve(sp, ipm.IpmOptions(), d['x0'][b], d['ref'][b], d['nbr'][b], d['zu'][b])
+    assert r['status'] == int(d['meta'][b, 0])
+print('sanitized ok')
+"""
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(**__import__("os").environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sanitized ok" in out.stdout, out.stderr[-2000:]
