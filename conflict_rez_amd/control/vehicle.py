@@ -1,0 +1,157 @@
+"""`Vehicle`: single-vehicle planning surface (mirror of the reference's `confrez/control/vehicle.py`).
+
+Built in this round: the constructor (:29-52), the collocation tables (`collocation_coefficients`
+:54-97), the warm-start resampling (`interp_ws_for_collocation` :298-358), the Lagrange
+interpolant of a collocation solution (`get_interpolator` :722-786, `interpolate_states`
+:788-829) -- all numpy, no CasADi.  The three planning NLPs (`state_ws` :99-231, `dual_ws`
+:233-296, `setup/solve_single_final_problem` :360-661) are the next rows of the coverage
+table (DESIGN.md "Next"); until their kernels land they raise
+`NotImplementedError` and a reference trajectory is supplied with `set_reference_trajectory`.
+"""
+from typing import Dict, Tuple
+
+import numpy as np
+
+from ..obstacle_types import GeofenceRegion
+from ..pytypes import VehiclePrediction, VehicleState
+from ..vehicle_types import VehicleBody, VehicleConfig
+from .compute_sets import compute_initial_states, compute_obstacles, compute_sets
+
+
+def radau_points(K: int) -> np.ndarray:
+    """Radau IIA collocation points on (0, 1]: what `ca.collocation_points(K, "radau")` returns.
+    They are the roots of P_{K-1}(x) - P_K(x) (Legendre, x in [-1,1]) mapped to [0,1]; the root
+    x = 1 gives tau = 1."""
+    from numpy.polynomial import legendre as L
+
+    c = np.zeros(K + 1)
+    c[K - 1], c[K] = 1.0, -1.0
+    roots = np.sort(np.real(L.legroots(c)))
+    return (roots + 1.0) / 2.0
+
+
+class Vehicle:
+    def __init__(
+        self,
+        rl_file_name: str,
+        agent: str,
+        color: Dict[str, Tuple[float, float, float]],
+        vehicle_config: VehicleConfig = None,
+        vehicle_body: VehicleBody = None,
+        region: GeofenceRegion = None,
+    ) -> None:
+        self.rl_file_name = rl_file_name
+        self.agent = agent
+        self.color = color
+        self.vehicle_config = vehicle_config or VehicleConfig()
+        self.vehicle_body = vehicle_body or VehicleBody()
+        self.region = region or GeofenceRegion()
+        self.init_state: VehicleState = compute_initial_states(rl_file_name, self.vehicle_body)[agent]
+        self.obstacles = compute_obstacles()
+        self.rl_tube = compute_sets(rl_file_name)[agent]
+        self.num_sets = len(self.rl_tube)
+        self.state_interpolator = None
+        self.input_interpolator = None
+
+    # ---- collocation tables -------------------------------------------------------------
+    def collocation_coefficients(self, K: int):
+        """A[j,k] = l_j'(tau_k), B[j] = int_0^1 l_j, D[j] = l_j(1) for the Lagrange basis on
+        tau = [0, radau_points(K)]."""
+        tau = np.append(0.0, radau_points(K))
+        A, B, D = np.zeros((K + 1, K + 1)), np.zeros(K + 1), np.zeros(K + 1)
+        for j in range(K + 1):
+            others = np.delete(tau, j)
+            p = np.poly1d(np.poly(others) / np.prod(tau[j] - others))
+            D[j] = p(1.0)
+            A[j, :] = np.polyder(p)(tau)
+            B[j] = np.polyint(p)(1.0)
+        return A, B, D
+
+    # ---- planning NLPs (next rows of the coverage table) ------------------------------------
+    def state_ws(self, *args, **kwargs) -> VehiclePrediction:
+        raise NotImplementedError("state_ws (vehicle.py:99-231) has no HIP kernel yet; see DESIGN.md 'Next'")
+
+    def dual_ws(self, zu0: VehiclePrediction, verbose: int = 0) -> VehiclePrediction:
+        raise NotImplementedError("dual_ws (vehicle.py:233-296) has no HIP kernel yet; see DESIGN.md 'Next'")
+
+    def setup_single_final_problem(self, *args, **kwargs):
+        raise NotImplementedError("collocation NLP (vehicle.py:360-640) has no HIP kernel yet; see DESIGN.md 'Next'")
+
+    def solve_single_final_problem(self, verbose: int = 0):
+        raise NotImplementedError("collocation NLP (vehicle.py:642-661) has no HIP kernel yet; see DESIGN.md 'Next'")
+
+    # ---- resampling of a warm start onto the collocation grid ---------------------------------
+    def interp_ws_for_collocation(self, zu0: VehiclePrediction, K: int = 5, N_per_set: int = 5):
+        """Linear interpolation of every array of `zu0` at t = (i + tau) / N * T_end; l, m come in as
+        [n, T+1] (after dual_ws) and go out as nested lists [N][K+1] of (n,) arrays."""
+        N = N_per_set * (self.num_sets - 1)
+        tau = np.append(0.0, radau_points(K))
+        t = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * zu0.t[-1]
+        out = VehiclePrediction()
+        out.t = t
+        for name in ("x", "y", "psi", "v", "u_steer", "u_a", "u_steer_dot"):
+            setattr(out, name, np.interp(t, zu0.t, getattr(zu0, name)))
+        for name in ("l", "m"):
+            arr = getattr(zu0, name)
+            if arr is None:
+                continue
+            cols = np.stack([np.interp(t, zu0.t, row) for row in np.asarray(arr)], 0)  # [n, N*(K+1)]
+            setattr(out, name, [[cols[:, i * (K + 1) + k] for k in range(K + 1)] for i in range(N)])
+        return out
+
+    # ---- interpolant of a collocation solution ---------------------------------------------------
+    def get_interpolator(self, K: int, N: int, dt: float, opt: VehiclePrediction):
+        """state: per interval the degree-K Lagrange polynomial through its K+1 collocation values,
+        interval chosen right-continuously (t >= t_i), final value sum_k D[k] X[-1,k] held for
+        t >= N dt; inputs: piecewise constant per collocation point."""
+        tau = np.append(0.0, radau_points(K))
+        _, _, D = self.collocation_coefficients(K)
+        X = np.stack([np.reshape(getattr(opt, n), (N, K + 1)) for n in ("x", "y", "psi", "v", "u_steer")], -1)
+        x_final = np.tensordot(D, X[-1], axes=(0, 0))
+        denom = np.array([np.prod(np.delete(tau[j] - tau, j)) for j in range(K + 1)])
+        t_in = np.asarray(opt.t, float)
+        ua, uw = np.asarray(opt.u_a, float), np.asarray(opt.u_steer_dot, float)
+
+        def state_interpolator(t):
+            t = float(t)
+            if t >= N * dt:
+                return x_final.copy()
+            i = min(max(int(np.floor(t / dt + 1e-12)), 0), N - 1)
+            rel = (t - i * dt) / dt
+            basis = np.array([np.prod(np.delete(rel - tau, j)) for j in range(K + 1)]) / denom
+            return basis @ X[i]
+
+        def input_interpolator(t):
+            idx = min(int(np.searchsorted(t_in[1:], float(t), side="right")), len(ua) - 1)
+            return np.array([ua[idx], uw[idx]])
+
+        self.state_interpolator, self.input_interpolator = state_interpolator, input_interpolator
+
+    def set_reference_trajectory(self, traj: VehiclePrediction):
+        """Interpolators from a sampled trajectory (t, x, y, psi, v, u_steer, u_a, u_steer_dot): linear in
+        the states, piecewise constant in the inputs, final sample held -- stands in for the
+        collocation interpolant while the planner kernels are not built."""
+        t = np.asarray(traj.t, float)
+        S = np.stack([np.asarray(getattr(traj, n), float) for n in ("x", "y", "psi", "v", "u_steer")], 1)
+        ua, uw = np.asarray(traj.u_a, float), np.asarray(traj.u_steer_dot, float)
+
+        def state_interpolator(tt):
+            return np.array([np.interp(float(tt), t, S[:, c]) for c in range(5)])
+
+        def input_interpolator(tt):
+            idx = min(int(np.searchsorted(t[1:], float(tt), side="right")), len(ua) - 1)
+            return np.array([ua[idx], uw[idx]])
+
+        self.state_interpolator, self.input_interpolator = state_interpolator, input_interpolator
+
+    def interpolate_states(self, time: np.ndarray) -> VehiclePrediction:
+        if self.state_interpolator is None:
+            raise RuntimeError("no interpolator: call get_solution/get_interpolator or set_reference_trajectory first")
+        time = np.asarray(time, float)
+        S = np.array([self.state_interpolator(t) for t in time]).reshape(len(time), 5)
+        U = np.array([self.input_interpolator(t) for t in time]).reshape(len(time), 2)
+        out = VehiclePrediction()
+        out.t = time.copy()
+        out.x, out.y, out.psi, out.v, out.u_steer = (S[:, c].copy() for c in range(5))
+        out.u_a, out.u_steer_dot = U[:, 0].copy(), U[:, 1].copy()
+        return out

@@ -1,0 +1,124 @@
+"""Host logic of `VehicleFollower` / `MultiDistributedFollower` (reference vehicle_follower.py:370-563,630-663)
+with the engine replaced by a stand-in that calls the oracle's C port -- checks the Python shim only
+(parameter assembly, Jacobi exchange order, read-back, shift fallback, plant step, bookkeeping)."""
+import numpy as np
+import pytest
+
+from conflict_rez_amd import scenarios, strategy as strat
+from conflict_rez_amd.control.vehicle import Vehicle, radau_points
+from conflict_rez_amd.control.vehicle_follower import MultiDistributedFollower, VehicleFollower
+from conflict_rez_amd.pytypes import VehiclePrediction, VehicleState
+from oracle import port
+from oracle.mpc_nlp import MpcSpec
+
+
+class OracleEngine:
+    """Test double with `Engine.solve`'s signature; optionally forces failures."""
+
+    def __init__(self, spec, fail_at=()):
+        self.ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
+        self.calls, self.fail_at = 0, set(fail_at)
+
+    def solve(self, x0, ref, nbr, zu, want_duals=True):
+        B, N, nn, no = len(x0), self.ospec.N, self.ospec.n_nbr, self.ospec.n_obs
+        out = dict(zu=np.zeros((B, 7, N)), status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), solve_ms=1.0,
+                   l=np.ones((B, N, 4 * no)), m=np.ones((B, N, 4 * no)), lam_ij=np.ones((B, nn, N, 4)),
+                   lam_ji=np.ones((B, nn, N, 4)), s=np.ones((B, nn, N, 2)))
+        for b in range(B):
+            r = port.solve(self.ospec, x0[b], ref[b], nbr[b], zu[b].T)
+            out["zu"][b], out["status"][b], out["iters"][b] = r["p"].T, r["status"], r["iters"]
+            if self.calls in self.fail_at:
+                out["status"][b] = 2
+            self.calls += 1
+        return out
+
+
+def _references():
+    table, lengths = scenarios.load_reference_table()
+    refs = {}
+    for v in range(4):
+        p = VehiclePrediction()
+        T = int(lengths[v])
+        p.t = 0.1 * np.arange(T)
+        p.x, p.y, p.psi, p.v, p.u_steer, p.u_a, p.u_steer_dot = (table[v, :T, c].copy() for c in range(7))
+        refs["vehicle_%d" % v] = p
+    return refs
+
+
+@pytest.fixture()
+def follower_setup(tmp_path, monkeypatch):
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    mdf = MultiDistributedFollower(fn, {f"vehicle_{i}": True for i in range(4)}, {f"vehicle_{i}": {"front": (1, 0, 0), "back": (0, 1, 0)} for i in range(4)},
+                                   {f"vehicle_{i}": VehicleState() for i in range(4)}, {f"vehicle_{i}": None for i in range(4)})
+    import conflict_rez_amd.control.vehicle_follower as vf
+
+    monkeypatch.setattr(vf, "Engine", lambda spec, max_batch, **kw: OracleEngine(spec))
+    mdf.setup_multi_vehicles(references=_references())
+    return mdf
+
+
+def test_setup_and_reference_lookup(follower_setup):
+    mdf = follower_setup
+    assert [v.agent for v in mdf.vehicles] == [f"vehicle_{i}" for i in range(4)]
+    v = mdf.vehicles[1]
+    assert v.others == ["vehicle_0", "vehicle_2", "vehicle_3"] and v.N == 30 and v.dt == 0.1
+    assert v.pred.l.shape == (30, 24) and v.pred.m.shape == (30, 24) and (v.pred.l < 0.1).all()
+    ref = v.get_current_ref()
+    assert np.allclose(ref.t, 0.1 * np.arange(30)) and np.isclose(ref.x[0], v.reference_traj.x[0])
+    assert len(v.ref_pair) == 2  # reference quirk: one entry from setup, one from this call
+    v.state.t = 1e9  # past the end: final pose held
+    assert np.allclose(v.get_current_ref().x, v.reference_traj.x[-1])
+
+
+def test_closed_loop_steps_and_bookkeeping(follower_setup):
+    mdf = follower_setup
+    mdf.solve(num_iter=6, dump=False)
+    for v in mdf.vehicles:
+        assert len(v.final_traj.t) == 7 and np.isclose(v.final_traj.t[-1], 0.6) and len(v.iter_time) == 6
+        assert v.status == 0 and v.back_up_steps == 29
+        assert np.isclose(v.state.u.u_a, v.final_traj.u_a[-1])
+        ref_now = v.interpolate_states([v.state.t])
+        assert np.hypot(v.state.x.x - ref_now.x[0], v.state.x.y - ref_now.y[0]) < 0.3
+        for o in v.others:
+            assert v.opt_lambda_ij[o].shape == (30, 4) and v.opt_s[o].shape == (30, 2)
+
+
+def test_shift_fallback_on_failure(follower_setup):
+    mdf = follower_setup
+    v = mdf.vehicles[0]
+    mdf.solve(num_iter=1, dump=False)
+    before = v.pred.copy()
+    lam = {o: v.opt_lambda_ij[o].copy() for o in v.others}
+    mdf.engine.fail_at = {mdf.engine.calls}  # next solve of vehicle_0 reports failure
+    mdf.solve(num_iter=1, dump=False)
+    assert v.status == 2 and v.back_up_steps == 28 and v.iter_time[-1] == 0.5
+    assert np.allclose(v.pred.x, np.append(before.x[1:], before.x[-1]))
+    assert np.allclose(v.pred.l, np.vstack([before.l[1:], before.l[-1]]))
+    for o in v.others:
+        assert np.allclose(v.opt_lambda_ij[o], np.vstack([lam[o][1:], lam[o][-1]]))
+    assert mdf.vehicles[1].status == 0
+
+
+def test_collocation_tables_and_interpolant(follower_setup):
+    veh: Vehicle = follower_setup.vehicles[0]
+    tau = radau_points(5)
+    assert np.allclose(tau, [0.05710420, 0.27684301, 0.58359043, 0.86024014, 1.0], atol=1e-8)
+    A, B, D = veh.collocation_coefficients(5)
+    assert np.isclose(B.sum(), 1.0) and np.isclose(D.sum(), 1.0) and np.allclose(A.sum(0), 0.0, atol=1e-10)
+    assert np.allclose(D, [0, 0, 0, 0, 0, 1], atol=1e-10)  # Radau: last point is the interval end
+    # a cubic is reproduced exactly by the degree-5 interpolant; after the end the final value is held
+    N, K, dt = 4, 5, 0.7
+    tgrid = np.array([(i + t) * dt for i in range(N) for t in np.append(0, tau)])
+    poly = lambda t: 1.0 + 0.5 * t - 0.2 * t**2 + 0.03 * t**3
+    opt = VehiclePrediction()
+    opt.t = tgrid
+    opt.x, opt.y, opt.psi, opt.v, opt.u_steer = poly(tgrid), 2 * poly(tgrid), -poly(tgrid), tgrid * 0, tgrid * 0 + 0.1
+    opt.u_a, opt.u_steer_dot = np.arange(len(tgrid), dtype=float), -np.arange(len(tgrid), dtype=float)
+    veh.get_interpolator(K, N, dt, opt)
+    for t in (0.0, 0.3, 0.7, 1.234, 2.79):
+        assert np.isclose(veh.state_interpolator(t)[0], poly(t), atol=1e-10)
+    assert np.isclose(veh.state_interpolator(5.0)[0], poly(N * dt), atol=1e-10)
+    assert np.allclose(veh.input_interpolator(0.0), [0, 0]) and np.allclose(veh.input_interpolator(tgrid[7]), [7, -7])
+    out = veh.interpolate_states([0.1, 0.2])
+    assert out.x.shape == (2,) and out.u_a.shape == (2,)
