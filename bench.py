@@ -141,7 +141,8 @@ def main():
                                    "N=30, 6 obstacles, closed loop on device", "scenarios_per_gpu": S,
                        "solves_per_step_per_gpu": B, "parallelism": f"scenario-sharded x{world}",
                        "max_iter": args.max_iter, "converged_last_step": n_ok / (B * world),
-                       "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V},
+                       "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
+                       "lds_bytes_per_instance": eng.kernel_info()[0], "instances_per_cu": eng.kernel_info()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "solve_kernel", "kernel_ms_per_launch": kern_s * 1e3,

@@ -43,7 +43,10 @@ __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cf
   if (b >= B) return;
   const int N = sp.N, no = sp.n_obs, nn = sp.n_nbr;
   int oi[2]; double od[3];
-  cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#ifdef CFZ_STAMPS
+  duo.stamps = reinterpret_cast<unsigned long long *>(stats) + (size_t)B * 3 + (size_t)b * 12;  // diagnostic build: stats has room
+#endif
   if (du.l) {
     duo.l = du.l + (size_t)b * N * 4 * no; duo.mm = du.m + (size_t)b * N * 4 * no;
     duo.lam_ij = du.lam_ij + (size_t)b * nn * N * 4; duo.lam_ji = du.lam_ji + (size_t)b * nn * N * 4;
@@ -124,6 +127,7 @@ struct cfz_handle {
   cfz::KSpec ks;
   cfz::Lay lay;
   size_t lds_bytes = 0;
+  int blocks_per_cu = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
@@ -241,12 +245,14 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
     hipError_t e = hipFuncSetAttribute((const void *)solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
   }
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, 64, h->lds_bytes);
   const size_t B = (size_t)max_batch, N = (size_t)k.N, no = (size_t)k.n_obs, nn = (size_t)k.n_nbr;
   HIP_OK(hipStreamCreate(&h->stream));
   HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
   HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
-  HIP_OK(hipMalloc(&h->stats, B * 3 * 8)); HIP_OK(hipMalloc(&h->status, B * 4)); HIP_OK(hipMalloc(&h->iters, B * 4));
+  // stats: 3 doubles per instance (+ 12 phase counters per instance for the -DCFZ_STAMPS diagnostic build)
+  HIP_OK(hipMalloc(&h->stats, B * (3 + 12) * 8)); HIP_OK(hipMalloc(&h->status, B * 4)); HIP_OK(hipMalloc(&h->iters, B * 4));
   HIP_OK(hipMalloc(&h->l, (B * N * 4 * no + 1) * 8)); HIP_OK(hipMalloc(&h->m, (B * N * 4 * no + 1) * 8));
   HIP_OK(hipMalloc(&h->lam_ij, (B * nn * N * 4 + 1) * 8)); HIP_OK(hipMalloc(&h->lam_ji, (B * nn * N * 4 + 1) * 8));
   HIP_OK(hipMalloc(&h->s, (B * nn * N * 2 + 1) * 8));
@@ -269,6 +275,13 @@ int cfz_destroy(cfz_handle *h) {
 }
 
 int cfz_max_batch(const cfz_handle *h) { return h ? h->max_batch : 0; }
+
+int cfz_kernel_info(const cfz_handle *h, int32_t *lds_bytes_per_instance, int32_t *instances_per_cu) {
+  if (!h) return fail("null handle");
+  if (lds_bytes_per_instance) *lds_bytes_per_instance = (int32_t)h->lds_bytes;
+  if (instances_per_cu) *instances_per_cu = h->blocks_per_cu;
+  return 0;
+}
 
 int cfz_mpc_set_params(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr) {
   if (check(h, B)) return -1;

@@ -28,8 +28,10 @@
 
 #if defined(__HIPCC__)
 #define CFZ_FN __host__ __device__ __forceinline__
+#define CFZ_CALL __host__ __device__ __forceinline__  // measured: out-of-line helpers cost 30 % (arguments spill to scratch)
 #else
 #define CFZ_FN static inline
+#define CFZ_CALL static inline
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CFZ_LANES(lane) { const int lane = (int)threadIdx.x;
@@ -39,10 +41,20 @@
 #define CFZ_END }
 #endif
 
+// Diagnostic build only (-DCFZ_STAMPS): shader-clock cycles per phase of the solver, summed over the
+// iterations of one instance and written to a debug buffer (never to an output).
+#if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CFZ_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } while (0)
+#define CFZ_STAMP_DECL unsigned long long stamp_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#else
+#define CFZ_STAMP(i) do {} while (0)
+#define CFZ_STAMP_DECL
+#endif
+
 namespace cfz {
 
 constexpr int kNP = 7;      // x y psi v delta a w
-constexpr int kRed = 8;     // reduction slots
+constexpr int kRed = 6;     // reduction slots
 constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
 
 // Everything the kernel needs besides per-instance data (plain old data, passed by value).
@@ -63,10 +75,11 @@ struct Lay {
   int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
   int dp, dsg, dpi0, dpi;                   // step
   int cj, gra, ab, d, hc, gk, kk;           // stage data
-  int sel, ref, nb4, x0, filt, red, total;
+  int sel, ref, nb4, x0, obs, cs, filt, red, total;
 };
 
 CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
+  const int n_obs = nb - n_nbr;
   Lay L; int o = 0;
   const int nr = 2 * nb;
   L.N = N; L.nb = nb; L.nr = nr;
@@ -74,16 +87,23 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.sg = o; o += N * nr; L.nuc = o; o += N * nr; L.zs = o; o += N * nr;
   L.zl = o; o += N * 6; L.zu = o; o += N * 6;
   L.pi0 = o; o += 5; L.pi = o; o += N * 5;
-  L.dp = o; o += N * kNP; L.dsg = o; o += N * nr; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
-  L.cj = o; o += N * nr; L.gra = o; o += N * nr * 3;
+  L.dp = o; o += N * kNP; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
+  L.cj = o; o += N * nr; L.dsg = L.cj;  // the slack step overwrites the row residual it is computed from
+  L.gra = o; o += N * nb * 4;           // per block: shared (d/dx, d/dy) and the two d/dpsi
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
-  L.sel = o; o += N * nb;  // working set codes, stored as doubles
-  L.ref = o; o += 3 * N; L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
-  L.filt = o; o += 64; L.red = o; o += kRed * 64;
+  L.sel = o; o += (N * nb + 1) / 2;  // working set codes, int32
+  L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
+  L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
+  L.obs = o; o += n_obs * 20;  // static obstacles: A[4][2], b[4], V[4][2] (lane-indexed reads of a kernel argument would go through scratch)
+  L.cs = o; o += 2 * N;  // cos, sin of the pose heading of every stage at the point being evaluated
+  L.filt = o; o += 32; L.red = o; o += kRed * 64;
   L.total = o;
   return L;
 }
+
+CFZ_FN int *sel_ptr(double *m, const Lay &L) { return reinterpret_cast<int *>(m + L.sel); }
+CFZ_FN const int *sel_ptr(const double *m, const Lay &L) { return reinterpret_cast<const int *>(m + L.sel); }
 
 // bounded columns of p: x y v delta a w  (psi is free)
 CFZ_FN int bcol(int q) { return q < 2 ? q : q + 1; }
@@ -109,8 +129,19 @@ CFZ_FN double red_min(const double *m, const Lay &L, int slot) {
 // RK4 (M sub-steps) of the kinematic bicycle.  The state rows v, delta integrate exactly
 // (v+ = v + a t, delta+ = delta + w t) and x, y never feed back, so only the sensitivities of
 // (x, y, psi) with respect to (psi0, v0, delta0, a, w) are propagated: S[3][5].
+// sin, cos of a small angle by Taylor series (|e| <= 0.06: truncation < 1e-21), sincos otherwise
+CFZ_FN void small_sincos(double e, double *s, double *c) {
+  if (fabs(e) > 0.06) { sincos(e, s, c); return; }
+  const double e2 = e * e;
+  *s = e * (1.0 - e2 / 6.0 * (1.0 - e2 / 20.0 * (1.0 - e2 / 42.0 * (1.0 - e2 / 72.0))));
+  *c = 1.0 - e2 / 2.0 * (1.0 - e2 / 12.0 * (1.0 - e2 / 30.0 * (1.0 - e2 / 56.0 * (1.0 - e2 / 90.0))));
+}
+
+// Three library sincos calls per interval instead of 32: the steering angle advances by w h/2 between RK
+// stage points (one fixed rotation), the heading by small increments (|h psi'| <= 0.03 rad inside the
+// actuator limits), so the stage-point sines/cosines come from rotating the previous ones.
 template <bool SENS>
-CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb, int M, double out[5],
+CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double wb, int M, double out[5],
                      double S[3][5]) {
   const double h = dt / M;
   double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
@@ -119,6 +150,10 @@ CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb
       for (int c = 0; c < 5; ++c) S[r][c] = 0.0;
     S[2][0] = 1.0;
   }
+  double sp_, cp_, sd0, cd0, sh, ch;  // heading and steering angle at the sub-step start, half-step steering rotation
+  sincos(psi, &sp_, &cp_);
+  sincos(de, &sd0, &cd0);
+  small_sincos(0.5 * h * w, &sh, &ch);
   double tsub = 0.0;  // time since the start of the interval: dv/da = ddelta/dw = tsub
   for (int m = 0; m < M; ++m) {
     double ax = 0, ay = 0, ap = 0;  // weighted stage sums
@@ -126,17 +161,27 @@ CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb
     if (SENS)
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 5; ++c) AS[r][c] = 0.0;
-    double kx = 0, ky = 0, kp = 0;  // previous stage derivative
+    double kp = 0;  // previous stage derivative of psi
     double KS[3][5];
     if (SENS)
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 5; ++c) KS[r][c] = 0.0;
+    // steering angle at the three distinct stage times of this sub-step: +0, +h/2, +h
+    const double sd1 = sd0 * ch + cd0 * sh, cd1 = cd0 * ch - sd0 * sh;
+    const double sd2 = sd1 * ch + cd1 * sh, cd2 = cd1 * ch - sd1 * sh;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
       const double wsum = (st == 0 || st == 3) ? 1.0 : 2.0;
-      const double ps = psi + wprev * kp, vs = v + wprev * a, ds = de + wprev * w;
-      const double c = cos(ps), s = sin(ps), t = tan(ds);
+      const double vs = v + wprev * a;
+      double s = sp_, c = cp_;
+      if (st > 0) {
+        double se, ce;
+        small_sincos(wprev * kp, &se, &ce);
+        s = sp_ * ce + cp_ * se; c = cp_ * ce - sp_ * se;
+      }
+      const double sd = (st == 0) ? sd0 : ((st == 3) ? sd2 : sd1), cd = (st == 0) ? cd0 : ((st == 3) ? cd2 : cd1);
+      const double t = sd / cd;
       const double fx = vs * c, fy = vs * s, fp = vs / wb * t;
       if (SENS) {
         // stage point sensitivities: psi row from S/KS, v and delta rows analytic
@@ -157,11 +202,17 @@ CFZ_FN void rk4_step(const double z[5], double a, double w, double dt, double wb
 #pragma unroll
           for (int q = 0; q < 5; ++q) { KS[r][q] = NS[r][q]; AS[r][q] += wsum * NS[r][q]; }
       }
-      kx = fx; ky = fy; kp = fp;
+      kp = fp;
       ax += wsum * fx; ay += wsum * fy; ap += wsum * fp;
     }
     x += h / 6 * ax; y += h / 6 * ay; psi += h / 6 * ap;
     v += h * a; de += h * w;
+    {
+      double se, ce;
+      small_sincos(h / 6 * ap, &se, &ce);
+      const double sn = sp_ * ce + cp_ * se, cn = cp_ * ce - sp_ * se;
+      sp_ = sn; cp_ = cn; sd0 = sd2; cd0 = cd2;
+    }
     if (SENS)
       for (int r = 0; r < 3; ++r)
         for (int q = 0; q < 5; ++q) S[r][q] += h / 6 * AS[r][q];
@@ -212,9 +263,8 @@ CFZ_FN double pick4(const double d[4], int v) {
   return r;
 }
 
-CFZ_FN int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
-                       const double g[4], int prev) {
-  const double c = cos(psi), s = sin(psi);
+CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
+                       double s, const double g[4], int prev) {
   const int pk = prev >> 6, pf = (prev >> 4) & 3;
   double best = 0.0, prev_val = 0.0, d[4];
   int have = 0, bk = 0, bf = 0, have_prev = 0;
@@ -244,9 +294,8 @@ CFZ_FN int select_rows(const double A[4][2], const double b[4], const double V[4
 
 // values (and gradients wrt x,y,psi) of the two rows of working set `sel`
 template <bool GRAD>
-CFZ_FN void rows_for(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
-                     const double g[4], int sel, double sep[2], double grad[2][3]) {
-  const double c = cos(psi), s = sin(psi);
+CFZ_CALL void rows_for(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
+                     double s, const double g[4], int sel, double sep[2], double grad[2][3]) {
   double d[4], gr[4][3];
   vertex_dist<GRAD>(A, b, V, x, y, c, s, g, sel >> 6, (sel >> 4) & 3, d, gr);
   const int va = (sel >> 2) & 3, vb = sel & 3;
@@ -264,10 +313,11 @@ CFZ_FN void rows_for(const double A[4][2], const double b[4], const double V[4][
 CFZ_FN void block_polygon(const KSpec &sp, const double *m, const Lay &L, int k, int j, double A[4][2], double b[4],
                           double V[4][2]) {
   if (j < sp.n_obs) {
+    const double *o = m + L.obs + j * 20;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      A[i][0] = sp.A_obs[j][i][0]; A[i][1] = sp.A_obs[j][i][1]; b[i] = sp.b_obs[j][i];
-      V[i][0] = sp.V_obs[j][i][0]; V[i][1] = sp.V_obs[j][i][1];
+      A[i][0] = o[2 * i]; A[i][1] = o[2 * i + 1]; b[i] = o[8 + i];
+      V[i][0] = o[12 + 2 * i]; V[i][1] = o[12 + 2 * i + 1];
     }
   } else {
     const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
@@ -336,22 +386,22 @@ CFZ_FN void sym2_solve6(const double M[2][2], const double rhs[2][6], double out
 // ------------------------------------------------------------------------------ trial-point evaluation
 // theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lanes write partials
 // into red slots 0 (theta), 1 (phi without the log terms), 2 (sum of logs), 3 (1 if infeasible).
-CFZ_FN void merit_partials(const KSpec &sp, double *m, const Lay &L, double alpha, int lane) {
+CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, const Lay &L, double alpha, int lane) {
   const int N = sp.N, nb = L.nb;
-  double th = 0.0, ph = 0.0, lg = 0.0, bad = 0.0;
+  // sum of logs taken as the log of a per-lane product (<= 22 factors in [1e-10, 1e2]: no over/underflow)
+  double th = 0.0, ph = 0.0, lprod = 1.0, bad = 0.0;
   for (int t = lane; t < N * nb; t += 64) {
     const int k = t / nb, j = t - k * nb;
     const double x = m[L.p + k * kNP + 0] + alpha * m[L.dp + k * kNP + 0];
     const double y = m[L.p + k * kNP + 1] + alpha * m[L.dp + k * kNP + 1];
-    const double ps = m[L.p + k * kNP + 2] + alpha * m[L.dp + k * kNP + 2];
     double A[4][2], b[4], V[4][2], sep[2];
     block_polygon(sp, m, L, k, j, A, b, V);
-    rows_for<false>(A, b, V, x, y, ps, sp.g, (int)m[L.sel + t], sep, nullptr);
+    rows_for<false>(A, b, V, x, y, m[L.cs + 2 * k], m[L.cs + 2 * k + 1], sp.g, sel_ptr(m, L)[t], sep, nullptr);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
       th += fabs(sep[r] - sp.dmin - sg);
-      if (!(sg > 0.0)) bad = 1.0; else lg += log(sg);
+      if (!(sg > 0.0)) bad = 1.0; else lprod *= sg;
     }
   }
   if (lane < N) {
@@ -360,9 +410,9 @@ CFZ_FN void merit_partials(const KSpec &sp, double *m, const Lay &L, double alph
     for (int i = 0; i < kNP; ++i) pt[i] = m[L.p + k * kNP + i] + alpha * m[L.dp + k * kNP + i];
     for (int q = 0; q < 6; ++q) {
       const double dl = pt[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pt[bcol(q)];
-      if (!(dl > 0.0) || !(du > 0.0)) bad = 1.0; else lg += log(dl) + log(du);
+      if (!(dl > 0.0) || !(du > 0.0)) bad = 1.0; else lprod *= dl * du;
     }
-    ph += stage_cost(sp, m + L.ref, k, pt);
+    ph += stage_cost(sp, refg, k, pt);
     if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
     if (k + 1 < N) {
       double F[5];
@@ -372,14 +422,14 @@ CFZ_FN void merit_partials(const KSpec &sp, double *m, const Lay &L, double alph
     }
   }
   m[L.red + 0 * 64 + lane] = th; m[L.red + 1 * 64 + lane] = ph;
-  m[L.red + 2 * 64 + lane] = lg; m[L.red + 3 * 64 + lane] = bad;
+  m[L.red + 2 * 64 + lane] = (bad == 0.0) ? log(lprod) : 0.0; m[L.red + 3 * 64 + lane] = bad;
 }
 
 // ------------------------------------------------------------------------------ the solver
 // x0[5], ref[3][N], nbr[n_nbr][3][N], zu[7][N] (warm start in, solution out) in global memory;
 // m = this instance's workspace (LDS on the device).  out: iters,status ; cost,err,min_sep.
 // dual_out (optional): l,m [N][4 n_obs], lam_ij, lam_ji [n_nbr][N][4], s [n_nbr][N][2].
-struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; };
+struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; unsigned long long *stamps; };
 
 CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *refg, const double *nbrg, double *zu,
                            double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo) {
@@ -389,7 +439,6 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
 
   // ---- load parameters, initial point ---------------------------------------------------
   CFZ_LANES(lane)
-    for (int i = lane; i < 3 * N; i += 64) m[L.ref + i] = refg[i];
     for (int t = lane; t < N * n_nbr; t += 64) {
       const int k = t / n_nbr, o = t - k * n_nbr;
       const double po = nbrg[(o * 3 + 2) * N + k];
@@ -397,6 +446,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
     }
     if (lane < 5) { m[L.x0 + lane] = x0g[lane]; m[L.pi0 + lane] = 0.0; }
+    for (int i = lane; i < n_obs * 20; i += 64) {
+      const int j = i / 20, r = i - 20 * j;
+      m[L.obs + i] = r < 8 ? sp.A_obs[j][r >> 1][r & 1] : (r < 12 ? sp.b_obs[j][r - 8] : sp.V_obs[j][(r - 12) >> 1][r & 1]);
+    }
     for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
     for (int i = lane; i < N * 5; i += 64) m[L.pi + i] = 0.0;
   CFZ_END
@@ -407,8 +460,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     if (lane < nb) {
       double A[4][2], b[4], V[4][2], sep[2];
       block_polygon(sp, m, L, 0, lane, A, b, V);
-      const int c0 = select_rows(A, b, V, m[L.x0], m[L.x0 + 1], m[L.x0 + 2], sp.g, 0);
-      rows_for<false>(A, b, V, m[L.x0], m[L.x0 + 1], m[L.x0 + 2], sp.g, c0, sep, nullptr);
+      double s0, c0_;
+      sincos(m[L.x0 + 2], &s0, &c0_);
+      const int c0 = select_rows(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0);
+      rows_for<false>(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, c0, sep, nullptr);
       worst = fmin(sep[0], sep[1]);
     }
     m[L.red + lane] = worst;
@@ -423,10 +478,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       const int k = t / nb, j = t - k * nb;
       double A[4][2], b[4], V[4][2], sep[2];
       block_polygon(sp, m, L, k, j, A, b, V);
-      const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], psi = m[L.p + k * kNP + 2];
-      const int c0 = select_rows(A, b, V, x, y, psi, sp.g, 0);
-      m[L.sel + t] = (double)c0;
-      rows_for<false>(A, b, V, x, y, psi, sp.g, c0, sep, nullptr);
+      const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1];
+      double sn, cn;
+      sincos(m[L.p + k * kNP + 2], &sn, &cn);
+      const int c0 = select_rows(A, b, V, x, y, cn, sn, sp.g, 0);
+      sel_ptr(m, L)[t] = c0;
+      rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c0, sep, nullptr);
       for (int r = 0; r < 2; ++r) {
         m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
         m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
@@ -448,23 +505,28 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   CFZ_END
 
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
+  CFZ_STAMP_DECL
+  CFZ_STAMP(0);  // setup
   int nfilt = 0, status = 1, iter = 0;
 
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
+    CFZ_LANES(lane)
+      if (lane < N) sincos(m[L.p + lane * kNP + 2], &m[L.cs + 2 * lane + 1], &m[L.cs + 2 * lane]);
+    CFZ_END
     CFZ_LANES(lane)
       double cmax = 0.0, csum = 0.0;
       for (int t = lane; t < N * nb; t += 64) {
         const int k = t / nb, j = t - k * nb;
         double A[4][2], b[4], V[4][2], sep[2], gr[2][3];
         block_polygon(sp, m, L, k, j, A, b, V);
-        const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], psi = m[L.p + k * kNP + 2];
-        int c1 = (int)m[L.sel + t];
+        const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], cn = m[L.cs + 2 * k], sn = m[L.cs + 2 * k + 1];
+        int c1 = sel_ptr(m, L)[t];
         if (iter > 0) {
           const int c0 = c1;
-          c1 = select_rows(A, b, V, x, y, psi, sp.g, c0);
-          if (c1 != c0) m[L.sel + t] = (double)c1;
-          rows_for<true>(A, b, V, x, y, psi, sp.g, c1, sep, gr);
+          c1 = select_rows(A, b, V, x, y, cn, sn, sp.g, c0);
+          if (c1 != c0) sel_ptr(m, L)[t] = c1;
+          rows_for<true>(A, b, V, x, y, cn, sn, sp.g, c1, sep, gr);
           if (c1 != c0) {
             // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
             // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
@@ -487,15 +549,21 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
             }
           }
         } else {
-          rows_for<true>(A, b, V, x, y, psi, sp.g, c1, sep, gr);
+          rows_for<true>(A, b, V, x, y, cn, sn, sp.g, c1, sep, gr);
         }
+        m[L.gra + 4 * t] = gr[0][0]; m[L.gra + 4 * t + 1] = gr[0][1];  // both rows share d/dx, d/dy (same face)
+        m[L.gra + 4 * t + 2] = gr[0][2]; m[L.gra + 4 * t + 3] = gr[1][2];
         for (int r = 0; r < 2; ++r) {
           const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
           m[L.cj + 2 * t + r] = c;
-          m[L.gra + (2 * t + r) * 3] = gr[r][0]; m[L.gra + (2 * t + r) * 3 + 1] = gr[r][1]; m[L.gra + (2 * t + r) * 3 + 2] = gr[r][2];
           cmax = fmax(cmax, fabs(c)); csum += fabs(c);
         }
       }
+      m[L.red + 2 * 64 + lane] = cmax; m[L.red + 3 * 64 + lane] = csum;
+    CFZ_END
+    CFZ_STAMP(9);  // working set + rows
+    CFZ_LANES(lane)
+      double cmax = m[L.red + 2 * 64 + lane], csum = m[L.red + 3 * 64 + lane];
       if (lane == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
       if (lane + 1 < N) {
         const int k = lane;
@@ -511,23 +579,25 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       m[L.red + 0 * 64 + lane] = cmax; m[L.red + 1 * 64 + lane] = csum;
     CFZ_END
     const double cviol = red_max(m, L, 0), theta = red_sum(m, L, 1);
+    CFZ_STAMP(1);  // working set, rows, dynamics
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
     CFZ_LANES(lane)
-      double dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, fv = 0.0, lg = 0.0;
+      double dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, fv = 0.0, lprod = 1.0;
       if (lane == 0) for (int i = 0; i < 5; ++i) snu += fabs(m[L.pi0 + i]);
       if (lane < N) {
         const int k = lane;
         const double *pk = m + L.p + k * kNP;
         double r[kNP];
-        stage_grad(sp, m + L.ref, k, pk, r);
-        fv = stage_cost(sp, m + L.ref, k, pk);
+        stage_grad(sp, refg, k, pk, r);
+        fv = stage_cost(sp, refg, k, pk);
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
           const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
-          r[0] += m[L.gra + t * 3] * nu; r[1] += m[L.gra + t * 3 + 1] * nu; r[2] += m[L.gra + t * 3 + 2] * nu;
+          const double *ga = m + L.gra + 4 * (t >> 1);
+          r[0] += ga[0] * nu; r[1] += ga[1] * nu; r[2] += ga[2 + (t & 1)] * nu;
           dinf = fmax(dinf, fabs(-nu - zs));
-          snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lg += log(sg);
+          snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lprod *= sg;
         }
         if (k + 1 < N) {
           double A[5][5], B[5][2];
@@ -546,18 +616,19 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           r[bcol(q)] += -zl + zu_; sz += zl + zu_;
           const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
           c0 = fmax(c0, fmax(fabs(dl * zl), fabs(du * zu_)));
-          lg += log(dl) + log(du);
+          lprod *= dl * du;
         }
         for (int i = 0; i < kNP; ++i) dinf = fmax(dinf, fabs(r[i]));
       }
       m[L.red + 0 * 64 + lane] = dinf; m[L.red + 1 * 64 + lane] = snu; m[L.red + 2 * 64 + lane] = sz;
-      m[L.red + 3 * 64 + lane] = c0; m[L.red + 4 * 64 + lane] = fv; m[L.red + 5 * 64 + lane] = lg;
+      m[L.red + 3 * 64 + lane] = c0; m[L.red + 4 * 64 + lane] = fv; m[L.red + 5 * 64 + lane] = log(lprod);
     CFZ_END
     const double dual_inf = red_max(m, L, 0), sum_nu = red_sum(m, L, 1), sum_z = red_sum(m, L, 2);
     const double cmp0 = red_max(m, L, 3), fval = red_sum(m, L, 4), logsum = red_sum(m, L, 5);
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max;
     const double s_c = fmax(sp.s_max, sum_z / (double)n_bnd) / sp.s_max;
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
+    CFZ_STAMP(2);  // residuals
     fval_last = fval;
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
@@ -582,27 +653,29 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       else break;
     }
     const double tau = fmax(sp.tau_min, 1.0 - mu);
+    CFZ_STAMP(3);  // barrier update
     // ---- condensed stage QP: H_k (compact), g_k ---------------------------------------------------
     CFZ_LANES(lane)
       if (lane < N) {
         const int k = lane;
         const double *w = sp.weights; const double *pk = m + L.p + k * kNP;
         double g[kNP], h[11];
-        stage_grad(sp, m + L.ref, k, pk, g);
+        stage_grad(sp, refg, k, pk, g);
         h[0] = 2 * w[0]; h[1] = 2 * w[1]; h[2] = 2 * w[2]; h[3] = 2 * w[4] * pk[6] * pk[6]; h[4] = 2 * w[5];
         h[5] = 2 * w[3]; h[6] = 2 * w[4] * pk[3] * pk[3]; h[7] = 0.0; h[8] = 0.0; h[9] = 0.0;
         h[10] = 2 * w[4] * pk[3] * pk[6];
         for (int i = 0; i < kNP; ++i) h[i] += sp.reg_primal;
         for (int q = 0; q < 6; ++q) {
-          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
-          h[bcol(q)] += m[L.zl + k * 6 + q] / dl + m[L.zu + k * 6 + q] / du;
-          g[bcol(q)] += -mu / dl + mu / du;
+          const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
+          h[bcol(q)] += m[L.zl + k * 6 + q] * il + m[L.zu + k * 6 + q] * iu;
+          g[bcol(q)] += mu * (iu - il);
         }
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
-          const double sg = m[L.sg + t], S = m[L.zs + t] / sg + sp.reg_primal;
-          const double coef = S * m[L.cj + t] - mu / sg;
-          const double a0 = m[L.gra + t * 3], a1 = m[L.gra + t * 3 + 1], a2 = m[L.gra + t * 3 + 2];
+          const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
+          const double coef = S * m[L.cj + t] - mu * isg;
+          const double *ga = m + L.gra + 4 * (t >> 1);
+          const double a0 = ga[0], a1 = ga[1], a2 = ga[2 + (t & 1)];
           g[0] += a0 * coef; g[1] += a1 * coef; g[2] += a2 * coef;
           h[0] += S * a0 * a0; h[1] += S * a1 * a1; h[2] += S * a2 * a2;
           h[7] += S * a0 * a1; h[8] += S * a0 * a2; h[9] += S * a1 * a2;
@@ -611,134 +684,213 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];
       }
     CFZ_END
-    // ---- Riccati: backward gains, forward step, costates (lane 0) ------------------------------------
+    CFZ_STAMP(4);  // assembly
+    // ---- Riccati backward sweep (lane 0; the 5x5 value function stays in registers) -------------------
+    // Structure used: A_k = I + [0 0 s00 s01 s02; 0 0 s10 s11 s12; 0 0 0 s21 s22; 0; 0] (s20 = 1),
+    // B_k = [s03 s04; s13 s14; s23 s24; dt 0; 0 dt]; H_k = diag(h0..h6) + pose off-diagonals
+    // h7 (0,1), h8 (0,2), h9 (1,2) + the v-w cross term h10 (3,6).  A lane-parallel variant (matrix
+    // entries spread over lanes, exchange through LDS) measured 2.2x slower: every exchange is a
+    // dependent LDS round trip of a lone wavefront.
+    double *const rP = m + L.red, *const rp = rP + 25;  // value function of stage 0 handed to the forward sweep
     CFZ_LANES(lane)
       if (lane == 0) {
-        double P[5][5], pv[5], H[kNP][kNP];
+        const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
+        const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP;
+        double *K = m + L.kk + k * 12;
+        for (int q = 0; q < 10; ++q) K[q] = 0.0;
+        K[5 + 3] = -h[10] / h[6]; K[10] = -gk[5] / h[5]; K[11] = -gk[6] / h[6];
+        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = 0.0; rP[i * 6] = h[i]; rp[i] = gk[i]; }
+        rP[1] = rP[5] = h[7]; rP[2] = rP[10] = h[8]; rP[7] = rP[11] = h[9];
+        rP[18] += h[10] * K[5 + 3]; rp[3] += h[10] * K[11];
+      }
+    CFZ_END
+    CFZ_LANES(lane)
+      if (lane == 0) {  // backward sweep on one lane, P in registers
+        const double dt = sp.dt;
+        double P[5][5], pv[5];
+        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) P[i][q] = rP[i * 5 + q]; pv[i] = rp[i]; }
+        // stage data (A/B entries, H, g, defect: 38 doubles) of stage k-1 is fetched while stage k computes
+        double buf[38], nxt[38];
         {
-          const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
-          load_H(m, L, k, H);
-          const double *gk = m + L.gk + k * kNP;
-          const double R2[2][2] = {{H[5][5], H[5][6]}, {H[6][5], H[6][6]}};
-          double rhs[2][6], sol[2][6];
-          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[5 + a][q]; rhs[a][5] = gk[5 + a]; }
-          sym2_solve6(R2, rhs, sol);
-          double *K = m + L.kk + k * 12;
-          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) K[a * 5 + q] = -sol[a][q]; K[10 + a] = -sol[a][5]; }
-          for (int i = 0; i < 5; ++i) {
-            for (int q = 0; q < 5; ++q) P[i][q] = H[i][q] + H[5][i] * K[q] + H[6][i] * K[5 + q];
-            pv[i] = gk[i] + H[5][i] * K[10] + H[6][i] * K[11];
-          }
+          const int k = N - 2;
+          for (int i = 0; i < 15; ++i) buf[i] = m[L.ab + k * 15 + i];
+          for (int i = 0; i < 11; ++i) buf[15 + i] = m[L.hc + k * 11 + i];
+          for (int i = 0; i < 7; ++i) buf[26 + i] = m[L.gk + k * kNP + i];
+          for (int i = 0; i < 5; ++i) buf[33 + i] = m[L.d + k * 5 + i];
         }
         for (int k = N - 2; k >= 0; --k) {
-          double A[5][5], B[5][2], PA[5][5], PB[5][2], Pd[5];
-          load_AB(m, L, k, sp.dt, A, B); load_H(m, L, k, H);
-          const double *gk = m + L.gk + k * kNP, *dk = m + L.d + k * 5;
+          const int kn = k > 0 ? k - 1 : 0;
+          for (int i = 0; i < 15; ++i) nxt[i] = m[L.ab + kn * 15 + i];
+          for (int i = 0; i < 11; ++i) nxt[15 + i] = m[L.hc + kn * 11 + i];
+          for (int i = 0; i < 7; ++i) nxt[26 + i] = m[L.gk + kn * kNP + i];
+          for (int i = 0; i < 5; ++i) nxt[33 + i] = m[L.d + kn * 5 + i];
+          const double *s = buf, *h = buf + 15, *gk = buf + 26, *dk = buf + 33;
+          const double s00 = s[0], s01 = s[1], s02 = s[2], s03 = s[3], s04 = s[4];
+          const double s10 = s[5], s11 = s[6], s12 = s[7], s13 = s[8], s14 = s[9];
+          const double s21 = s[11], s22 = s[12], s23 = s[13], s24 = s[14];
+          double M[5][5], PB[5][2], Pd[5];
+#pragma unroll
           for (int i = 0; i < 5; ++i) {
-            for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += P[i][r] * A[r][q]; PA[i][q] = s; }
-            for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += P[i][r] * B[r][q]; PB[i][q] = s; }
-            double s = pv[i]; for (int r = 0; r < 5; ++r) s += P[i][r] * dk[r]; Pd[i] = s;
+            M[i][0] = P[i][0]; M[i][1] = P[i][1];
+            M[i][2] = P[i][2] + s00 * P[i][0] + s10 * P[i][1];
+            M[i][3] = P[i][3] + s01 * P[i][0] + s11 * P[i][1] + s21 * P[i][2];
+            M[i][4] = P[i][4] + s02 * P[i][0] + s12 * P[i][1] + s22 * P[i][2];
+            PB[i][0] = s03 * P[i][0] + s13 * P[i][1] + s23 * P[i][2] + dt * P[i][3];
+            PB[i][1] = s04 * P[i][0] + s14 * P[i][1] + s24 * P[i][2] + dt * P[i][4];
+            Pd[i] = pv[i] + P[i][0] * dk[0] + P[i][1] * dk[1] + P[i][2] * dk[2] + P[i][3] * dk[3] + P[i][4] * dk[4];
           }
-          double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
-          for (int a = 0; a < 2; ++a) {
-            for (int b = 0; b < 2; ++b) { double s = H[5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += B[r][a] * PB[r][b]; Huu[a][b] = s; }
-            for (int q = 0; q < 5; ++q) { double s = H[5 + a][q]; for (int r = 0; r < 5; ++r) s += B[r][a] * PA[r][q]; Hux[a][q] = s; }
-            double s = gk[5 + a]; for (int r = 0; r < 5; ++r) s += B[r][a] * Pd[r]; hu[a] = s;
+          double Hxx[5][5], hx[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            Hxx[0][j] = M[0][j]; Hxx[1][j] = M[1][j];
+            Hxx[2][j] = M[2][j] + s00 * M[0][j] + s10 * M[1][j];
+            Hxx[3][j] = M[3][j] + s01 * M[0][j] + s11 * M[1][j] + s21 * M[2][j];
+            Hxx[4][j] = M[4][j] + s02 * M[0][j] + s12 * M[1][j] + s22 * M[2][j];
           }
-          for (int i = 0; i < 5; ++i) {
-            for (int q = 0; q < 5; ++q) { double s = H[i][q]; for (int r = 0; r < 5; ++r) s += A[r][i] * PA[r][q]; Hxx[i][q] = s; }
-            double s = gk[i]; for (int r = 0; r < 5; ++r) s += A[r][i] * Pd[r]; hx[i] = s;
+          Hxx[0][0] += h[0]; Hxx[1][1] += h[1]; Hxx[2][2] += h[2]; Hxx[3][3] += h[3]; Hxx[4][4] += h[4];
+          Hxx[0][1] += h[7]; Hxx[1][0] += h[7]; Hxx[0][2] += h[8]; Hxx[2][0] += h[8]; Hxx[1][2] += h[9]; Hxx[2][1] += h[9];
+          hx[0] = gk[0] + Pd[0]; hx[1] = gk[1] + Pd[1];
+          hx[2] = gk[2] + Pd[2] + s00 * Pd[0] + s10 * Pd[1];
+          hx[3] = gk[3] + Pd[3] + s01 * Pd[0] + s11 * Pd[1] + s21 * Pd[2];
+          hx[4] = gk[4] + Pd[4] + s02 * Pd[0] + s12 * Pd[1] + s22 * Pd[2];
+          double Hux[2][5], hu[2];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            Hux[0][j] = s03 * M[0][j] + s13 * M[1][j] + s23 * M[2][j] + dt * M[3][j];
+            Hux[1][j] = s04 * M[0][j] + s14 * M[1][j] + s24 * M[2][j] + dt * M[4][j];
           }
-          double rhs[2][6], sol[2][6];
-          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
-          sym2_solve6(Huu, rhs, sol);
+          Hux[1][3] += h[10];
+          const double a00 = h[5] + s03 * PB[0][0] + s13 * PB[1][0] + s23 * PB[2][0] + dt * PB[3][0];
+          const double a01 = s03 * PB[0][1] + s13 * PB[1][1] + s23 * PB[2][1] + dt * PB[3][1];
+          const double a11 = h[6] + s04 * PB[0][1] + s14 * PB[1][1] + s24 * PB[2][1] + dt * PB[4][1];
+          hu[0] = gk[5] + s03 * Pd[0] + s13 * Pd[1] + s23 * Pd[2] + dt * Pd[3];
+          hu[1] = gk[6] + s04 * Pd[0] + s14 * Pd[1] + s24 * Pd[2] + dt * Pd[4];
+          const double idet = 1.0 / (a00 * a11 - a01 * a01);
+          const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
+          double t0[6], t1[6];  // Huu^{-1} [Hux hu]
+#pragma unroll
+          for (int q = 0; q < 5; ++q) { t0[q] = i00 * Hux[0][q] + i01 * Hux[1][q]; t1[q] = i01 * Hux[0][q] + i11 * Hux[1][q]; }
+          t0[5] = i00 * hu[0] + i01 * hu[1]; t1[5] = i01 * hu[0] + i11 * hu[1];
           double *K = m + L.kk + k * 12;
-          for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) K[a * 5 + q] = -sol[a][q]; K[10 + a] = -sol[a][5]; }
+          for (int q = 0; q < 5; ++q) { K[q] = -t0[q]; K[5 + q] = -t1[q]; }
+          K[10] = -t0[5]; K[11] = -t1[5];
+#pragma unroll
           for (int i = 0; i < 5; ++i) {
-            for (int q = 0; q < 5; ++q) P[i][q] = Hxx[i][q] + Hux[0][i] * K[q] + Hux[1][i] * K[5 + q];
-            pv[i] = hx[i] + Hux[0][i] * K[10] + Hux[1][i] * K[11];
+#pragma unroll
+            for (int q = i; q < 5; ++q) {
+              const double v = 0.5 * (Hxx[i][q] + Hxx[q][i]) - (Hux[0][i] * t0[q] + Hux[1][i] * t1[q]);
+              P[i][q] = v; P[q][i] = v;
+            }
+            pv[i] = hx[i] - (Hux[0][i] * t0[5] + Hux[1][i] * t1[5]);
           }
-          for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { const double s = 0.5 * (P[i][q] + P[q][i]); P[i][q] = P[q][i] = s; }
+#pragma unroll
+          for (int i = 0; i < 38; ++i) buf[i] = nxt[i];
         }
+        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = P[i][q]; rp[i] = pv[i]; }
+      }
+    CFZ_END
+    CFZ_STAMP(11);  // Riccati backward sweep
+    // ---- forward step and costates (lane 0) -----------------------------------------------------------
+    CFZ_LANES(lane)
+      if (lane == 0) {
+        const double dt = sp.dt;
+        const double *pv = rp;
+        double P[5][5];
+        for (int i = 0; i < 5; ++i) for (int q = 0; q < 5; ++q) P[i][q] = rP[i * 5 + q];
         // forward sweep
         double *dp = m + L.dp;
         for (int i = 0; i < 5; ++i) dp[i] = m[L.x0 + i] - m[L.p + i];
         // multiplier of the initial-state row from the value function at stage 0
-        for (int i = 0; i < 5; ++i) { double s = pv[i]; for (int q = 0; q < 5; ++q) s += P[i][q] * dp[q]; m[L.dpi0 + i] = -s - m[L.pi0 + i]; }
-        for (int k = 0; k < N; ++k) {
+        for (int i = 0; i < 5; ++i) { double s_ = pv[i]; for (int q = 0; q < 5; ++q) s_ += P[i][q] * dp[q]; m[L.dpi0 + i] = -s_ - m[L.pi0 + i]; }
+        double z0 = dp[0], z1 = dp[1], z2 = dp[2], z3 = dp[3], z4 = dp[4];  // current dz kept in registers
+#pragma unroll 5
+        for (int k = 0; k < N; ++k) {  // unrolled so that the gain/dynamics loads of later stages are in flight early
           const double *K = m + L.kk + k * 12;
-          for (int a = 0; a < 2; ++a) { double s = K[10 + a]; for (int q = 0; q < 5; ++q) s += K[a * 5 + q] * dp[k * kNP + q]; dp[k * kNP + 5 + a] = s; }
+          const double u0 = K[10] + K[0] * z0 + K[1] * z1 + K[2] * z2 + K[3] * z3 + K[4] * z4;
+          const double u1 = K[11] + K[5] * z0 + K[6] * z1 + K[7] * z2 + K[8] * z3 + K[9] * z4;
+          dp[k * kNP + 5] = u0; dp[k * kNP + 6] = u1;
           if (k + 1 < N) {
-            double A[5][5], B[5][2];
-            load_AB(m, L, k, sp.dt, A, B);
-            for (int i = 0; i < 5; ++i) {
-              double s = m[L.d + k * 5 + i];
-              for (int q = 0; q < 5; ++q) s += A[i][q] * dp[k * kNP + q];
-              s += B[i][0] * dp[k * kNP + 5] + B[i][1] * dp[k * kNP + 6];
-              dp[(k + 1) * kNP + i] = s;
-            }
+            const double *s = m + L.ab + k * 15, *dk = m + L.d + k * 5;
+            const double n0 = dk[0] + z0 + s[0] * z2 + s[1] * z3 + s[2] * z4 + s[3] * u0 + s[4] * u1;
+            const double n1 = dk[1] + z1 + s[5] * z2 + s[6] * z3 + s[7] * z4 + s[8] * u0 + s[9] * u1;
+            const double n2 = dk[2] + z2 + s[11] * z3 + s[12] * z4 + s[13] * u0 + s[14] * u1;
+            const double n3 = dk[3] + z3 + dt * u0, n4 = dk[4] + z4 + dt * u1;
+            z0 = n0; z1 = n1; z2 = n2; z3 = n3; z4 = n4;
+            double *zn = dp + (k + 1) * kNP;
+            zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
           }
         }
         // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows)
         double lam[5] = {0, 0, 0, 0, 0};
+#pragma unroll 5
         for (int k = N - 1; k >= 1; --k) {
-          load_H(m, L, k, H);
+          const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *z = dp + k * kNP;
           double nl[5];
-          for (int i = 0; i < 5; ++i) {
-            double s = m[L.gk + k * kNP + i];
-            for (int q = 0; q < kNP; ++q) s += H[i][q] * dp[k * kNP + q];
-            nl[i] = s;
-          }
+          nl[0] = gk[0] + h[0] * z[0] + h[7] * z[1] + h[8] * z[2];
+          nl[1] = gk[1] + h[7] * z[0] + h[1] * z[1] + h[9] * z[2];
+          nl[2] = gk[2] + h[8] * z[0] + h[9] * z[1] + h[2] * z[2];
+          nl[3] = gk[3] + h[3] * z[3] + h[10] * z[6];
+          nl[4] = gk[4] + h[4] * z[4];
           if (k + 1 < N) {
-            double A[5][5], B[5][2];
-            load_AB(m, L, k, sp.dt, A, B);
-            for (int i = 0; i < 5; ++i) for (int r = 0; r < 5; ++r) nl[i] += A[r][i] * lam[r];
+            const double *s = m + L.ab + k * 15;
+            nl[0] += lam[0]; nl[1] += lam[1];
+            nl[2] += lam[2] + s[0] * lam[0] + s[5] * lam[1];
+            nl[3] += lam[3] + s[1] * lam[0] + s[6] * lam[1] + s[11] * lam[2];
+            nl[4] += lam[4] + s[2] * lam[0] + s[7] * lam[1] + s[12] * lam[2];
           }
           for (int i = 0; i < 5; ++i) { lam[i] = nl[i]; m[L.dpi + (k - 1) * 5 + i] = nl[i] - m[L.pi + (k - 1) * 5 + i]; }
         }
       }
     CFZ_END
+    CFZ_STAMP(5);  // Riccati
     // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
+    // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
+    // per bound and reused (a DP division is ~12 dependent instructions on this pipe).
     CFZ_LANES(lane)
-      double apri = 1.0, adual = 1.0, dphi = 0.0;
+      double rpri = 0.0, rdual = 0.0, dphi = 0.0;  // max of -dx/dist and -dz/z
       if (lane < N) {
         const int k = lane;
         const double *pk = m + L.p + k * kNP, *dpk = m + L.dp + k * kNP;
         double g[kNP];
-        stage_grad(sp, m + L.ref, k, pk, g);
+        stage_grad(sp, refg, k, pk, g);
         for (int q = 0; q < 6; ++q) {
           const double dx = dpk[bcol(q)];
-          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
           const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
-          g[bcol(q)] += -mu / dl + mu / du;
-          const double dzl = mu / dl - zl - zl / dl * dx, dzu = mu / du - zu_ + zu_ / du * dx;
-          if (dx < 0.0) apri = fmin(apri, -tau * dl / dx);
-          if (dx > 0.0) apri = fmin(apri, tau * du / dx);
-          if (dzl < 0.0) adual = fmin(adual, -tau * zl / dzl);
-          if (dzu < 0.0) adual = fmin(adual, -tau * zu_ / dzu);
+          g[bcol(q)] += mu * (iu - il);
+          const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
+          rpri = fmax(rpri, fmax(-dx * il, dx * iu));
+          rdual = fmax(rdual, fmax(-dzl / zl, -dzu / zu_));
         }
         for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
-          const double sg = m[L.sg + t], zs = m[L.zs + t];
-          const double ds = m[L.cj + t] + m[L.gra + t * 3] * dpk[0] + m[L.gra + t * 3 + 1] * dpk[1] + m[L.gra + t * 3 + 2] * dpk[2];
+          const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
+          const double *ga = m + L.gra + 4 * (t >> 1);
+          const double ds = m[L.cj + t] + ga[0] * dpk[0] + ga[1] * dpk[1] + ga[2 + (t & 1)] * dpk[2];
           m[L.dsg + t] = ds;
-          const double dzs = mu / sg - zs - zs / sg * ds;
-          dphi += -mu / sg * ds;
-          if (ds < 0.0) apri = fmin(apri, -tau * sg / ds);
-          if (dzs < 0.0) adual = fmin(adual, -tau * zs / dzs);
+          const double dzs = mu * isg - zs - zs * isg * ds;
+          dphi -= mu * isg * ds;
+          rpri = fmax(rpri, -ds * isg);
+          rdual = fmax(rdual, -dzs / zs);
         }
       }
-      m[L.red + 0 * 64 + lane] = apri; m[L.red + 1 * 64 + lane] = adual; m[L.red + 2 * 64 + lane] = dphi;
+      m[L.red + 0 * 64 + lane] = rpri; m[L.red + 1 * 64 + lane] = rdual; m[L.red + 2 * 64 + lane] = dphi;
     CFZ_END
-    const double a_pri = red_min(m, L, 0), a_dual = red_min(m, L, 1), dphi = red_sum(m, L, 2);
+    const double rp_max = red_max(m, L, 0), rd_max = red_max(m, L, 1);
+    const double a_pri = (rp_max > tau) ? tau / rp_max : 1.0, a_dual = (rd_max > tau) ? tau / rd_max : 1.0;
+    const double dphi = red_sum(m, L, 2);
+    CFZ_STAMP(6);  // step
     // ---- filter line search --------------------------------------------------------------------------------
     const double phi0 = fval - mu * logsum;
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; int accepted = 0, f_type = 0;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
       CFZ_LANES(lane)
-        merit_partials(sp, m, L, alpha, lane);
+        if (lane < N) sincos(m[L.p + lane * kNP + 2] + alpha * m[L.dp + lane * kNP + 2], &m[L.cs + 2 * lane + 1], &m[L.cs + 2 * lane]);
+      CFZ_END
+      CFZ_LANES(lane)
+        merit_partials(sp, refg, m, L, alpha, lane);
       CFZ_END
       const double th_t = red_sum(m, L, 0), ph_t = red_sum(m, L, 1) - mu * red_sum(m, L, 2);
       int ok = (red_max(m, L, 3) == 0.0) && isfinite(th_t) && isfinite(ph_t) && th_t <= theta_max;
@@ -752,6 +904,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       if (ok) { accepted = 1; break; }
       alpha *= 0.5;
     }
+    CFZ_STAMP(7);  // line search
     if (!accepted) { status = 2; break; }
     if (!f_type) {
       CFZ_LANES(lane)
@@ -769,32 +922,35 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       if (lane < N) {
         const int k = lane;
         double *pk = m + L.p + k * kNP; const double *dpk = m + L.dp + k * kNP;
+        const double ks = sp.kappa_sigma, iks = 1.0 / sp.kappa_sigma;
         for (int q = 0; q < 6; ++q) {
           const double dx = dpk[bcol(q)];
-          const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
+          const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
           const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
-          const double dzl = mu / dl - zl - zl / dl * dx, dzu = mu / du - zu_ + zu_ / du * dx;
+          const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
           const double xn = pk[bcol(q)] + alpha * dx;
-          const double dln = xn - sp.bounds[2 * q], dun = sp.bounds[2 * q + 1] - xn;
-          m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mu / (sp.kappa_sigma * dln)), sp.kappa_sigma * mu / dln);
-          m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mu / (sp.kappa_sigma * dun)), sp.kappa_sigma * mu / dun);
+          const double mln = mu / (xn - sp.bounds[2 * q]), mun = mu / (sp.bounds[2 * q + 1] - xn);  // mu / new distance
+          m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mln * iks), ks * mln);
+          m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mun * iks), ks * mun);
         }
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
-          const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t];
-          const double S = zs / sg + sp.reg_primal;
-          const double dnu = S * ds - mu / sg - m[L.nuc + t];
-          const double dzs = mu / sg - zs - zs / sg * ds;
-          const double sgn = sg + alpha * ds;
+          const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t], isg = 1.0 / sg;
+          const double S = zs * isg + sp.reg_primal;
+          const double dnu = S * ds - mu * isg - m[L.nuc + t];
+          const double dzs = mu * isg - zs - zs * isg * ds;
+          const double sgn = sg + alpha * ds, msn = mu / sgn;
           m[L.sg + t] = sgn; m[L.nuc + t] += alpha * dnu;
-          m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, mu / (sp.kappa_sigma * sgn)), sp.kappa_sigma * mu / sgn);
+          m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, msn * iks), ks * msn);
         }
         for (int i = 0; i < kNP; ++i) pk[i] += alpha * dpk[i];
         if (k + 1 < N) for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] += alpha * m[L.dpi + k * 5 + i];
       }
     CFZ_END
+    CFZ_STAMP(8);  // update
   }
 
+  CFZ_STAMP(10);
   // ---- write back: trajectory, separations, dual certificates ---------------------------------------------------
   CFZ_LANES(lane)
     for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
@@ -804,14 +960,15 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       double A[4][2], b[4], V[4][2], sep2[2];
       block_polygon(sp, m, L, k, j, A, b, V);
       const double psi = m[L.p + k * kNP + 2];
-      const int c1 = select_rows(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, (int)m[L.sel + t]);
-      rows_for<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], psi, sp.g, c1, sep2, nullptr);
+      double s, c;
+      sincos(psi, &s, &c);
+      const int c1 = select_rows(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, sel_ptr(m, L)[t]);
+      rows_for<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, c1, sep2, nullptr);
       const double sep = fmin(sep2[0], sep2[1]);
       const int cert = (c1 >> 6) * 16 + ((c1 >> 4) & 3) * 4 + (sep2[0] <= sep2[1] ? ((c1 >> 2) & 3) : (c1 & 3));
       smin = fmin(smin, sep);
       if (duo.l) {
         const int kind = cert >> 4, f = (cert >> 2) & 3;
-        const double c = cos(psi), s = sin(psi);
         double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
         if (j < n_obs) {
           if (kind == 1) {  // n = A_f ; G' mu = -R' n
@@ -864,6 +1021,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   CFZ_END
   out_d[0] = fval_last; out_d[1] = err0; out_d[2] = red_min(m, L, 0);
   out_i[0] = iter; out_i[1] = status;
+  CFZ_STAMP(10);  // output
+#if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  if (duo.stamps && threadIdx.x == 0) for (int i = 0; i < 12; ++i) duo.stamps[i] = stamp_acc[i];
+#endif
 }
 
 }  // namespace cfz

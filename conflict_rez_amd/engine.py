@@ -108,6 +108,7 @@ def load_library(path=None):
     lib.cfz_create.argtypes = [C.POINTER(_CSpec), C.POINTER(_COptions), C.c_int, C.c_int, C.POINTER(vp)]
     lib.cfz_destroy.argtypes = [vp]
     lib.cfz_max_batch.argtypes = [vp]
+    lib.cfz_kernel_info.argtypes = [vp, vp, vp]
     lib.cfz_mpc_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.cfz_mpc_set_warm.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
@@ -124,7 +125,7 @@ def load_library(path=None):
 
 
 EXPORTS = (
-    "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_mpc_set_params cfz_mpc_set_warm "
+    "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
     "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_loop_init cfz_loop_step "
     "cfz_loop_get cfz_last_error"
 ).split()
@@ -203,6 +204,12 @@ class Engine:
                                         _ptr(out["kkt_err"]), _ptr(out["min_sep"])), "cfz_mpc_stats")
         out["solve_ms"] = self.last_solve_ms()
         return out
+
+    def kernel_info(self):
+        """(LDS bytes per instance, resident instances per CU)."""
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.lib.cfz_kernel_info(self._h, C.byref(a), C.byref(b)), "cfz_kernel_info")
+        return a.value, b.value
 
     def last_solve_ms(self):
         return float(self.lib.cfz_last_solve_ms(self._h))

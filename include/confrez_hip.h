@@ -72,6 +72,8 @@ void cfz_default_options(cfz_options *opt);  /* reference s_opts + IPOPT default
 int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out);
 int cfz_destroy(cfz_handle *h);
 int cfz_max_batch(const cfz_handle *h);
+/* LDS bytes one instance (= one wavefront) occupies and how many instances the runtime keeps resident per CU. */
+int cfz_kernel_info(const cfz_handle *h, int32_t *lds_bytes_per_instance, int32_t *instances_per_cu);
 
 /* opti.set_value(current_x..current_delta, current_ref_*, p_other_pred[*]) (:432-456).
  * x0[B][5]; ref[B][3][N] rows x,y,psi; nbr[B][n_nbr][3][N] (already advanced by the caller

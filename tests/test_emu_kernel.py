@@ -25,7 +25,7 @@ def test_kernel_source_matches_oracle_on_goldens(golden, ospec):
         r = emu.solve(ospec, opt, golden["x0"][b], golden["ref"][b], golden["nbr"][b], golden["zu"][b])
         assert r["status"] == int(meta[b, 0]) and r["iters"] == int(meta[b, 1]), b
         if r["status"] == 0:
-            assert np.abs(r["zu"] - golden["sol"][b]).max() < 1e-8
+            assert np.abs(r["zu"] - golden["sol"][b]).max() < 1e-7
             assert np.isclose(r["cost"], meta[b, 2], rtol=1e-9) and np.isclose(r["min_sep"], meta[b, 3], atol=1e-8)
             res = reference_residuals(ospec, golden["x0"][b], golden["ref"][b], golden["nbr"][b], _sol(r))
             assert res["eq"] < 1e-2 and res["ineq"] < 1e-2 and res["bound"] == 0.0
@@ -48,7 +48,7 @@ def test_kernel_source_other_shapes(ospec):
             r2 = emu.solve(osp, opt, x0[b], ref[b], nbr[b], zu[b])
             assert (r1["status"], r1["iters"]) == (r2["status"], r2["iters"])
             if r1["status"] == 0:
-                assert np.abs(r1["p"].T - r2["zu"]).max() < 1e-8
+                assert np.abs(r1["p"].T - r2["zu"]).max() < 1e-7
 
 
 def test_kernel_source_under_sanitizers(golden, ospec, tmp_path):

@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-7
+TOL = 1e-7  # states x, y, psi, v, delta
+TOL_U = 1e-5  # inputs a, w: w is almost undetermined where v ~ 0 ((v w)^2 is its only cost), rounding shows there
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +31,8 @@ def test_golden_vectors(eng, golden):
     assert out["status"].tolist() == meta[:, 0].astype(int).tolist()
     ok = out["status"] == 0
     assert out["iters"][ok].tolist() == meta[ok, 1].astype(int).tolist()
-    assert np.abs(out["zu"][ok] - golden["sol"][ok]).max() < TOL
+    assert np.abs(out["zu"][ok][:, :5] - golden["sol"][ok][:, :5]).max() < TOL
+    assert np.abs(out["zu"][ok][:, 5:] - golden["sol"][ok][:, 5:]).max() < TOL_U
     assert np.allclose(out["cost"][ok], meta[ok, 2], rtol=1e-9, atol=1e-9)
     assert np.allclose(out["min_sep"][ok], meta[ok, 3], atol=1e-7)
     assert (out["status"] == 4).sum() == (meta[:, 0] == 4).sum() >= 1  # the infeasible-x0 fixture is detected
@@ -51,7 +53,8 @@ def test_matches_c_port_on_seeded_batch(eng, ospec):
         if r["status"] == 0:
             n_ok += 1
             assert r["iters"] == out["iters"][b]
-            assert np.abs(r["p"].T - out["zu"][b]).max() < TOL
+            assert np.abs(r["p"].T[:5] - out["zu"][b][:5]).max() < TOL
+            assert np.abs(r["p"].T[5:] - out["zu"][b][5:]).max() < TOL_U
     assert n_ok >= len(x0) // 2
 
 
