@@ -37,10 +37,11 @@ struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 
 __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
-                                                   int32_t *iters, double *stats, DualPtrs du) {
+                                                   int32_t *iters, double *stats, DualPtrs du, const int32_t *order) {
   extern __shared__ double smem[];
-  const int b = blockIdx.x;
-  if (b >= B) return;
+  if ((int)blockIdx.x >= B) return;
+  // workgroups are dispatched in index order: `order` puts the instances expected to run longest first
+  const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   const int N = sp.N, no = sp.n_obs, nn = sp.n_nbr;
   int oi[2]; double od[3];
   cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -104,6 +105,21 @@ __global__ void loop_post(int S, int V, int N, double dt, double wb, int plant_s
   if (b % V == 0) kidx[b / V] += 1;
 }
 
+// Longest-processing-time-first dispatch order for the next step: instances sorted by the iteration count of
+// the step just finished, descending (counting sort, one workgroup).  The solve of an instance does not depend
+// on where it runs, only the makespan of the launch does.
+__global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *iters, int32_t *order) {
+  __shared__ int hist[1024];
+  const int t = threadIdx.x;
+  hist[t] = 0;
+  __syncthreads();
+  for (int b = t; b < B; b += 1024) atomicAdd(&hist[1023 - min(iters[b], 1023)], 1);
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int i = 0; i < 1024; ++i) { const int c = hist[i]; hist[i] = acc; acc += c; } }
+  __syncthreads();
+  for (int b = t; b < B; b += 1024) order[atomicAdd(&hist[1023 - min(iters[b], 1023)], 1)] = b;
+}
+
 // first prediction = the planned trajectory at the horizon times, as get_current_ref seeds it
 // (:397-400); state = planned state at k0 + noise
 __global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
@@ -138,7 +154,8 @@ struct cfz_handle {
   // closed loop
   int S = 0, T = 0;
   double *ref_table = nullptr, *pred = nullptr, *state = nullptr;
-  int32_t *kidx = nullptr;
+  int32_t *kidx = nullptr, *order = nullptr;
+  bool have_order = false;
 };
 
 namespace {
@@ -159,12 +176,13 @@ bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
 }
 
 int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr, double *zu,
-                 int32_t *status, int32_t *iters, double *stats, bool duals, hipStream_t st) {
+                 int32_t *status, int32_t *iters, double *stats, bool duals, hipStream_t st,
+                 const int32_t *order = nullptr) {
   DualPtrs du = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
   HIP_OK(hipEventRecord(h->ev0, st));
   hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(64), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
-                     iters, stats, du);
+                     iters, stats, du, order);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   return 0;
@@ -265,7 +283,7 @@ int cfz_destroy(cfz_handle *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
-                  h->ref_table, h->pred, h->state, h->kidx};
+                  h->ref_table, h->pred, h->state, h->kidx, h->order};
   for (void *p : bufs) if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -354,12 +372,13 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   if (S < 1 || (long)S * V > h->max_batch) return fail("S * (n_nbr+1) exceeds max_batch");
   if (T < 1 || !ref_table || !k0) return fail("bad reference table");
   HIP_OK(hipSetDevice(h->device));
-  for (void *p : {(void *)h->ref_table, (void *)h->pred, (void *)h->state, (void *)h->kidx}) if (p) hipFree(p);
-  h->ref_table = h->pred = h->state = nullptr; h->kidx = nullptr;
+  for (void *p : {(void *)h->ref_table, (void *)h->pred, (void *)h->state, (void *)h->kidx, (void *)h->order}) if (p) hipFree(p);
+  h->ref_table = h->pred = h->state = nullptr; h->kidx = nullptr; h->order = nullptr; h->have_order = false;
   h->S = S; h->T = T;
   const size_t B = (size_t)S * V;
   HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 7 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
   HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
+  HIP_OK(hipMalloc(&h->order, B * 4));
   HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
   double *dn = nullptr;
@@ -381,7 +400,11 @@ int cfz_loop_step(cfz_handle *h) {
   hipLaunchKernelGGL(loop_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, S, V, N, h->T, h->ref_table,
                      h->kidx, h->pred, h->state, h->x0, h->ref, h->nbr, h->zu);
   HIP_OK(hipGetLastError());
-  if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, false, h->stream)) return -1;
+  if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, false, h->stream,
+                   h->have_order ? h->order : nullptr)) return -1;
+  hipLaunchKernelGGL(order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->iters, h->order);
+  HIP_OK(hipGetLastError());
+  h->have_order = true;
   hipLaunchKernelGGL(loop_post, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, S, V, N, h->ks.dt, h->ks.wb, 100,
                      h->status, h->zu, h->pred, h->state, h->kidx);
   HIP_OK(hipGetLastError());

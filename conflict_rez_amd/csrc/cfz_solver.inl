@@ -87,10 +87,11 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.sg = o; o += N * nr; L.nuc = o; o += N * nr; L.zs = o; o += N * nr;
   L.zl = o; o += N * 6; L.zu = o; o += N * 6;
   L.pi0 = o; o += 5; L.pi = o; o += N * 5;
-  L.dp = o; o += N * kNP; L.dpi0 = o; o += 5; L.dpi = o; o += N * 5;
+  L.dp = o; o += N * kNP; L.dpi0 = o; o += 5;
   L.cj = o; o += N * nr; L.dsg = L.cj;  // the slack step overwrites the row residual it is computed from
   L.gra = o; o += N * nb * 4;           // per block: shared (d/dx, d/dy) and the two d/dpsi
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
+  L.dpi = L.d;  // the costate sweep (last reader of the defects d_k was the forward sweep) overwrites them with d(pi)
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
   L.sel = o; o += (N * nb + 1) / 2;  // working set codes, int32
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
@@ -709,22 +710,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         const double dt = sp.dt;
         double P[5][5], pv[5];
         for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) P[i][q] = rP[i * 5 + q]; pv[i] = rp[i]; }
-        // stage data (A/B entries, H, g, defect: 38 doubles) of stage k-1 is fetched while stage k computes
-        double buf[38], nxt[38];
-        {
-          const int k = N - 2;
-          for (int i = 0; i < 15; ++i) buf[i] = m[L.ab + k * 15 + i];
-          for (int i = 0; i < 11; ++i) buf[15 + i] = m[L.hc + k * 11 + i];
-          for (int i = 0; i < 7; ++i) buf[26 + i] = m[L.gk + k * kNP + i];
-          for (int i = 0; i < 5; ++i) buf[33 + i] = m[L.d + k * 5 + i];
-        }
         for (int k = N - 2; k >= 0; --k) {
-          const int kn = k > 0 ? k - 1 : 0;
-          for (int i = 0; i < 15; ++i) nxt[i] = m[L.ab + kn * 15 + i];
-          for (int i = 0; i < 11; ++i) nxt[15 + i] = m[L.hc + kn * 11 + i];
-          for (int i = 0; i < 7; ++i) nxt[26 + i] = m[L.gk + kn * kNP + i];
-          for (int i = 0; i < 5; ++i) nxt[33 + i] = m[L.d + kn * 5 + i];
-          const double *s = buf, *h = buf + 15, *gk = buf + 26, *dk = buf + 33;
+          const double *s = m + L.ab + k * 15, *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *dk = m + L.d + k * 5;
           const double s00 = s[0], s01 = s[1], s02 = s[2], s03 = s[3], s04 = s[4];
           const double s10 = s[5], s11 = s[6], s12 = s[7], s13 = s[8], s14 = s[9];
           const double s21 = s[11], s22 = s[12], s23 = s[13], s24 = s[14];
@@ -783,8 +770,6 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
             }
             pv[i] = hx[i] - (Hux[0][i] * t0[5] + Hux[1][i] * t1[5]);
           }
-#pragma unroll
-          for (int i = 0; i < 38; ++i) buf[i] = nxt[i];
         }
         for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = P[i][q]; rp[i] = pv[i]; }
       }
