@@ -3,9 +3,9 @@
 Built in this round: the constructor (:29-52), the collocation tables (`collocation_coefficients`
 :54-97), the warm-start resampling (`interp_ws_for_collocation` :298-358), the Lagrange
 interpolant of a collocation solution (`get_interpolator` :722-786, `interpolate_states`
-:788-829) -- all numpy, no CasADi.  The three planning NLPs (`state_ws` :99-231, `dual_ws`
-:233-296, `setup/solve_single_final_problem` :360-661) are the next rows of the coverage
-table (SURVEY.md 8a V2/V3/V5, DESIGN.md "Next"); until their kernels land they raise
+:788-829) -- all numpy, no CasADi.  `dual_ws` (:233-296) runs on the GPU in closed form (`cfz_dual_ws`).  The two planning NLPs
+(`state_ws` :99-231, `setup/solve_single_final_problem` :360-661) are the next rows of the coverage
+table (SURVEY.md 8a V2/V5, DESIGN.md "Next"); until their kernels land they raise
 `NotImplementedError` and a reference trajectory is supplied with `set_reference_trajectory`.
 """
 from typing import Dict, Tuple
@@ -72,7 +72,19 @@ class Vehicle:
         raise NotImplementedError("state_ws (vehicle.py:99-231) has no HIP kernel yet; see DESIGN.md 'Next'")
 
     def dual_ws(self, zu0: VehiclePrediction, verbose: int = 0) -> VehiclePrediction:
-        raise NotImplementedError("dual_ws (vehicle.py:233-296) has no HIP kernel yet; see DESIGN.md 'Next'")
+        """Warm start of the OBCA duals for the fixed poses of `zu0` (vehicle.py:233-296): fills
+        `zu0.l`, `zu0.m` as [4 n_obs, T+1] arrays, like `sol.value(l)`, `sol.value(m)` (:293-294).
+        One GPU thread per (pose, obstacle): closed-form separation certificates (`cfz_dual_ws`)."""
+        from ..engine import Engine, ProblemSpec
+
+        if getattr(self, "_dual_engine", None) is None:
+            spec = ProblemSpec.from_objects(self.obstacles, self.vehicle_body, self.vehicle_config, self.region,
+                                            n_nbr=0, N=2)
+            self._dual_engine = Engine(spec, max_batch=1)
+        poses = np.stack([np.asarray(zu0.x, float), np.asarray(zu0.y, float), np.asarray(zu0.psi, float)], 1)
+        l, m, _ = self._dual_engine.dual_ws(poses)
+        zu0.l, zu0.m = l.T.copy(), m.T.copy()
+        return zu0
 
     def setup_single_final_problem(self, *args, **kwargs):
         raise NotImplementedError("collocation NLP (vehicle.py:360-640) has no HIP kernel yet; see DESIGN.md 'Next'")

@@ -120,6 +120,48 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
   for (int b = t; b < B; b += 1024) order[atomicAdd(&hist[1023 - min(iters[b], 1023)], 1)] = b;
 }
 
+// dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
+// pair and the separation it certifies -- closed form over the face normals of both polygons (the
+// reference maximises the same separation with IPOPT over lambda, mu).  One thread per pair.
+__global__ void dual_ws_kernel(const cfz::KSpec sp, int n, const double *poses, double *l, double *mu_out, double *d) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int no = sp.n_obs;
+  if (tid >= n * no) return;
+  const int k = tid / no, j = tid - k * no;
+  double A[4][2], b[4], V[4][2];
+  for (int i = 0; i < 4; ++i) {
+    A[i][0] = sp.A_obs[j][i][0]; A[i][1] = sp.A_obs[j][i][1]; b[i] = sp.b_obs[j][i];
+    V[i][0] = sp.V_obs[j][i][0]; V[i][1] = sp.V_obs[j][i][1];
+  }
+  const double x = poses[k * 3], y = poses[k * 3 + 1], psi = poses[k * 3 + 2];
+  double s, c, sep2[2];
+  sincos(psi, &s, &c);
+  const int sel = cfz::select_rows(A, b, V, x, y, c, s, sp.g, 0);
+  cfz::rows_for<false>(A, b, V, x, y, c, s, sp.g, sel, sep2, nullptr);
+  const int kind = sel >> 6, f = (sel >> 4) & 3, v = sep2[0] <= sep2[1] ? (sel >> 2) & 3 : sel & 3;
+  double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
+  if (kind == 1) {  // n = A_f ; G' mu = -R' n
+    lam[f] = 1.0;
+    const double mx = -(c * A[f][0] + s * A[f][1]), my = -(-s * A[f][0] + c * A[f][1]);
+    muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
+  } else {  // n = -R G_f ; A' lam = n from the two obstacle faces through vertex v
+    muv[f] = 1.0;
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    const double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
+    int i0 = 0, i1 = 1; double r0 = INFINITY, r1 = INFINITY;
+    for (int i = 0; i < 4; ++i) {
+      const double r = fabs(A[i][0] * V[v][0] + A[i][1] * V[v][1] - b[i]);
+      if (r < r0) { r1 = r0; i1 = i0; r0 = r; i0 = i; } else if (r < r1) { r1 = r; i1 = i; }
+    }
+    const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
+    const double det = A[ia][0] * A[ib][1] - A[ib][0] * A[ia][1];
+    lam[ia] = fmax((A[ib][1] * nx - A[ib][0] * ny) / det, 0.0);
+    lam[ib] = fmax((-A[ia][1] * nx + A[ia][0] * ny) / det, 0.0);
+  }
+  for (int i = 0; i < 4; ++i) { l[(size_t)k * 4 * no + 4 * j + i] = lam[i]; mu_out[(size_t)k * 4 * no + 4 * j + i] = muv[i]; }
+  if (d) d[(size_t)k * no + j] = fmin(sep2[0], sep2[1]);
+}
+
 // first prediction = the planned trajectory at the horizon times, as get_current_ref seeds it
 // (:397-400); state = planned state at k0 + noise
 __global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
@@ -364,6 +406,27 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
   if (!d_x0 || !d_ref || !d_zu || !d_status || !d_iters || !d_stats) return fail("null device pointer");
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   return launch_solve(h, B, d_x0, d_ref, d_nbr ? d_nbr : h->nbr, d_zu, d_status, d_iters, d_stats, false, st);
+}
+
+int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d) {
+  if (!h) return fail("null handle");
+  if (n < 1 || !poses || !l || !m) return fail("bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  const size_t no = h->ks.n_obs;
+  if (no == 0) return 0;
+  double *dp = nullptr, *dl = nullptr, *dm = nullptr, *dd = nullptr;
+  HIP_OK(hipMalloc(&dp, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dl, (size_t)n * 4 * no * 8));
+  HIP_OK(hipMalloc(&dm, (size_t)n * 4 * no * 8)); HIP_OK(hipMalloc(&dd, (size_t)n * no * 8));
+  HIP_OK(hipMemcpy(dp, poses, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
+  const int nt = n * (int)no;
+  hipLaunchKernelGGL(dual_ws_kernel, dim3((nt + 127) / 128), dim3(128), 0, h->stream, h->ks, n, dp, dl, dm, dd);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(l, dl, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(m, dm, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost));
+  if (d) HIP_OK(hipMemcpy(d, dd, (size_t)n * no * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dp); (void)hipFree(dl); (void)hipFree(dm); (void)hipFree(dd);
+  return 0;
 }
 
 int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const int32_t *k0, const double *noise) {

@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.cfz_last_solve_ms.argtypes = [vp]
     lib.cfz_last_solve_ms.restype = C.c_double
     lib.cfz_mpc_solve_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cfz_dual_ws.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.cfz_loop_init.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.cfz_loop_step.argtypes = [vp]
     lib.cfz_loop_get.argtypes = [vp, vp, vp, vp, vp]
@@ -126,7 +127,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_loop_init cfz_loop_step "
+    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -220,6 +221,16 @@ class Engine:
         self._ck(self.lib.cfz_mpc_solve_device(self._h, int(B), ptr(d_x0), ptr(d_ref), ptr(d_nbr), ptr(d_zu),
                                                ptr(d_status), ptr(d_iters), ptr(d_stats),
                                                None if stream is None else C.c_void_p(int(stream))), "cfz_mpc_solve_device")
+
+    # ---- dual warm start (Vehicle.dual_ws) ------------------------------------------------------------
+    def dual_ws(self, poses):
+        """poses [n,3] (x,y,psi) -> (l [n,4 n_obs], m [n,4 n_obs], d [n,n_obs])."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        n, no = poses.shape[0], self.spec.n_obs
+        poses = _f64(poses, (n, 3))
+        l, m, d = np.zeros((n, 4 * no)), np.zeros((n, 4 * no)), np.zeros((n, no))
+        self._ck(self.lib.cfz_dual_ws(self._h, n, _ptr(poses), _ptr(l), _ptr(m), _ptr(d)), "cfz_dual_ws")
+        return l, m, d
 
     # ---- batched closed loop ------------------------------------------------------------------------
     def loop_init(self, ref_table, k0, noise=None):

@@ -109,6 +109,15 @@ double cfz_last_solve_ms(const cfz_handle *h);
 int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double *d_ref, const double *d_nbr,
                          double *d_zu, int32_t *d_status, int32_t *d_iters, double *d_stats, void *stream);
 
+/* ---- dual warm start ----------------------------------------------------------------------
+ * Vehicle.dual_ws (confrez/control/vehicle.py:233-296): for n fixed poses[n][3] = (x, y, psi) the duals
+ * l, m [n][4*n_obs] that certify the separation d[n][n_obs] (may be NULL) of the vehicle body from every
+ * static obstacle of the handle's spec.  The reference maximises that separation with IPOPT
+ * (tol 1e-8); here it is the closed-form maximum over the face normals of both polygons, which
+ * satisfies the same rows (:276-280) exactly and equals the optimum whenever the closest features
+ * are a face and a vertex. */
+int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d);
+
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
  * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt
