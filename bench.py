@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--scenarios", type=int, default=1024, help="scenarios per GPU (x4 vehicles)")
     ap.add_argument("--max-iter", type=int, default=600, help="IPM iteration limit (reference: 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["persistent", "step"], default="persistent",
+                    help="persistent: K iterations in one launch, scenarios advance independently (cfz_loop_run); "
+                         "step: one launch per iteration with a device-wide barrier in between (cfz_loop_step)")
+    ap.add_argument("--count-iters", action="store_true", help="step mode: also sum the IPM iterations (adds a read-back)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,15 +98,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.loop_step()  # blocks until the step is complete on the device
+    persistent = args.mode == "persistent"
+    if persistent:
+        if args.warmup > 0:
+            eng.loop_run(args.warmup)  # blocks until all scenarios have done `warmup` iterations
+    else:
+        for _ in range(args.warmup):
+            eng.loop_step()  # blocks until the step is complete on the device
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
     n_ok = 0
-    for _ in range(args.steps):
-        eng.loop_step()
-        kernel_ms += eng.last_solve_ms()
+    if persistent:
+        ipm_iterations = eng.loop_run(args.steps)  # K iterations of every scenario, one launch
+        kernel_ms = eng.last_solve_ms()
+        launches = 1
+    else:
+        ipm_iterations = 0
+        for _ in range(args.steps):
+            eng.loop_step()
+            kernel_ms += eng.last_solve_ms()
+            ipm_iterations += int(eng.loop_get()["iters"].sum()) if args.count_iters else 0
+        launches = args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     got = eng.loop_get()
@@ -122,8 +139,9 @@ def main():
     if rank == 0:
         B = S * V
         solves = B * world * args.steps
-        kern_s = kernel_ms / 1e3 / max(args.steps, 1)  # average solver-kernel duration per launch
-        achieved = B * ALG_BYTES_PER_SOLVE / kern_s / 1e9
+        kern_s = kernel_ms / 1e3 / launches  # average solver-kernel duration per launch
+        solves_per_launch = B * args.steps // launches
+        achieved = solves_per_launch * ALG_BYTES_PER_SOLVE / kern_s / 1e9
         line = {
             "metric": "OBCA MPC-step solves/sec (4 vehicles, N=30)",
             "value": solves / elapsed,
@@ -140,12 +158,14 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 4-vehicle distributed MPC (VehicleFollower.step), "
                                    "N=30, 6 obstacles, closed loop on device", "scenarios_per_gpu": S,
                        "solves_per_step_per_gpu": B, "parallelism": f"scenario-sharded x{world}",
-                       "max_iter": args.max_iter, "converged_last_step": n_ok / (B * world),
+                       "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
+                       "ipm_iterations_rank0": ipm_iterations,
                        "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
                        "lds_bytes_per_instance": eng.kernel_info()[0], "instances_per_cu": eng.kernel_info()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "solve_kernel", "kernel_ms_per_launch": kern_s * 1e3,
+                         "kernel": "loop_kernel" if persistent else "solve_kernel",
+                         "kernel_ms_per_launch": kern_s * 1e3, "solves_per_launch": solves_per_launch,
                          "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "latency/FP64-issue bound: the iterate lives in LDS, so algorithmic HBM bytes "
                                  "are ~1e-5 of peak by construction (SURVEY.md 8d); see DESIGN.md"},

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -86,6 +87,11 @@ __global__ void loop_prep(int S, int V, int N, int T, const double *ref_table, c
   }
 }
 
+__global__ void advance_clock(int S, int K, int32_t *kidx) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) kidx[s] += K;
+}
+
 // One thread per instance: accept the solution or shift the old prediction, integrate the plant.
 __global__ void loop_post(int S, int V, int N, double dt, double wb, int plant_substeps, const int32_t *status,
                           const double *zu, double *pred, double *state, int32_t *kidx) {
@@ -118,6 +124,99 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
   if (t == 0) { int acc = 0; for (int i = 0; i < 1024; ++i) { const int c = hist[i]; hist[i] = acc; acc += c; } }
   __syncthreads();
   for (int b = t; b < B; b += 1024) order[atomicAdd(&hist[1023 - min(iters[b], 1023)], 1)] = b;
+}
+
+// ---- persistent closed loop -----------------------------------------------------------------------
+// K MPC iterations of every scenario in ONE launch.  The Jacobi exchange only couples the V vehicles of a
+// scenario, so there is no reason to stop the whole GPU after every iteration: work items (scenario, vehicle,
+// iteration t) sit in a queue; a wavefront pops one, builds its parameters from the scenario's predictions of
+// iteration t-1, solves, writes prediction t and the new plant state, and the last of the V vehicles to finish
+// iteration t publishes the V items of t+1.  Hard instances then delay only their own scenario.
+//   queue[total]  item = (s*V + v) | t << 20 ... stored as (t * B + b), -1 = not yet published; used once each
+//   ctrl[0] head (next queue index to pop)   ctrl[1] tail (next free queue index)   ctrl[2] error flag
+//   done[S]       finished vehicles of the scenario (monotone: iteration t is complete at (t+1)*V)
+//   pred[2][B][7][N] double-buffered by iteration parity (read t%2, write (t+1)%2)
+// Hand-offs between workgroups follow the agent-scope release/acquire recipe: payload stores, __threadfence()
+// (release), device-scope atomic; consumer: atomic load of the item, __threadfence() (acquire), payload loads.
+__global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
+                                                  const double *ref_table, const int32_t *kidx0, int t_base,
+                                                  double *pred, double *state, double *scratch, int32_t *queue,
+                                                  int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
+                                                  double *stats, int32_t *iter_sum) {
+  extern __shared__ double smem[];
+  __shared__ int s_item;
+  const int N = sp.N, nn = sp.n_nbr, B = S * V, total = B * K, lane = threadIdx.x;
+  double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
+  double *x0 = my, *ref = x0 + 5, *nbr = ref + 3 * N, *zu = nbr + nn * 3 * N;
+  while (true) {
+    if (lane == 0) {
+      int item = -2;
+      const int idx = atomicAdd(&ctrl[0], 1);
+      if (idx < total) {
+        int spins = 0;
+        while ((item = __hip_atomic_load(&queue[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 23) || __hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { item = -2; atomicExch(&ctrl[2], 1); break; }
+        }
+      }
+      s_item = item;
+    }
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();
+    if (item < 0) break;
+    __threadfence();  // acquire: predictions / states written by other workgroups
+    const int t = item / B, b = item - t * B, s = b / V, v = b - s * V;
+    const double *pin = pred + (size_t)(t & 1) * B * 7 * N;   // predictions after iteration t-1
+    double *pout = pred + (size_t)((t + 1) & 1) * B * 7 * N;
+    // ---- parameters and shifted warm start (vehicle_follower.py:432-476) -------------------------------
+    if (lane < 5) x0[lane] = state[b * 5 + lane];
+    for (int k = lane; k < N; k += 64) {
+      const int ka = (k + 1 < N) ? k + 1 : N - 1;
+      int kr = kidx0[s] + t_base + t + k; if (kr > T - 1) kr = T - 1;
+      for (int c = 0; c < 3; ++c) ref[c * N + k] = ref_table[((size_t)v * T + kr) * 7 + c];
+      for (int c = 0; c < 7; ++c) zu[c * N + k] = pin[((size_t)b * 7 + c) * N + ka];
+      int o = 0;
+      for (int u = 0; u < V; ++u) {
+        if (u == v) continue;
+        const size_t bo = (size_t)s * V + u;
+        for (int c = 0; c < 3; ++c) nbr[(o * 3 + c) * N + k] = pin[(bo * 7 + c) * N + ka];
+        ++o;
+      }
+    }
+    __syncthreads();
+    int oi[2]; double od[3];
+    cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo);
+    __syncthreads();
+    // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
+    for (int i = lane; i < 7 * N; i += 64) {
+      const int c = i / N, k = i - c * N;
+      const int ka = (k + 1 < N) ? k + 1 : N - 1;
+      pout[(size_t)b * 7 * N + i] = (oi[1] == 0) ? zu[i] : pin[((size_t)b * 7 + c) * N + ka];
+    }
+    if (lane == 0) {
+      const double a0 = (oi[1] == 0) ? zu[5 * N] : pin[((size_t)b * 7 + 5) * N + 1];
+      const double w0 = (oi[1] == 0) ? zu[6 * N] : pin[((size_t)b * 7 + 6) * N + 1];
+      double z[5], out[5];
+      for (int i = 0; i < 5; ++i) z[i] = x0[i];
+      cfz::rk4_step<false>(z, a0, w0, sp.dt, sp.wb, 100, out, nullptr);
+      for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
+      status[b] = oi[1]; iters[b] = oi[0];
+      stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
+      atomicAdd(iter_sum, oi[0]);
+    }
+    __syncthreads();
+    __threadfence();  // release: prediction and state of (s, v, t)
+    if (lane == 0) {
+      const int c = atomicAdd(&done[s], 1);
+      if ((c % V) == V - 1 && t + 1 < K) {  // last vehicle of the scenario: publish iteration t+1
+        const int pos = atomicAdd(&ctrl[1], V);
+        for (int u = 0; u < V; ++u)
+          __hip_atomic_store(&queue[pos + u], (t + 1) * B + s * V + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -198,6 +297,11 @@ struct cfz_handle {
   double *ref_table = nullptr, *pred = nullptr, *state = nullptr;
   int32_t *kidx = nullptr, *order = nullptr;
   bool have_order = false;
+  // persistent loop
+  double *pred2 = nullptr, *scratch = nullptr;
+  int32_t *queue = nullptr, *ctrl = nullptr, *done = nullptr, *iter_sum = nullptr;
+  int queue_cap = 0, grid_blocks = 0, steps_done = 0;
+  long last_iter_sum = 0;
 };
 
 namespace {
@@ -257,7 +361,7 @@ void cfz_default_options(cfz_options *o) {
   memset(o, 0, sizeof *o);
   o->max_iter = 600; o->max_backtrack = 25; o->filter_cap = 16;
   o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->dual_inf_tol = 1.0; o->compl_inf_tol = 1e-4;
-  o->mu_init = 0.1; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99;
+  o->mu_init = 1e-3; o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->tau_min = 0.99;
   o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
   o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
   o->reg_primal = 1e-8;
@@ -304,6 +408,8 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   if (h->lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
+    e = hipFuncSetAttribute((const void *)loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+    if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
   }
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, 64, h->lds_bytes);
   const size_t B = (size_t)max_batch, N = (size_t)k.N, no = (size_t)k.n_obs, nn = (size_t)k.n_nbr;
@@ -325,7 +431,8 @@ int cfz_destroy(cfz_handle *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
-                  h->ref_table, h->pred, h->state, h->kidx, h->order};
+                  h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
+                  h->iter_sum};
   for (void *p : bufs) if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -442,6 +549,8 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 7 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
   HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
   HIP_OK(hipMalloc(&h->order, B * 4));
+  for (void *p : {(void *)h->pred2, (void *)h->scratch, (void *)h->queue, (void *)h->ctrl, (void *)h->done, (void *)h->iter_sum}) if (p) (void)hipFree(p);
+  h->pred2 = h->scratch = nullptr; h->queue = h->ctrl = h->done = h->iter_sum = nullptr; h->queue_cap = 0; h->steps_done = 0;
   HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
   double *dn = nullptr;
@@ -475,6 +584,69 @@ int cfz_loop_step(cfz_handle *h) {
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   return 0;
 }
+
+int cfz_loop_run(cfz_handle *h, int K) {
+  if (!h || !h->pred) return fail("cfz_loop_init has not been called");
+  if (K < 1) return fail("K must be positive");
+  HIP_OK(hipSetDevice(h->device));
+  const int V = h->ks.n_nbr + 1, N = h->ks.N, S = h->S, B = S * V;
+  const size_t total = (size_t)B * K;
+  if (total > (size_t)1 << 30) return fail("too many work items");
+  int ncu = 0;
+  HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+  int per_cu = 0;
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)loop_kernel, 64, h->lds_bytes));
+  if (per_cu < 1) return fail("loop kernel does not fit on a CU");
+  // every workgroup of the grid must be resident: waiting workgroups poll the queue
+  const int grid = std::min(B, per_cu * ncu);
+  const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;
+  if (!h->pred2) {
+    HIP_OK(hipMalloc(&h->pred2, (size_t)2 * B * 7 * N * 8)); HIP_OK(hipMalloc(&h->ctrl, 4 * 4));
+    HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 4));
+  }
+  if (h->grid_blocks < grid) {
+    if (h->scratch) (void)hipFree(h->scratch);
+    HIP_OK(hipMalloc(&h->scratch, (size_t)grid * per_block * 8)); h->grid_blocks = grid;
+  }
+  if ((size_t)h->queue_cap < total) {
+    if (h->queue) (void)hipFree(h->queue);
+    HIP_OK(hipMalloc(&h->queue, total * 4)); h->queue_cap = (int)total;
+  }
+  // parity 0 of the double buffer <- current predictions; queue <- all items of iteration 0
+  HIP_OK(hipMemcpyAsync(h->pred2, h->pred, (size_t)B * 7 * N * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIP_OK(hipMemsetAsync(h->queue, 0xff, total * 4, h->stream));
+  {
+    std::vector<int32_t> first(B);
+    for (int b = 0; b < B; ++b) first[b] = b;
+    HIP_OK(hipMemcpyAsync(h->queue, first.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    const int32_t ctrl0[4] = {0, B, 0, 0};
+    HIP_OK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof ctrl0, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemsetAsync(h->done, 0, (size_t)S * 4, h->stream));
+    HIP_OK(hipMemsetAsync(h->iter_sum, 0, 4, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
+  }
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(64), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
+                     h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
+                     h->iters, h->stats, h->iter_sum);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  // predictions after K iterations live in parity K%2; advance the scenario clocks by K
+  HIP_OK(hipMemcpyAsync(h->pred, h->pred2 + (size_t)(K & 1) * B * 7 * N, (size_t)B * 7 * N * 8, hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(advance_clock, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, K, h->kidx);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  int32_t ctrl[4] = {0, 0, 0, 0}, isum = 0;
+  HIP_OK(hipMemcpy(ctrl, h->ctrl, sizeof ctrl, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(&isum, h->iter_sum, 4, hipMemcpyDeviceToHost));
+  h->last_iter_sum = isum;
+  h->have_order = false;
+  if (ctrl[2]) return fail("persistent loop kernel timed out waiting for a work item");
+  return 0;
+}
+
+long cfz_loop_last_iterations(const cfz_handle *h) { return h ? h->last_iter_sum : -1; }
 
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters) {
   if (!h || !h->pred) return fail("cfz_loop_init has not been called");

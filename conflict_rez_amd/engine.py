@@ -120,6 +120,9 @@ def load_library(path=None):
     lib.cfz_dual_ws.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.cfz_loop_init.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     lib.cfz_loop_step.argtypes = [vp]
+    lib.cfz_loop_run.argtypes = [vp, C.c_int]
+    lib.cfz_loop_last_iterations.argtypes = [vp]
+    lib.cfz_loop_last_iterations.restype = C.c_long
     lib.cfz_loop_get.argtypes = [vp, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -127,7 +130,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step "
+    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -248,6 +251,11 @@ class Engine:
 
     def loop_step(self):
         self._ck(self.lib.cfz_loop_step(self._h), "cfz_loop_step")
+
+    def loop_run(self, K):
+        """K closed-loop iterations in one persistent launch (same results as K x loop_step)."""
+        self._ck(self.lib.cfz_loop_run(self._h, int(K)), "cfz_loop_run")
+        return int(self.lib.cfz_loop_last_iterations(self._h))
 
     def loop_get(self):
         S, V, N = self._S, self._V, self.spec.N

@@ -58,7 +58,7 @@ typedef struct cfz_options {
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */
   double compl_inf_tol;   /* IPOPT default 1e-4 */
-  double mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max, kappa_sigma;
+  double mu_init /* 1e-3 (IPOPT: 0.1) */, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max, kappa_sigma;
   double eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi, reg_primal;
 } cfz_options;
 
@@ -130,6 +130,11 @@ int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m,
  *   fallback (:484-524), clock += dt (:526), plant integration over dt with (a0,w0) (:528-543). */
 int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const int32_t *k0, const double *noise);
 int cfz_loop_step(cfz_handle *h);
+/* K iterations for all scenarios in one persistent launch: the V solves of a scenario still exchange predictions
+ * after every iteration (Jacobi), but scenarios no longer wait for each other between iterations.  Same results
+ * as K calls of cfz_loop_step.  cfz_loop_last_iterations: IPM iterations summed over all solves of that call. */
+int cfz_loop_run(cfz_handle *h, int K);
+long cfz_loop_last_iterations(const cfz_handle *h);
 /* state[S][V][5], pred[S][V][7][N], status int32[S][V] of the last step; NULL to skip. */
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters);
 

@@ -38,7 +38,7 @@ def test_struct_mirrors_and_defaults(lib):
     assert (s.N, s.rk_substeps, s.dt, s.wb, s.dmin) == (30, 4, 0.1, 2.5, 0.05)
     assert list(s.g) == [3.3, 0.9, 0.6, 0.9] and list(s.weights) == [100, 100, 100, 1, 1, 1]
     assert list(s.bounds) == [2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0]
-    assert (o.max_iter, o.tol, o.constr_viol_tol, o.compl_inf_tol, o.mu_init) == (600, 1e-2, 1e-2, 1e-4, 0.1)
+    assert (o.max_iter, o.tol, o.constr_viol_tol, o.compl_inf_tol, o.mu_init) == (600, 1e-2, 1e-2, 1e-4, 1e-3)
     assert C.sizeof(engine._CSpec) == 4 * 4 + 8 * 3 + 8 * (4 + 12 + 6) + 8 * 8 * 8 + 8 * 8 * 4
     # the python-side spec of the parking lot round-trips
     from conflict_rez_amd import scenarios

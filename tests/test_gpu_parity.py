@@ -124,6 +124,33 @@ def test_closed_loop_on_device(eng):
             assert np.hypot(*(got["state"][s, v, :2] - tgt)) < 1.0
 
 
+def test_persistent_loop_equals_stepwise_loop(eng):
+    """cfz_loop_run(K) (one persistent launch, scenarios free-running) == K x cfz_loop_step, bit for bit:
+    the same solves on the same inputs, only scheduled differently.  More scenarios than resident
+    workgroups so that the work queue really recycles workgroups."""
+    from conflict_rez_amd import scenarios
+
+    table, _ = scenarios.load_reference_table()
+    S, K = 256, 6
+    k0, noise = scenarios.sample_scenarios(S, table, seed=11)
+    eng.loop_init(table, k0, noise)
+    for _ in range(K):
+        eng.loop_step()
+    a = eng.loop_get()
+    eng.loop_init(table, k0, noise)
+    n_it = eng.loop_run(K)
+    b = eng.loop_get()
+    for key in ("state", "pred", "status", "iters"):
+        assert np.array_equal(a[key], b[key]), key
+    assert n_it >= int(b["iters"].sum())
+    # split runs continue where the last one stopped
+    eng.loop_init(table, k0, noise)
+    eng.loop_run(2); eng.loop_run(1); eng.loop_run(3)
+    c = eng.loop_get()
+    for key in ("state", "pred", "status", "iters"):
+        assert np.array_equal(a[key], c[key]), key
+
+
 def test_python_shim_closed_loop_on_gpu(tmp_path):
     """`MultiDistributedFollower` through the real engine: 4 vehicles, 40 iterations, vehicles never overlap
     (separating-axis check on the driven states) and follow their plans; the drop-in surface end to end."""
