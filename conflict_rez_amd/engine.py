@@ -26,9 +26,9 @@ class _CSpec(C.Structure):
     ]
 
 
-_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "reserved")
+_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "reserved")
 _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split()
+             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split()
 
 
 class _COptions(C.Structure):
@@ -94,7 +94,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("CFZ_LIBRARY") or LIB_PATH  # CFZ_LIBRARY: diagnostic builds (tools/)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

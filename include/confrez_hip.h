@@ -53,6 +53,8 @@ typedef struct cfz_options {
   int32_t max_iter;       /* :364 600 */
   int32_t max_backtrack;  /* line-search halvings before status 2 */
   int32_t filter_cap;     /* filter entries kept per barrier problem */
+  int32_t stall_iters;    /* 10: iterations without progress of the constraint violation before status 5; 0 = off */
+  int32_t row_curvature;  /* 1: Hessian = Gauss-Newton objective part + multiplier-weighted curvature of the separation rows */
   int32_t reserved;
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
@@ -60,6 +62,7 @@ typedef struct cfz_options {
   double compl_inf_tol;   /* IPOPT default 1e-4 */
   double mu_init /* 1e-3 (IPOPT: 0.1) */, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max, kappa_sigma;
   double eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi, reg_primal;
+  double stall_kappa;     /* 0.9: progress = violation below stall_kappa x its last checkpoint */
 } cfz_options;
 
 typedef struct cfz_handle cfz_handle;
@@ -93,7 +96,11 @@ int cfz_mpc_solve(cfz_handle *h, int B);
 int cfz_mpc_get(cfz_handle *h, int B, double *zu, double *l, double *m, double *lam_ij, double *lam_ji, double *s);
 
 /* sol.stats() (:481): per-instance outcome.  Any pointer may be NULL.
- * status,iters int32[B]; cost, kkt_err (scaled optimality error E_0), min_sep fp64[B]. */
+ * status,iters int32[B]; cost, kkt_err (scaled optimality error E_0), min_sep fp64[B].
+ * status: 0 converged (IPOPT Solve_Succeeded); 1 iteration limit; 2 line search failed; 3 non-finite iterate;
+ *         4 measured state already violates a collision row by more than 2 constr_viol_tol (no iterations);
+ *         5 constraint violation stalled above constr_viol_tol (locally infeasible).  Every status != 0 is what
+ *         the reference sees as an exception from opti.solve() and answers with the shift fallback (:501-524). */
 int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double *cost, double *kkt_err,
                   double *min_sep);
 

@@ -31,8 +31,8 @@ typedef struct {
   /* solver options (oracle/ipm.py IpmOptions) */
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu,
       tau_min, bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw,
-      s_theta, s_phi, reg_primal;
-  int filter_cap, max_backtrack;
+      s_theta, s_phi, reg_primal, stall_kappa;
+  int filter_cap, max_backtrack, stall_iters, row_curvature;
 } cfz_port_spec;
 
 typedef struct {
@@ -123,7 +123,7 @@ static void rk4_sens(const double z[5], const double u[2], double dt, double wb,
 /* signed distances of the 4 vertices of one polygon to face f of the other (+ gradients wrt x,y,psi).
  * kind 1 = polygon face / body vertices, kind 2 = body face / polygon vertices. */
 static void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
-                        const double g[4], int kind, int f, double d[4], double gr[4][3]) {
+                        const double g[4], int kind, int f, double d[4], double gr[4][3], double cur[4][3]) {
   double c = cos(psi), s = sin(psi);
   if (kind == 1) {
     double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
@@ -132,6 +132,8 @@ static void vertex_dist(const double A[4][2], const double b[4], const double V[
       double dwx = -s * BV[v][0] - c * BV[v][1], dwy = c * BV[v][0] - s * BV[v][1];
       d[v] = wx * A[f][0] + wy * A[f][1] - b[f];
       if (gr) { gr[v][0] = A[f][0]; gr[v][1] = A[f][1]; gr[v][2] = A[f][0] * dwx + A[f][1] * dwy; }
+      /* second derivatives (d2/dx dpsi, d2/dy dpsi, d2/dpsi2): only the rotation of the body vertex curves */
+      if (cur) { cur[v][0] = 0.0; cur[v][1] = 0.0; cur[v][2] = -(A[f][0] * (wx - x) + A[f][1] * (wy - y)); }
     }
   } else {
     double nx = c * GB[f][0] - s * GB[f][1], ny = s * GB[f][0] + c * GB[f][1];
@@ -139,6 +141,7 @@ static void vertex_dist(const double A[4][2], const double b[4], const double V[
     for (int v = 0; v < 4; ++v) {
       d[v] = (V[v][0] - x) * nx + (V[v][1] - y) * ny - g[f];
       if (gr) { gr[v][0] = -nx; gr[v][1] = -ny; gr[v][2] = dnx * (V[v][0] - x) + dny * (V[v][1] - y); }
+      if (cur) { cur[v][0] = -dnx; cur[v][1] = -dny; cur[v][2] = -((V[v][0] - x) * nx + (V[v][1] - y) * ny); }
     }
   }
 }
@@ -151,13 +154,13 @@ static int select_rows(const double A[4][2], const double b[4], const double V[4
   int pk = prev >> 6, pf = (prev >> 4) & 3;
   for (int kind = 1; kind <= 2; ++kind)
     for (int f = 0; f < 4; ++f) {
-      vertex_dist(A, b, V, x, y, psi, g, kind, f, d, 0);
+      vertex_dist(A, b, V, x, y, psi, g, kind, f, d, 0, 0);
       double val = fmin(fmin(d[0], d[1]), fmin(d[2], d[3]));
       if (prev && kind == pk && f == pf) { prev_val = val; have_prev = 1; }
       if (!have || val > best) { have = 1; best = val; bk = kind; bf = f; }
     }
   if (have_prev && prev_val >= best - HYST) { bk = pk; bf = pf; }
-  vertex_dist(A, b, V, x, y, psi, g, bk, bf, d, 0);
+  vertex_dist(A, b, V, x, y, psi, g, bk, bf, d, 0, 0);
   int v0 = 0;
   for (int v = 1; v < 4; ++v) if (d[v] < d[v0]) v0 = v;
   int n1 = (v0 + 1) & 3, n2 = (v0 + 3) & 3, v1;
@@ -203,16 +206,17 @@ static void select_all(const cfz_port_spec *sp, const double *nbr, const double 
 
 /* rows of the current working set: sep[k][2j+r], grad[k][2j+r][3] */
 static void eval_rows(const cfz_port_spec *sp, const double *nbr, const double p[][NP], int sel[][MAXB],
-                      double sep[][MAXR], double grad[][MAXR][3]) {
+                      double sep[][MAXR], double grad[][MAXR][3], double curv[][MAXR][3]) {
   int nb = sp->n_obs + sp->n_nbr;
   for (int k = 0; k < sp->N; ++k)
     for (int j = 0; j < nb; ++j) {
-      double A[4][2], b[4], V[4][2], d[4], gr[4][3];
+      double A[4][2], b[4], V[4][2], d[4], gr[4][3], cu[4][3];
       block_polygon(sp, nbr, k, j, A, b, V);
       int c = sel[k][j], kind = c >> 6, f = (c >> 4) & 3, va = (c >> 2) & 3, vb = c & 3;
-      vertex_dist(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, kind, f, d, grad ? gr : 0);
+      vertex_dist(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, kind, f, d, grad ? gr : 0, curv ? cu : 0);
       sep[k][2 * j] = d[va]; sep[k][2 * j + 1] = d[vb];
       if (grad) for (int q = 0; q < 3; ++q) { grad[k][2 * j][q] = gr[va][q]; grad[k][2 * j + 1][q] = gr[vb][q]; }
+      if (curv) for (int q = 0; q < 3; ++q) { curv[k][2 * j][q] = cu[va][q]; curv[k][2 * j + 1][q] = cu[vb][q]; }
     }
 }
 
@@ -259,7 +263,7 @@ static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *
     rk4(p[k], p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, F);
     for (int i = 0; i < 5; ++i) th += fabs(F[i] - p[k + 1][i]);
   }
-  eval_rows(sp, nbr, p, sel, sep, 0);
+  eval_rows(sp, nbr, p, sel, sep, 0, 0);
   for (int k = 0; k < N; ++k)
     for (int j = 0; j < nb; ++j) th += fabs(sep[k][j] - sp->dmin - sg[k][j]);
   *theta = th; *phi = ph - mu * lg;
@@ -286,7 +290,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
   if (N > MAXN || N < 2 || nblk > MAXB) return -1;
   static iterate it, dt_; /* step stored in an `iterate` too */
-  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cj[MAXN][MAXR];
+  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cur[MAXN][MAXR][3], cj[MAXN][MAXR];
   static int sel[MAXN][MAXB];
   static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
   static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
@@ -295,6 +299,8 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
   double filt[64][2]; int nfilt = 0; double filt_mu = -1.0;
   double theta_min = -1.0, theta_max = -1.0;
   const double mu_floor = fmin(sp->tol, sp->compl_inf_tol) / (sp->kappa_eps + 1.0);
+  double stall_ref = 0.0;
+  int stall_cnt = 0;
   double mu = sp->mu_init;
   int status = 1, iter = 0;
   double err0 = INFINITY;
@@ -314,7 +320,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
       block_polygon(sp, nbr, 0, j, A, b, V);
       s0[0][j] = select_rows(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, 0);
       int c = s0[0][j];
-      vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0);
+      vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0, 0);
       r0[0][j] = fmin(d[(c >> 2) & 3], d[c & 3]);
       if (r0[0][j] < sp->dmin - 2.0 * sp->constr_viol_tol) {
         stats[0] = 0; stats[1] = 4; fstats[0] = 0.0; fstats[1] = INFINITY; fstats[2] = sp->mu_init;
@@ -326,7 +332,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
     (void)one;
   }
   select_all(sp, nbr, it.p, sel);
-  eval_rows(sp, nbr, it.p, sel, sep, 0);
+  eval_rows(sp, nbr, it.p, sel, sep, 0, 0);
   for (int k = 0; k < N; ++k) {
     for (int q = 0; q < 6; ++q) {
       double lo = sp->bounds[2 * q], hi = sp->bounds[2 * q + 1];
@@ -350,7 +356,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
       static int old[MAXN][MAXB];
       memcpy(old, sel, sizeof sel);
       select_all(sp, nbr, it.p, sel);
-      eval_rows(sp, nbr, it.p, sel, sep, 0);
+      eval_rows(sp, nbr, it.p, sel, sep, 0, 0);
       for (int k = 0; k < N; ++k)
         for (int j = 0; j < nblk; ++j) {
           int o = old[k][j], n_ = sel[k][j];
@@ -371,7 +377,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
         }
     }
     /* ---- evaluate ----------------------------------------------------------------- */
-    eval_rows(sp, nbr, it.p, sel, sep, gra);
+    eval_rows(sp, nbr, it.p, sel, sep, gra, cur);
     double cviol = 0.0, theta = 0.0;
     for (int i = 0; i < 5; ++i) { double r = it.p[0][i] - x0[i]; cviol = fmax(cviol, fabs(r)); theta += fabs(r); }
     for (int k = 0; k + 1 < N; ++k) {
@@ -426,6 +432,9 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
     if (iter == sp->max_iter) break;
+    /* infeasibility stall (oracle/ipm.py) */
+    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
+    if (sp->stall_iters > 0 && stall_cnt >= sp->stall_iters && cviol > sp->constr_viol_tol) { status = 5; break; }
     /* ---- barrier update ------------------------------------------------------------- */
     while (mu > mu_floor) {
       /* complementarity error against the current mu has to be recomputed for each candidate mu */
@@ -466,6 +475,21 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
           gk[k][a] += gra[k][j][a] * coef;
           for (int b = 0; b < 3; ++b) H[k][a][b] += S * gra[k][j][a] * gra[k][j][b];
         }
+      }
+      if (sp->row_curvature) {
+        /* exact curvature of the separation rows, sum_r nu_r d2 sep_r: C = [[0,0,a],[0,0,b],[a,b,c]], scaled by
+         * th in {1, 1/2, .., 2^-9, 0} so that diag(2 w) + th C keeps the margin 0.2 min(w) (oracle/mpc_nlp.py hess_gn) */
+        double ca = 0.0, cb = 0.0, cc = 0.0;
+        for (int j = 0; j < nb; ++j) { ca += it.nuc[k][j] * cur[k][j][0]; cb += it.nuc[k][j] * cur[k][j][1]; cc += it.nuc[k][j] * cur[k][j][2]; }
+        const double m_ = 0.2 * fmin(w[0], fmin(w[1], w[2]));
+        const double q0 = 2 * w[0] - m_, q1 = 2 * w[1] - m_, q2 = 2 * w[2] - m_;
+        double th = 1.0;
+        for (int h = 0; h < 11; ++h) {
+          if (h == 10) { th = 0.0; break; }
+          if (q2 + th * cc - th * th * (ca * ca / q0 + cb * cb / q1) >= 0.0) break;
+          th *= 0.5;
+        }
+        H[k][0][2] += th * ca; H[k][2][0] += th * ca; H[k][1][2] += th * cb; H[k][2][1] += th * cb; H[k][2][2] += th * cc;
       }
     }
     /* ---- Riccati backward: value function 0.5 dz'P_k dz + p_k'dz kept for every stage ------- */
@@ -601,7 +625,7 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
   }
   /* ---- output ---------------------------------------------------------------------------------- */
   select_all(sp, nbr, it.p, sel);
-  eval_rows(sp, nbr, it.p, sel, sep, 0);
+  eval_rows(sp, nbr, it.p, sel, sep, 0, 0);
   double fval = 0.0;
   for (int k = 0; k < N; ++k) {
     fval += stage_cost(sp, ref, k, it.p[k]);

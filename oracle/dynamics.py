@@ -4,7 +4,7 @@ Follows the reference's `confrez/control/dynamic_model.py`:
   * `bicycle_ct`      <- `kinematic_bicycle_ct`  :5-27   (state order x,y,psi,v,delta; input a,w)
   * `bicycle_rk4`     <- `kinematic_bicycle_rk`  :30-58  (classical RK4, M=4 sub-steps, h=dt/M)
   * `plant_step`      <- `simulator`             :61-93  (IDAS over [0,dt]; restated as RK4 with
-                                                         100 sub-steps, difference <= 1e-8)
+                                                         10 sub-steps, 6e-11 from the converged solution)
 All functions are vectorised over a leading batch axis.
 """
 import numpy as np
@@ -81,6 +81,6 @@ def bicycle_rk4_jac(z, u, dt, wb, M=4):
     return zk, Sz, Su
 
 
-def plant_step(z, u, dt, wb, substeps=100):
+def plant_step(z, u, dt, wb, substeps=10):
     """Plant integration over one control interval (stand-in for CasADi's IDAS integrator)."""
     return bicycle_rk4(z, u, dt, wb, M=substeps)

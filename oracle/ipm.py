@@ -40,6 +40,15 @@ class IpmOptions:
     tol: float = 1e-2  # vehicle_follower.py:362
     constr_viol_tol: float = 1e-2  # :363
     max_iter: int = 600  # :364
+    # Infeasibility stall test (stands in for the outcome of IPOPT's restoration phase, "converged to a point of
+    # local infeasibility"): give up when the max-norm constraint violation has not dropped below stall_kappa x its
+    # last checkpoint for stall_iters consecutive iterates while still above constr_viol_tol.  0 disables.
+    # Hessian of the Lagrangian = Gauss-Newton objective part + exact curvature of the separation rows weighted with
+    # their multipliers (NLPs that provide hess_gn(x, nu)).  Without it the iteration is not contractive when a
+    # vehicle is pushed hard against a separation row (period-2 oscillation, hundreds of iterations).
+    row_curvature: bool = True
+    stall_kappa: float = 0.9
+    stall_iters: int = 10
     dual_inf_tol: float = 1.0  # IPOPT default
     compl_inf_tol: float = 1e-4  # IPOPT default
     mu_init: float = 1e-3  # IPOPT's default is 0.1; the MPC warm start sits near the end of the central path and
@@ -67,6 +76,7 @@ class IpmOptions:
 
 
 STATUS_OK, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NAN = 0, 1, 2, 3
+STATUS_STALLED = 5  # constraint violation stopped decreasing above constr_viol_tol (4 is taken by mpc_nlp)
 
 
 def push_to_interior(x, xl, xu, opt: IpmOptions):
@@ -156,6 +166,13 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
             break
         if it == opt.max_iter:
             break
+        if it == 0 or cviol <= opt.stall_kappa * stall_ref:
+            stall_ref, stall_cnt = cviol, 0
+        else:
+            stall_cnt += 1
+        if opt.stall_iters > 0 and stall_cnt >= opt.stall_iters and cviol > opt.constr_viol_tol:
+            status = STATUS_STALLED
+            break
         # ---- barrier update (paper eq. 7) ---------------------------------------------
         while mu > mu_floor and E(mu) <= opt.kappa_eps * mu:
             mu = max(mu_floor, min(opt.kappa_mu * mu, mu**opt.theta_mu))
@@ -165,7 +182,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
         gphi = g - mu / dl * hasl + mu / du * hasu  # gradient of the barrier objective
         rhs = -np.concatenate([gphi + J.T @ nu, c])
         if opt.hessian == "gn":
-            H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
+            H = (nlp.hess_gn(x, nu) if opt.row_curvature and getattr(nlp, "has_row_curvature", False) else nlp.hess_gn(x)) + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
             sol = spla.splu(K).solve(rhs)
             dx, dnu = sol[:n], sol[n:]
@@ -244,6 +261,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
             filt.append(((1.0 - opt.gamma_theta) * theta, phi0 - opt.gamma_phi * theta))
             if len(filt) > opt.filter_cap:
                 filt.pop(0)
+        if trace is not None:
+            trace[-1].update(alpha=alpha, a_pri=a_pri, a_dual=a_dual, f_type=f_type, theta=theta, dphi=dphi)
         x = xt
         nu = nu + alpha * dnu
         zl = zl + a_dual * dzl

@@ -351,6 +351,35 @@ class MpcNlp:
                     A, b, PV, P[k, 0:2], P[k, 2], sp_.g, self.BV, int(self.sel[k, j]))
         return sep, gr
 
+    has_row_curvature = True
+
+    def row_curvature(self, P, NU):
+        """C[k] = sum over the rows of stage k of nu_r * Hessian of sep_r wrt (x, y, psi) -> [N,3,3].
+        kind 1 (polygon face A_f, body vertex b_v):  sep = A_f.(t + R b_v) - b_f       -> only d2/dpsi2 = -A_f.(R b_v)
+        kind 2 (body face g_f, polygon vertex p_v):  sep = (p_v - t).(R G_f) - g_f     -> d2/dpsi2 = -(p_v - t).(R G_f),
+                                                                                         d2/dt dpsi = -R' G_f"""
+        sp_ = self.spec
+        C = np.zeros((sp_.N, 3, 3))
+        for k in range(sp_.N):
+            c, s_ = np.cos(P[k, 2]), np.sin(P[k, 2])
+            R = np.array([[c, -s_], [s_, c]])
+            dR = np.array([[-s_, -c], [c, -s_]])
+            t = P[k, 0:2]
+            for j in range(self.nb):
+                A, b, PV = self.polygon(k, j)
+                sel = int(self.sel[k, j])
+                kind, f, vs = sel >> 6, (sel >> 4) & 3, ((sel >> 2) & 3, sel & 3)
+                for r, v in enumerate(vs):
+                    n_ = NU[k, 2 * j + r]
+                    if kind == 1:
+                        C[k, 2, 2] += n_ * (-(A[f] @ (R @ self.BV[v])))
+                    else:
+                        C[k, 2, 2] += n_ * (-((PV[v] - t) @ (R @ G_BODY[f])))
+                        m = -(dR @ G_BODY[f])
+                        C[k, 0, 2] += n_ * m[0]; C[k, 2, 0] += n_ * m[0]
+                        C[k, 1, 2] += n_ * m[1]; C[k, 2, 1] += n_ * m[1]
+        return C
+
     def new_iterate(self, x, zl, nu, mu, bound_push):
         """Hook of oracle/ipm.py, called with every accepted iterate: refresh the working set.
         A row that keeps its (face, vertex) identity keeps slack and multipliers; a new row starts
@@ -452,9 +481,10 @@ class MpcNlp:
         Gd[:, 6] = 2 * wt[4] * P[:, 3] ** 2 * P[:, 6]
         return Gd.ravel()
 
-    def hess_gn(self, X):
-        """Gauss-Newton Hessian of the Lagrangian: objective curvature only, with the
-        (v w)^2 term taken as the square of the residual r = v*w (PSD)."""
+    def hess_gn(self, X, nu=None):
+        """Gauss-Newton Hessian of the Lagrangian: objective curvature with the (v w)^2 term taken as the
+        square of the residual r = v*w (PSD); with `nu`, plus the exact curvature of the separation rows
+        sum_r nu_r d2 sep_r / d(x,y,psi)^2 (`row_curvature`)."""
         N, ns = self.spec.N, self.ns
         P = X.reshape(N, ns)
         wt = self.spec.weights
@@ -469,6 +499,27 @@ class MpcNlp:
         v, w = P[:, 3], P[:, 6]
         add(3, 3, 2 * wt[4] * w * w), add(6, 6, 2 * wt[4] * v * v)
         add(3, 6, 2 * wt[4] * v * w), add(6, 3, 2 * wt[4] * v * w)
+        if nu is not None:
+            C = self.row_curvature(P, np.asarray(nu)[self.c_blk0:].reshape(N, self.nr))
+            # Convexity safeguard per stage: C = [[0,0,a],[0,0,b],[a,b,c]] is scaled by th in {1, 1/2, .., 2^-9, 0} until
+            # diag(2 w_x, 2 w_y, 2 w_psi) + th C keeps a margin m = 0.2 min(w) (Schur complement on the psi entry).
+            q0, q1, q2 = 2 * wt[0], 2 * wt[1], 2 * wt[2]
+            m_ = 0.2 * min(wt[0], wt[1], wt[2])
+            for k in range(N):
+                a_, b_c, c_ = C[k, 0, 2], C[k, 1, 2], C[k, 2, 2]
+                th = 1.0
+                for h in range(11):
+                    if h == 10:
+                        th = 0.0
+                        break
+                    if (q2 - m_) + th * c_ - th * th * (a_ * a_ / (q0 - m_) + b_c * b_c / (q1 - m_)) >= 0.0:
+                        break
+                    th *= 0.5
+                Ck = th * C[k]
+                for a in range(3):
+                    for b_ in range(3):
+                        if Ck[a, b_] != 0.0:
+                            rows.append(np.array([k * ns + a])), cols.append(np.array([k * ns + b_])), vals.append(np.array([Ck[a, b_]]))
         return sp.csr_matrix(
             (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.n, self.n)
         )

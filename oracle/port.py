@@ -29,8 +29,8 @@ class _Spec(C.Structure):
         ("A_obs", C.c_double * (MAXB * 8)), ("b_obs", C.c_double * (MAXB * 4)), ("V_obs", C.c_double * (MAXB * 8)),
     ] + [(k, C.c_double) for k in (
         "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-        "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split()
-    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int)]
+        "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split()
+    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int)]
 
 
 def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
@@ -46,9 +46,10 @@ def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
         V[j] = polytope_vertices(spec.A_obs[j], spec.b_obs[j])[0]
     s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel()); s.V_obs[:] = list(V.ravel())
     for k in ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal").split():
+              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split():
         setattr(s, k, getattr(opt, k))
-    s.filter_cap, s.max_backtrack = opt.filter_cap, opt.max_backtrack
+    s.filter_cap, s.max_backtrack, s.stall_iters = opt.filter_cap, opt.max_backtrack, opt.stall_iters
+    s.row_curvature = int(opt.row_curvature)
     return s
 
 

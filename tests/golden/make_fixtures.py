@@ -111,6 +111,31 @@ def mpc_golden(table):
         META.append([res["status"], res["iters"], res["f"], res["sep"].min() if res["sep"] is not None else np.nan])
         print("case", case, "vehicle", v, "k0", k0, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"],
               "min sep", META[-1][3])
+    # cases 16, 17: locally infeasible starts out of the benchmark's scenario sampler (the perturbed state sits
+    # inside the dmin margin of a neighbour but within the 2 constr_viol_tol band of the status-4 pre-check):
+    # the constraint violation stalls and the solver stops with status 5
+    from conflict_rez_amd import scenarios
+
+    k0s, noise = scenarios.sample_scenarios(1024, table, seed=2024)
+    bx0, bref, bnbr, bzu = scenarios.mpc_batch_from_table(scenarios.parking_lot_spec(), table, k0s, noise)
+    for case, b in ((16, 800), (17, 1955)):
+        res = solve_mpc(spec, bx0[b], bref[b], bnbr[b], bzu[b])
+        X0.append(bx0[b]), REF.append(bref[b]), NBR.append(bnbr[b]), ZU.append(bzu[b])
+        SOL.append(res["zu"])
+        META.append([res["status"], res["iters"], res["f"], res["sep"].min() if res["sep"] is not None else np.nan])
+        print("case", case, "scenario instance", b, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"])
+        assert res["status"] == 5
+    # cases 18, 19: a vehicle pushed hard against a separation row (inputs recorded from a closed-loop run of the
+    # engine, tools/capture_hard.py -> contact_inputs.npz).  Without the curvature of the separation rows in the
+    # Hessian these need 450-600 iterations (period-2 oscillation of the Gauss-Newton iteration); with it about 10.
+    ci = np.load(os.path.join(HERE, "contact_inputs.npz"))
+    for case, i in ((18, 0), (19, 1)):
+        res = solve_mpc(spec, ci["x0"][i], ci["ref"][i], ci["nbr"][i], ci["zu"][i])
+        X0.append(ci["x0"][i]), REF.append(ci["ref"][i]), NBR.append(ci["nbr"][i]), ZU.append(ci["zu"][i])
+        SOL.append(res["zu"])
+        META.append([res["status"], res["iters"], res["f"], res["sep"].min()])
+        print("case", case, "contact input", i, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"])
+        assert res["status"] == 0 and res["iters"] < 20
     np.savez_compressed(os.path.join(HERE, "mpc_golden.npz"), x0=np.array(X0), ref=np.array(REF), nbr=np.array(NBR),
                         zu=np.array(ZU), sol=np.array(SOL), meta=np.array(META), A_obs=spec.A_obs, b_obs=spec.b_obs)
 
