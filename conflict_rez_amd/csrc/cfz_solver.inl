@@ -45,7 +45,7 @@
 // iterations of one instance and written to a debug buffer (never to an output).
 #if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define CFZ_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } while (0)
-#define CFZ_STAMP_DECL unsigned long long stamp_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#define CFZ_STAMP_DECL unsigned long long stamp_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; const unsigned long long stamp_wall0 = wall_clock64(); unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #else
 #define CFZ_STAMP(i) do {} while (0)
 #define CFZ_STAMP_DECL
@@ -54,7 +54,7 @@
 namespace cfz {
 
 constexpr int kNP = 7;      // x y psi v delta a w
-constexpr int kRed = 6;     // reduction slots
+constexpr int kRed = 6;     // reduction slots (0-3 own storage, 4-5 see make_layout)
 constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
 
 // Everything the kernel needs besides per-instance data (plain old data, passed by value).
@@ -76,7 +76,7 @@ struct Lay {
   int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
   int dp, dsg, dpi0, dpi;                   // step
   int cj, gra, ab, d, hc, gk, kk;           // stage data
-  int sel, ref, nb4, x0, obs, cs, filt, red, total;
+  int sel, ref, nb4, x0, obs, cs, filt, red, red2, total;
 };
 
 CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
@@ -94,36 +94,44 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
   L.dpi = L.d;  // the costate sweep (last reader of the defects d_k was the forward sweep) overwrites them with d(pi)
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
-  L.sel = o; o += (N * nb + 1) / 2;  // working set codes, int32
+  L.sel = o; o += (N * nb + 7) / 8;  // working set codes (< 192), one byte each
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
   L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
   L.obs = o; o += n_obs * 20;  // static obstacles: A[4][2], b[4], V[4][2] (lane-indexed reads of a kernel argument would go through scratch)
   L.cs = o; o += 2 * N;  // cos, sin of the pose heading of every stage at the point being evaluated
-  L.filt = o; o += 32; L.red = o; o += kRed * 64;
+  L.filt = o; o += 32; L.red = o; o += 4 * 64;
+  // reduction slots 4 and 5 are only used by the residual pass at the top of an iteration, when the step of the
+  // previous iteration is dead: they live in its storage (160 KiB of LDS hold three instances only if one
+  // instance stays within 26 allocation granules of 2 KiB = 6656 doubles)
+  if (N * kNP >= 128) L.red2 = L.dp; else { L.red2 = o; o += 128; }
   L.total = o;
   return L;
 }
 
-CFZ_FN int *sel_ptr(double *m, const Lay &L) { return reinterpret_cast<int *>(m + L.sel); }
-CFZ_FN const int *sel_ptr(const double *m, const Lay &L) { return reinterpret_cast<const int *>(m + L.sel); }
+CFZ_FN unsigned char *sel_ptr(double *m, const Lay &L) { return reinterpret_cast<unsigned char *>(m + L.sel); }
+CFZ_FN const unsigned char *sel_ptr(const double *m, const Lay &L) { return reinterpret_cast<const unsigned char *>(m + L.sel); }
 
 // bounded columns of p: x y v delta a w  (psi is free)
 CFZ_FN int bcol(int q) { return q < 2 ? q : q + 1; }
 
 // ------------------------------------------------------------------------------ reductions
+CFZ_FN int red_at(const Lay &L, int slot) { return slot < 4 ? L.red + slot * 64 : L.red2 + (slot - 4) * 64; }
 CFZ_FN double red_sum(const double *m, const Lay &L, int slot) {
+  const double *r = m + red_at(L, slot);
   double s = 0.0;
-  for (int i = 0; i < 64; ++i) s += m[L.red + slot * 64 + i];
+  for (int i = 0; i < 64; ++i) s += r[i];
   return s;
 }
 CFZ_FN double red_max(const double *m, const Lay &L, int slot) {
-  double s = m[L.red + slot * 64];
-  for (int i = 1; i < 64; ++i) s = fmax(s, m[L.red + slot * 64 + i]);
+  const double *r = m + red_at(L, slot);
+  double s = r[0];
+  for (int i = 1; i < 64; ++i) s = fmax(s, r[i]);
   return s;
 }
 CFZ_FN double red_min(const double *m, const Lay &L, int slot) {
-  double s = m[L.red + slot * 64];
-  for (int i = 1; i < 64; ++i) s = fmin(s, m[L.red + slot * 64 + i]);
+  const double *r = m + red_at(L, slot);
+  double s = r[0];
+  for (int i = 1; i < 64; ++i) s = fmin(s, r[i]);
   return s;
 }
 
@@ -625,7 +633,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         for (int i = 0; i < kNP; ++i) dinf = fmax(dinf, fabs(r[i]));
       }
       m[L.red + 0 * 64 + lane] = dinf; m[L.red + 1 * 64 + lane] = snu; m[L.red + 2 * 64 + lane] = sz;
-      m[L.red + 3 * 64 + lane] = c0; m[L.red + 4 * 64 + lane] = fv; m[L.red + 5 * 64 + lane] = log(lprod);
+      m[L.red + 3 * 64 + lane] = c0; m[red_at(L, 4) + lane] = fv; m[red_at(L, 5) + lane] = log(lprod);
     CFZ_END
     const double dual_inf = red_max(m, L, 0), sum_nu = red_sum(m, L, 1), sum_z = red_sum(m, L, 2);
     const double cmp0 = red_max(m, L, 3), fval = red_sum(m, L, 4), logsum = red_sum(m, L, 5);
@@ -1045,6 +1053,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   out_i[0] = iter; out_i[1] = status;
   CFZ_STAMP(10);  // output
 #if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  // slot 0 ("setup", a handful of ticks) carries the wall time of the solve in 10 ns units (constant 100 MHz counter)
+  stamp_acc[0] = wall_clock64() - stamp_wall0;
   if (duo.stamps && threadIdx.x == 0) for (int i = 0; i < 12; ++i) duo.stamps[i] = stamp_acc[i];
 #endif
 }

@@ -5,7 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from conflict_rez_amd import engine, scenarios
 
-S, K, thresh = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+S, K = int(sys.argv[1]), int(sys.argv[2])
+# third argument: iteration threshold, or inst:b1,b2,..@t1,t2,.. to record given instances at given iterations
+want = None
+if sys.argv[3].startswith("inst:"):
+    a, b = sys.argv[3][5:].split("@")
+    want = ([int(x) for x in a.split(",")], [int(x) for x in b.split(",")])
+    thresh = 10 ** 9
+else:
+    thresh = int(sys.argv[3])
 spec = scenarios.parking_lot_spec()
 table, _ = scenarios.load_reference_table()
 V, T, N = table.shape[0], table.shape[1], spec.N
@@ -18,8 +26,11 @@ for t in range(K):
     eng.loop_step()
     g1 = eng.loop_get()
     it, st = g1["iters"].reshape(S, V), g1["status"].reshape(S, V)
-    for s, v in zip(*np.nonzero(it >= thresh)):
-        if len(cases) >= 12:
+    picks = list(zip(*np.nonzero(it >= thresh)))
+    if want is not None and t in want[1]:
+        picks = [(b // V, b % V) for b in want[0]]
+    for s, v in picks:
+        if len(cases) >= 16:
             break
         adv = np.minimum(np.arange(N) + 1, N - 1)
         pred = g0["pred"].reshape(S, V, 7, N)

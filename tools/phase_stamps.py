@@ -40,10 +40,13 @@ for B in (1, 256, 768):
     it = int(dit[0])
     med = np.median(st, 0)
     print(f"B={B}: iters {it}, cycles per iteration by phase (median over instances):")
+    wall_us = med[0] / 100.0
+    med = med.copy(); med[0] = 0
     tot = med.sum()
     for n, c in zip(names, med):
         if n != "-":
             per = c / (it if n not in ("setup", "output") else 1)
             print(f"   {n:10s} {per:12.0f}  ({100 * c / tot:4.1f} % of the solve)")
-    print(f"   total cycles {tot:.0f}")
+    print(f"   solve wall time {wall_us:.1f} us -> shader clock {tot / wall_us / 1e3:.3f} GHz, {wall_us / it:.1f} us per iteration")
+    print(f"   total cycles {tot:.0f}; kernel {eng.last_solve_ms():.3f} ms -> {tot / eng.last_solve_ms() / 1e6:.3f} GHz if the stamps tick at the shader clock")
     eng.close()
