@@ -464,6 +464,13 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
     if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
   }
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, 64, h->lds_bytes);
+  {
+    // The runtime's answer ignores that gfx950 hands out LDS in 2 KiB granules (measured with tools/src/occupancy_test.hip:
+    // 54,208 B per workgroup -> the query says 3 per CU, 2 run); report what the hardware does.
+    const int granules = (int)((h->lds_bytes + 2047) / 2048);
+    const int by_lds = granules ? (160 * 1024 / 2048) / granules : h->blocks_per_cu;
+    if (by_lds < h->blocks_per_cu) h->blocks_per_cu = by_lds;
+  }
   const size_t B = (size_t)max_batch, N = (size_t)k.N, no = (size_t)k.n_obs, nn = (size_t)k.n_nbr;
   HIP_OK(hipStreamCreate(&h->stream));
   HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box job: smoke, GPU tests, the default bench line, rocprofv3 kernel trace and the PMC passes.
+# Usage (from the repo root on the box): bash tools/gpu_profile_job.sh <tag>     -> gpurun_out/<tag>_*
+tag=${1:-r1x}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 600 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 1500 $O/${tag}_bench.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_$tag
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag/trace -o t -- python3 $R/bench.py --no-cpu-baseline > $O/${tag}_bench_traced.json 2>$O/${tag}_trace.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/prof_$tag/$c -o t -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>$O/${tag}_$c.err
+done
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof_$tag/SQ -o t -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>$O/${tag}_SQ.err
+cd $R
+find $O/prof_$tag -name "*kernel_stats.csv" -exec cp {} $O/${tag}_kernel_stats.csv \;
+for c in FETCH_SIZE WRITE_SIZE SQ; do
+  f=$(find $O/prof_$tag/$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python tools/summarize_pmc.py $f $O/${tag}_pmc_${c}_summary.csv
+done
+head -8 $O/${tag}_kernel_stats.csv; cat $O/${tag}_pmc_*_summary.csv | grep -v "^kernel," | head -40
+find $O/prof_$tag -type f -size +8M -delete
