@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--scenarios", type=int, default=1024, help="scenarios per GPU (x4 vehicles)")
     ap.add_argument("--max-iter", type=int, default=600, help="IPM iteration limit (reference: 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-obs", type=int, default=6, help="static obstacles (reference map: 6); fewer = experiments only")
     ap.add_argument("--mode", choices=["persistent", "step"], default="persistent",
                     help="persistent: K iterations in one launch, scenarios advance independently (cfz_loop_run); "
                          "step: one launch per iteration with a device-wide barrier in between (cfz_loop_step)")
@@ -134,7 +135,7 @@ def main():
 
     from conflict_rez_amd import engine, scenarios
 
-    spec = scenarios.parking_lot_spec()
+    spec = scenarios.parking_lot_spec(n_obs=args.n_obs)
     V = spec.n_nbr + 1
     table, _ = scenarios.load_reference_table()
     S = args.scenarios

@@ -338,6 +338,7 @@ struct cfz_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
+  double *obs_tab = nullptr;  // n_obs x 20: A[4][2], b[4], V[4][2] (KSpec::obs_tab)
   // per-instance buffers
   double *x0 = nullptr, *ref = nullptr, *nbr = nullptr, *zu = nullptr, *stats = nullptr;
   int32_t *status = nullptr, *iters = nullptr;
@@ -456,6 +457,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature;
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
+  if (const char *pad = std::getenv("CFZ_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(pad);  // occupancy experiments only
   if (h->lds_bytes > 160 * 1024) { delete h; return fail("problem does not fit the 160 KiB LDS of one CU"); }
   if (h->lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -473,6 +475,17 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   }
   const size_t B = (size_t)max_batch, N = (size_t)k.N, no = (size_t)k.n_obs, nn = (size_t)k.n_nbr;
   HIP_OK(hipStreamCreate(&h->stream));
+  {
+    std::vector<double> tab((size_t)std::max(k.n_obs, 1) * 20, 0.0);
+    for (int j = 0; j < k.n_obs; ++j) {
+      double *o = tab.data() + (size_t)j * 20;
+      for (int i = 0; i < 4; ++i) { o[2 * i] = k.A_obs[j][i][0]; o[2 * i + 1] = k.A_obs[j][i][1]; o[8 + i] = k.b_obs[j][i];
+                                    o[12 + 2 * i] = k.V_obs[j][i][0]; o[13 + 2 * i] = k.V_obs[j][i][1]; }
+    }
+    HIP_OK(hipMalloc(&h->obs_tab, tab.size() * 8));
+    HIP_OK(hipMemcpy(h->obs_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    h->ks.obs_tab = h->obs_tab;
+  }
   HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
   HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
@@ -491,7 +504,7 @@ int cfz_destroy(cfz_handle *h) {
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
                   h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
-                  h->iter_sum};
+                  h->iter_sum, h->obs_tab};
   for (void *p : bufs) if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);

@@ -68,6 +68,9 @@ struct KSpec {
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
       bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
       reg_primal, stall_kappa;
+  // static obstacles as the kernel reads them, n_obs x 20 doubles in global memory: A[4][2], b[4], V[4][2]
+  // (L1/L2-resident; indexing the arrays above with a lane-varying j would copy this struct to scratch)
+  const double *obs_tab;
 };
 
 // Workspace layout (offsets in doubles) for one instance.
@@ -75,12 +78,12 @@ struct Lay {
   int N, nb, nr;                            // stages, blocks per stage, rows per stage (2 per block)
   int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
   int dp, dsg, dpi0, dpi;                   // step
-  int cj, gra, ab, d, hc, gk, kk;           // stage data
-  int sel, ref, nb4, x0, obs, cs, filt, red, red2, total;
+  int cj, ab, d, hc, gk, kk;                // stage data
+  int sel, ref, nb4, x0, cs, rP, filt, red, red2, total;
 };
 
 CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
-  const int n_obs = nb - n_nbr;
+  (void)n_nbr;
   Lay L; int o = 0;
   const int nr = 2 * nb;
   L.N = N; L.nb = nb; L.nr = nr;
@@ -90,16 +93,18 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.pi0 = o; o += 5; L.pi = o; o += N * 5;
   L.dp = o; o += N * kNP; L.dpi0 = o; o += 5;
   L.cj = o; o += N * nr; L.dsg = L.cj;  // the slack step overwrites the row residual it is computed from
-  L.gra = o; o += N * nb * 4;           // per block: shared (d/dx, d/dy) and the two d/dpsi
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
   L.dpi = L.d;  // the costate sweep (last reader of the defects d_k was the forward sweep) overwrites them with d(pi)
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
   L.sel = o; o += (N * nb + 7) / 8;  // working set codes (< 192), one byte each
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
   L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
-  L.obs = o; o += n_obs * 20;  // static obstacles: A[4][2], b[4], V[4][2] (lane-indexed reads of a kernel argument would go through scratch)
-  L.cs = o; o += 2 * N;  // cos, sin of the pose heading of every stage at the point being evaluated
-  L.filt = o; o += 32; L.red = o; o += 4 * 64;
+  L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the point being evaluated
+  L.rP = L.cs;  // value function of stage 0 (30 numbers) between the Riccati sweeps, when cos/sin are not needed
+  L.filt = o; o += 32;
+  // reduction slots 0-3: no reduction runs between the assembly of H_k and the costate sweep, the only phases that
+  // read hc, so the slots live there (the budget: four instances per CU need 20 LDS granules of 2 KiB = 5120 doubles)
+  if (N * 11 >= 256) L.red = L.hc; else { L.red = o; o += 256; }
   // reduction slots 4 and 5 are only used by the residual pass at the top of an iteration, when the step of the
   // previous iteration is dead: they live in its storage (160 KiB of LDS hold three instances only if one
   // instance stays within 26 allocation granules of 2 KiB = 6656 doubles)
@@ -323,7 +328,7 @@ CFZ_CALL void rows_for(const double A[4][2], const double b[4], const double V[4
 CFZ_FN void block_polygon(const KSpec &sp, const double *m, const Lay &L, int k, int j, double A[4][2], double b[4],
                           double V[4][2]) {
   if (j < sp.n_obs) {
-    const double *o = m + L.obs + j * 20;
+    const double *o = sp.obs_tab + j * 20;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       A[i][0] = o[2 * i]; A[i][1] = o[2 * i + 1]; b[i] = o[8 + i];
@@ -342,6 +347,53 @@ CFZ_FN void block_polygon(const KSpec &sp, const double *m, const Lay &L, int k,
     for (int i = 0; i < 4; ++i) {
       V[i][0] = xo + co * BV[i][0] - so * BV[i][1];
       V[i][1] = yo + so * BV[i][0] + co * BV[i][1];
+    }
+  }
+}
+
+// Gradients of the two rows of block j at stage k, rebuilt from the working-set code instead of being kept in LDS
+// (same expressions as vertex_dist<true>): both rows share d/dx = a0, d/dy = a1 (same face); ap[r] = d/dpsi of row r.
+CFZ_FN void block_grad(const KSpec &sp, const double *m, const Lay &L, int k, int j, int sl, double x, double y, double c,
+                       double s, double &a0, double &a1, double ap[2]) {
+  const int f = (sl >> 4) & 3;
+  const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
+  if ((sl >> 6) == 1) {
+    double ax, ay;
+    if (j < sp.n_obs) {
+      const double *o = sp.obs_tab + j * 20;
+      ax = o[2 * f]; ay = o[2 * f + 1];
+    } else {
+      const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+      const double co = q[2], so = q[3];
+      ax = f == 0 ? co : (f == 1 ? -so : (f == 2 ? -co : so));
+      ay = f == 0 ? so : (f == 1 ? co : (f == 2 ? -so : -co));
+    }
+    a0 = ax; a1 = ay;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int v = r == 0 ? ((sl >> 2) & 3) : (sl & 3);
+      const double bx = (v == 0 || v == 3) ? g0 : -g2, by = (v < 2) ? g1 : -g3;
+      const double dwx = -s * bx - c * by, dwy = c * bx - s * by;
+      ap[r] = ax * dwx + ay * dwy;
+    }
+  } else {
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    const double nx = c * gx - s * gy, ny = s * gx + c * gy, dnx = -s * gx - c * gy, dny = c * gx - s * gy;
+    a0 = -nx; a1 = -ny;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int v = r == 0 ? ((sl >> 2) & 3) : (sl & 3);
+      double vx, vy;
+      if (j < sp.n_obs) {
+        const double *o = sp.obs_tab + j * 20;
+        vx = o[12 + 2 * v]; vy = o[13 + 2 * v];
+      } else {
+        const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+        const double xo = q[0], yo = q[1], co = q[2], so = q[3];
+        const double bx = (v == 0 || v == 3) ? g0 : -g2, by = (v < 2) ? g1 : -g3;
+        vx = xo + co * bx - so * by; vy = yo + so * bx + co * by;
+      }
+      ap[r] = dnx * (vx - x) + dny * (vy - y);
     }
   }
 }
@@ -458,10 +510,6 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
     }
     if (lane < 5) { m[L.x0 + lane] = x0g[lane]; m[L.pi0 + lane] = 0.0; }
-    for (int i = lane; i < n_obs * 20; i += 64) {
-      const int j = i / 20, r = i - 20 * j;
-      m[L.obs + i] = r < 8 ? sp.A_obs[j][r >> 1][r & 1] : (r < 12 ? sp.b_obs[j][r - 8] : sp.V_obs[j][(r - 12) >> 1][r & 1]);
-    }
     for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
     for (int i = lane; i < N * 5; i += 64) m[L.pi + i] = 0.0;
   CFZ_END
@@ -563,8 +611,6 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         } else {
           rows_for<true>(A, b, V, x, y, cn, sn, sp.g, c1, sep, gr);
         }
-        m[L.gra + 4 * t] = gr[0][0]; m[L.gra + 4 * t + 1] = gr[0][1];  // both rows share d/dx, d/dy (same face)
-        m[L.gra + 4 * t + 2] = gr[0][2]; m[L.gra + 4 * t + 3] = gr[1][2];
         for (int r = 0; r < 2; ++r) {
           const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
           m[L.cj + 2 * t + r] = c;
@@ -603,13 +649,17 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         double r[kNP];
         stage_grad(sp, refg, k, pk, r);
         fv = stage_cost(sp, refg, k, pk);
-        for (int j = 0; j < nr; ++j) {
-          const int t = k * nr + j;
-          const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
-          const double *ga = m + L.gra + 4 * (t >> 1);
-          r[0] += ga[0] * nu; r[1] += ga[1] * nu; r[2] += ga[2 + (t & 1)] * nu;
-          dinf = fmax(dinf, fabs(-nu - zs));
-          snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lprod *= sg;
+        const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
+        for (int jb = 0; jb < nb; ++jb) {
+          double a0, a1, ap[2];
+          block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cpsi, spsi, a0, a1, ap);
+          for (int r_ = 0; r_ < 2; ++r_) {
+            const int t = k * nr + 2 * jb + r_;
+            const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
+            r[0] += a0 * nu; r[1] += a1 * nu; r[2] += ap[r_] * nu;
+            dinf = fmax(dinf, fabs(-nu - zs));
+            snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lprod *= sg;
+          }
         }
         if (k + 1 < N) {
           double A[5][5], B[5][2];
@@ -686,22 +736,24 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           g[bcol(q)] += mu * (iu - il);
         }
         // curvature of the separation rows weighted with their multipliers, sum_r nu_r d2 sep_r / d(x,y,psi)^2 =
-        // [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature), rebuilt from what the row pass left in LDS:
+        // [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature), rebuilt from the row gradients:
         //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
         //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
         double ca = 0.0, cb = 0.0, cc = 0.0;
         const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
+        double ba0 = 0.0, ba1 = 0.0, bap[2] = {0.0, 0.0};
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
           const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
           const double coef = S * m[L.cj + t] - mu * isg;
-          const double *ga = m + L.gra + 4 * (t >> 1);
-          const double a0 = ga[0], a1 = ga[1], a2 = ga[2 + (t & 1)];
+          const int sl = sel_ptr(m, L)[t >> 1];
+          if ((j & 1) == 0) block_grad(sp, m, L, k, j >> 1, sl, pk[0], pk[1], cpsi, spsi, ba0, ba1, bap);
+          const double a0 = ba0, a1 = ba1, a2 = bap[j & 1];
           g[0] += a0 * coef; g[1] += a1 * coef; g[2] += a2 * coef;
           h[0] += S * a0 * a0; h[1] += S * a1 * a1; h[2] += S * a2 * a2;
           h[7] += S * a0 * a1; h[8] += S * a0 * a2; h[9] += S * a1 * a2;
           if (sp.row_curvature) {
-            const int sl = sel_ptr(m, L)[t >> 1], f = (sl >> 4) & 3, v = (t & 1) ? (sl & 3) : ((sl >> 2) & 3);
+            const int f = (sl >> 4) & 3, v = (t & 1) ? (sl & 3) : ((sl >> 2) & 3);
             const double nu = m[L.nuc + t];
             if ((sl >> 6) == 1) {
               const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
@@ -737,7 +789,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     // h7 (0,1), h8 (0,2), h9 (1,2) + the v-w cross term h10 (3,6).  A lane-parallel variant (matrix
     // entries spread over lanes, exchange through LDS) measured 2.2x slower: every exchange is a
     // dependent LDS round trip of a lone wavefront.
-    double *const rP = m + L.red, *const rp = rP + 25;  // value function of stage 0 handed to the forward sweep
+    double *const rP = m + L.rP, *const rp = rP + 25;  // value function of stage 0 handed to the forward sweep
     CFZ_LANES(lane)
       if (lane == 0) {
         const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
@@ -893,11 +945,15 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           rdual = fmax(rdual, fmax(-dzl / zl, -dzu / zu_));
         }
         for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
+        double ba0 = 0.0, ba1 = 0.0, bap[2] = {0.0, 0.0};
+        // heading of the current iterate again: its cos/sin slots carried the value function through the Riccati sweeps
+        double sps, cps;
+        sincos(m[L.p + k * kNP + 2], &sps, &cps);
         for (int j = 0; j < nr; ++j) {
           const int t = k * nr + j;
           const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
-          const double *ga = m + L.gra + 4 * (t >> 1);
-          const double ds = m[L.cj + t] + ga[0] * dpk[0] + ga[1] * dpk[1] + ga[2 + (t & 1)] * dpk[2];
+          if ((j & 1) == 0) block_grad(sp, m, L, k, j >> 1, sel_ptr(m, L)[t >> 1], m[L.p + k * kNP], m[L.p + k * kNP + 1], cps, sps, ba0, ba1, bap);
+          const double ds = m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[j & 1] * dpk[2];
           m[L.dsg + t] = ds;
           const double dzs = mu * isg - zs - zs * isg * ds;
           dphi -= mu * isg * ds;

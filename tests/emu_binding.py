@@ -16,7 +16,7 @@ class KSpec(C.Structure):
         ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
         ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
         ("A_obs", C.c_double * 64), ("b_obs", C.c_double * 32), ("V_obs", C.c_double * 64),
-    ] + [(k, C.c_double) for k in _OPTS]
+    ] + [(k, C.c_double) for k in _OPTS] + [("obs_tab", C.c_void_p)]
 
 
 def build(force=False, sanitize=False):
@@ -47,6 +47,10 @@ def make_kspec(spec, opt):
     s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel()); s.V_obs[:] = list(V.ravel())
     for k in _OPTS:
         setattr(s, k, getattr(opt, k))
+    # the table the kernel reads: per obstacle A[4][2], b[4], V[4][2]; kept alive by the returned struct
+    tab = np.ascontiguousarray(np.concatenate([A.reshape(8, 8), b, V.reshape(8, 8)], axis=1)[: max(spec.n_obs, 1)])
+    s._obs_tab = tab
+    s.obs_tab = tab.ctypes.data
     return s
 
 
