@@ -45,7 +45,8 @@ struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 
 __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
-                                                   int32_t *iters, double *stats, DualPtrs du, const int32_t *order) {
+                                                   int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
+                                                   double *wst, int wst_stride, const int32_t *carry, int carry_all) {
   extern __shared__ double smem[];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` puts the instances expected to run longest first
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cf
     duo.lam_ij = du.lam_ij + (size_t)b * nn * N * 4; duo.lam_ji = du.lam_ji + (size_t)b * nn * N * 4;
     duo.s = du.s + (size_t)b * nn * N * 2;
   }
+  // carry record of slot b: used when the caller says that this solve is the successor of the previous one in the slot
   cfz::solve_instance(sp, x0 + (size_t)b * 5, ref + (size_t)b * 3 * N, nbr + (size_t)b * nn * 3 * N,
-                      zu + (size_t)b * 7 * N, smem, L, oi, od, duo);
+                      zu + (size_t)b * 7 * N, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr,
+                      carry_all || (carry && carry[b]));
   if (threadIdx.x == 0) {
     iters[b] = oi[0]; status[b] = oi[1];
     stats[b * 3 + 0] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
                                                   const double *ref_table, const int32_t *kidx0, int t_base,
                                                   double *pred, double *state, double *scratch, int32_t *qbuf,
                                                   int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
-                                                  double *stats, int32_t *iter_sum) {
+                                                  double *stats, int32_t *iter_sum, double *wst, int wst_stride) {
   extern __shared__ double smem[];
   const int N = sp.N, nn = sp.n_nbr, B = S * V, lane = threadIdx.x;
   double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
 #ifdef CFZ_DBG_NOSOLVE
     oi[0] = 0; oi[1] = 1; od[0] = od[1] = od[2] = 0.0;
 #else
-    cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo);
+    cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1);
 #endif
     __syncthreads();
     CFZ_MARK(4);
@@ -339,6 +342,11 @@ struct cfz_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   double *obs_tab = nullptr;  // n_obs x 20: A[4][2], b[4], V[4][2] (KSpec::obs_tab)
+  // carry records (multipliers handed from one MPC iteration to the next), one per slot; per-solve flags
+  double *wst = nullptr;
+  int32_t *carry = nullptr;
+  int wst_stride = 0, carry_duals = 1;
+  bool carry_set = false;
   // per-instance buffers
   double *x0 = nullptr, *ref = nullptr, *nbr = nullptr, *zu = nullptr, *stats = nullptr;
   int32_t *status = nullptr, *iters = nullptr;
@@ -374,12 +382,14 @@ bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
 
 int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr, double *zu,
                  int32_t *status, int32_t *iters, double *stats, bool duals, hipStream_t st,
-                 const int32_t *order = nullptr) {
+                 const int32_t *order = nullptr, int carry_all = 0) {
   DualPtrs du = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
   HIP_OK(hipEventRecord(h->ev0, st));
   hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(64), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
-                     iters, stats, du, order);
+                     iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
+                     h->carry_set ? h->carry : nullptr, carry_all);
+  h->carry_set = false;  // the flags of cfz_mpc_set_carry hold for one solve
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   return 0;
@@ -416,7 +426,7 @@ void cfz_default_options(cfz_options *o) {
   o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
   o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
   o->reg_primal = 1e-8;
-  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1;
+  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1; o->carry_duals = 1; o->warm_push = 1e-6;
 }
 
 int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out) {
@@ -454,7 +464,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   k.bound_frac = opt->bound_frac; k.s_max = opt->s_max; k.kappa_sigma = opt->kappa_sigma; k.eta_phi = opt->eta_phi;
   k.gamma_theta = opt->gamma_theta; k.gamma_phi = opt->gamma_phi; k.delta_sw = opt->delta_sw;
   k.s_theta = opt->s_theta; k.s_phi = opt->s_phi; k.reg_primal = opt->reg_primal;
-  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature;
+  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature; k.warm_push = opt->warm_push;
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
   if (const char *pad = std::getenv("CFZ_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(pad);  // occupancy experiments only
@@ -486,6 +496,11 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
     HIP_OK(hipMemcpy(h->obs_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     h->ks.obs_tab = h->obs_tab;
   }
+  h->carry_duals = opt->carry_duals;
+  h->wst_stride = cfz::carry_layout(k.N, k.n_obs + k.n_nbr).stride;
+  HIP_OK(hipMalloc(&h->wst, (size_t)max_batch * h->wst_stride * 8));
+  HIP_OK(hipMemset(h->wst, 0, (size_t)max_batch * h->wst_stride * 8));
+  HIP_OK(hipMalloc(&h->carry, (size_t)max_batch * 4));
   HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
   HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
@@ -504,7 +519,7 @@ int cfz_destroy(cfz_handle *h) {
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
                   h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
-                  h->iter_sum, h->obs_tab};
+                  h->iter_sum, h->obs_tab, h->wst, h->carry};
   for (void *p : bufs) if (p) hipFree(p);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -538,6 +553,14 @@ int cfz_mpc_set_warm(cfz_handle *h, int B, const double *zu) {
   if (!zu) return fail("null warm start");
   HIP_OK(hipMemcpyAsync(h->zu, zu, (size_t)B * 7 * h->ks.N * 8, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cfz_mpc_set_carry(cfz_handle *h, int B, const int32_t *carry) {
+  if (check(h, B)) return -1;
+  if (!carry) { h->carry_set = false; return 0; }
+  HIP_OK(hipMemcpy(h->carry, carry, (size_t)B * 4, hipMemcpyHostToDevice));
+  h->carry_set = true;
   return 0;
 }
 
@@ -621,6 +644,7 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   HIP_OK(hipMalloc(&h->ref_table, (size_t)V * T * 7 * 8)); HIP_OK(hipMalloc(&h->pred, B * 7 * N * 8));
   HIP_OK(hipMalloc(&h->state, B * 5 * 8)); HIP_OK(hipMalloc(&h->kidx, (size_t)S * 4));
   HIP_OK(hipMalloc(&h->order, B * 4));
+  HIP_OK(hipMemset(h->wst, 0, (size_t)h->max_batch * h->wst_stride * 8));  // first iteration: cold multipliers
   for (void *p : {(void *)h->pred2, (void *)h->scratch, (void *)h->queue, (void *)h->ctrl, (void *)h->done, (void *)h->iter_sum}) if (p) (void)hipFree(p);
   h->pred2 = h->scratch = nullptr; h->queue = h->ctrl = h->done = h->iter_sum = nullptr; h->queue_cap = 0; h->grid_blocks = 0; h->steps_done = 0;
   HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
@@ -645,7 +669,7 @@ int cfz_loop_step(cfz_handle *h) {
                      h->kidx, h->pred, h->state, h->x0, h->ref, h->nbr, h->zu);
   HIP_OK(hipGetLastError());
   if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, false, h->stream,
-                   h->have_order ? h->order : nullptr)) return -1;
+                   h->have_order ? h->order : nullptr, 1)) return -1;
   hipLaunchKernelGGL(order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->iters, h->order);
   HIP_OK(hipGetLastError());
   h->have_order = true;
@@ -703,7 +727,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(64), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
                      h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
-                     h->iters, h->stats, h->iter_sum);
+                     h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   // predictions after K iterations live in parity K%2; advance the scenario clocks by K

@@ -67,7 +67,7 @@ struct KSpec {
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
       bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
-      reg_primal, stall_kappa;
+      reg_primal, stall_kappa, warm_push;
   // static obstacles as the kernel reads them, n_obs x 20 doubles in global memory: A[4][2], b[4], V[4][2]
   // (L1/L2-resident; indexing the arrays above with a lane-varying j would copy this struct to scratch)
   const double *obs_tab;
@@ -493,8 +493,23 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
 // dual_out (optional): l,m [N][4 n_obs], lam_ij, lam_ji [n_nbr][N][4], s [n_nbr][N][2].
 struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; unsigned long long *stamps; };
 
+// State a converged solve leaves in global memory for the next MPC iteration of the same vehicle
+// (oracle/mpc_nlp.py carry_state), in doubles: z[N][nr] | zl[N][6] | zu[N][6] | pi0[5] | pi[N][5] | mu | valid |
+// working-set codes, one byte per block.
+struct CarryLay { int z, zl, zu, pi0, pi, mu, valid, sel, stride; };
+CFZ_FN CarryLay carry_layout(int N, int nb) {
+  CarryLay c; int o = 0;
+  c.z = o; o += N * 2 * nb; c.zl = o; o += N * 6; c.zu = o; o += N * 6; c.pi0 = o; o += 5; c.pi = o; o += N * 5;
+  c.mu = o; o += 1; c.valid = o; o += 1; c.sel = o; o += (N * nb + 7) / 8;
+  c.stride = (o + 7) & ~7;
+  return c;
+}
+
+// wst: this instance's carry record (nullptr: none kept).  carry_in != 0: start from it if it is valid
+// (oracle/mpc_nlp.py warm_from_carry).  A converged solve refreshes the record, any other outcome invalidates it.
 CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *refg, const double *nbrg, double *zu,
-                           double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo) {
+                           double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo, double *wst = nullptr,
+                           int carry_in = 0) {
   const int N = sp.N, nb = L.nb, nr = L.nr, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
   const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
@@ -530,8 +545,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   CFZ_END
   if (red_min(m, L, 0) < sp.dmin - 2.0 * sp.constr_viol_tol) {
     out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = red_min(m, L, 0);
+    if (wst) { CFZ_LANES(lane) if (lane == 0) wst[carry_layout(N, nb).valid] = 0.0; CFZ_END }
     return;
   }
+  const CarryLay CL = carry_layout(N, nb);
+  const bool warm = wst != nullptr && carry_in != 0 && wst[CL.valid] != 0.0;
+  const double mu0 = warm ? fmin(fmax(wst[CL.mu], mu_floor), sp.mu_init) : sp.mu_init;
   CFZ_LANES(lane)
     // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
     for (int t = lane; t < N * nb; t += 64) {
@@ -544,27 +563,58 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       const int c0 = select_rows(A, b, V, x, y, cn, sn, sp.g, 0);
       sel_ptr(m, L)[t] = c0;
       rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c0, sep, nullptr);
-      for (int r = 0; r < 2; ++r) {
-        m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
-        m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
+      if (!warm) {
+        for (int r = 0; r < 2; ++r) {
+          m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
+          m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
+        }
+      } else {
+        // a row whose (face, vertex) identity exists in the carried working set of stage k+1 keeps its multiplier
+        const int ko = k + 1 < N ? k + 1 : N - 1;
+        const int so = reinterpret_cast<const unsigned char *>(wst + CL.sel)[ko * nb + j];
+        for (int r = 0; r < 2; ++r) {
+          const int vn = r == 0 ? ((c0 >> 2) & 3) : (c0 & 3);
+          double z = 0.0;
+          if ((so >> 4) == (c0 >> 4)) {
+            if (((so >> 2) & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2];
+            else if ((so & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2 + 1];
+          }
+          const double gap = sep[r] - sp.dmin;
+          double sg;
+          if (z > 0.0) sg = fmax(fmax(gap, mu0 / z), sp.warm_push);
+          else { sg = fmax(gap, sp.bound_push); z = mu0 / sg; }
+          m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = z; m[L.nuc + 2 * t + r] = -z;
+        }
       }
     }
   CFZ_END
   CFZ_LANES(lane)
     if (lane < N) {
+      const int ko = lane + 1 < N ? lane + 1 : N - 1;
       for (int q = 0; q < 6; ++q) {
         const double lo = sp.bounds[2 * q], hi = sp.bounds[2 * q + 1];
-        const double pl = fmin(sp.bound_push * fmax(1.0, fabs(lo)), sp.bound_frac * (hi - lo));
-        const double pu = fmin(sp.bound_push * fmax(1.0, fabs(hi)), sp.bound_frac * (hi - lo));
         double v = m[L.p + lane * kNP + bcol(q)];
-        v = fmax(v, lo + pl); v = fmin(v, hi - pu);
+        if (!warm) {
+          const double pl = fmin(sp.bound_push * fmax(1.0, fabs(lo)), sp.bound_frac * (hi - lo));
+          const double pu = fmin(sp.bound_push * fmax(1.0, fabs(hi)), sp.bound_frac * (hi - lo));
+          v = fmax(v, lo + pl); v = fmin(v, hi - pu);
+          m[L.zl + lane * 6 + q] = 1.0; m[L.zu + lane * 6 + q] = 1.0;
+        } else {
+          v = fmin(fmax(v, lo + sp.warm_push), hi - sp.warm_push);
+          m[L.zl + lane * 6 + q] = fmax(wst[CL.zl + ko * 6 + q], mu0 / (hi - lo));
+          m[L.zu + lane * 6 + q] = fmax(wst[CL.zu + ko * 6 + q], mu0 / (hi - lo));
+        }
         m[L.p + lane * kNP + bcol(q)] = v;
-        m[L.zl + lane * 6 + q] = 1.0; m[L.zu + lane * 6 + q] = 1.0;
+      }
+      if (warm && lane + 1 < N) {
+        const int kp = lane + 1 < N - 1 ? lane + 1 : N - 2;
+        for (int i = 0; i < 5; ++i) m[L.pi + lane * 5 + i] = wst[CL.pi + kp * 5 + i];
       }
     }
+    if (warm && lane < 5) m[L.pi0 + lane] = wst[CL.pi + lane];
   CFZ_END
 
-  double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
+  double mu = mu0, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
   CFZ_STAMP_DECL
   CFZ_STAMP(0);  // setup
   int nfilt = 0, status = 1, iter = 0;
@@ -1107,6 +1157,21 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   CFZ_END
   out_d[0] = fval_last; out_d[1] = err0; out_d[2] = red_min(m, L, 0);
   out_i[0] = iter; out_i[1] = status;
+  if (wst) {  // leave the multipliers for the next MPC iteration of this vehicle, or say that there are none
+    CFZ_LANES(lane)
+      if (status == 0) {
+        for (int i = lane; i < N * nr; i += 64) wst[CL.z + i] = m[L.zs + i];
+        for (int i = lane; i < N * 6; i += 64) { wst[CL.zl + i] = m[L.zl + i]; wst[CL.zu + i] = m[L.zu + i]; }
+        for (int i = lane; i < N * 5; i += 64) wst[CL.pi + i] = i < (N - 1) * 5 ? m[L.pi + i] : 0.0;
+        if (lane < 5) wst[CL.pi0 + lane] = m[L.pi0 + lane];
+        unsigned char *ws = reinterpret_cast<unsigned char *>(wst + CL.sel);
+        for (int i = lane; i < N * nb; i += 64) ws[i] = sel_ptr(m, L)[i];
+        if (lane == 0) { wst[CL.mu] = mu; wst[CL.valid] = 1.0; }
+      } else if (lane == 0) {
+        wst[CL.valid] = 0.0;
+      }
+    CFZ_END
+  }
   CFZ_STAMP(10);  // output
 #if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
   // slot 0 ("setup", a handful of ticks) carries the wall time of the solve in 10 ns units (constant 100 MHz counter)

@@ -26,9 +26,9 @@ class _CSpec(C.Structure):
     ]
 
 
-_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "reserved")
+_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "carry_duals")
 _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split()
+             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
 
 
 class _COptions(C.Structure):
@@ -111,6 +111,7 @@ def load_library(path=None):
     lib.cfz_kernel_info.argtypes = [vp, vp, vp]
     lib.cfz_mpc_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.cfz_mpc_set_warm.argtypes = [vp, C.c_int, vp]
+    lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
     lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.cfz_mpc_stats.argtypes = [vp, C.c_int, i32p, i32p, vp, vp, vp]
@@ -130,7 +131,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -185,9 +186,11 @@ class Engine:
             raise RuntimeError(f"{what}: " + self.lib.cfz_last_error().decode())
 
     # ---- host-buffer path ------------------------------------------------------------------
-    def solve(self, x0, ref, nbr, zu, want_duals=True):
+    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None):
         """x0 [B,5], ref [B,3,N], nbr [B,n_nbr,3,N], zu [B,7,N] (warm start) ->
-        dict(zu, status, iters, cost, kkt_err, min_sep[, l, m, lam_ij, lam_ji, s], solve_ms)."""
+        dict(zu, status, iters, cost, kkt_err, min_sep[, l, m, lam_ij, lam_ji, s], solve_ms).
+        carry: int/bool [B]; carry[b] says that this solve of slot b is the MPC iteration following the one last
+        solved in slot b, so the interior point starts from its multipliers (`cfz_mpc_set_carry`)."""
         sp = self.spec
         N, no, nn = sp.N, sp.n_obs, sp.n_nbr
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
@@ -196,6 +199,9 @@ class Engine:
         nbr = _f64(nbr, (B, nn, 3, N)) if nn else None
         self._ck(self.lib.cfz_mpc_set_params(self._h, B, _ptr(x0), _ptr(ref), _ptr(nbr)), "cfz_mpc_set_params")
         self._ck(self.lib.cfz_mpc_set_warm(self._h, B, _ptr(zu)), "cfz_mpc_set_warm")
+        if carry is not None:
+            cflags = np.ascontiguousarray(np.broadcast_to(np.asarray(carry), (B,)), dtype=np.int32)
+            self._ck(self.lib.cfz_mpc_set_carry(self._h, B, _ptr(cflags)), "cfz_mpc_set_carry")
         self._ck(self.lib.cfz_mpc_solve(self._h, B), "cfz_mpc_solve")
         out = dict(zu=np.empty((B, 7, N)), status=np.empty(B, np.int32), iters=np.empty(B, np.int32),
                    cost=np.empty(B), kkt_err=np.empty(B), min_sep=np.empty(B))

@@ -31,9 +31,16 @@ typedef struct {
   /* solver options (oracle/ipm.py IpmOptions) */
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu,
       tau_min, bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw,
-      s_theta, s_phi, reg_primal, stall_kappa;
+      s_theta, s_phi, reg_primal, stall_kappa, warm_push;
   int filter_cap, max_backtrack, stall_iters, row_curvature;
 } cfz_port_spec;
+
+/* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
+typedef struct {
+  int valid;
+  int sel[MAXN][MAXB];
+  double z[MAXN][MAXR], zl[MAXN][6], zu[MAXN][6], pi0[5], pi[MAXN][5], mu;
+} cfz_port_carry;
 
 typedef struct {
   double p[MAXN][NP], sg[MAXN][MAXR];              /* primal: stage vars, slacks (one per row) */
@@ -285,8 +292,10 @@ static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *
 /* p_io: [N][7] warm start in (x,y,psi,v,delta,a,w per stage), solution out.
  * stats: [0]=iters [1]=status(0 ok,1 maxiter,2 linesearch,3 nan,4 initial state in collision) ; fstats: [0]=f [1]=err [2]=mu
  * trace (optional): per iteration 4 doubles (mu, err0, cviol, dual_inf) then p[N][7] -> stride 4+7N */
-int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
-                   double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap) {
+int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
+                         double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap,
+                         const cfz_port_carry *cin, cfz_port_carry *cout) {
+  if (cout) cout->valid = 0;
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
   if (N > MAXN || N < 2 || nblk > MAXB) return -1;
   static iterate it, dt_; /* step stored in an `iterate` too */
@@ -349,6 +358,37 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
     for (int i = 0; i < 5; ++i) it.pi[k][i] = 0.0;
   }
   for (int i = 0; i < 5; ++i) it.pi0[i] = 0.0;
+  if (cin && cin->valid) {
+    /* start from the previous MPC iteration's multipliers (oracle/mpc_nlp.py warm_from_carry): the horizon has
+     * moved on by one stage, new stage k takes old stage min(k+1, N-1) */
+    mu = fmin(fmax(cin->mu, mu_floor), sp->mu_init);
+    for (int k = 0; k < N; ++k) {
+      const int ko = k + 1 < N ? k + 1 : N - 1;
+      for (int q = 0; q < 6; ++q) {
+        double lo = sp->bounds[2 * q], hi = sp->bounds[2 * q + 1];
+        it.p[k][BCOL[q]] = fmin(fmax(p_io[k * NP + BCOL[q]], lo + sp->warm_push), hi - sp->warm_push);
+        it.zl[k][q] = fmax(cin->zl[ko][q], mu / (hi - lo)); it.zu[k][q] = fmax(cin->zu[ko][q], mu / (hi - lo));
+      }
+      for (int j = 0; j < nblk; ++j) {
+        const int so = cin->sel[ko][j], sn = sel[k][j];
+        for (int r = 0; r < 2; ++r) {
+          const int vn = r == 0 ? (sn >> 2) & 3 : sn & 3;
+          double z = 0.0;
+          if ((so >> 4) == (sn >> 4)) {
+            if (((so >> 2) & 3) == vn) z = cin->z[ko][2 * j];
+            else if ((so & 3) == vn) z = cin->z[ko][2 * j + 1];
+          }
+          const double gap = sep[k][2 * j + r] - sp->dmin;
+          double sg;
+          if (z > 0.0) sg = fmax(fmax(gap, mu / z), sp->warm_push);
+          else { sg = fmax(gap, sp->bound_push); z = mu / sg; }
+          it.sg[k][2 * j + r] = sg; it.zs[k][2 * j + r] = z; it.nuc[k][2 * j + r] = -z;
+        }
+      }
+    }
+    for (int i = 0; i < 5; ++i) it.pi0[i] = cin->pi[0][i];
+    for (int k = 0; k + 1 < N; ++k) { const int ko = k + 1 < N - 1 ? k + 1 : N - 2; for (int i = 0; i < 5; ++i) it.pi[k][i] = cin->pi[ko][i]; }
+  }
 
   for (iter = 0; iter <= sp->max_iter; ++iter) {
     /* ---- working set: rows keep slack and multipliers while their (face, vertex) identity lasts */
@@ -638,7 +678,24 @@ int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref,
   }
   stats[0] = iter; stats[1] = status;
   fstats[0] = fval; fstats[1] = err0; fstats[2] = mu;
+  if (cout && status == 0) {
+    cout->valid = 1; cout->mu = mu;
+    for (int k = 0; k < N; ++k) {
+      for (int j = 0; j < nblk; ++j) cout->sel[k][j] = sel[k][j];
+      for (int j = 0; j < nb; ++j) cout->z[k][j] = it.zs[k][j];
+      for (int q = 0; q < 6; ++q) { cout->zl[k][q] = it.zl[k][q]; cout->zu[k][q] = it.zu[k][q]; }
+      for (int i = 0; i < 5; ++i) cout->pi[k][i] = k + 1 < N ? it.pi[k][i] : 0.0;
+    }
+    for (int i = 0; i < 5; ++i) cout->pi0[i] = it.pi0[i];
+  }
   return 0;
 }
+
+int cfz_port_solve(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
+                   double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap) {
+  return cfz_port_solve_carry(sp, x0, ref, nbr, p_io, sep_out, cert_out, stats, fstats, trace, trace_cap, 0, 0);
+}
+
+int cfz_port_sizeof_carry(void) { return (int)sizeof(cfz_port_carry); }
 
 int cfz_port_sizeof_spec(void) { return (int)sizeof(cfz_port_spec); }

@@ -47,6 +47,7 @@ class IpmOptions:
     # their multipliers (NLPs that provide hess_gn(x, nu)).  Without it the iteration is not contractive when a
     # vehicle is pushed hard against a separation row (period-2 oscillation, hundreds of iterations).
     row_curvature: bool = True
+    warm_push: float = 1e-6  # distance from a bound kept by a start that carries the previous solve's multipliers
     stall_kappa: float = 0.9
     stall_iters: int = 10
     dual_inf_tol: float = 1.0  # IPOPT default
@@ -94,16 +95,25 @@ def push_to_interior(x, xl, xu, opt: IpmOptions):
     return x
 
 
-def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None):
-    """Returns dict(X, nu, zl, zu, status, iters, mu, err, f)."""
+def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
+    """Returns dict(X, nu, zl, zu, status, iters, mu, err, f).
+    warm: optional dict(zl, zu, nu, mu) -- start from these multipliers and barrier parameter instead of
+    z = 1, nu = 0, mu = mu_init; X0 is then taken as it is (the caller has placed it inside the bounds)."""
     xl, xu = nlp.xl, nlp.xu
     hasl, hasu = np.isfinite(xl), np.isfinite(xu)
     n, m = nlp.n, nlp.m
-    x = push_to_interior(np.asarray(X0, float), xl, xu, opt)
-    zl = np.where(hasl, 1.0, 0.0)
-    zu = np.where(hasu, 1.0, 0.0)
-    nu = np.zeros(m)
-    mu = opt.mu_init
+    if warm is None:
+        x = push_to_interior(np.asarray(X0, float), xl, xu, opt)
+        zl = np.where(hasl, 1.0, 0.0)
+        zu = np.where(hasu, 1.0, 0.0)
+        nu = np.zeros(m)
+        mu = opt.mu_init
+    else:
+        x = np.asarray(X0, float).copy()
+        zl = np.where(hasl, np.asarray(warm["zl"], float), 0.0)
+        zu = np.where(hasu, np.asarray(warm["zu"], float), 0.0)
+        nu = np.asarray(warm["nu"], float).copy()
+        mu = float(warm["mu"])
     mu_floor = min(opt.tol, opt.compl_inf_tol) / (opt.kappa_eps + 1.0)
     filt, filt_mu = None, None
     delta_w_last = 0.0

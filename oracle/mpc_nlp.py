@@ -596,18 +596,87 @@ def initial_state_in_collision(nlp: "MpcNlp", tol):
     return False
 
 
-def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None):
+def carry_state(nlp, res):
+    """What one converged solve hands to the solve of the next MPC iteration of the same vehicle (`solve_mpc(carry=)`):
+    multipliers of the row slacks z [N,nr], working set sel [N,nb], box multipliers zl, zu [N,6] (columns x,y,v,delta,a,w),
+    multipliers of the initial-state row pi0 [5] and of the dynamics pi [N-1,5], final barrier parameter mu."""
+    N, ns = nlp.spec.N, nlp.ns
+    Zl, Zu = res["zl"].reshape(N, ns), res["zu"].reshape(N, ns)
+    cols = [0, 1, 3, 4, 5, 6]
+    return dict(z=Zl[:, NP:].copy(), sel=nlp.sel.copy(), zl=Zl[:, cols].copy(), zu=Zu[:, cols].copy(),
+                pi0=res["nu"][0:5].copy(), pi=res["nu"][5 : nlp.c_blk0].reshape(N - 1, 5).copy(), mu=float(res["mu"]))
+
+
+def warm_from_carry(nlp, X, carry, opt):
+    """Initial point of the interior-point iteration from the previous MPC iteration's solution (IPOPT's
+    warm_start_init_point in spirit).  The horizon has moved on by one stage: new stage k takes old stage
+    min(k+1, N-1).  X: packed primal warm start with fresh working set and slacks sigma = sep - dmin.
+      mu0   = clip(carry mu, mu_floor, mu_init)
+      boxes : p clipped to [lo + warm_push, hi - warm_push]; z = max(carried z, mu0 / (hi - lo))
+      rows  : a row whose (face, vertex) identity exists in the carried working set of that stage keeps its
+              multiplier z and gets sigma = max(sep - dmin, mu0 / z, warm_push); any other row starts as in a cold
+              solve, sigma = max(sep - dmin, bound_push), z = mu0 / sigma; nu = -z
+      pi    : initial-state row <- old first dynamics row; dynamics row k <- old row min(k+1, N-2)
+    Returns (X, dict(zl, zu, nu, mu)) for ipm.solve(warm=)."""
+    N, ns, nr, nb = nlp.spec.N, nlp.ns, nlp.nr, nlp.nb
+    mu_floor = min(opt.tol, opt.compl_inf_tol) / (opt.kappa_eps + 1.0)
+    mu0 = min(max(carry["mu"], mu_floor), opt.mu_init)
+    X = X.reshape(N, ns).copy()
+    Zl, Zu = np.zeros((N, ns)), np.zeros((N, ns))
+    NU = np.zeros((N, nr))
+    xl, xu = nlp.xl.reshape(N, ns), nlp.xu.reshape(N, ns)
+    cols = [0, 1, 3, 4, 5, 6]
+    for k in range(N):
+        ko = min(k + 1, N - 1)
+        for q, c in enumerate(cols):
+            lo, hi = xl[k, c], xu[k, c]
+            X[k, c] = min(max(X[k, c], lo + opt.warm_push), hi - opt.warm_push)
+            Zl[k, c] = max(carry["zl"][ko, q], mu0 / (hi - lo))
+            Zu[k, c] = max(carry["zu"][ko, q], mu0 / (hi - lo))
+        for j in range(nb):
+            so, sn = int(carry["sel"][ko, j]), int(nlp.sel[k, j])
+            for r in range(2):
+                vn = (sn >> 2) & 3 if r == 0 else sn & 3
+                z = 0.0
+                if (so >> 4) == (sn >> 4):
+                    if ((so >> 2) & 3) == vn:
+                        z = carry["z"][ko, 2 * j]
+                    elif (so & 3) == vn:
+                        z = carry["z"][ko, 2 * j + 1]
+                gap = X[k, NP + 2 * j + r]
+                if z > 0.0:
+                    sg = max(gap, mu0 / z, opt.warm_push)
+                else:
+                    sg = max(gap, opt.bound_push)
+                    z = mu0 / sg
+                X[k, NP + 2 * j + r], Zl[k, NP + 2 * j + r], NU[k, 2 * j + r] = sg, z, -z
+    nu = np.zeros(nlp.m)
+    nu[0:5] = carry["pi"][0]
+    for k in range(N - 1):
+        nu[5 + 5 * k : 10 + 5 * k] = carry["pi"][min(k + 1, N - 2)]
+    nu[nlp.c_blk0 :] = NU.ravel()
+    return X.ravel(), dict(zl=Zl.ravel(), zu=Zu.ravel(), nu=nu, mu=mu0)
+
+
+def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None, carry=None):
     """One MPC-step solve by the full-KKT oracle.  zu [7,N] warm start (rows x,y,psi,v,delta,a,w).
-    Returns dict(zu [7,N], status, iters, f, sep [N,n_blk], sol (reference-layout dict))."""
+    carry: `carry` entry of the result of the previous MPC iteration of the same vehicle (None = cold multipliers).
+    Returns dict(zu [7,N], status, iters, f, sep [N,n_blk], sol (reference-layout dict), carry (None unless converged))."""
     from . import ipm
 
     opt = opt or ipm.IpmOptions()
     nlp = MpcNlp(spec, x0, ref, nbr)
     zu = np.asarray(zu, float)
     if initial_state_in_collision(nlp, opt.constr_viol_tol):
-        return dict(zu=zu.copy(), status=STATUS_INFEASIBLE_X0, iters=0, f=0.0, sep=None, sol=None)
+        return dict(zu=zu.copy(), status=STATUS_INFEASIBLE_X0, iters=0, f=0.0, sep=None, sol=None, carry=None)
     warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
-    res = ipm.solve(nlp, nlp.pack(warm), opt, trace=trace)
+    X0 = nlp.pack(warm)
+    if carry is None:
+        res = ipm.solve(nlp, X0, opt, trace=trace)
+    else:
+        X0, w = warm_from_carry(nlp, X0, carry, opt)
+        res = ipm.solve(nlp, X0, opt, trace=trace, warm=w)
     sol = nlp.unpack(res["X"])
     out = np.stack([sol[k] for k in ("x", "y", "psi", "v", "delta", "a", "w")])
-    return dict(zu=out, status=res["status"], iters=res["iters"], f=res["f"], sep=sol["sep"], sol=sol)
+    return dict(zu=out, status=res["status"], iters=res["iters"], f=res["f"], sep=sol["sep"], sol=sol,
+                carry=carry_state(nlp, res) if res["status"] == 0 else None)

@@ -29,7 +29,7 @@ class _Spec(C.Structure):
         ("A_obs", C.c_double * (MAXB * 8)), ("b_obs", C.c_double * (MAXB * 4)), ("V_obs", C.c_double * (MAXB * 8)),
     ] + [(k, C.c_double) for k in (
         "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-        "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split()
+        "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
     ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int)]
 
 
@@ -46,7 +46,7 @@ def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
         V[j] = polytope_vertices(spec.A_obs[j], spec.b_obs[j])[0]
     s.A_obs[:] = list(A.ravel()); s.b_obs[:] = list(b.ravel()); s.V_obs[:] = list(V.ravel())
     for k in ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split():
+              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split():
         setattr(s, k, getattr(opt, k))
     s.filter_cap, s.max_backtrack, s.stall_iters = opt.filter_cap, opt.max_backtrack, opt.stall_iters
     s.row_curvature = int(opt.row_curvature)
@@ -64,9 +64,21 @@ def _load():
     return _lib
 
 
-def solve(spec: MpcSpec, x0, ref, nbr, warm_p, opt: IpmOptions = IpmOptions(), trace_cap=0):
-    """warm_p [N,7] -> dict(p [N,7], sep [N,nb], cert [N,nb], iters, status, f, err, mu, trace)."""
+MAXN, MAXR = 64, 32
+
+
+class Carry(C.Structure):
+    """cfz_port_carry: the state a converged solve hands to the next MPC iteration of the same vehicle."""
+    _fields_ = [("valid", C.c_int), ("sel", C.c_int * (MAXN * MAXB)), ("z", C.c_double * (MAXN * MAXR)),
+                ("zl", C.c_double * (MAXN * 6)), ("zu", C.c_double * (MAXN * 6)), ("pi0", C.c_double * 5),
+                ("pi", C.c_double * (MAXN * 5)), ("mu", C.c_double)]
+
+
+def solve(spec: MpcSpec, x0, ref, nbr, warm_p, opt: IpmOptions = IpmOptions(), trace_cap=0, carry=None):
+    """warm_p [N,7] -> dict(p [N,7], sep [N,nb], cert [N,nb], iters, status, f, err, mu, trace, carry).
+    carry: the `carry` of the previous MPC iteration's result (None = cold multipliers)."""
     lib = _load()
+    assert lib.cfz_port_sizeof_carry() == C.sizeof(Carry)
     N, nb = spec.N, spec.n_blk
     cs = make_spec(spec, opt)
     p = np.ascontiguousarray(warm_p, dtype=np.float64).copy()
@@ -77,8 +89,10 @@ def solve(spec: MpcSpec, x0, ref, nbr, warm_p, opt: IpmOptions = IpmOptions(), t
     stats = np.zeros(2, dtype=np.int32); fst = np.zeros(3)
     trace = np.zeros((max(trace_cap, 1), 4 + 7 * N))
     dp = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = lib.cfz_port_solve(C.byref(cs), dp(x0), dp(ref), dp(nbr), dp(p), dp(sep), dp(cert), dp(stats), dp(fst),
-                            dp(trace) if trace_cap else None, C.c_int(trace_cap))
+    cout = Carry()
+    rc = lib.cfz_port_solve_carry(C.byref(cs), dp(x0), dp(ref), dp(nbr), dp(p), dp(sep), dp(cert), dp(stats), dp(fst),
+                                  dp(trace) if trace_cap else None, C.c_int(trace_cap),
+                                  C.byref(carry) if carry is not None else None, C.byref(cout))
     assert rc == 0
     return dict(p=p, sep=sep, cert=cert, iters=int(stats[0]), status=int(stats[1]), f=fst[0], err=fst[1], mu=fst[2],
-                trace=trace[: min(trace_cap, stats[0] + 1)])
+                trace=trace[: min(trace_cap, stats[0] + 1)], carry=cout if cout.valid else None)

@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(ROOT, "tests", "_build", "libcfz_emu.so")
 _OPTS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa").split()
+         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
 
 
 class KSpec(C.Structure):
@@ -57,8 +57,9 @@ def make_kspec(spec, opt):
 _lib = None
 
 
-def solve(spec, opt, x0, ref, nbr, zu, want_duals=True):
-    """zu [7,N] warm start -> dict(zu, iters, status, cost, err, min_sep, l, m, lam_ij, lam_ji, s)."""
+def solve(spec, opt, x0, ref, nbr, zu, want_duals=True, carry=None):
+    """zu [7,N] warm start -> dict(zu, iters, status, cost, err, min_sep, l, m, lam_ij, lam_ji, s, carry).
+    carry: the `carry` record (numpy array) of the previous MPC iteration's result; None = cold multipliers."""
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
@@ -73,7 +74,9 @@ def solve(spec, opt, x0, ref, nbr, zu, want_duals=True):
     lij = np.zeros((nn, N, 4)); lji = np.zeros((nn, N, 4)); s = np.zeros((nn, N, 2))
     dp = lambda a: a.ctypes.data_as(C.c_void_p)
     dd = (lambda a: dp(a)) if want_duals else (lambda a: None)
-    rc = _lib.cfz_emu_solve(C.byref(ks), dp(x0), dp(ref), dp(nbr), dp(zu), dp(oi), dp(od), dd(l), dd(m), dd(lij), dd(lji), dd(s))
+    wst = np.zeros(_lib.cfz_emu_carry_doubles(N, no + nn)) if carry is None else np.array(carry, dtype=np.float64)
+    rc = _lib.cfz_emu_solve(C.byref(ks), dp(x0), dp(ref), dp(nbr), dp(zu), dp(oi), dp(od), dd(l), dd(m), dd(lij), dd(lji), dd(s),
+                            dp(wst), C.c_int(0 if carry is None else 1))
     assert rc > 0
     return dict(zu=zu, iters=int(oi[0]), status=int(oi[1]), cost=od[0], err=od[1], min_sep=od[2], l=l, m=m, lam_ij=lij,
-                lam_ji=lji, s=s, lds_doubles=rc)
+                lam_ji=lji, s=s, lds_doubles=rc, carry=wst)

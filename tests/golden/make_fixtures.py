@@ -140,6 +140,28 @@ def mpc_golden(table):
                         zu=np.array(ZU), sol=np.array(SOL), meta=np.array(META), A_obs=spec.A_obs, b_obs=spec.b_obs)
 
 
+def carry_golden():
+    """Two vehicles over three consecutive MPC iterations (inputs recorded from a closed-loop run of the engine,
+    tools/capture_hard.py -> carry_inputs.npz): every solve after the first starts from the multipliers of the one
+    before (`solve_mpc(carry=)`).  Stored: status, iterations, solution of every solve, with and without carrying."""
+    obs = compute_obstacles()
+    spec = MpcSpec(A_obs=np.stack([o.A for o in obs]), b_obs=np.stack([o.b for o in obs]), n_nbr=3)
+    ci = np.load(os.path.join(HERE, "carry_inputs.npz"))
+    sol, meta = [], []
+    for seq in range(2):
+        carry = None
+        for t in range(3):
+            i = 3 * seq + t
+            cold = solve_mpc(spec, ci["x0"][i], ci["ref"][i], ci["nbr"][i], ci["zu"][i])
+            res = solve_mpc(spec, ci["x0"][i], ci["ref"][i], ci["nbr"][i], ci["zu"][i], carry=carry)
+            carry = res["carry"]
+            sol.append(res["zu"]); meta.append([res["status"], res["iters"], res["f"], cold["status"], cold["iters"], cold["f"]])
+            print("sequence", seq, "step", t, "carried: status", res["status"], "iters", res["iters"], "| cold: iters", cold["iters"],
+                  "max |dz|", np.abs(res["zu"] - cold["zu"]).max())
+    np.savez_compressed(os.path.join(HERE, "carry_golden.npz"), sol=np.array(sol), meta=np.array(meta))
+
+
 if __name__ == "__main__":
     pytypes_fields()
     mpc_golden(refs_4v())
+    carry_golden()

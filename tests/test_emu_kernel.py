@@ -31,6 +31,30 @@ def test_kernel_source_matches_oracle_on_goldens(golden, ospec):
             assert res["eq"] < 1e-2 and res["ineq"] < 1e-2 and res["bound"] == 0.0
 
 
+def test_carried_multipliers_port_and_kernel_source_match_oracle(ospec):
+    """Three consecutive MPC iterations of two vehicles, each solve started from the multipliers of the one before
+    (tests/golden/carry_golden.npz from the full-KKT oracle): the C port and the kernel source reproduce status,
+    iteration count and solution; carrying takes far fewer iterations than the cold solves and lands in the same
+    local solution to within the solver tolerance."""
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ci, cg = np.load(os.path.join(here, "carry_inputs.npz")), np.load(os.path.join(here, "carry_golden.npz"))
+    opt = ipm.IpmOptions()
+    for seq in range(2):
+        ce, cp = None, None
+        for t in range(3):
+            i = 3 * seq + t
+            st, it, cold_it = int(cg["meta"][i, 0]), int(cg["meta"][i, 1]), int(cg["meta"][i, 4])
+            re_ = emu.solve(ospec, opt, ci["x0"][i], ci["ref"][i], ci["nbr"][i], ci["zu"][i], want_duals=False, carry=ce)
+            rp = port.solve(ospec, ci["x0"][i], ci["ref"][i], ci["nbr"][i], ci["zu"][i].T.copy(), opt, carry=cp)
+            ce, cp = re_["carry"], rp["carry"]
+            assert (re_["status"], re_["iters"]) == (st, it) == (rp["status"], rp["iters"]), (seq, t)
+            assert np.abs(re_["zu"] - cg["sol"][i]).max() < 1e-6 and np.abs(rp["p"].T - cg["sol"][i]).max() < 1e-6
+            if t > 0:
+                assert it <= cold_it // 3
+
+
 def test_kernel_source_other_shapes(ospec):
     """n_nbr = 0 / n_obs = 4 (BASELINE.json config 2) and a short horizon: same answers as the C port."""
     from conflict_rez_amd import scenarios

@@ -151,6 +151,52 @@ def test_persistent_loop_equals_stepwise_loop(eng):
         assert np.array_equal(a[key], c[key]), key
 
 
+def test_carried_multipliers_match_oracle(eng):
+    """cfz_mpc_set_carry: consecutive MPC iterations of one slot started from the previous solve's multipliers
+    reproduce the oracle's carried sequence (tests/golden/carry_golden.npz); without the flag the solve is cold."""
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ci, cg = np.load(os.path.join(here, "carry_inputs.npz")), np.load(os.path.join(here, "carry_golden.npz"))
+    for t in range(3):
+        idx = [t, 3 + t]  # slot 0 = sequence 0, slot 1 = sequence 1
+        out = eng.solve(ci["x0"][idx], ci["ref"][idx], ci["nbr"][idx], ci["zu"][idx], want_duals=False,
+                        carry=None if t == 0 else [1, 1])
+        for slot, i in enumerate(idx):
+            assert (out["status"][slot], out["iters"][slot]) == (int(cg["meta"][i, 0]), int(cg["meta"][i, 1])), (t, slot)
+            assert np.abs(out["zu"][slot] - cg["sol"][i]).max() < 1e-6
+    # same inputs again without the flag: the cold iteration counts
+    out = eng.solve(ci["x0"][[2, 5]], ci["ref"][[2, 5]], ci["nbr"][[2, 5]], ci["zu"][[2, 5]], want_duals=False)
+    assert list(out["iters"]) == [int(cg["meta"][2, 4]), int(cg["meta"][5, 4])]
+
+
+def test_closed_loop_carry_saves_iterations():
+    """The closed loop carries multipliers from one MPC iteration to the next: same outcomes (statuses within a
+    handful of instances, states within the solver tolerance band), less than 60 % of the iterations."""
+    from conflict_rez_amd import engine, scenarios
+
+    spec = scenarios.parking_lot_spec()
+    table, _ = scenarios.load_reference_table()
+    S, K = 128, 8
+    k0, noise = scenarios.sample_scenarios(S, table, seed=5)
+    res = {}
+    for carry in (1, 0):
+        e = engine.Engine(spec, max_batch=S * 4, carry_duals=carry)
+        e.loop_init(table, k0, noise)
+        e.loop_run(1)
+        first = e.loop_get()["iters"].sum()
+        n_it = e.loop_run(K - 1)
+        res[carry] = (e.loop_get(), n_it, first)
+        e.close()
+    a, b = res[1][0], res[0][0]
+    assert res[1][2] == res[0][2]  # the first iteration has nothing to carry
+    assert res[1][1] < 0.6 * res[0][1], (res[1][1], res[0][1])
+    assert (a["status"] != b["status"]).mean() < 0.02
+    # a different outcome of one solve (converged / fallback) sends that scenario down another path: compare the rest
+    d = np.abs(a["state"].reshape(-1, 5) - b["state"].reshape(-1, 5)).max(1)
+    assert (d < 5e-2).mean() > 0.95 and np.median(d) < 1e-3
+
+
 def test_python_shim_closed_loop_on_gpu(tmp_path):
     """`MultiDistributedFollower` through the real engine: 4 vehicles, 40 iterations, vehicles never overlap
     (separating-axis check on the driven states) and follow their plans; the drop-in surface end to end."""
