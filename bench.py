@@ -62,15 +62,23 @@ def cpu_baseline(spec, table, seconds=12.0, max_solves=4096):
     single = {"value": n1 / dt1, "unit": "solves/s", "cores": 1, "kind": "port",
               "sample": f"{n1} cold first-step solves of the same scenario sampler in {dt1:.1f} s, single thread "
                         f"({os.cpu_count()} host cores present), mean {its1 / max(n1, 1):.1f} IPM iterations"}
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    per = (max_solves + cores - 1) // cores
-    jobs = [(i * per, min((i + 1) * per, max_solves), seconds) for i in range(cores) if i * per < max_solves]
+    # The box reports 256 logical cores but the job may own fewer (cgroup quota): try 8, 16, 32, 64 processes over the
+    # same 4096 instances, a few seconds each, and report the best.
+    best = None
     try:  # spawn: this process already holds a GPU context; a worker that dies breaks the pool instead of hanging it
-        with cf.ProcessPoolExecutor(len(jobs), mp_context=mp.get_context("spawn")) as pool:
-            res = list(pool.map(_cpu_worker, jobs, timeout=seconds + 120))
+        for cores in [c for c in (8, 16, 32, 64) if c <= (os.cpu_count() or 1)] or [1]:
+            per = (max_solves + cores - 1) // cores
+            jobs = [(i * per, min((i + 1) * per, max_solves), seconds / 4) for i in range(cores) if i * per < max_solves]
+            with cf.ProcessPoolExecutor(len(jobs), mp_context=mp.get_context("spawn")) as pool:
+                res = list(pool.map(_cpu_worker, jobs, timeout=seconds + 120))
+            rate = sum(r[0] for r in res) / max(r[2] for r in res)  # slowest worker; start-up (imports) not counted
+            if best is None or rate > best[0]:
+                best = (rate, len(jobs), per, res)
     except Exception as e:  # noqa: BLE001 - the baseline is reporting only; fall back to the single-core figure
         single["note"] = f"all-core leg failed ({type(e).__name__}); single core only"
         return single
+    _, ncores, per, res = best
+    jobs = [None] * ncores
     wall = max(r[2] for r in res)  # slowest worker; process start-up (imports) is not counted
     n = sum(r[0] for r in res)
     return {"value": n / wall, "unit": "solves/s", "cores": len(jobs), "kind": "port",
@@ -113,6 +121,9 @@ def main():
     ap.add_argument("--max-iter", type=int, default=600, help="IPM iteration limit (reference: 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-obs", type=int, default=6, help="static obstacles (reference map: 6); fewer = experiments only")
+    ap.add_argument("--workload", choices=["mpc4", "single"], default="mpc4",
+                    help="mpc4: BASELINE.json configs[2], 4-vehicle distributed MPC (the metric); single: configs[1] in MPC form, "
+                         "independent single-vehicle problems, 4 obstacles, no neighbours (use --scenarios 256)")
     ap.add_argument("--mode", choices=["persistent", "step"], default="persistent",
                     help="persistent: K iterations in one launch, scenarios advance independently (cfz_loop_run); "
                          "step: one launch per iteration with a device-wide barrier in between (cfz_loop_step)")
@@ -135,9 +146,12 @@ def main():
 
     from conflict_rez_amd import engine, scenarios
 
-    spec = scenarios.parking_lot_spec(n_obs=args.n_obs)
+    single = args.workload == "single"
+    spec = scenarios.parking_lot_spec(n_obs=4 if single else args.n_obs, n_nbr=0 if single else 3)
     V = spec.n_nbr + 1
     table, _ = scenarios.load_reference_table()
+    if single:
+        table = table[rank % table.shape[0]][None].copy()  # every scenario follows one vehicle's plan, alone on the map
     S = args.scenarios
     k0, noise = scenarios.sample_scenarios(S, table, seed=2024 + rank)
     eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter)
@@ -210,8 +224,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: 4-vehicle distributed MPC (VehicleFollower.step), "
-                                   "N=30, 6 obstacles, closed loop on device", "scenarios_per_gpu": S,
+            "config": {"workload": ("BASELINE.json configs[1] in MPC form: independent single-vehicle problems, N=30, 4 obstacles, "
+                                    "no neighbours, closed loop on device") if single else
+                                   ("BASELINE.json configs[2]: 4-vehicle distributed MPC (VehicleFollower.step), "
+                                    "N=30, 6 obstacles, closed loop on device"), "scenarios_per_gpu": S,
                        "solves_per_step_per_gpu": B, "parallelism": f"scenario-sharded x{world}",
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
                        "ipm_iterations_rank0": ipm_iterations,
@@ -225,7 +241,7 @@ def main():
                          "note": "latency/FP64-issue bound: the iterate lives in LDS, so algorithmic HBM bytes "
                                  "are ~1e-5 of peak by construction (SURVEY.md 8d); see DESIGN.md"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not single:
             line["cpu_baseline"] = cpu_baseline(spec, table)
         print(json.dumps(line), flush=True)
     if dist is not None:

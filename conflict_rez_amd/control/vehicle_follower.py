@@ -180,7 +180,9 @@ class VehicleFollower(Vehicle):
     def step(self):
         """step the controller (:428-563)"""
         x0, ref, nbr, zu = self.prepare_step()
-        out = self.engine.solve(x0[None], ref[None], nbr[None], zu[None])
+        # slot 0 of this vehicle's engine: after a converged step the next one starts from its multipliers (the
+        # reference hands the previous duals to opti.set_initial, :458-464, :475-476)
+        out = self.engine.solve(x0[None], ref[None], nbr[None], zu[None], carry=[int(getattr(self, "status", 1) == 0)])
         self.finish_step(out, 0)
 
 
@@ -229,7 +231,9 @@ class MultiDistributedFollower:
                 v.get_others_pred(self.vehicles)
             batch = [v.prepare_step() for v in self.vehicles]
             t0 = time.perf_counter()
-            out = self.engine.solve(*(np.stack([b[i] for b in batch]) for i in range(4)))
+            # slot b is always vehicle b: a vehicle whose last step converged starts from its multipliers
+            carry = [int(getattr(v, "status", 1) == 0) for v in self.vehicles]
+            out = self.engine.solve(*(np.stack([b[i] for b in batch]) for i in range(4)), carry=carry)
             wall = time.perf_counter() - t0
             for b, v in enumerate(self.vehicles):
                 v.finish_step(out, b, solve_time=wall / len(self.vehicles))

@@ -17,10 +17,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof_$tag/SQ -o t -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>$O/${tag}_SQ.err
 cd $R
-find $O/prof_$tag -name "*kernel_stats.csv" -exec cp {} $O/${tag}_kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE SQ; do
-  f=$(find $O/prof_$tag/$c -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python tools/summarize_pmc.py $f $O/${tag}_pmc_${c}_summary.csv
-done
-head -8 $O/${tag}_kernel_stats.csv; cat $O/${tag}_pmc_*_summary.csv | grep -v "^kernel," | head -40
+# ROCm 7.2 writes a rocpd sqlite database; turn it into the CSV summaries kept under profiles/
+python tools/rocpd_summary.py $O/prof_$tag/trace/t_results.db $O/$tag
+for c in FETCH_SIZE WRITE_SIZE SQ; do python tools/rocpd_summary.py $O/prof_$tag/$c/t_results.db $O/$tag $c; done
+head -12 $O/${tag}_kernel_stats.csv; grep -h loop_kernel $O/${tag}_pmc_*.csv | cut -c1-160
 find $O/prof_$tag -type f -size +8M -delete
