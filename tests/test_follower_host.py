@@ -18,14 +18,18 @@ class OracleEngine:
     def __init__(self, spec, fail_at=()):
         self.ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
         self.calls, self.fail_at = 0, set(fail_at)
+        self.records, self.carried = {}, 0  # per-slot carry records, as the engine keeps them
 
-    def solve(self, x0, ref, nbr, zu, want_duals=True):
+    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None):
         B, N, nn, no = len(x0), self.ospec.N, self.ospec.n_nbr, self.ospec.n_obs
         out = dict(zu=np.zeros((B, 7, N)), status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), solve_ms=1.0,
                    l=np.ones((B, N, 4 * no)), m=np.ones((B, N, 4 * no)), lam_ij=np.ones((B, nn, N, 4)),
                    lam_ji=np.ones((B, nn, N, 4)), s=np.ones((B, nn, N, 2)))
         for b in range(B):
-            r = port.solve(self.ospec, x0[b], ref[b], nbr[b], zu[b].T)
+            rec = self.records.get(b) if carry is not None and carry[b] else None
+            self.carried += rec is not None
+            r = port.solve(self.ospec, x0[b], ref[b], nbr[b], zu[b].T, carry=rec)
+            self.records[b] = r["carry"]
             out["zu"][b], out["status"][b], out["iters"][b] = r["p"].T, r["status"], r["iters"]
             if self.calls in self.fail_at:
                 out["status"][b] = 2
@@ -82,6 +86,8 @@ def test_closed_loop_steps_and_bookkeeping(follower_setup):
         assert np.hypot(v.state.x.x - ref_now.x[0], v.state.x.y - ref_now.y[0]) < 0.3
         for o in v.others:
             assert v.opt_lambda_ij[o].shape == (30, 4) and v.opt_s[o].shape == (30, 2)
+    # after its first converged step every vehicle asks the engine to start from the slot's multipliers
+    assert mdf.engine.carried == 4 * 5
 
 
 def test_shift_fallback_on_failure(follower_setup):
