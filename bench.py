@@ -161,7 +161,7 @@ def main():
         if dist is not None:
             import torch
 
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
 
     persistent = args.mode == "persistent"

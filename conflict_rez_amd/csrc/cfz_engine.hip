@@ -602,6 +602,15 @@ int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double 
 
 double cfz_last_solve_ms(const cfz_handle *h) { return h ? (double)h->last_ms : -1.0; }
 
+#ifdef CFZ_STAMPS
+// diagnostic build only: the 12 phase counters of every instance of the last solve_kernel launch
+int cfz_debug_stamps(cfz_handle *h, int B, unsigned long long *out) {
+  if (check(h, B)) return -1;
+  HIP_OK(hipMemcpy(out, h->stats + (size_t)B * 3, (size_t)B * 12 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
+
 int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double *d_ref, const double *d_nbr,
                          double *d_zu, int32_t *d_status, int32_t *d_iters, double *d_stats, void *stream) {
   if (check(h, B)) return -1;
