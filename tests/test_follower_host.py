@@ -128,3 +128,29 @@ def test_collocation_tables_and_interpolant(follower_setup):
     assert np.allclose(veh.input_interpolator(0.0), [0, 0]) and np.allclose(veh.input_interpolator(tgrid[7]), [7, -7])
     out = veh.interpolate_states([0.1, 0.2])
     assert out.x.shape == (2,) and out.u_a.shape == (2,)
+
+
+def test_node_loop_over_in_process_bus(follower_setup):
+    """The ROS2 deployment's protocol without ROS (conflict_rez_amd/node.py): a node steps only once every other
+    vehicle has announced itself, publishes x, y, psi after every step, and a received prediction replaces
+    `others_pred` at once."""
+    from conflict_rez_amd.node import InProcessBus, VehicleNode, VehiclePredictionMsg, populate_msg, unpack_msg
+
+    mdf = follower_setup
+    bus = InProcessBus()
+    nodes = [VehicleNode(v, len(mdf.vehicles), bus) for v in mdf.vehicles]
+    for n in nodes:
+        n.publish_prediction()  # vehicle_node.py:151-157
+    nodes[0].timer_callback()  # nobody else has said `info` yet: announce only
+    assert nodes[0].steps == 0 and bus.published["/vehicle_0/info"] == 1
+    for tick in range(3):
+        for n in nodes:
+            n.timer_callback()
+    assert [n.steps for n in nodes] == [2, 2, 2, 3]  # in the first round only the last node has heard everybody
+    v0, v3 = mdf.vehicles[0], mdf.vehicles[3]
+    assert np.array_equal(v3.others_pred["vehicle_0"].x, v0.pred.x) and len(v3.others_pred["vehicle_0"].v) == 0  # only x, y, psi travel
+    msg = populate_msg(VehiclePredictionMsg(), v0.pred)
+    assert list(msg.get_fields_and_field_types())[:4] == ["header", "t", "dt", "x"] and len(msg.x) == 30 and len(msg.v) == 30
+    back = VehiclePrediction()
+    unpack_msg(msg, back)
+    assert np.allclose(back.u_steer, v0.pred.u_steer) and back.l is None

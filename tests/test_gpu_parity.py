@@ -197,6 +197,43 @@ def test_closed_loop_carry_saves_iterations():
     assert (d < 5e-2).mean() > 0.95 and np.median(d) < 1e-3
 
 
+def test_other_shapes_and_error_paths():
+    """Shapes other than the headline one (no neighbours / 4 obstacles = BASELINE.json configs[1]; short horizons; no
+    obstacles; a batch of one) against the C port, and the C ABI's error convention (-1 + cfz_last_error)."""
+    from conflict_rez_amd import engine, scenarios
+    from oracle import port
+    from oracle.mpc_nlp import MpcSpec
+
+    table, _ = scenarios.load_reference_table()
+    for n_obs, n_nbr, N, B in ((4, 0, 30, 5), (6, 1, 12, 3), (0, 2, 8, 1)):
+        sp = scenarios.parking_lot_spec(n_nbr=n_nbr, N=N, n_obs=n_obs)
+        osp = MpcSpec(N=N, dt=sp.dt, A_obs=sp.A_obs, b_obs=sp.b_obs, n_nbr=n_nbr)
+        k0, noise = scenarios.sample_scenarios(B, table, seed=4)
+        x0, ref, nbr, zu = scenarios.mpc_batch_from_table(sp, table[: n_nbr + 1], k0, noise[:, : n_nbr + 1])
+        x0, ref, nbr, zu = x0[:B], ref[:B], nbr[:B], zu[:B]
+        e = engine.Engine(sp, max_batch=B)
+        out = e.solve(x0, ref, nbr, zu)
+        for b in range(B):
+            r = port.solve(osp, x0[b], ref[b], nbr[b], zu[b].T)
+            assert (r["status"], r["iters"]) == (out["status"][b], out["iters"][b]), (n_obs, n_nbr, N, b)
+            if r["status"] == 0:
+                assert np.abs(r["p"].T[:5] - out["zu"][b][:5]).max() < TOL and np.abs(r["p"].T[5:] - out["zu"][b][5:]).max() < TOL_U
+        assert out["l"].shape == (B, N, 4 * n_obs) and out["lam_ij"].shape == (B, n_nbr, N, 4)
+        # one instance more than the handle was built for
+        with pytest.raises(RuntimeError, match="batch size out of range"):
+            e.solve(np.repeat(x0, 2, 0), np.repeat(ref, 2, 0), np.repeat(nbr, 2, 0), np.repeat(zu, 2, 0))
+        e.close()
+    # a horizon or an obstacle count beyond the compiled limits is refused at creation
+    with pytest.raises(RuntimeError):
+        engine.Engine(scenarios.parking_lot_spec(N=65), max_batch=1)
+    with pytest.raises(RuntimeError, match="loop_init"):
+        e2 = engine.Engine(scenarios.parking_lot_spec(), max_batch=4)
+        try:
+            e2.loop_step()
+        finally:
+            e2.close()
+
+
 def test_python_shim_closed_loop_on_gpu(tmp_path):
     """`MultiDistributedFollower` through the real engine: 4 vehicles, 40 iterations, vehicles never overlap
     (separating-axis check on the driven states) and follow their plans; the drop-in surface end to end."""
