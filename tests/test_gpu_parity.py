@@ -224,8 +224,10 @@ def test_other_shapes_and_error_paths():
             e.solve(np.repeat(x0, 2, 0), np.repeat(ref, 2, 0), np.repeat(nbr, 2, 0), np.repeat(zu, 2, 0))
         e.close()
     # a horizon or an obstacle count beyond the compiled limits is refused at creation
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError, match="compiled limits"):
         engine.Engine(scenarios.parking_lot_spec(N=65), max_batch=1)
+    with pytest.raises(RuntimeError, match="batch"):
+        engine.Engine(scenarios.parking_lot_spec(), max_batch=0)
     with pytest.raises(RuntimeError, match="loop_init"):
         e2 = engine.Engine(scenarios.parking_lot_spec(), max_batch=4)
         try:
