@@ -1,0 +1,80 @@
+"""The oracle against an independent solver on the reference's own formulation.
+
+scipy's SLSQP (a general-purpose SQP, no code in common with oracle/ipm.py) solves the MPC-step NLP in the
+reference's own variables -- primal AND the OBCA duals l, m, lambda_ij, lambda_ji, s, as IPOPT sees it
+(oracle/reference_nlp.py, vehicle_follower.py:146-368) -- on reduced instances (short horizon, two obstacles, one
+neighbour, so that finite-difference Jacobians stay cheap).  The engine's formulation restricts the duals to
+face-normal certificates, so its feasible set is contained in the reference's:
+    cost(reference optimum) <= cost(oracle) <= cost(reference optimum) + what <= 0.3 dmin of extra clearance costs.
+Both solvers are run to tight tolerances here (the production tolerance 1e-2 would hide any difference)."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from conflict_rez_amd import scenarios
+from oracle import ipm
+from oracle.mpc_nlp import MpcNlp, MpcSpec, reference_residuals, solve_mpc
+from oracle.reference_nlp import ReferenceNlp
+
+
+def _instance(k0, v, n_obs_keep, N):
+    table, _ = scenarios.load_reference_table()
+    sp = scenarios.parking_lot_spec(n_nbr=1, N=N, n_obs=6)
+    A, b = sp.A_obs[list(n_obs_keep)], sp.b_obs[list(n_obs_keep)]
+    spec = MpcSpec(N=N, dt=sp.dt, A_obs=A, b_obs=b, n_nbr=1)
+    T = table.shape[1]
+    idx = np.minimum(k0 + np.arange(N), T - 1)
+    adv = np.minimum(idx + 1, T - 1)
+    u = (v + 1) % 4
+    x0 = table[v, k0, :5] + np.array([0.03, -0.02, 0.01, 0.02, 0.0])
+    return spec, x0, table[v, idx, :3].T.copy(), table[u, adv, :3].T.copy()[None], table[v, adv, :].T.copy()
+
+
+def _slsqp(nlp, X0):
+    lo, hi = nlp.bounds()
+    cons = [dict(type="eq", fun=lambda X: nlp.constraints(X)[0]), dict(type="ineq", fun=lambda X: nlp.constraints(X)[1])]
+    out = minimize(nlp.cost, X0, method="SLSQP", bounds=list(zip(lo, hi)), constraints=cons, options=dict(maxiter=300, ftol=1e-12))
+    eq, ineq = nlp.constraints(out.x)
+    assert out.status == 0 and np.abs(eq).max() < 1e-6 and ineq.min() > -1e-6
+    return out
+
+
+TIGHT = dict(tol=1e-7, constr_viol_tol=1e-8, compl_inf_tol=1e-8, dual_inf_tol=1e-5)
+
+
+@pytest.mark.parametrize("k0,v,obs", [(60, 1, (0, 1)), (150, 3, (3, 4)), (30, 0, (1, 4))])
+def test_slsqp_cannot_improve_the_oracle_solution(k0, v, obs):
+    """Started AT the oracle's solution (with its certificate duals), the independent solver stays there."""
+    spec, x0, ref, nbr, zu = _instance(k0, v, obs, 6)
+    r = solve_mpc(spec, x0, ref, nbr, zu, ipm.IpmOptions(**TIGHT))
+    assert r["status"] == 0
+    res = reference_residuals(spec, x0, ref, nbr, r["sol"])
+    assert res["eq"] < 1e-7 and res["ineq"] < 1e-7 and res["bound"] < 1e-9  # feasible for the reference NLP, duals included
+    nlp = ReferenceNlp(spec, x0, ref, nbr)
+    X0 = nlp.pack(r["sol"])
+    assert abs(nlp.cost(X0) - res["cost"]) < 1e-9
+    out = _slsqp(nlp, X0)
+    assert abs(out.fun - res["cost"]) <= 1e-6 * max(1.0, res["cost"])
+    s2 = nlp.unpack(out.x)
+    assert max(np.abs(s2[k] - r["sol"][k]).max() for k in ("x", "y", "psi")) < 1e-5
+
+
+@pytest.mark.parametrize("k0,v,obs,dmin,active_block", [(120, 1, (0, 1), 0.12, 1), (50, 2, (1, 4), 0.09, 2)])
+def test_slsqp_from_the_warm_start_reaches_the_oracle_solution(k0, v, obs, dmin, active_block):
+    """Independent convergence with an ACTIVE collision constraint (dmin raised until a static obstacle, resp. the
+    neighbour, is touched): from the MPC warm start, with the duals of the warm-start poses, SLSQP ends at the oracle's
+    cost and trajectory -- the certificate-eliminated problem and the reference's NLP have the same optimum here."""
+    spec, x0, ref, nbr, zu = _instance(k0, v, obs, 6)
+    spec.dmin = dmin
+    r = solve_mpc(spec, x0, ref, nbr, zu, ipm.IpmOptions(**TIGHT))
+    assert r["status"] == 0 and abs(r["sep"].min() - dmin) < 1e-6
+    assert np.unravel_index(np.argmin(r["sep"]), r["sep"].shape)[1] == active_block
+    res = reference_residuals(spec, x0, ref, nbr, r["sol"])
+    m = MpcNlp(spec, x0, ref, nbr)
+    ws = m.unpack(m.pack(dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))))  # warm-start poses and their certificates
+    nlp = ReferenceNlp(spec, x0, ref, nbr)
+    out = _slsqp(nlp, nlp.pack(ws))
+    assert out.fun <= res["cost"] + 1e-7  # the reference's feasible set contains the engine's
+    assert res["cost"] - out.fun <= 1e-6 * max(1.0, res["cost"])
+    s2 = nlp.unpack(out.x)
+    assert max(np.abs(s2[k] - r["sol"][k]).max() for k in ("x", "y", "psi")) < 1e-5
