@@ -3,10 +3,10 @@
 Built in this round: the constructor (:29-52), the collocation tables (`collocation_coefficients`
 :54-97), the warm-start resampling (`interp_ws_for_collocation` :298-358), the Lagrange
 interpolant of a collocation solution (`get_interpolator` :722-786, `interpolate_states`
-:788-829) -- all numpy, no CasADi.  `dual_ws` (:233-296) runs on the GPU in closed form (`cfz_dual_ws`).  The two planning NLPs
-(`state_ws` :99-231, `setup/solve_single_final_problem` :360-661) are the next rows of the coverage
-table (DESIGN.md "Next"); until their kernels land they raise
-`NotImplementedError` and a reference trajectory is supplied with `set_reference_trajectory`.
+:788-829) -- all numpy, no CasADi.  `state_ws` (:99-231) and `dual_ws` (:233-296) run on the GPU (`cfz_state_ws`: banded interior point,
+`cfz_dual_ws`: closed form).  The Radau collocation NLP (`setup/solve_single_final_problem` :360-661) is the next
+row of the coverage table (DESIGN.md "Next"); until its kernel lands it raises
+`NotImplementedError`, and `VehicleFollower.plan_single_path` follows the `state_ws` trajectory.
 """
 from typing import Dict, Tuple
 
@@ -68,8 +68,39 @@ class Vehicle:
         return A, B, D
 
     # ---- planning NLPs (next rows of the coverage table) ------------------------------------
-    def state_ws(self, *args, **kwargs) -> VehiclePrediction:
-        raise NotImplementedError("state_ws (vehicle.py:99-231) has no HIP kernel yet; see DESIGN.md 'Next'")
+    def state_ws(self, N: int = 30, dt: float = 0.1, init_offset: VehicleState = None, final_heading: float = None,
+                 bounded_input: bool = False, shrink_tube: float = 0.8, spline_ws: bool = False,
+                 verbose: int = 0) -> VehiclePrediction:
+        """Warm-start plan through the strategy's tube (vehicle.py:99-231) on the GPU (`cfz_state_ws`): T = N (S-1)
+        Euler steps, rear-axle and front point inside the shrunk back/front cells at every strategy step, cost
+        sum a^2 + w^2.  Returns t, x, y, psi, v, u_steer (= delta), u_a, u_steer_dot with the last input repeated
+        (:219-231); raises RuntimeError when the solver does not converge, as `opti.solve()` does."""
+        from ..engine import state_ws as cfz_state_ws
+        from .compute_sets import interp_along_sets
+
+        print("Solving state ws...")
+        off = init_offset if init_offset is not None else VehicleState()
+        s0 = self.init_state
+        init_pose = [s0.x.x + off.x.x, s0.x.y + off.x.y, s0.e.psi + off.e.psi]
+        tube = [((st["back"].A, st["back"].b), (st["front"].A, st["front"].b)) for st in self.rl_tube[1:]]
+        guess = None
+        if spline_ws:
+            guess = interp_along_sets(file_name=self.rl_file_name, vehicle_body=self.vehicle_body, N=N)[self.agent]
+        vc, r = self.vehicle_config, self.region
+        bounds = [r.x_min, r.x_max, r.y_min, r.y_max, vc.v_min, vc.v_max, vc.delta_min, vc.delta_max,
+                  vc.a_min, vc.a_max, vc.w_delta_min, vc.w_delta_max]
+        res = cfz_state_ws([init_pose], [tube], None if guess is None else [guess], [final_heading], N=N, dt=dt,
+                           wb=self.vehicle_body.wb, shrink_tube=shrink_tube, bounded_input=int(bounded_input), bounds=bounds)[0]
+        self.state_ws_stats = dict(status=res["status"], iters=res["iters"], cost=res["cost"])
+        if res["status"] != 0:
+            raise RuntimeError(f"state_ws did not converge (status {res['status']} after {res['iters']} iterations)")
+        T = N * (self.num_sets - 1)
+        tr = res["traj"]
+        out = VehiclePrediction()
+        out.t = np.linspace(0, T * dt, T + 1, endpoint=True)
+        out.x, out.y, out.psi, out.v, out.u_steer = (tr[:, c].copy() for c in range(5))
+        out.u_a, out.u_steer_dot = tr[:, 5].copy(), tr[:, 6].copy()
+        return out
 
     def dual_ws(self, zu0: VehiclePrediction, verbose: int = 0) -> VehiclePrediction:
         """Warm start of the OBCA duals for the fixed poses of `zu0` (vehicle.py:233-296): fills

@@ -71,11 +71,21 @@ class VehicleFollower(Vehicle):
     # ---- reference path ---------------------------------------------------------------------
     def plan_single_path(self, N_ws=30, dt_ws=0.1, K=5, N_per_set=5, shrink_tube=0.5, dmin=0.05, spline_ws=True,
                          interp_dt=0.01):
-        """state_ws -> dual_ws -> collocation (:91-138).  The planning kernels are the next rows of the
-        coverage table; until then supply the plan with `set_reference(...)`."""
-        zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=self.final_heading,
-                            shrink_tube=shrink_tube, spline_ws=spline_ws)
-        raise NotImplementedError(zu0)  # pragma: no cover (state_ws raises first)
+        """plan a single vehicle reference path (:91-138): state_ws -> dual_ws -> collocation.  The collocation
+        refinement (`setup_single_final_problem`, vehicle.py:360-661) has no kernel yet: the reference trajectory is
+        the `state_ws` solution (feasible for the tube and the bicycle model at dt_ws, minimum sum a^2 + w^2, not
+        time-optimal); `self.plan_refined` says so.  A final heading the warm start cannot meet is retried without it."""
+        try:
+            zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=self.final_heading,
+                                shrink_tube=shrink_tube, spline_ws=spline_ws)
+        except RuntimeError:
+            if self.final_heading is None:
+                raise
+            zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=None,
+                                shrink_tube=shrink_tube, spline_ws=spline_ws)
+        zu0 = self.dual_ws(zu0=zu0)
+        self.plan_refined = False
+        self.set_reference(zu0, interp_dt=interp_dt)
 
     def set_reference(self, traj: VehiclePrediction, interp_dt: float = 0.01):
         """Installs a planned trajectory: builds the interpolators and `reference_traj` sampled every

@@ -25,6 +25,7 @@
 
 #include "../../include/confrez_hip.h"
 #include "cfz_solver.inl"
+#include "cfz_plan.inl"
 
 namespace {
 
@@ -270,6 +271,15 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
     CFZ_MARK(8);
   }
   CFZ_MARK(9);
+}
+
+// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
+__global__ void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
+                                const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
+  cfzp::solve_state_ws(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b);
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -617,6 +627,89 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
   if (!d_x0 || !d_ref || !d_zu || !d_status || !d_iters || !d_stats) return fail("null device pointer");
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   return launch_solve(h, B, d_x0, d_ref, d_nbr ? d_nbr : h->nbr, d_zu, d_status, d_iters, d_stats, false, st);
+}
+
+int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
+                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                 int32_t *iters, double *cost) {
+  if (B < 1 || !po || !n_sets || !init_pose || !tube || !traj) return fail("bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  HIP_OK(hipSetDevice(device));
+  std::vector<cfzp::PSpec> specs(B);
+  std::vector<long long> toff(B), xoff(B), soff(B);
+  long long nt = 0, nx = 0, ns = 0, npts = 0;
+  for (int b = 0; b < B; ++b) {
+    if (n_sets[b] < 2 || po->N < 1) return fail("a plan needs at least two strategy steps");
+    cfzp::PSpec &p = specs[b];
+    memset(&p, 0, sizeof p);
+    p.N = po->N; p.n_chk = n_sets[b] - 1; p.T = po->N * p.n_chk;
+    p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
+    p.bounded_input = po->bounded_input;
+    p.max_iter = po->max_iter; p.max_backtrack = 25; p.filter_cap = 16; p.stall_iters = 0;
+    p.dt = po->dt; p.wb = po->wb; p.shrink = po->shrink_tube;
+    for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
+    memcpy(p.bounds, po->bounds, sizeof p.bounds);
+    p.tol = po->tol; p.constr_viol_tol = po->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = po->mu_init;
+    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
+    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
+    p.reg_primal = 1e-8; p.reg_dual = 1e-9; p.curv_kappa = po->curv_kappa; p.stall_kappa = 0.9;
+    toff[b] = nt; xoff[b] = nx; soff[b] = ns;
+    nt += (long long)p.n_chk * 24; nx += cfzp::dims(p).n; ns += (long long)cfzp::work_doubles(p); npts += p.T + 1;
+  }
+  // initial guess: x, y, psi of every stage (vehicle.py:199-205), everything else zero
+  std::vector<double> X((size_t)nx, 0.0);
+  long long g0 = 0;
+  for (int b = 0; b < B; ++b) {
+    const int T = specs[b].T;
+    if (guess) for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
+    else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
+    g0 += T + 1;
+  }
+  cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;
+  long long *doff = nullptr; int32_t *doi = nullptr;
+  HIP_OK(hipMalloc(&dspec, sizeof(cfzp::PSpec) * B)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8));
+  HIP_OK(hipMalloc(&dslab, (size_t)ns * 8)); HIP_OK(hipMalloc(&doff, (size_t)B * 3 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4));
+  HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
+  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzp::PSpec) * B, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff, toff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), 0, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
+  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
+  for (void *p : {(void *)dspec, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
+  long long o = 0;
+  for (int b = 0; b < B; ++b) {
+    const int T = specs[b].T;
+    for (int k = 0; k <= T; ++k) {
+      const int ku = k < T ? k : T - 1;  // the last input is repeated (vehicle.py:226-229)
+      for (int c = 0; c < 5; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * k + c];
+      for (int c = 5; c < 7; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * ku + c];
+    }
+    o += T + 1;
+    if (status) status[b] = oi[2 * b + 1];
+    if (iters) iters[b] = oi[2 * b];
+    if (cost) cost[b] = od[3 * b];
+  }
+  return 0;
+}
+
+void cfz_default_plan_options(cfz_plan_options *o) {
+  memset(o, 0, sizeof *o);
+  o->N = 30; o->max_iter = 500; o->bounded_input = 0;
+  o->dt = 0.1; o->wb = 2.5; o->shrink_tube = 0.5;
+  const double bd[12] = {2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0};
+  memcpy(o->bounds, bd, sizeof bd);
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 1e-3; o->curv_kappa = 1e-8;
 }
 
 int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d) {

@@ -31,6 +31,12 @@ _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps k
              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
 
 
+class _CPlanOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("N", "max_iter", "bounded_input", "reserved")] + [
+        ("dt", C.c_double), ("wb", C.c_double), ("shrink_tube", C.c_double), ("bounds", C.c_double * 12),
+        ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
+
+
 class _COptions(C.Structure):
     _fields_ = [(k, C.c_int32) for k in _OPT_INTS] + [(k, C.c_double) for k in _OPT_DBLS]
 
@@ -111,6 +117,8 @@ def load_library(path=None):
     lib.cfz_kernel_info.argtypes = [vp, vp, vp]
     lib.cfz_mpc_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.cfz_mpc_set_warm.argtypes = [vp, C.c_int, vp]
+    lib.cfz_default_plan_options.argtypes = [C.POINTER(_CPlanOptions)]
+    lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
     lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -131,7 +139,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_default_plan_options cfz_state_ws cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -156,6 +164,44 @@ def _f64(a, shape):
     if a.shape != tuple(shape):
         raise ValueError(f"expected array of shape {tuple(shape)}, got {a.shape}")
     return a
+
+
+def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, **options):
+    """`cfz_state_ws`: the warm-start plans of several vehicles in one launch.
+    init_poses [B][3]; tubes: per vehicle a list over strategy steps 1.. of ((A_back, b_back), (A_front, b_front));
+    guesses: per vehicle an array [T+1, 3] of x, y, psi or None; final_headings: per vehicle a float or None.
+    options: fields of `cfz_plan_options` (N, dt, wb, shrink_tube, bounded_input, max_iter, tol, ...).
+    Returns a list of dict(traj [T+1,7], status, iters, cost)."""
+    lib = load_library()
+    po = _CPlanOptions()
+    lib.cfz_default_plan_options(C.byref(po))
+    for k, v in options.items():
+        if k == "bounds":
+            po.bounds[:] = [float(x) for x in v]
+        else:
+            setattr(po, k, v)
+    B = len(tubes)
+    n_sets = np.array([len(t) + 1 for t in tubes], dtype=np.int32)
+    T = po.N * (n_sets - 1)
+    tube = np.concatenate([np.concatenate([np.concatenate([np.asarray(A, float).ravel(), np.asarray(b, float).ravel()])
+                                           for cellpair in t for (A, b) in cellpair]) for t in tubes])
+    init = _f64(np.asarray(init_poses, float), (B, 3))
+    fh = np.array([np.nan if (final_headings is None or final_headings[b] is None) else float(final_headings[b]) for b in range(B)])
+    guess = None
+    if guesses is not None and all(g is not None for g in guesses):
+        guess = np.ascontiguousarray(np.concatenate([np.asarray(g, float)[: T[b] + 1, :3] for b, g in enumerate(guesses)]))
+        assert guess.shape[0] == int((T + 1).sum())
+    traj = np.zeros((int((T + 1).sum()), 7))
+    status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+    rc = lib.cfz_state_ws(int(device), B, C.byref(po), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(np.ascontiguousarray(tube)), _ptr(guess),
+                          _ptr(traj), _ptr(status), _ptr(iters), _ptr(cost))
+    if rc != 0:
+        raise RuntimeError("cfz_state_ws: " + lib.cfz_last_error().decode())
+    out, o = [], 0
+    for b in range(B):
+        out.append(dict(traj=traj[o : o + T[b] + 1].copy(), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
+        o += T[b] + 1
+    return out
 
 
 class Engine:

@@ -134,6 +134,38 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
  * are a face and a vertex. */
 int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d);
 
+/* ---- Vehicle.state_ws (confrez/control/vehicle.py:99-231): warm-start plan through the strategy's tube -----------
+ * One NLP per vehicle, B of them in one call (no handle: nothing is kept).  Instance b has n_sets[b] strategy steps,
+ * T_b = N (n_sets[b] - 1) Euler steps and T_b + 1 trajectory points.
+ *   init_pose[B][3]       x, y, psi of the first point (:131-138; v, delta, a0, w0 start at zero)
+ *   final_heading[B]      psi of the last point (:194-195), NaN = free; the pointer may be NULL
+ *   tube                  for every instance, for strategy steps 1..n_sets-1: back cell then front cell, each as
+ *                         A[4][2] row-major followed by b[4] (24 doubles per step), instances back to back (:178-192)
+ *   guess                 x, y, psi of every point, instances back to back (spline_ws, :199-205); NULL = the initial pose
+ *   traj (out)            x, y, psi, v, delta, a, w of every point, instances back to back; the last input is repeated
+ *   status, iters, cost   per instance (may be NULL); status as in cfz_mpc_stats, the reference raises on status != 0
+ * The solver is the interior point of the MPC path with the exact Hessian of the Lagrangian, IPOPT's delta_w ladder
+ * driven by a curvature test, delta_c = 1e-9, on the banded primal-dual system (csrc/cfz_plan.inl). */
+typedef struct cfz_plan_options {
+  int32_t N;              /* :100 steps per strategy step, 30 */
+  int32_t max_iter;       /* :210 500 */
+  int32_t bounded_input;  /* :104, :155-167 */
+  int32_t reserved;
+  double dt;              /* :101 0.1 */
+  double wb;              /* wheelbase */
+  double shrink_tube;     /* :106 0.5 in the callers */
+  double bounds[12];      /* lo,hi of x, y, v, delta, a, w */
+  double tol;             /* :208 1e-2 */
+  double constr_viol_tol; /* :209 1e-2 */
+  double mu_init;         /* 1e-3 */
+  double curv_kappa;      /* 1e-8 */
+} cfz_plan_options;
+
+void cfz_default_plan_options(cfz_plan_options *opt);
+int cfz_state_ws(int device, int B, const cfz_plan_options *opt, const int32_t *n_sets, const double *init_pose,
+                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                 int32_t *iters, double *cost);
+
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
  * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt

@@ -1,0 +1,99 @@
+"""state_ws (reference vehicle.py:99-231): the planning solver source against the numpy oracle (CPU), and the HIP
+build through the C ABI and the Python surface (GPU)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conflict_rez_amd import strategy as strat
+from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+from conflict_rez_amd.vehicle_types import VehicleBody
+from oracle import ipm
+from oracle.plan_nlp import StateWsNlp
+
+PLAN_OPT = dict(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0)
+
+
+@pytest.fixture(scope="module")
+def plans():
+    """The synthetic 4-vehicle strategy: per agent (tube for the oracle, spline guess [T+1,3])."""
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    out = {}
+    for a in sorted(hist):
+        out[a] = ([dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]], paths[a])
+    return out
+
+
+def test_plan_kernel_source_matches_oracle(plans):
+    """Same iterates as the full-KKT sparse-LU oracle (iteration counts equal, solutions to 1e-8) with the terminal
+    heading free, with bounded inputs, and with a terminal heading on a well-conditioned case; where the terminal
+    heading makes the heading rows rank deficient at the zero-velocity guess the two linear solvers drift apart and
+    only the solutions are compared, at the solver's tolerance."""
+    import plan_emu_binding as pe
+
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    for a, (tube, p) in plans.items():
+        for fh, bounded, exact in ((None, False, True), (None, True, True), (float(p[-1, 2]), False, a == "vehicle_1")):
+            nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5, bounded_input=bounded)
+            X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2])
+            ro, re_ = ipm.solve(nlp, X0, opt), pe.solve(nlp, X0, opt)
+            assert re_["bandwidth"] <= 40
+            assert ro["status"] == re_["status"], (a, fh, bounded)
+            if exact:
+                assert ro["iters"] == re_["iters"] and np.abs(ro["X"][: nlp.s0] - re_["X"][: nlp.s0]).max() < 1e-7
+            elif ro["status"] == 0:
+                assert abs(ro["f"] - re_["f"]) < 1e-2 * max(1.0, ro["f"])
+                so, se = nlp.unpack(ro["X"]), nlp.unpack(re_["X"])
+                assert max(np.abs(so[k] - se[k]).max() for k in ("x", "y", "psi")) < 5e-2
+            if ro["status"] == 0:  # the tube is respected
+                s = nlp.unpack(re_["X"])
+                c = nlp.cons(re_["X"])
+                assert np.abs(c).max() < 2e-2 and re_["X"][nlp.s0 :].min() >= 0.0
+                assert np.isclose(s["x"][0], p[0, 0]) and np.isclose(s["v"][0], 0.0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_state_ws_on_gpu_matches_oracle(plans):
+    """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory."""
+    from conflict_rez_amd import engine
+
+    agents = sorted(plans)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    res = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], [None] * 4, shrink_tube=0.5)
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    for a, r in zip(agents, res):
+        tube, p = plans[a]
+        nlp = StateWsNlp(p[0], tube, final_heading=None, shrink_tube=0.5)
+        ro = ipm.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2]), opt)
+        so = nlp.unpack(ro["X"])
+        assert (r["status"], r["iters"]) == (ro["status"], ro["iters"]) == (0, ro["iters"])
+        want = np.stack([so["x"], so["y"], so["psi"], so["v"], so["delta"], so["a"], so["w"]], 1)
+        assert np.abs(r["traj"] - want).max() < 1e-7 and abs(r["cost"] - ro["f"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_plan_single_path_then_follow_on_gpu(tmp_path):
+    """The reference's flow from a strategy file alone: MultiDistributedFollower plans every vehicle (state_ws and
+    dual_ws on the GPU; collocation refinement not built) and runs the distributed MPC on the result."""
+    from conflict_rez_amd.control.vehicle_follower import MultiDistributedFollower
+
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    agents = ["vehicle_%d" % i for i in range(4)]
+    colors = {a: {"front": (1.0, 0.0, 0.0), "back": (0.0, 0.0, 1.0)} for a in agents}
+    mdf = MultiDistributedFollower(fn, {a: True for a in agents}, colors, {a: None for a in agents}, {a: None for a in agents})
+    mdf.setup_multi_vehicles()
+    for v in mdf.vehicles:
+        assert v.plan_refined is False and v.state_ws_stats["status"] == 0
+        assert v.reference_traj.t[-1] == pytest.approx(0.1 * 30 * (v.num_sets - 1), abs=0.02)
+        assert v.reference_traj.x.shape == v.reference_traj.psi.shape and np.isfinite(v.reference_xy).all()
+    mdf.solve(num_iter=5, dump=False)
+    assert sum(v.status == 0 for v in mdf.vehicles) >= 3
+    for v in mdf.vehicles:
+        ref = v.interpolate_states([v.state.t])
+        assert np.hypot(v.state.x.x - ref.x[0], v.state.x.y - ref.y[0]) < 0.5
