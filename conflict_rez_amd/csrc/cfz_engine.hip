@@ -226,11 +226,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
     CFZ_MARK(3);
     int oi[2]; double od[3];
     cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-#ifdef CFZ_DBG_NOSOLVE
-    oi[0] = 0; oi[1] = 1; od[0] = od[1] = od[2] = 0.0;
-#else
     cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1);
-#endif
     __syncthreads();
     CFZ_MARK(4);
     // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
@@ -245,11 +241,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
       const double w0 = (oi[1] == 0) ? zu[6 * N] : pin[((size_t)b * 7 + 6) * N + 1];
       double z[5], out[5];
       for (int i = 0; i < 5; ++i) z[i] = x0[i];
-#ifdef CFZ_DBG_NOPLANT
-      for (int i = 0; i < 5; ++i) out[i] = z[i] + a0 + w0;
-#else
       cfz::rk4_step<false>(z, a0, w0, sp.dt, sp.wb, kPlantSubsteps, out, nullptr);
-#endif
       for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
       status[b] = oi[1]; iters[b] = oi[0];
       stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
