@@ -137,7 +137,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = None
-    if world > 1:
+    # CFZ_BENCH_FORCE_DIST=1: go through torch.distributed even with one rank (exercises the N > 1 code path on one GPU)
+    if world > 1 or os.environ.get("CFZ_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
 
