@@ -127,6 +127,10 @@ def main():
     ap.add_argument("--mode", choices=["persistent", "step"], default="persistent",
                     help="persistent: K iterations in one launch, scenarios advance independently (cfz_loop_run); "
                          "step: one launch per iteration with a device-wide barrier in between (cfz_loop_step)")
+    ap.add_argument("--parallelism", choices=["scenario", "vehicle"], default="scenario",
+                    help="scenario: every GPU owns whole scenarios, no data-path collective (default); vehicle: every GPU owns "
+                         "vehicles of all scenarios and all-gathers the predictions over RCCL every iteration (the reference's ROS "
+                         "deployment; needs torch.distributed, --gpus dividing 4, one launch per iteration)")
     ap.add_argument("--count-iters", action="store_true", help="step mode: also sum the IPM iterations (adds a read-back)")
     args = ap.parse_args()
 
@@ -155,8 +159,21 @@ def main():
         table = table[rank % table.shape[0]][None].copy()  # every scenario follows one vehicle's plan, alone on the map
     S = args.scenarios
     k0, noise = scenarios.sample_scenarios(S, table, seed=2024 + rank)
-    eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter)
-    eng.loop_init(table, k0, noise)
+    vehicle_sharded = args.parallelism == "vehicle"
+    if vehicle_sharded:
+        if dist is None or single:
+            raise SystemExit("--parallelism vehicle needs torch.distributed (torchrun, or CFZ_BENCH_FORCE_DIST=1) and the mpc4 workload")
+        from conflict_rez_amd.distributed import VehicleShardedExchange, VehicleShardedLoop
+
+        S = args.scenarios * world  # all scenarios on every rank, a share of the vehicles each: same solves per GPU
+        k0, noise = scenarios.sample_scenarios(S, table, seed=2024)
+        ex = VehicleShardedExchange(V)
+        eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)
+        vloop = VehicleShardedLoop(eng, ex, table, k0, noise, device=f"cuda:{local_rank}")
+        args.mode = "step"
+    else:
+        eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter)
+        eng.loop_init(table, k0, noise)
 
     def barrier():
         if dist is not None:
@@ -166,7 +183,10 @@ def main():
             torch.cuda.synchronize()
 
     persistent = args.mode == "persistent"
-    if persistent:
+    if vehicle_sharded:
+        for _ in range(args.warmup):
+            vloop.step()
+    elif persistent:
         if args.warmup > 0:
             eng.loop_run(args.warmup)  # blocks until all scenarios have done `warmup` iterations
     else:
@@ -176,7 +196,13 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = 0.0
     n_ok = 0
-    if persistent:
+    if vehicle_sharded:
+        ipm_iterations = 0
+        for _ in range(args.steps):
+            vloop.step()
+            kernel_ms += vloop.solve_ms
+        launches = args.steps
+    elif persistent:
         ipm_iterations = eng.loop_run(args.steps)  # K iterations of every scenario, one launch
         kernel_ms = eng.last_solve_ms()
         launches = 1
@@ -189,9 +215,15 @@ def main():
         launches = args.steps
     barrier()
     elapsed = time.perf_counter() - t0
-    got = eng.loop_get()
-    n_ok = int((got["status"] == 0).sum())
-    iters_mean = float(got["iters"].mean())
+    if vehicle_sharded:
+        n_ok = int((vloop.status == 0).sum())
+        iters_mean = float(vloop.iters.double().mean())
+        V_local = len(ex.owned)
+    else:
+        got = eng.loop_get()
+        n_ok = int((got["status"] == 0).sum())
+        iters_mean = float(got["iters"].mean())
+        V_local = V
 
     if dist is not None:
         import torch
@@ -204,13 +236,13 @@ def main():
         n_ok = int(c[0])
 
     if rank == 0:
-        B = S * V
+        B = S * V_local  # solves per iteration on one GPU
         solves = B * world * args.steps
         kern_s = kernel_ms / 1e3 / launches  # average solver-kernel duration per launch
         solves_per_launch = B * args.steps // launches
         achieved = solves_per_launch * ALG_BYTES_PER_SOLVE / kern_s / 1e9
         traffic, traffic_src = (None, None)
-        if persistent and args.steps == 20 and S == 1024:  # the committed PMC passes are of the default command
+        if persistent and not vehicle_sharded and args.steps == 20 and S == 1024:  # the committed PMC passes are of the default command
             traffic, traffic_src = profiled_traffic("loop_kernel")
         line = {
             "metric": "OBCA MPC-step solves/sec (4 vehicles, N=30)",
@@ -229,14 +261,16 @@ def main():
                                     "no neighbours, closed loop on device") if single else
                                    ("BASELINE.json configs[2]: 4-vehicle distributed MPC (VehicleFollower.step), "
                                     "N=30, 6 obstacles, closed loop on device"), "scenarios_per_gpu": S,
-                       "solves_per_step_per_gpu": B, "parallelism": f"scenario-sharded x{world}",
+                       "solves_per_step_per_gpu": B,
+                       "parallelism": (f"vehicle-sharded x{world}, all-gather of predictions per iteration" if vehicle_sharded
+                                       else f"scenario-sharded x{world}"),
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
                        "ipm_iterations_rank0": ipm_iterations,
                        "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
                        "lds_bytes_per_instance": eng.kernel_info()[0], "instances_per_cu": eng.kernel_info()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "loop_kernel" if persistent else "solve_kernel",
+                         "kernel": "loop_kernel" if persistent and not vehicle_sharded else "solve_kernel",
                          "kernel_ms_per_launch": kern_s * 1e3, "solves_per_launch": solves_per_launch,
                          "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "latency/FP64-issue bound: the iterate lives in LDS, so algorithmic HBM bytes "

@@ -348,7 +348,7 @@ struct cfz_handle {
   double *wst = nullptr;
   int32_t *carry = nullptr;
   int wst_stride = 0, carry_duals = 1;
-  bool carry_set = false;
+  bool carry_set = false, ms_pending = false;
   // per-instance buffers
   double *x0 = nullptr, *ref = nullptr, *nbr = nullptr, *zu = nullptr, *stats = nullptr;
   int32_t *status = nullptr, *iters = nullptr;
@@ -392,6 +392,7 @@ int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, cons
                      iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      h->carry_set ? h->carry : nullptr, carry_all);
   h->carry_set = false;  // the flags of cfz_mpc_set_carry hold for one solve
+  h->ms_pending = true;
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   return 0;
@@ -571,6 +572,7 @@ int cfz_mpc_solve(cfz_handle *h, int B) {
   if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, h->status, h->iters, h->stats, true, h->stream)) return -1;
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  h->ms_pending = false;
   return 0;
 }
 
@@ -602,7 +604,16 @@ int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double 
   return 0;
 }
 
-double cfz_last_solve_ms(const cfz_handle *h) { return h ? (double)h->last_ms : -1.0; }
+double cfz_last_solve_ms(const cfz_handle *h_) {
+  cfz_handle *h = const_cast<cfz_handle *>(h_);
+  if (!h) return -1.0;
+  if (h->ms_pending) {  // launched through cfz_mpc_solve_device: the events have not been read yet
+    if (hipSetDevice(h->device) == hipSuccess && hipEventSynchronize(h->ev1) == hipSuccess)
+      (void)hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1);
+    h->ms_pending = false;
+  }
+  return (double)h->last_ms;
+}
 
 #ifdef CFZ_STAMPS
 // diagnostic build only: the 12 phase counters of every instance of the last solve_kernel launch
@@ -772,6 +783,7 @@ int cfz_loop_step(cfz_handle *h) {
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  h->ms_pending = false;
   return 0;
 }
 
@@ -855,6 +867,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   }
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  h->ms_pending = false;
   int32_t ctrl[4] = {0, 0, 0, 0}, isum = 0;
   HIP_OK(hipMemcpy(ctrl, h->ctrl, sizeof ctrl, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(&isum, h->iter_sum, 4, hipMemcpyDeviceToHost));

@@ -90,3 +90,70 @@ class VehicleShardedExchange:
             others = [u for u in range(self.V) if u != v]
             rows.append(adv[:, others])
         return torch.stack(rows, 1).reshape(-1, self.V - 1, 3, all_pred.shape[-1])
+
+
+def rk4_plant(z, u, dt, wb, substeps=10):
+    """Plant step (`simulator`, dynamic_model.py:61-93) on torch tensors z [B,5], u [B,2]: RK4, `substeps` sub-steps."""
+    import torch
+
+    def f(zz):
+        psi, v, de = zz[:, 2], zz[:, 3], zz[:, 4]
+        return torch.stack([v * torch.cos(psi), v * torch.sin(psi), v / wb * torch.tan(de), u[:, 0], u[:, 1]], 1)
+
+    h = dt / substeps
+    for _ in range(substeps):
+        k1 = f(z); k2 = f(z + 0.5 * h * k1); k3 = f(z + 0.5 * h * k2); k4 = f(z + h * k3)
+        z = z + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return z
+
+
+class VehicleShardedLoop:
+    """Closed loop of partitioning B on GPUs: this rank owns `exchange.owned` vehicles of all S scenarios; every MPC
+    iteration all-gathers the owned predictions (RCCL), builds the neighbour parameters, solves its S * V_local NLPs
+    with the HIP engine on device tensors (`Engine.solve_device`), applies read-back / shift fallback and the plant.
+    Same Jacobi semantics as `cfz_loop_step` (which keeps all V vehicles of a scenario on one GPU)."""
+
+    def __init__(self, engine, exchange, table, k0, noise, device="cuda"):
+        import torch
+
+        self.torch, self.eng, self.ex = torch, engine, exchange
+        self.N, self.dt, self.wb = engine.spec.N, engine.spec.dt, engine.spec.wb
+        V, T = table.shape[0], table.shape[1]
+        self.S, self.T, self.own = len(k0), T, list(exchange.owned)
+        dev = torch.device(device)
+        self.table = torch.tensor(table[self.own], dtype=torch.float64, device=dev)  # [Vl, T, 7]
+        self.k0 = torch.tensor(np.asarray(k0), dtype=torch.long, device=dev)
+        self.t = 0
+        self.state = self._rows(torch.zeros(self.N, dtype=torch.long, device=dev)[:1] * 0)[..., 0, :5] + torch.tensor(
+            np.asarray(noise)[:, self.own], dtype=torch.float64, device=dev)
+        self.pred = self._rows(torch.arange(self.N, device=dev)).permute(0, 1, 3, 2).contiguous()  # [S, Vl, 7, N]
+        B = self.S * len(self.own)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(B * 3, dtype=torch.float64, device=dev)
+        self.solve_ms = 0.0
+
+    def _rows(self, offs):
+        """Reference rows k0[s] + t + offs (clipped to the table) of the owned vehicles -> [S, Vl, len(offs), 7]."""
+        idx = (self.k0[:, None] + self.t + offs[None, :]).clamp(max=self.T - 1)  # [S, n]
+        return self.table[:, idx].permute(1, 0, 2, 3)  # table[Vl, S, n, 7] -> [S, Vl, n, 7]
+
+    def step(self):
+        torch, S, Vl, N = self.torch, self.S, len(self.own), self.N
+        nbr = self.ex.neighbour_params(self.ex.gather(self.pred[:, :, :3, :].contiguous())).contiguous()  # [S*Vl, V-1, 3, N]
+        ref = self._rows(torch.arange(N, device=self.pred.device))[..., :3].permute(0, 1, 3, 2).reshape(S * Vl, 3, N).contiguous()
+        warm = advance_one_step(self.pred, axis=-1).reshape(S * Vl, 7, N).contiguous()
+        zu = warm.clone()
+        x0 = self.state.reshape(S * Vl, 5).contiguous()
+        torch.cuda.synchronize()
+        if self.t > 0:
+            self.eng.set_carry(np.ones(S * Vl, np.int32))  # slot b is the same vehicle as in the previous iteration
+        self.eng.solve_device(S * Vl, x0, ref, nbr, zu, self.status, self.iters, self.stats,
+                              stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        self.solve_ms = self.eng.last_solve_ms()
+        ok = (self.status == 0)[:, None, None]
+        new = torch.where(ok, zu, warm)
+        self.pred = new.reshape(S, Vl, 7, N)
+        self.state = rk4_plant(x0, new[:, 5:7, 0], self.dt, self.wb).reshape(S, Vl, 5)
+        self.t += 1

@@ -270,6 +270,11 @@ class Engine:
     def last_solve_ms(self):
         return float(self.lib.cfz_last_solve_ms(self._h))
 
+    def set_carry(self, flags):
+        """`cfz_mpc_set_carry` for the next solve (host or device path): flags [B] int."""
+        flags = np.ascontiguousarray(flags, dtype=np.int32)
+        self._ck(self.lib.cfz_mpc_set_carry(self._h, len(flags), _ptr(flags)), "cfz_mpc_set_carry")
+
     # ---- device-pointer path (torch tensors or any object with data_ptr()) --------------------
     def solve_device(self, B, d_x0, d_ref, d_nbr, d_zu, d_status, d_iters, d_stats, stream=None):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))

@@ -236,6 +236,42 @@ def test_other_shapes_and_error_paths():
             e2.close()
 
 
+def test_vehicle_sharded_loop_matches_device_loop():
+    """Partitioning B (distributed.VehicleShardedLoop: RCCL all-gather of the predictions, `solve_device` on torch
+    tensors, plant in torch) with a single rank owning all four vehicles = the device-resident loop, step for step."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from conflict_rez_amd import engine, scenarios
+    from conflict_rez_amd.distributed import VehicleShardedExchange, VehicleShardedLoop
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        spec = scenarios.parking_lot_spec()
+        table, _ = scenarios.load_reference_table()
+        S, K = 32, 4
+        k0, noise = scenarios.sample_scenarios(S, table, seed=21)
+        ea, eb = engine.Engine(spec, max_batch=S * 4), engine.Engine(spec, max_batch=S * 4)
+        ea.loop_init(table, k0, noise)
+        vl = VehicleShardedLoop(eb, VehicleShardedExchange(4), table, k0, noise)
+        for t in range(K):
+            ea.loop_step()
+            vl.step()
+            a = ea.loop_get()
+            assert np.array_equal(a["status"].ravel(), vl.status.cpu().numpy()), t
+            assert np.array_equal(a["iters"].ravel(), vl.iters.cpu().numpy()), t
+            assert np.abs(a["state"].reshape(-1, 5) - vl.state.reshape(-1, 5).cpu().numpy()).max() < 1e-9
+            assert np.abs(a["pred"].reshape(-1, 7, spec.N) - vl.pred.reshape(-1, 7, spec.N).cpu().numpy()).max() < 1e-9
+        ea.close(); eb.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_python_shim_closed_loop_on_gpu(tmp_path):
     """`MultiDistributedFollower` through the real engine: 4 vehicles, 40 iterations, vehicles never overlap
     (separating-axis check on the driven states) and follow their plans; the drop-in surface end to end."""
