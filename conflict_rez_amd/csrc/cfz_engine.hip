@@ -269,9 +269,10 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
 __global__ void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
                                 const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
   const int b = blockIdx.x;
+  extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
   if (b >= B) return;
   // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
-  cfzp::solve_state_ws(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b);
+  cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -682,7 +683,9 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n
   HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), 0, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  const size_t win_bytes = (size_t)cfzp::kWinCols * cfzp::kLd * sizeof(double);
+  HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);

@@ -210,45 +210,68 @@ CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const
 }
 
 // LU with partial pivoting of an n x n band matrix (kl = ku = kKB) in LAPACK gb layout, then one solve; 0 = ok
-CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b) {
+// `win`: optional fast storage (LDS on the GPU) for the kv+1 = 81 columns the elimination is working on; column q lives
+// in slot q mod 81 while j <= q <= j + kv, enters from `ab` when pivot j = q - kv starts and is written back after
+// its own pivot step.  nullptr: work in `ab` directly.
+constexpr int kWinCols = 2 * kKB + 1;
+template <bool WIN>
+CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
   const int kl = kKB, ku = kKB, kv = kl + ku;
+// WIN is a compile-time switch so that the window pointer keeps its (LDS) address space through the optimiser
+#define CFZP_COL(q) (WIN ? win + (size_t)((q) % kWinCols) * kLd : ab + (size_t)(q) * kLd)
+  if (WIN) {
+    const int last = kv < n - 1 ? kv : n - 1;
+    for (int q = 0; q <= last; ++q) CFZP_LANE_FOR(r, 0, kLd - 1) win[(size_t)q * kLd + r] = ab[(size_t)q * kLd + r];
+    CFZP_SYNC();
+  }
   int ju = 0;
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+    double *cj = CFZP_COL(j);
     int jp = 0; double best;
 #if defined(__HIP_DEVICE_COMPILE__)
     {  // pivot search: one candidate per lane, butterfly arg-max (first maximum wins, as in the serial loop)
       const int lane = threadIdx.x;
-      best = lane <= km ? fabs(ab[(size_t)j * kLd + kv + lane]) : -1.0; jp = lane;
+      best = lane <= km ? fabs(cj[kv + lane]) : -1.0; jp = lane;
       for (int off = 32; off > 0; off >>= 1) {
         const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
         if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
       }
     }
 #else
-    best = fabs(ab[(size_t)j * kLd + kv]);
-    for (int i = 1; i <= km; ++i) { const double a = fabs(ab[(size_t)j * kLd + kv + i]); if (a > best) { best = a; jp = i; } }
+    best = fabs(cj[kv]);
+    for (int i = 1; i <= km; ++i) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
 #endif
     ipiv[j] = j + jp;
     if (!(best > 0.0)) return 1;
     const int reach = j + ku + jp; ju = ju > (reach < n - 1 ? reach : n - 1) ? ju : (reach < n - 1 ? reach : n - 1);
     if (jp != 0) {
       CFZP_LANE_FOR(q, j, ju) {  // swap rows j and j+jp over columns j..ju
-        double &a = ab[(size_t)q * kLd + kv + j - q], &c = ab[(size_t)q * kLd + kv + j + jp - q];
+        double *cq = CFZP_COL(q);
+        double &a = cq[kv + j - q], &c = cq[kv + j + jp - q];
         const double t = a; a = c; c = t;
       }
       CFZP_SYNC();
     }
-    const double inv = 1.0 / ab[(size_t)j * kLd + kv];
-
-    CFZP_LANE_FOR(i, 1, km) ab[(size_t)j * kLd + kv + i] *= inv;
+    const double inv = 1.0 / cj[kv];
+    CFZP_SYNC();
+    CFZP_LANE_FOR(i, 1, km) cj[kv + i] *= inv;
     CFZP_SYNC();
     CFZP_LANE_FOR(q, j + 1, ju) {  // rank-1 update of the trailing window, one column per lane
-      const double u = ab[(size_t)q * kLd + kv + j - q];
-      if (u != 0.0) for (int i = 1; i <= km; ++i) ab[(size_t)q * kLd + kv + j + i - q] -= ab[(size_t)j * kLd + kv + i] * u;
+      double *cq = CFZP_COL(q);
+      const double u = cq[kv + j - q];
+      if (u != 0.0) for (int i = 1; i <= km; ++i) cq[kv + j + i - q] -= cj[kv + i] * u;
     }
     CFZP_SYNC();
+    if (WIN) {  // column j is final: back to `ab`; its slot takes column j + kv + 1
+      CFZP_LANE_FOR(r, 0, kLd - 1) ab[(size_t)j * kLd + r] = cj[r];
+      CFZP_SYNC();
+      const int qn = j + kv + 1;
+      if (qn < n) { CFZP_LANE_FOR(r, 0, kLd - 1) cj[r] = ab[(size_t)qn * kLd + r]; }
+      CFZP_SYNC();
+    }
   }
+#undef CFZP_COL
   for (int j = 0; j < n; ++j) {  // L y = P b
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
     if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
@@ -279,7 +302,9 @@ CFZP_FN double barrier_obj(const PSpec &sp, const PWork &w, const double *X, dou
 }
 
 // X: initial guess in (x, y, psi of every stage; the rest zero), solution out.  out_i = iterations, status; out_d = f, err, mu
-CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d) {
+template <bool WIN>
+CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d,
+                            double *win) {
   const PDims d = dims(sp);
   const PWork w = carve(sp, slab);
   const int n = d.n, m = d.m;
@@ -356,7 +381,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       assemble(sp, tube, w, sig, delta);
       for (int i = 0; i < n; ++i) w.rhs[w.posx[i]] = -w.r1[i];
       for (int i = 0; i < m; ++i) w.rhs[w.posc[i]] = -w.c[i];
-      const int fail = band_solve(w.ab, d.nk, w.ipiv, w.rhs);
+      const int fail = band_solve<WIN>(w.ab, d.nk, w.ipiv, w.rhs, win);
       bool ok = !fail;
       if (ok) {
         double curv = 0.0, dd = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
