@@ -35,6 +35,26 @@
 
 namespace cfzp {
 
+// reductions over the lanes' partial results of a CFZP_LANE_FOR loop (identity on the CPU, where the loop ran in full)
+CFZP_FN double wsum(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+#endif
+  return v;
+}
+CFZP_FN double wmax(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+#endif
+  return v;
+}
+CFZP_FN double wmin(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+#endif
+  return v;
+}
+
 constexpr int kKB = 40;               // half-bandwidth of the permuted KKT matrix (asserted at set-up)
 constexpr int kLd = 3 * kKB + 1;      // band storage rows (LAPACK gb layout with room for the pivoting fill-in)
 
@@ -84,21 +104,21 @@ CFZP_FN const double *cell(const double *tube, int i, int front) { return tube +
 // ---- problem functions (oracle/plan_nlp.py StateWsNlp) ---------------------------------------------------------
 CFZP_FN double objective(const PSpec &sp, const double *X) {
   double f = 0.0;
-  for (int k = 0; k < sp.T; ++k) f += X[7 * k + 5] * X[7 * k + 5] + X[7 * k + 6] * X[7 * k + 6];
-  return f;
+  CFZP_LANE_FOR(k, 0, sp.T - 1) f += X[7 * k + 5] * X[7 * k + 5] + X[7 * k + 6] * X[7 * k + 6];
+  return wsum(f);
 }
 
 CFZP_FN void constraints(const PSpec &sp, const double *tube, const double *X, double *c) {
   const PDims d = dims(sp);
   for (int i = 0; i < 3; ++i) c[i] = X[i] - sp.init_pose[i];
   for (int i = 3; i < 7; ++i) c[i] = X[i];
-  for (int k = 0; k < sp.T; ++k) {
+  CFZP_LANE_FOR(k, 0, sp.T - 1) {
     const double *z = X + 7 * k, *zn = X + 7 * (k + 1);
     const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]);
     const double f[5] = {z[3] * cs, z[3] * sn, z[3] / sp.wb * tn, z[5], z[6]};
     for (int i = 0; i < 5; ++i) c[7 + 5 * k + i] = z[i] + sp.dt * f[i] - zn[i];
   }
-  for (int i = 0; i < sp.n_chk; ++i) {
+  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {
     const double *z = X + 7 * chk_stage(sp, i);
     const double fx = z[0] + sp.wb * cos(z[2]), fy = z[1] + sp.wb * sin(z[2]);
     const double *cb = cell(tube, i, 0), *cf = cell(tube, i, 1);
@@ -108,24 +128,30 @@ CFZP_FN void constraints(const PSpec &sp, const double *tube, const double *X, d
     }
   }
   if (sp.has_final) c[d.m - 1] = X[7 * sp.T + 2] - sp.final_heading;
+  CFZP_SYNC();
 }
 
-// out = J(X)' nu
+// out = J(X)' nu; every stage block is written by one lane (own Euler rows minus the previous stage's), then the tube rows
 CFZP_FN void jt_nu(const PSpec &sp, const double *tube, const double *X, const double *nu, double *out) {
   const PDims d = dims(sp);
-  for (int i = 0; i < d.n; ++i) out[i] = 0.0;
-  for (int i = 0; i < 7; ++i) out[i] += nu[i];
-  for (int k = 0; k < sp.T; ++k) {
-    const double *z = X + 7 * k, *l = nu + 7 + 5 * k;
-    double *o = out + 7 * k, *on = out + 7 * (k + 1);
-    const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]), dt = sp.dt;
-    for (int i = 0; i < 5; ++i) { o[i] += l[i]; on[i] -= l[i]; }
-    o[2] += dt * (-z[3] * sn * l[0] + z[3] * cs * l[1]);
-    o[3] += dt * (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
-    o[4] += dt * (z[3] / sp.wb * (1.0 + tn * tn) * l[2]);
-    o[5] += dt * l[3]; o[6] += dt * l[4];
+  CFZP_LANE_FOR(k, 0, sp.T) {
+    double o[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (k < sp.T) {
+      const double *z = X + 7 * k, *l = nu + 7 + 5 * k;
+      const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]), dt = sp.dt;
+      for (int i = 0; i < 5; ++i) o[i] += l[i];
+      o[2] += dt * (-z[3] * sn * l[0] + z[3] * cs * l[1]);
+      o[3] += dt * (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
+      o[4] += dt * (z[3] / sp.wb * (1.0 + tn * tn) * l[2]);
+      o[5] += dt * l[3]; o[6] += dt * l[4];
+    }
+    if (k > 0) { const double *lp = nu + 7 + 5 * (k - 1); for (int i = 0; i < 5; ++i) o[i] -= lp[i]; }
+    if (k == 0) for (int i = 0; i < 7; ++i) o[i] += nu[i];
+    if (k == sp.T && sp.has_final) o[2] += nu[d.m - 1];
+    for (int i = 0; i < (k < sp.T ? 7 : 5); ++i) out[7 * k + i] = o[i];
   }
-  for (int i = 0; i < sp.n_chk; ++i) {
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {
     const int b = 7 * chk_stage(sp, i);
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
     const double *cb = cell(tube, i, 0), *cf = cell(tube, i, 1);
@@ -133,10 +159,10 @@ CFZP_FN void jt_nu(const PSpec &sp, const double *tube, const double *X, const d
       const double lb = nu[d.r0 + 8 * i + q], lf = nu[d.r0 + 8 * i + 4 + q];
       out[b] += cb[2 * q] * lb + cf[2 * q] * lf; out[b + 1] += cb[2 * q + 1] * lb + cf[2 * q + 1] * lf;
       out[b + 2] += sp.wb * (-cf[2 * q] * sn + cf[2 * q + 1] * cs) * lf;
-      out[d.s0 + 8 * i + q] += lb; out[d.s0 + 8 * i + 4 + q] += lf;
+      out[d.s0 + 8 * i + q] = lb; out[d.s0 + 8 * i + 4 + q] = lf;
     }
   }
-  if (sp.has_final) out[7 * sp.T + 2] += nu[d.m - 1];
+  CFZP_SYNC();
 }
 
 // ---- banded storage -----------------------------------------------------------------------------------------
@@ -170,11 +196,12 @@ CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const
   CFZP_LANE_FOR(col, 0, d.nk - 1) for (int r = 0; r < kLd; ++r) w.ab[(size_t)col * kLd + r] = 0.0;
   CFZP_SYNC();
   const double *X = w.x, *nu = w.nu;
-  for (int i = 0; i < d.n; ++i) band(w.ab, px[i], px[i]) += sig[i] + delta + sp.reg_primal;
+  CFZP_LANE_FOR(i, 0, d.n - 1) band(w.ab, px[i], px[i]) += sig[i] + delta + sp.reg_primal;
   // IPOPT's delta_c: with v = delta = 0 in the guess the heading rows lose rank once the terminal heading is fixed
-  for (int i = 0; i < d.m; ++i) band(w.ab, pc[i], pc[i]) -= sp.reg_dual;
-  for (int i = 0; i < 7; ++i) put(w.ab, pc[i], px[i], 1.0);
-  for (int k = 0; k < sp.T; ++k) {
+  CFZP_LANE_FOR(i, 0, d.m - 1) band(w.ab, pc[i], pc[i]) -= sp.reg_dual;
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, 6) put(w.ab, pc[i], px[i], 1.0);
+  CFZP_LANE_FOR(k, 0, sp.T - 1) {  // every entry written here belongs to stage k alone
     const double *z = X + 7 * k, *l = nu + 7 + 5 * k;
     const int b = 7 * k, bn = 7 * (k + 1), r = 7 + 5 * k;
     const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]), dt = sp.dt, sec2 = 1.0 + tn * tn, v = z[3];
@@ -192,7 +219,8 @@ CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const
     put(w.ab, pc[r + 2], px[b + 3], dt * tn / sp.wb); put(w.ab, pc[r + 2], px[b + 4], dt * v / sp.wb * sec2);
     put(w.ab, pc[r + 3], px[b + 5], dt); put(w.ab, pc[r + 4], px[b + 6], dt);
   }
-  for (int i = 0; i < sp.n_chk; ++i) {
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {
     const int b = 7 * chk_stage(sp, i), r = d.r0 + 8 * i, s = d.s0 + 8 * i;
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
     const double *cb = cell(tube, i, 0), *cf = cell(tube, i, 1);
@@ -207,6 +235,7 @@ CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const
     band(w.ab, px[b + 2], px[b + 2]) += curv;
   }
   if (sp.has_final) put(w.ab, pc[d.m - 1], px[7 * sp.T + 2], 1.0);
+  CFZP_SYNC();
 }
 
 // LU with partial pivoting of an n x n band matrix (kl = ku = kKB) in LAPACK gb layout, then one solve; 0 = ok
@@ -293,15 +322,15 @@ CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
 
 CFZP_FN double barrier_obj(const PSpec &sp, const PWork &w, const double *X, double mu) {
   const PDims d = dims(sp);
-  double s = 0.0;
-  for (int i = 0; i < d.n; ++i) {
-    if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) return INFINITY; s += log(dl); }
-    if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) return INFINITY; s += log(du); }
+  double s = 0.0, bad = 0.0;
+  CFZP_LANE_FOR(i, 0, d.n - 1) {
+    if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) bad = 1.0; else s += log(dl); }
+    if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) bad = 1.0; else s += log(du); }
   }
-  return objective(sp, X) - mu * s;
+  if (wmax(bad) > 0.0) return INFINITY;
+  return objective(sp, X) - mu * wsum(s);
 }
 
-// X: initial guess in (x, y, psi of every stage; the rest zero), solution out.  out_i = iterations, status; out_d = f, err, mu
 template <bool WIN>
 CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d,
                             double *win) {
@@ -310,27 +339,30 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
   const int n = d.n, m = d.m;
   build_order(sp, w.posx, w.posc);
   // bounds
-  for (int i = 0; i < n; ++i) { w.xl[i] = -INFINITY; w.xu[i] = INFINITY; }
-  for (int k = 0; k < sp.T; ++k) {
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.s0 ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i < d.s0 ? X[i] : 0.0; }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(k, 0, sp.T - 1) {
     const int col[6] = {0, 1, 3, 4, 5, 6};
     for (int q = 0; q < (sp.bounded_input ? 6 : 4); ++q) { w.xl[7 * k + col[q]] = sp.bounds[2 * q]; w.xu[7 * k + col[q]] = sp.bounds[2 * q + 1]; }
   }
-  for (int i = d.s0; i < n; ++i) w.xl[i] = 0.0;
+  CFZP_SYNC();
   // slacks from the guess (sigma = -(A p - b + shrink)), then push everything inside its bounds
-  for (int i = 0; i < d.s0; ++i) w.x[i] = X[i];
-  for (int i = d.s0; i < n; ++i) w.x[i] = 0.0;
   constraints(sp, tube, w.x, w.c);
-  for (int i = 0; i < 8 * sp.n_chk; ++i) w.x[d.s0 + i] = -w.c[d.r0 + i];
-  int nb = 0;
-  for (int i = 0; i < n; ++i) {
+  CFZP_LANE_FOR(i, 0, 8 * sp.n_chk - 1) w.x[d.s0 + i] = -w.c[d.r0 + i];
+  CFZP_SYNC();
+  double nbd = 0.0;
+  CFZP_LANE_FOR(i, 0, n - 1) {
     const bool hl = w.xl[i] > -1e300, hu = w.xu[i] < 1e300;
     double pl = hl ? sp.bound_push * fmax(1.0, fabs(w.xl[i])) : 0.0, pu = hu ? sp.bound_push * fmax(1.0, fabs(w.xu[i])) : 0.0;
     if (hl && hu) { pl = fmin(pl, sp.bound_frac * (w.xu[i] - w.xl[i])); pu = fmin(pu, sp.bound_frac * (w.xu[i] - w.xl[i])); }
     if (hl) w.x[i] = fmax(w.x[i], w.xl[i] + pl);
     if (hu) w.x[i] = fmin(w.x[i], w.xu[i] - pu);
-    w.zl[i] = hl ? 1.0 : 0.0; w.zu[i] = hu ? 1.0 : 0.0; nb += hl + hu;
+    w.zl[i] = hl ? 1.0 : 0.0; w.zu[i] = hu ? 1.0 : 0.0; nbd += hl + hu;
   }
-  for (int i = 0; i < m; ++i) w.nu[i] = 0.0;
+  const int nb = (int)wsum(nbd);
+  CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] = 0.0;
+  CFZP_SYNC();
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
@@ -338,19 +370,21 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
   int status = 1, iter = 0;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     constraints(sp, tube, w.x, w.c);
-    for (int i = 0; i < n; ++i) w.g[i] = 0.0;
-    for (int k = 0; k < sp.T; ++k) { w.g[7 * k + 5] = 2.0 * w.x[7 * k + 5]; w.g[7 * k + 6] = 2.0 * w.x[7 * k + 6]; }
-    jt_nu(sp, tube, w.x, w.nu, w.r1);  // J' nu
+    CFZP_LANE_FOR(i, 0, n - 1) { const int c7 = i < d.s0 ? i % 7 : 0; w.g[i] = (i < 7 * sp.T && c7 >= 5) ? 2.0 * w.x[i] : 0.0; }
+    jt_nu(sp, tube, w.x, w.nu, w.r1);  // J' nu (ends with a barrier)
     double theta = 0.0, cviol = 0.0, sum_nu = 0.0, sum_z = 0.0, dual_inf = 0.0;
-    for (int i = 0; i < m; ++i) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
+    CFZP_LANE_FOR(i, 0, m - 1) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
+    theta = wsum(theta); cviol = wmax(cviol); sum_nu = wsum(sum_nu);
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
-    for (int i = 0; i < n; ++i) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
+    CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
+    sum_z = wsum(sum_z); dual_inf = wmax(dual_inf);
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
     double cmp0 = 0.0;
-    for (int i = 0; i < n; ++i) {
+    CFZP_LANE_FOR(i, 0, n - 1) {
       if (w.xl[i] > -1e300) cmp0 = fmax(cmp0, fabs((w.x[i] - w.xl[i]) * w.zl[i]));
       if (w.xu[i] < 1e300) cmp0 = fmax(cmp0, fabs((w.xu[i] - w.x[i]) * w.zu[i]));
     }
+    cmp0 = wmax(cmp0);
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
@@ -359,42 +393,46 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     while (mu > mu_floor) {  // barrier update
       double cm = 0.0;
-      for (int i = 0; i < n; ++i) {
+      CFZP_LANE_FOR(i, 0, n - 1) {
         if (w.xl[i] > -1e300) cm = fmax(cm, fabs((w.x[i] - w.xl[i]) * w.zl[i] - mu));
         if (w.xu[i] < 1e300) cm = fmax(cm, fabs((w.xu[i] - w.x[i]) * w.zu[i] - mu));
       }
+      cm = wmax(cm);
       if (fmax(dual_inf / s_d, fmax(cviol, cm / s_c)) <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
       else break;
     }
     const double tau = fmax(sp.tau_min, 1.0 - mu);
     // gradient of the barrier problem's Lagrangian -> r1; Sigma -> hd
     double *sig = w.hd;
-    for (int i = 0; i < n; ++i) {
+    CFZP_LANE_FOR(i, 0, n - 1) {
       double gphi = w.g[i], s = 0.0;
       if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; gphi -= mu / dl; s += w.zl[i] / dl; }
       if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; gphi += mu / du; s += w.zu[i] / du; }
       w.g[i] = gphi; w.r1[i] = gphi + w.r1[i]; sig[i] = s;
     }
+    CFZP_SYNC();
     // Newton step with the curvature test
     double delta = 0.0; bool have = false;
     for (int tries = 0; tries < 60; ++tries) {
       assemble(sp, tube, w, sig, delta);
-      for (int i = 0; i < n; ++i) w.rhs[w.posx[i]] = -w.r1[i];
-      for (int i = 0; i < m; ++i) w.rhs[w.posc[i]] = -w.c[i];
+      CFZP_LANE_FOR(i, 0, n - 1) w.rhs[w.posx[i]] = -w.r1[i];
+      CFZP_LANE_FOR(i, 0, m - 1) w.rhs[w.posc[i]] = -w.c[i];
+      CFZP_SYNC();
       const int fail = band_solve<WIN>(w.ab, d.nk, w.ipiv, w.rhs, win);
-      bool ok = !fail;
-      if (ok) {
-        double curv = 0.0, dd = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
-        for (int i = 0; i < n; ++i) { const double v = w.rhs[w.posx[i]]; ok = ok && isfinite(v); w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v; }
-        for (int i = 0; i < m; ++i) { const double v = w.rhs[w.posc[i]]; ok = ok && isfinite(v); w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v; }
-        if (ok && curv >= sp.curv_kappa * dd) { have = true; break; }
+      if (!fail) {
+        double curv = 0.0, dd = 0.0, bad = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
+        CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.rhs[w.posx[i]]; if (!isfinite(v)) bad = 1.0; w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v; }
+        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.rhs[w.posc[i]]; if (!isfinite(v)) bad = 1.0; w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v; }
+        curv = wsum(curv); dd = wsum(dd); bad = wmax(bad);
+        CFZP_SYNC();
+        if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
       }
       delta = delta == 0.0 ? 1e-4 : delta * 8.0;
       if (delta > 1e20) break;
     }
     if (!have) { status = 3; break; }
     double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
-    for (int i = 0; i < n; ++i) {
+    CFZP_LANE_FOR(i, 0, n - 1) {
       const double dxi = w.dx[i];
       dphi += w.g[i] * dxi;
       w.dzl[i] = 0.0; w.dzu[i] = 0.0;
@@ -411,14 +449,18 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         if (w.dzu[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zu[i] / w.dzu[i]);
       }
     }
+    a_pri = wmin(a_pri); a_dual = wmin(a_dual); dphi = wsum(dphi);
+    CFZP_SYNC();
     const double phi0 = barrier_obj(sp, w, w.x, mu);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; bool accepted = false, f_type = false;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
-      for (int i = 0; i < n; ++i) w.xt[i] = w.x[i] + alpha * w.dx[i];
+      CFZP_LANE_FOR(i, 0, n - 1) w.xt[i] = w.x[i] + alpha * w.dx[i];
+      CFZP_SYNC();
       constraints(sp, tube, w.xt, w.ct);
       double th_t = 0.0;
-      for (int i = 0; i < m; ++i) th_t += fabs(w.ct[i]);
+      CFZP_LANE_FOR(i, 0, m - 1) th_t += fabs(w.ct[i]);
+      th_t = wsum(th_t);
       const double ph_t = barrier_obj(sp, w, w.xt, mu);
       bool ok = isfinite(ph_t) && isfinite(th_t) && th_t <= theta_max;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = false; break; }
@@ -436,14 +478,16 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;
     }
-    for (int i = 0; i < m; ++i) w.nu[i] += alpha * w.dnu[i];
-    for (int i = 0; i < n; ++i) {
+    CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += alpha * w.dnu[i];
+    CFZP_LANE_FOR(i, 0, n - 1) {
       w.x[i] = w.xt[i];
       if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; w.zl[i] = fmin(fmax(w.zl[i] + a_dual * w.dzl[i], mu / (sp.kappa_sigma * dl)), sp.kappa_sigma * mu / dl); }
       if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; w.zu[i] = fmin(fmax(w.zu[i] + a_dual * w.dzu[i], mu / (sp.kappa_sigma * du)), sp.kappa_sigma * mu / du); }
     }
+    CFZP_SYNC();
   }
-  for (int i = 0; i < n; ++i) X[i] = w.x[i];  // trajectory and tube slacks
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, n - 1) X[i] = w.x[i];  // trajectory and tube slacks
   out_i[0] = iter; out_i[1] = status;
   out_d[0] = objective(sp, w.x); out_d[1] = err0; out_d[2] = mu;
 }
