@@ -317,6 +317,45 @@ __global__ void dual_ws_kernel(const cfz::KSpec sp, int n, const double *poses, 
   if (d) d[(size_t)k * no + j] = fmin(sep2[0], sep2[1]);
 }
 
+// joint_dual_ws (reference multi_vehicle_planner.py:208-341): for n pairs of fixed poses of two vehicles, the duals
+// lam (faces of the first), mu (faces of the second), s and the certified separation d of the rows
+//   -b_this'lam - b_other'mu = d,  A_this'lam + s = 0,  A_other'mu - s = 0,  |s| <= 1,  lam, mu >= 0   (:292-295)
+// The reference maximises d with IPOPT; here it is the closed-form maximum over the face normals of both rectangles
+// (exact whenever the closest features are a face and a vertex), built like the neighbour blocks of the MPC kernel.
+__global__ void joint_dual_ws_kernel(const cfz::KSpec sp, int n, const double *pa, const double *pb, double *lam_o,
+                                     double *mu_o, double *s_o, double *d_o) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double x = pa[3 * k], y = pa[3 * k + 1], xo = pb[3 * k], yo = pb[3 * k + 1];
+  double s, c, so, co;
+  sincos(pa[3 * k + 2], &s, &c); sincos(pb[3 * k + 2], &so, &co);
+  const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
+  double A[4][2] = {{co, so}, {-so, co}, {-co, -so}, {so, -co}}, b[4], V[4][2];
+  for (int i = 0; i < 4; ++i) b[i] = A[i][0] * xo + A[i][1] * yo + sp.g[i];
+  const double BV[4][2] = {{g0, g1}, {-g2, g1}, {-g2, -g3}, {g0, -g3}};
+  for (int i = 0; i < 4; ++i) { V[i][0] = xo + co * BV[i][0] - so * BV[i][1]; V[i][1] = yo + so * BV[i][0] + co * BV[i][1]; }
+  double sep2[2];
+  const int sel = cfz::select_rows(A, b, V, x, y, c, s, sp.g, 0);
+  cfz::rows_for<false>(A, b, V, x, y, c, s, sp.g, sel, sep2, nullptr);
+  const int kind = sel >> 6, f = (sel >> 4) & 3;
+  const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+  double lam[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, wx, wy;  // w: unit direction from this vehicle towards the other
+  if (kind == 1) {  // a face of the OTHER vehicle separates: its outward normal points at this vehicle, w = -Ro G_f
+    mu[f] = 1.0;
+    wx = -(co * gx - so * gy); wy = -(so * gx + co * gy);
+    const double lx = c * wx + s * wy, ly = -s * wx + c * wy;  // R' w = G' lam
+    lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
+  } else {  // a face of THIS vehicle separates: w = R G_f
+    lam[f] = 1.0;
+    wx = c * gx - s * gy; wy = s * gx + c * gy;
+    const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);  // Ro' (-w) = G' mu
+    mu[0] = fmax(mx, 0.0); mu[1] = fmax(my, 0.0); mu[2] = fmax(-mx, 0.0); mu[3] = fmax(-my, 0.0);
+  }
+  for (int i = 0; i < 4; ++i) { lam_o[4 * k + i] = lam[i]; mu_o[4 * k + i] = mu[i]; }
+  s_o[2 * k] = -wx; s_o[2 * k + 1] = -wy;  // s = -A_this' lam = A_other' mu
+  if (d_o) d_o[k] = fmin(sep2[0], sep2[1]);
+}
+
 // first prediction = the planned trajectory at the horizon times, as get_current_ref seeds it
 // (:397-400); state = planned state at k0 + noise
 __global__ void loop_seed(int S, int V, int N, int T, const double *ref_table, const int32_t *kidx,
@@ -736,6 +775,26 @@ int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m,
   HIP_OK(hipMemcpy(m, dm, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost));
   if (d) HIP_OK(hipMemcpy(d, dd, (size_t)n * no * 8, hipMemcpyDeviceToHost));
   (void)hipFree(dp); (void)hipFree(dl); (void)hipFree(dm); (void)hipFree(dd);
+  return 0;
+}
+
+int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const double *poses_other, double *lam, double *mu,
+                      double *s, double *d) {
+  if (!h) return fail("null handle");
+  if (n < 1 || !poses_this || !poses_other || !lam || !mu || !s) return fail("bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  double *dpa = nullptr, *dpb = nullptr, *dout = nullptr;
+  HIP_OK(hipMalloc(&dpa, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dpb, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dout, (size_t)n * 11 * 8));
+  HIP_OK(hipMemcpy(dpa, poses_this, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dpb, poses_other, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
+  double *dl = dout, *dm = dout + (size_t)n * 4, *ds = dout + (size_t)n * 8, *dd = dout + (size_t)n * 10;
+  hipLaunchKernelGGL(joint_dual_ws_kernel, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->ks, n, dpa, dpb, dl, dm, ds, dd);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(lam, dl, (size_t)n * 4 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mu, dm, (size_t)n * 4 * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(s, ds, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
+  if (d) HIP_OK(hipMemcpy(d, dd, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dpa); (void)hipFree(dpb); (void)hipFree(dout);
   return 0;
 }
 

@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.cfz_kernel_info.argtypes = [vp, vp, vp]
     lib.cfz_mpc_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.cfz_mpc_set_warm.argtypes = [vp, C.c_int, vp]
+    lib.cfz_joint_dual_ws.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.cfz_default_plan_options.argtypes = [C.POINTER(_CPlanOptions)]
     lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
@@ -139,7 +140,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_default_plan_options cfz_state_ws cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -291,6 +292,15 @@ class Engine:
         l, m, d = np.zeros((n, 4 * no)), np.zeros((n, 4 * no)), np.zeros((n, no))
         self._ck(self.lib.cfz_dual_ws(self._h, n, _ptr(poses), _ptr(l), _ptr(m), _ptr(d)), "cfz_dual_ws")
         return l, m, d
+
+    def joint_dual_ws(self, poses_this, poses_other):
+        """`cfz_joint_dual_ws`: poses [n,3] of two vehicles -> (lam [n,4], mu [n,4], s [n,2], d [n])."""
+        pa = _f64(np.asarray(poses_this, float), (len(poses_this), 3))
+        pb = _f64(np.asarray(poses_other, float), (len(pa), 3))
+        n = len(pa)
+        lam, mu, s, d = np.zeros((n, 4)), np.zeros((n, 4)), np.zeros((n, 2)), np.zeros(n)
+        self._ck(self.lib.cfz_joint_dual_ws(self._h, n, _ptr(pa), _ptr(pb), _ptr(lam), _ptr(mu), _ptr(s), _ptr(d)), "cfz_joint_dual_ws")
+        return lam, mu, s, d
 
     # ---- batched closed loop ------------------------------------------------------------------------
     def loop_init(self, ref_table, k0, noise=None):

@@ -134,6 +134,14 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
  * are a face and a vertex. */
 int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d);
 
+/* MultiVehiclePlanner.joint_dual_ws (confrez/control/multi_vehicle_planner.py:208-341): for n pairs of fixed poses
+ * poses_this[n][3], poses_other[n][3] of two vehicles the duals lam[n][4] (faces of the first), mu[n][4] (faces of the
+ * second), s[n][2] of the rows -b_this'lam - b_other'mu = d, A_this'lam + s = 0, A_other'mu - s = 0, |s| <= 1,
+ * lam, mu >= 0 (:292-295) and the separation d[n] they certify (may be NULL).  The reference maximises d with IPOPT;
+ * here: closed-form maximum over the face normals of both rectangles (exact for face-vertex closest features). */
+int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const double *poses_other, double *lam, double *mu,
+                      double *s, double *d);
+
 /* ---- Vehicle.state_ws (confrez/control/vehicle.py:99-231): warm-start plan through the strategy's tube -----------
  * One NLP per vehicle, B of them in one call (no handle: nothing is kept).  Instance b has n_sets[b] strategy steps,
  * T_b = N (n_sets[b] - 1) Euler steps and T_b + 1 trajectory points.

@@ -272,6 +272,51 @@ def test_vehicle_sharded_loop_matches_device_loop():
         dist.destroy_process_group()
 
 
+def test_joint_dual_ws_certificates(eng, tmp_path):
+    """cfz_joint_dual_ws (multi_vehicle_planner.py:208-341): the duals satisfy the reference's rows (:292-295) exactly,
+    d is the separation of the two bodies for face-vertex closest features (known distances of aligned rectangles),
+    and `MultiVehiclePlanner.joint_dual_ws` lays the results out as the reference does."""
+    from oracle.mpc_nlp import rot
+
+    rng = np.random.default_rng(3)
+    n = 200
+    pa = np.stack([rng.uniform(5, 30, n), rng.uniform(8, 27, n), rng.uniform(-3.2, 3.2, n)], 1)
+    pb = pa + np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-3.2, 3.2, n)], 1)
+    lam, mu, s, d = eng.joint_dual_ws(pa, pb)
+    G, g = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]]), np.asarray(eng.spec.g, float)
+    for k in range(n):
+        tA = G @ rot(-pa[k, 2]); tb = tA @ pa[k, :2] + g
+        oA = G @ rot(-pb[k, 2]); ob = oA @ pb[k, :2] + g
+        assert (lam[k] >= 0).all() and (mu[k] >= 0).all() and s[k] @ s[k] <= 1 + 1e-12
+        assert np.abs(tA.T @ lam[k] + s[k]).max() < 1e-12 and np.abs(oA.T @ mu[k] - s[k]).max() < 1e-12
+        assert abs(-tb @ lam[k] - ob @ mu[k] - d[k]) < 1e-10
+    # two parallel vehicles side by side, 3 m apart centre to centre: 3 - 0.9 - 0.9; nose to tail on one line: gap 2
+    lam, mu, s, d = eng.joint_dual_ws([[10.0, 15.0, 0.0], [10.0, 15.0, 0.0]], [[10.0, 18.0, 0.0], [15.9, 15.0, 0.0]])
+    assert abs(d[0] - 1.2) < 1e-12 and abs(d[1] - (15.9 - 0.6 - 10.0 - 3.3)) < 1e-12
+    # the planner surface
+    from conflict_rez_amd import strategy as strat
+    from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
+    from conflict_rez_amd.pytypes import VehiclePrediction
+
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    agents = ["vehicle_%d" % i for i in range(4)]
+    mvp = MultiVehiclePlanner(fn, {a: True for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
+                              {a: None for a in agents}, {a: None for a in agents})
+    K = 5
+    for i, a in enumerate(agents):
+        mvp.vehicles[a].N = 4 + i
+        p = VehiclePrediction()
+        m_ = mvp.vehicles[a].N * (K + 1)
+        p.x, p.y, p.psi = 10.0 + 5 * i + 0.01 * np.arange(m_), 15.0 + 0.0 * np.arange(m_), 0.1 * i + 0.0 * np.arange(m_)
+        mvp.single_results[a] = p
+    mvp.joint_dual_ws(K=K)
+    assert len(mvp.agent_pairs) == 6 and set(mvp.joint_l0["vehicle_0"]) == {"vehicle_1", "vehicle_2", "vehicle_3"}
+    l01 = mvp.joint_l0["vehicle_0"]["vehicle_1"]
+    assert len(l01) == 4 and len(l01[0]) == K + 1 and l01[0][0].shape == (4,)
+    assert mvp.joint_s0[("vehicle_2", "vehicle_3")][5][K].shape == (2,) and len(mvp.joint_l0["vehicle_3"]["vehicle_2"]) == 6
+
+
 def test_python_shim_closed_loop_on_gpu(tmp_path):
     """`MultiDistributedFollower` through the real engine: 4 vehicles, 40 iterations, vehicles never overlap
     (separating-axis check on the driven states) and follow their plans; the drop-in surface end to end."""
