@@ -123,6 +123,35 @@ class Vehicle:
     def solve_single_final_problem(self, verbose: int = 0):
         raise NotImplementedError("collocation NLP (vehicle.py:642-661) has no HIP kernel yet; see DESIGN.md 'Next'")
 
+    def get_solution(self, sol) -> VehiclePrediction:
+        """get solution of this vehicle (vehicle.py:663-720): the collocation arrays (N, K+1) flattened row-major,
+        t = (i + tau) dt, l, m as nested lists [N][K+1] of (24,) arrays, and the interpolators set.  `sol` is whatever
+        holds the solved arrays: a mapping with x, y, psi, v, delta, a, w of shape (N, K+1), dt, and optionally l, m
+        of shape (N, K+1, 24) -- the reference reads the same quantities off a CasADi `OptiSol`; when l, m are absent
+        they are the closed-form certificates of the poses (`dual_ws`)."""
+        X = {k: np.asarray(sol[k], float) for k in ("x", "y", "psi", "v", "delta", "a", "w")}
+        N, K1 = X["x"].shape
+        self.N, self.K = N, K1 - 1
+        dt = float(sol["dt"])
+        result = VehiclePrediction()
+        result.dt = dt
+        tau_root = np.append(0.0, radau_points(self.K))
+        result.t = (np.arange(N)[:, None] + tau_root[None, :]).ravel() * dt
+        result.x, result.y, result.psi = X["x"].ravel(), X["y"].ravel(), X["psi"].ravel()
+        result.v, result.u_steer = X["v"].ravel(), X["delta"].ravel()
+        result.u_a, result.u_steer_dot = X["a"].ravel(), X["w"].ravel()
+        if "l" in sol and "m" in sol:
+            L, M = np.asarray(sol["l"], float), np.asarray(sol["m"], float)
+        else:
+            tmp = VehiclePrediction()
+            tmp.x, tmp.y, tmp.psi = result.x, result.y, result.psi
+            self.dual_ws(tmp)
+            L, M = tmp.l.T.reshape(N, K1, -1), tmp.m.T.reshape(N, K1, -1)
+        result.l = [[np.array(L[i, k]) for k in range(K1)] for i in range(N)]
+        result.m = [[np.array(M[i, k]) for k in range(K1)] for i in range(N)]
+        self.get_interpolator(K=self.K, N=N, dt=dt, opt=result)
+        return result
+
     # ---- resampling of a warm start onto the collocation grid ---------------------------------
     def interp_ws_for_collocation(self, zu0: VehiclePrediction, K: int = 5, N_per_set: int = 5):
         """Linear interpolation of every array of `zu0` at t = (i + tau) / N * T_end; l, m come in as

@@ -128,6 +128,14 @@ def test_collocation_tables_and_interpolant(follower_setup):
     assert np.allclose(veh.input_interpolator(0.0), [0, 0]) and np.allclose(veh.input_interpolator(tgrid[7]), [7, -7])
     out = veh.interpolate_states([0.1, 0.2])
     assert out.x.shape == (2,) and out.u_a.shape == (2,)
+    # get_solution (vehicle.py:663-720): (N, K+1) arrays -> flat arrays, t = (i + tau) dt, nested duals, interpolators
+    sol = dict(dt=dt, l=np.ones((N, K + 1, 24)), m=2 * np.ones((N, K + 1, 24)),
+               **{k: getattr(opt, a).reshape(N, K + 1) for k, a in (("x", "x"), ("y", "y"), ("psi", "psi"), ("v", "v"),
+                                                                      ("delta", "u_steer"), ("a", "u_a"), ("w", "u_steer_dot"))})
+    res = veh.get_solution(sol)
+    assert np.allclose(res.t, tgrid) and res.dt == dt and np.array_equal(res.x, opt.x) and np.array_equal(res.u_steer, opt.u_steer)
+    assert len(res.l) == N and len(res.l[0]) == K + 1 and res.l[2][3].shape == (24,) and res.m[0][0][5] == 2.0
+    assert np.isclose(veh.state_interpolator(1.234)[1], 2 * poly(1.234), atol=1e-10) and (veh.N, veh.K) == (N, K)
 
 
 def test_node_loop_over_in_process_bus(follower_setup):
