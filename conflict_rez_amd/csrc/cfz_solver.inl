@@ -952,17 +952,30 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
             zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
           }
         }
-        // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows)
+      }
+    CFZ_END
+    // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows).  The stage-local
+    // part (H dp + g)_z is formed by one lane per stage into the slot of d(pi_{k-1}); only the 5-vector recursion
+    // through A_k' stays on lane 0.
+    CFZ_LANES(lane)
+      if (lane >= 1 && lane < N) {
+        const int k = lane;
+        const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *z = m + L.dp + k * kNP;
+        double *q = m + L.dpi + (k - 1) * 5;
+        q[0] = gk[0] + h[0] * z[0] + h[7] * z[1] + h[8] * z[2];
+        q[1] = gk[1] + h[7] * z[0] + h[1] * z[1] + h[9] * z[2];
+        q[2] = gk[2] + h[8] * z[0] + h[9] * z[1] + h[2] * z[2];
+        q[3] = gk[3] + h[3] * z[3] + h[10] * z[6];
+        q[4] = gk[4] + h[4] * z[4];
+      }
+    CFZ_END
+    CFZ_LANES(lane)
+      if (lane == 0) {
         double lam[5] = {0, 0, 0, 0, 0};
 #pragma unroll 5
         for (int k = N - 1; k >= 1; --k) {
-          const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *z = dp + k * kNP;
-          double nl[5];
-          nl[0] = gk[0] + h[0] * z[0] + h[7] * z[1] + h[8] * z[2];
-          nl[1] = gk[1] + h[7] * z[0] + h[1] * z[1] + h[9] * z[2];
-          nl[2] = gk[2] + h[8] * z[0] + h[9] * z[1] + h[2] * z[2];
-          nl[3] = gk[3] + h[3] * z[3] + h[10] * z[6];
-          nl[4] = gk[4] + h[4] * z[4];
+          double *q = m + L.dpi + (k - 1) * 5;
+          double nl[5] = {q[0], q[1], q[2], q[3], q[4]};
           if (k + 1 < N) {
             const double *s = m + L.ab + k * 15;
             nl[0] += lam[0]; nl[1] += lam[1];
@@ -970,7 +983,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
             nl[3] += lam[3] + s[1] * lam[0] + s[6] * lam[1] + s[11] * lam[2];
             nl[4] += lam[4] + s[2] * lam[0] + s[7] * lam[1] + s[12] * lam[2];
           }
-          for (int i = 0; i < 5; ++i) { lam[i] = nl[i]; m[L.dpi + (k - 1) * 5 + i] = nl[i] - m[L.pi + (k - 1) * 5 + i]; }
+          for (int i = 0; i < 5; ++i) { lam[i] = nl[i]; q[i] = nl[i] - m[L.pi + (k - 1) * 5 + i]; }
         }
       }
     CFZ_END
