@@ -10,6 +10,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    # torch bundles its own HIP runtime: when a test uses torch.cuda (RCCL) in the same process as the engine's library,
+    # torch has to touch the GPU first, or it no longer finds one.  No-op on a machine without a GPU.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001 - torch is optional for everything but the RCCL tests
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
 
 
