@@ -862,6 +862,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)loop_kernel, 64, h->lds_bytes));
   if (per_cu < 1) return fail("loop kernel does not fit on a CU");
   // every workgroup of the grid must be resident: waiting workgroups poll the queue
+  if (const char *cap = std::getenv("CFZ_LOOP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(cap)));  // experiments
   const int grid = std::min(B, per_cu * ncu);
   const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;
   if (!h->pred2) {
