@@ -78,3 +78,46 @@ def test_slsqp_from_the_warm_start_reaches_the_oracle_solution(k0, v, obs, dmin,
     assert res["cost"] - out.fun <= 1e-6 * max(1.0, res["cost"])
     s2 = nlp.unpack(out.x)
     assert max(np.abs(s2[k] - r["sol"][k]).max() for k in ("x", "y", "psi")) < 1e-5
+
+
+def test_state_ws_oracle_matches_slsqp():
+    """The planning oracle (oracle/plan_nlp.py, vehicle.py:99-231) against scipy's SLSQP on a short tube (4 strategy
+    steps, 6 Euler steps each): same optimal cost and trajectory, started from the spline guess."""
+    import os
+    import tempfile
+
+    from conflict_rez_amd import strategy as strat
+    from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+    from conflict_rez_amd.vehicle_types import VehicleBody
+    from oracle.plan_nlp import StateWsNlp
+
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 6)
+    a = "vehicle_1"
+    tube = [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]][:4]
+    p = paths[a][: 6 * 3 + 1]
+    nlp = StateWsNlp(p[0], tube, N=6, shrink_tube=0.5)
+    X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2])
+    ro = ipm.solve(nlp, X0, ipm.IpmOptions(max_iter=300, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8,
+                                           constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6))
+    assert ro["status"] == 0
+    nz = 7 * nlp.T + 5  # SLSQP works on the trajectory variables; the tube rows become inequalities
+    r0 = 7 + 5 * nlp.T
+
+    def eq(z):
+        return nlp.cons(np.concatenate([z, np.zeros(nlp.n - nz)]))[:r0]
+
+    def ineq(z):  # A p - (b - shrink) <= 0
+        return -nlp.cons(np.concatenate([z, np.zeros(nlp.n - nz)]))[r0 : r0 + 8 * nlp.n_chk]
+
+    lo, hi = nlp.xl[:nz], nlp.xu[:nz]
+    out = minimize(lambda z: nlp.f(np.concatenate([z, np.zeros(nlp.n - nz)])), X0[:nz], method="SLSQP",
+                   bounds=[(None if not np.isfinite(l) else l, None if not np.isfinite(u) else u) for l, u in zip(lo, hi)],
+                   constraints=[dict(type="eq", fun=eq), dict(type="ineq", fun=ineq)], options=dict(maxiter=500, ftol=1e-13))
+    assert out.status == 0 and np.abs(eq(out.x)).max() < 1e-7 and ineq(out.x).min() > -1e-7
+    assert abs(out.fun - ro["f"]) < 1e-5 * max(1.0, ro["f"]), (out.fun, ro["f"])
+    so, ss = nlp.unpack(ro["X"]), nlp.unpack(np.concatenate([out.x, np.zeros(nlp.n - nz)]))
+    assert max(np.abs(so[k] - ss[k]).max() for k in ("x", "y", "psi", "v")) < 1e-3
