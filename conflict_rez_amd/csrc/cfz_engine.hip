@@ -706,8 +706,17 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n
   long long g0 = 0;
   for (int b = 0; b < B; ++b) {
     const int T = specs[b].T;
-    if (guess) for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
-    else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
+    if (guess) {
+      for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
+      // The reference seeds x, y, psi only.  With v = 0 everywhere the heading rows of the linearisation have no control
+      // authority (rank deficient once a terminal heading is fixed); the signed speed along the guessed path costs
+      // nothing and takes the solver from 14-150 iterations (one failure) to 8-35 on the four-vehicle strategy.
+      for (int k = 1; k < T; ++k) {
+        const double *p0 = guess + (size_t)(g0 + k) * 3, *p1 = p0 + 3;
+        const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], along = dx * cos(p0[2]) + dy * sin(p0[2]);
+        X[(size_t)xoff[b] + 7 * k + 3] = (along > 0.0 ? 1.0 : (along < 0.0 ? -1.0 : 0.0)) * sqrt(dx * dx + dy * dy) / po->dt;
+      }
+    } else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
     g0 += T + 1;
   }
   cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;

@@ -16,6 +16,17 @@ import scipy.sparse as sp
 from .dynamics import bicycle_ct, bicycle_ct_jac
 
 
+def speed_guess(p, dt):
+    """Signed speed along a guessed path p [T+1, >=3] (x, y, psi), as `cfz_state_ws` adds it to the spline guess:
+    v_k = sign((p_{k+1} - p_k) . heading_k) |p_{k+1} - p_k| / dt for 0 < k < T, v_0 = v_T = 0."""
+    p = np.asarray(p, float)
+    d = np.diff(p[:, :2], axis=0)
+    along = d[:, 0] * np.cos(p[:-1, 2]) + d[:, 1] * np.sin(p[:-1, 2])
+    v = np.append(np.sign(along) * np.hypot(d[:, 0], d[:, 1]) / dt, 0.0)
+    v[0] = 0.0
+    return v
+
+
 class StateWsNlp:
     """X layout: [z_0 u_0 | z_1 u_1 | ... | z_{T-1} u_{T-1} | z_T | tube slacks (8 per checkpoint)]."""
 

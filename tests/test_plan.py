@@ -10,7 +10,7 @@ from conflict_rez_amd import strategy as strat
 from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
 from conflict_rez_amd.vehicle_types import VehicleBody
 from oracle import ipm
-from oracle.plan_nlp import StateWsNlp
+from oracle.plan_nlp import StateWsNlp, speed_guess
 
 PLAN_OPT = dict(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0)
 
@@ -31,16 +31,17 @@ def plans():
 
 def test_plan_kernel_source_matches_oracle(plans):
     """Same iterates as the full-KKT sparse-LU oracle (iteration counts equal, solutions to 1e-8) with the terminal
-    heading free, with bounded inputs, and with a terminal heading on a well-conditioned case; where the terminal
-    heading makes the heading rows rank deficient at the zero-velocity guess the two linear solvers drift apart and
-    only the solutions are compared, at the solver's tolerance."""
+    heading free, with bounded inputs, and with a terminal heading when the guess carries the speed along the path (what
+    `cfz_state_ws` does); with a terminal heading and the zero-velocity guess the heading rows are rank deficient, the two
+    linear solvers drift apart and only the outcomes are compared, at the solver's tolerance."""
     import plan_emu_binding as pe
 
     opt = ipm.IpmOptions(**PLAN_OPT)
     for a, (tube, p) in plans.items():
-        for fh, bounded, exact in ((None, False, True), (None, True, True), (float(p[-1, 2]), False, a == "vehicle_1")):
+        for fh, bounded, exact, seeded in ((None, False, True, False), (None, True, True, True), (float(p[-1, 2]), False, True, True),
+                                           (float(p[-1, 2]), False, a == "vehicle_1", False)):
             nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5, bounded_input=bounded)
-            X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2])
+            X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt) if seeded else None)
             ro, re_ = ipm.solve(nlp, X0, opt), pe.solve(nlp, X0, opt)
             assert re_["bandwidth"] <= 40
             assert ro["status"] == re_["status"], (a, fh, bounded)
@@ -64,16 +65,20 @@ def test_state_ws_on_gpu_matches_oracle(plans):
 
     agents = sorted(plans)
     tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
-    res = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], [None] * 4, shrink_tube=0.5)
     opt = ipm.IpmOptions(**PLAN_OPT)
-    for a, r in zip(agents, res):
-        tube, p = plans[a]
-        nlp = StateWsNlp(p[0], tube, final_heading=None, shrink_tube=0.5)
-        ro = ipm.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2]), opt)
-        so = nlp.unpack(ro["X"])
-        assert (r["status"], r["iters"]) == (ro["status"], ro["iters"]) == (0, ro["iters"])
-        want = np.stack([so["x"], so["y"], so["psi"], so["v"], so["delta"], so["a"], so["w"]], 1)
-        assert np.abs(r["traj"] - want).max() < 1e-7 and abs(r["cost"] - ro["f"]) < 1e-8
+    for with_heading in (False, True):  # the reference's callers fix the terminal heading (vehicle.py:901-912)
+        fhs = [float(plans[a][1][-1, 2]) if with_heading else None for a in agents]
+        res = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5)
+        for a, fh, r in zip(agents, fhs, res):
+            tube, p = plans[a]
+            nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
+            ro = ipm.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)), opt)
+            so = nlp.unpack(ro["X"])
+            assert (r["status"], r["iters"]) == (ro["status"], ro["iters"]) == (0, ro["iters"]), (a, fh)
+            want = np.stack([so["x"], so["y"], so["psi"], so["v"], so["delta"], so["a"], so["w"]], 1)
+            assert np.abs(r["traj"] - want).max() < 1e-6 and abs(r["cost"] - ro["f"]) < 1e-7
+            if fh is not None:
+                assert abs(r["traj"][-1, 2] - fh) < 1e-6
 
 
 @pytest.mark.gpu
@@ -86,10 +91,13 @@ def test_plan_single_path_then_follow_on_gpu(tmp_path):
     strat.write_strategy(fn, strat.generate_strategy(4))
     agents = ["vehicle_%d" % i for i in range(4)]
     colors = {a: {"front": (1.0, 0.0, 0.0), "back": (0.0, 0.0, 1.0)} for a in agents}
-    mdf = MultiDistributedFollower(fn, {a: True for a in agents}, colors, {a: None for a in agents}, {a: None for a in agents})
+    paths = interp_along_sets(fn, VehicleBody(), 30)
+    mdf = MultiDistributedFollower(fn, {a: True for a in agents}, colors, {a: None for a in agents},
+                                   {a: float(paths[a][-1, 2]) for a in agents})
     mdf.setup_multi_vehicles()
     for v in mdf.vehicles:
         assert v.plan_refined is False and v.state_ws_stats["status"] == 0
+        assert abs(v.reference_traj.psi[-1] - v.final_heading) < 1e-3  # the terminal heading of the reference's callers
         assert v.reference_traj.t[-1] == pytest.approx(0.1 * 30 * (v.num_sets - 1), abs=0.02)
         assert v.reference_traj.x.shape == v.reference_traj.psi.shape and np.isfinite(v.reference_xy).all()
     mdf.solve(num_iter=5, dump=False)
