@@ -1,0 +1,599 @@
+// The single-vehicle collocation plan (reference confrez/control/vehicle.py:360-661, `setup_single_final_problem` +
+// `solve_single_final_problem`): N = N_per_set (S-1) intervals of free length dt, K = 5 Radau points each.
+//
+//   variables    p_ik = (x, y, psi, v, delta, a, w) at the 6 points of every interval (:402-409), dt (:386-390)
+//   ODE          sum_j A[j,k] z_ij / dt = f(z_ik, u_ik) at ALL six points (:487-509)  [stated times dt: sum_j A z - dt f = 0]
+//   continuity   sum_j D[j] p_{i-1,j} = p_{i,0}, states and inputs (:544-568); Radau: D = e_K, so p_{i,0} = p_{i-1,K}
+//   tube         rear-axle and front point of p_{i,0} inside the shrunk cells at every N_per_set-th interval (:570-588)
+//                and of the end state z_F = p_{N-1,K} in the last cells (:606-617)
+//   terminal     v = delta = a = w = 0 at the end (:622-626), optional heading (:619-620); initial pose fixed,
+//                v = delta = a = w = 0 at the start (:426-436)
+//   boxes        x, y, v, delta, a, w at every point (:439-478)
+//   collision    every point against every static obstacle, at least dmin apart (:523-541) -- with the OBCA duals
+//                eliminated into two smooth rows per (point, obstacle) over a working set, exactly as in the MPC step
+//                (DESIGN.md "Certificate elimination"); the duals l, m are rebuilt from the poses afterwards
+//   cost         sum_ik B[k] (a^2 + v^2 w^2 + delta^2) dt + (N dt)^2 (:512-521, :638)
+//
+// Solver: the banded primal-dual interior point of cfz_plan.inl (exact Hessian, delta_w ladder with the curvature test,
+// delta_c), with two additions: dt couples to everything, so it is kept out of the band and handled by bordering
+// (one factorisation, two substitutions); the working set of the collision rows is refreshed at every accepted iterate.
+// One workgroup per plan, workspace in global memory; all lanes run the scalar logic, the marked loops are shared.
+#pragma once
+#include "cfz_solver.inl"
+#include "cfz_plan.inl"
+
+namespace cfzc {
+
+constexpr int kPts = 6;     // points per interval (K + 1)
+constexpr int kMaxObs = 8;
+
+struct CSpec {
+  int N, Nps, n_chk, n_obs, has_final;
+  int max_iter, max_backtrack, filter_cap, pad0, pad1;
+  double wb, dmin, shrink, final_heading, dt0;
+  double init_pose[3];
+  double bounds[12];  // lo,hi of x, y, v, delta, a, w
+  double g[4];        // body polytope offsets
+  double A[kPts][kPts], B[kPts];  // collocation tables: A[j][k] = l_j'(tau_k), B[k] = quadrature weights
+  double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
+      bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
+      reg_primal, reg_dual, curv_kappa;
+  const double *obs_tab;  // n_obs x 20: A[4][2], b[4], V[4][2]
+  const double *tube;     // n_chk x 2 x 12: back cell, front cell (A[4][2], b[4]) of strategy steps 1..S-1
+};
+
+struct CDims {
+  int np, nr, n, m, nk;          // points, collision rows per point, variables, constraints, band system size
+  int iDt, sO, sT;               // variable offsets: dt, collision slacks, tube slacks
+  int rO, rC, rR, rT, rF, rH;    // constraint offsets: ODE, continuity, collision rows, tube rows, terminal, heading
+};
+CFZP_FN CDims cdims(const CSpec &sp) {
+  CDims d;
+  d.np = sp.N * kPts; d.nr = 2 * sp.n_obs;
+  d.iDt = 7 * d.np; d.sO = d.iDt + 1; d.sT = d.sO + d.np * d.nr; d.n = d.sT + 8 * sp.n_chk;
+  d.rO = 7; d.rC = d.rO + 5 * d.np; d.rR = d.rC + 7 * (sp.N - 1); d.rT = d.rR + d.np * d.nr; d.rF = d.rT + 8 * sp.n_chk;
+  d.rH = d.rF + 4; d.m = d.rH + (sp.has_final ? 1 : 0);
+  d.nk = d.n - 1 + d.m;  // dt is bordered, not in the band
+  return d;
+}
+// point of tube checkpoint q: start of interval (q+1) Nps, or the very last point
+CFZP_FN int chk_point(const CSpec &sp, int q) { return q + 1 < sp.n_chk ? (q + 1) * sp.Nps * kPts : sp.N * kPts - 1; }
+
+CFZP_FN void obstacle(const CSpec &sp, int j, double A[4][2], double b[4], double V[4][2]) {
+  const double *o = sp.obs_tab + j * 20;
+  for (int i = 0; i < 4; ++i) { A[i][0] = o[2 * i]; A[i][1] = o[2 * i + 1]; b[i] = o[8 + i]; V[i][0] = o[12 + 2 * i]; V[i][1] = o[13 + 2 * i]; }
+}
+
+CFZP_FN void f_ct(const double *p, double wb, double f[5]) {
+  f[0] = p[3] * cos(p[2]); f[1] = p[3] * sin(p[2]); f[2] = p[3] / wb * tan(p[4]); f[3] = p[5]; f[4] = p[6];
+}
+CFZP_FN double stage_err(const double *p) { return p[5] * p[5] + p[3] * p[3] * p[6] * p[6] + p[4] * p[4]; }
+
+CFZP_FN double objective(const CSpec &sp, const double *X) {
+  const CDims d = cdims(sp);
+  double s = 0.0;
+  CFZP_LANE_FOR(q, 0, d.np - 1) s += sp.B[q % kPts] * stage_err(X + 7 * q);
+  const double dt = X[d.iDt];
+  return cfzp::wsum(s) * dt + (sp.N * dt) * (sp.N * dt);
+}
+
+// c(X); sel[np * n_obs] is the working set of the collision rows
+CFZP_FN void constraints(const CSpec &sp, const unsigned char *sel, const double *X, double *c) {
+  const CDims d = cdims(sp);
+  const double dt = X[d.iDt];
+  for (int i = 0; i < 3; ++i) c[i] = X[i] - sp.init_pose[i];
+  for (int i = 3; i < 7; ++i) c[i] = X[i];
+  CFZP_LANE_FOR(q, 0, d.np - 1) {
+    const int i = q / kPts, k = q - i * kPts;
+    const double *p = X + 7 * q;
+    double f[5];
+    f_ct(p, sp.wb, f);
+    for (int cc = 0; cc < 5; ++cc) {
+      double s = -dt * f[cc];
+      for (int j = 0; j < kPts; ++j) s += sp.A[j][k] * X[7 * (i * kPts + j) + cc];
+      c[d.rO + 5 * q + cc] = s;
+    }
+    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) c[d.rC + 7 * (i - 1) + cc] = p[cc] - X[7 * (q - 1) + cc];
+    double sn, cs;
+    sincos(p[2], &sn, &cs);
+    for (int j = 0; j < sp.n_obs; ++j) {
+      double A[4][2], b[4], V[4][2], sep[2];
+      obstacle(sp, j, A, b, V);
+      cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, sel[q * sp.n_obs + j], sep, nullptr);
+      for (int r = 0; r < 2; ++r) c[d.rR + q * d.nr + 2 * j + r] = sep[r] - sp.dmin - X[d.sO + q * d.nr + 2 * j + r];
+    }
+  }
+  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
+    const double *z = X + 7 * chk_point(sp, t);
+    const double fx = z[0] + sp.wb * cos(z[2]), fy = z[1] + sp.wb * sin(z[2]);
+    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    for (int r = 0; r < 4; ++r) {
+      c[d.rT + 8 * t + r] = cb[2 * r] * z[0] + cb[2 * r + 1] * z[1] - (cb[8 + r] - sp.shrink) + X[d.sT + 8 * t + r];
+      c[d.rT + 8 * t + 4 + r] = cf[2 * r] * fx + cf[2 * r + 1] * fy - (cf[8 + r] - sp.shrink) + X[d.sT + 8 * t + 4 + r];
+    }
+  }
+  const double *pl = X + 7 * (d.np - 1);
+  for (int i = 0; i < 4; ++i) c[d.rF + i] = pl[3 + i];
+  if (sp.has_final) c[d.rH] = pl[2] - sp.final_heading;
+  CFZP_SYNC();
+}
+
+CFZP_FN void gradient(const CSpec &sp, const double *X, double *g) {
+  const CDims d = cdims(sp);
+  const double dt = X[d.iDt];
+  double s = 0.0;
+  CFZP_LANE_FOR(q, 0, d.np - 1) {
+    const double *p = X + 7 * q; const double bk = sp.B[q % kPts];
+    double *o = g + 7 * q;
+    o[0] = o[1] = o[2] = 0.0;
+    o[3] = bk * dt * 2.0 * p[3] * p[6] * p[6]; o[4] = bk * dt * 2.0 * p[4]; o[5] = bk * dt * 2.0 * p[5]; o[6] = bk * dt * 2.0 * p[3] * p[3] * p[6];
+    s += bk * stage_err(p);
+  }
+  CFZP_LANE_FOR(i, d.sO, d.n - 1) g[i] = 0.0;
+  g[d.iDt] = cfzp::wsum(s) + 2.0 * sp.N * sp.N * dt;
+  CFZP_SYNC();
+}
+
+// out = J(X)' nu (all n entries, dt included)
+CFZP_FN void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X, const double *nu, double *out) {
+  const CDims d = cdims(sp);
+  const double dt = X[d.iDt];
+  double sdt = 0.0;
+  CFZP_LANE_FOR(q, 0, d.np - 1) {
+    const int i = q / kPts, k = q - i * kPts;
+    const double *p = X + 7 * q, *l = nu + d.rO + 5 * q;
+    double o[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int kk = 0; kk < kPts; ++kk) {  // this point's states enter the ODE rows of all six points of the interval
+      const double *lk = nu + d.rO + 5 * (i * kPts + kk);
+      for (int cc = 0; cc < 5; ++cc) o[cc] += sp.A[k][kk] * lk[cc];
+    }
+    const double cs = cos(p[2]), sn = sin(p[2]), tn = tan(p[4]), v = p[3];
+    double f[5];
+    f_ct(p, sp.wb, f);
+    for (int cc = 0; cc < 5; ++cc) sdt -= l[cc] * f[cc];
+    o[2] -= dt * (-v * sn * l[0] + v * cs * l[1]);
+    o[3] -= dt * (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
+    o[4] -= dt * (v / sp.wb * (1.0 + tn * tn) * l[2]);
+    o[5] -= dt * l[3]; o[6] -= dt * l[4];
+    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[d.rC + 7 * (i - 1) + cc];
+    if (k == kPts - 1 && i + 1 < sp.N) for (int cc = 0; cc < 7; ++cc) o[cc] -= nu[d.rC + 7 * i + cc];
+    if (q == 0) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[cc];
+    if (q == d.np - 1) { for (int cc = 0; cc < 4; ++cc) o[3 + cc] += nu[d.rF + cc]; if (sp.has_final) o[2] += nu[d.rH]; }
+    for (int j = 0; j < sp.n_obs; ++j) {
+      double A[4][2], b[4], V[4][2], sep[2], gr[2][3];
+      obstacle(sp, j, A, b, V);
+      cfz::rows_for<true>(A, b, V, p[0], p[1], cs, sn, sp.g, sel[q * sp.n_obs + j], sep, gr);
+      for (int r = 0; r < 2; ++r) {
+        const double nr_ = nu[d.rR + q * d.nr + 2 * j + r];
+        o[0] += gr[r][0] * nr_; o[1] += gr[r][1] * nr_; o[2] += gr[r][2] * nr_;
+        out[d.sO + q * d.nr + 2 * j + r] = -nr_;
+      }
+    }
+    for (int cc = 0; cc < 7; ++cc) out[7 * q + cc] = o[cc];
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
+    const int b = 7 * chk_point(sp, t);
+    const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
+    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    for (int r = 0; r < 4; ++r) {
+      const double lb = nu[d.rT + 8 * t + r], lf = nu[d.rT + 8 * t + 4 + r];
+      out[b] += cb[2 * r] * lb + cf[2 * r] * lf; out[b + 1] += cb[2 * r + 1] * lb + cf[2 * r + 1] * lf;
+      out[b + 2] += sp.wb * (-cf[2 * r] * sn + cf[2 * r + 1] * cs) * lf;
+      out[d.sT + 8 * t + r] = lb; out[d.sT + 8 * t + 4 + r] = lf;
+    }
+  }
+  out[d.iDt] = cfzp::wsum(sdt);
+  CFZP_SYNC();
+}
+
+// ---- band ordering ---------------------------------------------------------------------------------------------
+// per interval: [continuity mults | (tube) | pt0 | pt1 | pt2 | ODE mults of the 6 points | pt3 | pt4 | pt5 | (last tube)], pt =
+// [7 variables | collision slacks | collision row mults]; initial rows first, terminal rows last.  dt has no position.
+CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
+  const CDims d = cdims(sp);
+  int p = 0;
+  for (int i = 0; i < 7; ++i) posc[i] = p++;
+  for (int i = 0; i < sp.N; ++i) {
+    for (int k = 0; k < kPts; ++k) {
+      const int q = i * kPts + k;
+      for (int pass = 0; pass < 2; ++pass) {  // tube block: before an interval's first point, after the very last point
+        if (pass == 0 && k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) posc[d.rC + 7 * (i - 1) + cc] = p++;
+        for (int t = 0; t < sp.n_chk; ++t)
+          if (chk_point(sp, t) == q && (pass == 0) == (k == 0)) {
+            for (int r = 0; r < 8; ++r) posx[d.sT + 8 * t + r] = p++;
+            for (int r = 0; r < 8; ++r) posc[d.rT + 8 * t + r] = p++;
+          }
+        if (pass == 1) break;
+        if (k == 3) for (int kk = 0; kk < kPts; ++kk) for (int cc = 0; cc < 5; ++cc) posc[d.rO + 5 * (i * kPts + kk) + cc] = p++;
+        for (int cc = 0; cc < 7; ++cc) posx[7 * q + cc] = p++;
+        for (int r = 0; r < d.nr; ++r) posx[d.sO + q * d.nr + r] = p++;
+        for (int r = 0; r < d.nr; ++r) posc[d.rR + q * d.nr + r] = p++;
+      }
+    }
+  }
+  for (int i = 0; i < 4; ++i) posc[d.rF + i] = p++;
+  if (sp.has_final) posc[d.rH] = p++;
+  posx[d.iDt] = -1;
+  return p;
+}
+
+struct Band { double *ab; int kb, ld; };
+CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld + (2 * B.kb + i - j)]; }
+CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
+
+struct CWork {
+  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig;
+  int *posx, *posc, *ipiv;
+  unsigned char *sel;
+};
+CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
+  const CDims d = cdims(sp);
+  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)(d.n + d.m + d.nk + 2) / 2 +
+         (size_t)(d.np * sp.n_obs + 7) / 8 + 64;
+}
+CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
+  const CDims d = cdims(sp);
+  CWork w; double *p = slab;
+  w.x = p; p += d.n; w.xt = p; p += d.n; w.zl = p; p += d.n; w.zu = p; p += d.n; w.dx = p; p += d.n; w.dzl = p; p += d.n;
+  w.dzu = p; p += d.n; w.g = p; p += d.n; w.xl = p; p += d.n; w.xu = p; p += d.n; w.r1 = p; p += d.n; w.sig = p; p += d.n;
+  w.nu = p; p += d.m; w.dnu = p; p += d.m; w.c = p; p += d.m; w.ct = p; p += d.m;
+  w.rhs = p; p += d.nk; w.rhs2 = p; p += d.nk; w.bord = p; p += d.nk; w.ab = p; p += (size_t)d.nk * (3 * kb + 1);
+  w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
+  p += (size_t)(d.n + d.m + d.nk + 2) / 2;
+  w.sel = reinterpret_cast<unsigned char *>(p);
+  return w;
+}
+
+// band part of [[W + Sigma + (delta + reg) I, J'], [J, -reg_dual I]] (dt row and column left out) and the border:
+// bord = column of dt restricted to the band unknowns, hdd = its diagonal entry
+CFZP_FN double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
+  const CDims d = cdims(sp);
+  const int *px = w.posx, *pc = w.posc;
+  const double *X = w.x, *nu = w.nu;
+  const double dt = X[d.iDt];
+  CFZP_LANE_FOR(col, 0, d.nk - 1) { for (int r = 0; r < Bd.ld; ++r) Bd.ab[(size_t)col * Bd.ld + r] = 0.0; w.bord[col] = 0.0; }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, d.n - 1) if (i != d.iDt) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
+  CFZP_LANE_FOR(i, 0, d.m - 1) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, 6) put(Bd, pc[i], px[i], 1.0);
+  CFZP_LANE_FOR(q, 0, d.np - 1) {  // every entry written here belongs to point q alone
+    const int i = q / kPts, k = q - i * kPts, b = 7 * q;
+    const double *p = X + b, *l = nu + d.rO + 5 * q;
+    const double cs = cos(p[2]), sn = sin(p[2]), tn = tan(p[4]), sec2 = 1.0 + tn * tn, v = p[3], wv = p[6], bk = sp.B[k];
+    // objective curvature B_k dt e''
+    bnd(Bd, px[b + 3], px[b + 3]) += bk * dt * 2.0 * wv * wv; bnd(Bd, px[b + 6], px[b + 6]) += bk * dt * 2.0 * v * v;
+    put(Bd, px[b + 3], px[b + 6], bk * dt * 4.0 * v * wv);
+    bnd(Bd, px[b + 4], px[b + 4]) += bk * dt * 2.0; bnd(Bd, px[b + 5], px[b + 5]) += bk * dt * 2.0;
+    // ODE curvature: rows are sum_j A z - dt f, multipliers l
+    const double l0 = -l[0] * dt, l1 = -l[1] * dt, l2 = -l[2] * dt;
+    bnd(Bd, px[b + 2], px[b + 2]) += l0 * (-v * cs) + l1 * (-v * sn);
+    put(Bd, px[b + 2], px[b + 3], l0 * (-sn) + l1 * cs);
+    put(Bd, px[b + 3], px[b + 4], l2 * sec2 / sp.wb);
+    bnd(Bd, px[b + 4], px[b + 4]) += l2 * 2.0 * v * tn * sec2 / sp.wb;
+    // border: d2L / dp ddt = B_k e' - (f_z, f_u)' l
+    w.bord[px[b + 2]] += -(-v * sn * l[0] + v * cs * l[1]);
+    w.bord[px[b + 3]] += bk * 2.0 * v * wv * wv - (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
+    w.bord[px[b + 4]] += bk * 2.0 * p[4] - v / sp.wb * sec2 * l[2];
+    w.bord[px[b + 5]] += bk * 2.0 * p[5] - l[3];
+    w.bord[px[b + 6]] += bk * 2.0 * v * v * wv - l[4];
+    // Jacobian of this point's ODE rows: A[j][k] on the states of every point j of the interval, -dt f' on its own
+    double f[5];
+    f_ct(p, sp.wb, f);
+    const int r = d.rO + 5 * q;
+    for (int cc = 0; cc < 5; ++cc) {
+      for (int j = 0; j < kPts; ++j) put(Bd, pc[r + cc], px[7 * (i * kPts + j) + cc], sp.A[j][k]);
+      w.bord[pc[r + cc]] += -f[cc];
+    }
+    put(Bd, pc[r + 0], px[b + 2], -dt * (-v * sn)); put(Bd, pc[r + 0], px[b + 3], -dt * cs);
+    put(Bd, pc[r + 1], px[b + 2], -dt * (v * cs)); put(Bd, pc[r + 1], px[b + 3], -dt * sn);
+    put(Bd, pc[r + 2], px[b + 3], -dt * tn / sp.wb); put(Bd, pc[r + 2], px[b + 4], -dt * v / sp.wb * sec2);
+    put(Bd, pc[r + 3], px[b + 5], -dt); put(Bd, pc[r + 4], px[b + 6], -dt);
+    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) { put(Bd, pc[d.rC + 7 * (i - 1) + cc], px[b + cc], 1.0); put(Bd, pc[d.rC + 7 * (i - 1) + cc], px[b - 7 + cc], -1.0); }
+    // collision rows: gradient, slack, curvature
+    for (int j = 0; j < sp.n_obs; ++j) {
+      double A[4][2], bb[4], V[4][2], sep[2], gr[2][3];
+      obstacle(sp, j, A, bb, V);
+      const int sl = w.sel[q * sp.n_obs + j], fc = (sl >> 4) & 3;
+      cfz::rows_for<true>(A, bb, V, p[0], p[1], cs, sn, sp.g, sl, sep, gr);
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = d.rR + q * d.nr + 2 * j + rr, sk = d.sO + q * d.nr + 2 * j + rr;
+        put(Bd, pc[row], px[b], gr[rr][0]); put(Bd, pc[row], px[b + 1], gr[rr][1]); put(Bd, pc[row], px[b + 2], gr[rr][2]);
+        put(Bd, pc[row], px[sk], -1.0);
+        const double nr_ = nu[row];
+        const int vtx = rr == 0 ? ((sl >> 2) & 3) : (sl & 3);
+        if ((sl >> 6) == 1) {  // polygon face (a0,a1), body vertex: d2/dpsi2 = -A_f.(R b_v)
+          const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
+          bnd(Bd, px[b + 2], px[b + 2]) += nr_ * -(gr[rr][0] * (cs * bx - sn * by) + gr[rr][1] * (sn * bx + cs * by));
+        } else {  // body face: d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
+          const double gf = sp.g[fc];
+          put(Bd, px[b], px[b + 2], nr_ * -gr[rr][1]); put(Bd, px[b + 1], px[b + 2], nr_ * gr[rr][0]);
+          bnd(Bd, px[b + 2], px[b + 2]) += nr_ * -(sep[rr] + gf);
+        }
+      }
+    }
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
+    const int b = 7 * chk_point(sp, t), r = d.rT + 8 * t, s = d.sT + 8 * t;
+    const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
+    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    double curv = 0.0;
+    for (int rr = 0; rr < 4; ++rr) {
+      put(Bd, pc[r + rr], px[b], cb[2 * rr]); put(Bd, pc[r + rr], px[b + 1], cb[2 * rr + 1]); put(Bd, pc[r + rr], px[s + rr], 1.0);
+      put(Bd, pc[r + 4 + rr], px[b], cf[2 * rr]); put(Bd, pc[r + 4 + rr], px[b + 1], cf[2 * rr + 1]);
+      put(Bd, pc[r + 4 + rr], px[b + 2], sp.wb * (-cf[2 * rr] * sn + cf[2 * rr + 1] * cs));
+      put(Bd, pc[r + 4 + rr], px[s + 4 + rr], 1.0);
+      curv += nu[r + 4 + rr] * sp.wb * (-cf[2 * rr] * cs - cf[2 * rr + 1] * sn);
+    }
+    bnd(Bd, px[b + 2], px[b + 2]) += curv;
+  }
+  const int bl = 7 * (d.np - 1);
+  for (int i = 0; i < 4; ++i) put(Bd, pc[d.rF + i], px[bl + 3 + i], 1.0);
+  if (sp.has_final) put(Bd, pc[d.rH], px[bl + 2], 1.0);
+  CFZP_SYNC();
+  return 2.0 * sp.N * sp.N + delta + sp.reg_primal;  // d2L/ddt2
+}
+
+// ---- banded LU with partial pivoting, runtime half-bandwidth, factor once / substitute many -----------------------
+CFZP_FN int band_factor(const Band &B, int n, int *ipiv) {
+  const int kl = B.kb, ku = B.kb, kv = kl + ku, ld = B.ld;
+  double *ab = B.ab;
+  int ju = 0;
+  for (int j = 0; j < n; ++j) {
+    const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+    double *cj = ab + (size_t)j * ld;
+    int jp = 0; double best = fabs(cj[kv]);
+    for (int i = 1; i <= km; ++i) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
+    ipiv[j] = j + jp;
+    if (!(best > 0.0)) return 1;
+    const int reach = j + ku + jp; ju = ju > (reach < n - 1 ? reach : n - 1) ? ju : (reach < n - 1 ? reach : n - 1);
+    if (jp != 0) {
+      CFZP_LANE_FOR(q, j, ju) { double *cq = ab + (size_t)q * ld; const double t = cq[kv + j - q]; cq[kv + j - q] = cq[kv + j + jp - q]; cq[kv + j + jp - q] = t; }
+      CFZP_SYNC();
+    }
+    const double inv = 1.0 / cj[kv];
+    CFZP_SYNC();
+    CFZP_LANE_FOR(i, 1, km) cj[kv + i] *= inv;
+    CFZP_SYNC();
+    CFZP_LANE_FOR(q, j + 1, ju) {
+      double *cq = ab + (size_t)q * ld;
+      const double u = cq[kv + j - q];
+      if (u != 0.0) for (int i = 1; i <= km; ++i) cq[kv + j + i - q] -= cj[kv + i] * u;
+    }
+    CFZP_SYNC();
+  }
+  return 0;
+}
+CFZP_FN void band_substitute(const Band &B, int n, const int *ipiv, double *b) {
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld;
+  const double *ab = B.ab;
+  for (int j = 0; j < n; ++j) {
+    const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
+    if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
+    const double bj = b[j];
+    CFZP_SYNC();
+    if (bj != 0.0) CFZP_LANE_FOR(i, 1, km) b[j + i] -= ab[(size_t)j * ld + kv + i] * bj;
+    CFZP_SYNC();
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    b[j] /= ab[(size_t)j * ld + kv];
+    const double bj = b[j];
+    const int lo = j - kv > 0 ? j - kv : 0;
+    CFZP_SYNC();
+    if (bj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) b[i] -= ab[(size_t)j * ld + kv + i - j] * bj;
+    CFZP_SYNC();
+  }
+}
+
+CFZP_FN double barrier_obj(const CSpec &sp, const CWork &w, const double *X, double mu) {
+  const CDims d = cdims(sp);
+  double s = 0.0, bad = 0.0;
+  CFZP_LANE_FOR(i, 0, d.n - 1) {
+    if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) bad = 1.0; else s += log(dl); }
+    if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) bad = 1.0; else s += log(du); }
+  }
+  if (cfzp::wmax(bad) > 0.0) return INFINITY;
+  return objective(sp, X) - mu * cfzp::wsum(s);
+}
+
+// refresh the working set at the poses of X; a block whose (face, vertices) change restarts its two rows
+CFZP_FN void refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
+  const CDims d = cdims(sp);
+  CFZP_LANE_FOR(q, 0, d.np - 1) {
+    const double *p = X + 7 * q;
+    double sn, cs;
+    sincos(p[2], &sn, &cs);
+    for (int j = 0; j < sp.n_obs; ++j) {
+      double A[4][2], b[4], V[4][2], sep[2];
+      obstacle(sp, j, A, b, V);
+      const int old = first ? 0 : w.sel[q * sp.n_obs + j];
+      const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
+      if (nw != old) {
+        w.sel[q * sp.n_obs + j] = (unsigned char)nw;
+        cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
+        for (int r = 0; r < 2; ++r) {
+          const int sk = d.sO + q * d.nr + 2 * j + r;
+          if (first) X[sk] = sep[r] - sp.dmin;  // pushed inside the bound afterwards
+          else { const double sg = fmax(sep[r] - sp.dmin, sp.bound_push); X[sk] = sg; w.zl[sk] = mu / sg; w.nu[d.rR + q * d.nr + 2 * j + r] = -mu / sg; }
+        }
+      }
+    }
+  }
+  CFZP_SYNC();
+}
+
+// X: guess for the 7 N 6 point variables followed by dt; solution out (same layout).  out_i = iterations, status;
+// out_d = cost, err, mu.  kb: half-bandwidth the caller sized the slab for.
+CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d) {
+  const CDims d = cdims(sp);
+  const CWork w = carve(sp, kb, slab);
+  const Band Bd = {w.ab, kb, 3 * kb + 1};
+  const int n = d.n, m = d.m;
+  build_order(sp, w.posx, w.posc);
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(q, 0, d.np - 1) {
+    const int col[6] = {0, 1, 3, 4, 5, 6};
+    for (int c = 0; c < 6; ++c) { w.xl[7 * q + col[c]] = sp.bounds[2 * c]; w.xu[7 * q + col[c]] = sp.bounds[2 * c + 1]; }
+  }
+  CFZP_SYNC();
+  refresh_working_set(sp, w, w.x, sp.mu_init, true);
+  constraints(sp, w.sel, w.x, w.c);
+  CFZP_LANE_FOR(i, 0, 8 * sp.n_chk - 1) w.x[d.sT + i] = -w.c[d.rT + i];
+  CFZP_SYNC();
+  double nbd = 0.0;
+  CFZP_LANE_FOR(i, 0, n - 1) {
+    const bool hl = w.xl[i] > -1e300, hu = w.xu[i] < 1e300;
+    double pl = hl ? sp.bound_push * fmax(1.0, fabs(w.xl[i])) : 0.0, pu = hu ? sp.bound_push * fmax(1.0, fabs(w.xu[i])) : 0.0;
+    if (hl && hu) { pl = fmin(pl, sp.bound_frac * (w.xu[i] - w.xl[i])); pu = fmin(pu, sp.bound_frac * (w.xu[i] - w.xl[i])); }
+    if (hl) w.x[i] = fmax(w.x[i], w.xl[i] + pl);
+    if (hu) w.x[i] = fmin(w.x[i], w.xu[i] - pu);
+    w.zl[i] = hl ? 1.0 : 0.0; w.zu[i] = hu ? 1.0 : 0.0; nbd += hl + hu;
+  }
+  const int nb = (int)cfzp::wsum(nbd);
+  CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] = 0.0;
+  CFZP_SYNC();
+  double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
+  const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
+  double filt[64][2]; int nfilt = 0;
+  int status = 1, iter = 0;
+  for (iter = 0; iter <= sp.max_iter; ++iter) {
+    if (iter > 0) refresh_working_set(sp, w, w.x, mu, false);
+    constraints(sp, w.sel, w.x, w.c);
+    gradient(sp, w.x, w.g);
+    jt_nu(sp, w.sel, w.x, w.nu, w.r1);
+    double theta = 0.0, cviol = 0.0, sum_nu = 0.0, sum_z = 0.0, dual_inf = 0.0;
+    CFZP_LANE_FOR(i, 0, m - 1) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
+    theta = cfzp::wsum(theta); cviol = cfzp::wmax(cviol); sum_nu = cfzp::wsum(sum_nu);
+    if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+    CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
+    sum_z = cfzp::wsum(sum_z); dual_inf = cfzp::wmax(dual_inf);
+    const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
+    double cmp0 = 0.0;
+    CFZP_LANE_FOR(i, 0, n - 1) {
+      if (w.xl[i] > -1e300) cmp0 = fmax(cmp0, fabs((w.x[i] - w.xl[i]) * w.zl[i]));
+      if (w.xu[i] < 1e300) cmp0 = fmax(cmp0, fabs((w.xu[i] - w.x[i]) * w.zu[i]));
+    }
+    cmp0 = cfzp::wmax(cmp0);
+    err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
+    if (!isfinite(err0)) { status = 3; break; }
+    if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
+    if (iter == sp.max_iter) break;
+    while (mu > mu_floor) {
+      double cm = 0.0;
+      CFZP_LANE_FOR(i, 0, n - 1) {
+        if (w.xl[i] > -1e300) cm = fmax(cm, fabs((w.x[i] - w.xl[i]) * w.zl[i] - mu));
+        if (w.xu[i] < 1e300) cm = fmax(cm, fabs((w.xu[i] - w.x[i]) * w.zu[i] - mu));
+      }
+      cm = cfzp::wmax(cm);
+      if (fmax(dual_inf / s_d, fmax(cviol, cm / s_c)) <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
+      else break;
+    }
+    const double tau = fmax(sp.tau_min, 1.0 - mu);
+    CFZP_LANE_FOR(i, 0, n - 1) {
+      double gphi = w.g[i], s = 0.0;
+      if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; gphi -= mu / dl; s += w.zl[i] / dl; }
+      if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; gphi += mu / du; s += w.zu[i] / du; }
+      w.g[i] = gphi; w.r1[i] = gphi + w.r1[i]; w.sig[i] = s;
+    }
+    CFZP_SYNC();
+    double delta = 0.0; bool have = false;
+    for (int tries = 0; tries < 60; ++tries) {
+      const double hdd = assemble(sp, w, Bd, delta);
+      CFZP_LANE_FOR(i, 0, n - 1) if (i != d.iDt) w.rhs[w.posx[i]] = -w.r1[i];
+      CFZP_LANE_FOR(i, 0, m - 1) w.rhs[w.posc[i]] = -w.c[i];
+      CFZP_LANE_FOR(i, 0, d.nk - 1) w.rhs2[i] = w.bord[i];
+      CFZP_SYNC();
+      const int fail = band_factor(Bd, d.nk, w.ipiv);
+      if (!fail) {
+        band_substitute(Bd, d.nk, w.ipiv, w.rhs);
+        band_substitute(Bd, d.nk, w.ipiv, w.rhs2);
+        // bordered system: [K b; b' h] [y; s] = [r; r_dt]  ->  s = (r_dt - b'K^-1 r) / (h - b'K^-1 b)
+        double bty = 0.0, btw = 0.0;
+        CFZP_LANE_FOR(i, 0, d.nk - 1) { bty += w.bord[i] * w.rhs[i]; btw += w.bord[i] * w.rhs2[i]; }
+        bty = cfzp::wsum(bty); btw = cfzp::wsum(btw);
+        const double ddt = (-w.r1[d.iDt] - bty) / (hdd - btw);
+        double curv = 0.0, dd = 0.0, bad = isfinite(ddt) ? 0.0 : 1.0;
+        CFZP_LANE_FOR(i, 0, n - 1) {
+          const double v = i == d.iDt ? ddt : w.rhs[w.posx[i]] - w.rhs2[w.posx[i]] * ddt;
+          if (!isfinite(v)) bad = 1.0;
+          w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v;
+        }
+        CFZP_LANE_FOR(i, 0, m - 1) {
+          const double v = w.rhs[w.posc[i]] - w.rhs2[w.posc[i]] * ddt;
+          if (!isfinite(v)) bad = 1.0;
+          w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v;
+        }
+        curv = cfzp::wsum(curv); dd = cfzp::wsum(dd); bad = cfzp::wmax(bad);
+        CFZP_SYNC();
+        if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
+      }
+      delta = delta == 0.0 ? 1e-4 : delta * 8.0;
+      if (delta > 1e20) break;
+    }
+    if (!have) { status = 3; break; }
+    double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
+    CFZP_LANE_FOR(i, 0, n - 1) {
+      const double dxi = w.dx[i];
+      dphi += w.g[i] * dxi;
+      w.dzl[i] = 0.0; w.dzu[i] = 0.0;
+      if (w.xl[i] > -1e300) {
+        const double dl = w.x[i] - w.xl[i];
+        w.dzl[i] = mu / dl - w.zl[i] - w.zl[i] / dl * dxi;
+        if (dxi < 0.0) a_pri = fmin(a_pri, -tau * dl / dxi);
+        if (w.dzl[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zl[i] / w.dzl[i]);
+      }
+      if (w.xu[i] < 1e300) {
+        const double du = w.xu[i] - w.x[i];
+        w.dzu[i] = mu / du - w.zu[i] + w.zu[i] / du * dxi;
+        if (dxi > 0.0) a_pri = fmin(a_pri, tau * du / dxi);
+        if (w.dzu[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zu[i] / w.dzu[i]);
+      }
+    }
+    a_pri = cfzp::wmin(a_pri); a_dual = cfzp::wmin(a_dual); dphi = cfzp::wsum(dphi);
+    CFZP_SYNC();
+    const double phi0 = barrier_obj(sp, w, w.x, mu);
+    if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
+    double alpha = a_pri; bool accepted = false, f_type = false;
+    for (int bt = 0; bt < sp.max_backtrack; ++bt) {
+      CFZP_LANE_FOR(i, 0, n - 1) w.xt[i] = w.x[i] + alpha * w.dx[i];
+      CFZP_SYNC();
+      constraints(sp, w.sel, w.xt, w.ct);
+      double th_t = 0.0;
+      CFZP_LANE_FOR(i, 0, m - 1) th_t += fabs(w.ct[i]);
+      th_t = cfzp::wsum(th_t);
+      const double ph_t = barrier_obj(sp, w, w.xt, mu);
+      bool ok = isfinite(ph_t) && isfinite(th_t) && th_t <= theta_max && w.xt[d.iDt] > 0.0;
+      if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = false; break; }
+      f_type = false;
+      if (ok) {
+        const bool sw = theta <= theta_min && dphi < 0.0 && alpha * pow(-dphi, sp.s_phi) > sp.delta_sw * pow(theta, sp.s_theta);
+        if (sw) { f_type = true; ok = ph_t <= phi0 + sp.eta_phi * alpha * dphi; }
+        else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
+      }
+      if (ok) { accepted = true; break; }
+      alpha *= 0.5;
+    }
+    if (!accepted) { status = 2; break; }
+    if (!f_type) {
+      if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
+      filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;
+    }
+    CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += alpha * w.dnu[i];
+    CFZP_LANE_FOR(i, 0, n - 1) {
+      w.x[i] = w.xt[i];
+      if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; w.zl[i] = fmin(fmax(w.zl[i] + a_dual * w.dzl[i], mu / (sp.kappa_sigma * dl)), sp.kappa_sigma * mu / dl); }
+      if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; w.zu[i] = fmin(fmax(w.zu[i] + a_dual * w.dzu[i], mu / (sp.kappa_sigma * du)), sp.kappa_sigma * mu / du); }
+    }
+    CFZP_SYNC();
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(i, 0, d.iDt) X[i] = w.x[i];
+  out_i[0] = iter; out_i[1] = status;
+  out_d[0] = objective(sp, w.x); out_d[1] = err0; out_d[2] = mu;
+}
+
+}  // namespace cfzc

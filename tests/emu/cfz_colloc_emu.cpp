@@ -1,0 +1,68 @@
+// Test-only CPU build of the collocation planning solver source (conflict_rez_amd/csrc/cfz_colloc.inl), see cfz_emu.cpp.
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../conflict_rez_amd/csrc/cfz_colloc.inl"
+
+extern "C" {
+int cfzc_emu_sizeof_spec(void) { return (int)sizeof(cfzc::CSpec); }
+void cfzc_emu_dims(const cfzc::CSpec *sp, int *out) {
+  const cfzc::CDims d = cfzc::cdims(*sp);
+  const int v[] = {d.np, d.nr, d.n, d.m, d.nk, d.iDt, d.sO, d.sT, d.rO, d.rC, d.rR, d.rT, d.rF, d.rH};
+  memcpy(out, v, sizeof(v));
+}
+// working set at X's poses (sel: np * n_obs bytes, in: previous codes or zeros with first = 1)
+void cfzc_emu_select(const cfzc::CSpec *sp, const double *X, unsigned char *sel) {
+  for (int q = 0; q < sp->N * cfzc::kPts; ++q) {
+    const double *p = X + 7 * q;
+    for (int j = 0; j < sp->n_obs; ++j) {
+      double A[4][2], b[4], V[4][2];
+      cfzc::obstacle(*sp, j, A, b, V);
+      sel[q * sp->n_obs + j] = (unsigned char)cfz::select_rows(A, b, V, p[0], p[1], cos(p[2]), sin(p[2]), sp->g, sel[q * sp->n_obs + j]);
+    }
+  }
+}
+void cfzc_emu_eval(const cfzc::CSpec *sp, const unsigned char *sel, const double *X, const double *nu, double *f, double *c,
+                   double *g, double *jtnu) {
+  *f = cfzc::objective(*sp, X);
+  cfzc::constraints(*sp, sel, X, c);
+  cfzc::gradient(*sp, X, g);
+  cfzc::jt_nu(*sp, sel, X, nu, jtnu);
+}
+// dense (n+m)^2 matrix [[W + diag(sig) + delta I, J'], [J, -reg_dual I]] in the natural ordering, from the band and the
+// border; returns the half-bandwidth the ordering needs
+int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *X, const double *nu, const double *sig,
+                 double delta, double *K) {
+  const cfzc::CDims d = cfzc::cdims(*sp);
+  const int kb = 400 < d.nk - 1 ? 400 : d.nk - 1;
+  double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
+  cfzc::CWork w = cfzc::carve(*sp, kb, slab);
+  cfzc::build_order(*sp, w.posx, w.posc);
+  memcpy(w.x, X, sizeof(double) * d.n); memcpy(w.nu, nu, sizeof(double) * d.m); memcpy(w.sig, sig, sizeof(double) * d.n);
+  memcpy(w.sel, sel, d.np * sp->n_obs);
+  const cfzc::Band Bd = {w.ab, kb, 3 * kb + 1};
+  const double hdd = cfzc::assemble(*sp, w, Bd, delta);
+  const int nt = d.n + d.m;
+  int *nat = (int *)malloc(sizeof(int) * d.nk);  // band position -> natural index
+  for (int i = 0; i < d.n; ++i) if (i != d.iDt) nat[w.posx[i]] = i;
+  for (int i = 0; i < d.m; ++i) nat[w.posc[i]] = d.n + i;
+  int bw = 0;
+  memset(K, 0, sizeof(double) * nt * nt);
+  for (int a = 0; a < d.nk; ++a)
+    for (int b = (a - kb > 0 ? a - kb : 0); b <= (a + kb < d.nk - 1 ? a + kb : d.nk - 1); ++b) {
+      const double v = cfzc::bnd(Bd, a, b);
+      if (v != 0.0) { K[(size_t)nat[a] * nt + nat[b]] = v; const int df = a > b ? a - b : b - a; if (df > bw) bw = df; }
+    }
+  for (int a = 0; a < d.nk; ++a) { K[(size_t)nat[a] * nt + d.iDt] = w.bord[a]; K[(size_t)d.iDt * nt + nat[a]] = w.bord[a]; }
+  K[(size_t)d.iDt * nt + d.iDt] = hdd + sig[d.iDt];
+  free(nat); free(slab);
+  return bw;
+}
+int cfzc_emu_solve(const cfzc::CSpec *sp, int kb, double *X, int *out_i, double *out_d) {
+  double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
+  if (!slab) return -1;
+  cfzc::solve_colloc(*sp, X, slab, kb, out_i, out_d);
+  free(slab);
+  return 0;
+}
+}

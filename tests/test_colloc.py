@@ -1,0 +1,112 @@
+"""The single-vehicle collocation plan (reference vehicle.py:360-661): the solver source on the CPU against the numpy
+statement (values), finite differences (derivatives) and the reference's own rows (solutions); the HIP build through the
+C ABI and the Python surface on the GPU."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+from scipy.interpolate import interp1d
+
+from conflict_rez_amd import scenarios, strategy as strat
+from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+from conflict_rez_amd.vehicle_types import VehicleBody
+from oracle import ipm
+from oracle.colloc_nlp import CollocNlp, radau_tables, reference_residuals
+from oracle.plan_nlp import StateWsNlp, speed_guess
+
+COLLOC_OPT = dict(max_iter=400, reg_dual=1e-9, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
+
+
+@pytest.fixture(scope="module")
+def plans():
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    return {a: ([dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]], paths[a]) for a in sorted(hist)}
+
+
+def warm_start(tube, p, fh):
+    """state_ws through the planning solver source, as `plan_single_path` does before the collocation solve."""
+    import plan_emu_binding as pe
+
+    ws = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
+    r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0))
+    assert r["status"] == 0
+    return ws.unpack(r["X"])
+
+
+def colloc_guess(nlp, z):
+    """interp_ws_for_collocation (vehicle.py:298-358) + dt0 = t_end / N (:388)."""
+    t_i = np.concatenate([i + nlp.tau for i in range(nlp.N)]) / nlp.N * z["t"][-1]
+    return nlp.pack({k: interp1d(z["t"], z[k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")}, z["t"][-1] / nlp.N)
+
+
+def test_collocation_tables():
+    from conflict_rez_amd.control.vehicle import Vehicle, radau_points
+
+    tau, A, B, D = radau_tables(5)
+    assert np.allclose(tau[1:], radau_points(5), atol=1e-14)
+    A2, B2, D2 = Vehicle.collocation_coefficients(None, 5)
+    assert np.allclose(A, A2) and np.allclose(B, B2) and np.allclose(D, D2)
+
+
+def test_colloc_source_values_and_derivatives(plans):
+    """Objective and constraints equal the numpy statement; gradient, J'nu, the assembled Jacobian and the assembled
+    Hessian of the Lagrangian (dt border included) equal central differences; the permuted system is banded."""
+    import colloc_emu_binding as ce
+
+    tube, p = plans["vehicle_0"]
+    sp = scenarios.parking_lot_spec()
+    nlp = CollocNlp(p[0], tube[:3], sp.A_obs, sp.b_obs, N_per_set=2, final_heading=0.3)
+    opt = ipm.IpmOptions(**COLLOC_OPT)
+    d = ce.dims(nlp, opt)
+    assert (d["n"], d["m"], d["iDt"], d["sO"], d["sT"], d["rR"], d["rH"]) == (nlp.n, nlp.m, nlp.iDt, nlp.sO, nlp.sT, nlp.rR, nlp.rH)
+    rng = np.random.default_rng(0)
+    X = np.zeros(nlp.n)
+    P = X[: nlp.iDt].reshape(nlp.np, 7)
+    P[:, :3] = p[np.linspace(0, 60, nlp.np).astype(int)] + 0.05 * rng.standard_normal((nlp.np, 3))
+    P[:, 3:] = 0.3 * rng.standard_normal((nlp.np, 4))
+    X[nlp.iDt] = 0.7
+    X[nlp.sO :] = rng.uniform(0.1, 1.0, nlp.n - nlp.sO)
+    nu = rng.standard_normal(nlp.m)
+    sel = ce.select(nlp, opt, X)
+    assert (sel == nlp.select(X)).all() and len(set(sel.ravel() >> 6)) == 2  # both kinds of certificate are exercised
+    f, c, g, jt = ce.evaluate(nlp, opt, sel, X, nu)
+    assert abs(f - nlp.f(X)) < 1e-12 and np.abs(c - nlp.cons(X, sel)).max() < 1e-12
+    h, n = 1e-6, nlp.n
+    gfd, J, H = np.zeros(n), np.zeros((nlp.m, n)), np.zeros((n, n))
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = h
+        fp, cp, gp, jp = ce.evaluate(nlp, opt, sel, X + e, nu)
+        fm, cm, gm, jm = ce.evaluate(nlp, opt, sel, X - e, nu)
+        gfd[i], J[:, i], H[:, i] = (fp - fm) / (2 * h), (cp - cm) / (2 * h), (gp + jp - gm - jm) / (2 * h)
+    K, bw = ce.kkt(nlp, opt, sel, X, nu)
+    assert np.abs(g - gfd).max() < 1e-7 and np.abs(jt - J.T @ nu).max() < 1e-6
+    assert np.abs(K[n:, :n] - J).max() < 1e-6 and np.abs(K[:n, :n] - H).max() < 1e-6 and np.abs(K - K.T).max() == 0.0
+    assert bw <= 125
+
+
+@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_3"])
+def test_colloc_source_solves_reference_problem(plans, agent):
+    """Full size (N_per_set = 5, K = 5, six obstacles), from the state_ws warm start: converges at the reference's
+    tolerances, and the plan with the rebuilt OBCA duals satisfies the reference's own rows."""
+    import colloc_emu_binding as ce
+
+    tube, p = plans[agent]
+    fh = float(p[-1, 2])
+    sp = scenarios.parking_lot_spec()
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    X0 = colloc_guess(nlp, warm_start(tube, p, fh))
+    res = ce.solve(nlp, X0, ipm.IpmOptions(**COLLOC_OPT), 125)
+    assert res["status"] == 0 and res["iters"] < 100
+    sol = nlp.unpack(res["X"])
+    rr = reference_residuals(nlp, sol)
+    assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9 and abs(rr["cost"] - res["f"]) < 1e-9 * max(1, res["f"])
+    T_end = sol["dt"] * nlp.N
+    assert 2.0 < T_end < 0.1 * (len(p) - 1) * 1.5 and abs(sol["psi"][-1, -1] - fh) < 1e-2
+    # faster than the warm start's fixed timetable would allow at these input costs, and it actually moved
+    assert np.hypot(sol["x"][-1, -1] - p[0, 0], sol["y"][-1, -1] - p[0, 1]) > 1.0
