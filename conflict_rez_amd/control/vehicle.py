@@ -117,11 +117,56 @@ class Vehicle:
         zu0.l, zu0.m = l.T.copy(), m.T.copy()
         return zu0
 
-    def setup_single_final_problem(self, *args, **kwargs):
-        raise NotImplementedError("collocation NLP (vehicle.py:360-640) has no HIP kernel yet; see DESIGN.md 'Next'")
+    def setup_single_final_problem(self, zu0: VehiclePrediction, init_offset: VehicleState = None, final_heading: float = None,
+                                   opti=None, dt=None, K: int = 5, N_per_set: int = 5, dmin: float = 0.05,
+                                   shrink_tube: float = 0.8):
+        """setup the final problem of a single vehicle (vehicle.py:360-640): N = N_per_set (S-1) intervals of free length
+        dt with K = 5 Radau points, ODE at every point, continuity, tube rows at every N_per_set-th interval and at the
+        end, terminal v = delta = a = w = 0 (+ heading), boxes, at least `dmin` from every static obstacle at every point,
+        cost sum B_k (a^2 + v^2 w^2 + delta^2) dt + (N dt)^2.  `zu0`: guess at the collocation points
+        (`interp_ws_for_collocation`); its l, m are not used: the OBCA duals are eliminated in the kernel
+        (csrc/cfz_colloc.inl) and rebuilt from the poses by `get_solution`.  Returns the problem description that
+        `solve_single_final_problem` hands to `cfz_colloc` (the reference returns its `ca.Opti`)."""
+        if opti is not None or dt is not None:
+            raise NotImplementedError("a shared Opti / shared dt belongs to the joint multi-vehicle problem "
+                                      "(multi_vehicle_planner.py:63-206), which has no HIP kernel; see DESIGN.md 'Next'")
+        if K != 5:
+            raise NotImplementedError("cfz_colloc is built for K = 5 (CFZ_COLLOC_K), the reference's only caller value")
+        from ..engine import ProblemSpec
+
+        off = init_offset if init_offset is not None else VehicleState()
+        s0 = self.init_state
+        N = N_per_set * (self.num_sets - 1)
+        self.N, self.K = N, K
+        guess = np.stack([np.asarray(getattr(zu0, n), float).reshape(N * (K + 1)) for n in
+                          ("x", "y", "psi", "v", "u_steer", "u_a", "u_steer_dot")], 1)
+        self.final_problem = dict(
+            spec=ProblemSpec.from_objects(self.obstacles, self.vehicle_body, self.vehicle_config, self.region, n_nbr=0, N=2, dmin=dmin),
+            init_pose=[s0.x.x + off.x.x, s0.x.y + off.x.y, s0.e.psi + off.e.psi], final_heading=final_heading,
+            tube=[((st["back"].A, st["back"].b), (st["front"].A, st["front"].b)) for st in self.rl_tube[1:]],
+            guess=guess, dt0=float(zu0.t[-1]) / N, N_per_set=N_per_set, shrink_tube=shrink_tube)
+        return self.final_problem
 
     def solve_single_final_problem(self, verbose: int = 0):
-        raise NotImplementedError("collocation NLP (vehicle.py:642-661) has no HIP kernel yet; see DESIGN.md 'Next'")
+        """solve the trajectory of single vehicle problem (vehicle.py:642-661) on the GPU (`cfz_colloc`, tol =
+        constr_viol_tol = 1e-2 as :650-651).  Returns the mapping `get_solution` reads (x, y, psi, v, delta, a, w of shape
+        (N, K+1), dt); raises RuntimeError when the solver does not converge, as `opti.solve()` does."""
+        from ..engine import colloc as cfz_colloc
+
+        print("Solving single vehicle final trajectory...")
+        fp = self.final_problem
+        res = cfz_colloc(fp["spec"], [fp["init_pose"]], [fp["tube"]], [fp["guess"]], [fp["dt0"]], [fp["final_heading"]],
+                         N_per_set=fp["N_per_set"], shrink_tube=fp["shrink_tube"])[0]
+        self.final_problem_stats = dict(status=res["status"], iters=res["iters"], cost=res["cost"])
+        if verbose:
+            print(self.final_problem_stats)
+        if res["status"] != 0:
+            raise RuntimeError(f"single final problem did not converge (status {res['status']} after {res['iters']} iterations)")
+        print("Solve_Succeeded")
+        tr = res["traj"]
+        sol = {k: tr[:, :, c].copy() for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}
+        sol["dt"] = res["dt"]
+        return sol
 
     def get_solution(self, sol) -> VehiclePrediction:
         """get solution of this vehicle (vehicle.py:663-720): the collocation arrays (N, K+1) flattened row-major,

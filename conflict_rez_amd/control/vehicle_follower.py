@@ -71,10 +71,11 @@ class VehicleFollower(Vehicle):
     # ---- reference path ---------------------------------------------------------------------
     def plan_single_path(self, N_ws=30, dt_ws=0.1, K=5, N_per_set=5, shrink_tube=0.5, dmin=0.05, spline_ws=True,
                          interp_dt=0.01):
-        """plan a single vehicle reference path (:91-138): state_ws -> dual_ws -> collocation.  The collocation
-        refinement (`setup_single_final_problem`, vehicle.py:360-661) has no kernel yet: the reference trajectory is
-        the `state_ws` solution (feasible for the tube and the bicycle model at dt_ws, minimum sum a^2 + w^2, not
-        time-optimal); `self.plan_refined` says so.  A final heading the warm start cannot meet is retried without it."""
+        """plan a single vehicle reference path (:91-138): state_ws -> dual_ws -> resampling onto the collocation grid ->
+        collocation plan -> `reference_traj` sampled every `interp_dt` from the collocation interpolant.
+        `self.plan_refined` is True when the reference is the collocation plan.  Two fallbacks the reference does not
+        have (it would raise): a final heading the warm start cannot meet is retried without it, and if the collocation
+        solve fails the warm start itself becomes the reference (`plan_refined` False)."""
         try:
             zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=self.final_heading,
                                 shrink_tube=shrink_tube, spline_ws=spline_ws)
@@ -84,8 +85,21 @@ class VehicleFollower(Vehicle):
             zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=None,
                                 shrink_tube=shrink_tube, spline_ws=spline_ws)
         zu0 = self.dual_ws(zu0=zu0)
-        self.plan_refined = False
-        self.set_reference(zu0, interp_dt=interp_dt)
+        zuc = self.interp_ws_for_collocation(zu0=zu0, K=K, N_per_set=N_per_set)
+        self.setup_single_final_problem(zu0=zuc, init_offset=self.init_offset, final_heading=self.final_heading, K=K,
+                                        N_per_set=N_per_set, shrink_tube=shrink_tube, dmin=dmin)
+        try:
+            sol = self.solve_single_final_problem()
+        except RuntimeError as e:
+            self.print(f"{self.agent}: {e}; following the warm start")
+            self.plan_refined = False
+            self.set_reference(zu0, interp_dt=interp_dt)
+            return
+        result = self.get_solution(sol=sol)
+        self.plan_refined = True
+        interp_time = np.linspace(start=result.t[0], stop=result.t[-1], num=int((result.t[-1] - result.t[0]) / interp_dt), endpoint=True)
+        self.reference_traj = self.interpolate_states(interp_time)
+        self.reference_xy = np.vstack([self.reference_traj.x, self.reference_traj.y]).T
 
     def set_reference(self, traj: VehiclePrediction, interp_dt: float = 0.01):
         """Installs a planned trajectory: builds the interpolators and `reference_traj` sampled every

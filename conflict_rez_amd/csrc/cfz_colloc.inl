@@ -56,6 +56,8 @@ CFZP_FN CDims cdims(const CSpec &sp) {
   d.nk = d.n - 1 + d.m;  // dt is bordered, not in the band
   return d;
 }
+// half-bandwidth of the ordering of build_order: the 30 ODE rows of an interval sit between its third and fourth point
+CFZP_FN int half_bandwidth(const CSpec &sp) { return 30 + 3 * (7 + 4 * sp.n_obs); }
 // point of tube checkpoint q: start of interval (q+1) Nps, or the very last point
 CFZP_FN int chk_point(const CSpec &sp, int q) { return q + 1 < sp.n_chk ? (q + 1) * sp.Nps * kPts : sp.N * kPts - 1; }
 
@@ -344,8 +346,14 @@ CFZP_FN int band_factor(const Band &B, int n, int *ipiv) {
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
     double *cj = ab + (size_t)j * ld;
-    int jp = 0; double best = fabs(cj[kv]);
-    for (int i = 1; i <= km; ++i) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
+    int jp = 0; double best = -1.0;  // first largest entry of the column, searched by all lanes together
+    CFZP_LANE_FOR(i, 0, km) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
+      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
+    }
+#endif
     ipiv[j] = j + jp;
     if (!(best > 0.0)) return 1;
     const int reach = j + ku + jp; ju = ju > (reach < n - 1 ? reach : n - 1) ? ju : (reach < n - 1 ? reach : n - 1);
@@ -366,23 +374,25 @@ CFZP_FN int band_factor(const Band &B, int n, int *ipiv) {
   }
   return 0;
 }
-CFZP_FN void band_substitute(const Band &B, int n, const int *ipiv, double *b) {
+// two right-hand sides at once (the KKT residual and the dt border)
+CFZP_FN void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld;
   const double *ab = B.ab;
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
-    if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
-    const double bj = b[j];
+    if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; const double t2 = b2[j]; b2[j] = b2[p]; b2[p] = t2; }
+    const double bj = b[j], cj = b2[j];
     CFZP_SYNC();
-    if (bj != 0.0) CFZP_LANE_FOR(i, 1, km) b[j + i] -= ab[(size_t)j * ld + kv + i] * bj;
+    if (bj != 0.0 || cj != 0.0) CFZP_LANE_FOR(i, 1, km) { const double l = ab[(size_t)j * ld + kv + i]; b[j + i] -= l * bj; b2[j + i] -= l * cj; }
     CFZP_SYNC();
   }
   for (int j = n - 1; j >= 0; --j) {
-    b[j] /= ab[(size_t)j * ld + kv];
-    const double bj = b[j];
+    const double dg = ab[(size_t)j * ld + kv];
+    b[j] /= dg; b2[j] /= dg;
+    const double bj = b[j], cj = b2[j];
     const int lo = j - kv > 0 ? j - kv : 0;
     CFZP_SYNC();
-    if (bj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) b[i] -= ab[(size_t)j * ld + kv + i - j] * bj;
+    if (bj != 0.0 || cj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) { const double u = ab[(size_t)j * ld + kv + i - j]; b[i] -= u * bj; b2[i] -= u * cj; }
     CFZP_SYNC();
   }
 }
@@ -411,6 +421,9 @@ CFZP_FN void refresh_working_set(const CSpec &sp, const CWork &w, double *X, dou
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
       const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
       if (nw != old) {
+#if defined(CFZC_TRACE)
+        if (!first) printf("   ws change pt %d obs %d: %d/%d/%d%d -> %d/%d/%d%d  slack %.3e %.3e z %.3e %.3e\n", q, j, old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sO + q * d.nr + 2 * j], X[d.sO + q * d.nr + 2 * j + 1], w.zl[d.sO + q * d.nr + 2 * j], w.zl[d.sO + q * d.nr + 2 * j + 1]);
+#endif
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
         cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
         for (int r = 0; r < 2; ++r) {
@@ -471,6 +484,11 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
     sum_z = cfzp::wsum(sum_z); dual_inf = cfzp::wmax(dual_inf);
+#if defined(CFZC_TRACE)
+    { int am = 0; double av = -1; for (int i = 0; i < n; ++i) { const double v = fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i]); if (v > av) { av = v; am = i; } }
+      if (iter == 100 || iter == 101) { for (int q = 0; q < 8; ++q) { printf("   pt %d: p %.5f %.5f %.6f %.2e %.2e %.2e %.2e |", q, w.x[7*q], w.x[7*q+1], w.x[7*q+2], w.x[7*q+3], w.x[7*q+4], w.x[7*q+5], w.x[7*q+6]); for (int r = 0; r < d.nr; ++r) printf(" [%d s %.2e z %.2e nu %.2e]", w.sel[q * sp.n_obs + r / 2], w.x[d.sO + q * d.nr + r], w.zl[d.sO + q * d.nr + r], w.nu[d.rR + q * d.nr + r]); printf("\n      lam:"); for (int c = 0; c < 5; ++c) printf(" %.3e", w.nu[d.rO + 5 * q + c]); printf(" gradL:"); for (int c = 0; c < 7; ++c) printf(" %.2e", w.g[7*q+c] + w.r1[7*q+c] - w.zl[7*q+c] + w.zu[7*q+c]); printf("\n"); } }
+      printf("   dual_inf argmax var %d (%s q=%d c=%d) val %.3e x %.5f zl %.3e zu %.3e s_d %.3f\n", am, am < d.iDt ? "pt" : am == d.iDt ? "dt" : am < d.sT ? "slackO" : "slackT", am < d.iDt ? am / 7 : (am - d.sO) / d.nr, am < d.iDt ? am % 7 : (am - d.sO) % d.nr, av, w.x[am], w.zl[am], w.zu[am], fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max); }
+#endif
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
     double cmp0 = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
@@ -509,8 +527,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       CFZP_SYNC();
       const int fail = band_factor(Bd, d.nk, w.ipiv);
       if (!fail) {
-        band_substitute(Bd, d.nk, w.ipiv, w.rhs);
-        band_substitute(Bd, d.nk, w.ipiv, w.rhs2);
+        band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         // bordered system: [K b; b' h] [y; s] = [r; r_dt]  ->  s = (r_dt - b'K^-1 r) / (h - b'K^-1 b)
         double bty = 0.0, btw = 0.0;
         CFZP_LANE_FOR(i, 0, d.nk - 1) { bty += w.bord[i] * w.rhs[i]; btw += w.bord[i] * w.rhs2[i]; }
@@ -578,6 +595,9 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       alpha *= 0.5;
     }
     if (!accepted) { status = 2; break; }
+#if defined(CFZC_TRACE)
+    printf("it %3d mu %.2e err %.3e theta %.3e cviol %.2e dinf %.2e cmp %.2e delta %.1e alpha %.3e a_pri %.3e a_dual %.3e ftype %d dt %.5f f %.5f\n", iter, mu, err0, theta, cviol, dual_inf, cmp0, delta, alpha, a_pri, a_dual, (int)f_type, w.x[d.iDt], objective(sp, w.x));
+#endif
     if (!f_type) {
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;

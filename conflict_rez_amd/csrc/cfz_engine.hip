@@ -26,6 +26,7 @@
 #include "../../include/confrez_hip.h"
 #include "cfz_solver.inl"
 #include "cfz_plan.inl"
+#include "cfz_colloc.inl"
 
 namespace {
 
@@ -275,6 +276,15 @@ __global__ void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *t
   cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
 }
 
+// single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
+// cfz_colloc.inl.
+__global__ void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
+                              const long long *slab_off, int kb, int32_t *oi, double *od) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  cfzc::solve_colloc(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + 3 * b);
+}
+
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
 // pair and the separation it certifies -- closed form over the face normals of both polygons (the
 // reference maximises the same separation with IPOPT over lambda, mu).  One thread per pair.
@@ -407,7 +417,7 @@ struct cfz_handle {
 
 namespace {
 
-// vertices of {A p <= b} for a bounded quadrilateral, faces paired in index order
+// vertices of {A p <= b} for a bounded quadrilateral
 bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
   int n = 0;
   for (int i = 0; i < 4; ++i)
@@ -419,7 +429,18 @@ bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
       for (int q = 0; q < 4; ++q) in = in && (A[q][0] * px + A[q][1] * py <= b[q] + 1e-9);
       if (in) { if (n == 4) return false; V[n][0] = px; V[n][1] = py; ++n; }
     }
-  return n == 4;
+  if (n != 4) return false;
+  // counter-clockwise around the polygon, starting from the first vertex found: v-1 and v+1 (mod 4) are then the
+  // neighbours of v, which cfz::select_rows relies on
+  const double cx = 0.25 * (V[0][0] + V[1][0] + V[2][0] + V[3][0]), cy = 0.25 * (V[0][1] + V[1][1] + V[2][1] + V[3][1]);
+  const double two_pi = 6.283185307179586, a0 = std::atan2(V[0][1] - cy, V[0][0] - cx);
+  double key[4], W[4][2];
+  int ord[4] = {0, 1, 2, 3};
+  for (int i = 0; i < 4; ++i) { double a = std::atan2(V[i][1] - cy, V[i][0] - cx) - a0; while (a < 0.0) a += two_pi; while (a >= two_pi) a -= two_pi; key[i] = a; }
+  for (int i = 1; i < 4; ++i) for (int q = i; q > 0 && key[ord[q]] < key[ord[q - 1]]; --q) { const int t = ord[q]; ord[q] = ord[q - 1]; ord[q - 1] = t; }
+  for (int i = 0; i < 4; ++i) { W[i][0] = V[ord[i]][0]; W[i][1] = V[ord[i]][1]; }
+  memcpy(V, W, sizeof W);
+  return true;
 }
 
 int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr, double *zu,
@@ -755,6 +776,119 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n
     if (cost) cost[b] = od[3 * b];
   }
   return 0;
+}
+
+// Lagrange basis on tau = [0, Radau IIA points of degree 5]: A[j][k] = l_j'(tau_k), B[j] = int_0^1 l_j (vehicle.py:54-97)
+static void radau5_tables(double A[6][6], double B[6]) {
+  const double tau[6] = {0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0};
+  for (int j = 0; j < 6; ++j) {
+    double c[7] = {1.0, 0, 0, 0, 0, 0, 0};  // coefficients of l_j, ascending powers
+    int deg = 0;
+    for (int m = 0; m < 6; ++m) {
+      if (m == j) continue;
+      const double den = tau[j] - tau[m];
+      for (int q = deg + 1; q >= 0; --q) c[q] = ((q > 0 ? c[q - 1] : 0.0) - tau[m] * (q <= deg ? c[q] : 0.0)) / den;
+      ++deg;
+    }
+    B[j] = 0.0;
+    for (int q = 0; q <= deg; ++q) B[j] += c[q] / (q + 1);
+    for (int k = 0; k < 6; ++k) {
+      double dv = 0.0, pw = 1.0;
+      for (int q = 1; q <= deg; ++q) { dv += q * c[q] * pw; pw *= tau[k]; }
+      A[j][k] = dv;
+    }
+  }
+}
+
+int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
+  if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  HIP_OK(hipSetDevice(device));
+  std::vector<double> tab((size_t)std::max(spec->n_obs, 1) * 20, 0.0);
+  for (int j = 0; j < spec->n_obs; ++j) {
+    double V[4][2];
+    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], V)) return fail("obstacle is not a bounded quadrilateral");
+    double *o = tab.data() + (size_t)j * 20;
+    for (int i = 0; i < 4; ++i) { o[2 * i] = spec->A_obs[j][i][0]; o[2 * i + 1] = spec->A_obs[j][i][1]; o[8 + i] = spec->b_obs[j][i];
+                                  o[12 + 2 * i] = V[i][0]; o[13 + 2 * i] = V[i][1]; }
+  }
+  double *dtab = nullptr, *dtube = nullptr;
+  long long nt = 0;
+  for (int b = 0; b < B; ++b) { if (n_sets[b] < 2) return fail("a plan needs at least two strategy steps"); nt += (long long)(n_sets[b] - 1) * 24; }
+  HIP_OK(hipMalloc(&dtab, tab.size() * 8)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8));
+  HIP_OK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
+  std::vector<cfzc::CSpec> specs(B);
+  std::vector<long long> xoff(B), soff(B);
+  long long nx = 0, ns = 0, to = 0;
+  int kb = 0;
+  for (int b = 0; b < B; ++b) {
+    cfzc::CSpec &p = specs[b];
+    memset(&p, 0, sizeof p);
+    p.Nps = co->N_per_set; p.n_chk = n_sets[b] - 1; p.N = p.Nps * p.n_chk; p.n_obs = spec->n_obs;
+    p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
+    p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
+    p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
+    for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
+    memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
+    radau5_tables(p.A, p.B);
+    p.tol = co->tol; p.constr_viol_tol = co->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = co->mu_init;
+    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
+    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
+    // delta_c = 1e-7: while a vehicle stands still with its heading along an axis, the six ODE rows of x (or y) of an
+    // interval only see the rank-5 derivative matrix and their multipliers drift (288 iterations at 1e-9, 38 at 1e-7)
+    p.reg_primal = 1e-8; p.reg_dual = 1e-7; p.curv_kappa = co->curv_kappa;
+    p.obs_tab = dtab; p.tube = dtube + to;
+    kb = std::max(kb, cfzc::half_bandwidth(p));
+    xoff[b] = nx; nx += 7LL * p.N * cfzc::kPts + 1; to += (long long)p.n_chk * 24;
+  }
+  for (int b = 0; b < B; ++b) { soff[b] = ns; ns += (long long)cfzc::work_doubles(specs[b], kb); }
+  std::vector<double> X((size_t)nx);
+  long long g0 = 0;
+  for (int b = 0; b < B; ++b) {  // guess: x, y, psi, v, delta, a, w at every point (:629-636), dt0 (:388-389)
+    const long long np_ = (long long)specs[b].N * cfzc::kPts;
+    memcpy(X.data() + xoff[b], guess + g0 * 7, (size_t)np_ * 7 * 8);
+    X[(size_t)(xoff[b] + 7 * np_)] = dt0[b];
+    g0 += np_;
+  }
+  cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr;
+  HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
+  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
+  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(64), 0, 0, B, dspec, dX, doff, dslab, doff + B, kb, doi, dod);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
+  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
+  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
+  g0 = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long np_ = (long long)specs[b].N * cfzc::kPts;
+    memcpy(traj + g0 * 7, X.data() + xoff[b], (size_t)np_ * 7 * 8);
+    dt[b] = X[(size_t)(xoff[b] + 7 * np_)];
+    g0 += np_;
+    if (status) status[b] = oi[2 * b + 1];
+    if (iters) iters[b] = oi[2 * b];
+    if (cost) cost[b] = od[3 * b];
+  }
+  return 0;
+}
+
+void cfz_default_colloc_options(cfz_colloc_options *o) {
+  memset(o, 0, sizeof *o);
+  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5;
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 1e-3; o->curv_kappa = 1e-8;
 }
 
 void cfz_default_plan_options(cfz_plan_options *o) {

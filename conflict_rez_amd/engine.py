@@ -120,6 +120,8 @@ def load_library(path=None):
     lib.cfz_joint_dual_ws.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.cfz_default_plan_options.argtypes = [C.POINTER(_CPlanOptions)]
     lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
+    lib.cfz_default_colloc_options.argtypes = [C.POINTER(_CCollocOptions)]
+    lib.cfz_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
     lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -140,7 +142,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -202,6 +204,47 @@ def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, **o
     for b in range(B):
         out.append(dict(traj=traj[o : o + T[b] + 1].copy(), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
         o += T[b] + 1
+    return out
+
+
+class _CCollocOptions(C.Structure):
+    _fields_ = [("N_per_set", C.c_int32), ("max_iter", C.c_int32), ("reserved", C.c_int32 * 2), ("shrink_tube", C.c_double),
+                ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
+
+
+def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0, **options):
+    """`cfz_colloc`: the collocation plans (vehicle.py:360-661) of several vehicles in one launch.
+    spec: ProblemSpec (wb, dmin, body, bounds, static obstacles); init_poses [B][3]; tubes as in `state_ws`;
+    guesses: per vehicle an array [6 N, 7] of x, y, psi, v, delta, a, w at the collocation points; dt0s [B];
+    options: fields of `cfz_colloc_options` (N_per_set, max_iter, shrink_tube, tol, constr_viol_tol, ...).
+    Returns a list of dict(traj [N, 6, 7], dt, status, iters, cost)."""
+    lib = load_library()
+    co = _CCollocOptions()
+    lib.cfz_default_colloc_options(C.byref(co))
+    for k, v in options.items():
+        if not hasattr(co, k):
+            raise TypeError(f"unknown collocation option {k!r}")
+        setattr(co, k, v)
+    B = len(tubes)
+    n_sets = np.array([len(t) + 1 for t in tubes], dtype=np.int32)
+    Np = co.N_per_set * (n_sets - 1) * 6
+    tube = np.ascontiguousarray(np.concatenate([np.concatenate([np.concatenate([np.asarray(A, float).ravel(), np.asarray(b, float).ravel()])
+                                                                for cellpair in t for (A, b) in cellpair]) for t in tubes]))
+    init = _f64(np.asarray(init_poses, float), (B, 3))
+    fh = np.array([np.nan if (final_headings is None or final_headings[b] is None) else float(final_headings[b]) for b in range(B)])
+    guess = np.ascontiguousarray(np.concatenate([_f64(np.asarray(g, float), (int(Np[b]), 7)) for b, g in enumerate(guesses)]))
+    dt0 = _f64(np.asarray(dt0s, float), (B,))
+    traj, dt = np.zeros((int(Np.sum()), 7)), np.zeros(B)
+    status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
+    cs = spec.to_c()
+    rc = lib.cfz_colloc(int(device), B, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
+                        _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
+    if rc != 0:
+        raise RuntimeError("cfz_colloc: " + lib.cfz_last_error().decode())
+    out, o = [], 0
+    for b in range(B):
+        out.append(dict(traj=traj[o : o + Np[b]].reshape(-1, 6, 7).copy(), dt=float(dt[b]), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
+        o += Np[b]
     return out
 
 

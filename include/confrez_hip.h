@@ -174,6 +174,34 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *opt, const int32_t *
                  const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
                  int32_t *iters, double *cost);
 
+/* ---- Vehicle.setup_single_final_problem + solve_single_final_problem (confrez/control/vehicle.py:360-661) -------------
+ * The single-vehicle collocation plan: N = N_per_set (n_sets - 1) intervals of free length dt, K = 5 Radau points each,
+ * 6 N points per instance; B instances in one call (no handle: nothing is kept).
+ *   spec                  wb, dmin (:369), g, bounds (:439-478) and the static obstacles (:523-541); N, dt, n_nbr, weights unused
+ *   init_pose, final_heading, tube   as in cfz_state_ws (:426-436, :619-620, :570-617)
+ *   guess                 x, y, psi, v, delta, a, w at every point, instances back to back (interp_ws_for_collocation's
+ *                         output, :629-636); dt0[B] the initial interval length (:388-389)
+ *   traj (out)            x, y, psi, v, delta, a, w at every point; dt (out) [B]
+ *   status, iters, cost   per instance (may be NULL); the reference raises on status != 0
+ * The OBCA duals l, m (:411-416) are eliminated as in the MPC step and rebuilt from the poses by cfz_dual_ws.  Same
+ * interior point as cfz_state_ws; dt is bordered out of the banded system (csrc/cfz_colloc.inl). */
+#define CFZ_COLLOC_K 5
+typedef struct cfz_colloc_options {
+  int32_t N_per_set;      /* :368 5 */
+  int32_t max_iter;       /* IPOPT default 3000 (:652 leaves it unset) */
+  int32_t reserved[2];
+  double shrink_tube;     /* :370; 0.5 in plan_single_path */
+  double tol;             /* :650 1e-2 */
+  double constr_viol_tol; /* :651 1e-2 */
+  double mu_init;         /* 1e-3 */
+  double curv_kappa;      /* 1e-8 */
+} cfz_colloc_options;
+
+void cfz_default_colloc_options(cfz_colloc_options *opt);
+int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
+               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
+
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
  * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt

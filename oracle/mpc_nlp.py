@@ -153,8 +153,8 @@ def body_vertices(g):
 
 
 def polytope_vertices(A, b):
-    """Vertices of the 4-face polygon {A p <= b}; returns (V[4,2], adj[4,2]) where adj holds
-    the two faces meeting at each vertex.  Faces are paired in index order (i<j)."""
+    """Vertices of the 4-face polygon {A p <= b} in counter-clockwise order; returns (V[4,2], adj[4,2]) where adj holds
+    the two faces meeting at each vertex."""
     V, adj = [], []
     for i in range(4):
         for j in range(i + 1, 4):
@@ -166,7 +166,12 @@ def polytope_vertices(A, b):
                 V.append(p)
                 adj.append((i, j))
     assert len(V) == 4, "obstacle must be a bounded quadrilateral"
-    return np.array(V), np.array(adj)
+    V, adj = np.array(V), np.array(adj)
+    # counter-clockwise around the polygon starting from the first one found, so that vertices v-1, v+1 (mod 4) are the
+    # neighbours of v -- what select_rows assumes
+    ang = np.arctan2(V[:, 1] - V[:, 1].mean(), V[:, 0] - V[:, 0].mean())
+    order = np.argsort((ang - ang[0]) % (2 * np.pi), kind="stable")
+    return V[order], adj[order]
 
 
 HYST = 1e-3  # m: a block keeps its separating face until another one is better by this much

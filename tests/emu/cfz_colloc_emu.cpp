@@ -58,7 +58,9 @@ int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *
   free(nat); free(slab);
   return bw;
 }
-int cfzc_emu_solve(const cfzc::CSpec *sp, int kb, double *X, int *out_i, double *out_d) {
+int cfzc_emu_half_bandwidth(const cfzc::CSpec *sp) { return cfzc::half_bandwidth(*sp); }
+int cfzc_emu_solve(const cfzc::CSpec *sp, double *X, int *out_i, double *out_d) {
+  const int kb = cfzc::half_bandwidth(*sp);
   double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
   if (!slab) return -1;
   cfzc::solve_colloc(*sp, X, slab, kb, out_i, out_d);

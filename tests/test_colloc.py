@@ -15,7 +15,7 @@ from oracle import ipm
 from oracle.colloc_nlp import CollocNlp, radau_tables, reference_residuals
 from oracle.plan_nlp import StateWsNlp, speed_guess
 
-COLLOC_OPT = dict(max_iter=400, reg_dual=1e-9, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
+COLLOC_OPT = dict(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +87,11 @@ def test_colloc_source_values_and_derivatives(plans):
     K, bw = ce.kkt(nlp, opt, sel, X, nu)
     assert np.abs(g - gfd).max() < 1e-7 and np.abs(jt - J.T @ nu).max() < 1e-6
     assert np.abs(K[n:, :n] - J).max() < 1e-6 and np.abs(K[:n, :n] - H).max() < 1e-6 and np.abs(K - K.T).max() == 0.0
-    assert bw <= 125
+    assert bw <= ce.half_bandwidth(nlp, opt) == 123
+    free = CollocNlp(p[0], tube[:3], sp.A_obs[:0], sp.b_obs[:0], N_per_set=2)  # no obstacles, free terminal heading
+    Xf, nuf = np.append(X[: free.iDt + 1], X[nlp.sT :]), rng.standard_normal(free.m)
+    Kf, bwf = ce.kkt(free, opt, np.zeros((free.np, 0), np.uint8), Xf, nuf)
+    assert bwf <= ce.half_bandwidth(free, opt) == 51 and Kf.shape[0] == free.n + free.m
 
 
 @pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_3"])
@@ -101,7 +105,7 @@ def test_colloc_source_solves_reference_problem(plans, agent):
     sp = scenarios.parking_lot_spec()
     nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
     X0 = colloc_guess(nlp, warm_start(tube, p, fh))
-    res = ce.solve(nlp, X0, ipm.IpmOptions(**COLLOC_OPT), 125)
+    res = ce.solve(nlp, X0, ipm.IpmOptions(**COLLOC_OPT))
     assert res["status"] == 0 and res["iters"] < 100
     sol = nlp.unpack(res["X"])
     rr = reference_residuals(nlp, sol)
@@ -110,3 +114,42 @@ def test_colloc_source_solves_reference_problem(plans, agent):
     assert 2.0 < T_end < 0.1 * (len(p) - 1) * 1.5 and abs(sol["psi"][-1, -1] - fh) < 1e-2
     # faster than the warm start's fixed timetable would allow at these input costs, and it actually moved
     assert np.hypot(sol["x"][-1, -1] - p[0, 0], sol["y"][-1, -1] - p[0, 1]) > 1.0
+
+
+@pytest.mark.gpu
+def test_colloc_on_gpu(plans):
+    """cfz_colloc, the four vehicles in one launch from their state_ws warm starts: converged, the reference's own rows
+    hold for every plan (duals rebuilt by cfz_dual_ws through `Vehicle.get_solution`'s path), and the HIP build lands
+    where the CPU build of the same source does."""
+    import colloc_emu_binding as ce
+    from conflict_rez_amd import engine
+
+    agents = sorted(plans)
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    fhs = [float(plans[a][1][-1, 2]) for a in agents]
+    ws = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5)
+    nlps, guesses, dt0s = [], [], []
+    for a, fh, w in zip(agents, fhs, ws):
+        assert w["status"] == 0
+        tube, p = plans[a]
+        nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+        tr = w["traj"]
+        z = dict(t=0.1 * np.arange(len(tr)), **{k: tr[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))})
+        X0 = colloc_guess(nlp, z)
+        nlps.append(nlp), guesses.append(X0[: nlp.iDt].reshape(-1, 7)), dt0s.append(X0[nlp.iDt])
+    res = engine.colloc(sp, [plans[a][1][0] for a in agents], tubes, guesses, dt0s, fhs, max_iter=400)
+    eng = engine.Engine(sp, max_batch=1)
+    for a, nlp, g, d0, r in zip(agents, nlps, guesses, dt0s, res):
+        assert r["status"] == 0, (a, r["status"], r["iters"])
+        sol = {k: r["traj"][:, :, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}
+        sol["dt"] = r["dt"]
+        poses = r["traj"].reshape(-1, 7)[:, :3]
+        l, m, _ = eng.dual_ws(poses)
+        sol["l"], sol["m"] = l.reshape(nlp.N, 6, -1), m.reshape(nlp.N, 6, -1)
+        rr = reference_residuals(nlp, sol)
+        assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9 and abs(rr["cost"] - r["cost"]) < 1e-8 * max(1.0, r["cost"])
+        if a in ("vehicle_1", "vehicle_3"):  # the CPU build from the same guess (seconds there; the others take longer)
+            re_ = ce.solve(nlp, np.append(g.ravel(), d0), ipm.IpmOptions(**COLLOC_OPT))
+            assert re_["status"] == 0 and abs(re_["f"] - r["cost"]) < 2e-2 * re_["f"]
+            assert np.abs(re_["X"][: nlp.iDt].reshape(-1, 7)[:, :2] - poses[:, :2]).max() < 0.1
