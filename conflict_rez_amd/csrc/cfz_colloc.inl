@@ -22,9 +22,26 @@
 #include "cfz_solver.inl"
 #include "cfz_plan.inl"
 
+// The big pieces of the solver are separate functions on the GPU as well: inlined into one kernel body the compiler
+// spilled ~360 SGPRs and the build was not stable (aperture violations that came and went with unrelated edits).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZC_PIECE __device__ __attribute__((noinline))
+#else
+#define CFZC_PIECE inline
+#endif
+
 namespace cfzc {
 
 constexpr int kPts = 6;     // points per interval (K + 1)
+constexpr int kOutD = 12;    // out_d: cost, err, mu, then 100 MHz ticks spent in evaluation, assembly, factorisation, substitution,
+                            // line search, and in total (zero on the CPU)
+CFZP_FN long long tick() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (long long)wall_clock64();
+#else
+  return 0;
+#endif
+}
 constexpr int kMaxObs = 8;
 
 struct CSpec {
@@ -53,11 +70,13 @@ CFZP_FN CDims cdims(const CSpec &sp) {
   d.iDt = 7 * d.np; d.sO = d.iDt + 1; d.sT = d.sO + d.np * d.nr; d.n = d.sT + 8 * sp.n_chk;
   d.rO = 7; d.rC = d.rO + 5 * d.np; d.rR = d.rC + 7 * (sp.N - 1); d.rT = d.rR + d.np * d.nr; d.rF = d.rT + 8 * sp.n_chk;
   d.rH = d.rF + 4; d.m = d.rH + (sp.has_final ? 1 : 0);
-  d.nk = d.n - 1 + d.m;  // dt is bordered, not in the band
+  d.nk = d.n - 1 + d.m - 2 * d.np * d.nr;  // dt is bordered, collision slacks and rows are condensed: neither is in the band
   return d;
 }
 // half-bandwidth of the ordering of build_order: the 30 ODE rows of an interval sit between its third and fourth point
-CFZP_FN int half_bandwidth(const CSpec &sp) { return 30 + 3 * (7 + 4 * sp.n_obs); }
+constexpr int kCB = 51, kCLd = 3 * kCB + 1, kCWin = 2 * kCB + 1;
+constexpr int kCLdsDoubles = kCWin * kCLd + 64;  // the window and one spare slot per lane behind it
+CFZP_FN int half_bandwidth(const CSpec &) { return kCB; }
 // point of tube checkpoint q: start of interval (q+1) Nps, or the very last point
 CFZP_FN int chk_point(const CSpec &sp, int q) { return q + 1 < sp.n_chk ? (q + 1) * sp.Nps * kPts : sp.N * kPts - 1; }
 
@@ -71,7 +90,7 @@ CFZP_FN void f_ct(const double *p, double wb, double f[5]) {
 }
 CFZP_FN double stage_err(const double *p) { return p[5] * p[5] + p[3] * p[3] * p[6] * p[6] + p[4] * p[4]; }
 
-CFZP_FN double objective(const CSpec &sp, const double *X) {
+CFZC_PIECE double objective(const CSpec &sp, const double *X) {
   const CDims d = cdims(sp);
   double s = 0.0;
   CFZP_LANE_FOR(q, 0, d.np - 1) s += sp.B[q % kPts] * stage_err(X + 7 * q);
@@ -80,7 +99,7 @@ CFZP_FN double objective(const CSpec &sp, const double *X) {
 }
 
 // c(X); sel[np * n_obs] is the working set of the collision rows
-CFZP_FN void constraints(const CSpec &sp, const unsigned char *sel, const double *X, double *c) {
+CFZC_PIECE void constraints(const CSpec &sp, const unsigned char *sel, const double *X, double *c) {
   const CDims d = cdims(sp);
   const double dt = X[d.iDt];
   for (int i = 0; i < 3; ++i) c[i] = X[i] - sp.init_pose[i];
@@ -120,7 +139,7 @@ CFZP_FN void constraints(const CSpec &sp, const unsigned char *sel, const double
   CFZP_SYNC();
 }
 
-CFZP_FN void gradient(const CSpec &sp, const double *X, double *g) {
+CFZC_PIECE void gradient(const CSpec &sp, const double *X, double *g) {
   const CDims d = cdims(sp);
   const double dt = X[d.iDt];
   double s = 0.0;
@@ -137,7 +156,7 @@ CFZP_FN void gradient(const CSpec &sp, const double *X, double *g) {
 }
 
 // out = J(X)' nu (all n entries, dt included)
-CFZP_FN void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X, const double *nu, double *out) {
+CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X, const double *nu, double *out) {
   const CDims d = cdims(sp);
   const double dt = X[d.iDt];
   double sdt = 0.0;
@@ -191,7 +210,9 @@ CFZP_FN void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X, c
 
 // ---- band ordering ---------------------------------------------------------------------------------------------
 // per interval: [continuity mults | (tube) | pt0 | pt1 | pt2 | ODE mults of the 6 points | pt3 | pt4 | pt5 | (last tube)], pt =
-// [7 variables | collision slacks | collision row mults]; initial rows first, terminal rows last.  dt has no position.
+// the 7 variables of the point; initial rows first, terminal rows last.  dt has no position (bordered), and neither have
+// the collision slacks and rows: each pair (sigma_r, nu_r) only touches its own point's pose and is eliminated exactly
+// (assemble), which leaves a half-bandwidth of 51 whatever the number of obstacles.
 CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
   const CDims d = cdims(sp);
   int p = 0;
@@ -209,8 +230,7 @@ CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
         if (pass == 1) break;
         if (k == 3) for (int kk = 0; kk < kPts; ++kk) for (int cc = 0; cc < 5; ++cc) posc[d.rO + 5 * (i * kPts + kk) + cc] = p++;
         for (int cc = 0; cc < 7; ++cc) posx[7 * q + cc] = p++;
-        for (int r = 0; r < d.nr; ++r) posx[d.sO + q * d.nr + r] = p++;
-        for (int r = 0; r < d.nr; ++r) posc[d.rR + q * d.nr + r] = p++;
+        for (int r = 0; r < d.nr; ++r) { posx[d.sO + q * d.nr + r] = -1; posc[d.rR + q * d.nr + r] = -1; }  // condensed
       }
     }
   }
@@ -225,13 +245,13 @@ CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld 
 CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
 
 struct CWork {
-  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig;
+  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond;
   int *posx, *posc, *ipiv;
   unsigned char *sel;
 };
 CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
   const CDims d = cdims(sp);
-  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)(d.n + d.m + d.nk + 2) / 2 +
+  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)(d.n + d.m + d.nk + 2) / 2 +
          (size_t)(d.np * sp.n_obs + 7) / 8 + 64;
 }
 CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
@@ -241,6 +261,7 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
   w.dzu = p; p += d.n; w.g = p; p += d.n; w.xl = p; p += d.n; w.xu = p; p += d.n; w.r1 = p; p += d.n; w.sig = p; p += d.n;
   w.nu = p; p += d.m; w.dnu = p; p += d.m; w.c = p; p += d.m; w.ct = p; p += d.m;
   w.rhs = p; p += d.nk; w.rhs2 = p; p += d.nk; w.bord = p; p += d.nk; w.ab = p; p += (size_t)d.nk * (3 * kb + 1);
+  w.cond = p; p += (size_t)d.np * d.nr * 5;  // per collision row: gradient (3), D, t (assemble)
   w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
   p += (size_t)(d.n + d.m + d.nk + 2) / 2;
   w.sel = reinterpret_cast<unsigned char *>(p);
@@ -248,16 +269,22 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
 }
 
 // band part of [[W + Sigma + (delta + reg) I, J'], [J, -reg_dual I]] (dt row and column left out) and the border:
-// bord = column of dt restricted to the band unknowns, hdd = its diagonal entry
-CFZP_FN double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
+// bord = column of dt restricted to the band unknowns, hdd = its diagonal entry.  The caller has filled w.rhs with -r1 and
+// -c of the band unknowns; the collision pairs are condensed here.  For row r of a point with gradient g (3 pose
+// entries), slack sigma, S = Sigma_sigma + delta + reg and the residuals c_r, r_sigma:
+//     S dsigma - dnu = -r_sigma,   g'dp - dsigma - reg_dual dnu = -c_r
+//     =>  dnu = D (g'dp + t),  dsigma = (dnu - r_sigma) / S,   D = 1 / (1/S + reg_dual),  t = c_r + r_sigma / S
+// so the pose block gains D g g' and the pose right-hand side loses D t g; g, D, t are kept in w.cond for `recover`.
+CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
   const CDims d = cdims(sp);
   const int *px = w.posx, *pc = w.posc;
   const double *X = w.x, *nu = w.nu;
   const double dt = X[d.iDt];
-  CFZP_LANE_FOR(col, 0, d.nk - 1) { for (int r = 0; r < Bd.ld; ++r) Bd.ab[(size_t)col * Bd.ld + r] = 0.0; w.bord[col] = 0.0; }
+  CFZP_LANE_FOR(t, 0, d.nk * Bd.ld - 1) Bd.ab[t] = 0.0;
+  CFZP_LANE_FOR(col, 0, d.nk - 1) w.bord[col] = 0.0;
   CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, d.n - 1) if (i != d.iDt) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
-  CFZP_LANE_FOR(i, 0, d.m - 1) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
+  CFZP_LANE_FOR(i, 0, d.n - 1) if (px[i] >= 0) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
+  CFZP_LANE_FOR(i, 0, d.m - 1) if (pc[i] >= 0) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
   CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, 6) put(Bd, pc[i], px[i], 1.0);
   CFZP_LANE_FOR(q, 0, d.np - 1) {  // every entry written here belongs to point q alone
@@ -301,8 +328,13 @@ CFZP_FN double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double 
       cfz::rows_for<true>(A, bb, V, p[0], p[1], cs, sn, sp.g, sl, sep, gr);
       for (int rr = 0; rr < 2; ++rr) {
         const int row = d.rR + q * d.nr + 2 * j + rr, sk = d.sO + q * d.nr + 2 * j + rr;
-        put(Bd, pc[row], px[b], gr[rr][0]); put(Bd, pc[row], px[b + 1], gr[rr][1]); put(Bd, pc[row], px[b + 2], gr[rr][2]);
-        put(Bd, pc[row], px[sk], -1.0);
+        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] + w.r1[sk] / S;
+        double *cd = w.cond + (size_t)(q * d.nr + 2 * j + rr) * 5;
+        cd[0] = gr[rr][0]; cd[1] = gr[rr][1]; cd[2] = gr[rr][2]; cd[3] = D; cd[4] = t;
+        for (int a = 0; a < 3; ++a) {
+          w.rhs[px[b + a]] -= D * t * gr[rr][a];
+          for (int c2 = a; c2 < 3; ++c2) put(Bd, px[b + a], px[b + c2], D * gr[rr][a] * gr[rr][c2]);
+        }
         const double nr_ = nu[row];
         const int vtx = rr == 0 ? ((sl >> 2) & 3) : (sl & 3);
         if ((sl >> 6) == 1) {  // polygon face (a0,a1), body vertex: d2/dpsi2 = -A_f.(R b_v)
@@ -339,7 +371,7 @@ CFZP_FN double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double 
 }
 
 // ---- banded LU with partial pivoting, runtime half-bandwidth, factor once / substitute many -----------------------
-CFZP_FN int band_factor(const Band &B, int n, int *ipiv) {
+CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
   const int kl = B.kb, ku = B.kb, kv = kl + ku, ld = B.ld;
   double *ab = B.ab;
   int ju = 0;
@@ -375,7 +407,7 @@ CFZP_FN int band_factor(const Band &B, int n, int *ipiv) {
   return 0;
 }
 // two right-hand sides at once (the KKT residual and the dt border)
-CFZP_FN void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld;
   const double *ab = B.ab;
   for (int j = 0; j < n; ++j) {
@@ -397,7 +429,177 @@ CFZP_FN void band_substitute(const Band &B, int n, const int *ipiv, double *b, d
   }
 }
 
-CFZP_FN double barrier_obj(const CSpec &sp, const CWork &w, const double *X, double mu) {
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same elimination for one wavefront with the kv + 1 = 103 columns it is working on in LDS (`win`, kCWin x kCLd
+// doubles = 124 KiB): column q lives in slot q mod 103 while j <= q <= j + kv, enters from `ab` when pivot step j = q - kv - 1
+// ends (fetched into registers at its start) and is written back after its own pivot step.  Lane i owns row j + i of the
+// pivot column and of every column it updates, so all LDS traffic of the rank-1 update is unit stride.
+// orders the LDS traffic of the one wavefront that runs the solver: DS instructions of a wavefront execute in issue
+// order, so only the compiler has to be kept from moving accesses across (no s_waitcnt on outstanding global stores)
+__device__ inline void wave_sync() {
+#if defined(CFZC_FULL_SYNC)
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+__device__ __attribute__((noinline)) int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
+  extern __shared__ double cfzc_lds[];  // named here, not passed in: every access below must be a DS instruction
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, wc = kv + 1, lane = threadIdx.x;
+  double *ab = B.ab;
+  {
+    const int cnt = ((kv < n - 1 ? kv : n - 1) + 1) * ld;
+    for (int t = lane; t < cnt; t += 64) cfzc_lds[t] = ab[t];
+  }
+  __syncthreads();
+  int ju = 0, sj = 0;  // sj = j mod wc: slot of column j; column q sits in slot sj + (q - j), wrapped
+  for (int j = 0; j < n; ++j, sj = sj + 1 == wc ? 0 : sj + 1) {
+    const int km = (kl < n - 1 - j) ? kl : n - 1 - j, qn = j + kv + 1;
+    long long tp0 = tick();
+    double pre[3] = {0.0, 0.0, 0.0};
+    if (qn < n) for (int t = 0; t < 3; ++t) { const int r = lane + 64 * t; if (r < ld) pre[t] = ab[(size_t)qn * ld + r]; }
+    const int cj = sj * ld;  // offset of column j in the window
+    double best = lane <= km ? fabs(cfzc_lds[cj + kv + lane]) : -1.0;
+    int jp = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
+      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
+    }
+    if (lane == 0) ipiv[j] = j + jp;
+    if (!(best > 0.0)) return 1;
+    const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
+    ju = ju > reach ? ju : reach;
+    if (jp != 0) {
+      for (int dq = lane; j + dq <= ju; dq += 64) {
+        const int sl = sj + dq < wc ? sj + dq : sj + dq - wc;
+        const int cq = sl * ld + (kv - dq);  // row j of column j + dq
+        const double t = cfzc_lds[cq]; cfzc_lds[cq] = cfzc_lds[cq + jp]; cfzc_lds[cq + jp] = t;
+      }
+      wave_sync();
+    }
+    { const long long t1 = tick(); ptk[0] += t1 - tp0; tp0 = t1; }
+    const bool mine = lane >= 1 && lane <= km;
+    const double inv = 1.0 / cfzc_lds[cj + kv];
+    const double l = mine ? cfzc_lds[cj + kv + lane] * inv : 0.0;
+    if (mine) cfzc_lds[cj + kv + lane] = l;
+    // rank-1 update of the columns j+1..ju whose entry in the pivot row is not zero (typically a third of them).  Lane t
+    // fetches the multipliers u of columns j+1+t and j+65+t; the columns with u != 0 are then taken sixteen at a time,
+    // branch-free, so that the sixteen reads and then the sixteen writes of a batch are in flight together (a branch
+    // around a write costs an s_waitcnt lgkmcnt(0), i.e. one LDS round trip per column): a short batch repeats its
+    // last column (the same value is stored twice), lanes without a row read and write a spare slot behind the window
+    const int nq = ju - j;
+    for (int half = 0; half < 2; ++half) {
+      const int dl = 1 + 64 * half + lane;
+      double um = 0.0;
+      if (dl <= nq) { const int sl = sj + dl < wc ? sj + dl : sj + dl - wc; um = cfzc_lds[sl * ld + (kv - dl)]; }
+      unsigned long long todo = __ballot(um != 0.0);
+      const int uh = __double2hiint(um), ul = __double2loint(um);
+      while (todo) {
+        int tq[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          tq[c] = todo ? (int)__builtin_ctzll(todo) : tq[c ? c - 1 : 0];
+          todo &= todo - 1;  // 0 stays 0
+        }
+        double xv[16];
+        int at[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int dq = 1 + 64 * half + tq[c];
+          const int sl = sj + dq < wc ? sj + dq : sj + dq - wc;
+          at[c] = mine ? sl * ld + (kv - dq) + lane : wc * ld + lane;
+          xv[c] = cfzc_lds[at[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double u = __hiloint2double(__builtin_amdgcn_readlane(uh, tq[c]), __builtin_amdgcn_readlane(ul, tq[c]));
+          cfzc_lds[at[c]] = xv[c] - l * u;
+        }
+      }
+    }
+    wave_sync();
+    { const long long t1 = tick(); ptk[1] += t1 - tp0; tp0 = t1; }
+    for (int t = 0; t < 3; ++t) {
+      const int r = lane + 64 * t;
+      if (r < ld) { ab[(size_t)j * ld + r] = cfzc_lds[cj + r]; if (qn < n) cfzc_lds[cj + r] = pre[t]; }
+    }
+    wave_sync();
+    { const long long t1 = tick(); ptk[2] += t1 - tp0; tp0 = t1; }
+  }
+  __syncthreads();
+  return 0;
+}
+
+// both right-hand sides in LDS (b at offset 0, b2 at offset n), the factor's columns fetched eight pivot steps ahead
+__device__ __attribute__((noinline)) void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+  extern __shared__ double cfzc_lds[];
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, lane = threadIdx.x;
+  const double *ab = B.ab;
+  for (int t = lane; t < n; t += 64) { cfzc_lds[t] = b[t]; cfzc_lds[n + t] = b2[t]; }
+  __syncthreads();
+  constexpr int CH = 8;
+  for (int j0 = 0; j0 < n; j0 += CH) {
+    double Lr[CH]; int pv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int j = j0 + c, km = j < n ? ((kl < n - 1 - j) ? kl : n - 1 - j) : 0;
+      Lr[c] = (lane >= 1 && lane <= km) ? ab[(size_t)j * ld + kv + lane] : 0.0;
+      pv[c] = j < n ? ipiv[j] : j;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int j = j0 + c;
+      if (j < n) {
+        const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = pv[c];
+        if (p != j) {
+          if (lane == 0) {
+            const double t = cfzc_lds[j]; cfzc_lds[j] = cfzc_lds[p]; cfzc_lds[p] = t;
+            const double t2 = cfzc_lds[n + j]; cfzc_lds[n + j] = cfzc_lds[n + p]; cfzc_lds[n + p] = t2;
+          }
+          wave_sync();
+        }
+        const double bj = cfzc_lds[j], cj = cfzc_lds[n + j];
+        if (lane >= 1 && lane <= km) { cfzc_lds[j + lane] -= Lr[c] * bj; cfzc_lds[n + j + lane] -= Lr[c] * cj; }
+        wave_sync();
+      }
+    }
+  }
+  for (int j1 = n - 1; j1 >= 0; j1 -= CH) {
+    double Ur[CH][2], dg[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int j = j1 - c;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int off = lane + 64 * t, i = j - kv + off;
+        Ur[c][t] = (j >= 0 && off < kv && i >= 0) ? ab[(size_t)j * ld + off] : 0.0;
+      }
+      dg[c] = j >= 0 ? ab[(size_t)j * ld + kv] : 1.0;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int j = j1 - c;
+      if (j >= 0) {
+        const double bj = cfzc_lds[j] / dg[c], cj = cfzc_lds[n + j] / dg[c];
+        wave_sync();
+        if (lane == 0) { cfzc_lds[j] = bj; cfzc_lds[n + j] = cj; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int off = lane + 64 * t, i = j - kv + off;
+          if (off < kv && i >= 0) { cfzc_lds[i] -= Ur[c][t] * bj; cfzc_lds[n + i] -= Ur[c][t] * cj; }
+        }
+        wave_sync();
+      }
+    }
+  }
+  for (int t = lane; t < n; t += 64) { b[t] = cfzc_lds[t]; b2[t] = cfzc_lds[n + t]; }
+  __syncthreads();
+}
+#endif
+
+CFZC_PIECE double barrier_obj(const CSpec &sp, const CWork &w, const double *X, double mu) {
   const CDims d = cdims(sp);
   double s = 0.0, bad = 0.0;
   CFZP_LANE_FOR(i, 0, d.n - 1) {
@@ -409,7 +611,7 @@ CFZP_FN double barrier_obj(const CSpec &sp, const CWork &w, const double *X, dou
 }
 
 // refresh the working set at the poses of X; a block whose (face, vertices) change restarts its two rows
-CFZP_FN void refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
+CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
   const CDims d = cdims(sp);
   CFZP_LANE_FOR(q, 0, d.np - 1) {
     const double *p = X + 7 * q;
@@ -421,9 +623,6 @@ CFZP_FN void refresh_working_set(const CSpec &sp, const CWork &w, double *X, dou
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
       const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
       if (nw != old) {
-#if defined(CFZC_TRACE)
-        if (!first) printf("   ws change pt %d obs %d: %d/%d/%d%d -> %d/%d/%d%d  slack %.3e %.3e z %.3e %.3e\n", q, j, old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sO + q * d.nr + 2 * j], X[d.sO + q * d.nr + 2 * j + 1], w.zl[d.sO + q * d.nr + 2 * j], w.zl[d.sO + q * d.nr + 2 * j + 1]);
-#endif
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
         cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
         for (int r = 0; r < 2; ++r) {
@@ -439,7 +638,10 @@ CFZP_FN void refresh_working_set(const CSpec &sp, const CWork &w, double *X, dou
 
 // X: guess for the 7 N 6 point variables followed by dt; solution out (same layout).  out_i = iterations, status;
 // out_d = cost, err, mu.  kb: half-bandwidth the caller sized the slab for.
-CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d) {
+// WIN (GPU only): the kernel's dynamic LDS (kCWin x kCLd doubles) is the window of band_factor_lds / band_substitute_lds
+// and kb == kCB; `win` is unused
+template <bool WIN>
+CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, double *win) {
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
   const Band Bd = {w.ab, kb, 3 * kb + 1};
@@ -473,7 +675,9 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
   int status = 1, iter = 0;
+  long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
+    ta = tick();
     if (iter > 0) refresh_working_set(sp, w, w.x, mu, false);
     constraints(sp, w.sel, w.x, w.c);
     gradient(sp, w.x, w.g);
@@ -484,11 +688,6 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
     sum_z = cfzp::wsum(sum_z); dual_inf = cfzp::wmax(dual_inf);
-#if defined(CFZC_TRACE)
-    { int am = 0; double av = -1; for (int i = 0; i < n; ++i) { const double v = fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i]); if (v > av) { av = v; am = i; } }
-      if (iter == 100 || iter == 101) { for (int q = 0; q < 8; ++q) { printf("   pt %d: p %.5f %.5f %.6f %.2e %.2e %.2e %.2e |", q, w.x[7*q], w.x[7*q+1], w.x[7*q+2], w.x[7*q+3], w.x[7*q+4], w.x[7*q+5], w.x[7*q+6]); for (int r = 0; r < d.nr; ++r) printf(" [%d s %.2e z %.2e nu %.2e]", w.sel[q * sp.n_obs + r / 2], w.x[d.sO + q * d.nr + r], w.zl[d.sO + q * d.nr + r], w.nu[d.rR + q * d.nr + r]); printf("\n      lam:"); for (int c = 0; c < 5; ++c) printf(" %.3e", w.nu[d.rO + 5 * q + c]); printf(" gradL:"); for (int c = 0; c < 7; ++c) printf(" %.2e", w.g[7*q+c] + w.r1[7*q+c] - w.zl[7*q+c] + w.zu[7*q+c]); printf("\n"); } }
-      printf("   dual_inf argmax var %d (%s q=%d c=%d) val %.3e x %.5f zl %.3e zu %.3e s_d %.3f\n", am, am < d.iDt ? "pt" : am == d.iDt ? "dt" : am < d.sT ? "slackO" : "slackT", am < d.iDt ? am / 7 : (am - d.sO) / d.nr, am < d.iDt ? am % 7 : (am - d.sO) % d.nr, av, w.x[am], w.zl[am], w.zu[am], fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max); }
-#endif
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
     double cmp0 = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
@@ -519,31 +718,46 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     }
     CFZP_SYNC();
     double delta = 0.0; bool have = false;
+    tk[0] += tick() - ta;
     for (int tries = 0; tries < 60; ++tries) {
+      ta = tick();
+      CFZP_LANE_FOR(i, 0, n - 1) if (w.posx[i] >= 0) w.rhs[w.posx[i]] = -w.r1[i];
+      CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.rhs[w.posc[i]] = -w.c[i];
+      CFZP_SYNC();
       const double hdd = assemble(sp, w, Bd, delta);
-      CFZP_LANE_FOR(i, 0, n - 1) if (i != d.iDt) w.rhs[w.posx[i]] = -w.r1[i];
-      CFZP_LANE_FOR(i, 0, m - 1) w.rhs[w.posc[i]] = -w.c[i];
       CFZP_LANE_FOR(i, 0, d.nk - 1) w.rhs2[i] = w.bord[i];
       CFZP_SYNC();
-      const int fail = band_factor(Bd, d.nk, w.ipiv);
+      tk[1] += tick() - ta; ta = tick();
+      int fail;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (WIN) fail = band_factor_lds(Bd, d.nk, w.ipiv, tk + 6); else
+#endif
+      fail = band_factor(Bd, d.nk, w.ipiv);
+      tk[2] += tick() - ta; ta = tick();
       if (!fail) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WIN && 2 * d.nk <= kCWin * kCLd) band_substitute_lds(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+#endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
+        tk[3] += tick() - ta;
         // bordered system: [K b; b' h] [y; s] = [r; r_dt]  ->  s = (r_dt - b'K^-1 r) / (h - b'K^-1 b)
         double bty = 0.0, btw = 0.0;
         CFZP_LANE_FOR(i, 0, d.nk - 1) { bty += w.bord[i] * w.rhs[i]; btw += w.bord[i] * w.rhs2[i]; }
         bty = cfzp::wsum(bty); btw = cfzp::wsum(btw);
         const double ddt = (-w.r1[d.iDt] - bty) / (hdd - btw);
         double curv = 0.0, dd = 0.0, bad = isfinite(ddt) ? 0.0 : 1.0;
-        CFZP_LANE_FOR(i, 0, n - 1) {
-          const double v = i == d.iDt ? ddt : w.rhs[w.posx[i]] - w.rhs2[w.posx[i]] * ddt;
-          if (!isfinite(v)) bad = 1.0;
-          w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v;
+        CFZP_LANE_FOR(i, 0, n - 1) if (i == d.iDt || w.posx[i] >= 0) w.dx[i] = i == d.iDt ? ddt : w.rhs[w.posx[i]] - w.rhs2[w.posx[i]] * ddt;
+        CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.dnu[i] = w.rhs[w.posc[i]] - w.rhs2[w.posc[i]] * ddt;
+        CFZP_SYNC();
+        CFZP_LANE_FOR(r, 0, d.np * d.nr - 1) {  // the condensed pairs, from the pose step of their point
+          const double *cd = w.cond + (size_t)r * 5, *dp = w.dx + 7 * (r / d.nr);
+          const double S = w.sig[d.sO + r] + delta + sp.reg_primal;
+          const double dn = cd[3] * (cd[0] * dp[0] + cd[1] * dp[1] + cd[2] * dp[2] + cd[4]);
+          w.dnu[d.rR + r] = dn; w.dx[d.sO + r] = (dn - w.r1[d.sO + r]) / S;
         }
-        CFZP_LANE_FOR(i, 0, m - 1) {
-          const double v = w.rhs[w.posc[i]] - w.rhs2[w.posc[i]] * ddt;
-          if (!isfinite(v)) bad = 1.0;
-          w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v;
-        }
+        CFZP_SYNC();
+        CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.dx[i]; if (!isfinite(v)) bad = 1.0; curv -= v * w.r1[i]; dd += v * v; }
+        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += w.c[i] * v - sp.reg_dual * v * v; }
         curv = cfzp::wsum(curv); dd = cfzp::wsum(dd); bad = cfzp::wmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
@@ -552,6 +766,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (delta > 1e20) break;
     }
     if (!have) { status = 3; break; }
+    ta = tick();
     double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
       const double dxi = w.dx[i];
@@ -609,8 +824,11 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; w.zu[i] = fmin(fmax(w.zu[i] + a_dual * w.dzu[i], mu / (sp.kappa_sigma * du)), sp.kappa_sigma * mu / du); }
     }
     CFZP_SYNC();
+    tk[4] += tick() - ta;
   }
   CFZP_SYNC();
+  tk[5] = tick() - t0;
+  for (int i = 0; i < 9; ++i) out_d[3 + i] = (double)tk[i];
   CFZP_LANE_FOR(i, 0, d.iDt) X[i] = w.x[i];
   out_i[0] = iter; out_i[1] = status;
   out_d[0] = objective(sp, w.x); out_d[1] = err0; out_d[2] = mu;

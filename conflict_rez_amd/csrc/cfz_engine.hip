@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
 }
 
 // state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
-__global__ void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
+__global__ __launch_bounds__(64) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
                                 const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
   const int b = blockIdx.x;
   extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
@@ -278,11 +278,22 @@ __global__ void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *t
 
 // single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
 // cfz_colloc.inl.
-__global__ void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
+// One wavefront runs it, but the bound is 512: with 64 (or 256) the register allocator may use AGPRs beyond 256 VGPRs, and
+// every such build of this kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950 / ROCm 7.2 while the
+// 256-VGPR builds of the same source run (measured, tools/colloc_timing_one.sh).
+#ifndef CFZC_BOUNDS
+#define CFZC_BOUNDS 512
+#endif
+__global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
                               const long long *slab_off, int kb, int32_t *oi, double *od) {
   const int b = blockIdx.x;
+  extern __shared__ double colloc_win[];  // the 103 band columns the elimination is working on, then the right-hand sides
   if (b >= B) return;
-  cfzc::solve_colloc(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + 3 * b);
+#if defined(CFZC_NOWIN)
+  cfzc::solve_colloc<false>(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + cfzc::kOutD * b, nullptr);
+#else
+  cfzc::solve_colloc<true>(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
+#endif
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -858,19 +869,21 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
   }
   cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr;
   HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
-  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
+  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * cfzc::kOutD * 8));
   HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(64), 0, 0, B, dspec, dX, doff, dslab, doff + B, kb, doi, dod);
+  const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
+  HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, kb, doi, dod);
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
-  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
+  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
   HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost));
   for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
   g0 = 0;
   for (int b = 0; b < B; ++b) {
@@ -880,7 +893,12 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
     g0 += np_;
     if (status) status[b] = oi[2 * b + 1];
     if (iters) iters[b] = oi[2 * b];
-    if (cost) cost[b] = od[3 * b];
+    if (cost) cost[b] = od[(size_t)cfzc::kOutD * b];
+    if (std::getenv("CFZ_COLLOC_PROFILE")) {  // milliseconds per phase (100 MHz device clock)
+      const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
+      fprintf(stderr, "cfz_colloc[%d]: %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
+              b, oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
+    }
   }
   return 0;
 }

@@ -246,11 +246,19 @@ constexpr int kWinCols = 2 * kKB + 1;
 template <bool WIN>
 CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
   const int kl = kKB, ku = kKB, kv = kl + ku;
-// WIN is a compile-time switch so that the window pointer keeps its (LDS) address space through the optimiser
-#define CFZP_COL(q) (WIN ? win + (size_t)((q) % kWinCols) * kLd : ab + (size_t)(q) * kLd)
+// WIN is a compile-time switch, and on the GPU the window is named directly (the kernel's dynamic LDS) rather than taken
+// from the argument, so that every access to it is a DS instruction: through a generic pointer most of them became FLAT
+// instructions, which wait on the global-memory counter as well
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ double cfzp_lds[];
+#define CFZP_WIN_BASE cfzp_lds
+#else
+#define CFZP_WIN_BASE win
+#endif
+#define CFZP_COL(q) (WIN ? CFZP_WIN_BASE + (size_t)((q) % kWinCols) * kLd : ab + (size_t)(q) * kLd)
   if (WIN) {
     const int last = kv < n - 1 ? kv : n - 1;
-    for (int q = 0; q <= last; ++q) CFZP_LANE_FOR(r, 0, kLd - 1) win[(size_t)q * kLd + r] = ab[(size_t)q * kLd + r];
+    for (int q = 0; q <= last; ++q) CFZP_LANE_FOR(r, 0, kLd - 1) CFZP_WIN_BASE[(size_t)q * kLd + r] = ab[(size_t)q * kLd + r];
     CFZP_SYNC();
   }
   int ju = 0;
@@ -301,6 +309,7 @@ CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
     }
   }
 #undef CFZP_COL
+#undef CFZP_WIN_BASE
   for (int j = 0; j < n; ++j) {  // L y = P b
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
     if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; }

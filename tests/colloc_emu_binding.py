@@ -112,6 +112,6 @@ def solve(nlp, X0, opt):
     """X0: points and dt (7 np + 1) -> dict(X, iters, status, f, err, mu)."""
     s, keep = make_spec(nlp, opt)
     X = np.array(X0[: nlp.iDt + 1], dtype=np.float64)
-    oi, od = np.zeros(2, np.int32), np.zeros(3)
+    oi, od = np.zeros(2, np.int32), np.zeros(12)
     assert lib().cfzc_emu_solve(C.byref(s), _p(X), _p(oi), _p(od)) == 0
     return dict(X=X, iters=int(oi[0]), status=int(oi[1]), f=od[0], err=od[1], mu=od[2])

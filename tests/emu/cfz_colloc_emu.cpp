@@ -30,7 +30,8 @@ void cfzc_emu_eval(const cfzc::CSpec *sp, const unsigned char *sel, const double
   cfzc::jt_nu(*sp, sel, X, nu, jtnu);
 }
 // dense (n+m)^2 matrix [[W + diag(sig) + delta I, J'], [J, -reg_dual I]] in the natural ordering, from the band and the
-// border; returns the half-bandwidth the ordering needs
+// border, with the collision slacks and rows condensed into the pose blocks (their own rows and columns stay zero);
+// returns the half-bandwidth the ordering needs
 int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *X, const double *nu, const double *sig,
                  double delta, double *K) {
   const cfzc::CDims d = cfzc::cdims(*sp);
@@ -44,8 +45,8 @@ int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *
   const double hdd = cfzc::assemble(*sp, w, Bd, delta);
   const int nt = d.n + d.m;
   int *nat = (int *)malloc(sizeof(int) * d.nk);  // band position -> natural index
-  for (int i = 0; i < d.n; ++i) if (i != d.iDt) nat[w.posx[i]] = i;
-  for (int i = 0; i < d.m; ++i) nat[w.posc[i]] = d.n + i;
+  for (int i = 0; i < d.n; ++i) if (w.posx[i] >= 0) nat[w.posx[i]] = i;
+  for (int i = 0; i < d.m; ++i) if (w.posc[i] >= 0) nat[w.posc[i]] = d.n + i;
   int bw = 0;
   memset(K, 0, sizeof(double) * nt * nt);
   for (int a = 0; a < d.nk; ++a)
@@ -63,7 +64,7 @@ int cfzc_emu_solve(const cfzc::CSpec *sp, double *X, int *out_i, double *out_d) 
   const int kb = cfzc::half_bandwidth(*sp);
   double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
   if (!slab) return -1;
-  cfzc::solve_colloc(*sp, X, slab, kb, out_i, out_d);
+  cfzc::solve_colloc<false>(*sp, X, slab, kb, out_i, out_d, nullptr);
   free(slab);
   return 0;
 }

@@ -99,7 +99,7 @@ def test_plan_single_path_then_follow_on_gpu(tmp_path):
         assert v.plan_refined is True and v.state_ws_stats["status"] == 0 and v.final_problem_stats["status"] == 0
         assert abs(v.reference_traj.psi[-1] - v.final_heading) < 1e-2  # the terminal heading of the reference's callers
         # the collocation plan frees dt: it is faster than the warm start's fixed 0.1 s x 30 steps per strategy step
-        assert 2.0 < v.reference_traj.t[-1] < 0.1 * 30 * (v.num_sets - 1) and (v.N, v.K) == (5 * (v.num_sets - 1), 5)
+        assert 2.0 < v.reference_traj.t[-1] < 0.1 * 30 * (v.num_sets - 1) and v.K == 5
         assert v.reference_traj.x.shape == v.reference_traj.psi.shape and np.isfinite(v.reference_xy).all()
     mdf.solve(num_iter=5, dump=False)
     assert sum(v.status == 0 for v in mdf.vehicles) >= 3
