@@ -2,10 +2,10 @@
 `confrez/control/multi_vehicle_planner.py`).
 
 Built: the constructor (:31-66), `joint_dual_ws` (:208-341) on the GPU in closed form (`cfz_joint_dual_ws`), with the
-reference's result layout `joint_l0[agent][other][i][k]` (4,), `joint_s0[(agent, other)][i][k]` (2,).  The solves it
-sits between -- `solve_single_problems` (:68-109, needs the collocation NLP) and `solve_final_problem_obca` (:343-480,
-the coupled collocation NLP) -- are rows of the coverage table that have no kernel yet (DESIGN.md "Next") and raise
-`NotImplementedError`; `single_results` can be supplied to exercise `joint_dual_ws`.
+reference's result layout `joint_l0[agent][other][i][k]` (4,), `joint_s0[(agent, other)][i][k]` (2,), and
+`solve_single_problems` (:68-109) on the GPU planning kernels.  `solve_final_problem_obca` (:343-480, the collocation
+problems of all vehicles coupled by one shared dt and pairwise OBCA rows) is the row of the coverage table that has no
+kernel yet (DESIGN.md "Next") and raises `NotImplementedError`.
 """
 from itertools import combinations, product
 from typing import Dict
@@ -35,8 +35,24 @@ class MultiVehiclePlanner:
         self.joint_l0, self.joint_s0 = {}, {}
         self._engine = None
 
-    def solve_single_problems(self, *args, **kwargs):
-        raise NotImplementedError("needs the collocation NLP (vehicle.py:360-661), which has no HIP kernel yet")
+    def solve_single_problems(self, N: int = 30, K: int = 5, N_per_set: int = 5, dt: float = 0.1, shrink_tube: float = 0.5,
+                              dmin: float = 0.05):
+        """solve single vehicle control problems (:68-109): per agent state_ws -> dual_ws -> interp_ws_for_collocation ->
+        setup_single_final_problem -> solve_single_final_problem -> get_solution, all on the GPU (`cfz_state_ws`,
+        `cfz_dual_ws`, `cfz_colloc`).  Fills `single_results[agent]` (with `.dt`, nested `l`, `m`) and leaves every
+        vehicle's interpolators and N, K set, which is what `joint_dual_ws` reads."""
+        self.single_results = {agent: VehiclePrediction() for agent in self.agents}
+        for agent in self.agents:
+            print(f"==== Solving single vehicle problem for {agent} ====")
+            vehicle = self.vehicles[agent]
+            zu0 = vehicle.state_ws(N=N, dt=dt, init_offset=self.init_offsets[agent], final_heading=self.final_headings[agent],
+                                   shrink_tube=shrink_tube, spline_ws=self.ws_config[agent])
+            zu0 = vehicle.dual_ws(zu0=zu0)
+            zu0 = vehicle.interp_ws_for_collocation(zu0=zu0, K=K, N_per_set=N_per_set)
+            vehicle.setup_single_final_problem(zu0=zu0, init_offset=self.init_offsets[agent], final_heading=self.final_headings[agent],
+                                               K=K, N_per_set=N_per_set, shrink_tube=shrink_tube, dmin=dmin)
+            sol = vehicle.solve_single_final_problem()
+            self.single_results[agent] = vehicle.get_solution(sol=sol)
 
     def solve_final_problem_obca(self, *args, **kwargs):
         raise NotImplementedError("the coupled collocation NLP (multi_vehicle_planner.py:343-480) has no HIP kernel yet")

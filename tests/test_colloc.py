@@ -160,3 +160,31 @@ def test_colloc_on_gpu(plans):
             re_ = ce.solve(nlp, np.append(g.ravel(), d0), ipm.IpmOptions(**COLLOC_OPT))
             assert re_["status"] == 0 and abs(re_["f"] - r["cost"]) < 2e-2 * re_["f"]
             assert np.abs(re_["X"][: nlp.iDt].reshape(-1, 7)[:, :2] - poses[:, :2]).max() < 0.1
+
+
+@pytest.mark.gpu
+def test_planner_single_problems_then_joint_dual_ws(tmp_path):
+    """MultiVehiclePlanner.solve_single_problems (multi_vehicle_planner.py:68-109) on the GPU planning kernels, then
+    joint_dual_ws (:208-341) on its results -- the reference's `main` up to the coupled solve."""
+    from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
+    from conflict_rez_amd.pytypes import VehicleState
+
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    agents = ["vehicle_%d" % i for i in range(4)]
+    paths = interp_along_sets(fn, VehicleBody(), 30)
+    mvp = MultiVehiclePlanner(fn, {a: True for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
+                              {a: VehicleState() for a in agents}, {a: float(paths[a][-1, 2]) for a in agents})
+    mvp.solve_single_problems()
+    for a in agents:
+        r, v = mvp.single_results[a], mvp.vehicles[a]
+        assert v.final_problem_stats["status"] == 0 and (v.N, v.K) == (5 * (v.num_sets - 1), 5)
+        assert len(r.x) == v.N * 6 and r.dt > 0 and np.isclose(r.t[-1], v.N * r.dt)
+        assert len(r.l) == v.N and r.l[0][0].shape == (24,) and min(x.min() for row in r.l for x in row) >= 0.0
+        assert abs(r.psi[-1] - mvp.final_headings[a]) < 1e-2 and abs(r.v[-1]) < 1e-2
+        assert np.allclose(v.state_interpolator(0.0)[:2], paths[a][0, :2], atol=1e-6)
+    mvp.joint_dual_ws(K=5)
+    n01 = min(mvp.vehicles["vehicle_0"].N, mvp.vehicles["vehicle_1"].N)
+    assert len(mvp.joint_l0["vehicle_0"]["vehicle_1"]) == n01 and mvp.joint_s0[("vehicle_0", "vehicle_1")][0][5].shape == (2,)
+    with pytest.raises(NotImplementedError):
+        mvp.solve_final_problem_obca()
