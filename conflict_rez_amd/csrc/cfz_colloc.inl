@@ -21,6 +21,7 @@
 #pragma once
 #include "cfz_solver.inl"
 #include "cfz_plan.inl"
+#include "cfz_band.inl"
 
 // The big pieces of the solver are separate functions on the GPU as well: inlined into one kernel body the compiler
 // spilled ~360 SGPRs and the build was not stable (aperture violations that came and went with unrelated edits).
@@ -240,7 +241,7 @@ CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
   return p;
 }
 
-struct Band { double *ab; int kb, ld; };
+using cfzb::Band;
 CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld + (2 * B.kb + i - j)]; }
 CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
 
@@ -429,176 +430,6 @@ CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b
   }
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// The same elimination for one wavefront with the kv + 1 = 103 columns it is working on in LDS (`win`, kCWin x kCLd
-// doubles = 124 KiB): column q lives in slot q mod 103 while j <= q <= j + kv, enters from `ab` when pivot step j = q - kv - 1
-// ends (fetched into registers at its start) and is written back after its own pivot step.  Lane i owns row j + i of the
-// pivot column and of every column it updates, so all LDS traffic of the rank-1 update is unit stride.
-// orders the LDS traffic of the one wavefront that runs the solver: DS instructions of a wavefront execute in issue
-// order, so only the compiler has to be kept from moving accesses across (no s_waitcnt on outstanding global stores)
-__device__ inline void wave_sync() {
-#if defined(CFZC_FULL_SYNC)
-  __syncthreads();
-#else
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#endif
-}
-
-__device__ __attribute__((noinline)) int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
-  extern __shared__ double cfzc_lds[];  // named here, not passed in: every access below must be a DS instruction
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, wc = kv + 1, lane = threadIdx.x;
-  double *ab = B.ab;
-  {
-    const int cnt = ((kv < n - 1 ? kv : n - 1) + 1) * ld;
-    for (int t = lane; t < cnt; t += 64) cfzc_lds[t] = ab[t];
-  }
-  __syncthreads();
-  int ju = 0, sj = 0;  // sj = j mod wc: slot of column j; column q sits in slot sj + (q - j), wrapped
-  for (int j = 0; j < n; ++j, sj = sj + 1 == wc ? 0 : sj + 1) {
-    const int km = (kl < n - 1 - j) ? kl : n - 1 - j, qn = j + kv + 1;
-    long long tp0 = tick();
-    double pre[3] = {0.0, 0.0, 0.0};
-    if (qn < n) for (int t = 0; t < 3; ++t) { const int r = lane + 64 * t; if (r < ld) pre[t] = ab[(size_t)qn * ld + r]; }
-    const int cj = sj * ld;  // offset of column j in the window
-    double best = lane <= km ? fabs(cfzc_lds[cj + kv + lane]) : -1.0;
-    int jp = lane;
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
-      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
-    }
-    if (lane == 0) ipiv[j] = j + jp;
-    if (!(best > 0.0)) return 1;
-    const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
-    ju = ju > reach ? ju : reach;
-    if (jp != 0) {
-      for (int dq = lane; j + dq <= ju; dq += 64) {
-        const int sl = sj + dq < wc ? sj + dq : sj + dq - wc;
-        const int cq = sl * ld + (kv - dq);  // row j of column j + dq
-        const double t = cfzc_lds[cq]; cfzc_lds[cq] = cfzc_lds[cq + jp]; cfzc_lds[cq + jp] = t;
-      }
-      wave_sync();
-    }
-    { const long long t1 = tick(); ptk[0] += t1 - tp0; tp0 = t1; }
-    const bool mine = lane >= 1 && lane <= km;
-    const double inv = 1.0 / cfzc_lds[cj + kv];
-    const double l = mine ? cfzc_lds[cj + kv + lane] * inv : 0.0;
-    if (mine) cfzc_lds[cj + kv + lane] = l;
-    // rank-1 update of the columns j+1..ju whose entry in the pivot row is not zero (typically a third of them).  Lane t
-    // fetches the multipliers u of columns j+1+t and j+65+t; the columns with u != 0 are then taken sixteen at a time,
-    // branch-free, so that the sixteen reads and then the sixteen writes of a batch are in flight together (a branch
-    // around a write costs an s_waitcnt lgkmcnt(0), i.e. one LDS round trip per column): a short batch repeats its
-    // last column (the same value is stored twice), lanes without a row read and write a spare slot behind the window
-    const int nq = ju - j;
-    for (int half = 0; half < 2; ++half) {
-      const int dl = 1 + 64 * half + lane;
-      double um = 0.0;
-      if (dl <= nq) { const int sl = sj + dl < wc ? sj + dl : sj + dl - wc; um = cfzc_lds[sl * ld + (kv - dl)]; }
-      unsigned long long todo = __ballot(um != 0.0);
-      const int uh = __double2hiint(um), ul = __double2loint(um);
-      while (todo) {
-        int tq[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          tq[c] = todo ? (int)__builtin_ctzll(todo) : tq[c ? c - 1 : 0];
-          todo &= todo - 1;  // 0 stays 0
-        }
-        double xv[16];
-        int at[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const int dq = 1 + 64 * half + tq[c];
-          const int sl = sj + dq < wc ? sj + dq : sj + dq - wc;
-          at[c] = mine ? sl * ld + (kv - dq) + lane : wc * ld + lane;
-          xv[c] = cfzc_lds[at[c]];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double u = __hiloint2double(__builtin_amdgcn_readlane(uh, tq[c]), __builtin_amdgcn_readlane(ul, tq[c]));
-          cfzc_lds[at[c]] = xv[c] - l * u;
-        }
-      }
-    }
-    wave_sync();
-    { const long long t1 = tick(); ptk[1] += t1 - tp0; tp0 = t1; }
-    for (int t = 0; t < 3; ++t) {
-      const int r = lane + 64 * t;
-      if (r < ld) { ab[(size_t)j * ld + r] = cfzc_lds[cj + r]; if (qn < n) cfzc_lds[cj + r] = pre[t]; }
-    }
-    wave_sync();
-    { const long long t1 = tick(); ptk[2] += t1 - tp0; tp0 = t1; }
-  }
-  __syncthreads();
-  return 0;
-}
-
-// both right-hand sides in LDS (b at offset 0, b2 at offset n), the factor's columns fetched eight pivot steps ahead
-__device__ __attribute__((noinline)) void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
-  extern __shared__ double cfzc_lds[];
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, lane = threadIdx.x;
-  const double *ab = B.ab;
-  for (int t = lane; t < n; t += 64) { cfzc_lds[t] = b[t]; cfzc_lds[n + t] = b2[t]; }
-  __syncthreads();
-  constexpr int CH = 8;
-  for (int j0 = 0; j0 < n; j0 += CH) {
-    double Lr[CH]; int pv[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int j = j0 + c, km = j < n ? ((kl < n - 1 - j) ? kl : n - 1 - j) : 0;
-      Lr[c] = (lane >= 1 && lane <= km) ? ab[(size_t)j * ld + kv + lane] : 0.0;
-      pv[c] = j < n ? ipiv[j] : j;
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int j = j0 + c;
-      if (j < n) {
-        const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = pv[c];
-        if (p != j) {
-          if (lane == 0) {
-            const double t = cfzc_lds[j]; cfzc_lds[j] = cfzc_lds[p]; cfzc_lds[p] = t;
-            const double t2 = cfzc_lds[n + j]; cfzc_lds[n + j] = cfzc_lds[n + p]; cfzc_lds[n + p] = t2;
-          }
-          wave_sync();
-        }
-        const double bj = cfzc_lds[j], cj = cfzc_lds[n + j];
-        if (lane >= 1 && lane <= km) { cfzc_lds[j + lane] -= Lr[c] * bj; cfzc_lds[n + j + lane] -= Lr[c] * cj; }
-        wave_sync();
-      }
-    }
-  }
-  for (int j1 = n - 1; j1 >= 0; j1 -= CH) {
-    double Ur[CH][2], dg[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int j = j1 - c;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int off = lane + 64 * t, i = j - kv + off;
-        Ur[c][t] = (j >= 0 && off < kv && i >= 0) ? ab[(size_t)j * ld + off] : 0.0;
-      }
-      dg[c] = j >= 0 ? ab[(size_t)j * ld + kv] : 1.0;
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int j = j1 - c;
-      if (j >= 0) {
-        const double bj = cfzc_lds[j] / dg[c], cj = cfzc_lds[n + j] / dg[c];
-        wave_sync();
-        if (lane == 0) { cfzc_lds[j] = bj; cfzc_lds[n + j] = cj; }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int off = lane + 64 * t, i = j - kv + off;
-          if (off < kv && i >= 0) { cfzc_lds[i] -= Ur[c][t] * bj; cfzc_lds[n + i] -= Ur[c][t] * cj; }
-        }
-        wave_sync();
-      }
-    }
-  }
-  for (int t = lane; t < n; t += 64) { b[t] = cfzc_lds[t]; b2[t] = cfzc_lds[n + t]; }
-  __syncthreads();
-}
-#endif
-
 CFZC_PIECE double barrier_obj(const CSpec &sp, const CWork &w, const double *X, double mu) {
   const CDims d = cdims(sp);
   double s = 0.0, bad = 0.0;
@@ -730,13 +561,13 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[1] += tick() - ta; ta = tick();
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (WIN) fail = band_factor_lds(Bd, d.nk, w.ipiv, tk + 6); else
+      if (WIN) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (WIN && 2 * d.nk <= kCWin * kCLd) band_substitute_lds(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+        if (WIN && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         tk[3] += tick() - ta;

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
 }
 
 // state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
-__global__ __launch_bounds__(64) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
+// bound 512 = at most 256 VGPRs, no AGPRs: see colloc_kernel
+__global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
                                 const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
   const int b = blockIdx.x;
   extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
@@ -763,7 +764,7 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n
   HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  const size_t win_bytes = (size_t)cfzp::kWinCols * cfzp::kLd * sizeof(double);
+  const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
   HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
   hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
   HIP_OK(hipGetLastError());

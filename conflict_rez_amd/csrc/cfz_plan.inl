@@ -15,6 +15,8 @@
 #pragma once
 #include <math.h>
 
+#include "cfz_band.inl"
+
 #if defined(__HIPCC__)
 #define CFZP_FN __host__ __device__ inline
 #else
@@ -427,7 +429,16 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       CFZP_LANE_FOR(i, 0, n - 1) w.rhs[w.posx[i]] = -w.r1[i];
       CFZP_LANE_FOR(i, 0, m - 1) w.rhs[w.posc[i]] = -w.c[i];
       CFZP_SYNC();
-      const int fail = band_solve<WIN>(w.ab, d.nk, w.ipiv, w.rhs, win);
+      int fail;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (WIN && d.nk <= kWinCols * kLd) {  // the batched LDS elimination of cfz_band.inl; the right-hand side follows in LDS
+        const cfzb::Band Bd = {w.ab, kKB, kLd};
+        long long unused[3] = {0, 0, 0};
+        fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, unused);
+        if (!fail) cfzb::band_substitute_lds<false>(Bd, d.nk, w.ipiv, w.rhs, nullptr);
+      } else
+#endif
+      fail = band_solve<WIN>(w.ab, d.nk, w.ipiv, w.rhs, win);
       if (!fail) {
         double curv = 0.0, dd = 0.0, bad = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
         CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.rhs[w.posx[i]]; if (!isfinite(v)) bad = 1.0; w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v; }
