@@ -3,9 +3,9 @@
 
 Built: the constructor (:31-66), `joint_dual_ws` (:208-341) on the GPU in closed form (`cfz_joint_dual_ws`), with the
 reference's result layout `joint_l0[agent][other][i][k]` (4,), `joint_s0[(agent, other)][i][k]` (2,), and
-`solve_single_problems` (:68-109) on the GPU planning kernels.  `solve_final_problem_obca` (:343-480, the collocation
-problems of all vehicles coupled by one shared dt and pairwise OBCA rows) is the row of the coverage table that has no
-kernel yet (DESIGN.md "Next") and raises `NotImplementedError`.
+`solve_single_problems` (:68-109) and `solve_final_problem_obca` (:343-480: the collocation problems of all vehicles coupled
+by one shared dt and pairwise separation rows, `cfz_joint_colloc`) on the GPU planning kernels.  Not reproduced:
+`solve_final_problem_circles` (:111-206, unused by the reference's `main`) and the matplotlib animation (:482-603).
 """
 from itertools import combinations, product
 from typing import Dict
@@ -33,6 +33,7 @@ class MultiVehiclePlanner:
         self.agent_pairs = list(combinations(self.agents, 2))  # (:56-58)
         self.single_results: Dict[str, VehiclePrediction] = {}
         self.joint_l0, self.joint_s0 = {}, {}
+        self.final_results: Dict[str, VehiclePrediction] = {}
         self._engine = None
 
     def solve_single_problems(self, N: int = 30, K: int = 5, N_per_set: int = 5, dt: float = 0.1, shrink_tube: float = 0.5,
@@ -54,8 +55,46 @@ class MultiVehiclePlanner:
             sol = vehicle.solve_single_final_problem()
             self.single_results[agent] = vehicle.get_solution(sol=sol)
 
-    def solve_final_problem_obca(self, *args, **kwargs):
-        raise NotImplementedError("the coupled collocation NLP (multi_vehicle_planner.py:343-480) has no HIP kernel yet")
+    def solve_final_problem_obca(self, K: int = 5, N_per_set: int = 5, shrink_tube: float = 0.5, dmin: float = 0.05,
+                                 interp_dt: float = None):
+        """solve joint collision avoidance problem with OBCA (:343-480): every vehicle's collocation problem (from its single
+        result) with ONE shared dt, cost sum_a J_a, and every pair of vehicles at least `dmin` apart at every collocation
+        point of the shorter plan -- on the GPU (`cfz_joint_colloc`).  `joint_dual_ws` runs first as in the reference; its
+        duals are not needed by the kernel (the vehicle-vehicle duals are eliminated like the obstacle duals).  Fills
+        `final_results[agent]` = the plan interpolated on the common time grid (:466-480), `final_dt`, `final_stats`;
+        raises RuntimeError when the solver does not converge, as `opti.solve()` does."""
+        from ..engine import joint_colloc
+
+        self.joint_dual_ws(K=K)
+        print("Solving joint final problem with obca...")
+        dt0 = float(np.mean([self.single_results[agent].dt for agent in self.agents]))
+        probs = []
+        for agent in self.agents:
+            vehicle = self.vehicles[agent]
+            probs.append(vehicle.setup_single_final_problem(zu0=self.single_results[agent], init_offset=self.init_offsets[agent],
+                                                            final_heading=self.final_headings[agent], K=K, N_per_set=N_per_set,
+                                                            dmin=dmin, shrink_tube=shrink_tube))
+        index = {a: i for i, a in enumerate(self.agents)}
+        res = joint_colloc(probs[0]["spec"], [p["init_pose"] for p in probs], [p["tube"] for p in probs], [p["guess"] for p in probs], dt0,
+                           [p["final_heading"] for p in probs], pairs=[(index[a], index[b]) for a, b in self.agent_pairs],
+                           N_per_set=N_per_set, shrink_tube=shrink_tube)
+        self.final_stats = dict(status=res["status"], iters=res["iters"], cost=res["cost"])
+        if res["status"] != 0:
+            raise RuntimeError(f"joint final problem did not converge (status {res['status']} after {res['iters']} iterations)")
+        print("Solve_Succeeded")
+        self.final_dt = res["dt"]
+        N_max = max(self.vehicles[agent].N for agent in self.agents)
+        if interp_dt is None:
+            final_t = np.linspace(0, N_max * res["dt"], N_max * (K + 1) + 1, endpoint=True)
+        else:
+            final_t = np.arange(0, N_max * res["dt"], interp_dt)
+        self.final_results = {agent: VehiclePrediction() for agent in self.agents}
+        for agent in self.agents:
+            tr = res["traj"][index[agent]]
+            sol = {k: tr[:, :, c].copy() for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}
+            sol["dt"] = res["dt"]
+            self.vehicles[agent].get_solution(sol=sol)
+            self.final_results[agent] = self.vehicles[agent].interpolate_states(final_t)
 
     def joint_dual_ws(self, K: int = 5, verbose: int = 0):
         """warm starting the dual multipliers for joint collision avoidance (:208-341): for every pair of vehicles and

@@ -7,6 +7,8 @@ namespace cfzb {
 struct Band { double *ab; int kb, ld; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// inline on purpose: functions that name LDS must end up inside the kernel (see cfz_colloc.inl)
+#define CFZB_LDS_FN __device__ inline
 // Elimination by one wavefront with the kv + 1 columns it is working on in LDS (the kernel's dynamic LDS: (kv + 1) x ld
 // doubles plus one spare slot per lane; 124 KiB for the collocation plan, 78 KiB for state_ws): column q lives in slot q mod 103 while j <= q <= j + kv, enters from `ab` when pivot step j = q - kv - 1
 // ends (fetched into registers at its start) and is written back after its own pivot step.  Lane i owns row j + i of the
@@ -22,7 +24,7 @@ __device__ inline void wave_sync() {
 #endif
 }
 
-__device__ __attribute__((noinline)) int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
+CFZB_LDS_FN int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
   extern __shared__ double cfzb_lds[];  // named here, not passed in: every access below must be a DS instruction
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, wc = kv + 1, lane = threadIdx.x;
   double *ab = B.ab;
@@ -111,7 +113,7 @@ __device__ __attribute__((noinline)) int band_factor_lds(const Band &B, int n, i
 
 // the right-hand side(s) in LDS (b at offset 0, b2 at offset n when TWO), the factor's columns fetched eight pivot steps ahead
 template <bool TWO>
-__device__ __attribute__((noinline)) void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+CFZB_LDS_FN void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
   extern __shared__ double cfzb_lds[];
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, lane = threadIdx.x;
   const double *ab = B.ab;

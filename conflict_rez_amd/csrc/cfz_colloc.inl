@@ -23,10 +23,12 @@
 #include "cfz_plan.inl"
 #include "cfz_band.inl"
 
-// The big pieces of the solver are separate functions on the GPU as well: inlined into one kernel body the compiler
-// spilled ~360 SGPRs and the build was not stable (aperture violations that came and went with unrelated edits).
+// Everything is inlined into the kernel on purpose.  With the big pieces as separate (noinline) device functions the
+// build was broken on this toolchain (gfx950, ROCm 7.2) as soon as such a function named LDS -- the dynamic window
+// (`extern __shared__`) or the static scratch of the block reductions: memory aperture violations, or silently wrong
+// LDS contents (measured with tools/colloc_timing_one.sh on four build variants).  The price is ~360 spilled SGPRs.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CFZC_PIECE __device__ __attribute__((noinline))
+#define CFZC_PIECE __device__ inline
 #else
 #define CFZC_PIECE inline
 #endif
@@ -45,41 +47,110 @@ CFZP_FN long long tick() {
 }
 constexpr int kMaxObs = 8;
 
+// Reductions over the partial results of a CFZP_LANE_FOR loop.  The solver may run on several wavefronts (the joint plan:
+// every thread executes the scalar logic redundantly, the marked loops are split over all threads of the workgroup); the
+// partial results of the wavefronts are then combined through LDS in a fixed order, so every thread gets the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline double block_combine(double v, int op) {  // op 0 sum, 1 max, 2 min of the per-wavefront values
+  __shared__ double part[16];
+  const int nw = (int)(blockDim.x >> 6);
+  if (nw <= 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = part[0];
+  for (int i = 1; i < nw; ++i) r = op == 0 ? r + part[i] : (op == 1 ? fmax(r, part[i]) : fmin(r, part[i]));
+  return r;
+}
+#endif
+CFZP_FN double bsum(double v) {
+  v = cfzp::wsum(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = block_combine(v, 0);
+#endif
+  return v;
+}
+CFZP_FN double bmax(double v) {
+  v = cfzp::wmax(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = block_combine(v, 1);
+#endif
+  return v;
+}
+CFZP_FN double bmin(double v) {
+  v = cfzp::wmin(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = block_combine(v, 2);
+#endif
+  return v;
+}
+
+constexpr int kMaxVeh = 4, kMaxPairs = 6;
+
+// V = 1: the single-vehicle plan.  V > 1: the joint plan of the centralised planner (reference
+// confrez/control/multi_vehicle_planner.py:343-480, `solve_final_problem_obca`): every vehicle's collocation problem
+// with ONE shared dt (:365-366, :378-387), cost sum_a J_a, and for every pair of vehicles and every point of the shorter
+// plan the two bodies at least dmin apart (:389-456) -- again as two smooth rows per (pair, point) over a working set.
 struct CSpec {
-  int N, Nps, n_chk, n_obs, has_final;
-  int max_iter, max_backtrack, filter_cap, pad0, pad1;
-  double wb, dmin, shrink, final_heading, dt0;
-  double init_pose[3];
+  int V, Nps, n_obs, n_pairs;
+  int max_iter, max_backtrack, filter_cap, pad0;
+  int N[kMaxVeh], n_chk[kMaxVeh], has_final[kMaxVeh];
+  int pair_a[kMaxPairs], pair_b[kMaxPairs];
+  double wb, dmin, shrink, dt0;
+  double final_heading[kMaxVeh];
+  double init_pose[kMaxVeh][3];
   double bounds[12];  // lo,hi of x, y, v, delta, a, w
   double g[4];        // body polytope offsets
   double A[kPts][kPts], B[kPts];  // collocation tables: A[j][k] = l_j'(tau_k), B[k] = quadrature weights
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
       bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
       reg_primal, reg_dual, curv_kappa;
-  const double *obs_tab;  // n_obs x 20: A[4][2], b[4], V[4][2]
-  const double *tube;     // n_chk x 2 x 12: back cell, front cell (A[4][2], b[4]) of strategy steps 1..S-1
+  const double *obs_tab;         // n_obs x 20: A[4][2], b[4], V[4][2]
+  const double *tube[kMaxVeh];   // per vehicle n_chk x 2 x 12: back cell, front cell (A[4][2], b[4]) of strategy steps 1..S-1
 };
 
+// Intervals of all vehicles are numbered vehicle-major: I = off[a] + i, points q = 6 I + k.
+//   variables    7 per point | dt | static-obstacle slacks (nr per point) | tube slacks (8 per checkpoint) | pair slacks (2 per pair point)
+//   constraints  init 7 per vehicle | ODE 5 per point | continuity 7 per interval but each vehicle's first | obstacle rows |
+//                tube rows | terminal 5 per vehicle (v, delta, a, w, heading; the heading row is dead without one) | pair rows
 struct CDims {
-  int np, nr, n, m, nk;          // points, collision rows per point, variables, constraints, band system size
-  int iDt, sO, sT;               // variable offsets: dt, collision slacks, tube slacks
-  int rO, rC, rR, rT, rF, rH;    // constraint offsets: ODE, continuity, collision rows, tube rows, terminal, heading
+  int V, NI, np, nr, nchk, npp, n, m, nk;
+  int iDt, sO, sT, sP;
+  int rO, rC, rR, rT, rF, rP;
+  int off[kMaxVeh + 1], coff[kMaxVeh + 1], poff[kMaxPairs + 1];
 };
 CFZP_FN CDims cdims(const CSpec &sp) {
   CDims d;
-  d.np = sp.N * kPts; d.nr = 2 * sp.n_obs;
-  d.iDt = 7 * d.np; d.sO = d.iDt + 1; d.sT = d.sO + d.np * d.nr; d.n = d.sT + 8 * sp.n_chk;
-  d.rO = 7; d.rC = d.rO + 5 * d.np; d.rR = d.rC + 7 * (sp.N - 1); d.rT = d.rR + d.np * d.nr; d.rF = d.rT + 8 * sp.n_chk;
-  d.rH = d.rF + 4; d.m = d.rH + (sp.has_final ? 1 : 0);
-  d.nk = d.n - 1 + d.m - 2 * d.np * d.nr;  // dt is bordered, collision slacks and rows are condensed: neither is in the band
+  d.V = sp.V; d.off[0] = 0; d.coff[0] = 0;
+  int nfin = 0;
+  for (int a = 0; a < sp.V; ++a) { d.off[a + 1] = d.off[a] + sp.N[a]; d.coff[a + 1] = d.coff[a] + sp.n_chk[a]; nfin += sp.has_final[a] ? 1 : 0; }
+  for (int a = sp.V; a < kMaxVeh; ++a) { d.off[a + 1] = d.off[sp.V]; d.coff[a + 1] = d.coff[sp.V]; }
+  d.NI = d.off[sp.V]; d.nchk = d.coff[sp.V]; d.np = d.NI * kPts; d.nr = 2 * sp.n_obs;
+  d.poff[0] = 0;
+  for (int e = 0; e < kMaxPairs; ++e) {
+    int cnt = 0;
+    if (e < sp.n_pairs) { const int na = sp.N[sp.pair_a[e]], nb = sp.N[sp.pair_b[e]]; cnt = (na < nb ? na : nb) * kPts; }
+    d.poff[e + 1] = d.poff[e] + cnt;
+  }
+  d.npp = d.poff[kMaxPairs];
+  d.iDt = 7 * d.np; d.sO = d.iDt + 1; d.sT = d.sO + d.np * d.nr; d.sP = d.sT + 8 * d.nchk; d.n = d.sP + 2 * d.npp;
+  d.rO = 7 * sp.V; d.rC = d.rO + 5 * d.np; d.rR = d.rC + 7 * (d.NI - sp.V); d.rT = d.rR + d.np * d.nr; d.rF = d.rT + 8 * d.nchk;
+  d.rP = d.rF + 5 * sp.V; d.m = d.rP + 2 * d.npp;
+  // dt is bordered, collision slacks and rows (obstacles and pairs) are condensed, dead heading rows are left out
+  d.nk = 7 * d.np + 8 * d.nchk + 7 * sp.V + 5 * d.np + 7 * (d.NI - sp.V) + 8 * d.nchk + 4 * sp.V + nfin;
   return d;
 }
+CFZP_FN int veh_of_interval(const CDims &d, int I) { int a = 0; while (a + 1 < d.V && I >= d.off[a + 1]) ++a; return a; }
+CFZP_FN int veh_of_chk(const CDims &d, int T) { int a = 0; while (a + 1 < d.V && T >= d.coff[a + 1]) ++a; return a; }
 // half-bandwidth of the ordering of build_order: the 30 ODE rows of an interval sit between its third and fourth point
 constexpr int kCB = 51, kCLd = 3 * kCB + 1, kCWin = 2 * kCB + 1;
 constexpr int kCLdsDoubles = kCWin * kCLd + 64;  // the window and one spare slot per lane behind it
-CFZP_FN int half_bandwidth(const CSpec &) { return kCB; }
-// point of tube checkpoint q: start of interval (q+1) Nps, or the very last point
-CFZP_FN int chk_point(const CSpec &sp, int q) { return q + 1 < sp.n_chk ? (q + 1) * sp.Nps * kPts : sp.N * kPts - 1; }
+// point of tube checkpoint T (global index): start of interval (t+1) Nps of its vehicle, or the vehicle's very last point
+CFZP_FN int chk_point(const CSpec &sp, const CDims &d, int T) {
+  const int a = veh_of_chk(d, T), t = T - d.coff[a];
+  return t + 1 < sp.n_chk[a] ? (d.off[a] + (t + 1) * sp.Nps) * kPts : d.off[a + 1] * kPts - 1;
+}
+CFZP_FN const double *chk_cell(const CSpec &sp, const CDims &d, int T, int front) { const int a = veh_of_chk(d, T); return cfzp::cell(sp.tube[a], T - d.coff[a], front); }
 
 CFZP_FN void obstacle(const CSpec &sp, int j, double A[4][2], double b[4], double V[4][2]) {
   const double *o = sp.obs_tab + j * 20;
@@ -91,22 +162,71 @@ CFZP_FN void f_ct(const double *p, double wb, double f[5]) {
 }
 CFZP_FN double stage_err(const double *p) { return p[5] * p[5] + p[3] * p[3] * p[6] * p[6] + p[4] * p[4]; }
 
+// polygon of a vehicle body at pose (x, y, psi): faces R G_f, vertices t + R b_v (the layout cfz::select_rows expects)
+CFZP_FN void veh_polygon(const double *q, const double g[4], double A[4][2], double b[4], double V[4][2]) {
+  const double co = cos(q[2]), so = sin(q[2]);
+  A[0][0] = co; A[0][1] = so; A[1][0] = -so; A[1][1] = co; A[2][0] = -co; A[2][1] = -so; A[3][0] = so; A[3][1] = -co;
+  for (int i = 0; i < 4; ++i) b[i] = A[i][0] * q[0] + A[i][1] * q[1] + g[i];
+  const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  for (int i = 0; i < 4; ++i) { V[i][0] = q[0] + co * BV[i][0] - so * BV[i][1]; V[i][1] = q[1] + so * BV[i][0] + co * BV[i][1]; }
+}
+
+// One separation row of a pair of vehicles a, b (poses pa, pb = x, y, psi), as seen from a like the rows of an obstacle:
+// kind 1 = face f of b against body vertex v of a, kind 2 = face f of a against body vertex v of b.  With F the vehicle that
+// owns the face and W the one that owns the vertex:  val = n.(t_W + R_W b_v - t_F) - g_f,  n = R_F G_f.
+// gr, H: derivatives with respect to (a: x, y, psi | b: x, y, psi).
+template <bool DER>
+CFZP_FN double pair_row(const double *pa, const double *pb, const double g[4], int kind, int f, int v, double gr[6], double H[6][6]) {
+  const double *pF = kind == 1 ? pb : pa, *pW = kind == 1 ? pa : pb;
+  const int oF = kind == 1 ? 3 : 0, oW = kind == 1 ? 0 : 3;
+  const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+  const double gf = f == 0 ? g[0] : (f == 1 ? g[1] : (f == 2 ? g[2] : g[3]));
+  const double cF = cos(pF[2]), sF = sin(pF[2]), cW = cos(pW[2]), sW = sin(pW[2]);
+  const double nx = cF * gx - sF * gy, ny = sF * gx + cF * gy;
+  const double bx = (v == 0 || v == 3) ? g[0] : -g[2], by = (v < 2) ? g[1] : -g[3];
+  const double rx = cW * bx - sW * by, ry = sW * bx + cW * by;
+  const double wx = pW[0] + rx - pF[0], wy = pW[1] + ry - pF[1];
+  if (DER) {
+    const double dnx = -ny, dny = nx, drx = -ry, dry = rx;
+    for (int i = 0; i < 6; ++i) { gr[i] = 0.0; for (int j = 0; j < 6; ++j) H[i][j] = 0.0; }
+    gr[oW] = nx; gr[oW + 1] = ny; gr[oW + 2] = nx * drx + ny * dry;
+    gr[oF] = -nx; gr[oF + 1] = -ny; gr[oF + 2] = dnx * wx + dny * wy;
+    H[oF + 2][oF + 2] = -(nx * wx + ny * wy);
+    H[oW + 2][oW + 2] = -(nx * rx + ny * ry);
+    H[oF + 2][oW + 2] = H[oW + 2][oF + 2] = dnx * drx + dny * dry;
+    H[oF + 2][oW] = H[oW][oF + 2] = dnx; H[oF + 2][oW + 1] = H[oW + 1][oF + 2] = dny;
+    H[oF + 2][oF] = H[oF][oF + 2] = -dnx; H[oF + 2][oF + 1] = H[oF + 1][oF + 2] = -dny;
+  }
+  return nx * wx + ny * wy - gf;
+}
+// the two points of pair point r of pair e: same interval and collocation index in both vehicles' plans
+CFZP_FN void pair_points(const CSpec &sp, const CDims &d, int e, int r, int *qa, int *qb) {
+  *qa = d.off[sp.pair_a[e]] * kPts + r; *qb = d.off[sp.pair_b[e]] * kPts + r;
+}
+
 CFZC_PIECE double objective(const CSpec &sp, const double *X) {
   const CDims d = cdims(sp);
   double s = 0.0;
   CFZP_LANE_FOR(q, 0, d.np - 1) s += sp.B[q % kPts] * stage_err(X + 7 * q);
   const double dt = X[d.iDt];
-  return cfzp::wsum(s) * dt + (sp.N * dt) * (sp.N * dt);
+  double tt = 0.0;
+  for (int a = 0; a < sp.V; ++a) tt += (sp.N[a] * dt) * (sp.N[a] * dt);
+  return bsum(s) * dt + tt;
 }
 
-// c(X); sel[np * n_obs] is the working set of the collision rows
+// c(X); sel[np * n_obs | npp] is the working set of the collision rows (obstacles, then pairs)
 CFZC_PIECE void constraints(const CSpec &sp, const unsigned char *sel, const double *X, double *c) {
   const CDims d = cdims(sp);
   const double dt = X[d.iDt];
-  for (int i = 0; i < 3; ++i) c[i] = X[i] - sp.init_pose[i];
-  for (int i = 3; i < 7; ++i) c[i] = X[i];
+  for (int a = 0; a < sp.V; ++a) {
+    const double *p0 = X + 7 * kPts * d.off[a], *pl = X + 7 * (kPts * d.off[a + 1] - 1);
+    for (int i = 0; i < 3; ++i) c[7 * a + i] = p0[i] - sp.init_pose[a][i];
+    for (int i = 3; i < 7; ++i) c[7 * a + i] = p0[i];
+    for (int i = 0; i < 4; ++i) c[d.rF + 5 * a + i] = pl[3 + i];
+    c[d.rF + 5 * a + 4] = sp.has_final[a] ? pl[2] - sp.final_heading[a] : 0.0;
+  }
   CFZP_LANE_FOR(q, 0, d.np - 1) {
-    const int i = q / kPts, k = q - i * kPts;
+    const int i = q / kPts, k = q - i * kPts, va = veh_of_interval(d, i), il = i - d.off[va];
     const double *p = X + 7 * q;
     double f[5];
     f_ct(p, sp.wb, f);
@@ -115,7 +235,7 @@ CFZC_PIECE void constraints(const CSpec &sp, const unsigned char *sel, const dou
       for (int j = 0; j < kPts; ++j) s += sp.A[j][k] * X[7 * (i * kPts + j) + cc];
       c[d.rO + 5 * q + cc] = s;
     }
-    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) c[d.rC + 7 * (i - 1) + cc] = p[cc] - X[7 * (q - 1) + cc];
+    if (k == 0 && il >= 1) for (int cc = 0; cc < 7; ++cc) c[d.rC + 7 * (i - va - 1) + cc] = p[cc] - X[7 * (q - 1) + cc];
     double sn, cs;
     sincos(p[2], &sn, &cs);
     for (int j = 0; j < sp.n_obs; ++j) {
@@ -125,18 +245,25 @@ CFZC_PIECE void constraints(const CSpec &sp, const unsigned char *sel, const dou
       for (int r = 0; r < 2; ++r) c[d.rR + q * d.nr + 2 * j + r] = sep[r] - sp.dmin - X[d.sO + q * d.nr + 2 * j + r];
     }
   }
-  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
-    const double *z = X + 7 * chk_point(sp, t);
+  CFZP_LANE_FOR(t, 0, d.nchk - 1) {
+    const double *z = X + 7 * chk_point(sp, d, t);
     const double fx = z[0] + sp.wb * cos(z[2]), fy = z[1] + sp.wb * sin(z[2]);
-    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    const double *cb = chk_cell(sp, d, t, 0), *cf = chk_cell(sp, d, t, 1);
     for (int r = 0; r < 4; ++r) {
       c[d.rT + 8 * t + r] = cb[2 * r] * z[0] + cb[2 * r + 1] * z[1] - (cb[8 + r] - sp.shrink) + X[d.sT + 8 * t + r];
       c[d.rT + 8 * t + 4 + r] = cf[2 * r] * fx + cf[2 * r + 1] * fy - (cf[8 + r] - sp.shrink) + X[d.sT + 8 * t + 4 + r];
     }
   }
-  const double *pl = X + 7 * (d.np - 1);
-  for (int i = 0; i < 4; ++i) c[d.rF + i] = pl[3 + i];
-  if (sp.has_final) c[d.rH] = pl[2] - sp.final_heading;
+  for (int e = 0; e < sp.n_pairs; ++e) {
+    CFZP_LANE_FOR(r, 0, d.poff[e + 1] - d.poff[e] - 1) {
+      int qa, qb;
+      pair_points(sp, d, e, r, &qa, &qb);
+      const int pp = d.poff[e] + r, sl = sel[d.np * sp.n_obs + pp];
+      for (int rr = 0; rr < 2; ++rr)
+        c[d.rP + 2 * pp + rr] = pair_row<false>(X + 7 * qa, X + 7 * qb, sp.g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, nullptr, nullptr) -
+                                sp.dmin - X[d.sP + 2 * pp + rr];
+    }
+  }
   CFZP_SYNC();
 }
 
@@ -152,7 +279,9 @@ CFZC_PIECE void gradient(const CSpec &sp, const double *X, double *g) {
     s += bk * stage_err(p);
   }
   CFZP_LANE_FOR(i, d.sO, d.n - 1) g[i] = 0.0;
-  g[d.iDt] = cfzp::wsum(s) + 2.0 * sp.N * sp.N * dt;
+  double nn = 0.0;
+  for (int a = 0; a < sp.V; ++a) nn += 2.0 * sp.N[a] * sp.N[a];
+  g[d.iDt] = bsum(s) + nn * dt;
   CFZP_SYNC();
 }
 
@@ -162,7 +291,7 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
   const double dt = X[d.iDt];
   double sdt = 0.0;
   CFZP_LANE_FOR(q, 0, d.np - 1) {
-    const int i = q / kPts, k = q - i * kPts;
+    const int i = q / kPts, k = q - i * kPts, va = veh_of_interval(d, i), il = i - d.off[va];
     const double *p = X + 7 * q, *l = nu + d.rO + 5 * q;
     double o[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int kk = 0; kk < kPts; ++kk) {  // this point's states enter the ODE rows of all six points of the interval
@@ -177,10 +306,10 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
     o[3] -= dt * (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
     o[4] -= dt * (v / sp.wb * (1.0 + tn * tn) * l[2]);
     o[5] -= dt * l[3]; o[6] -= dt * l[4];
-    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[d.rC + 7 * (i - 1) + cc];
-    if (k == kPts - 1 && i + 1 < sp.N) for (int cc = 0; cc < 7; ++cc) o[cc] -= nu[d.rC + 7 * i + cc];
-    if (q == 0) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[cc];
-    if (q == d.np - 1) { for (int cc = 0; cc < 4; ++cc) o[3 + cc] += nu[d.rF + cc]; if (sp.has_final) o[2] += nu[d.rH]; }
+    if (k == 0 && il >= 1) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[d.rC + 7 * (i - va - 1) + cc];
+    if (k == kPts - 1 && il + 1 < sp.N[va]) for (int cc = 0; cc < 7; ++cc) o[cc] -= nu[d.rC + 7 * (i - va) + cc];
+    if (k == 0 && il == 0) for (int cc = 0; cc < 7; ++cc) o[cc] += nu[7 * va + cc];
+    if (k == kPts - 1 && il + 1 == sp.N[va]) { for (int cc = 0; cc < 4; ++cc) o[3 + cc] += nu[d.rF + 5 * va + cc]; if (sp.has_final[va]) o[2] += nu[d.rF + 5 * va + 4]; }
     for (int j = 0; j < sp.n_obs; ++j) {
       double A[4][2], b[4], V[4][2], sep[2], gr[2][3];
       obstacle(sp, j, A, b, V);
@@ -194,10 +323,10 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
     for (int cc = 0; cc < 7; ++cc) out[7 * q + cc] = o[cc];
   }
   CFZP_SYNC();
-  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
-    const int b = 7 * chk_point(sp, t);
+  CFZP_LANE_FOR(t, 0, d.nchk - 1) {
+    const int b = 7 * chk_point(sp, d, t);
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
-    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    const double *cb = chk_cell(sp, d, t, 0), *cf = chk_cell(sp, d, t, 1);
     for (int r = 0; r < 4; ++r) {
       const double lb = nu[d.rT + 8 * t + r], lf = nu[d.rT + 8 * t + 4 + r];
       out[b] += cb[2 * r] * lb + cf[2 * r] * lf; out[b + 1] += cb[2 * r + 1] * lb + cf[2 * r + 1] * lf;
@@ -205,7 +334,23 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
       out[d.sT + 8 * t + r] = lb; out[d.sT + 8 * t + 4 + r] = lf;
     }
   }
-  out[d.iDt] = cfzp::wsum(sdt);
+  CFZP_SYNC();
+  for (int e = 0; e < sp.n_pairs; ++e) {  // one pair after the other: within a pair every point appears once
+    CFZP_LANE_FOR(r, 0, d.poff[e + 1] - d.poff[e] - 1) {
+      int qa, qb;
+      pair_points(sp, d, e, r, &qa, &qb);
+      const int pp = d.poff[e] + r, sl = sel[d.np * sp.n_obs + pp];
+      for (int rr = 0; rr < 2; ++rr) {
+        double gr[6], H[6][6];
+        pair_row<true>(X + 7 * qa, X + 7 * qb, sp.g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, gr, H);
+        const double nr_ = nu[d.rP + 2 * pp + rr];
+        for (int a = 0; a < 3; ++a) { out[7 * qa + a] += gr[a] * nr_; out[7 * qb + a] += gr[3 + a] * nr_; }
+        out[d.sP + 2 * pp + rr] = -nr_;
+      }
+    }
+    CFZP_SYNC();
+  }
+  out[d.iDt] = bsum(sdt);
   CFZP_SYNC();
 }
 
@@ -214,31 +359,59 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
 // the 7 variables of the point; initial rows first, terminal rows last.  dt has no position (bordered), and neither have
 // the collision slacks and rows: each pair (sigma_r, nu_r) only touches its own point's pose and is eliminated exactly
 // (assemble), which leaves a half-bandwidth of 51 whatever the number of obstacles.
+// With several vehicles the interval blocks are interleaved in time (interval t of vehicle 0, of vehicle 1, ...): the pair
+// rows couple the poses of the same (t, k) of two vehicles, which then sit (b - a) blocks apart.
 CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
   const CDims d = cdims(sp);
-  int p = 0;
-  for (int i = 0; i < 7; ++i) posc[i] = p++;
-  for (int i = 0; i < sp.N; ++i) {
-    for (int k = 0; k < kPts; ++k) {
-      const int q = i * kPts + k;
-      for (int pass = 0; pass < 2; ++pass) {  // tube block: before an interval's first point, after the very last point
-        if (pass == 0 && k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) posc[d.rC + 7 * (i - 1) + cc] = p++;
-        for (int t = 0; t < sp.n_chk; ++t)
-          if (chk_point(sp, t) == q && (pass == 0) == (k == 0)) {
-            for (int r = 0; r < 8; ++r) posx[d.sT + 8 * t + r] = p++;
-            for (int r = 0; r < 8; ++r) posc[d.rT + 8 * t + r] = p++;
-          }
-        if (pass == 1) break;
-        if (k == 3) for (int kk = 0; kk < kPts; ++kk) for (int cc = 0; cc < 5; ++cc) posc[d.rO + 5 * (i * kPts + kk) + cc] = p++;
-        for (int cc = 0; cc < 7; ++cc) posx[7 * q + cc] = p++;
-        for (int r = 0; r < d.nr; ++r) { posx[d.sO + q * d.nr + r] = -1; posc[d.rR + q * d.nr + r] = -1; }  // condensed
+  int p = 0, nmax = 0;
+  for (int a = 0; a < sp.V; ++a) nmax = sp.N[a] > nmax ? sp.N[a] : nmax;
+  for (int t = 0; t < nmax; ++t)
+    for (int a = 0; a < sp.V; ++a) {
+      if (t >= sp.N[a]) continue;
+      const int i = d.off[a] + t;
+      if (t == 0) for (int cc = 0; cc < 7; ++cc) posc[7 * a + cc] = p++;
+      for (int k = 0; k < kPts; ++k) {
+        const int q = i * kPts + k;
+        for (int pass = 0; pass < 2; ++pass) {  // tube block: before an interval's first point, after the very last point
+          if (pass == 0 && k == 0 && t >= 1) for (int cc = 0; cc < 7; ++cc) posc[d.rC + 7 * (i - a - 1) + cc] = p++;
+          for (int T = d.coff[a]; T < d.coff[a + 1]; ++T)
+            if (chk_point(sp, d, T) == q && (pass == 0) == (k == 0)) {
+              for (int r = 0; r < 8; ++r) posx[d.sT + 8 * T + r] = p++;
+              for (int r = 0; r < 8; ++r) posc[d.rT + 8 * T + r] = p++;
+            }
+          if (pass == 1) break;
+          if (k == 3) for (int kk = 0; kk < kPts; ++kk) for (int cc = 0; cc < 5; ++cc) posc[d.rO + 5 * (i * kPts + kk) + cc] = p++;
+          for (int cc = 0; cc < 7; ++cc) posx[7 * q + cc] = p++;
+          for (int r = 0; r < d.nr; ++r) { posx[d.sO + q * d.nr + r] = -1; posc[d.rR + q * d.nr + r] = -1; }  // condensed
+        }
+      }
+      if (t + 1 == sp.N[a]) {
+        for (int cc = 0; cc < 4; ++cc) posc[d.rF + 5 * a + cc] = p++;
+        posc[d.rF + 5 * a + 4] = sp.has_final[a] ? p++ : -1;
       }
     }
-  }
-  for (int i = 0; i < 4; ++i) posc[d.rF + i] = p++;
-  if (sp.has_final) posc[d.rH] = p++;
+  for (int r = 0; r < 2 * d.npp; ++r) { posx[d.sP + r] = -1; posc[d.rP + r] = -1; }  // condensed
   posx[d.iDt] = -1;
   return p;
+}
+// half-bandwidth: 51 within an interval block; with several vehicles the continuity rows reach back over the other vehicles'
+// blocks to the previous interval of their own, and the pair rows couple the poses of two vehicles
+CFZP_FN int half_bandwidth(const CSpec &sp, const int *posx, const int *posc) {
+  const CDims d = cdims(sp);
+  int kb = kCB;
+  for (int a = 0; a < sp.V; ++a)
+    for (int t = 1; t < sp.N[a]; ++t) {
+      const int i = d.off[a] + t, lo = posx[7 * (kPts * i - 1)], hi = posc[d.rC + 7 * (i - a - 1) + 6];
+      if (hi - lo > kb) kb = hi - lo;
+    }
+  for (int e = 0; e < sp.n_pairs; ++e)
+    for (int r = 0; r < d.poff[e + 1] - d.poff[e]; ++r) {
+      int qa, qb;
+      pair_points(sp, d, e, r, &qa, &qb);
+      const int lo = posx[7 * qa] < posx[7 * qb] ? posx[7 * qa] : posx[7 * qb], hi = posx[7 * qa] < posx[7 * qb] ? posx[7 * qb] : posx[7 * qa];
+      if (hi + 2 - lo > kb) kb = hi + 2 - lo;
+    }
+  return kb;
 }
 
 using cfzb::Band;
@@ -246,14 +419,14 @@ CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld 
 CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
 
 struct CWork {
-  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond;
+  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond, *condp;
   int *posx, *posc, *ipiv;
   unsigned char *sel;
 };
 CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
   const CDims d = cdims(sp);
-  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)(d.n + d.m + d.nk + 2) / 2 +
-         (size_t)(d.np * sp.n_obs + 7) / 8 + 64;
+  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
+         (size_t)(d.n + d.m + d.nk + 2) / 2 + (size_t)(d.np * sp.n_obs + d.npp + 7) / 8 + 64;
 }
 CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
   const CDims d = cdims(sp);
@@ -262,7 +435,8 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
   w.dzu = p; p += d.n; w.g = p; p += d.n; w.xl = p; p += d.n; w.xu = p; p += d.n; w.r1 = p; p += d.n; w.sig = p; p += d.n;
   w.nu = p; p += d.m; w.dnu = p; p += d.m; w.c = p; p += d.m; w.ct = p; p += d.m;
   w.rhs = p; p += d.nk; w.rhs2 = p; p += d.nk; w.bord = p; p += d.nk; w.ab = p; p += (size_t)d.nk * (3 * kb + 1);
-  w.cond = p; p += (size_t)d.np * d.nr * 5;  // per collision row: gradient (3), D, t (assemble)
+  w.cond = p; p += (size_t)d.np * d.nr * 5;  // per obstacle row: gradient (3), D, t (assemble)
+  w.condp = p; p += (size_t)d.npp * 16;     // per pair row: gradient (6), D, t
   w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
   p += (size_t)(d.n + d.m + d.nk + 2) / 2;
   w.sel = reinterpret_cast<unsigned char *>(p);
@@ -287,9 +461,9 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
   CFZP_LANE_FOR(i, 0, d.n - 1) if (px[i] >= 0) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
   CFZP_LANE_FOR(i, 0, d.m - 1) if (pc[i] >= 0) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
   CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, 6) put(Bd, pc[i], px[i], 1.0);
+  CFZP_LANE_FOR(i, 0, 7 * sp.V - 1) put(Bd, pc[i], px[7 * kPts * d.off[i / 7] + i % 7], 1.0);
   CFZP_LANE_FOR(q, 0, d.np - 1) {  // every entry written here belongs to point q alone
-    const int i = q / kPts, k = q - i * kPts, b = 7 * q;
+    const int i = q / kPts, k = q - i * kPts, b = 7 * q, va = veh_of_interval(d, i), il = i - d.off[va];
     const double *p = X + b, *l = nu + d.rO + 5 * q;
     const double cs = cos(p[2]), sn = sin(p[2]), tn = tan(p[4]), sec2 = 1.0 + tn * tn, v = p[3], wv = p[6], bk = sp.B[k];
     // objective curvature B_k dt e''
@@ -320,7 +494,7 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
     put(Bd, pc[r + 1], px[b + 2], -dt * (v * cs)); put(Bd, pc[r + 1], px[b + 3], -dt * sn);
     put(Bd, pc[r + 2], px[b + 3], -dt * tn / sp.wb); put(Bd, pc[r + 2], px[b + 4], -dt * v / sp.wb * sec2);
     put(Bd, pc[r + 3], px[b + 5], -dt); put(Bd, pc[r + 4], px[b + 6], -dt);
-    if (k == 0 && i >= 1) for (int cc = 0; cc < 7; ++cc) { put(Bd, pc[d.rC + 7 * (i - 1) + cc], px[b + cc], 1.0); put(Bd, pc[d.rC + 7 * (i - 1) + cc], px[b - 7 + cc], -1.0); }
+    if (k == 0 && il >= 1) for (int cc = 0; cc < 7; ++cc) { put(Bd, pc[d.rC + 7 * (i - va - 1) + cc], px[b + cc], 1.0); put(Bd, pc[d.rC + 7 * (i - va - 1) + cc], px[b - 7 + cc], -1.0); }
     // collision rows: gradient, slack, curvature
     for (int j = 0; j < sp.n_obs; ++j) {
       double A[4][2], bb[4], V[4][2], sep[2], gr[2][3];
@@ -350,10 +524,10 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
     }
   }
   CFZP_SYNC();
-  CFZP_LANE_FOR(t, 0, sp.n_chk - 1) {
-    const int b = 7 * chk_point(sp, t), r = d.rT + 8 * t, s = d.sT + 8 * t;
+  CFZP_LANE_FOR(t, 0, d.nchk - 1) {
+    const int b = 7 * chk_point(sp, d, t), r = d.rT + 8 * t, s = d.sT + 8 * t;
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
-    const double *cb = cfzp::cell(sp.tube, t, 0), *cf = cfzp::cell(sp.tube, t, 1);
+    const double *cb = chk_cell(sp, d, t, 0), *cf = chk_cell(sp, d, t, 1);
     double curv = 0.0;
     for (int rr = 0; rr < 4; ++rr) {
       put(Bd, pc[r + rr], px[b], cb[2 * rr]); put(Bd, pc[r + rr], px[b + 1], cb[2 * rr + 1]); put(Bd, pc[r + rr], px[s + rr], 1.0);
@@ -364,11 +538,40 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
     }
     bnd(Bd, px[b + 2], px[b + 2]) += curv;
   }
-  const int bl = 7 * (d.np - 1);
-  for (int i = 0; i < 4; ++i) put(Bd, pc[d.rF + i], px[bl + 3 + i], 1.0);
-  if (sp.has_final) put(Bd, pc[d.rH], px[bl + 2], 1.0);
+  CFZP_LANE_FOR(a, 0, sp.V - 1) {
+    const int bl = 7 * (kPts * d.off[a + 1] - 1);
+    for (int i = 0; i < 4; ++i) put(Bd, pc[d.rF + 5 * a + i], px[bl + 3 + i], 1.0);
+    if (sp.has_final[a]) put(Bd, pc[d.rF + 5 * a + 4], px[bl + 2], 1.0);
+  }
   CFZP_SYNC();
-  return 2.0 * sp.N * sp.N + delta + sp.reg_primal;  // d2L/ddt2
+  // pair rows, condensed like the obstacle rows but into the poses of both vehicles (6 x 6: D g g' + nu H); one pair after
+  // the other, because two pairs may share a point
+  for (int e = 0; e < sp.n_pairs; ++e) {
+    CFZP_LANE_FOR(r, 0, d.poff[e + 1] - d.poff[e] - 1) {
+      int qa, qb;
+      pair_points(sp, d, e, r, &qa, &qb);
+      const int pp = d.poff[e] + r, sl = w.sel[d.np * sp.n_obs + pp];
+      int at[6];
+      for (int a = 0; a < 3; ++a) { at[a] = px[7 * qa + a]; at[3 + a] = px[7 * qb + a]; }
+      for (int rr = 0; rr < 2; ++rr) {
+        double gr[6], H[6][6];
+        pair_row<true>(X + 7 * qa, X + 7 * qb, sp.g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, gr, H);
+        const int row = d.rP + 2 * pp + rr, sk = d.sP + 2 * pp + rr;
+        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] + w.r1[sk] / S, nr_ = nu[row];
+        double *cd = w.condp + (size_t)(2 * pp + rr) * 8;
+        for (int a = 0; a < 6; ++a) cd[a] = gr[a];
+        cd[6] = D; cd[7] = t;
+        for (int a = 0; a < 6; ++a) {
+          w.rhs[at[a]] -= D * t * gr[a];
+          for (int c2 = a; c2 < 6; ++c2) { const double v = D * gr[a] * gr[c2] + nr_ * H[a][c2]; if (v != 0.0) put(Bd, at[a], at[c2], v); }
+        }
+      }
+    }
+    CFZP_SYNC();
+  }
+  double nn = 0.0;
+  for (int a = 0; a < sp.V; ++a) nn += 2.0 * sp.N[a] * sp.N[a];
+  return nn + delta + sp.reg_primal;  // d2L/ddt2
 }
 
 // ---- banded LU with partial pivoting, runtime half-bandwidth, factor once / substitute many -----------------------
@@ -385,6 +588,16 @@ CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
     for (int off = 32; off > 0; off >>= 1) {
       const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
       if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
+    }
+    if (blockDim.x > 64) {  // combine the wavefronts' candidates (first largest wins, as in the serial loop)
+      __shared__ double pb[16];
+      __shared__ int pj[16];
+      const int nw = (int)(blockDim.x >> 6);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) { pb[threadIdx.x >> 6] = best; pj[threadIdx.x >> 6] = jp; }
+      __syncthreads();
+      best = pb[0]; jp = pj[0];
+      for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; }
     }
 #endif
     ipiv[j] = j + jp;
@@ -408,23 +621,110 @@ CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
   return 0;
 }
 // two right-hand sides at once (the KKT residual and the dt border)
+#if defined(__HIP_DEVICE_COMPILE__)
+// The elimination for a band too wide for LDS (the joint plan: half-bandwidth ~100 per vehicle), from global memory with all
+// wavefronts of the workgroup: the multipliers u of the pivot row go to LDS once, wavefront w updates the columns
+// j+1+w, j+1+w+nw, ... whose u is not zero, lane i owning rows j+1+i, j+65+i, ... (unit stride, the pivot column's
+// multipliers l in registers).  Three barriers per pivot plus two for the pivot search.
+constexpr int kWideMaxKb = 448;
+// NC = row chunks of 64 per column (compile time), NB = 16 / NC columns per batch: the NB * NC reads of a batch are issued
+// before its first write, so a wavefront pays one global-memory round trip per batch, not per column
+template <int NC>
+__device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
+  constexpr int NB = 16 / NC;
+  __shared__ double ulds[2 * kWideMaxKb];
+  __shared__ double pb[16];
+  __shared__ int pj[16];
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  double *ab = B.ab;
+  int ju = 0;
+  for (int j = 0; j < n; ++j) {
+    const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+    double *cj = ab + (size_t)j * ld;
+    double best = -1.0; int jp = 0;
+    for (int i = tid; i <= km; i += nt) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
+      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
+    }
+    if (lane == 0) { pb[wave] = best; pj[wave] = jp; }
+    __syncthreads();
+    best = pb[0]; jp = pj[0];
+    for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; }
+    if (tid == 0) ipiv[j] = j + jp;
+    if (!(best > 0.0)) return 1;
+    const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
+    ju = ju > reach ? ju : reach;
+    if (jp != 0) {
+      for (int q = j + tid; q <= ju; q += nt) { double *cq = ab + (size_t)q * ld + (kv + j - q); const double t = cq[0]; cq[0] = cq[jp]; cq[jp] = t; }
+    }
+    __syncthreads();  // swapped rows visible; pb/pj free again
+    const int nq = ju - j;
+    for (int t = tid; t < nq; t += nt) ulds[t] = ab[(size_t)(j + 1 + t) * ld + (kv - 1 - t)];
+    const double inv = 1.0 / cj[kv];
+    double l[NC];
+    int row[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int i = 1 + lane + 64 * c; row[c] = i <= km ? i : 0; l[c] = i <= km ? cj[kv + i] * inv : 0.0; }
+    __syncthreads();
+    for (int t0 = wave * NB; t0 < nq; t0 += nw * NB) {
+      double u[NB], x[NB][NC];
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { u[b] = t0 + b < nq ? ulds[t0 + b] : 0.0; any = any || u[b] != 0.0; }
+      if (!any) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int t = t0 + b < nq ? t0 + b : nq - 1;
+        const double *cq = ab + (size_t)(j + 1 + t) * ld + (kv - 1 - t);  // row j of column j+1+t; row j+i at cq[i]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[b][c] = cq[row[c]];  // lanes without a row read row j (and do not write)
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (t0 + b < nq && u[b] != 0.0) {
+          double *cq = ab + (size_t)(j + 1 + t0 + b) * ld + (kv - 1 - t0 - b);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) if (row[c]) cq[row[c]] = x[b][c] - l[c] * u[b];
+        }
+      }
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (row[c]) cj[kv + row[c]] = l[c];
+    }
+    __syncthreads();
+  }
+  return 0;
+}
+#endif
+
 CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld;
   const double *ab = B.ab;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool first = threadIdx.x == 0;  // the swaps and the division are not idempotent: one thread does them
+#else
+  const bool first = true;
+#endif
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
-    if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; const double t2 = b2[j]; b2[j] = b2[p]; b2[p] = t2; }
+    if (p != j) {
+      if (first) { const double t = b[j]; b[j] = b[p]; b[p] = t; const double t2 = b2[j]; b2[j] = b2[p]; b2[p] = t2; }
+      CFZP_SYNC();
+    }
     const double bj = b[j], cj = b2[j];
-    CFZP_SYNC();
-    if (bj != 0.0 || cj != 0.0) CFZP_LANE_FOR(i, 1, km) { const double l = ab[(size_t)j * ld + kv + i]; b[j + i] -= l * bj; b2[j + i] -= l * cj; }
-    CFZP_SYNC();
+    if (bj != 0.0 || cj != 0.0) {
+      CFZP_LANE_FOR(i, 1, km) { const double l = ab[(size_t)j * ld + kv + i]; b[j + i] -= l * bj; b2[j + i] -= l * cj; }
+      CFZP_SYNC();
+    }
   }
   for (int j = n - 1; j >= 0; --j) {
     const double dg = ab[(size_t)j * ld + kv];
-    b[j] /= dg; b2[j] /= dg;
-    const double bj = b[j], cj = b2[j];
-    const int lo = j - kv > 0 ? j - kv : 0;
+    const double bj = b[j] / dg, cj = b2[j] / dg;
     CFZP_SYNC();
+    if (first) { b[j] = bj; b2[j] = cj; }
+    const int lo = j - kv > 0 ? j - kv : 0;
     if (bj != 0.0 || cj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) { const double u = ab[(size_t)j * ld + kv + i - j]; b[i] -= u * bj; b2[i] -= u * cj; }
     CFZP_SYNC();
   }
@@ -437,8 +737,8 @@ CFZC_PIECE double barrier_obj(const CSpec &sp, const CWork &w, const double *X, 
     if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) bad = 1.0; else s += log(dl); }
     if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) bad = 1.0; else s += log(du); }
   }
-  if (cfzp::wmax(bad) > 0.0) return INFINITY;
-  return objective(sp, X) - mu * cfzp::wsum(s);
+  if (bmax(bad) > 0.0) return INFINITY;
+  return objective(sp, X) - mu * bsum(s);
 }
 
 // refresh the working set at the poses of X; a block whose (face, vertices) change restarts its two rows
@@ -454,6 +754,9 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
       const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
       if (nw != old) {
+#if defined(CFZC_TRACE)
+        if (!first) printf("   obs ws change q %d obs %d: %d/%d/%d%d -> %d/%d/%d%d slack %.3e %.3e z %.2e %.2e\n", q, j, old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sO + q * d.nr + 2 * j], X[d.sO + q * d.nr + 2 * j + 1], w.zl[d.sO + q * d.nr + 2 * j], w.zl[d.sO + q * d.nr + 2 * j + 1]);
+#endif
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
         cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
         for (int r = 0; r < 2; ++r) {
@@ -461,6 +764,29 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
           if (first) X[sk] = sep[r] - sp.dmin;  // pushed inside the bound afterwards
           else { const double sg = fmax(sep[r] - sp.dmin, sp.bound_push); X[sk] = sg; w.zl[sk] = mu / sg; w.nu[d.rR + q * d.nr + 2 * j + r] = -mu / sg; }
         }
+      }
+    }
+  }
+  CFZP_LANE_FOR(pp, 0, d.npp - 1) {
+    int e = 0;
+    while (pp >= d.poff[e + 1]) ++e;
+    int qa, qb;
+    pair_points(sp, d, e, pp - d.poff[e], &qa, &qb);
+    const double *pa = X + 7 * qa, *pb = X + 7 * qb;
+    double A[4][2], b[4], V[4][2];
+    veh_polygon(pb, sp.g, A, b, V);
+    const int old = first ? 0 : w.sel[d.np * sp.n_obs + pp];
+    const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old);
+    if (nw != old) {
+#if defined(CFZC_TRACE)
+      if (!first) printf("   pair ws change pp %d (pair %d r %d): %d/%d/%d%d -> %d/%d/%d%d slack %.3e %.3e z %.2e %.2e\n", pp, e, pp - d.poff[e], old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sP + 2 * pp], X[d.sP + 2 * pp + 1], w.zl[d.sP + 2 * pp], w.zl[d.sP + 2 * pp + 1]);
+#endif
+      w.sel[d.np * sp.n_obs + pp] = (unsigned char)nw;
+      for (int r = 0; r < 2; ++r) {
+        const double sep = pair_row<false>(pa, pb, sp.g, nw >> 6, (nw >> 4) & 3, r == 0 ? (nw >> 2) & 3 : nw & 3, nullptr, nullptr);
+        const int sk = d.sP + 2 * pp + r;
+        if (first) X[sk] = sep - sp.dmin;
+        else { const double sg = fmax(sep - sp.dmin, sp.bound_push); X[sk] = sg; w.zl[sk] = mu / sg; w.nu[d.rP + 2 * pp + r] = -mu / sg; }
       }
     }
   }
@@ -488,7 +814,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   CFZP_SYNC();
   refresh_working_set(sp, w, w.x, sp.mu_init, true);
   constraints(sp, w.sel, w.x, w.c);
-  CFZP_LANE_FOR(i, 0, 8 * sp.n_chk - 1) w.x[d.sT + i] = -w.c[d.rT + i];
+  CFZP_LANE_FOR(i, 0, 8 * d.nchk - 1) w.x[d.sT + i] = -w.c[d.rT + i];
   CFZP_SYNC();
   double nbd = 0.0;
   CFZP_LANE_FOR(i, 0, n - 1) {
@@ -499,7 +825,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     if (hu) w.x[i] = fmin(w.x[i], w.xu[i] - pu);
     w.zl[i] = hl ? 1.0 : 0.0; w.zu[i] = hu ? 1.0 : 0.0; nbd += hl + hu;
   }
-  const int nb = (int)cfzp::wsum(nbd);
+  const int nb = (int)bsum(nbd);
   CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] = 0.0;
   CFZP_SYNC();
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
@@ -515,17 +841,17 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     jt_nu(sp, w.sel, w.x, w.nu, w.r1);
     double theta = 0.0, cviol = 0.0, sum_nu = 0.0, sum_z = 0.0, dual_inf = 0.0;
     CFZP_LANE_FOR(i, 0, m - 1) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
-    theta = cfzp::wsum(theta); cviol = cfzp::wmax(cviol); sum_nu = cfzp::wsum(sum_nu);
+    theta = bsum(theta); cviol = bmax(cviol); sum_nu = bsum(sum_nu);
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
-    sum_z = cfzp::wsum(sum_z); dual_inf = cfzp::wmax(dual_inf);
+    sum_z = bsum(sum_z); dual_inf = bmax(dual_inf);
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
     double cmp0 = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
       if (w.xl[i] > -1e300) cmp0 = fmax(cmp0, fabs((w.x[i] - w.xl[i]) * w.zl[i]));
       if (w.xu[i] < 1e300) cmp0 = fmax(cmp0, fabs((w.xu[i] - w.x[i]) * w.zu[i]));
     }
-    cmp0 = cfzp::wmax(cmp0);
+    cmp0 = bmax(cmp0);
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
@@ -536,7 +862,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         if (w.xl[i] > -1e300) cm = fmax(cm, fabs((w.x[i] - w.xl[i]) * w.zl[i] - mu));
         if (w.xu[i] < 1e300) cm = fmax(cm, fabs((w.xu[i] - w.x[i]) * w.zu[i] - mu));
       }
-      cm = cfzp::wmax(cm);
+      cm = bmax(cm);
       if (fmax(dual_inf / s_d, fmax(cviol, cm / s_c)) <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
       else break;
     }
@@ -561,20 +887,23 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[1] += tick() - ta; ta = tick();
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (WIN) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6); else
+      if (WIN && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
+      else if (blockDim.x > 64 && kb <= 128) fail = band_factor_wide<2>(Bd, d.nk, w.ipiv);
+      else if (blockDim.x > 64 && kb <= 256) fail = band_factor_wide<4>(Bd, d.nk, w.ipiv);
+      else if (blockDim.x > 64 && kb <= kWideMaxKb) fail = band_factor_wide<7>(Bd, d.nk, w.ipiv); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (WIN && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+        if (WIN && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         tk[3] += tick() - ta;
         // bordered system: [K b; b' h] [y; s] = [r; r_dt]  ->  s = (r_dt - b'K^-1 r) / (h - b'K^-1 b)
         double bty = 0.0, btw = 0.0;
         CFZP_LANE_FOR(i, 0, d.nk - 1) { bty += w.bord[i] * w.rhs[i]; btw += w.bord[i] * w.rhs2[i]; }
-        bty = cfzp::wsum(bty); btw = cfzp::wsum(btw);
+        bty = bsum(bty); btw = bsum(btw);
         const double ddt = (-w.r1[d.iDt] - bty) / (hdd - btw);
         double curv = 0.0, dd = 0.0, bad = isfinite(ddt) ? 0.0 : 1.0;
         CFZP_LANE_FOR(i, 0, n - 1) if (i == d.iDt || w.posx[i] >= 0) w.dx[i] = i == d.iDt ? ddt : w.rhs[w.posx[i]] - w.rhs2[w.posx[i]] * ddt;
@@ -586,10 +915,20 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
           const double dn = cd[3] * (cd[0] * dp[0] + cd[1] * dp[1] + cd[2] * dp[2] + cd[4]);
           w.dnu[d.rR + r] = dn; w.dx[d.sO + r] = (dn - w.r1[d.sO + r]) / S;
         }
+        CFZP_LANE_FOR(r, 0, 2 * d.npp - 1) {  // pair rows: from the pose steps of both vehicles
+          int e = 0;
+          while (r / 2 >= d.poff[e + 1]) ++e;
+          int qa, qb;
+          pair_points(sp, d, e, r / 2 - d.poff[e], &qa, &qb);
+          const double *cd = w.condp + (size_t)r * 8, *da = w.dx + 7 * qa, *db = w.dx + 7 * qb;
+          const double S = w.sig[d.sP + r] + delta + sp.reg_primal;
+          const double dn = cd[6] * (cd[0] * da[0] + cd[1] * da[1] + cd[2] * da[2] + cd[3] * db[0] + cd[4] * db[1] + cd[5] * db[2] + cd[7]);
+          w.dnu[d.rP + r] = dn; w.dx[d.sP + r] = (dn - w.r1[d.sP + r]) / S;
+        }
         CFZP_SYNC();
         CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.dx[i]; if (!isfinite(v)) bad = 1.0; curv -= v * w.r1[i]; dd += v * v; }
         CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += w.c[i] * v - sp.reg_dual * v * v; }
-        curv = cfzp::wsum(curv); dd = cfzp::wsum(dd); bad = cfzp::wmax(bad);
+        curv = bsum(curv); dd = bsum(dd); bad = bmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
       }
@@ -616,7 +955,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         if (w.dzu[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zu[i] / w.dzu[i]);
       }
     }
-    a_pri = cfzp::wmin(a_pri); a_dual = cfzp::wmin(a_dual); dphi = cfzp::wsum(dphi);
+    a_pri = bmin(a_pri); a_dual = bmin(a_dual); dphi = bsum(dphi);
     CFZP_SYNC();
     const double phi0 = barrier_obj(sp, w, w.x, mu);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
@@ -627,7 +966,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       constraints(sp, w.sel, w.xt, w.ct);
       double th_t = 0.0;
       CFZP_LANE_FOR(i, 0, m - 1) th_t += fabs(w.ct[i]);
-      th_t = cfzp::wsum(th_t);
+      th_t = bsum(th_t);
       const double ph_t = barrier_obj(sp, w, w.xt, mu);
       bool ok = isfinite(ph_t) && isfinite(th_t) && th_t <= theta_max && w.xt[d.iDt] > 0.0;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = false; break; }
@@ -637,8 +976,35 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         if (sw) { f_type = true; ok = ph_t <= phi0 + sp.eta_phi * alpha * dphi; }
         else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
       }
+#if defined(CFZC_TRACE)
+      if (bt >= 6) printf("     bt %d alpha %.3e th_t %.6e (theta %.6e) ph_t %.10e phi0 %.10e dphi %.3e nfilt %d\n", bt, alpha, th_t, theta, ph_t, phi0, dphi, nfilt);
+#endif
       if (ok) { accepted = true; break; }
       alpha *= 0.5;
+    }
+    bool nu_done = false;
+    if (!accepted) {
+      // The filter line search has failed: typically the iterate is feasible (theta tiny), the multipliers are still
+      // off and the Newton step, which mostly corrects them, is no descent direction for the barrier function.  IPOPT
+      // would enter its restoration phase here; this solver falls back on the primal-dual merit instead: the step (or a
+      // fraction) is taken if it lowers max(scaled dual infeasibility, constraint violation) by a tenth, and the filter
+      // starts afresh.
+      const double e0 = fmax(dual_inf / s_d, cviol);
+      double af = a_pri;
+      for (int k = 0; k < 4 && !accepted; ++k, af *= 0.5) {
+        CFZP_LANE_FOR(i, 0, n - 1) w.xt[i] = w.x[i] + af * w.dx[i];
+        CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += af * w.dnu[i];
+        CFZP_SYNC();
+        constraints(sp, w.sel, w.xt, w.ct);
+        gradient(sp, w.xt, w.g);
+        jt_nu(sp, w.sel, w.xt, w.nu, w.r1);
+        double cv = 0.0, di = 0.0;
+        CFZP_LANE_FOR(i, 0, m - 1) cv = fmax(cv, fabs(w.ct[i]));
+        CFZP_LANE_FOR(i, 0, n - 1) di = fmax(di, fabs(w.g[i] + w.r1[i] - (w.zl[i] + a_dual * w.dzl[i]) + (w.zu[i] + a_dual * w.dzu[i])));
+        cv = bmax(cv); di = bmax(di);
+        if (isfinite(cv) && isfinite(di) && w.xt[d.iDt] > 0.0 && fmax(di / s_d, cv) <= 0.9 * e0) { accepted = true; alpha = af; nu_done = true; f_type = true; nfilt = 0; }
+        else { CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] -= af * w.dnu[i]; CFZP_SYNC(); }
+      }
     }
     if (!accepted) { status = 2; break; }
 #if defined(CFZC_TRACE)
@@ -648,7 +1014,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;
     }
-    CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += alpha * w.dnu[i];
+    if (!nu_done) CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += alpha * w.dnu[i];
     CFZP_LANE_FOR(i, 0, n - 1) {
       w.x[i] = w.xt[i];
       if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; w.zl[i] = fmin(fmax(w.zl[i] + a_dual * w.dzl[i], mu / (sp.kappa_sigma * dl)), sp.kappa_sigma * mu / dl); }

@@ -286,14 +286,14 @@ __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec 
 #define CFZC_BOUNDS 512
 #endif
 __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
-                              const long long *slab_off, int kb, int32_t *oi, double *od) {
+                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od) {
   const int b = blockIdx.x;
   extern __shared__ double colloc_win[];  // the 103 band columns the elimination is working on, then the right-hand sides
   if (b >= B) return;
 #if defined(CFZC_NOWIN)
-  cfzc::solve_colloc<false>(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + cfzc::kOutD * b, nullptr);
+  cfzc::solve_colloc<false>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, nullptr);
 #else
-  cfzc::solve_colloc<true>(specs[b], X + x_off[b], slab + slab_off[b], kb, oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
+  cfzc::solve_colloc<true>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
 #endif
 }
 
@@ -812,10 +812,13 @@ static void radau5_tables(double A[6][6], double B[6]) {
   }
 }
 
-int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
-               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
-               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
-  if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
+// B collocation problems in one launch; problem b plans nveh[b] vehicles with one shared dt (1: the single-vehicle plan).
+// Vehicles are numbered through all problems: n_sets, init_pose, final_heading, tube, guess and traj are per vehicle,
+// dt0, dt, status, iters, cost per problem; pairs[b]: vehicle pairs (local indices) with a separation row, per problem.
+static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<std::vector<std::pair<int, int>>> &pairs, const cfz_spec *spec,
+                      const cfz_colloc_options *co, const int32_t *n_sets, const double *init_pose, const double *final_heading,
+                      const double *tube, const double *guess, const double *dt0, double *traj, double *dt, int32_t *status,
+                      int32_t *iters, double *cost) {
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
@@ -829,24 +832,41 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
     for (int i = 0; i < 4; ++i) { o[2 * i] = spec->A_obs[j][i][0]; o[2 * i + 1] = spec->A_obs[j][i][1]; o[8 + i] = spec->b_obs[j][i];
                                   o[12 + 2 * i] = V[i][0]; o[13 + 2 * i] = V[i][1]; }
   }
-  double *dtab = nullptr, *dtube = nullptr;
+  int nv_total = 0;
   long long nt = 0;
-  for (int b = 0; b < B; ++b) { if (n_sets[b] < 2) return fail("a plan needs at least two strategy steps"); nt += (long long)(n_sets[b] - 1) * 24; }
+  for (int b = 0; b < B; ++b) {
+    if (nveh[b] < 1 || nveh[b] > cfzc::kMaxVeh || (int)pairs[b].size() > cfzc::kMaxPairs) return fail("problem size outside compiled limits");
+    for (int a = 0; a < nveh[b]; ++a) { if (n_sets[nv_total + a] < 2) return fail("a plan needs at least two strategy steps"); nt += (long long)(n_sets[nv_total + a] - 1) * 24; }
+    nv_total += nveh[b];
+  }
+  double *dtab = nullptr, *dtube = nullptr;
   HIP_OK(hipMalloc(&dtab, tab.size() * 8)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8));
   HIP_OK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
   std::vector<cfzc::CSpec> specs(B);
   std::vector<long long> xoff(B), soff(B);
+  std::vector<int32_t> kbs(B);
   long long nx = 0, ns = 0, to = 0;
-  int kb = 0;
+  int v0 = 0;
   for (int b = 0; b < B; ++b) {
     cfzc::CSpec &p = specs[b];
     memset(&p, 0, sizeof p);
-    p.Nps = co->N_per_set; p.n_chk = n_sets[b] - 1; p.N = p.Nps * p.n_chk; p.n_obs = spec->n_obs;
-    p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
+    p.V = nveh[b]; p.Nps = co->N_per_set; p.n_obs = spec->n_obs; p.n_pairs = (int)pairs[b].size();
+    long long npts = 0;
+    for (int a = 0; a < p.V; ++a) {
+      const int v = v0 + a;
+      p.n_chk[a] = n_sets[v] - 1; p.N[a] = p.Nps * p.n_chk[a];
+      p.has_final[a] = final_heading && final_heading[v] == final_heading[v]; p.final_heading[a] = p.has_final[a] ? final_heading[v] : 0.0;
+      for (int i = 0; i < 3; ++i) p.init_pose[a][i] = init_pose[v * 3 + i];
+      p.tube[a] = dtube + to; to += (long long)p.n_chk[a] * 24;
+      npts += (long long)p.N[a] * cfzc::kPts;
+    }
+    for (int e = 0; e < p.n_pairs; ++e) {
+      p.pair_a[e] = pairs[b][e].first; p.pair_b[e] = pairs[b][e].second;
+      if (p.pair_a[e] < 0 || p.pair_b[e] >= p.V || p.pair_a[e] >= p.pair_b[e]) return fail("bad vehicle pair");
+    }
     p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
     p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
-    for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
     memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
     radau5_tables(p.A, p.B);
     p.tol = co->tol; p.constr_viol_tol = co->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = co->mu_init;
@@ -855,40 +875,53 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
     // delta_c = 1e-7: while a vehicle stands still with its heading along an axis, the six ODE rows of x (or y) of an
     // interval only see the rank-5 derivative matrix and their multipliers drift (288 iterations at 1e-9, 38 at 1e-7)
     p.reg_primal = 1e-8; p.reg_dual = 1e-7; p.curv_kappa = co->curv_kappa;
-    p.obs_tab = dtab; p.tube = dtube + to;
-    kb = std::max(kb, cfzc::half_bandwidth(p));
-    xoff[b] = nx; nx += 7LL * p.N * cfzc::kPts + 1; to += (long long)p.n_chk * 24;
+    p.obs_tab = dtab;
+    {  // half-bandwidth of this problem's ordering (51 for one vehicle)
+      const cfzc::CDims d = cfzc::cdims(p);
+      std::vector<int> pos((size_t)d.n + d.m);
+      if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
+      kbs[b] = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
+    }
+    xoff[b] = nx; nx += 7 * npts + 1;
+    soff[b] = ns; ns += (long long)cfzc::work_doubles(p, kbs[b]);
+    v0 += p.V;
   }
-  for (int b = 0; b < B; ++b) { soff[b] = ns; ns += (long long)cfzc::work_doubles(specs[b], kb); }
   std::vector<double> X((size_t)nx);
   long long g0 = 0;
   for (int b = 0; b < B; ++b) {  // guess: x, y, psi, v, delta, a, w at every point (:629-636), dt0 (:388-389)
-    const long long np_ = (long long)specs[b].N * cfzc::kPts;
+    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
     memcpy(X.data() + xoff[b], guess + g0 * 7, (size_t)np_ * 7 * 8);
     X[(size_t)(xoff[b] + 7 * np_)] = dt0[b];
     g0 += np_;
   }
-  cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr;
+  cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr, *dkb = nullptr;
   HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
   HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * cfzc::kOutD * 8));
+  HIP_OK(hipMalloc(&dkb, (size_t)B * 4));
   HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
   const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
   HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, kb, doi, dod);
+  // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
+  // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
+  int threads = 64;
+  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) threads = 512;
+  if (const char *e = std::getenv("CFZ_COLLOC_THREADS")) threads = std::max(64, std::min(512, std::atoi(e) / 64 * 64));
+  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(threads), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
   HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost));
-  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
+  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod, (void *)dkb}) (void)hipFree(p);
   g0 = 0;
   for (int b = 0; b < B; ++b) {
-    const long long np_ = (long long)specs[b].N * cfzc::kPts;
+    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
     memcpy(traj + g0 * 7, X.data() + xoff[b], (size_t)np_ * 7 * 8);
     dt[b] = X[(size_t)(xoff[b] + 7 * np_)];
     g0 += np_;
@@ -897,11 +930,31 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
     if (cost) cost[b] = od[(size_t)cfzc::kOutD * b];
     if (std::getenv("CFZ_COLLOC_PROFILE")) {  // milliseconds per phase (100 MHz device clock)
       const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
-      fprintf(stderr, "cfz_colloc[%d]: %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
-              b, oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
+      fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
+              b, specs[b].V, kbs[b], oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
     }
   }
   return 0;
+}
+
+int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
+  std::vector<int32_t> one((size_t)B, 1);
+  std::vector<std::vector<std::pair<int, int>>> none((size_t)B);
+  return colloc_run(device, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+}
+
+int cfz_joint_colloc(int device, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, double dt0,
+                     int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  if (V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !traj || !dt || n_pairs < 0) return fail("bad argument");
+  std::vector<std::vector<std::pair<int, int>>> pr(1);
+  if (pairs) for (int e = 0; e < n_pairs; ++e) pr[0].push_back({pairs[2 * e], pairs[2 * e + 1]});
+  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr[0].push_back({a, b});  // :56-58 all pairs
+  const int32_t nv = V;
+  return colloc_run(device, 1, &nv, pr, spec, co, n_sets, init_pose, final_heading, tube, guess, &dt0, traj, dt, status, iters, cost);
 }
 
 void cfz_default_colloc_options(cfz_colloc_options *o) {

@@ -28,7 +28,7 @@
 // iterations over the lanes, with a workgroup barrier before anybody reads what another lane wrote.  On the CPU the
 // marked loops simply run in full.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CFZP_LANE_FOR(q, lo, hi) for (int q = (lo) + (int)threadIdx.x; q <= (hi); q += 64)
+#define CFZP_LANE_FOR(q, lo, hi) for (int q = (lo) + (int)threadIdx.x; q <= (hi); q += (int)blockDim.x)
 #define CFZP_SYNC() __syncthreads()
 #else
 #define CFZP_LANE_FOR(q, lo, hi) for (int q = (lo); q <= (hi); ++q)

@@ -7,17 +7,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(ROOT, "tests", "_build", "libcfz_colloc_emu.so")
-_INTS = "N Nps n_chk n_obs has_final max_iter max_backtrack filter_cap pad0 pad1".split()
 _OPTS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
          "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal reg_dual curv_kappa").split()
+MAX_VEH, MAX_PAIRS = 4, 6
 
 
 class CSpec(C.Structure):
-    _fields_ = ([(k, C.c_int) for k in _INTS] +
-                [(k, C.c_double) for k in "wb dmin shrink final_heading dt0".split()] +
-                [("init_pose", C.c_double * 3), ("bounds", C.c_double * 12), ("g", C.c_double * 4),
-                 ("A", C.c_double * 36), ("B", C.c_double * 6)] + [(k, C.c_double) for k in _OPTS] +
-                [("obs_tab", C.c_void_p), ("tube", C.c_void_p)])
+    _fields_ = ([(k, C.c_int) for k in "V Nps n_obs n_pairs max_iter max_backtrack filter_cap pad0".split()] +
+                [("N", C.c_int * MAX_VEH), ("n_chk", C.c_int * MAX_VEH), ("has_final", C.c_int * MAX_VEH),
+                 ("pair_a", C.c_int * MAX_PAIRS), ("pair_b", C.c_int * MAX_PAIRS)] +
+                [(k, C.c_double) for k in "wb dmin shrink dt0".split()] +
+                [("final_heading", C.c_double * MAX_VEH), ("init_pose", C.c_double * (3 * MAX_VEH)), ("bounds", C.c_double * 12),
+                 ("g", C.c_double * 4), ("A", C.c_double * 36), ("B", C.c_double * 6)] + [(k, C.c_double) for k in _OPTS] +
+                [("obs_tab", C.c_void_p), ("tube", C.c_void_p * MAX_VEH)])
 
 
 def build(force=False):
@@ -41,13 +43,27 @@ def lib():
 
 
 def make_spec(nlp, opt):
-    """nlp: oracle.colloc_nlp.CollocNlp, opt: oracle.ipm.IpmOptions -> (CSpec, keep-alive arrays)."""
+    """nlp: oracle.colloc_nlp.JointCollocNlp (or CollocNlp), opt: oracle.ipm.IpmOptions -> (CSpec, keep-alive arrays)."""
     s = CSpec()
-    s.N, s.Nps, s.n_chk, s.n_obs, s.has_final = nlp.N, nlp.Nps, nlp.n_chk, nlp.n_obs, int(nlp.final_heading is not None)
+    s.V, s.Nps, s.n_obs, s.n_pairs = nlp.V, nlp.Nps, nlp.n_obs, len(nlp.pairs)
     s.max_iter, s.max_backtrack, s.filter_cap = opt.max_iter, opt.max_backtrack, opt.filter_cap
     s.wb, s.dmin, s.shrink = nlp.wb, nlp.dmin, nlp.shrink
-    s.final_heading = float(nlp.final_heading) if nlp.final_heading is not None else 0.0
-    s.init_pose[:] = list(nlp.init_pose)
+    keep = []
+    for a, v in enumerate(nlp.veh):
+        s.N[a], s.n_chk[a] = nlp.N[a], nlp.n_chk[a]
+        fh = v.get("final_heading")
+        s.has_final[a], s.final_heading[a] = int(fh is not None), float(fh) if fh is not None else 0.0
+        for i in range(3):
+            s.init_pose[3 * a + i] = float(v["init_pose"][i])
+        tube = np.zeros((nlp.n_chk[a], 2, 12))
+        for i in range(1, len(v["tube"])):
+            for f, key in enumerate(("back", "front")):
+                A, b = v["tube"][i][key]
+                tube[i - 1, f, :8], tube[i - 1, f, 8:] = np.asarray(A, float).ravel(), b
+        keep.append(tube)
+        s.tube[a] = tube.ctypes.data
+    for e, (a, b) in enumerate(nlp.pairs):
+        s.pair_a[e], s.pair_b[e] = a, b
     s.bounds[:] = list(nlp.bounds)
     s.g[:] = list(nlp.g)
     s.A[:] = list(nlp.A.ravel())
@@ -57,13 +73,9 @@ def make_spec(nlp, opt):
     tab = np.zeros((max(nlp.n_obs, 1), 20))
     for j in range(nlp.n_obs):
         tab[j, :8], tab[j, 8:12], tab[j, 12:] = nlp.A_obs[j].ravel(), nlp.b_obs[j], np.asarray(nlp.PV[j]).ravel()
-    tube = np.zeros((nlp.n_chk, 2, 12))
-    for i in range(1, nlp.S):
-        for f, key in enumerate(("back", "front")):
-            A, b = nlp.tube[i][key]
-            tube[i - 1, f, :8], tube[i - 1, f, 8:] = np.asarray(A, float).ravel(), b
-    s.obs_tab, s.tube = tab.ctypes.data, tube.ctypes.data
-    return s, (tab, tube)
+    s.obs_tab = tab.ctypes.data
+    keep.append(tab)
+    return s, keep
 
 
 def _p(a):
@@ -72,15 +84,18 @@ def _p(a):
 
 def dims(nlp, opt):
     s, keep = make_spec(nlp, opt)
-    out = np.zeros(14, np.int32)
+    out = np.zeros(16, np.int32)
     lib().cfzc_emu_dims(C.byref(s), _p(out))
-    return dict(zip("np nr n m nk iDt sO sT rO rC rR rT rF rH".split(), map(int, out)))
+    return dict(zip("np nr n m nk iDt sO sT sP rO rC rR rT rF rP npp".split(), map(int, out)))
 
 
 def select(nlp, opt, X, prev=None):
+    """Working-set codes (obstacles [np, n_obs] then pairs [npp], flat); prev: codes to keep with hysteresis."""
     s, keep = make_spec(nlp, opt)
-    sel = np.zeros((nlp.np, nlp.n_obs), np.uint8) if prev is None else np.array(prev, np.uint8)
-    lib().cfzc_emu_select(C.byref(s), _p(np.ascontiguousarray(X)), _p(sel))
+    sel = np.zeros(nlp.np * nlp.n_obs + nlp.npp, np.uint8) if prev is None else np.array(prev, np.uint8).ravel()
+    Xf = np.zeros(nlp.n)
+    Xf[: len(X)] = X
+    lib().cfzc_emu_select(C.byref(s), _p(Xf), _p(sel), int(prev is None))
     return sel
 
 

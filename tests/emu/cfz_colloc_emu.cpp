@@ -4,23 +4,33 @@
 
 #include "../../conflict_rez_amd/csrc/cfz_colloc.inl"
 
+static int order_half_bandwidth(const cfzc::CSpec *sp) {
+  const cfzc::CDims d = cfzc::cdims(*sp);
+  int *px = (int *)malloc(sizeof(int) * (d.n + d.m)), *pc = px + d.n;
+  const int cnt = cfzc::build_order(*sp, px, pc);
+  const int kb = cnt == d.nk ? cfzc::half_bandwidth(*sp, px, pc) : -1;
+  free(px);
+  return kb;
+}
+
 extern "C" {
 int cfzc_emu_sizeof_spec(void) { return (int)sizeof(cfzc::CSpec); }
 void cfzc_emu_dims(const cfzc::CSpec *sp, int *out) {
   const cfzc::CDims d = cfzc::cdims(*sp);
-  const int v[] = {d.np, d.nr, d.n, d.m, d.nk, d.iDt, d.sO, d.sT, d.rO, d.rC, d.rR, d.rT, d.rF, d.rH};
+  const int v[] = {d.np, d.nr, d.n, d.m, d.nk, d.iDt, d.sO, d.sT, d.sP, d.rO, d.rC, d.rR, d.rT, d.rF, d.rP, d.npp};
   memcpy(out, v, sizeof(v));
 }
-// working set at X's poses (sel: np * n_obs bytes, in: previous codes or zeros with first = 1)
-void cfzc_emu_select(const cfzc::CSpec *sp, const double *X, unsigned char *sel) {
-  for (int q = 0; q < sp->N * cfzc::kPts; ++q) {
-    const double *p = X + 7 * q;
-    for (int j = 0; j < sp->n_obs; ++j) {
-      double A[4][2], b[4], V[4][2];
-      cfzc::obstacle(*sp, j, A, b, V);
-      sel[q * sp->n_obs + j] = (unsigned char)cfz::select_rows(A, b, V, p[0], p[1], cos(p[2]), sin(p[2]), sp->g, sel[q * sp->n_obs + j]);
-    }
-  }
+int cfzc_emu_half_bandwidth(const cfzc::CSpec *sp) { return order_half_bandwidth(sp); }
+// working set at X's poses (sel: np * n_obs + npp bytes; first = 1: from scratch, else with hysteresis from the codes in sel)
+void cfzc_emu_select(const cfzc::CSpec *sp, const double *X, unsigned char *sel, int first) {
+  const cfzc::CDims d = cfzc::cdims(*sp);
+  double *slab = (double *)calloc(cfzc::work_doubles(*sp, 1), sizeof(double));
+  cfzc::CWork w = cfzc::carve(*sp, 1, slab);
+  memcpy(w.x, X, sizeof(double) * d.n);
+  memcpy(w.sel, sel, d.np * sp->n_obs + d.npp);
+  cfzc::refresh_working_set(*sp, w, w.x, 1e-3, first != 0);
+  memcpy(sel, w.sel, d.np * sp->n_obs + d.npp);
+  free(slab);
 }
 void cfzc_emu_eval(const cfzc::CSpec *sp, const unsigned char *sel, const double *X, const double *nu, double *f, double *c,
                    double *g, double *jtnu) {
@@ -35,12 +45,13 @@ void cfzc_emu_eval(const cfzc::CSpec *sp, const unsigned char *sel, const double
 int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *X, const double *nu, const double *sig,
                  double delta, double *K) {
   const cfzc::CDims d = cfzc::cdims(*sp);
-  const int kb = 400 < d.nk - 1 ? 400 : d.nk - 1;
+  int kb = order_half_bandwidth(sp) + 64;
+  if (kb > d.nk - 1) kb = d.nk - 1;
   double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
   cfzc::CWork w = cfzc::carve(*sp, kb, slab);
   cfzc::build_order(*sp, w.posx, w.posc);
   memcpy(w.x, X, sizeof(double) * d.n); memcpy(w.nu, nu, sizeof(double) * d.m); memcpy(w.sig, sig, sizeof(double) * d.n);
-  memcpy(w.sel, sel, d.np * sp->n_obs);
+  memcpy(w.sel, sel, d.np * sp->n_obs + d.npp);
   const cfzc::Band Bd = {w.ab, kb, 3 * kb + 1};
   const double hdd = cfzc::assemble(*sp, w, Bd, delta);
   const int nt = d.n + d.m;
@@ -59,9 +70,9 @@ int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *
   free(nat); free(slab);
   return bw;
 }
-int cfzc_emu_half_bandwidth(const cfzc::CSpec *sp) { return cfzc::half_bandwidth(*sp); }
 int cfzc_emu_solve(const cfzc::CSpec *sp, double *X, int *out_i, double *out_d) {
-  const int kb = cfzc::half_bandwidth(*sp);
+  const int kb = order_half_bandwidth(sp);
+  if (kb < 0) return -2;
   double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
   if (!slab) return -1;
   cfzc::solve_colloc<false>(*sp, X, slab, kb, out_i, out_d, nullptr);

@@ -40,8 +40,9 @@ def warm_start(tube, p, fh):
 
 def colloc_guess(nlp, z):
     """interp_ws_for_collocation (vehicle.py:298-358) + dt0 = t_end / N (:388)."""
-    t_i = np.concatenate([i + nlp.tau for i in range(nlp.N)]) / nlp.N * z["t"][-1]
-    return nlp.pack({k: interp1d(z["t"], z[k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")}, z["t"][-1] / nlp.N)
+    N = nlp.N[0]
+    t_i = np.concatenate([i + nlp.tau for i in range(N)]) / N * z["t"][-1]
+    return nlp.pack({k: interp1d(z["t"], z[k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")}, z["t"][-1] / N)
 
 
 def test_collocation_tables():
@@ -63,7 +64,7 @@ def test_colloc_source_values_and_derivatives(plans):
     nlp = CollocNlp(p[0], tube[:3], sp.A_obs, sp.b_obs, N_per_set=2, final_heading=0.3)
     opt = ipm.IpmOptions(**COLLOC_OPT)
     d = ce.dims(nlp, opt)
-    assert (d["n"], d["m"], d["iDt"], d["sO"], d["sT"], d["rR"], d["rH"]) == (nlp.n, nlp.m, nlp.iDt, nlp.sO, nlp.sT, nlp.rR, nlp.rH)
+    assert (d["n"], d["m"], d["iDt"], d["sO"], d["sT"], d["rR"], d["rF"], d["rP"]) == (nlp.n, nlp.m, nlp.iDt, nlp.sO, nlp.sT, nlp.rR, nlp.rF, nlp.rP)
     rng = np.random.default_rng(0)
     X = np.zeros(nlp.n)
     P = X[: nlp.iDt].reshape(nlp.np, 7)
@@ -73,7 +74,7 @@ def test_colloc_source_values_and_derivatives(plans):
     X[nlp.sO :] = rng.uniform(0.1, 1.0, nlp.n - nlp.sO)
     nu = rng.standard_normal(nlp.m)
     sel = ce.select(nlp, opt, X)
-    assert (sel == nlp.select(X)).all() and len(set(sel.ravel() >> 6)) == 2  # both kinds of certificate are exercised
+    assert (sel == nlp.select(X).ravel()).all() and len(set(sel.ravel() >> 6)) == 2  # both kinds of certificate are exercised
     f, c, g, jt = ce.evaluate(nlp, opt, sel, X, nu)
     assert abs(f - nlp.f(X)) < 1e-12 and np.abs(c - nlp.cons(X, sel)).max() < 1e-12
     h, n = 1e-6, nlp.n
@@ -97,7 +98,7 @@ def test_colloc_source_values_and_derivatives(plans):
     assert np.abs(K[E]).max() == 0.0 and np.abs(K[:, E]).max() == 0.0
     free = CollocNlp(p[0], tube[:3], sp.A_obs[:0], sp.b_obs[:0], N_per_set=2)  # no obstacles, free terminal heading
     Xf, nuf = np.append(X[: free.iDt + 1], X[nlp.sT :]), rng.standard_normal(free.m)
-    Kf, bwf = ce.kkt(free, opt, np.zeros((free.np, 0), np.uint8), Xf, nuf)
+    Kf, bwf = ce.kkt(free, opt, np.zeros(0, np.uint8), Xf, nuf)
     assert bwf <= 51 and Kf.shape[0] == free.n + free.m
 
 
@@ -117,7 +118,7 @@ def test_colloc_source_solves_reference_problem(plans, agent):
     sol = nlp.unpack(res["X"])
     rr = reference_residuals(nlp, sol)
     assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9 and abs(rr["cost"] - res["f"]) < 1e-9 * max(1, res["f"])
-    T_end = sol["dt"] * nlp.N
+    T_end = sol["dt"] * nlp.N[0]
     assert 2.0 < T_end < 0.1 * (len(p) - 1) * 1.5 and abs(sol["psi"][-1, -1] - fh) < 1e-2
     # faster than the warm start's fixed timetable would allow at these input costs, and it actually moved
     assert np.hypot(sol["x"][-1, -1] - p[0, 0], sol["y"][-1, -1] - p[0, 1]) > 1.0
@@ -153,7 +154,7 @@ def test_colloc_on_gpu(plans):
         sol["dt"] = r["dt"]
         poses = r["traj"].reshape(-1, 7)[:, :3]
         l, m, _ = eng.dual_ws(poses)
-        sol["l"], sol["m"] = l.reshape(nlp.N, 6, -1), m.reshape(nlp.N, 6, -1)
+        sol["l"], sol["m"] = l.reshape(nlp.N[0], 6, -1), m.reshape(nlp.N[0], 6, -1)
         rr = reference_residuals(nlp, sol)
         assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9 and abs(rr["cost"] - r["cost"]) < 1e-8 * max(1.0, r["cost"])
         if a in ("vehicle_1", "vehicle_3"):  # the CPU build from the same guess (seconds there; the others take longer)
@@ -186,5 +187,142 @@ def test_planner_single_problems_then_joint_dual_ws(tmp_path):
     mvp.joint_dual_ws(K=5)
     n01 = min(mvp.vehicles["vehicle_0"].N, mvp.vehicles["vehicle_1"].N)
     assert len(mvp.joint_l0["vehicle_0"]["vehicle_1"]) == n01 and mvp.joint_s0[("vehicle_0", "vehicle_1")][0][5].shape == (2,)
-    with pytest.raises(NotImplementedError):
-        mvp.solve_final_problem_obca()
+    # the four-vehicle joint solve itself takes about a minute on the GPU: tools/joint_timing.py; two vehicles below
+
+
+# ---- the joint plan (multi_vehicle_planner.py:343-480): several vehicles, one shared dt, pairwise separation rows ----
+def _joint_problem(plans, agents, nsets, n_obs=6, nps=2, headings=None):
+    from oracle.colloc_nlp import JointCollocNlp
+
+    sp = scenarios.parking_lot_spec()
+    vehs = []
+    for i, (a, ns) in enumerate(zip(agents, nsets)):
+        tube, p = plans[a]
+        tube = tube[:ns] if ns else tube
+        fh = (float(p[-1, 2]) if not ns else 0.3) if headings is None else headings[i]
+        vehs.append(dict(init_pose=p[0], tube=tube, final_heading=fh))
+    return JointCollocNlp(vehs, sp.A_obs[:n_obs], sp.b_obs[:n_obs], N_per_set=nps), sp
+
+
+def test_joint_source_values_and_derivatives(plans):
+    """Three vehicles with plans of different lengths, one without terminal heading, all pairs: values against the numpy
+    statement; gradient, J'nu and the assembled matrix (time-interleaved blocks, dt border, obstacle AND pair rows condensed,
+    6 x 6 pair curvature) against central differences / the Schur complement of the full KKT matrix."""
+    import colloc_emu_binding as ce
+
+    nlp, _ = _joint_problem(plans, ["vehicle_0", "vehicle_1", "vehicle_3"], [3, 4, 3], n_obs=2, headings=[0.3, None, 0.3])
+    opt = ipm.IpmOptions(**COLLOC_OPT)
+    d = ce.dims(nlp, opt)
+    assert (d["n"], d["m"], d["sP"], d["rP"], d["rF"], d["npp"]) == (nlp.n, nlp.m, nlp.sP, nlp.rP, nlp.rF, nlp.npp) and nlp.npp == 72
+    rng = np.random.default_rng(1)
+    X = np.zeros(nlp.n)
+    P = X[: nlp.iDt].reshape(nlp.np, 7)
+    for a in range(nlp.V):  # the vehicles scattered around one spot, so that pair rows of both kinds are near active
+        blk = P[nlp.off[a] * 6 : nlp.off[a + 1] * 6]
+        blk[:, 0] = 16 + 4.0 * a + 0.5 * rng.standard_normal(len(blk))
+        blk[:, 1] = 17 + 1.5 * a + 0.5 * rng.standard_normal(len(blk))
+        blk[:, 2] = rng.uniform(-3, 3, len(blk))
+    P[:, 3:] = 0.3 * rng.standard_normal((nlp.np, 4))
+    X[nlp.iDt] = 0.7
+    X[nlp.sO :] = rng.uniform(0.1, 1.0, nlp.n - nlp.sO)
+    nu = rng.standard_normal(nlp.m)
+    nu[nlp.rF + 5 * 1 + 4] = 0.0  # the dead heading row of the vehicle without a terminal heading
+    sel = ce.select(nlp, opt, X)
+    assert (sel == nlp.select(X)).all() and set((sel[nlp.np * nlp.n_obs :] >> 6).tolist()) == {1, 2}
+    f, c, g, jt = ce.evaluate(nlp, opt, sel, X, nu)
+    assert abs(f - nlp.f(X)) < 1e-11 and np.abs(c - nlp.cons(X, sel)).max() < 1e-11
+    h, n = 1e-6, nlp.n
+    gfd, J, H = np.zeros(n), np.zeros((nlp.m, n)), np.zeros((n, n))
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = h
+        fp, cp, gp, jp = ce.evaluate(nlp, opt, sel, X + e, nu)
+        fm, cm, gm, jm = ce.evaluate(nlp, opt, sel, X - e, nu)
+        gfd[i], J[:, i], H[:, i] = (fp - fm) / (2 * h), (cp - cm) / (2 * h), (gp + jp - gm - jm) / (2 * h)
+    assert np.abs(g - gfd).max() < 1e-7 and np.abs(jt - J.T @ nu).max() < 1e-6
+    sig = np.zeros(n)
+    sig[nlp.sO :] = rng.uniform(0.5, 50.0, n - nlp.sO)
+    K, bw = ce.kkt(nlp, opt, sel, X, nu, sig=sig)
+    M = np.block([[H + np.diag(sig + opt.reg_primal), J.T], [J, -opt.reg_dual * np.eye(nlp.m)]])
+    dead = [n + nlp.rF + 5 * 1 + 4]
+    E = np.r_[nlp.sO : nlp.sT, nlp.sP : n, n + nlp.rR : n + nlp.rT, n + nlp.rP : n + nlp.m]
+    R = np.setdiff1d(np.arange(n + nlp.m), np.r_[E, dead])
+    schur = M[np.ix_(R, R)] - M[np.ix_(R, E)] @ np.linalg.solve(M[np.ix_(E, E)], M[np.ix_(E, R)])
+    assert np.abs(K[np.ix_(R, R)] - schur).max() < 1e-8 * np.abs(schur).max() and np.abs(K - K.T).max() == 0.0
+    assert np.abs(K[E]).max() == 0.0 and np.abs(K[dead]).max() == 0.0 and bw <= ce.half_bandwidth(nlp, opt)
+
+
+def _joint_guess(plans, agents, jn, sp, nps):
+    """Every vehicle's single plan (the CPU build), packed with the mean dt (multi_vehicle_planner.py:361, :370-385)."""
+    import colloc_emu_binding as ce
+
+    singles = []
+    for a in agents:
+        tube, p = plans[a]
+        fh = float(p[-1, 2])
+        nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=nps, final_heading=fh)
+        res = ce.solve(nlp, colloc_guess(nlp, warm_start(tube, p, fh)), ipm.IpmOptions(**COLLOC_OPT))
+        assert res["status"] == 0
+        singles.append(nlp.unpack(res["X"]))
+    return jn.pack(singles, float(np.mean([s["dt"] for s in singles]))), singles
+
+
+def test_joint_source_solves_pair(plans):
+    """Vehicles 2 and 3 at full size (N_per_set = 5): on one clock their single plans pass each other with 0.08 m to spare in
+    one separation row; the joint plan converges, every vehicle's own rows and the reference's vehicle-vehicle rows (with
+    the duals rebuilt from the poses) hold, and both plans now run on the shared dt."""
+    import colloc_emu_binding as ce
+    from oracle.colloc_nlp import pair_residuals
+
+    agents = ["vehicle_2", "vehicle_3"]
+    jn, sp = _joint_problem(plans, agents, [0, 0], nps=5)
+    X0, singles = _joint_guess(plans, agents, jn, sp, 5)
+    Xf = np.zeros(jn.n)
+    Xf[: len(X0)] = X0
+    c0 = jn.cons(Xf, jn.select(Xf))
+    assert c0[jn.rP :].min() < 0.2  # the guess is close to contact in some pair row
+    res = ce.solve(jn, X0, ipm.IpmOptions(**COLLOC_OPT))
+    assert res["status"] == 0 and res["iters"] < 60 and ce.half_bandwidth(jn, ipm.IpmOptions(**COLLOC_OPT)) <= 128
+    sols, duals = jn.unpack(res["X"])
+    for a in range(2):
+        rr = reference_residuals(jn, sols[a], a)
+        assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9 and sols[a]["dt"] == sols[0]["dt"]
+    pr = pair_residuals(jn, sols, duals)
+    assert pr["eq"] < 1e-9 and pr["ineq"] < 1e-9 and pr["bound"] == 0.0
+    cost = sum(reference_residuals(jn, sols[a], a)["cost"] for a in range(2))
+    assert abs(cost - res["f"]) < 1e-8 * res["f"] and cost >= sum(reference_residuals(jn, singles[a], a)["cost"] for a in range(2)) - 1e-6
+
+
+@pytest.mark.gpu
+def test_joint_colloc_on_gpu(plans, tmp_path):
+    """cfz_joint_colloc against the CPU build of the same source, and MultiVehiclePlanner.solve_single_problems ->
+    solve_final_problem_obca (multi_vehicle_planner.py `main`) for two vehicles."""
+    import colloc_emu_binding as ce
+    from conflict_rez_amd import engine
+    from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
+    from conflict_rez_amd.pytypes import VehicleState
+
+    agents = ["vehicle_2", "vehicle_3"]
+    jn, sp = _joint_problem(plans, agents, [0, 0], nps=5)
+    X0, _ = _joint_guess(plans, agents, jn, sp, 5)
+    re_ = ce.solve(jn, X0, ipm.IpmOptions(**COLLOC_OPT))
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    guesses = [X0[7 * 6 * jn.off[a] : 7 * 6 * jn.off[a + 1]].reshape(-1, 7) for a in range(2)]
+    r = engine.joint_colloc(scenarios.parking_lot_spec(n_nbr=0, N=2), [plans[a][1][0] for a in agents], tubes, guesses, X0[jn.iDt],
+                            [float(plans[a][1][-1, 2]) for a in agents], max_iter=400)
+    assert (r["status"], r["iters"]) == (re_["status"], re_["iters"]) == (0, re_["iters"])
+    assert abs(r["cost"] - re_["f"]) < 1e-6 * re_["f"] and abs(r["dt"] - re_["X"][jn.iDt]) < 1e-7
+    assert np.abs(np.concatenate([t.reshape(-1, 7) for t in r["traj"]]) - re_["X"][: jn.iDt].reshape(-1, 7)).max() < 1e-5
+    # the planner surface
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    mvp = MultiVehiclePlanner(fn, {a: True for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
+                              {a: VehicleState() for a in agents}, {a: float(plans[a][1][-1, 2]) for a in agents})
+    mvp.solve_single_problems()
+    mvp.solve_final_problem_obca()
+    assert mvp.final_stats["status"] == 0 and abs(mvp.final_dt - r["dt"]) < 1e-3
+    n_max = max(mvp.vehicles[a].N for a in agents)
+    fr = mvp.final_results
+    assert all(len(fr[a].x) == n_max * 6 + 1 and np.isclose(fr[a].t[-1], n_max * mvp.final_dt) for a in agents)
+    # on the common clock the two bodies never come closer than dmin: centres of the rear axles at least a body width apart
+    assert np.hypot(fr[agents[0]].x - fr[agents[1]].x, fr[agents[0]].y - fr[agents[1]].y).min() > 1.8
