@@ -627,14 +627,23 @@ CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
 // j+1+w, j+1+w+nw, ... whose u is not zero, lane i owning rows j+1+i, j+65+i, ... (unit stride, the pivot column's
 // multipliers l in registers).  Three barriers per pivot plus two for the pivot search.
 constexpr int kWideMaxKb = 448;
-// NC = row chunks of 64 per column (compile time), NB = 16 / NC columns per batch: the NB * NC reads of a batch are issued
-// before its first write, so a wavefront pays one global-memory round trip per batch, not per column
-template <int NC>
-__device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
-  constexpr int NB = 16 / NC;
+// NC = row chunks of 64 per column (compile time), NB = 24 / NC columns per batch: the NB * NC reads of a batch are issued
+// before its first write, so a wavefront pays one global-memory round trip per batch, not per column; only the columns
+// whose multiplier is not zero are visited (their indices are compacted into LDS first).
+struct WideScratch { double *ulds; int *cols; double *pb; int *pj; int *ncol; };
+__device__ inline WideScratch wide_scratch() {  // one set of LDS arrays for all instantiations below
   __shared__ double ulds[2 * kWideMaxKb];
+  __shared__ int cols[2 * kWideMaxKb];
   __shared__ double pb[16];
   __shared__ int pj[16];
+  __shared__ int ncol;
+  return {ulds, cols, pb, pj, &ncol};
+}
+template <int NC>
+__device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
+  constexpr int NB = 24 / NC;
+  const WideScratch ws = wide_scratch();
+  double *ulds = ws.ulds; int *cols = ws.cols; double *pb = ws.pb; int *pj = ws.pj;
   const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   double *ab = B.ab;
   int ju = 0;
@@ -648,6 +657,7 @@ __device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
       if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
     }
     if (lane == 0) { pb[wave] = best; pj[wave] = jp; }
+    if (tid == 0) *ws.ncol = 0;
     __syncthreads();
     best = pb[0]; jp = pj[0];
     for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; }
@@ -660,30 +670,38 @@ __device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
     }
     __syncthreads();  // swapped rows visible; pb/pj free again
     const int nq = ju - j;
-    for (int t = tid; t < nq; t += nt) ulds[t] = ab[(size_t)(j + 1 + t) * ld + (kv - 1 - t)];
+    for (int t0 = 0; t0 < nq; t0 += nt) {  // multipliers of the pivot row -> LDS, indices of the nonzero ones compacted
+      const int t = t0 + tid;
+      const double u = t < nq ? ab[(size_t)(j + 1 + t) * ld + (kv - 1 - t)] : 0.0;
+      if (t < nq) ulds[t] = u;
+      const unsigned long long mask = __ballot(u != 0.0);
+      int base = 0;
+      if (lane == 0 && mask) base = atomicAdd(ws.ncol, __popcll(mask));
+      base = __shfl(base, 0);
+      if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+    }
     const double inv = 1.0 / cj[kv];
     double l[NC];
     int row[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { const int i = 1 + lane + 64 * c; row[c] = i <= km ? i : 0; l[c] = i <= km ? cj[kv + i] * inv : 0.0; }
     __syncthreads();
-    for (int t0 = wave * NB; t0 < nq; t0 += nw * NB) {
+    const int nc = *ws.ncol;
+    for (int c0 = wave * NB; c0 < nc; c0 += nw * NB) {
       double u[NB], x[NB][NC];
-      bool any = false;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) { u[b] = t0 + b < nq ? ulds[t0 + b] : 0.0; any = any || u[b] != 0.0; }
-      if (!any) continue;
+      int tt[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int t = t0 + b < nq ? t0 + b : nq - 1;
-        const double *cq = ab + (size_t)(j + 1 + t) * ld + (kv - 1 - t);  // row j of column j+1+t; row j+i at cq[i]
+        tt[b] = cols[c0 + b < nc ? c0 + b : nc - 1];
+        u[b] = ulds[tt[b]];
+        const double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);  // row j of column j+1+t; row j+i at cq[i]
 #pragma unroll
         for (int c = 0; c < NC; ++c) x[b][c] = cq[row[c]];  // lanes without a row read row j (and do not write)
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        if (t0 + b < nq && u[b] != 0.0) {
-          double *cq = ab + (size_t)(j + 1 + t0 + b) * ld + (kv - 1 - t0 - b);
+        if (c0 + b < nc) {
+          double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);
 #pragma unroll
           for (int c = 0; c < NC; ++c) if (row[c]) cq[row[c]] = x[b][c] - l[c] * u[b];
         }
@@ -889,7 +907,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
 #if defined(__HIP_DEVICE_COMPILE__)
       if (WIN && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
       else if (blockDim.x > 64 && kb <= 128) fail = band_factor_wide<2>(Bd, d.nk, w.ipiv);
-      else if (blockDim.x > 64 && kb <= 256) fail = band_factor_wide<4>(Bd, d.nk, w.ipiv);
+      else if (blockDim.x > 64 && kb <= 192) fail = band_factor_wide<3>(Bd, d.nk, w.ipiv);
+      else if (blockDim.x > 64 && kb <= 320) fail = band_factor_wide<5>(Bd, d.nk, w.ipiv);
       else if (blockDim.x > 64 && kb <= kWideMaxKb) fail = band_factor_wide<7>(Bd, d.nk, w.ipiv); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
