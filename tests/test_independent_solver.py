@@ -121,3 +121,68 @@ def test_state_ws_oracle_matches_slsqp():
     assert abs(out.fun - ro["f"]) < 1e-5 * max(1.0, ro["f"]), (out.fun, ro["f"])
     so, ss = nlp.unpack(ro["X"]), nlp.unpack(np.concatenate([out.x, np.zeros(nlp.n - nz)]))
     assert max(np.abs(so[k] - ss[k]).max() for k in ("x", "y", "psi", "v")) < 1e-3
+
+
+def test_collocation_plan_is_stationary_for_slsqp():
+    """The collocation plan of the kernel source (CPU build, tight tolerances) on a short tube with the two nearest
+    obstacles, handed to scipy's SLSQP in the trajectory variables and dt (numpy statement of oracle/colloc_nlp.py; the
+    collision rows of the final working set and the tube rows as inequalities): five SLSQP iterations started there do
+    not move it (1e-5) and do not lower the cost.  Run to convergence (175 iterations, 200 s) it ends 9e-7 away at the
+    same cost to 1e-10 -- too slow to keep in the suite."""
+    import os
+    import tempfile
+
+    import colloc_emu_binding as ce
+    from conflict_rez_amd import scenarios, strategy as strat
+    from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+    from conflict_rez_amd.vehicle_types import VehicleBody
+    from oracle.colloc_nlp import CollocNlp
+
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    a, ns = "vehicle_1", 4
+    tube = [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]][:ns]
+    p = paths[a][: 30 * (ns - 1) + 1]
+    sp = scenarios.parking_lot_spec()
+    keep = np.argsort([np.min([np.max(sp.A_obs[j] @ q[:2] - sp.b_obs[j]) for q in p]) for j in range(6)])[:2]
+    nlp = CollocNlp(p[0], tube, sp.A_obs[keep], sp.b_obs[keep], N_per_set=2, final_heading=float(p[-1, 2]))
+    N = nlp.N[0]
+    t = 0.1 * np.arange(len(p))
+    t_i = np.concatenate([i + nlp.tau for i in range(N)]) / N * t[-1]
+    zu0 = {k: np.interp(t_i, t, p[:, c]) for c, k in enumerate(("x", "y", "psi"))}
+    zu0.update({k: np.zeros(len(t_i)) for k in ("delta", "a", "w")})
+    vp = np.hypot(np.gradient(p[:, 0], 0.1), np.gradient(p[:, 1], 0.1))  # speed along the spline, zero at both ends
+    vp[0] = vp[-1] = 0.0
+    zu0["v"] = np.interp(t_i, t, vp)
+    X0 = nlp.pack(zu0, t[-1] / N)
+    res = ce.solve(nlp, X0, ipm.IpmOptions(max_iter=600, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6))
+    assert res["status"] == 0
+    nz = nlp.iDt + 1
+    Xs = np.zeros(nlp.n)
+    Xs[:nz] = res["X"]
+    sel = nlp.select(Xs)
+
+    def full(z):
+        X = np.zeros(nlp.n)
+        X[:nz] = z
+        return X
+
+    def eq(z):
+        c = nlp.cons(full(z), sel)
+        return np.concatenate([c[: nlp.rR], c[nlp.rF :]])
+
+    def ineq(z):  # separation - dmin >= 0 ; tube rows <= 0
+        c = nlp.cons(full(z), sel)
+        return np.concatenate([c[nlp.rR : nlp.rT], -c[nlp.rT : nlp.rF]])
+
+    lo, hi = np.full(nz, -np.inf), np.full(nz, np.inf)
+    for c, j in ((0, 0), (1, 1), (3, 2), (4, 3), (5, 4), (6, 5)):
+        lo[c : nlp.iDt : 7], hi[c : nlp.iDt : 7] = nlp.bounds[2 * j], nlp.bounds[2 * j + 1]
+    bounds = [(None if not np.isfinite(l) else l, None if not np.isfinite(u) else u) for l, u in zip(lo, hi)]
+    assert np.abs(eq(res["X"])).max() < 1e-8 and ineq(res["X"]).min() > -1e-8
+    out = minimize(lambda z: nlp.f(full(z)), res["X"][:nz], method="SLSQP", bounds=bounds,
+                   constraints=[dict(type="eq", fun=eq), dict(type="ineq", fun=ineq)], options=dict(maxiter=5, ftol=1e-14))
+    assert np.abs(out.x - res["X"][:nz]).max() < 1e-5 and out.fun > res["f"] - 1e-7 and np.abs(eq(out.x)).max() < 1e-7
