@@ -946,15 +946,16 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
   return colloc_run(device, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
 }
 
-int cfz_joint_colloc(int device, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
-                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, double dt0,
+int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
                      int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
-  if (V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !traj || !dt || n_pairs < 0) return fail("bad argument");
-  std::vector<std::vector<std::pair<int, int>>> pr(1);
-  if (pairs) for (int e = 0; e < n_pairs; ++e) pr[0].push_back({pairs[2 * e], pairs[2 * e + 1]});
-  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr[0].push_back({a, b});  // :56-58 all pairs
-  const int32_t nv = V;
-  return colloc_run(device, 1, &nv, pr, spec, co, n_sets, init_pose, final_heading, tube, guess, &dt0, traj, dt, status, iters, cost);
+  if (B < 1 || V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt || n_pairs < 0) return fail("bad argument");
+  std::vector<std::pair<int, int>> pr;
+  if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});  // :56-58 all pairs
+  std::vector<std::vector<std::pair<int, int>>> all((size_t)B, pr);
+  std::vector<int32_t> nv((size_t)B, V);
+  return colloc_run(device, B, nv.data(), all, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
 }
 
 void cfz_default_colloc_options(cfz_colloc_options *o) {

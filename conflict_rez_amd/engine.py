@@ -122,7 +122,7 @@ def load_library(path=None):
     lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
     lib.cfz_default_colloc_options.argtypes = [C.POINTER(_CCollocOptions)]
     lib.cfz_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
-    lib.cfz_joint_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 5 + [C.c_double, C.c_int] + [vp] * 6
+    lib.cfz_joint_colloc.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 6 + [C.c_int] + [vp] * 6
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
     lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -249,10 +249,11 @@ def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0
     return out
 
 
-def joint_colloc(spec, init_poses, tubes, guesses, dt0, final_headings=None, pairs=None, device=0, **options):
-    """`cfz_joint_colloc`: the joint collocation plan of V vehicles with one shared dt and pairwise separation rows
-    (multi_vehicle_planner.py:343-480).  Arguments per vehicle as in `colloc`; dt0: initial shared interval length;
-    pairs: list of (a, b) vehicle index pairs, default all.  Returns dict(traj: per vehicle [N_a, 6, 7], dt, status, iters, cost)."""
+def joint_colloc_batch(spec, scenarios, pairs=None, device=0, **options):
+    """`cfz_joint_colloc`: B joint collocation plans (one workgroup each) of V vehicles with one shared dt per plan and pairwise
+    separation rows (multi_vehicle_planner.py:343-480).  scenarios: list of dict(init_poses [V][3], tubes, guesses, dt0,
+    final_headings) with per-vehicle entries as in `colloc`, the same V in every scenario; pairs: list of (a, b) vehicle
+    index pairs, default all.  Returns a list of dict(traj: per vehicle [N_a, 6, 7], dt, status, iters, cost)."""
     lib = load_library()
     co = _CCollocOptions()
     lib.cfz_default_colloc_options(C.byref(co))
@@ -260,27 +261,42 @@ def joint_colloc(spec, init_poses, tubes, guesses, dt0, final_headings=None, pai
         if not hasattr(co, k):
             raise TypeError(f"unknown collocation option {k!r}")
         setattr(co, k, v)
-    V = len(tubes)
+    B, V = len(scenarios), len(scenarios[0]["tubes"])
+    assert all(len(sc["tubes"]) == V for sc in scenarios)
+    tubes = [t for sc in scenarios for t in sc["tubes"]]
     n_sets = np.array([len(t) + 1 for t in tubes], dtype=np.int32)
     Np = co.N_per_set * (n_sets - 1) * 6
     tube = np.ascontiguousarray(np.concatenate([np.concatenate([np.concatenate([np.asarray(A, float).ravel(), np.asarray(b, float).ravel()])
                                                                 for cellpair in t for (A, b) in cellpair]) for t in tubes]))
-    init = _f64(np.asarray(init_poses, float), (V, 3))
-    fh = np.array([np.nan if (final_headings is None or final_headings[b] is None) else float(final_headings[b]) for b in range(V)])
+    init = _f64(np.concatenate([np.asarray(sc["init_poses"], float).reshape(V, 3) for sc in scenarios]), (B * V, 3))
+    fhs = [fh for sc in scenarios for fh in (sc.get("final_headings") or [None] * V)]
+    fh = np.array([np.nan if f is None else float(f) for f in fhs])
+    guesses = [g for sc in scenarios for g in sc["guesses"]]
     guess = np.ascontiguousarray(np.concatenate([_f64(np.asarray(g, float), (int(Np[b]), 7)) for b, g in enumerate(guesses)]))
+    dt0 = _f64(np.array([float(sc["dt0"]) for sc in scenarios]), (B,))
     pr = None if pairs is None else np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
-    traj, dt = np.zeros((int(Np.sum()), 7)), np.zeros(1)
-    status, iters, cost = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1)
+    traj, dt = np.zeros((int(Np.sum()), 7)), np.zeros(B)
+    status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
     cs = spec.to_c()
-    rc = lib.cfz_joint_colloc(int(device), V, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), float(dt0),
+    rc = lib.cfz_joint_colloc(int(device), B, V, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
                               0 if pr is None else len(pr), _ptr(pr), _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
     if rc != 0:
         raise RuntimeError("cfz_joint_colloc: " + lib.cfz_last_error().decode())
     out, o = [], 0
-    for b in range(V):
-        out.append(traj[o : o + Np[b]].reshape(-1, 6, 7).copy())
-        o += Np[b]
-    return dict(traj=out, dt=float(dt[0]), status=int(status[0]), iters=int(iters[0]), cost=float(cost[0]))
+    for b in range(B):
+        tr = []
+        for a in range(V):
+            n = int(Np[b * V + a])
+            tr.append(traj[o : o + n].reshape(-1, 6, 7).copy())
+            o += n
+        out.append(dict(traj=tr, dt=float(dt[b]), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
+    return out
+
+
+def joint_colloc(spec, init_poses, tubes, guesses, dt0, final_headings=None, pairs=None, device=0, **options):
+    """One joint plan: `joint_colloc_batch` with a single scenario.  Returns dict(traj: per vehicle [N_a, 6, 7], dt, status, iters, cost)."""
+    return joint_colloc_batch(spec, [dict(init_poses=init_poses, tubes=tubes, guesses=guesses, dt0=dt0, final_headings=final_headings)],
+                              pairs=pairs, device=device, **options)[0]
 
 
 class Engine:

@@ -205,16 +205,18 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
 /* ---- MultiVehiclePlanner.solve_final_problem_obca (confrez/control/multi_vehicle_planner.py:343-480) -----------------------
  * The joint plan: the collocation problems of V vehicles (each as in cfz_colloc, from its own single-vehicle result) with ONE
  * shared interval length dt (:365-366), cost sum_a J_a (:387), and for every pair of vehicles and every collocation point
- * of the shorter plan the two bodies at least spec->dmin apart (:389-456).  One instance per call.
- *   n_sets[V], init_pose[V][3], final_heading[V], tube, guess   per vehicle, vehicles back to back, as in cfz_colloc
- *   dt0                   initial shared interval length (:361 the mean of the single results')
- *   pairs[n_pairs][2]     vehicle index pairs a < b with a separation row; NULL = all pairs (:56-58)
- *   traj (out)            x, y, psi, v, delta, a, w at every point, vehicles back to back; dt (out) one value
+ * of the shorter plan the two bodies at least spec->dmin apart (:389-456).  B independent instances (scenarios) of V vehicles
+ * each in one launch, one workgroup per instance (BASELINE.json configs[3]); the reference solves one.
+ *   n_sets[B*V], init_pose[B*V][3], final_heading[B*V], tube, guess   per vehicle, instance-major, as in cfz_colloc
+ *   dt0[B]                initial shared interval length (:361 the mean of the single results')
+ *   pairs[n_pairs][2]     vehicle index pairs a < b with a separation row, the same for every instance; NULL = all pairs (:56-58)
+ *   traj (out)            x, y, psi, v, delta, a, w at every point, vehicles back to back; dt (out) [B]
+ *   status, iters, cost   per instance (may be NULL)
  * The vehicle-vehicle OBCA duals (:404-431) are eliminated like the obstacle duals (two smooth rows per pair and point over a
  * working set) and rebuilt from the poses by cfz_joint_dual_ws.  The vehicles' interval blocks are interleaved in time, which
  * widens the band to ~100 V; the elimination then runs from global memory (csrc/cfz_colloc.inl). */
-int cfz_joint_colloc(int device, int V, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
-                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, double dt0,
+int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
+                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
                      int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
 
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------

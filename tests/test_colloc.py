@@ -313,6 +313,18 @@ def test_joint_colloc_on_gpu(plans, tmp_path):
     assert (r["status"], r["iters"]) == (re_["status"], re_["iters"]) == (0, re_["iters"])
     assert abs(r["cost"] - re_["f"]) < 1e-6 * re_["f"] and abs(r["dt"] - re_["X"][jn.iDt]) < 1e-7
     assert np.abs(np.concatenate([t.reshape(-1, 7) for t in r["traj"]]) - re_["X"][: jn.iDt].reshape(-1, 7)).max() < 1e-5
+    # BASELINE.json configs[3] in small: a batch of joint plans in one launch (one workgroup each) -- scenarios that differ in the
+    # start pose of the first vehicle; every one equals its own call
+    scen = []
+    for dx in (0.0, 0.05, -0.05):
+        ip = [np.array(plans[a][1][0], float) for a in agents]
+        ip[0] = ip[0] + np.array([dx, 0.0, 0.0])
+        scen.append(dict(init_poses=ip, tubes=tubes, guesses=guesses, dt0=X0[jn.iDt], final_headings=[float(plans[a][1][-1, 2]) for a in agents]))
+    spec0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    rb = engine.joint_colloc_batch(spec0, scen, max_iter=400)
+    assert [x["status"] for x in rb] == [0, 0, 0] and abs(rb[0]["cost"] - r["cost"]) < 1e-9 and rb[0]["iters"] == r["iters"]
+    r2 = engine.joint_colloc(spec0, scen[2]["init_poses"], tubes, guesses, X0[jn.iDt], scen[2]["final_headings"], max_iter=400)
+    assert (r2["status"], r2["iters"]) == (0, rb[2]["iters"]) and r2["cost"] == rb[2]["cost"] and abs(rb[2]["traj"][0][0, 0, 0] - (plans[agents[0]][1][0, 0] - 0.05)) < 1e-6
     # the planner surface
     fn = str(tmp_path / "4v_rl_traj")
     strat.write_strategy(fn, strat.generate_strategy(4))
