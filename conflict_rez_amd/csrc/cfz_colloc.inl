@@ -14,10 +14,16 @@
 //                (DESIGN.md "Certificate elimination"); the duals l, m are rebuilt from the poses afterwards
 //   cost         sum_ik B[k] (a^2 + v^2 w^2 + delta^2) dt + (N dt)^2 (:512-521, :638)
 //
+// The same source solves the JOINT plan of several vehicles (reference confrez/control/multi_vehicle_planner.py:343-480):
+// see CSpec below.
+//
 // Solver: the banded primal-dual interior point of cfz_plan.inl (exact Hessian, delta_w ladder with the curvature test,
-// delta_c), with two additions: dt couples to everything, so it is kept out of the band and handled by bordering
-// (one factorisation, two substitutions); the working set of the collision rows is refreshed at every accepted iterate.
-// One workgroup per plan, workspace in global memory; all lanes run the scalar logic, the marked loops are shared.
+// delta_c), with these additions: dt couples to everything, so it is kept out of the band and handled by bordering
+// (one factorisation, two right-hand sides); the working set of the collision rows is refreshed at every accepted
+// iterate; every collision pair (slack, multiplier) is condensed into the poses it touches (assemble); a primal-dual
+// merit takes over when the filter line search fails (solve_colloc).  One workgroup per plan, workspace in global
+// memory; every thread runs the scalar logic, the marked loops are shared.  One vehicle: one wavefront, elimination in
+// an LDS window (cfz_band.inl).  Several vehicles: eight wavefronts, elimination from global memory (band_factor_wide).
 #pragma once
 #include "cfz_solver.inl"
 #include "cfz_plan.inl"
@@ -811,10 +817,10 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
   CFZP_SYNC();
 }
 
-// X: guess for the 7 N 6 point variables followed by dt; solution out (same layout).  out_i = iterations, status;
-// out_d = cost, err, mu.  kb: half-bandwidth the caller sized the slab for.
-// WIN (GPU only): the kernel's dynamic LDS (kCWin x kCLd doubles) is the window of band_factor_lds / band_substitute_lds
-// and kb == kCB; `win` is unused
+// X: guess for the 7 variables of every point (vehicles back to back) followed by dt; solution out (same layout).
+// out_i = iterations, status; out_d = cost, err, mu, phase timers.  kb: half-bandwidth the caller sized the slab for
+// (half_bandwidth() of the ordering).  WIN (GPU only): with one wavefront and kb == kCB the kernel's dynamic LDS
+// (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; `win` is unused
 template <bool WIN>
 CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, double *win) {
   const CDims d = cdims(sp);
