@@ -721,6 +721,111 @@ __device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
   }
   return 0;
 }
+
+// barrier that orders LDS traffic only: the global stores still in flight are not waited for (what is read after it was
+// either not written in this phase or is forwarded through LDS)
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Second version of the wide elimination, built around the number of dependent global-memory round trips per pivot (the
+// band does not fit the L2, a trip costs ~2.5 us): (1) the pivot column is read once, every thread keeping its own row;
+// (2) one pass over the trailing columns does the row swap AND fetches the pivot-row multipliers u -- the value that
+// moves to row j+jp is forwarded through LDS instead of being re-read; (3) only the rows whose multiplier l is not
+// zero and the columns whose u is not zero are updated (both lists compacted in LDS; typically ~40 rows x ~80 columns
+// of 298 x 596), one row per lane, sixteen columns per batch.  Needs blockDim.x > kb.
+__device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long long *ptk) {
+  constexpr int NB = 16;
+  __shared__ double ulds[2 * kWideMaxKb], alds[2 * kWideMaxKb], lval[kWideMaxKb + 64];
+  __shared__ int cols[2 * kWideMaxKb], lrow[kWideMaxKb + 64];
+  __shared__ double pb[16], pbv[16];
+  __shared__ int pj[16];
+  __shared__ int ncol, nrow;
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  double *ab = B.ab;
+  int ju = 0;
+  for (int j = 0; j < n; ++j) {
+    const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+    double *cj = ab + (size_t)j * ld;
+    long long tp0 = tick();
+    // (1) pivot search; thread i keeps row j+i of the pivot column
+    const double own = tid <= km ? cj[kv + tid] : 0.0, diag = cj[kv];
+    double best = tid <= km ? fabs(own) : -1.0, bv = own;
+    int jp = tid;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off), ov = __shfl_xor(bv, off); const int oj = __shfl_xor(jp, off);
+      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; bv = ov; }
+    }
+    if (lane == 0) { pb[wave] = best; pj[wave] = jp; pbv[wave] = bv; }
+    if (tid == 0) { ncol = 0; nrow = 0; }
+    __syncthreads();
+    best = pb[0]; jp = pj[0]; bv = pbv[0];
+    for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; bv = pbv[i]; }
+    if (tid == 0) ipiv[j] = j + jp;
+    if (!(best > 0.0)) return 1;
+    const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
+    ju = ju > reach ? ju : reach;
+    const int nq = ju - j;
+    { const long long t1 = tick(); ptk[0] += t1 - tp0; tp0 = t1; }
+    // (2a) the pivot column: diagonal <- pivot value, multipliers l = (swapped column) / pivot; nonzero rows compacted
+    {
+      const double inv = 1.0 / bv;
+      const double l = (tid >= 1 && tid <= km) ? (tid == jp ? diag : own) * inv : 0.0;
+      if (tid == 0) cj[kv] = bv;
+      if (tid >= 1 && tid <= km) cj[kv + tid] = l;
+      const unsigned long long mask = __ballot(l != 0.0);
+      int base = 0;
+      if (lane == 0 && mask) base = atomicAdd(&nrow, __popcll(mask));
+      base = __shfl(base, 0);
+      if (l != 0.0) { const int at = base + __popcll(mask & ((1ull << lane) - 1ull)); lrow[at] = tid; lval[at] = l; }
+    }
+    // (2b) trailing columns: swap rows j and j+jp, u = new row j; the value now in row j+jp goes to LDS as well
+    for (int t0 = 0; t0 < nq; t0 += nt) {
+      const int t = t0 + tid;
+      double u = 0.0;
+      if (t < nq) {
+        double *cq = ab + (size_t)(j + 1 + t) * ld + (kv - 1 - t);  // row j of column j+1+t; row j+i at cq[i]
+        const double a = cq[0];
+        u = jp ? cq[jp] : a;
+        if (jp) { cq[0] = u; cq[jp] = a; }
+        ulds[t] = u; alds[t] = a;
+      }
+      const unsigned long long mask = __ballot(u != 0.0);
+      int base = 0;
+      if (lane == 0 && mask) base = atomicAdd(&ncol, __popcll(mask));
+      base = __shfl(base, 0);
+      if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+    }
+    lds_barrier();
+    { const long long t1 = tick(); ptk[1] += t1 - tp0; tp0 = t1; }
+    // (3) rank-1 update of (nonzero rows) x (nonzero columns)
+    const int nc = ncol, nr = nrow;
+    for (int r0 = 0; r0 < nr; r0 += 64) {
+      const bool mine = r0 + lane < nr;
+      const int i = mine ? lrow[r0 + lane] : 0;
+      const double l = mine ? lval[r0 + lane] : 0.0;
+      for (int c0 = wave * NB; c0 < nc; c0 += nw * NB) {
+        double x[NB], u[NB];
+        int tt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          tt[b] = cols[c0 + b < nc ? c0 + b : nc - 1];
+          u[b] = ulds[tt[b]];
+          const double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);
+          x[b] = cq[i];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (c0 + b < nc && mine) {
+            const double xv = (jp && i == jp) ? alds[tt[b]] : x[b];  // row j+jp was rewritten in (2b): take it from LDS
+            ab[(size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]) + i] = xv - l * u[b];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    { const long long t1 = tick(); ptk[2] += t1 - tp0; }
+  }
+  return 0;
+}
 #endif
 
 CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
@@ -912,6 +1017,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (WIN && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
+      else if (blockDim.x > kb && kb <= kWideMaxKb && !sp.pad0) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6);
       else if (blockDim.x > 64 && kb <= 128) fail = band_factor_wide<2>(Bd, d.nk, w.ipiv);
       else if (blockDim.x > 64 && kb <= 192) fail = band_factor_wide<3>(Bd, d.nk, w.ipiv);
       else if (blockDim.x > 64 && kb <= 320) fail = band_factor_wide<5>(Bd, d.nk, w.ipiv);

@@ -866,6 +866,7 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
       if (p.pair_a[e] < 0 || p.pair_b[e] >= p.V || p.pair_a[e] >= p.pair_b[e]) return fail("bad vehicle pair");
     }
     p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
+    p.pad0 = std::getenv("CFZ_COLLOC_WIDE1") ? 1 : 0;  // experiments: the first version of the wide elimination
     p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
     memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
     radau5_tables(p.A, p.B);
