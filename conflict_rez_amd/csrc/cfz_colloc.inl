@@ -629,104 +629,13 @@ CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
 // two right-hand sides at once (the KKT residual and the dt border)
 #if defined(__HIP_DEVICE_COMPILE__)
 // The elimination for a band too wide for LDS (the joint plan: half-bandwidth ~100 per vehicle), from global memory with all
-// wavefronts of the workgroup: the multipliers u of the pivot row go to LDS once, wavefront w updates the columns
-// j+1+w, j+1+w+nw, ... whose u is not zero, lane i owning rows j+1+i, j+65+i, ... (unit stride, the pivot column's
-// multipliers l in registers).  Three barriers per pivot plus two for the pivot search.
+// wavefronts of the workgroup.
 constexpr int kWideMaxKb = 448;
-// NC = row chunks of 64 per column (compile time), NB = 24 / NC columns per batch: the NB * NC reads of a batch are issued
-// before its first write, so a wavefront pays one global-memory round trip per batch, not per column; only the columns
-// whose multiplier is not zero are visited (their indices are compacted into LDS first).
-struct WideScratch { double *ulds; int *cols; double *pb; int *pj; int *ncol; };
-__device__ inline WideScratch wide_scratch() {  // one set of LDS arrays for all instantiations below
-  __shared__ double ulds[2 * kWideMaxKb];
-  __shared__ int cols[2 * kWideMaxKb];
-  __shared__ double pb[16];
-  __shared__ int pj[16];
-  __shared__ int ncol;
-  return {ulds, cols, pb, pj, &ncol};
-}
-template <int NC>
-__device__ inline int band_factor_wide(const Band &B, int n, int *ipiv) {
-  constexpr int NB = 24 / NC;
-  const WideScratch ws = wide_scratch();
-  double *ulds = ws.ulds; int *cols = ws.cols; double *pb = ws.pb; int *pj = ws.pj;
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  double *ab = B.ab;
-  int ju = 0;
-  for (int j = 0; j < n; ++j) {
-    const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
-    double *cj = ab + (size_t)j * ld;
-    double best = -1.0; int jp = 0;
-    for (int i = tid; i <= km; i += nt) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
-      if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
-    }
-    if (lane == 0) { pb[wave] = best; pj[wave] = jp; }
-    if (tid == 0) *ws.ncol = 0;
-    __syncthreads();
-    best = pb[0]; jp = pj[0];
-    for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; }
-    if (tid == 0) ipiv[j] = j + jp;
-    if (!(best > 0.0)) return 1;
-    const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
-    ju = ju > reach ? ju : reach;
-    if (jp != 0) {
-      for (int q = j + tid; q <= ju; q += nt) { double *cq = ab + (size_t)q * ld + (kv + j - q); const double t = cq[0]; cq[0] = cq[jp]; cq[jp] = t; }
-    }
-    __syncthreads();  // swapped rows visible; pb/pj free again
-    const int nq = ju - j;
-    for (int t0 = 0; t0 < nq; t0 += nt) {  // multipliers of the pivot row -> LDS, indices of the nonzero ones compacted
-      const int t = t0 + tid;
-      const double u = t < nq ? ab[(size_t)(j + 1 + t) * ld + (kv - 1 - t)] : 0.0;
-      if (t < nq) ulds[t] = u;
-      const unsigned long long mask = __ballot(u != 0.0);
-      int base = 0;
-      if (lane == 0 && mask) base = atomicAdd(ws.ncol, __popcll(mask));
-      base = __shfl(base, 0);
-      if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
-    }
-    const double inv = 1.0 / cj[kv];
-    double l[NC];
-    int row[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { const int i = 1 + lane + 64 * c; row[c] = i <= km ? i : 0; l[c] = i <= km ? cj[kv + i] * inv : 0.0; }
-    __syncthreads();
-    const int nc = *ws.ncol;
-    for (int c0 = wave * NB; c0 < nc; c0 += nw * NB) {
-      double u[NB], x[NB][NC];
-      int tt[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        tt[b] = cols[c0 + b < nc ? c0 + b : nc - 1];
-        u[b] = ulds[tt[b]];
-        const double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);  // row j of column j+1+t; row j+i at cq[i]
-#pragma unroll
-        for (int c = 0; c < NC; ++c) x[b][c] = cq[row[c]];  // lanes without a row read row j (and do not write)
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (c0 + b < nc) {
-          double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) if (row[c]) cq[row[c]] = x[b][c] - l[c] * u[b];
-        }
-      }
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) if (row[c]) cj[kv + row[c]] = l[c];
-    }
-    __syncthreads();
-  }
-  return 0;
-}
-
 // barrier that orders LDS traffic only: the global stores still in flight are not waited for (what is read after it was
 // either not written in this phase or is forwarded through LDS)
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Second version of the wide elimination, built around the number of dependent global-memory round trips per pivot (the
+// Built around the number of dependent global-memory round trips per pivot (the
 // band does not fit the L2, a trip costs ~2.5 us): (1) the pivot column is read once, every thread keeping its own row;
 // (2) one pass over the trailing columns does the row swap AND fetches the pivot-row multipliers u -- the value that
 // moves to row j+jp is forwarded through LDS instead of being re-read; (3) only the rows whose multiplier l is not
@@ -924,9 +833,10 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
 
 // X: guess for the 7 variables of every point (vehicles back to back) followed by dt; solution out (same layout).
 // out_i = iterations, status; out_d = cost, err, mu, phase timers.  kb: half-bandwidth the caller sized the slab for
-// (half_bandwidth() of the ordering).  WIN (GPU only): with one wavefront and kb == kCB the kernel's dynamic LDS
-// (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; `win` is unused
-template <bool WIN>
+// (half_bandwidth() of the ordering).  MODE (GPU only; 0 = the generic elimination everywhere): 1 = one wavefront, kb == kCB:
+// the kernel's dynamic LDS (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; 2 = several
+// wavefronts, band_factor_wide2.  `win` is unused.
+template <int MODE>
 CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, double *win) {
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
@@ -1016,18 +926,14 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[1] += tick() - ta; ta = tick();
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (WIN && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
-      else if (blockDim.x > kb && kb <= kWideMaxKb && !sp.pad0) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6);
-      else if (blockDim.x > 64 && kb <= 128) fail = band_factor_wide<2>(Bd, d.nk, w.ipiv);
-      else if (blockDim.x > 64 && kb <= 192) fail = band_factor_wide<3>(Bd, d.nk, w.ipiv);
-      else if (blockDim.x > 64 && kb <= 320) fail = band_factor_wide<5>(Bd, d.nk, w.ipiv);
-      else if (blockDim.x > 64 && kb <= kWideMaxKb) fail = band_factor_wide<7>(Bd, d.nk, w.ipiv); else
+      if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
+      else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (WIN && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+        if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         tk[3] += tick() - ta;

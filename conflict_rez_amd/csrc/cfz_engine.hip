@@ -285,16 +285,15 @@ __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec 
 #ifndef CFZC_BOUNDS
 #define CFZC_BOUNDS 512
 #endif
+// MODE 1: single-vehicle plans, one wavefront each, elimination in the LDS window; MODE 2: joint plans, 512 threads each,
+// elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
+template <int MODE>
 __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
                               const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od) {
   const int b = blockIdx.x;
-  extern __shared__ double colloc_win[];  // the 103 band columns the elimination is working on, then the right-hand sides
+  extern __shared__ double colloc_win[];  // MODE 1: the 103 band columns the elimination is working on, then the right-hand sides
   if (b >= B) return;
-#if defined(CFZC_NOWIN)
-  cfzc::solve_colloc<false>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, nullptr);
-#else
-  cfzc::solve_colloc<true>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
-#endif
+  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -866,7 +865,6 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
       if (p.pair_a[e] < 0 || p.pair_b[e] >= p.V || p.pair_a[e] >= p.pair_b[e]) return fail("bad vehicle pair");
     }
     p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
-    p.pad0 = std::getenv("CFZ_COLLOC_WIDE1") ? 1 : 0;  // experiments: the first version of the wide elimination
     p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
     memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
     radau5_tables(p.A, p.B);
@@ -908,14 +906,18 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
   HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
   HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
-  HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
   // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
   // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
-  int threads = 64;
-  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) threads = 512;
-  if (const char *e = std::getenv("CFZ_COLLOC_THREADS")) threads = std::max(64, std::min(512, std::atoi(e) / 64 * 64));
-  hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(threads), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
+  bool wide = false;
+  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
+  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: single plans through the wide path
+  if (!wide) {
+    const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
+    HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
+  } else {
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), 0, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
+  }
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
