@@ -735,6 +735,78 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
   }
   return 0;
 }
+
+// Substitution for the wide band with the right-hand side in LDS (the kernel's dynamic LDS, n doubles; one right-hand side
+// after the other) and the factor's columns fetched eight pivots ahead, so that a pivot costs two LDS barriers instead of
+// two global-memory round trips.  Needs blockDim.x > kb.
+__device__ inline void band_substitute_wide(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+  extern __shared__ double wlds[];
+  constexpr int CH = 8;
+  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x;
+  const double *ab = B.ab;
+  for (int pass = 0; pass < 2; ++pass) {
+    double *v = pass ? b2 : b;
+    for (int t = tid; t < n; t += nt) wlds[t] = v[t];
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += CH) {  // L y = P b
+      double Lr[CH]; int pv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j0 + c, km = j < n ? ((kl < n - 1 - j) ? kl : n - 1 - j) : 0;
+        Lr[c] = tid < km ? ab[(size_t)j * ld + kv + 1 + tid] : 0.0;
+        pv[c] = j < n ? ipiv[j] : j;
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j0 + c;
+        if (j < n) {
+          const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = pv[c];
+          if (p != j) {
+            if (tid == 0) { const double t = wlds[j]; wlds[j] = wlds[p]; wlds[p] = t; }
+            lds_barrier();
+          }
+          const double bj = wlds[j];
+          if (bj != 0.0) {
+            if (tid < km) wlds[j + 1 + tid] -= Lr[c] * bj;
+            lds_barrier();
+          }
+        }
+      }
+    }
+    for (int j1 = n - 1; j1 >= 0; j1 -= CH) {  // U x = y
+      double Ur[CH][2], dg[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j1 - c;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int off = tid + nt * t, i = j - kv + off;
+          Ur[c][t] = (j >= 0 && off < kv && i >= 0) ? ab[(size_t)j * ld + off] : 0.0;
+        }
+        dg[c] = j >= 0 ? ab[(size_t)j * ld + kv] : 1.0;
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j1 - c;
+        if (j >= 0) {
+          const double bj = wlds[j] / dg[c];
+          lds_barrier();
+          if (tid == 0) wlds[j] = bj;
+          if (bj != 0.0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int off = tid + nt * t, i = j - kv + off;
+              if (off < kv && i >= 0) wlds[i] -= Ur[c][t] * bj;
+            }
+          }
+          lds_barrier();
+        }
+      }
+    }
+    for (int t = tid; t < n; t += nt) v[t] = wlds[t];
+    __syncthreads();
+  }
+}
 #endif
 
 CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
@@ -835,9 +907,9 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
 // out_i = iterations, status; out_d = cost, err, mu, phase timers.  kb: half-bandwidth the caller sized the slab for
 // (half_bandwidth() of the ordering).  MODE (GPU only; 0 = the generic elimination everywhere): 1 = one wavefront, kb == kCB:
 // the kernel's dynamic LDS (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; 2 = several
-// wavefronts, band_factor_wide2.  `win` is unused.
+// wavefronts, band_factor_wide2 and, if the right-hand side fits the dynamic LDS (lds_doubles), band_substitute_wide.
 template <int MODE>
-CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, double *win) {
+CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles) {
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
   const Band Bd = {w.ab, kb, 3 * kb + 1};
@@ -933,7 +1005,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+        if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
+        else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_doubles) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         tk[3] += tick() - ta;

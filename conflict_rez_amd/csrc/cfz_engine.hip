@@ -289,11 +289,12 @@ __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec 
 // elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
 template <int MODE>
 __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
-                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od) {
+                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles) {
   const int b = blockIdx.x;
-  extern __shared__ double colloc_win[];  // MODE 1: the 103 band columns the elimination is working on, then the right-hand sides
+  // dynamic LDS: MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2 one
+  // right-hand side of the substitution (lds_doubles of them, 0 = none)
   if (b >= B) return;
-  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, colloc_win);
+  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles);
 }
 
 // dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
@@ -914,9 +915,13 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
   if (!wide) {
     const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
     HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
+    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
   } else {
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), 0, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod);
+    int nk_max = 0;  // the right-hand side of the largest instance in LDS if it fits beside the static arrays of the elimination
+    for (int b = 0; b < B; ++b) nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk);
+    const int lds_doubles = (size_t)nk_max * 8 <= 120 * 1024 ? nk_max : 0;
+    if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());

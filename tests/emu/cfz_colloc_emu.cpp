@@ -75,7 +75,7 @@ int cfzc_emu_solve(const cfzc::CSpec *sp, double *X, int *out_i, double *out_d) 
   if (kb < 0) return -2;
   double *slab = (double *)calloc(cfzc::work_doubles(*sp, kb), sizeof(double));
   if (!slab) return -1;
-  cfzc::solve_colloc<0>(*sp, X, slab, kb, out_i, out_d, nullptr);
+  cfzc::solve_colloc<0>(*sp, X, slab, kb, out_i, out_d, 0);
   free(slab);
   return 0;
 }
