@@ -7,8 +7,15 @@ namespace cfzb {
 struct Band { double *ab; int kb, ld; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// inline on purpose: functions that name LDS must end up inside the kernel (see cfz_colloc.inl)
-#define CFZB_LDS_FN __device__ inline
+// The two routines below are functions of their own (registers of their own: inlined into a solver their loops reloaded
+// spilled values from scratch at every pivot).  On this toolchain such a function must not NAME any LDS (see
+// cfz_colloc.inl), so the window comes in as an address-space-3 pointer from an inlined wrapper that names it, and the band
+// as an address-space-1 pointer so that it is read with GLOBAL rather than FLAT instructions.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(1))) double glb_f64;
+typedef __attribute__((address_space(1))) int glb_i32;
+#define CFZB_LDS_FN __device__ __attribute__((noinline))
 // Elimination by one wavefront with the kv + 1 columns it is working on in LDS (the kernel's dynamic LDS: (kv + 1) x ld
 // doubles plus one spare slot per lane; 124 KiB for the collocation plan, 78 KiB for state_ws): column q lives in slot q mod 103 while j <= q <= j + kv, enters from `ab` when pivot step j = q - kv - 1
 // ends (fetched into registers at its start) and is written back after its own pivot step.  Lane i owns row j + i of the
@@ -24,10 +31,8 @@ __device__ inline void wave_sync() {
 #endif
 }
 
-CFZB_LDS_FN int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
-  extern __shared__ double cfzb_lds[];  // named here, not passed in: every access below must be a DS instruction
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, wc = kv + 1, lane = threadIdx.x;
-  double *ab = B.ab;
+CFZB_LDS_FN int band_factor_lds_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *cfzb_lds, lds_f64 *ptk) {
+  const int kl = kb, kv = 2 * kb, wc = kv + 1, lane = threadIdx.x;
   {
     const int cnt = ((kv < n - 1 ? kv : n - 1) + 1) * ld;
     for (int t = lane; t < cnt; t += 64) cfzb_lds[t] = ab[t];
@@ -58,7 +63,7 @@ CFZB_LDS_FN int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk)
       }
       wave_sync();
     }
-    { const long long t1 = (long long)wall_clock64(); ptk[0] += t1 - tp0; tp0 = t1; }
+    { const long long t1 = (long long)wall_clock64(); if (lane == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
     const bool mine = lane >= 1 && lane <= km;
     const double inv = 1.0 / cfzb_lds[cj + kv];
     const double l = mine ? cfzb_lds[cj + kv + lane] * inv : 0.0;
@@ -99,13 +104,13 @@ CFZB_LDS_FN int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk)
       }
     }
     wave_sync();
-    { const long long t1 = (long long)wall_clock64(); ptk[1] += t1 - tp0; tp0 = t1; }
+    { const long long t1 = (long long)wall_clock64(); if (lane == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
     for (int t = 0; t < 3; ++t) {
       const int r = lane + 64 * t;
       if (r < ld) { ab[(size_t)j * ld + r] = cfzb_lds[cj + r]; if (qn < n) cfzb_lds[cj + r] = pre[t]; }
     }
     wave_sync();
-    { const long long t1 = (long long)wall_clock64(); ptk[2] += t1 - tp0; tp0 = t1; }
+    { const long long t1 = (long long)wall_clock64(); if (lane == 0) ptk[2] += (double)(t1 - tp0); tp0 = t1; }
   }
   __syncthreads();
   return 0;
@@ -113,10 +118,8 @@ CFZB_LDS_FN int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk)
 
 // the right-hand side(s) in LDS (b at offset 0, b2 at offset n when TWO), the factor's columns fetched eight pivot steps ahead
 template <bool TWO>
-CFZB_LDS_FN void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
-  extern __shared__ double cfzb_lds[];
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, lane = threadIdx.x;
-  const double *ab = B.ab;
+CFZB_LDS_FN void band_substitute_lds_core(const glb_f64 *ab, int kb, int ld, int n, const glb_i32 *ipiv, glb_f64 *b, glb_f64 *b2, lds_f64 *cfzb_lds) {
+  const int kl = kb, kv = 2 * kb, lane = threadIdx.x;
   for (int t = lane; t < n; t += 64) { cfzb_lds[t] = b[t]; if (TWO) cfzb_lds[n + t] = b2[t]; }
   __syncthreads();
   constexpr int CH = 8;
@@ -176,6 +179,22 @@ CFZB_LDS_FN void band_substitute_lds(const Band &B, int n, const int *ipiv, doub
   }
   for (int t = lane; t < n; t += 64) { b[t] = cfzb_lds[t]; if (TWO) b2[t] = cfzb_lds[n + t]; }
   __syncthreads();
+}
+// the wrappers are inlined into the kernel and name its dynamic LDS
+__device__ inline int band_factor_lds(const Band &B, int n, int *ipiv, long long *ptk) {
+  extern __shared__ double cfzb_dyn[];
+  __shared__ double tks[3];
+  if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
+  __syncthreads();
+  const int fail = band_factor_lds_core((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)cfzb_dyn, (lds_f64 *)tks);
+  __syncthreads();
+  for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
+  return fail;
+}
+template <bool TWO>
+__device__ inline void band_substitute_lds(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+  extern __shared__ double cfzb_dyn[];
+  band_substitute_lds_core<TWO>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)cfzb_dyn);
 }
 #endif
 

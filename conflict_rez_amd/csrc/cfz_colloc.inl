@@ -641,19 +641,19 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // moves to row j+jp is forwarded through LDS instead of being re-read; (3) only the rows whose multiplier l is not
 // zero and the columns whose u is not zero are updated (both lists compacted in LDS; typically ~40 rows x ~80 columns
 // of 298 x 596), one row per lane, sixteen columns per batch.  Needs blockDim.x > kb.
-__device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long long *ptk) {
+// A function of its own (registers of its own: inlined into the solver its loops reloaded spilled values from scratch at
+// every pivot).  Such a function must not NAME any LDS on this toolchain (see the top of this file), so its LDS arrays
+// are declared by the inlined wrapper below and come in as address-space-3 pointers.
+using cfzb::lds_f64; using cfzb::lds_i32; using cfzb::glb_f64; using cfzb::glb_i32;  // address-space-qualified pointers, see cfz_band.inl
+__device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *ulds, lds_f64 *alds,
+                                                                lds_f64 *lval, lds_i32 *cols, lds_i32 *lrow, lds_f64 *pb, lds_f64 *pbv,
+                                                                lds_i32 *pj, lds_i32 *cnt, lds_f64 *ptk) {
   constexpr int NB = 16;
-  __shared__ double ulds[2 * kWideMaxKb], alds[2 * kWideMaxKb], lval[kWideMaxKb + 64];
-  __shared__ int cols[2 * kWideMaxKb], lrow[kWideMaxKb + 64];
-  __shared__ double pb[16], pbv[16];
-  __shared__ int pj[16];
-  __shared__ int ncol, nrow;
-  const int kl = B.kb, kv = 2 * B.kb, ld = B.ld, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  double *ab = B.ab;
+  const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   int ju = 0;
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
-    double *cj = ab + (size_t)j * ld;
+    glb_f64 *cj = ab + (size_t)j * ld;
     long long tp0 = tick();
     // (1) pivot search; thread i keeps row j+i of the pivot column
     const double own = tid <= km ? cj[kv + tid] : 0.0, diag = cj[kv];
@@ -664,7 +664,7 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
       if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; bv = ov; }
     }
     if (lane == 0) { pb[wave] = best; pj[wave] = jp; pbv[wave] = bv; }
-    if (tid == 0) { ncol = 0; nrow = 0; }
+    if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
     __syncthreads();
     best = pb[0]; jp = pj[0]; bv = pbv[0];
     for (int i = 1; i < nw; ++i) if (pb[i] > best || (pb[i] == best && pj[i] < jp)) { best = pb[i]; jp = pj[i]; bv = pbv[i]; }
@@ -673,7 +673,7 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
     const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
     ju = ju > reach ? ju : reach;
     const int nq = ju - j;
-    { const long long t1 = tick(); ptk[0] += t1 - tp0; tp0 = t1; }
+    { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
     // (2a) the pivot column: diagonal <- pivot value, multipliers l = (swapped column) / pivot; nonzero rows compacted
     {
       const double inv = 1.0 / bv;
@@ -682,7 +682,7 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
       if (tid >= 1 && tid <= km) cj[kv + tid] = l;
       const unsigned long long mask = __ballot(l != 0.0);
       int base = 0;
-      if (lane == 0 && mask) base = atomicAdd(&nrow, __popcll(mask));
+      if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt + 1, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (l != 0.0) { const int at = base + __popcll(mask & ((1ull << lane) - 1ull)); lrow[at] = tid; lval[at] = l; }
     }
@@ -691,7 +691,7 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
       const int t = t0 + tid;
       double u = 0.0;
       if (t < nq) {
-        double *cq = ab + (size_t)(j + 1 + t) * ld + (kv - 1 - t);  // row j of column j+1+t; row j+i at cq[i]
+        glb_f64 *cq = ab + (size_t)(j + 1 + t) * ld + (kv - 1 - t);  // row j of column j+1+t; row j+i at cq[i]
         const double a = cq[0];
         u = jp ? cq[jp] : a;
         if (jp) { cq[0] = u; cq[jp] = a; }
@@ -699,14 +699,14 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
       }
       const unsigned long long mask = __ballot(u != 0.0);
       int base = 0;
-      if (lane == 0 && mask) base = atomicAdd(&ncol, __popcll(mask));
+      if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
     }
     lds_barrier();
-    { const long long t1 = tick(); ptk[1] += t1 - tp0; tp0 = t1; }
+    { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
     // (3) rank-1 update of (nonzero rows) x (nonzero columns)
-    const int nc = ncol, nr = nrow;
+    const int nc = cnt[0], nr = cnt[1];
     for (int r0 = 0; r0 < nr; r0 += 64) {
       const bool mine = r0 + lane < nr;
       const int i = mine ? lrow[r0 + lane] : 0;
@@ -718,7 +718,7 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
         for (int b = 0; b < NB; ++b) {
           tt[b] = cols[c0 + b < nc ? c0 + b : nc - 1];
           u[b] = ulds[tt[b]];
-          const double *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);
+          const glb_f64 *cq = ab + (size_t)(j + 1 + tt[b]) * ld + (kv - 1 - tt[b]);
           x[b] = cq[i];
         }
 #pragma unroll
@@ -731,9 +731,24 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
       }
     }
     __syncthreads();
-    { const long long t1 = tick(); ptk[2] += t1 - tp0; }
+    { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
   }
   return 0;
+}
+
+__device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long long *ptk) {
+  __shared__ double ulds[2 * kWideMaxKb], alds[2 * kWideMaxKb], lval[kWideMaxKb + 64];
+  __shared__ int cols[2 * kWideMaxKb], lrow[kWideMaxKb + 64];
+  __shared__ double pb[16], pbv[16], tks[3];
+  __shared__ int pj[16];
+  __shared__ int cnt[2];
+  if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
+  __syncthreads();
+  const int fail = band_factor_wide2_core((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)ulds, (lds_f64 *)alds, (lds_f64 *)lval, (lds_i32 *)cols, (lds_i32 *)lrow,
+                                          (lds_f64 *)pb, (lds_f64 *)pbv, (lds_i32 *)pj, (lds_i32 *)cnt, (lds_f64 *)tks);
+  __syncthreads();
+  for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
+  return fail;
 }
 
 // Substitution for the wide band with the right-hand side in LDS (the kernel's dynamic LDS, n doubles; one right-hand side
