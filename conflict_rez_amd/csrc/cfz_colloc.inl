@@ -879,9 +879,6 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
       const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
       if (nw != old) {
-#if defined(CFZC_TRACE)
-        if (!first) printf("   obs ws change q %d obs %d: %d/%d/%d%d -> %d/%d/%d%d slack %.3e %.3e z %.2e %.2e\n", q, j, old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sO + q * d.nr + 2 * j], X[d.sO + q * d.nr + 2 * j + 1], w.zl[d.sO + q * d.nr + 2 * j], w.zl[d.sO + q * d.nr + 2 * j + 1]);
-#endif
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
         cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
         for (int r = 0; r < 2; ++r) {
@@ -903,9 +900,6 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
     const int old = first ? 0 : w.sel[d.np * sp.n_obs + pp];
     const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old);
     if (nw != old) {
-#if defined(CFZC_TRACE)
-      if (!first) printf("   pair ws change pp %d (pair %d r %d): %d/%d/%d%d -> %d/%d/%d%d slack %.3e %.3e z %.2e %.2e\n", pp, e, pp - d.poff[e], old >> 6, (old >> 4) & 3, (old >> 2) & 3, old & 3, nw >> 6, (nw >> 4) & 3, (nw >> 2) & 3, nw & 3, X[d.sP + 2 * pp], X[d.sP + 2 * pp + 1], w.zl[d.sP + 2 * pp], w.zl[d.sP + 2 * pp + 1]);
-#endif
       w.sel[d.np * sp.n_obs + pp] = (unsigned char)nw;
       for (int r = 0; r < 2; ++r) {
         const double sep = pair_row<false>(pa, pb, sp.g, nw >> 6, (nw >> 4) & 3, r == 0 ? (nw >> 2) & 3 : nw & 3, nullptr, nullptr);
@@ -1101,9 +1095,6 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         if (sw) { f_type = true; ok = ph_t <= phi0 + sp.eta_phi * alpha * dphi; }
         else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
       }
-#if defined(CFZC_TRACE)
-      if (bt >= 6) printf("     bt %d alpha %.3e th_t %.6e (theta %.6e) ph_t %.10e phi0 %.10e dphi %.3e nfilt %d\n", bt, alpha, th_t, theta, ph_t, phi0, dphi, nfilt);
-#endif
       if (ok) { accepted = true; break; }
       alpha *= 0.5;
     }
@@ -1132,7 +1123,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       }
     }
     if (!accepted) { status = 2; break; }
-#if defined(CFZC_TRACE)
+#if defined(CFZC_TRACE)  // CPU build only (tests/emu): g++ -DCFZC_TRACE -include stdio.h
     printf("it %3d mu %.2e err %.3e theta %.3e cviol %.2e dinf %.2e cmp %.2e delta %.1e alpha %.3e a_pri %.3e a_dual %.3e ftype %d dt %.5f f %.5f\n", iter, mu, err0, theta, cviol, dual_inf, cmp0, delta, alpha, a_pri, a_dual, (int)f_type, w.x[d.iDt], objective(sp, w.x));
 #endif
     if (!f_type) {
