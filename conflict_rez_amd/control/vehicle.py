@@ -3,10 +3,9 @@
 Built in this round: the constructor (:29-52), the collocation tables (`collocation_coefficients`
 :54-97), the warm-start resampling (`interp_ws_for_collocation` :298-358), the Lagrange
 interpolant of a collocation solution (`get_interpolator` :722-786, `interpolate_states`
-:788-829) -- all numpy, no CasADi.  `state_ws` (:99-231) and `dual_ws` (:233-296) run on the GPU (`cfz_state_ws`: banded interior point,
-`cfz_dual_ws`: closed form).  The Radau collocation NLP (`setup/solve_single_final_problem` :360-661) is the next
-row of the coverage table (DESIGN.md "Next"); until its kernel lands it raises
-`NotImplementedError`, and `VehicleFollower.plan_single_path` follows the `state_ws` trajectory.
+:788-829) -- all numpy, no CasADi.  The three NLPs run on the GPU: `state_ws` (:99-231, `cfz_state_ws`: banded interior
+point), `dual_ws` (:233-296, `cfz_dual_ws`: closed form) and the Radau collocation plan with free dt
+(`setup_single_final_problem` / `solve_single_final_problem` :360-661, `cfz_colloc`).
 """
 from typing import Dict, Tuple
 
@@ -128,8 +127,8 @@ class Vehicle:
         (csrc/cfz_colloc.inl) and rebuilt from the poses by `get_solution`.  Returns the problem description that
         `solve_single_final_problem` hands to `cfz_colloc` (the reference returns its `ca.Opti`)."""
         if opti is not None or dt is not None:
-            raise NotImplementedError("a shared Opti / shared dt belongs to the joint multi-vehicle problem "
-                                      "(multi_vehicle_planner.py:63-206), which has no HIP kernel; see DESIGN.md 'Next'")
+            raise NotImplementedError("a shared Opti / shared dt belongs to the joint multi-vehicle problem: "
+                                      "MultiVehiclePlanner.solve_final_problem_obca assembles it for cfz_joint_colloc")
         if K != 5:
             raise NotImplementedError("cfz_colloc is built for K = 5 (CFZ_COLLOC_K), the reference's only caller value")
         from ..engine import ProblemSpec
@@ -247,7 +246,7 @@ class Vehicle:
     def set_reference_trajectory(self, traj: VehiclePrediction):
         """Interpolators from a sampled trajectory (t, x, y, psi, v, u_steer, u_a, u_steer_dot): linear in
         the states, piecewise constant in the inputs, final sample held -- stands in for the
-        collocation interpolant while the planner kernels are not built."""
+        collocation interpolant when a trajectory comes from elsewhere (a `state_ws` result, a recorded plan)."""
         t = np.asarray(traj.t, float)
         S = np.stack([np.asarray(getattr(traj, n), float) for n in ("x", "y", "psi", "v", "u_steer")], 1)
         ua, uw = np.asarray(traj.u_a, float), np.asarray(traj.u_steer_dot, float)

@@ -232,7 +232,7 @@ class MultiDistributedFollower:
 
     def setup_multi_vehicles(self, references: Dict[str, VehiclePrediction] = None):
         """plan -> get_others -> setup_controller -> get_current_ref for every vehicle (:614-624).
-        `references` supplies the planned trajectories while the planning kernels are not built."""
+        `references` supplies planned trajectories from elsewhere instead of planning them here."""
         for v in self.vehicles:
             if references is not None:
                 v.set_reference(references[v.agent])
