@@ -57,3 +57,16 @@ rj = engine.joint_colloc_batch(sp, scen, max_iter=400)
 t1 = time.time()
 print(f"{B} two-vehicle joint plans: {t1 - t0:.2f} s ({sum(r['status'] == 0 for r in rj)} converged, iterations {min(r['iters'] for r in rj)}-{max(r['iters'] for r in rj)})"
       f" -> {B / (t1 - t0):.1f} plans/s", flush=True)
+# configs[3] proper: B4 four-vehicle joint plans (default 32; argv[2])
+B4 = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+scen = []
+for b in range(B4):
+    base = (b % (B // 4)) * 4
+    sing = [res[base + i] for i in range(4)]
+    scen.append(dict(init_poses=[init[base + i] for i in range(4)], tubes=[tubes[a] for a in agents], guesses=[s["traj"].reshape(-1, 7) for s in sing],
+                     dt0=float(np.mean([s["dt"] for s in sing])), final_headings=[fh[a] for a in agents]))
+t0 = time.time()
+rj = engine.joint_colloc_batch(sp, scen, max_iter=300)
+t1 = time.time()
+print(f"{B4} four-vehicle joint plans: {t1 - t0:.2f} s ({sum(r['status'] == 0 for r in rj)} converged, iterations {sorted(r['iters'] for r in rj)})"
+      f" -> {B4 / (t1 - t0):.2f} plans/s", flush=True)
