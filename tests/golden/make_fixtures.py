@@ -161,7 +161,41 @@ def carry_golden():
     np.savez_compressed(os.path.join(HERE, "carry_golden.npz"), sol=np.array(sol), meta=np.array(meta))
 
 
+def colloc_golden():
+    """Regression pins of the planning solvers (NOT an oracle: produced by the CPU build of the kernel source,
+    tests/emu/cfz_colloc_emu.cpp; what checks those solutions independently is tests/test_colloc.py and
+    tests/test_independent_solver.py): the single plan of vehicle_1 and the joint plan of vehicles 2 and 3 of the synthetic
+    strategy at the reference's sizes -- guess (points + dt) in, status, iterations, cost and solution out."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import colloc_emu_binding as ce
+    import test_colloc as tc
+    from conflict_rez_amd import scenarios
+    from oracle.colloc_nlp import CollocNlp
+
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    plans = {a: ([dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]], paths[a]) for a in sorted(hist)}
+    opt = ipm.IpmOptions(**tc.COLLOC_OPT)
+    sp = scenarios.parking_lot_spec()
+    tube, p = plans["vehicle_1"]
+    fh = float(p[-1, 2])
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    X0 = tc.colloc_guess(nlp, tc.warm_start(tube, p, fh))
+    r1 = ce.solve(nlp, X0, opt)
+    jn, _ = tc._joint_problem(plans, ["vehicle_2", "vehicle_3"], [0, 0], nps=5)
+    J0, _ = tc._joint_guess(plans, ["vehicle_2", "vehicle_3"], jn, sp, 5)
+    r2 = ce.solve(jn, J0, opt)
+    print("single", r1["status"], r1["iters"], r1["f"], "joint", r2["status"], r2["iters"], r2["f"])
+    np.savez_compressed(os.path.join(HERE, "colloc_golden.npz"), single_guess=X0[: nlp.iDt + 1], single_sol=r1["X"],
+                        single_meta=np.array([r1["status"], r1["iters"], r1["f"]]), joint_guess=J0[: jn.iDt + 1], joint_sol=r2["X"],
+                        joint_meta=np.array([r2["status"], r2["iters"], r2["f"]]))
+
+
 if __name__ == "__main__":
     pytypes_fields()
     mpc_golden(refs_4v())
     carry_golden()
+    colloc_golden()

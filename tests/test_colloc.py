@@ -338,3 +338,43 @@ def test_joint_colloc_on_gpu(plans, tmp_path):
     assert all(len(fr[a].x) == n_max * 6 + 1 and np.isclose(fr[a].t[-1], n_max * mvp.final_dt) for a in agents)
     # on the common clock the two bodies never come closer than dmin: centres of the rear axles at least a body width apart
     assert np.hypot(fr[agents[0]].x - fr[agents[1]].x, fr[agents[0]].y - fr[agents[1]].y).min() > 1.8
+
+
+def test_colloc_source_reproduces_fixture(plans):
+    """tests/golden/colloc_golden.npz (make_fixtures.py:colloc_golden): from the stored guesses the kernel source reproduces
+    status, iteration count, cost and solution of the single plan of vehicle_1 and of the joint plan of vehicles 2 and 3.
+    A regression pin of the solver's behaviour, not an oracle; the GPU build is compared with the same data below."""
+    import colloc_emu_binding as ce
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "colloc_golden.npz"))
+    sp = scenarios.parking_lot_spec()
+    tube, p = plans["vehicle_1"]
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=float(p[-1, 2]))
+    jn, _ = _joint_problem(plans, ["vehicle_2", "vehicle_3"], [0, 0], nps=5)
+    for prob, key in ((nlp, "single"), (jn, "joint")):
+        r = ce.solve(prob, g[key + "_guess"], ipm.IpmOptions(**COLLOC_OPT))
+        st, it, f = g[key + "_meta"]
+        assert (r["status"], r["iters"]) == (int(st), int(it)) and abs(r["f"] - f) < 1e-9 * f
+        assert np.abs(r["X"] - g[key + "_sol"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_colloc_fixture_on_gpu(plans):
+    """The same fixture through the C ABI: cfz_colloc and cfz_joint_colloc from the stored guesses."""
+    from conflict_rez_amd import engine
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "colloc_golden.npz"))
+    spec = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tb = lambda a: [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]]
+    fh = lambda a: float(plans[a][1][-1, 2])
+    X0, st = g["single_guess"], g["single_meta"]
+    r = engine.colloc(spec, [plans["vehicle_1"][1][0]], [tb("vehicle_1")], [X0[:-1].reshape(-1, 7)], [X0[-1]], [fh("vehicle_1")], max_iter=400)[0]
+    assert (r["status"], r["iters"]) == (int(st[0]), int(st[1])) and abs(r["cost"] - st[2]) < 1e-8 * st[2]
+    assert np.abs(r["traj"].reshape(-1, 7) - g["single_sol"][:-1].reshape(-1, 7)).max() < 1e-6 and abs(r["dt"] - g["single_sol"][-1]) < 1e-8
+    J0, st = g["joint_guess"], g["joint_meta"]
+    agents = ["vehicle_2", "vehicle_3"]
+    n2 = 6 * 5 * (len(plans["vehicle_2"][0]) - 1)
+    r = engine.joint_colloc(spec, [plans[a][1][0] for a in agents], [tb(a) for a in agents],
+                            [J0[: 7 * n2].reshape(-1, 7), J0[7 * n2 : -1].reshape(-1, 7)], J0[-1], [fh(a) for a in agents], max_iter=400)
+    assert (r["status"], r["iters"]) == (int(st[0]), int(st[1])) and abs(r["cost"] - st[2]) < 1e-8 * st[2]
+    assert np.abs(np.concatenate([t.reshape(-1, 7) for t in r["traj"]]) - g["joint_sol"][:-1].reshape(-1, 7)).max() < 1e-6
