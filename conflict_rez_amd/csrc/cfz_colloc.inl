@@ -41,6 +41,14 @@
 
 namespace cfzc {
 
+// Dual regularisation of proximal type: the constraint rows of the Newton system read  J dx - delta_c (nu + dnu) = -c
+// instead of IPOPT's  J dx - delta_c dnu = -c.  With the latter, multiplier components that the rows do not
+// determine (the reference's formulation loses LICQ wherever a vehicle stands still: six ODE rows per interval and state
+// on a rank-5 derivative matrix) accumulate c_y / delta_c per iteration and wander; with the former they are SET to
+// c_y / delta_c each time.  The fixed point moves to c = delta_c nu (a quadratic penalty of weight 1 / delta_c on the
+// rows), which the termination test sees as constraint violation and bounds by constr_viol_tol.
+// CSpec::no_prox = 1 switches it off (the exact solution at tight tolerances, tests/test_independent_solver.py).
+
 constexpr int kPts = 6;     // points per interval (K + 1)
 constexpr int kOutD = 12;    // out_d: cost, err, mu, then 100 MHz ticks spent in evaluation, assembly, factorisation, substitution,
                             // line search, and in total (zero on the CPU)
@@ -99,7 +107,7 @@ constexpr int kMaxVeh = 4, kMaxPairs = 6;
 // plan the two bodies at least dmin apart (:389-456) -- again as two smooth rows per (pair, point) over a working set.
 struct CSpec {
   int V, Nps, n_obs, n_pairs;
-  int max_iter, max_backtrack, filter_cap, pad0;
+  int max_iter, max_backtrack, filter_cap, no_prox;
   int N[kMaxVeh], n_chk[kMaxVeh], has_final[kMaxVeh];
   int pair_a[kMaxPairs], pair_b[kMaxPairs];
   double wb, dmin, shrink, dt0;
@@ -458,6 +466,7 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
 // so the pose block gains D g g' and the pose right-hand side loses D t g; g, D, t are kept in w.cond for `recover`.
 CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
   const CDims d = cdims(sp);
+  const double prox = sp.no_prox ? 0.0 : 1.0;
   const int *px = w.posx, *pc = w.posc;
   const double *X = w.x, *nu = w.nu;
   const double dt = X[d.iDt];
@@ -509,7 +518,7 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
       cfz::rows_for<true>(A, bb, V, p[0], p[1], cs, sn, sp.g, sl, sep, gr);
       for (int rr = 0; rr < 2; ++rr) {
         const int row = d.rR + q * d.nr + 2 * j + rr, sk = d.sO + q * d.nr + 2 * j + rr;
-        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] + w.r1[sk] / S;
+        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] - prox * sp.reg_dual * nu[row] + w.r1[sk] / S;
         double *cd = w.cond + (size_t)(q * d.nr + 2 * j + rr) * 5;
         cd[0] = gr[rr][0]; cd[1] = gr[rr][1]; cd[2] = gr[rr][2]; cd[3] = D; cd[4] = t;
         for (int a = 0; a < 3; ++a) {
@@ -563,7 +572,7 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
         double gr[6], H[6][6];
         pair_row<true>(X + 7 * qa, X + 7 * qb, sp.g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, gr, H);
         const int row = d.rP + 2 * pp + rr, sk = d.sP + 2 * pp + rr;
-        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] + w.r1[sk] / S, nr_ = nu[row];
+        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), nr_ = nu[row], t = w.c[row] - prox * sp.reg_dual * nr_ + w.r1[sk] / S;
         double *cd = w.condp + (size_t)(2 * pp + rr) * 8;
         for (int a = 0; a < 6; ++a) cd[a] = gr[a];
         cd[6] = D; cd[7] = t;
@@ -923,6 +932,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   const CWork w = carve(sp, kb, slab);
   const Band Bd = {w.ab, kb, 3 * kb + 1};
   const int n = d.n, m = d.m;
+  const double prox = sp.no_prox ? 0.0 : 1.0;
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
@@ -975,7 +985,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
-    if (iter == sp.max_iter) break;
+    if (iter == sp.max_iter) { status = 1; break; }  // (assigned here as well: the GPU build returned 0 for this exit without it)
     while (mu > mu_floor) {
       double cm = 0.0;
       CFZP_LANE_FOR(i, 0, n - 1) {
@@ -999,7 +1009,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     for (int tries = 0; tries < 60; ++tries) {
       ta = tick();
       CFZP_LANE_FOR(i, 0, n - 1) if (w.posx[i] >= 0) w.rhs[w.posx[i]] = -w.r1[i];
-      CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.rhs[w.posc[i]] = -w.c[i];
+      CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.rhs[w.posc[i]] = -w.c[i] + prox * sp.reg_dual * w.nu[i];
       CFZP_SYNC();
       const double hdd = assemble(sp, w, Bd, delta);
       CFZP_LANE_FOR(i, 0, d.nk - 1) w.rhs2[i] = w.bord[i];
@@ -1046,7 +1056,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         }
         CFZP_SYNC();
         CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.dx[i]; if (!isfinite(v)) bad = 1.0; curv -= v * w.r1[i]; dd += v * v; }
-        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += w.c[i] * v - sp.reg_dual * v * v; }
+        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += (w.c[i] - prox * sp.reg_dual * w.nu[i]) * v - sp.reg_dual * v * v; }
         curv = bsum(curv); dd = bsum(dd); bad = bmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }

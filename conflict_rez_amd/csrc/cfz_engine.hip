@@ -872,12 +872,13 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
     p.tol = co->tol; p.constr_viol_tol = co->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = co->mu_init;
     p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
     p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
-    // delta_c = 3e-6: while a vehicle stands still with its heading along an axis, the six ODE rows of x (or y) of an
-    // interval only see the rank-5 derivative matrix and their multipliers drift.  The vehicle of the synthetic strategy
-    // that waits at its start, 16 start poses scattered by 3 cm: 1e-7 -> 44-272 iterations and 2 failures, 1e-6 -> 31-154,
-    // 3e-6 -> 28-57, 1e-5 -> 2 failures; the other vehicles pay 1-4 iterations.  The rows are then met to ~1e-3 instead of
-    // ~1e-6 (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = 3e-6; p.curv_kappa = co->curv_kappa;
+    // delta_c = 1e-7 of proximal type (cfz_colloc.inl): while a vehicle stands still with its heading along an axis, the
+    // six ODE rows of x (or y) of an interval only see the rank-5 derivative matrix and their multipliers are not
+    // determined.  Measured on the synthetic strategy: IPOPT's form of delta_c needs 288 iterations at 1e-9, 38 at 1e-7
+    // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
+    // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
+    // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
+    p.reg_primal = 1e-8; p.reg_dual = 1e-7; p.curv_kappa = co->curv_kappa;
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);

@@ -399,7 +399,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
-    if (iter == sp.max_iter) break;
+    if (iter == sp.max_iter) { status = 1; break; }
     if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     while (mu > mu_floor) {  // barrier update

@@ -744,7 +744,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     fval_last = fval;
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
-    if (iter == sp.max_iter) break;
+    if (iter == sp.max_iter) { status = 1; break; }
     // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
     if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }

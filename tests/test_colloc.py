@@ -15,7 +15,7 @@ from oracle import ipm
 from oracle.colloc_nlp import CollocNlp, radau_tables, reference_residuals
 from oracle.plan_nlp import StateWsNlp, speed_guess
 
-COLLOC_OPT = dict(max_iter=400, reg_dual=3e-6, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
+COLLOC_OPT = dict(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
 
 
 @pytest.fixture(scope="module")
@@ -371,6 +371,9 @@ def test_colloc_fixture_on_gpu(plans):
     r = engine.colloc(spec, [plans["vehicle_1"][1][0]], [tb("vehicle_1")], [X0[:-1].reshape(-1, 7)], [X0[-1]], [fh("vehicle_1")], max_iter=400)[0]
     assert (r["status"], r["iters"]) == (int(st[0]), int(st[1])) and abs(r["cost"] - st[2]) < 1e-8 * st[2]
     assert np.abs(r["traj"].reshape(-1, 7) - g["single_sol"][:-1].reshape(-1, 7)).max() < 1e-6 and abs(r["dt"] - g["single_sol"][-1]) < 1e-8
+    # the iteration limit is reported as such (status 1): the GPU build once returned 0 for this exit
+    r5 = engine.colloc(spec, [plans["vehicle_1"][1][0]], [tb("vehicle_1")], [X0[:-1].reshape(-1, 7)], [X0[-1]], [fh("vehicle_1")], max_iter=5)[0]
+    assert (r5["status"], r5["iters"]) == (1, 5)
     J0, st = g["joint_guess"], g["joint_meta"]
     agents = ["vehicle_2", "vehicle_3"]
     n2 = 6 * 5 * (len(plans["vehicle_2"][0]) - 1)

@@ -158,7 +158,9 @@ def test_collocation_plan_is_stationary_for_slsqp():
     vp[0] = vp[-1] = 0.0
     zu0["v"] = np.interp(t_i, t, vp)
     X0 = nlp.pack(zu0, t[-1] / N)
-    res = ce.solve(nlp, X0, ipm.IpmOptions(max_iter=600, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6))
+    opt = ipm.IpmOptions(max_iter=600, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
+    opt.no_prox = 1  # the unregularised rows: the proximal form stops at c = delta_c nu
+    res = ce.solve(nlp, X0, opt)
     assert res["status"] == 0
     nz = nlp.iDt + 1
     Xs = np.zeros(nlp.n)

@@ -26,5 +26,5 @@ for a, fh, w in zip(agents, fhs, ws):
     guesses.append(X0[: nlp.iDt].reshape(-1, 7)); dt0s.append(X0[nlp.iDt])
 for sel in ([1], [0, 1, 2, 3]):
     t0 = time.time()
-    res = engine.colloc(sp, [plans[agents[i]][1][0] for i in sel], [tubes[i] for i in sel], [guesses[i] for i in sel], [dt0s[i] for i in sel], [fhs[i] for i in sel], max_iter=400)
+    res = engine.colloc(sp, [plans[agents[i]][1][0] for i in sel], [tubes[i] for i in sel], [guesses[i] for i in sel], [dt0s[i] for i in sel], [fhs[i] for i in sel], max_iter=int(os.environ.get("MAXIT", 400)))
     print(sel, "time", time.time() - t0, [(r["status"], r["iters"], round(r["cost"], 4), round(r["dt"], 5)) for r in res], flush=True)

@@ -30,7 +30,7 @@ ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh
 t1 = time.time()
 gs = [guess_of(w["traj"], len(tubes[a]) + 1) for w, a in zip(ws, who)]
 good = [i for i, w in enumerate(ws) if w["status"] == 0]  # a vehicle whose warm start failed is not refined (plan_single_path raises there)
-rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=150)
+rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=int(os.environ.get("MAXIT", 150)))
 t2 = time.time()
 res = [None] * B
 for i, r in zip(good, rg):
@@ -40,6 +40,7 @@ for i in range(B):
         res[i] = res[i - 4]
 ok = sum(r["status"] == 0 for r in rg)
 its = np.sort([r['iters'] for r in rg])
+print('slow or failed:', sorted((r['iters'], r['status']) for r in rg if r['iters'] > 60 or r['status'] != 0))
 print('collocation iterations: median', int(np.median(its)), '90%', int(its[int(0.9 * len(its))]), '99%', int(its[int(0.99 * len(its))]), 'top', its[-4:].tolist())
 print(f"{B} single plans: state_ws {t1 - t0:.2f} s ({sum(w['status'] == 0 for w in ws)} converged), collocation {t2 - t1:.2f} s ({ok} converged, "
       f"iterations {min(r['iters'] for r in rg)}-{max(r['iters'] for r in rg)}) -> {len(good) / (t2 - t0):.0f} plans/s", flush=True)
