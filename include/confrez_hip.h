@@ -193,7 +193,7 @@ typedef struct cfz_colloc_options {
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */
-  double mu_init;         /* 1e-3 */
+  double mu_init;         /* 0.1 (IPOPT's default) */
   double curv_kappa;      /* 1e-8 */
 } cfz_colloc_options;
 

@@ -15,7 +15,7 @@ from oracle import ipm
 from oracle.colloc_nlp import CollocNlp, radau_tables, reference_residuals
 from oracle.plan_nlp import StateWsNlp, speed_guess
 
-COLLOC_OPT = dict(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2)  # vehicle.py:650-651
+COLLOC_OPT = dict(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2, mu_init=0.1)  # vehicle.py:650-651
 
 
 @pytest.fixture(scope="module")

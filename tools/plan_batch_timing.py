@@ -8,6 +8,7 @@ from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_set
 from conflict_rez_amd.vehicle_types import VehicleBody
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+MU = dict(mu_init=float(os.environ["MU0"])) if "MU0" in os.environ else {}  # experiments: initial barrier parameter
 hist = strat.generate_strategy(4)
 with tempfile.TemporaryDirectory() as d:
     fn = os.path.join(d, "4v_rl_traj"); strat.write_strategy(fn, hist)
@@ -30,7 +31,7 @@ ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh
 t1 = time.time()
 gs = [guess_of(w["traj"], len(tubes[a]) + 1) for w, a in zip(ws, who)]
 good = [i for i, w in enumerate(ws) if w["status"] == 0]  # a vehicle whose warm start failed is not refined (plan_single_path raises there)
-rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=int(os.environ.get("MAXIT", 150)))
+rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=int(os.environ.get("MAXIT", 150)), **MU)
 t2 = time.time()
 res = [None] * B
 for i, r in zip(good, rg):
@@ -54,7 +55,7 @@ for b in range(B):
     scen.append(dict(init_poses=ip, tubes=[tubes[a] for a in pair], guesses=[s["traj"].reshape(-1, 7) for s in sing],
                      dt0=float(np.mean([s["dt"] for s in sing])), final_headings=[fh[a] for a in pair]))
 t0 = time.time()
-rj = engine.joint_colloc_batch(sp, scen, max_iter=400)
+rj = engine.joint_colloc_batch(sp, scen, max_iter=400, **MU)
 t1 = time.time()
 print(f"{B} two-vehicle joint plans: {t1 - t0:.2f} s ({sum(r['status'] == 0 for r in rj)} converged, iterations {min(r['iters'] for r in rj)}-{max(r['iters'] for r in rj)})"
       f" -> {B / (t1 - t0):.1f} plans/s", flush=True)
@@ -67,7 +68,7 @@ for b in range(B4):
     scen.append(dict(init_poses=[init[base + i] for i in range(4)], tubes=[tubes[a] for a in agents], guesses=[s["traj"].reshape(-1, 7) for s in sing],
                      dt0=float(np.mean([s["dt"] for s in sing])), final_headings=[fh[a] for a in agents]))
 t0 = time.time()
-rj = engine.joint_colloc_batch(sp, scen, max_iter=300)
+rj = engine.joint_colloc_batch(sp, scen, max_iter=300, **MU)
 t1 = time.time()
 print(f"{B4} four-vehicle joint plans: {t1 - t0:.2f} s ({sum(r['status'] == 0 for r in rj)} converged, iterations {sorted(r['iters'] for r in rj)})"
       f" -> {B4 / (t1 - t0):.2f} plans/s", flush=True)
