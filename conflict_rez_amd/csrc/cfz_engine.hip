@@ -973,7 +973,8 @@ int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_c
 void cfz_default_colloc_options(cfz_colloc_options *o) {
   memset(o, 0, sizeof *o);
   o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5;
-  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1;  /* IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations */ o->curv_kappa = 1e-8;
+  // mu_init: IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1; o->curv_kappa = 1e-8;
 }
 
 void cfz_default_plan_options(cfz_plan_options *o) {
