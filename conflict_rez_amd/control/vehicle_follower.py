@@ -204,9 +204,11 @@ class VehicleFollower(Vehicle):
     def step(self):
         """step the controller (:428-563)"""
         x0, ref, nbr, zu = self.prepare_step()
-        # slot 0 of this vehicle's engine: after a converged step the next one starts from its multipliers (the
-        # reference hands the previous duals to opti.set_initial, :458-464, :475-476)
-        out = self.engine.solve(x0[None], ref[None], nbr[None], zu[None], carry=[int(getattr(self, "status", 1) == 0)])
+        # a batch of one in THIS vehicle's carry slot of the (possibly shared) engine: after a converged step the next
+        # one starts from its own multipliers (the reference hands the previous duals to opti.set_initial, :458-464,
+        # :475-476), never from another vehicle's
+        out = self.engine.solve(x0[None], ref[None], nbr[None], zu[None], carry=[int(getattr(self, "status", 1) == 0)],
+                                slots=[getattr(self, "slot", 0)])
         self.finish_step(out, 0)
 
 
@@ -243,8 +245,8 @@ class MultiDistributedFollower:
         spec = ProblemSpec.from_objects(first.obstacles, first.vehicle_body, first.vehicle_config, first.region,
                                         n_nbr=len(self.vehicles) - 1)
         self.engine = Engine(spec, max_batch=len(self.vehicles))
-        for v in self.vehicles:
-            v.engine = self.engine
+        for b, v in enumerate(self.vehicles):
+            v.engine, v.slot = self.engine, b  # slot b of the shared engine is vehicle b, in `solve()` and in `v.step()`
             v.setup_controller()
             v.get_current_ref()
             self.single_results[v.agent] = v.reference_traj

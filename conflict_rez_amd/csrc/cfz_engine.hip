@@ -48,7 +48,8 @@ struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
                                                    int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
-                                                   double *wst, int wst_stride, const int32_t *carry, int carry_all) {
+                                                   double *wst, int wst_stride, const int32_t *carry, int carry_all,
+                                                   const int32_t *slots) {
   extern __shared__ double smem[];
   if ((int)blockIdx.x >= B) return;
   // workgroups are dispatched in index order: `order` puts the instances expected to run longest first
@@ -64,9 +65,11 @@ __global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cf
     duo.lam_ij = du.lam_ij + (size_t)b * nn * N * 4; duo.lam_ji = du.lam_ji + (size_t)b * nn * N * 4;
     duo.s = du.s + (size_t)b * nn * N * 2;
   }
-  // carry record of slot b: used when the caller says that this solve is the successor of the previous one in the slot
+  // carry record of the instance's slot (default: slot b): used when the caller says that this solve is the successor of
+  // the previous one in that slot
+  const int slot = slots ? slots[b] : b;
   cfz::solve_instance(sp, x0 + (size_t)b * 5, ref + (size_t)b * 3 * N, nbr + (size_t)b * nn * 3 * N,
-                      zu + (size_t)b * 7 * N, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr,
+                      zu + (size_t)b * 7 * N, smem, L, oi, od, duo, wst ? wst + (size_t)slot * wst_stride : nullptr,
                       carry_all || (carry && carry[b]));
   if (threadIdx.x == 0) {
     iters[b] = oi[0]; status[b] = oi[1];
@@ -408,9 +411,12 @@ struct cfz_handle {
   double *obs_tab = nullptr;  // n_obs x 20: A[4][2], b[4], V[4][2] (KSpec::obs_tab)
   // carry records (multipliers handed from one MPC iteration to the next), one per slot; per-solve flags
   double *wst = nullptr;
-  int32_t *carry = nullptr;
+  int32_t *carry = nullptr, *slots = nullptr;   // device: per-solve flags and slot ids
+  int32_t *stage_host = nullptr;                // pinned staging for both (2 x max_batch): no blocking copy per solve
+  hipEvent_t ev_stage = nullptr;                // the staged copy, for solves launched on a caller's stream
   int wst_stride = 0, carry_duals = 1;
-  bool carry_set = false, ms_pending = false;
+  bool carry_set = false, slots_set = false, ms_pending = false;
+  const int32_t *carry_ext = nullptr;           // cfz_mpc_set_carry_device: the caller's device array, for one solve
   // per-instance buffers
   double *x0 = nullptr, *ref = nullptr, *nbr = nullptr, *zu = nullptr, *stats = nullptr;
   int32_t *status = nullptr, *iters = nullptr;
@@ -460,16 +466,19 @@ int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, cons
                  const int32_t *order = nullptr, int carry_all = 0) {
   DualPtrs du = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
+  if ((h->carry_set || h->slots_set) && st != h->stream) HIP_OK(hipStreamWaitEvent(st, h->ev_stage, 0));  // staged on the handle's stream
   HIP_OK(hipEventRecord(h->ev0, st));
   hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(64), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
                      iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
-                     h->carry_set ? h->carry : nullptr, carry_all);
-  h->carry_set = false;  // the flags of cfz_mpc_set_carry hold for one solve
+                     h->carry_ext ? h->carry_ext : (h->carry_set ? h->carry : nullptr), carry_all, h->slots_set ? h->slots : nullptr);
+  h->carry_set = false; h->slots_set = false; h->carry_ext = nullptr;  // the flags of cfz_mpc_set_carry / cfz_mpc_set_slots hold for one solve
   h->ms_pending = true;
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   return 0;
 }
+
+int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt);
 
 int check(cfz_handle *h, int B) {
   if (!h) return fail("null handle");
@@ -523,6 +532,16 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
 
   cfz_handle *h = new cfz_handle();
   h->device = device; h->max_batch = max_batch;
+  if (create_fill(h, spec, opt) != 0) { cfz_destroy(h); return -1; }  // g_err is set; everything allocated so far is released
+  *out = h;
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
+  const int max_batch = h->max_batch;
   cfz::KSpec &k = h->ks;
   memset(&k, 0, sizeof k);
   k.N = spec->N; k.n_obs = spec->n_obs; k.n_nbr = spec->n_nbr; k.rk_substeps = spec->rk_substeps;
@@ -532,7 +551,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   memcpy(k.weights, spec->weights, sizeof k.weights);
   for (int j = 0; j < spec->n_obs; ++j) {
     memcpy(k.A_obs[j], spec->A_obs[j], sizeof k.A_obs[j]); memcpy(k.b_obs[j], spec->b_obs[j], sizeof k.b_obs[j]);
-    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], k.V_obs[j])) { delete h; return fail("obstacle is not a bounded quadrilateral"); }
+    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], k.V_obs[j])) return fail("obstacle is not a bounded quadrilateral");
   }
   k.tol = opt->tol; k.constr_viol_tol = opt->constr_viol_tol; k.dual_inf_tol = opt->dual_inf_tol;
   k.compl_inf_tol = opt->compl_inf_tol; k.mu_init = opt->mu_init; k.kappa_eps = opt->kappa_eps;
@@ -544,12 +563,12 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
   if (const char *pad = std::getenv("CFZ_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(pad);  // occupancy experiments only
-  if (h->lds_bytes > 160 * 1024) { delete h; return fail("problem does not fit the 160 KiB LDS of one CU"); }
+  if (h->lds_bytes > 160 * 1024) return fail("problem does not fit the 160 KiB LDS of one CU");
   if (h->lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-    if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
+    if (e != hipSuccess) return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
     e = hipFuncSetAttribute((const void *)loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-    if (e != hipSuccess) { delete h; return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); }
+    if (e != hipSuccess) return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
   }
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, 64, h->lds_bytes);
   {
@@ -576,8 +595,9 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   h->wst_stride = cfz::carry_layout(k.N, k.n_obs + k.n_nbr).stride;
   HIP_OK(hipMalloc(&h->wst, (size_t)max_batch * h->wst_stride * 8));
   HIP_OK(hipMemset(h->wst, 0, (size_t)max_batch * h->wst_stride * 8));
-  HIP_OK(hipMalloc(&h->carry, (size_t)max_batch * 4));
-  HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1));
+  HIP_OK(hipMalloc(&h->carry, (size_t)max_batch * 4)); HIP_OK(hipMalloc(&h->slots, (size_t)max_batch * 4));
+  HIP_OK(hipHostMalloc(&h->stage_host, (size_t)max_batch * 2 * 4, hipHostMallocDefault));
+  HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1)); HIP_OK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
   HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
   // stats: 3 doubles per instance (+ 12 phase counters per instance for the -DCFZ_STAMPS diagnostic build)
@@ -586,19 +606,23 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   HIP_OK(hipMalloc(&h->lam_ij, (B * nn * N * 4 + 1) * 8)); HIP_OK(hipMalloc(&h->lam_ji, (B * nn * N * 4 + 1) * 8));
   HIP_OK(hipMalloc(&h->s, (B * nn * N * 2 + 1) * 8));
   HIP_OK(hipMemset(h->status, 0, B * 4)); HIP_OK(hipMemset(h->iters, 0, B * 4));
-  *out = h;
   return 0;
 }
+}  // namespace
+
+extern "C" {
 
 int cfz_destroy(cfz_handle *h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
                   h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
-                  h->iter_sum, h->obs_tab, h->wst, h->carry};
+                  h->iter_sum, h->obs_tab, h->wst, h->carry, h->slots};
   for (void *p : bufs) if (p) hipFree(p);
+  if (h->stage_host) hipHostFree(h->stage_host);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->ev_stage) hipEventDestroy(h->ev_stage);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -635,8 +659,34 @@ int cfz_mpc_set_warm(cfz_handle *h, int B, const double *zu) {
 int cfz_mpc_set_carry(cfz_handle *h, int B, const int32_t *carry) {
   if (check(h, B)) return -1;
   if (!carry) { h->carry_set = false; return 0; }
-  HIP_OK(hipMemcpy(h->carry, carry, (size_t)B * 4, hipMemcpyHostToDevice));
+  // staged through pinned memory and copied on the handle's stream, so the caller's array is free at once and no
+  // device-wide synchronisation happens; the stream is drained first because the staging buffer may still be feeding
+  // the previous copy (free after cfz_mpc_solve, which ends synchronised).  Device-resident loops that cannot afford
+  // the drain pass their flags with cfz_mpc_set_carry_device.
+  HIP_OK(hipStreamSynchronize(h->stream));
+  memcpy(h->stage_host, carry, (size_t)B * 4);
+  HIP_OK(hipMemcpyAsync(h->carry, h->stage_host, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipEventRecord(h->ev_stage, h->stream));
   h->carry_set = true;
+  return 0;
+}
+
+int cfz_mpc_set_carry_device(cfz_handle *h, int B, const int32_t *d_carry) {
+  if (check(h, B)) return -1;
+  h->carry_ext = d_carry;  // read by the next solve kernel on whatever stream it is launched on; nothing is copied
+  return 0;
+}
+
+int cfz_mpc_set_slots(cfz_handle *h, int B, const int32_t *slots) {
+  if (check(h, B)) return -1;
+  if (!slots) { h->slots_set = false; return 0; }
+  for (int b = 0; b < B; ++b) if (slots[b] < 0 || slots[b] >= h->max_batch) return fail("slot index out of range");
+  HIP_OK(hipStreamSynchronize(h->stream));
+  int32_t *stage = h->stage_host + h->max_batch;
+  memcpy(stage, slots, (size_t)B * 4);
+  HIP_OK(hipMemcpyAsync(h->slots, stage, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipEventRecord(h->ev_stage, h->stream));
+  h->slots_set = true;
   return 0;
 }
 
@@ -1089,8 +1139,10 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
   int per_cu = 0;
   HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)loop_kernel, 64, h->lds_bytes));
+  per_cu = std::min(per_cu, h->blocks_per_cu);  // the 2 KiB LDS granules (cfz_create): what the hardware really keeps resident
   if (per_cu < 1) return fail("loop kernel does not fit on a CU");
-  // every workgroup of the grid must be resident: waiting workgroups poll the queue
+  // one workgroup per resident slot: more would only queue behind them (any workgroup can serve any item, so a surplus
+  // is harmless, just useless)
   if (const char *cap = std::getenv("CFZ_LOOP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(cap)));  // experiments
   const int grid = std::min(B, per_cu * ncu);
   const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;

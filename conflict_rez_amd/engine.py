@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libconfrez_hip.so")
 MAX_OBS, MAX_NBR, MAX_N = 8, 7, 64
 
 STATUS_NAMES = {0: "converged", 1: "iteration limit", 2: "line search failed", 3: "non-finite iterate",
-                4: "measured state in collision (infeasible)"}
+                4: "measured state in collision (infeasible)", 5: "constraint violation stalled (locally infeasible)"}
 
 
 class _CSpec(C.Structure):
@@ -124,6 +124,8 @@ def load_library(path=None):
     lib.cfz_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
     lib.cfz_joint_colloc.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 6 + [C.c_int] + [vp] * 6
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
+    lib.cfz_mpc_set_carry_device.argtypes = [vp, C.c_int, vp]
+    lib.cfz_mpc_set_slots.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_solve.argtypes = [vp, C.c_int]
     lib.cfz_mpc_get.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.cfz_mpc_stats.argtypes = [vp, C.c_int, i32p, i32p, vp, vp, vp]
@@ -143,7 +145,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_mpc_set_carry cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -327,11 +329,12 @@ class Engine:
             raise RuntimeError(f"{what}: " + self.lib.cfz_last_error().decode())
 
     # ---- host-buffer path ------------------------------------------------------------------
-    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None):
+    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None, slots=None):
         """x0 [B,5], ref [B,3,N], nbr [B,n_nbr,3,N], zu [B,7,N] (warm start) ->
         dict(zu, status, iters, cost, kkt_err, min_sep[, l, m, lam_ij, lam_ji, s], solve_ms).
         carry: int/bool [B]; carry[b] says that this solve of slot b is the MPC iteration following the one last
-        solved in slot b, so the interior point starts from its multipliers (`cfz_mpc_set_carry`)."""
+        solved in slot b, so the interior point starts from its multipliers (`cfz_mpc_set_carry`).
+        slots: int [B]; the carry record instance b reads and refreshes (`cfz_mpc_set_slots`; default b)."""
         sp = self.spec
         N, no, nn = sp.N, sp.n_obs, sp.n_nbr
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
@@ -343,6 +346,9 @@ class Engine:
         if carry is not None:
             cflags = np.ascontiguousarray(np.broadcast_to(np.asarray(carry), (B,)), dtype=np.int32)
             self._ck(self.lib.cfz_mpc_set_carry(self._h, B, _ptr(cflags)), "cfz_mpc_set_carry")
+        if slots is not None:
+            sl = np.ascontiguousarray(np.broadcast_to(np.asarray(slots), (B,)), dtype=np.int32)
+            self._ck(self.lib.cfz_mpc_set_slots(self._h, B, _ptr(sl)), "cfz_mpc_set_slots")
         self._ck(self.lib.cfz_mpc_solve(self._h, B), "cfz_mpc_solve")
         out = dict(zu=np.empty((B, 7, N)), status=np.empty(B, np.int32), iters=np.empty(B, np.int32),
                    cost=np.empty(B), kkt_err=np.empty(B), min_sep=np.empty(B))
@@ -369,6 +375,11 @@ class Engine:
         """`cfz_mpc_set_carry` for the next solve (host or device path): flags [B] int."""
         flags = np.ascontiguousarray(flags, dtype=np.int32)
         self._ck(self.lib.cfz_mpc_set_carry(self._h, len(flags), _ptr(flags)), "cfz_mpc_set_carry")
+
+    def set_carry_device(self, B, d_flags):
+        """`cfz_mpc_set_carry_device`: flags as a device int32 array (torch tensor or pointer), no copy, no sync."""
+        p = C.c_void_p(d_flags.data_ptr() if hasattr(d_flags, "data_ptr") else int(d_flags))
+        self._ck(self.lib.cfz_mpc_set_carry_device(self._h, int(B), p), "cfz_mpc_set_carry_device")
 
     # ---- device-pointer path (torch tensors or any object with data_ptr()) --------------------
     def solve_device(self, B, d_x0, d_ref, d_nbr, d_zu, d_status, d_iters, d_stats, stream=None):

@@ -11,7 +11,8 @@
  * Return value: 0 on success, <0 on an API error (cfz_last_error() explains).  Solver
  * outcomes are per instance, in `status`:
  *   0 converged | 1 iteration limit | 2 line search failed | 3 non-finite iterate |
- *   4 measured state already violates a collision row (NLP infeasible, nothing iterated)
+ *   4 measured state already violates a collision row (NLP infeasible, nothing iterated) |
+ *   5 constraint violation stalled above constr_viol_tol (locally infeasible; IPOPT: restoration failed)
  * The reference turns any non-zero outcome into a Python exception that `step()` catches
  * to apply its shift fallback (vehicle_follower.py:478-524); the Python shim does the same.
  *
@@ -96,6 +97,16 @@ int cfz_mpc_set_warm(cfz_handle *h, int B, const double *zu);
  * parameter, shifted by one stage, instead of z = 1, nu = 0, mu = mu_init.  The flags hold for one solve; NULL or
  * no call = cold.  The closed loop (cfz_loop_*) always carries.  Typically 1.8 instead of 4.2 iterations. */
 int cfz_mpc_set_carry(cfz_handle *h, int B, const int32_t *carry);
+
+/* The same flags as a HIP device array int32[B] (e.g. `status == 0` of the previous iteration, computed on the device):
+ * nothing is copied or synchronised; the array is read by the next solve's kernel and must stay valid until it ends. */
+int cfz_mpc_set_carry_device(cfz_handle *h, int B, const int32_t *d_carry);
+
+/* Which carry record each instance of the next solve reads and refreshes: slots[b] in [0, max_batch).  Default (no
+ * call, or NULL): instance b uses record b.  Lets several callers share one handle without mixing their multipliers:
+ * the reference's `for v in vehicles: v.step()` loop (:642-647) and the ROS nodes (vehicle_node.py:150-152) step ONE
+ * vehicle at a time, so each vehicle solves a batch of one in its own slot.  Holds for one solve, like the flags. */
+int cfz_mpc_set_slots(cfz_handle *h, int B, const int32_t *slots);
 
 /* sol = opti.solve() (:479): runs the batched solver and blocks until done. */
 int cfz_mpc_solve(cfz_handle *h, int B);

@@ -1,0 +1,206 @@
+"""BASELINE.json configs[1] and configs[3] on the GPU planning kernels, at their named sizes, through the C ABI.
+
+configs[1]: B = 256 independent single-vehicle OBCA plans (`Vehicle.state_ws` -> `dual_ws` -> collocation plan,
+            reference vehicle.py:99-661) in one launch each of `cfz_state_ws` and `cfz_colloc`.
+configs[3]: the centralised plan of the reference itself -- FOUR vehicles, all six pairs, one shared dt
+            (`MultiVehiclePlanner.solve_final_problem_obca`, multi_vehicle_planner.py:343-480, pairs :56-58) -- and a batch of
+            them in one launch of `cfz_joint_colloc`.
+
+The acceptance check is solver-independent: the reference's own rows, restated as plain loops in
+oracle/colloc_nlp.py (`reference_residuals` per vehicle, vehicle.py:426-638; `pair_residuals` for the vehicle-vehicle rows,
+multi_vehicle_planner.py:423-456), evaluated on the returned plans with the OBCA duals the product path rebuilds
+(`cfz_dual_ws`, `cfz_joint_dual_ws`).  Tolerances are the reference's (tol = constr_viol_tol = 1e-2, vehicle.py:650-651).
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conflict_rez_amd import scenarios, strategy as strat
+from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+from conflict_rez_amd.vehicle_types import VehicleBody
+from oracle.colloc_nlp import CollocNlp, JointCollocNlp, pair_residuals, reference_residuals
+
+pytestmark = pytest.mark.gpu
+
+TAU = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])
+KEYS = ("x", "y", "psi", "v", "delta", "a", "w")
+
+
+@pytest.fixture(scope="module")
+def lot():
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        sets, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    agents = sorted(hist)
+    tubes = {a: [((s["back"].A, s["back"].b), (s["front"].A, s["front"].b)) for s in sets[a][1:]] for a in agents}
+    otubes = {a: [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in sets[a]] for a in agents}
+    return dict(agents=agents, tubes=tubes, otubes=otubes, paths=paths, fh={a: float(paths[a][-1, 2]) for a in agents})
+
+
+def _guess_of(ws, n_sets, nps=5):
+    """interp_ws_for_collocation (vehicle.py:298-358) + dt0 = t_end / N (:388) of a state_ws result [T+1, 7]."""
+    N = nps * (n_sets - 1)
+    t = 0.1 * np.arange(len(ws))
+    ti = (np.arange(N)[:, None] + TAU[None, :]).ravel() / N * t[-1]
+    return np.stack([np.interp(ti, t, ws[:, c]) for c in range(7)], 1), t[-1] / N
+
+
+def _sol_of(traj, dt, eng):
+    """Plan [N, 6, 7] + dt -> the dict `reference_residuals` reads, duals rebuilt on the GPU (`Vehicle.get_solution`'s path)."""
+    sol = {k: traj[:, :, c] for c, k in enumerate(KEYS)}
+    sol["dt"] = dt
+    l, m, _ = eng.dual_ws(traj.reshape(-1, 7)[:, :3])
+    sol["l"], sol["m"] = l.reshape(traj.shape[0], 6, -1), m.reshape(traj.shape[0], 6, -1)
+    return sol
+
+
+def _single_plans(lot, who, init):
+    from conflict_rez_amd import engine
+
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tubes, paths, fh = lot["tubes"], lot["paths"], lot["fh"]
+    ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh[a] for a in who], shrink_tube=0.5)
+    good = [i for i, w in enumerate(ws) if w["status"] == 0]
+    gs = {i: _guess_of(ws[i]["traj"], len(tubes[who[i]]) + 1) for i in good}
+    rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good],
+                       [fh[who[i]] for i in good], max_iter=400)
+    return ws, good, dict(zip(good, rg))
+
+
+def test_config1_256_single_vehicle_plans(lot):
+    """configs[1] at B = 256: the four vehicles of the synthetic strategy in turn, start poses scattered by +-3 cm.  Every
+    warm start that converges is refined; every refined plan meets the cheap vectorised rows (initial pose, terminal
+    v = delta = a = w = 0 and heading, boxes, dt > 0); a sample of 16 plans is put through the reference's full row list."""
+    from conflict_rez_amd import engine
+
+    B = 256
+    agents = lot["agents"]
+    rng = np.random.default_rng(0)
+    who = [agents[i % 4] for i in range(B)]
+    init = [lot["paths"][a][0] + np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] for a in who]
+    ws, good, plans = _single_plans(lot, who, init)
+    assert len(good) >= B - 4, len(good)  # state_ws: the reference raises where IPOPT fails; <= 4 of 256 here
+    assert sum(r["status"] == 0 for r in plans.values()) >= len(good) - 2
+    sp = scenarios.parking_lot_spec()
+    bd = sp.bounds
+    D = None
+    for i, r in plans.items():
+        if r["status"] != 0:
+            continue
+        tr, a = r["traj"], who[i]
+        assert tr.shape == (5 * len(lot["tubes"][a]), 6, 7) and 0.01 < r["dt"] < 2.0
+        assert np.abs(tr[0, 0, :3] - init[i]).max() < 1e-2 and np.abs(tr[0, 0, 3:]).max() < 1e-2
+        if D is None:
+            D = CollocNlp(init[i], lot["otubes"][a], sp.A_obs, sp.b_obs).D
+        zF = D @ tr[-1]
+        assert np.abs(zF[3:]).max() < 1e-2 and abs(zF[2] - lot["fh"][a]) < 1e-2
+        for col, j in ((0, 0), (1, 1), (3, 2), (4, 3), (5, 4), (6, 5)):
+            assert tr[:, :, col].min() >= bd[2 * j] - 1e-9 and tr[:, :, col].max() <= bd[2 * j + 1] + 1e-9
+    eng = engine.Engine(scenarios.parking_lot_spec(n_nbr=0, N=2), max_batch=1)
+    checked = 0
+    for i in [i for i in sorted(plans) if plans[i]["status"] == 0][:: max(1, len(plans) // 16)][:16]:
+        a, r = who[i], plans[i]
+        nlp = CollocNlp(init[i], lot["otubes"][a], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=lot["fh"][a])
+        rr = reference_residuals(nlp, _sol_of(r["traj"], r["dt"], eng))
+        assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9, (i, rr)
+        assert abs(rr["cost"] - r["cost"]) < 1e-8 * max(1.0, r["cost"])
+        checked += 1
+    assert checked == 16
+    eng.close()
+
+
+def test_config3_four_vehicle_joint_plans(lot):
+    """configs[3] in the reference's own shape: four vehicles, six pairs, one shared dt.  One plan from the nominal start
+    poses plus seven with the start poses scattered by +-3 cm, all in ONE launch (one workgroup per plan).  Every plan
+    converges; every vehicle's rows and all six pairs' rows hold in the reference's layout; all vehicles of a plan run on
+    the shared dt; the joint cost is not below the sum of the single-vehicle optima (those ignore the other vehicles)."""
+    from conflict_rez_amd import engine
+
+    agents = lot["agents"]
+    B = 8
+    rng = np.random.default_rng(1)
+    who = [a for _ in range(B) for a in agents]
+    init = [lot["paths"][a][0] + (np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] if i >= 4 else 0.0) for i, a in enumerate(who)]
+    ws, good, plans = _single_plans(lot, who, init)
+    assert len(good) == len(who) and all(r["status"] == 0 for r in plans.values())
+    scen = []
+    for b in range(B):
+        sing = [plans[4 * b + i] for i in range(4)]
+        scen.append(dict(init_poses=[init[4 * b + i] for i in range(4)], tubes=[lot["tubes"][a] for a in agents],
+                         guesses=[s["traj"].reshape(-1, 7) for s in sing], dt0=float(np.mean([s["dt"] for s in sing])),  # :360
+                         final_headings=[lot["fh"][a] for a in agents]))
+    sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    rj = engine.joint_colloc_batch(sp0, scen, max_iter=300)
+    assert [r["status"] for r in rj] == [0] * B, [(r["status"], r["iters"]) for r in rj]
+    sp = scenarios.parking_lot_spec()
+    eng = engine.Engine(sp0, max_batch=1)
+    for b, r in enumerate(rj):
+        jn = JointCollocNlp([dict(init_pose=init[4 * b + i], tube=lot["otubes"][a], final_heading=lot["fh"][a]) for i, a in enumerate(agents)],
+                            sp.A_obs, sp.b_obs, N_per_set=5)
+        assert len(jn.pairs) == 6
+        sols = [_sol_of(r["traj"][i], r["dt"], eng) for i in range(4)]
+        cost = 0.0
+        for i in range(4):
+            rr = reference_residuals(jn, sols[i], i)
+            assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9, (b, i, rr)
+            cost += rr["cost"]
+        assert abs(cost - r["cost"]) < 1e-8 * r["cost"]
+        singles_cost = sum(plans[4 * b + i]["cost"] for i in range(4))
+        assert cost >= singles_cost * (1 - 1e-2), (cost, singles_cost)
+        duals = []
+        for (ia, ib) in jn.pairs:  # pair duals from the product path (MultiVehiclePlanner.joint_dual_ws's kernel)
+            nmin = min(jn.N[ia], jn.N[ib])
+            pa, pb = r["traj"][ia][:nmin].reshape(-1, 7)[:, :3], r["traj"][ib][:nmin].reshape(-1, 7)[:, :3]
+            lam, mu, s, d = eng.joint_dual_ws(pa, pb)
+            assert d.min() > sp.dmin - 1e-2, (b, ia, ib, d.min())
+            duals.append(dict(lam=lam.reshape(nmin, 6, 4), mu=mu.reshape(nmin, 6, 4), s=s.reshape(nmin, 6, 2)))
+        pr = pair_residuals(jn, sols, duals)
+        assert pr["eq"] < 1e-9 and pr["ineq"] < 1e-2 and pr["bound"] == 0.0, (b, pr)
+    # the batch entry equals its own single call (instances are independent)
+    r1 = engine.joint_colloc(sp0, scen[3]["init_poses"], scen[3]["tubes"], scen[3]["guesses"], scen[3]["dt0"], scen[3]["final_headings"], max_iter=300)
+    assert (r1["status"], r1["iters"]) == (rj[3]["status"], rj[3]["iters"]) and r1["cost"] == rj[3]["cost"]
+    eng.close()
+
+
+def test_planner_surface_four_vehicles(tmp_path):
+    """`MultiVehiclePlanner` as the reference's `main` drives it (multi_vehicle_planner.py:609-668) with all four agents:
+    solve_single_problems -> joint_dual_ws -> solve_final_problem_obca; results on the common clock never overlap."""
+    from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
+    from conflict_rez_amd.pytypes import VehicleState
+
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    agents = ["vehicle_%d" % i for i in range(4)]
+    paths = interp_along_sets(fn, VehicleBody(), 30)
+    mvp = MultiVehiclePlanner(fn, {a: True for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
+                              {a: VehicleState() for a in agents}, {a: float(paths[a][-1, 2]) for a in agents})
+    mvp.solve_single_problems()
+    mvp.joint_dual_ws(K=5)
+    mvp.solve_final_problem_obca()
+    assert mvp.final_stats["status"] == 0 and 0.01 < mvp.final_dt < 2.0
+    fr = mvp.final_results
+    n_max = max(mvp.vehicles[a].N for a in agents)
+    assert all(len(fr[a].x) == n_max * 6 + 1 for a in agents)
+    g = np.array([3.3, 0.9, 0.6, 0.9])
+    corners = np.array([[g[0], g[1]], [-g[2], g[1]], [-g[2], -g[3]], [g[0], -g[3]]])
+
+    def poly(p, i):
+        c, s = np.cos(p.psi[i]), np.sin(p.psi[i])
+        return np.array([p.x[i], p.y[i]]) + corners @ np.array([[c, s], [-s, c]])
+
+    def separated(P, Q):
+        for poly_ in (P, Q):
+            for a_, b_ in zip(poly_, np.roll(poly_, -1, 0)):
+                n = np.array([b_[1] - a_[1], a_[0] - b_[0]])
+                if (P @ n).max() < (Q @ n).min() or (Q @ n).max() < (P @ n).min():
+                    return True
+        return False
+
+    for i in range(0, n_max * 6 + 1, 2):
+        for ia in range(4):
+            for ib in range(ia + 1, 4):
+                assert separated(poly(fr[agents[ia]], i), poly(fr[agents[ib]], i)), (i, ia, ib)

@@ -20,16 +20,17 @@ class OracleEngine:
         self.calls, self.fail_at = 0, set(fail_at)
         self.records, self.carried = {}, 0  # per-slot carry records, as the engine keeps them
 
-    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None):
+    def solve(self, x0, ref, nbr, zu, want_duals=True, carry=None, slots=None):
         B, N, nn, no = len(x0), self.ospec.N, self.ospec.n_nbr, self.ospec.n_obs
         out = dict(zu=np.zeros((B, 7, N)), status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), solve_ms=1.0,
                    l=np.ones((B, N, 4 * no)), m=np.ones((B, N, 4 * no)), lam_ij=np.ones((B, nn, N, 4)),
                    lam_ji=np.ones((B, nn, N, 4)), s=np.ones((B, nn, N, 2)))
         for b in range(B):
-            rec = self.records.get(b) if carry is not None and carry[b] else None
+            slot = b if slots is None else int(slots[b])  # cfz_mpc_set_slots: default record b
+            rec = self.records.get(slot) if carry is not None and carry[b] else None
             self.carried += rec is not None
             r = port.solve(self.ospec, x0[b], ref[b], nbr[b], zu[b].T, carry=rec)
-            self.records[b] = r["carry"]
+            self.records[slot] = r["carry"]
             out["zu"][b], out["status"][b], out["iters"][b] = r["p"].T, r["status"], r["iters"]
             if self.calls in self.fail_at:
                 out["status"][b] = 2
@@ -88,6 +89,38 @@ def test_closed_loop_steps_and_bookkeeping(follower_setup):
             assert v.opt_lambda_ij[o].shape == (30, 4) and v.opt_s[o].shape == (30, 2)
     # after its first converged step every vehicle asks the engine to start from the slot's multipliers
     assert mdf.engine.carried == 4 * 5
+
+
+def test_one_by_one_steps_use_own_slots(follower_setup, tmp_path, monkeypatch):
+    """The reference's own loop shape -- `for v in vehicles: v.get_others_pred(...)` then `for v in vehicles: v.step()`
+    (vehicle_follower.py:636-647), also what every ROS node does (vehicle_node.py:150-152) -- on the SHARED engine of
+    `setup_multi_vehicles`: every vehicle solves a batch of one in its own carry slot, so statuses, iteration counts and
+    trajectories equal those of the batched `solve()`; with everything in slot 0 a vehicle would start from another
+    vehicle's multipliers."""
+    import conflict_rez_amd.control.vehicle_follower as vf
+
+    a = follower_setup
+    fn = str(tmp_path / "again")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    b = MultiDistributedFollower(fn, {f"vehicle_{i}": True for i in range(4)}, {f"vehicle_{i}": {"front": (1, 0, 0), "back": (0, 1, 0)} for i in range(4)},
+                                 {f"vehicle_{i}": VehicleState() for i in range(4)}, {f"vehicle_{i}": None for i in range(4)})
+    monkeypatch.setattr(vf, "Engine", lambda spec, max_batch, **kw: OracleEngine(spec))
+    b.setup_multi_vehicles(references=_references())
+    assert [v.slot for v in b.vehicles] == [0, 1, 2, 3]
+    iters_a, iters_b = [], []
+    orig = a.engine.solve
+    a.engine.solve = lambda *args, **kw: (lambda out: (iters_a.extend(out["iters"].tolist()), out)[1])(orig(*args, **kw))
+    origb = b.engine.solve
+    b.engine.solve = lambda *args, **kw: (lambda out: (iters_b.extend(out["iters"].tolist()), out)[1])(origb(*args, **kw))
+    a.solve(num_iter=4, dump=False)
+    for _ in range(4):
+        for v in b.vehicles:
+            v.get_others_pred(b.vehicles)
+        for v in b.vehicles:
+            v.step()
+    assert iters_a == iters_b and b.engine.carried == a.engine.carried == 4 * 3
+    for va, vb in zip(a.vehicles, b.vehicles):
+        assert va.status == vb.status and np.array_equal(va.pred.x, vb.pred.x) and np.array_equal(va.final_traj.x, vb.final_traj.x)
 
 
 def test_shift_fallback_on_failure(follower_setup):

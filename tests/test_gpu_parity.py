@@ -103,19 +103,68 @@ def test_full_batch_properties(eng):
     assert np.array_equal(out2["zu"], out["zu"][perm])
 
 
-def test_closed_loop_on_device(eng):
-    """cfz_loop_* against a host replay of the same Jacobi iteration through the host-buffer API."""
+def _host_replay(spec, ospec, table, k0, noise, steps):
+    """The Jacobi iteration of `MultiDistributedFollower.solve` (vehicle_follower.py:630-663) on the host with the oracle's
+    C port: `_adv_onestep` shift of every prediction (:413-426, 444-476), solve with the multipliers carried from the
+    vehicle's previous solve (oracle/mpc_nlp.py warm_from_carry), read-back or shift fallback (:484-524), plant
+    (:528-543).  Yields (state, pred, status, iters) after every iteration."""
+    from oracle import port
+    from oracle.dynamics import plant_step
+
+    S, V, T, N = len(k0), table.shape[0], table.shape[1], spec.N
+    state = np.zeros((S, V, 5)); pred = np.zeros((S, V, 7, N))
+    for s in range(S):
+        for v in range(V):
+            pred[s, v] = table[v, np.minimum(k0[s] + np.arange(N), T - 1), :].T
+            state[s, v] = table[v, k0[s], :5] + noise[s, v]
+    carry = [[None] * V for _ in range(S)]
+    adv = np.minimum(np.arange(N) + 1, N - 1)
+    for t in range(steps):
+        newp = pred.copy()
+        status = np.zeros((S, V), int); iters = np.zeros((S, V), int)
+        for s in range(S):
+            for v in range(V):
+                kr = np.minimum(k0[s] + t + np.arange(N), T - 1)
+                nb = np.stack([pred[s, u][:3][:, adv] for u in range(V) if u != v])
+                w = pred[s, v][:, adv]
+                r = port.solve(ospec, state[s, v], table[v, kr, :3].T, nb, w.T.copy(), carry=carry[s][v])
+                carry[s][v] = r["carry"]
+                newp[s, v] = r["p"].T if r["status"] == 0 else w
+                state[s, v] = plant_step(state[s, v], newp[s, v][5:7, 0], spec.dt, spec.wb)
+                status[s, v], iters[s, v] = r["status"], r["iters"]
+        pred = newp
+        yield state.copy(), pred.copy(), status, iters
+
+
+def test_closed_loop_on_device(eng, ospec):
+    """cfz_loop_step (loop_prep / solve_kernel / loop_post) AND cfz_loop_run (the persistent loop_kernel, what bench.py
+    times) against a host replay of the same Jacobi iteration with the oracle's C port: reference-table indexing,
+    `_adv_onestep`, carried multipliers, shift fallback, plant RK4 -- equal status and iteration count of every solve,
+    states and predictions to 1e-6 (rounding is amplified by the closed loop, not reset by it)."""
     from conflict_rez_amd import scenarios
 
     table, _ = scenarios.load_reference_table()
     S, steps = 8, 5
     k0, noise = scenarios.sample_scenarios(S, table, seed=3)
     eng.loop_init(table, k0, noise)
-    for _ in range(steps):
+    replay = list(_host_replay(eng.spec, ospec, table, k0, noise, steps))
+    n_fallback = 0
+    for t, (state, pred, status, iters) in enumerate(replay):
         eng.loop_step()
+        got = eng.loop_get()
+        assert np.array_equal(got["status"], status), (t, got["status"], status)
+        assert np.array_equal(got["iters"], iters), (t, got["iters"], iters)
+        assert np.abs(got["state"] - state).max() < 1e-6, t
+        assert np.abs(got["pred"] - pred).max() < 1e-6, t
+        n_fallback += int((status != 0).sum())
+    assert (replay[-1][2] == 0).mean() > 0.7
+    # the persistent launch: all `steps` iterations in one kernel, same end point as the replay
+    eng.loop_init(table, k0, noise)
+    eng.loop_run(steps)
     got = eng.loop_get()
-    assert np.isfinite(got["state"]).all() and np.isfinite(got["pred"]).all()
-    assert (got["status"] == 0).mean() > 0.7
+    state, pred, status, iters = replay[-1]
+    assert np.array_equal(got["status"], status) and np.array_equal(got["iters"], iters)
+    assert np.abs(got["state"] - state).max() < 1e-6 and np.abs(got["pred"] - pred).max() < 1e-6
     # every vehicle moved along its reference: position error against the table after `steps`
     V, T = table.shape[0], table.shape[1]
     for s in range(S):
