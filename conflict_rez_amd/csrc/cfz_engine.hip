@@ -45,7 +45,7 @@ constexpr int kPlantSubsteps = 10;
 
 struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 
-__global__ __launch_bounds__(64) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
+__global__ __launch_bounds__(cfz::kNL, 2) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
                                                    int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
                                                    double *wst, int wst_stride, const int32_t *carry, int carry_all,
@@ -166,54 +166,70 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
 #else
 #define CFZ_MARK(c) do { } while (0)
 #endif
-__global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
-                                                  const double *ref_table, const int32_t *kidx0, int t_base,
-                                                  double *pred, double *state, double *scratch, int32_t *qbuf,
-                                                  int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
-                                                  double *stats, int32_t *iter_sum, double *wst, int wst_stride) {
+__global__ __launch_bounds__(cfz::kNL, 2) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
+                                                        const double *ref_table, const int32_t *kidx0, int t_base,
+                                                        double *pred, double *state, double *scratch, int32_t *qbuf,
+                                                        int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
+                                                        double *stats, int32_t *iter_sum, double *wst, int wst_stride) {
   extern __shared__ double smem[];
-  const int N = sp.N, nn = sp.n_nbr, B = S * V, lane = threadIdx.x;
+  const int N = sp.N, nn = sp.n_nbr, B = S * V, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
   double *x0 = my, *ref = x0 + 5, *nbr = ref + 3 * N, *zu = nbr + nn * 3 * N;
   int32_t *head = qbuf, *tail = qbuf + K, *slots = qbuf + 2 * K;
+  // what wavefront 0 popped, for wavefront 1: {iteration t (-1: leave), instance b}.  Lives in the reduction exchange
+  // area of the workspace, which is idle between two solves.
+  volatile int32_t *cmd = reinterpret_cast<volatile int32_t *>(smem + L.xw);
 #define CFZ_LD(p) __builtin_amdgcn_readfirstlane(__hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
   int idle = 0;
   while (true) {
-    // ---- pop: lowest iteration first ---------------------------------------------------------------------
-    int t0 = CFZ_LD(&ctrl[0]);
-    const int hint = t0;
-    while (t0 < K && CFZ_LD(&head[t0]) >= B) ++t0;
-    if (t0 > hint && lane == 0) atomicMax(&ctrl[0], t0);
-    if (t0 >= K) break;  // every item of every iteration has been handed out
-    int t = -1, idx = 0;
-    for (int tt = t0; tt < K; ++tt) {
-      const int hd = CFZ_LD(&head[tt]), tl = CFZ_LD(&tail[tt]);
-      if (tl == 0) break;  // no scenario has reached iteration tt yet, hence none is further either
-      if (hd >= tl) continue;
-      idx = __builtin_amdgcn_readfirstlane(atomicAdd(&head[tt], lane == 0 ? 1 : 0));
-      if (idx < B) { t = tt; break; }
+    if (wave == 0) {
+      // ---- pop (wavefront 0 only): lowest iteration first -----------------------------------------------
+      int t = -1, b = -1;
+      while (true) {
+        int t0 = CFZ_LD(&ctrl[0]);
+        const int hint = t0;
+        while (t0 < K && CFZ_LD(&head[t0]) >= B) ++t0;
+        if (t0 > hint && lane == 0) atomicMax(&ctrl[0], t0);
+        if (t0 >= K) break;  // every item of every iteration has been handed out
+        int idx = 0;
+        for (int tt = t0; tt < K; ++tt) {
+          const int hd = CFZ_LD(&head[tt]), tl = CFZ_LD(&tail[tt]);
+          if (tl == 0) break;  // no scenario has reached iteration tt yet, hence none is further either
+          if (hd >= tl) continue;
+          idx = __builtin_amdgcn_readfirstlane(atomicAdd(&head[tt], lane == 0 ? 1 : 0));
+          if (idx < B) { t = tt; break; }
+        }
+        if (t < 0) {  // nothing to hand out right now
+          __builtin_amdgcn_s_sleep(32);
+          if (++idle > (1 << 22) || CFZ_LD(&ctrl[2])) { if (lane == 0) atomicExch(&ctrl[2], 1); break; }
+          continue;
+        }
+        idle = 0;
+        for (int spins = 0; (b = CFZ_LD(&slots[(size_t)t * B + idx])) < 0; ++spins) {
+          __builtin_amdgcn_s_sleep(8);
+          if (spins > (1 << 23) || CFZ_LD(&ctrl[2])) break;
+        }
+        if (b < 0) { if (lane == 0) atomicExch(&ctrl[2], 1); t = -1; }
+        break;
+      }
+      CFZ_MARK(1);
+      // acquire: predictions / states written by other workgroups.  One agent-scope acquire by the polling wavefront
+      // (invalidates this CU's L1), completed before the barrier that releases the other wavefront's loads.
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) { cmd[0] = t; cmd[1] = b; }
     }
-    if (t < 0) {  // nothing to hand out right now
-      __builtin_amdgcn_s_sleep(32);
-      if (++idle > (1 << 22) || CFZ_LD(&ctrl[2])) { if (lane == 0) atomicExch(&ctrl[2], 1); break; }
-      continue;
-    }
-    idle = 0;
-    int b = -1;
-    for (int spins = 0; (b = CFZ_LD(&slots[(size_t)t * B + idx])) < 0; ++spins) {
-      __builtin_amdgcn_s_sleep(8);
-      if (spins > (1 << 23) || CFZ_LD(&ctrl[2])) break;
-    }
-    if (b < 0) { if (lane == 0) atomicExch(&ctrl[2], 1); break; }
-    CFZ_MARK(1);
-    __threadfence();  // acquire: predictions / states written by other workgroups
+    __syncthreads();
+    const int t = cmd[0], b = cmd[1];
+    if (t < 0) break;
     CFZ_MARK(2);
     const int s = b / V, v = b - s * V;
     const double *pin = pred + (size_t)(t & 1) * B * 7 * N;   // predictions after iteration t-1
     double *pout = pred + (size_t)((t + 1) & 1) * B * 7 * N;
     // ---- parameters and shifted warm start (vehicle_follower.py:432-476) -------------------------------
-    if (lane < 5) x0[lane] = state[b * 5 + lane];
-    for (int k = lane; k < N; k += 64) {
+    if (tid < 5) x0[tid] = state[b * 5 + tid];
+    for (int k = tid; k < N; k += cfz::kNL) {
       const int ka = (k + 1 < N) ? k + 1 : N - 1;
       int kr = kidx0[s] + t_base + t + k; if (kr > T - 1) kr = T - 1;
       for (int c = 0; c < 3; ++c) ref[c * N + k] = ref_table[((size_t)v * T + kr) * 7 + c];
@@ -234,13 +250,13 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
     __syncthreads();
     CFZ_MARK(4);
     // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
-    for (int i = lane; i < 7 * N; i += 64) {
+    for (int i = tid; i < 7 * N; i += cfz::kNL) {
       const int c = i / N, k = i - c * N;
       const int ka = (k + 1 < N) ? k + 1 : N - 1;
       pout[(size_t)b * 7 * N + i] = (oi[1] == 0) ? zu[i] : pin[((size_t)b * 7 + c) * N + ka];
     }
     CFZ_MARK(5);
-    if (lane == 0) {
+    if (tid == 0) {
       const double a0 = (oi[1] == 0) ? zu[5 * N] : pin[((size_t)b * 7 + 5) * N + 1];
       const double w0 = (oi[1] == 0) ? zu[6 * N] : pin[((size_t)b * 7 + 6) * N + 1];
       double z[5], out[5];
@@ -251,11 +267,14 @@ __global__ __launch_bounds__(64) void loop_kernel(const cfz::KSpec sp, const cfz
       stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
       atomicAdd(iter_sum, oi[0]);
     }
+    // release: prediction and state of (s, v, t).  Every storing wavefront drains its stores, the workgroup meets, one
+    // lane writes the XCD's L2 back and only then signals (the asm wait keeps the compiler from dropping the drain).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CFZ_MARK(6);
-    __threadfence();  // release: prediction and state of (s, v, t)
-    CFZ_MARK(7);
-    if (lane == 0) {
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int c = atomicAdd(&done[s], 1);
       if ((c % V) == V - 1 && t + 1 < K) {  // last vehicle of the scenario: publish iteration t+1
         const int pos = atomicAdd(&tail[t + 1], V);
@@ -468,7 +487,7 @@ int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, cons
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
   if ((h->carry_set || h->slots_set) && st != h->stream) HIP_OK(hipStreamWaitEvent(st, h->ev_stage, 0));  // staged on the handle's stream
   HIP_OK(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(64), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
+  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(cfz::kNL), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
                      iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      h->carry_ext ? h->carry_ext : (h->carry_set ? h->carry : nullptr), carry_all, h->slots_set ? h->slots : nullptr);
   h->carry_set = false; h->slots_set = false; h->carry_ext = nullptr;  // the flags of cfz_mpc_set_carry / cfz_mpc_set_slots hold for one solve
@@ -521,7 +540,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   if (spec->N < 2 || spec->N > CFZ_MAX_N) return fail("N out of range");
   if (spec->n_obs < 0 || spec->n_obs > CFZ_MAX_OBS || spec->n_nbr < 0 || spec->n_nbr > CFZ_MAX_NBR)
     return fail("n_obs / n_nbr out of range");
-  if (spec->N > 64) return fail("N > 64 lanes is not supported by the one-wavefront kernel");
+  if (spec->N > cfz::kMaxN) return fail("N exceeds the four-lanes-per-stage kernel");
   if (max_batch < 1) return fail("max_batch must be positive");
   if (opt->filter_cap < 1 || opt->filter_cap > 32) return fail("filter_cap must be in 1..32");
   int ndev = 0;
@@ -570,7 +589,7 @@ int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
     e = hipFuncSetAttribute((const void *)loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
     if (e != hipSuccess) return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
   }
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, 64, h->lds_bytes);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&h->blocks_per_cu, (const void *)solve_kernel, cfz::kNL, h->lds_bytes);
   {
     // The runtime's answer ignores that gfx950 hands out LDS in 2 KiB granules (measured with tools/src/occupancy_test.hip:
     // 54,208 B per workgroup -> the query says 3 per CU, 2 run); report what the hardware does.
@@ -1138,7 +1157,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   int ncu = 0;
   HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
   int per_cu = 0;
-  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)loop_kernel, 64, h->lds_bytes));
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)loop_kernel, cfz::kNL, h->lds_bytes));
   per_cu = std::min(per_cu, h->blocks_per_cu);  // the 2 KiB LDS granules (cfz_create): what the hardware really keeps resident
   if (per_cu < 1) return fail("loop kernel does not fit on a CU");
   // one workgroup per resident slot: more would only queue behind them (any workgroup can serve any item, so a surplus
@@ -1175,7 +1194,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
     HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
   }
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(64), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
+  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
                      h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
                      h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride);
   HIP_OK(hipGetLastError());

@@ -1,24 +1,29 @@
-// cfz_solver.inl -- one MPC-step NLP solved by one wavefront.
+// cfz_solver.inl -- one MPC-step NLP solved by one 128-lane workgroup (two wavefronts).
 //
-// Included by cfz_engine.hip (gfx950 device code: one 64-lane workgroup per problem instance,
-// iterate and stage data in LDS) and by tests/emu/cfz_emu.cpp (same source, lanes run as a
-// loop, so the kernel logic can be checked and sanitised on a CPU).  Not a CPU fallback: the
+// Included by cfz_engine.hip (gfx950 device code: iterate and stage data in LDS) and by tests/emu/cfz_emu.cpp (same
+// source, lanes run as a loop, so the kernel logic can be checked and sanitised on a CPU).  Not a CPU fallback: the
 // product library only ever contains the device build.
 //
-// NLP: reference confrez/control/vehicle_follower.py:146-368 with the OBCA duals eliminated
-// into closed-form separation certificates; dynamics confrez/control/dynamic_model.py:5-58;
-// algorithm DESIGN.md "CFZ-IPM" (interior point, filter line search, slack elimination +
-// Riccati recursion).  Work split inside the wavefront:
-//   blocks    (stage k, obstacle/neighbour j) tasks strided over the 64 lanes
-//   dynamics  RK4 + forward sensitivities, one stage per lane
-//   assembly  condensed stage Hessian / gradient, one stage per lane
-//   Riccati   backward / forward / costate sweeps on lane 0 (30 dependent steps)
-//   step      slack and multiplier steps, fraction-to-boundary minima, one stage per lane
+// NLP: reference confrez/control/vehicle_follower.py:146-368 with the OBCA duals eliminated into closed-form separation
+// certificates; dynamics confrez/control/dynamic_model.py:5-58; algorithm DESIGN.md "CFZ-IPM" (interior point, filter
+// line search, slack elimination + Riccati recursion).
 //
-// Conventions: code inside CFZ_LANES(lane){...}CFZ_END runs once per lane and may only write
-// lane-private locals or workspace cells it owns; everything outside runs uniformly (every
-// lane computes the same value from the workspace).  Cross-lane sums/maxima go through the
-// `red` slots of the workspace.
+// Lane map: lane = 4 k + sub.  The four lanes of a DPP quad own stage k (N <= 32 stages):
+//   rows      lane (k, sub) owns the separation blocks j = sub, sub + 4, .. of its stage (working set, row values, slack
+//             and multiplier steps, their share of the condensed stage Hessian); the shares meet in a quad sum (two DPP
+//             quad_perm exchanges, no LDS, no barrier)
+//   dynamics  all four lanes integrate the stage (RK4, identical instruction stream, so the redundancy costs no time) and
+//             each propagates its own columns of the sensitivities: lane sub column sub, every lane column 4
+//   stage     condensed H_k, g_k, bound multipliers, costs: computed by the whole quad, written by sub 0
+//   Riccati   backward / forward / costate sweeps: 30 dependent steps on lane 0, out of line (registers of their own)
+// Reductions over the workgroup run on registers: DPP butterflies inside a row of 16 lanes, v_readlane across the four
+// rows of a wavefront, one 16-double LDS exchange between the two wavefronts.
+//
+// Conventions: code inside CFZ_LANES(tid){...}CFZ_END runs once per lane and may only write lane-private locals or
+// workspace cells it owns; everything outside runs uniformly (every lane computes the same value).  A lane-private value
+// that another lane of the quad (CFZ_QSUM) or a reduction (CFZ_REDUCE) reads goes through a CFZ_PART array: registers on
+// the device, [lane] arrays in the CPU build; CFZ_MID separates the producing from the consuming half of a lane block
+// (nothing on the device; the CPU build closes the lane loop and opens it again, so that all lanes have produced).
 
 #ifndef CFZ_SOLVER_INL
 #define CFZ_SOLVER_INL
@@ -28,17 +33,39 @@
 
 #if defined(__HIPCC__)
 #define CFZ_FN __host__ __device__ __forceinline__
-#define CFZ_CALL __host__ __device__ __forceinline__  // measured: out-of-line helpers cost 30 % (arguments spill to scratch)
+#define CFZ_CALL __host__ __device__ __forceinline__  // measured: out-of-line helpers with array arguments cost 30 % (the arrays go to scratch)
 #else
 #define CFZ_FN static inline
 #define CFZ_CALL static inline
 #endif
+
+namespace cfz {
+constexpr int kNL = 128;  // lanes per instance
+constexpr int kLPS = 4;   // lanes per stage
+constexpr int kMaxN = kNL / kLPS;
+}  // namespace cfz
+
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CFZ_LANES(lane) { const int lane = (int)threadIdx.x;
+#define CFZ_LANES(tid) { const int tid = (int)threadIdx.x;
+#define CFZ_MID } { const int tid = (int)threadIdx.x;
 #define CFZ_END } __syncthreads();
+#define CFZ_PART(name, n) double name[n]
+#define CFZ_P(name, i) name[i]
+#define CFZ_QSUM(name, i) cfz::quad_sum(name[i])
+#define CFZ_REDUCE(NS, NX, NI, part, out) cfz::reduce_all<NS, NX, NI>(m, L, xpar, part, out)
+// the sweeps run on lane 0 of the workgroup, out of line; every lane calls (uniform control flow), lane 0 works
+#define CFZ_SERIAL(call) do { call; __syncthreads(); } while (0)
+#define CFZ_WSP(p) ((cfz::wsp_f64 *)(p))
 #else
-#define CFZ_LANES(lane) for (int lane = 0; lane < 64; ++lane) {
+#define CFZ_LANES(tid) for (int tid = 0; tid < cfz::kNL; ++tid) {
+#define CFZ_MID } for (int tid = 0; tid < cfz::kNL; ++tid) {
 #define CFZ_END }
+#define CFZ_PART(name, n) double name[n][cfz::kNL]
+#define CFZ_P(name, i) name[i][tid]
+#define CFZ_QSUM(name, i) cfz::quad_sum_emu(name[i], tid)
+#define CFZ_REDUCE(NS, NX, NI, part, out) cfz::reduce_all_emu<NS, NX, NI>(part, out)
+#define CFZ_SERIAL(call) do { call; } while (0)
+#define CFZ_WSP(p) (p)
 #endif
 
 // Diagnostic build only (-DCFZ_STAMPS): shader-clock cycles per phase of the solver, summed over the
@@ -54,7 +81,6 @@
 namespace cfz {
 
 constexpr int kNP = 7;      // x y psi v delta a w
-constexpr int kRed = 6;     // reduction slots (0-3 own storage, 4-5 see make_layout)
 constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
 
 // Everything the kernel needs besides per-instance data (plain old data, passed by value).
@@ -79,11 +105,10 @@ struct Lay {
   int p, sg, nuc, zs, zl, zu, pi0, pi;      // iterate
   int dp, dsg, dpi0, dpi;                   // step
   int cj, ab, d, hc, gk, kk;                // stage data
-  int sel, ref, nb4, x0, cs, rP, filt, red, red2, total;
+  int sel, ref, nb4, x0, cs, rP, filt, xw, total;
 };
 
 CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
-  (void)n_nbr;
   Lay L; int o = 0;
   const int nr = 2 * nb;
   L.N = N; L.nb = nb; L.nr = nr;
@@ -99,17 +124,11 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.sel = o; o += (N * nb + 7) / 8;  // working set codes (< 192), one byte each
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
   L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
-  L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the point being evaluated
+  L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the current iterate
   L.rP = L.cs;  // value function of stage 0 (30 numbers) between the Riccati sweeps, when cos/sin are not needed
   L.filt = o; o += 32;
-  // reduction slots 0-3: no reduction runs between the assembly of H_k and the costate sweep, the only phases that
-  // read hc, so the slots live there (the budget: four instances per CU need 20 LDS granules of 2 KiB = 5120 doubles)
-  if (N * 11 >= 256) L.red = L.hc; else { L.red = o; o += 256; }
-  // reduction slots 4 and 5 are only used by the residual pass at the top of an iteration, when the step of the
-  // previous iteration is dead: they live in its storage (160 KiB of LDS hold three instances only if one
-  // instance stays within 26 allocation granules of 2 KiB = 6656 doubles)
-  if (N * kNP >= 128) L.red2 = L.dp; else { L.red2 = o; o += 128; }
-  L.total = o;
+  L.xw = o; o += 24;  // exchange between the two wavefronts of a reduction: [parity 2][wavefront 2][6 values]
+  L.total = o;  // N = 30, 9 blocks: 5,115 doubles = 40,920 B = 20 LDS granules of 2 KiB: four instances per CU (cfz_create)
   return L;
 }
 
@@ -120,25 +139,76 @@ CFZ_FN const unsigned char *sel_ptr(const double *m, const Lay &L) { return rein
 CFZ_FN int bcol(int q) { return q < 2 ? q : q + 1; }
 
 // ------------------------------------------------------------------------------ reductions
-CFZ_FN int red_at(const Lay &L, int slot) { return slot < 4 ? L.red + slot * 64 : L.red2 + (slot - 4) * 64; }
-CFZ_FN double red_sum(const double *m, const Lay &L, int slot) {
-  const double *r = m + red_at(L, slot);
-  double s = 0.0;
-  for (int i = 0; i < 64; ++i) s += r[i];
-  return s;
+// One tree for both builds, so that the CPU build of this source sums in the order the wavefronts do:
+//   inside a row of 16 lanes: partner lane^1, lane^2 (quad_perm), mirror inside 8 (row_half_mirror), mirror inside 16
+//   (row_mirror); then (row0 . row1) . (row2 . row3) of a wavefront; then wavefront 0 . wavefront 1.
+// OP 0 sum, 1 max, 2 min.  Every lane ends with the same bits (each level combines a pair commutatively).
+template <int OP> CFZ_FN double op2(double a, double b) { return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b)); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double wsp_f64;  // the workspace as the out-of-line sweeps see it: DS instructions, no FLAT
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
-CFZ_FN double red_max(const double *m, const Lay &L, int slot) {
-  const double *r = m + red_at(L, slot);
-  double s = r[0];
-  for (int i = 1; i < 64; ++i) s = fmax(s, r[i]);
-  return s;
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
 }
-CFZ_FN double red_min(const double *m, const Lay &L, int slot) {
-  const double *r = m + red_at(L, slot);
-  double s = r[0];
-  for (int i = 1; i < 64; ++i) s = fmin(s, r[i]);
-  return s;
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+template <int OP> __device__ __forceinline__ double wave_reduce(double v) {
+  v = op2<OP>(v, dpp_mov<0xB1>(v));
+  v = op2<OP>(v, dpp_mov<0x4E>(v));
+  v = op2<OP>(v, dpp_mov<0x141>(v));  // row_half_mirror
+  v = op2<OP>(v, dpp_mov<0x140>(v));  // row_mirror
+  return op2<OP>(op2<OP>(lane_value(v, 0), lane_value(v, 16)), op2<OP>(lane_value(v, 32), lane_value(v, 48)));
+}
+// part[0..NS) are summed, part[NS..NS+NX) maximised, the next NI minimised, over all lanes of the workgroup.  One
+// barrier; the exchange buffer alternates (xpar) so that a wavefront may already write the next reduction while the
+// other still reads this one.
+template <int NS, int NX, int NI>
+__device__ __forceinline__ void reduce_all(double *m, const Lay &L, int &xpar, const double *part, double *out) {
+  constexpr int n = NS + NX + NI;
+  static_assert(n <= 6, "exchange slots");
+  double w[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) w[i] = i < NS ? wave_reduce<0>(part[i]) : (i < NS + NX ? wave_reduce<1>(part[i]) : wave_reduce<2>(part[i]));
+  double *x = m + L.xw + xpar * 12;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[(threadIdx.x >> 6) * 6 + i] = w[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < n; ++i) out[i] = i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i]));
+  xpar ^= 1;
+}
+#else
+typedef double wsp_f64;
+static inline double quad_sum_emu(const double *v, int tid) {
+  const int q = tid & ~3;
+  return (tid & 2) ? (v[q + 2] + v[q + 3]) + (v[q] + v[q + 1]) : (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+}
+template <int OP> static inline double wave_reduce_emu(const double *v) {
+  double a[64], b[64];
+  for (int i = 0; i < 64; ++i) b[i] = op2<OP>(v[i], v[i ^ 1]);
+  for (int i = 0; i < 64; ++i) a[i] = op2<OP>(b[i], b[i ^ 2]);
+  for (int i = 0; i < 64; ++i) b[i] = op2<OP>(a[i], a[(i & ~7) | (7 - (i & 7))]);
+  for (int i = 0; i < 64; ++i) a[i] = op2<OP>(b[i], b[(i & ~15) | (15 - (i & 15))]);
+  return op2<OP>(op2<OP>(a[0], a[16]), op2<OP>(a[32], a[48]));
+}
+template <int NS, int NX, int NI> static inline void reduce_all_emu(const double (*part)[kNL], double *out) {
+  for (int i = 0; i < NS + NX + NI; ++i) {
+    if (i < NS) out[i] = op2<0>(wave_reduce_emu<0>(part[i]), wave_reduce_emu<0>(part[i] + 64));
+    else if (i < NS + NX) out[i] = op2<1>(wave_reduce_emu<1>(part[i]), wave_reduce_emu<1>(part[i] + 64));
+    else out[i] = op2<2>(wave_reduce_emu<2>(part[i]), wave_reduce_emu<2>(part[i] + 64));
+  }
+}
+#endif
 
 // ------------------------------------------------------------------------------ dynamics
 // RK4 (M sub-steps) of the kinematic bicycle.  The state rows v, delta integrate exactly
@@ -445,46 +515,269 @@ CFZ_FN void sym2_solve6(const double M[2][2], const double rhs[2][6], double out
   }
 }
 
-// ------------------------------------------------------------------------------ trial-point evaluation
-// theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lanes write partials
-// into red slots 0 (theta), 1 (phi without the log terms), 2 (sum of logs), 3 (1 if infeasible).
-CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, const Lay &L, double alpha, int lane) {
-  const int N = sp.N, nb = L.nb;
-  // sum of logs taken as the log of a per-lane product (<= 22 factors in [1e-10, 1e2]: no over/underflow)
-  double th = 0.0, ph = 0.0, lprod = 1.0, bad = 0.0;
-  for (int t = lane; t < N * nb; t += 64) {
-    const int k = t / nb, j = t - k * nb;
-    const double x = m[L.p + k * kNP + 0] + alpha * m[L.dp + k * kNP + 0];
-    const double y = m[L.p + k * kNP + 1] + alpha * m[L.dp + k * kNP + 1];
-    double A[4][2], b[4], V[4][2], sep[2];
-    block_polygon(sp, m, L, k, j, A, b, V);
-    rows_for<false>(A, b, V, x, y, m[L.cs + 2 * k], m[L.cs + 2 * k + 1], sp.g, sel_ptr(m, L)[t], sep, nullptr);
+// RK4 with the sensitivities of (x, y, psi) for TWO columns of (psi0, v0, delta0, a, w): column qa (0..3, chosen by the
+// lane) and column 4.  The four lanes of a stage's quad run this in lockstep with qa = 0, 1, 2, 3 and so cover all five
+// columns; the nominal trajectory is the same in all of them.  Same recurrences as rk4_step<true>, column by column.
+CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double wb, int M, int qa, double out[5],
+                        double Sa[3], double Sb[3]) {
+  const double h = dt / M;
+  double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
+  Sa[0] = 0.0; Sa[1] = 0.0; Sa[2] = (qa == 0) ? 1.0 : 0.0;
+  Sb[0] = 0.0; Sb[1] = 0.0; Sb[2] = 0.0;
+  // d(v at a stage point)/d(column), d(delta at a stage point)/d(column): 1 for the state's own column, the elapsed
+  // time for its input's column
+  const double va1 = (qa == 1) ? 1.0 : 0.0, vat = (qa == 3) ? 1.0 : 0.0;  // dvs = va1 + vat * tau
+  const double da1 = (qa == 2) ? 1.0 : 0.0;                                 // dds = da1        (column 4: dds = tau)
+  double sp_, cp_, sd0, cd0, sh, ch;
+  sincos(psi, &sp_, &cp_);
+  sincos(de, &sd0, &cd0);
+  small_sincos(0.5 * h * w, &sh, &ch);
+  double tsub = 0.0;
+  for (int m_ = 0; m_ < M; ++m_) {
+    double ax = 0, ay = 0, ap = 0, kp = 0;
+    double ASa[3] = {0.0, 0.0, 0.0}, ASb[3] = {0.0, 0.0, 0.0}, KSa2 = 0.0, KSb2 = 0.0;
+    const double sd1 = sd0 * ch + cd0 * sh, cd1 = cd0 * ch - sd0 * sh;
+    const double sd2 = sd1 * ch + cd1 * sh, cd2 = cd1 * ch - sd1 * sh;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
-      th += fabs(sep[r] - sp.dmin - sg);
-      if (!(sg > 0.0)) bad = 1.0; else lprod *= sg;
+    for (int st = 0; st < 4; ++st) {
+      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+      const double wsum = (st == 0 || st == 3) ? 1.0 : 2.0;
+      const double vs = v + wprev * a;
+      double s = sp_, c = cp_;
+      if (st > 0) {
+        double se, ce;
+        small_sincos(wprev * kp, &se, &ce);
+        s = sp_ * ce + cp_ * se; c = cp_ * ce - sp_ * se;
+      }
+      const double sd = (st == 0) ? sd0 : ((st == 3) ? sd2 : sd1), cd = (st == 0) ? cd0 : ((st == 3) ? cd2 : cd1);
+      const double t = sd / cd;
+      const double fx = vs * c, fy = vs * s, fp = vs / wb * t;
+      const double tau = tsub + wprev;
+      const double j24 = vs / wb * (1.0 + t * t), j23 = t / wb;
+      {  // column qa
+        const double dps = Sa[2] + wprev * KSa2, dvs = va1 + vat * tau, dds = da1;
+        const double n0 = -vs * s * dps + c * dvs, n1 = vs * c * dps + s * dvs, n2 = j23 * dvs + j24 * dds;
+        KSa2 = n2; ASa[0] += wsum * n0; ASa[1] += wsum * n1; ASa[2] += wsum * n2;
+      }
+      {  // column 4 (w): dvs = 0, dds = tau
+        const double dps = Sb[2] + wprev * KSb2;
+        const double n0 = -vs * s * dps, n1 = vs * c * dps, n2 = j24 * tau;
+        KSb2 = n2; ASb[0] += wsum * n0; ASb[1] += wsum * n1; ASb[2] += wsum * n2;
+      }
+      kp = fp;
+      ax += wsum * fx; ay += wsum * fy; ap += wsum * fp;
     }
+    x += h / 6 * ax; y += h / 6 * ay; psi += h / 6 * ap;
+    v += h * a; de += h * w;
+    {
+      double se, ce;
+      small_sincos(h / 6 * ap, &se, &ce);
+      const double sn = sp_ * ce + cp_ * se, cn = cp_ * ce - sp_ * se;
+      sp_ = sn; cp_ = cn; sd0 = sd2; cd0 = cd2;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Sa[r] += h / 6 * ASa[r]; Sb[r] += h / 6 * ASb[r]; }
+    tsub += h;
   }
-  if (lane < N) {
-    const int k = lane;
+  out[0] = x; out[1] = y; out[2] = psi; out[3] = v; out[4] = de;
+}
+
+// ------------------------------------------------------------------------------ trial-point evaluation
+// theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lane partials: part 0 theta, 1 phi without the
+// log terms, 2 sum of logs, 3 = 1 if a bound or a slack is not strictly inside.
+CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, const Lay &L, double alpha, int tid,
+                             double &th_o, double &ph_o, double &ll_o, double &bad_o) {
+  const int N = sp.N, nb = L.nb;
+  const int k = tid >> 2, sub = tid & 3;
+  // sum of logs taken as the log of a per-lane product (<= 18 factors in [1e-10, 1e2]: no over/underflow)
+  double th = 0.0, ph = 0.0, lprod = 1.0, bad = 0.0;
+  if (k < N) {
     double pt[kNP];
     for (int i = 0; i < kNP; ++i) pt[i] = m[L.p + k * kNP + i] + alpha * m[L.dp + k * kNP + i];
-    for (int q = 0; q < 6; ++q) {
-      const double dl = pt[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pt[bcol(q)];
-      if (!(dl > 0.0) || !(du > 0.0)) bad = 1.0; else lprod *= dl * du;
+    double sn, cn;
+    sincos(pt[2], &sn, &cn);
+    for (int j = sub; j < nb; j += kLPS) {
+      const int t = k * nb + j;
+      double A[4][2], b[4], V[4][2], sep[2];
+      block_polygon(sp, m, L, k, j, A, b, V);
+      rows_for<false>(A, b, V, pt[0], pt[1], cn, sn, sp.g, sel_ptr(m, L)[t], sep, nullptr);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
+        th += fabs(sep[r] - sp.dmin - sg);
+        if (!(sg > 0.0)) bad = 1.0; else lprod *= sg;
+      }
     }
-    ph += stage_cost(sp, refg, k, pt);
-    if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
-    if (k + 1 < N) {
-      double F[5];
-      rk4_step<false>(pt, pt[5], pt[6], sp.dt, sp.wb, sp.rk_substeps, F, nullptr);
-      for (int i = 0; i < 5; ++i)
-        th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
+    if (sub == 0) {
+      for (int q = 0; q < 6; ++q) {
+        const double dl = pt[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pt[bcol(q)];
+        if (!(dl > 0.0) || !(du > 0.0)) bad = 1.0; else lprod *= dl * du;
+      }
+      ph += stage_cost(sp, refg, k, pt);
+      if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
+      if (k + 1 < N) {
+        double F[5];
+        rk4_step<false>(pt, pt[5], pt[6], sp.dt, sp.wb, sp.rk_substeps, F, nullptr);
+        for (int i = 0; i < 5; ++i)
+          th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
+      }
     }
   }
-  m[L.red + 0 * 64 + lane] = th; m[L.red + 1 * 64 + lane] = ph;
-  m[L.red + 2 * 64 + lane] = (bad == 0.0) ? log(lprod) : 0.0; m[L.red + 3 * 64 + lane] = bad;
+  th_o = th; ph_o = ph; ll_o = (bad == 0.0) ? log(lprod) : 0.0; bad_o = bad;
+}
+
+// ------------------------------------------------------------------------------ Riccati sweeps (lane 0, out of line)
+// Functions of their own so that their registers are their own (inlined into the solver the backward sweep kept ~100
+// doubles live on top of the solver's state and spilled into AGPRs and scratch).  Device: they must not NAME any LDS
+// (toolchain, see cfz_band.inl); the workspace comes in as an address-space-3 pointer, so every access is a DS
+// instruction.  Every lane calls them (uniform control flow), lane 0 does the work.
+// Structure used: A_k = I + [0 0 s00 s01 s02; 0 0 s10 s11 s12; 0 0 0 s21 s22; 0; 0] (s20 = 1),
+// B_k = [s03 s04; s13 s14; s23 s24; dt 0; 0 dt]; H_k = diag(h0..h6) + pose off-diagonals h7 (0,1), h8 (0,2), h9 (1,2) +
+// the v-w cross term h10 (3,6).  A lane-parallel variant (matrix entries spread over lanes, exchange through LDS) measured
+// 2.2x slower: every exchange is a dependent LDS round trip.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZ_SWEEP __device__ __attribute__((noinline)) void
+#define CFZ_SWEEP_GUARD if (threadIdx.x != 0) return;
+#else
+#define CFZ_SWEEP static void
+#define CFZ_SWEEP_GUARD
+#endif
+
+// backward sweep: gains K_k (12 per stage) into kk, value function of stage 0 into rP (25) and rP + 25 (5)
+CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
+  CFZ_SWEEP_GUARD
+  double P[5][5], pv[5];
+  {
+    const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
+    const wsp_f64 *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
+    wsp_f64 *K = m + o_kk + k * 12;
+    for (int q = 0; q < 10; ++q) K[q] = 0.0;
+    const double k53 = -h[10] / h[6], k10 = -gk[5] / h[5], k11 = -gk[6] / h[6];
+    K[5 + 3] = k53; K[10] = k10; K[11] = k11;
+    for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) P[i][q] = 0.0; P[i][i] = h[i]; pv[i] = gk[i]; }
+    P[0][1] = P[1][0] = h[7]; P[0][2] = P[2][0] = h[8]; P[1][2] = P[2][1] = h[9];
+    P[3][3] += h[10] * k53; pv[3] += h[10] * k11;
+  }
+  for (int k = N - 2; k >= 0; --k) {
+    const wsp_f64 *s = m + o_ab + k * 15, *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP, *dk = m + o_d + k * 5;
+    const double s00 = s[0], s01 = s[1], s02 = s[2], s03 = s[3], s04 = s[4];
+    const double s10 = s[5], s11 = s[6], s12 = s[7], s13 = s[8], s14 = s[9];
+    const double s21 = s[11], s22 = s[12], s23 = s[13], s24 = s[14];
+    const double d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3], d4 = dk[4];
+    double M[5][5], PB[5][2], Pd[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      M[i][0] = P[i][0]; M[i][1] = P[i][1];
+      M[i][2] = P[i][2] + s00 * P[i][0] + s10 * P[i][1];
+      M[i][3] = P[i][3] + s01 * P[i][0] + s11 * P[i][1] + s21 * P[i][2];
+      M[i][4] = P[i][4] + s02 * P[i][0] + s12 * P[i][1] + s22 * P[i][2];
+      PB[i][0] = s03 * P[i][0] + s13 * P[i][1] + s23 * P[i][2] + dt * P[i][3];
+      PB[i][1] = s04 * P[i][0] + s14 * P[i][1] + s24 * P[i][2] + dt * P[i][4];
+      Pd[i] = pv[i] + P[i][0] * d0 + P[i][1] * d1 + P[i][2] * d2 + P[i][3] * d3 + P[i][4] * d4;
+    }
+    double Hxx[5][5], hx[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      Hxx[0][j] = M[0][j]; Hxx[1][j] = M[1][j];
+      Hxx[2][j] = M[2][j] + s00 * M[0][j] + s10 * M[1][j];
+      Hxx[3][j] = M[3][j] + s01 * M[0][j] + s11 * M[1][j] + s21 * M[2][j];
+      Hxx[4][j] = M[4][j] + s02 * M[0][j] + s12 * M[1][j] + s22 * M[2][j];
+    }
+    const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7], h8 = h[8], h9 = h[9], h10 = h[10];
+    Hxx[0][0] += h0; Hxx[1][1] += h1; Hxx[2][2] += h2; Hxx[3][3] += h3; Hxx[4][4] += h4;
+    Hxx[0][1] += h7; Hxx[1][0] += h7; Hxx[0][2] += h8; Hxx[2][0] += h8; Hxx[1][2] += h9; Hxx[2][1] += h9;
+    hx[0] = gk[0] + Pd[0]; hx[1] = gk[1] + Pd[1];
+    hx[2] = gk[2] + Pd[2] + s00 * Pd[0] + s10 * Pd[1];
+    hx[3] = gk[3] + Pd[3] + s01 * Pd[0] + s11 * Pd[1] + s21 * Pd[2];
+    hx[4] = gk[4] + Pd[4] + s02 * Pd[0] + s12 * Pd[1] + s22 * Pd[2];
+    double Hux[2][5], hu[2];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      Hux[0][j] = s03 * M[0][j] + s13 * M[1][j] + s23 * M[2][j] + dt * M[3][j];
+      Hux[1][j] = s04 * M[0][j] + s14 * M[1][j] + s24 * M[2][j] + dt * M[4][j];
+    }
+    Hux[1][3] += h10;
+    const double a00 = h5 + s03 * PB[0][0] + s13 * PB[1][0] + s23 * PB[2][0] + dt * PB[3][0];
+    const double a01 = s03 * PB[0][1] + s13 * PB[1][1] + s23 * PB[2][1] + dt * PB[3][1];
+    const double a11 = h6 + s04 * PB[0][1] + s14 * PB[1][1] + s24 * PB[2][1] + dt * PB[4][1];
+    hu[0] = gk[5] + s03 * Pd[0] + s13 * Pd[1] + s23 * Pd[2] + dt * Pd[3];
+    hu[1] = gk[6] + s04 * Pd[0] + s14 * Pd[1] + s24 * Pd[2] + dt * Pd[4];
+    const double idet = 1.0 / (a00 * a11 - a01 * a01);
+    const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
+    double t0[6], t1[6];  // Huu^{-1} [Hux hu]
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { t0[q] = i00 * Hux[0][q] + i01 * Hux[1][q]; t1[q] = i01 * Hux[0][q] + i11 * Hux[1][q]; }
+    t0[5] = i00 * hu[0] + i01 * hu[1]; t1[5] = i01 * hu[0] + i11 * hu[1];
+    wsp_f64 *K = m + o_kk + k * 12;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { K[q] = -t0[q]; K[5 + q] = -t1[q]; }
+    K[10] = -t0[5]; K[11] = -t1[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+      for (int q = i; q < 5; ++q) {
+        const double v = 0.5 * (Hxx[i][q] + Hxx[q][i]) - (Hux[0][i] * t0[q] + Hux[1][i] * t1[q]);
+        P[i][q] = v; P[q][i] = v;
+      }
+      pv[i] = hx[i] - (Hux[0][i] * t0[5] + Hux[1][i] * t1[5]);
+    }
+  }
+  wsp_f64 *rP = m + o_rP;
+  for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = P[i][q]; rP[25 + i] = pv[i]; }
+}
+
+// forward sweep: dp (all stages) and the step of the initial-state multiplier from the value function at stage 0
+CFZ_SWEEP riccati_forward(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
+                          int o_pi0, int o_dpi0) {
+  CFZ_SWEEP_GUARD
+  const wsp_f64 *rP = m + o_rP, *pv = rP + 25;
+  wsp_f64 *dp = m + o_dp;
+  double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
+         z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
+  dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
+  for (int i = 0; i < 5; ++i) {
+    const double s_ = pv[i] + rP[i * 5 + 0] * z0 + rP[i * 5 + 1] * z1 + rP[i * 5 + 2] * z2 + rP[i * 5 + 3] * z3 + rP[i * 5 + 4] * z4;
+    m[o_dpi0 + i] = -s_ - m[o_pi0 + i];
+  }
+#pragma unroll 5
+  for (int k = 0; k < N; ++k) {  // unrolled so that the gain/dynamics loads of later stages are in flight early
+    const wsp_f64 *K = m + o_kk + k * 12;
+    const double u0 = K[10] + K[0] * z0 + K[1] * z1 + K[2] * z2 + K[3] * z3 + K[4] * z4;
+    const double u1 = K[11] + K[5] * z0 + K[6] * z1 + K[7] * z2 + K[8] * z3 + K[9] * z4;
+    dp[k * kNP + 5] = u0; dp[k * kNP + 6] = u1;
+    if (k + 1 < N) {
+      const wsp_f64 *s = m + o_ab + k * 15, *dk = m + o_d + k * 5;
+      const double n0 = dk[0] + z0 + s[0] * z2 + s[1] * z3 + s[2] * z4 + s[3] * u0 + s[4] * u1;
+      const double n1 = dk[1] + z1 + s[5] * z2 + s[6] * z3 + s[7] * z4 + s[8] * u0 + s[9] * u1;
+      const double n2 = dk[2] + z2 + s[11] * z3 + s[12] * z4 + s[13] * u0 + s[14] * u1;
+      const double n3 = dk[3] + z3 + dt * u0, n4 = dk[4] + z4 + dt * u1;
+      z0 = n0; z1 = n1; z2 = n2; z3 = n3; z4 = n4;
+      wsp_f64 *zn = dp + (k + 1) * kNP;
+      zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
+    }
+  }
+}
+
+// costate sweep: dpi holds the stage-local part (H dp + g)_z of stage k in slot k - 1; the recursion through A_k' turns
+// it into d(pi_{k-1}) = pi_new - pi
+CFZ_SWEEP costate_sweep(wsp_f64 *m, int N, int o_ab, int o_dpi, int o_pi) {
+  CFZ_SWEEP_GUARD
+  double l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
+#pragma unroll 5
+  for (int k = N - 1; k >= 1; --k) {
+    wsp_f64 *q = m + o_dpi + (k - 1) * 5;
+    const wsp_f64 *pi = m + o_pi + (k - 1) * 5;
+    double n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3], n4 = q[4];
+    if (k + 1 < N) {
+      const wsp_f64 *s = m + o_ab + k * 15;
+      n0 += l0; n1 += l1;
+      n2 += l2 + s[0] * l0 + s[5] * l1;
+      n3 += l3 + s[1] * l0 + s[6] * l1 + s[11] * l2;
+      n4 += l4 + s[2] * l0 + s[7] * l1 + s[12] * l2;
+    }
+    l0 = n0; l1 = n1; l2 = n2; l3 = n3; l4 = n4;
+    q[0] = n0 - pi[0]; q[1] = n1 - pi[1]; q[2] = n2 - pi[2]; q[3] = n3 - pi[3]; q[4] = n4 - pi[4];
+  }
 }
 
 // ------------------------------------------------------------------------------ the solver
@@ -515,103 +808,113 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double stall_ref = 0.0;
   int stall_cnt = 0;
+  int xpar = 0;  // which half of the wavefront exchange buffer the next reduction uses
+  (void)xpar;
+  CFZ_PART(rd, 6);   // lane partials of the workgroup reductions
+  CFZ_PART(qx, 12);  // lane shares that meet in a quad sum
+  double ro[6];      // results of a reduction (uniform)
 
   // ---- load parameters, initial point ---------------------------------------------------
-  CFZ_LANES(lane)
-    for (int t = lane; t < N * n_nbr; t += 64) {
+  CFZ_LANES(tid)
+    for (int t = tid; t < N * n_nbr; t += kNL) {
       const int k = t / n_nbr, o = t - k * n_nbr;
       const double po = nbrg[(o * 3 + 2) * N + k];
       double *q = m + L.nb4 + t * 4;
       q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
     }
-    if (lane < 5) { m[L.x0 + lane] = x0g[lane]; m[L.pi0 + lane] = 0.0; }
-    for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
-    for (int i = lane; i < N * 5; i += 64) m[L.pi + i] = 0.0;
+    if (tid < 5) { m[L.x0 + tid] = x0g[tid]; m[L.pi0 + tid] = 0.0; }
+    for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
+    for (int i = tid; i < N * 5; i += kNL) m[L.pi + i] = 0.0;
   CFZ_END
   // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
   // than 2*constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
-  CFZ_LANES(lane)
+  CFZ_LANES(tid)
     double worst = INFINITY;
-    if (lane < nb) {
+    if (tid < nb) {
       double A[4][2], b[4], V[4][2], sep[2];
-      block_polygon(sp, m, L, 0, lane, A, b, V);
+      block_polygon(sp, m, L, 0, tid, A, b, V);
       double s0, c0_;
       sincos(m[L.x0 + 2], &s0, &c0_);
       const int c0 = select_rows(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0);
       rows_for<false>(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, c0, sep, nullptr);
       worst = fmin(sep[0], sep[1]);
     }
-    m[L.red + lane] = worst;
+    CFZ_P(rd, 0) = worst;
   CFZ_END
-  if (red_min(m, L, 0) < sp.dmin - 2.0 * sp.constr_viol_tol) {
-    out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = red_min(m, L, 0);
-    if (wst) { CFZ_LANES(lane) if (lane == 0) wst[carry_layout(N, nb).valid] = 0.0; CFZ_END }
+  CFZ_REDUCE(0, 0, 1, rd, ro);
+  const CarryLay CL = carry_layout(N, nb);
+  if (ro[0] < sp.dmin - 2.0 * sp.constr_viol_tol) {
+    out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = ro[0];
+    if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
     return;
   }
-  const CarryLay CL = carry_layout(N, nb);
   const bool warm = wst != nullptr && carry_in != 0 && wst[CL.valid] != 0.0;
   const double mu0 = warm ? fmin(fmax(wst[CL.mu], mu_floor), sp.mu_init) : sp.mu_init;
-  CFZ_LANES(lane)
-    // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
-    for (int t = lane; t < N * nb; t += 64) {
-      const int k = t / nb, j = t - k * nb;
-      double A[4][2], b[4], V[4][2], sep[2];
-      block_polygon(sp, m, L, k, j, A, b, V);
+  CFZ_LANES(tid)
+    const int k = tid >> 2, sub = tid & 3;
+    if (k < N) {
+      // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
       const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1];
       double sn, cn;
       sincos(m[L.p + k * kNP + 2], &sn, &cn);
-      const int c0 = select_rows(A, b, V, x, y, cn, sn, sp.g, 0);
-      sel_ptr(m, L)[t] = c0;
-      rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c0, sep, nullptr);
-      if (!warm) {
-        for (int r = 0; r < 2; ++r) {
-          m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
-          m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
-        }
-      } else {
-        // a row whose (face, vertex) identity exists in the carried working set of stage k+1 keeps its multiplier
-        const int ko = k + 1 < N ? k + 1 : N - 1;
-        const int so = reinterpret_cast<const unsigned char *>(wst + CL.sel)[ko * nb + j];
-        for (int r = 0; r < 2; ++r) {
-          const int vn = r == 0 ? ((c0 >> 2) & 3) : (c0 & 3);
-          double z = 0.0;
-          if ((so >> 4) == (c0 >> 4)) {
-            if (((so >> 2) & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2];
-            else if ((so & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2 + 1];
+      for (int j = sub; j < nb; j += kLPS) {
+        const int t = k * nb + j;
+        double A[4][2], b[4], V[4][2], sep[2];
+        block_polygon(sp, m, L, k, j, A, b, V);
+        const int c0 = select_rows(A, b, V, x, y, cn, sn, sp.g, 0);
+        sel_ptr(m, L)[t] = c0;
+        rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c0, sep, nullptr);
+        if (!warm) {
+          for (int r = 0; r < 2; ++r) {
+            m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
+            m[L.zs + 2 * t + r] = 1.0; m[L.nuc + 2 * t + r] = 0.0;
           }
-          const double gap = sep[r] - sp.dmin;
-          double sg;
-          if (z > 0.0) sg = fmax(fmax(gap, mu0 / z), sp.warm_push);
-          else { sg = fmax(gap, sp.bound_push); z = mu0 / sg; }
-          m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = z; m[L.nuc + 2 * t + r] = -z;
+        } else {
+          // a row whose (face, vertex) identity exists in the carried working set of stage k+1 keeps its multiplier
+          const int ko = k + 1 < N ? k + 1 : N - 1;
+          const int so = reinterpret_cast<const unsigned char *>(wst + CL.sel)[ko * nb + j];
+          for (int r = 0; r < 2; ++r) {
+            const int vn = r == 0 ? ((c0 >> 2) & 3) : (c0 & 3);
+            double z = 0.0;
+            if ((so >> 4) == (c0 >> 4)) {
+              if (((so >> 2) & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2];
+              else if ((so & 3) == vn) z = wst[CL.z + (ko * nb + j) * 2 + 1];
+            }
+            const double gap = sep[r] - sp.dmin;
+            double sg;
+            if (z > 0.0) sg = fmax(fmax(gap, mu0 / z), sp.warm_push);
+            else { sg = fmax(gap, sp.bound_push); z = mu0 / sg; }
+            m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = z; m[L.nuc + 2 * t + r] = -z;
+          }
         }
       }
     }
   CFZ_END
-  CFZ_LANES(lane)
-    if (lane < N) {
-      const int ko = lane + 1 < N ? lane + 1 : N - 1;
+  CFZ_LANES(tid)
+    const int k = tid >> 2, sub = tid & 3;
+    if (k < N && sub == 0) {
+      const int ko = k + 1 < N ? k + 1 : N - 1;
       for (int q = 0; q < 6; ++q) {
         const double lo = sp.bounds[2 * q], hi = sp.bounds[2 * q + 1];
-        double v = m[L.p + lane * kNP + bcol(q)];
+        double v = m[L.p + k * kNP + bcol(q)];
         if (!warm) {
           const double pl = fmin(sp.bound_push * fmax(1.0, fabs(lo)), sp.bound_frac * (hi - lo));
           const double pu = fmin(sp.bound_push * fmax(1.0, fabs(hi)), sp.bound_frac * (hi - lo));
           v = fmax(v, lo + pl); v = fmin(v, hi - pu);
-          m[L.zl + lane * 6 + q] = 1.0; m[L.zu + lane * 6 + q] = 1.0;
+          m[L.zl + k * 6 + q] = 1.0; m[L.zu + k * 6 + q] = 1.0;
         } else {
           v = fmin(fmax(v, lo + sp.warm_push), hi - sp.warm_push);
-          m[L.zl + lane * 6 + q] = fmax(wst[CL.zl + ko * 6 + q], mu0 / (hi - lo));
-          m[L.zu + lane * 6 + q] = fmax(wst[CL.zu + ko * 6 + q], mu0 / (hi - lo));
+          m[L.zl + k * 6 + q] = fmax(wst[CL.zl + ko * 6 + q], mu0 / (hi - lo));
+          m[L.zu + k * 6 + q] = fmax(wst[CL.zu + ko * 6 + q], mu0 / (hi - lo));
         }
-        m[L.p + lane * kNP + bcol(q)] = v;
+        m[L.p + k * kNP + bcol(q)] = v;
       }
-      if (warm && lane + 1 < N) {
-        const int kp = lane + 1 < N - 1 ? lane + 1 : N - 2;
-        for (int i = 0; i < 5; ++i) m[L.pi + lane * 5 + i] = wst[CL.pi + kp * 5 + i];
+      if (warm && k + 1 < N) {
+        const int kp = k + 1 < N - 1 ? k + 1 : N - 2;
+        for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] = wst[CL.pi + kp * 5 + i];
       }
     }
-    if (warm && lane < 5) m[L.pi0 + lane] = wst[CL.pi + lane];
+    if (warm && tid < 5) m[L.pi0 + tid] = wst[CL.pi + tid];
   CFZ_END
 
   double mu = mu0, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
@@ -621,102 +924,114 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
 
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
-    CFZ_LANES(lane)
-      if (lane < N) sincos(m[L.p + lane * kNP + 2], &m[L.cs + 2 * lane + 1], &m[L.cs + 2 * lane]);
-    CFZ_END
-    CFZ_LANES(lane)
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
       double cmax = 0.0, csum = 0.0;
-      for (int t = lane; t < N * nb; t += 64) {
-        const int k = t / nb, j = t - k * nb;
-        double A[4][2], b[4], V[4][2], sep[2], gr[2][3];
-        block_polygon(sp, m, L, k, j, A, b, V);
-        const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1], cn = m[L.cs + 2 * k], sn = m[L.cs + 2 * k + 1];
-        int c1 = sel_ptr(m, L)[t];
-        if (iter > 0) {
-          const int c0 = c1;
-          c1 = select_rows(A, b, V, x, y, cn, sn, sp.g, c0);
-          if (c1 != c0) sel_ptr(m, L)[t] = c1;
-          rows_for<true>(A, b, V, x, y, cn, sn, sp.g, c1, sep, gr);
-          if (c1 != c0) {
-            // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
-            // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
-            const int same_face = (c0 >> 4) == (c1 >> 4);
-            const int ov0 = (c0 >> 2) & 3, ov1 = c0 & 3;
-            const double o_sg[2] = {m[L.sg + 2 * t], m[L.sg + 2 * t + 1]};
-            const double o_zs[2] = {m[L.zs + 2 * t], m[L.zs + 2 * t + 1]};
-            const double o_nu[2] = {m[L.nuc + 2 * t], m[L.nuc + 2 * t + 1]};
-            for (int r = 0; r < 2; ++r) {
-              const int nv = r == 0 ? ((c1 >> 2) & 3) : (c1 & 3);
-              const int src = same_face ? (nv == ov0 ? 0 : (nv == ov1 ? 1 : -1)) : -1;
-              if (src >= 0) {
-                m[L.sg + 2 * t + r] = src == 0 ? o_sg[0] : o_sg[1];
-                m[L.zs + 2 * t + r] = src == 0 ? o_zs[0] : o_zs[1];
-                m[L.nuc + 2 * t + r] = src == 0 ? o_nu[0] : o_nu[1];
-              } else {
-                const double sg = fmax(sep[r] - sp.dmin, sp.bound_push);
-                m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = mu / sg; m[L.nuc + 2 * t + r] = -mu / sg;
+      if (k < N) {
+        const double *pk = m + L.p + k * kNP;
+        const double x = pk[0], y = pk[1];
+        double sn, cn;
+        sincos(pk[2], &sn, &cn);
+        if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+        for (int j = sub; j < nb; j += kLPS) {
+          const int t = k * nb + j;
+          double A[4][2], b[4], V[4][2], sep[2];
+          block_polygon(sp, m, L, k, j, A, b, V);
+          int c1 = sel_ptr(m, L)[t];
+          if (iter > 0) {
+            const int c0 = c1;
+            c1 = select_rows(A, b, V, x, y, cn, sn, sp.g, c0);
+            if (c1 != c0) sel_ptr(m, L)[t] = c1;
+            rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c1, sep, nullptr);
+            if (c1 != c0) {
+              // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
+              // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
+              const int same_face = (c0 >> 4) == (c1 >> 4);
+              const int ov0 = (c0 >> 2) & 3, ov1 = c0 & 3;
+              const double o_sg[2] = {m[L.sg + 2 * t], m[L.sg + 2 * t + 1]};
+              const double o_zs[2] = {m[L.zs + 2 * t], m[L.zs + 2 * t + 1]};
+              const double o_nu[2] = {m[L.nuc + 2 * t], m[L.nuc + 2 * t + 1]};
+              for (int r = 0; r < 2; ++r) {
+                const int nv = r == 0 ? ((c1 >> 2) & 3) : (c1 & 3);
+                const int src = same_face ? (nv == ov0 ? 0 : (nv == ov1 ? 1 : -1)) : -1;
+                if (src >= 0) {
+                  m[L.sg + 2 * t + r] = src == 0 ? o_sg[0] : o_sg[1];
+                  m[L.zs + 2 * t + r] = src == 0 ? o_zs[0] : o_zs[1];
+                  m[L.nuc + 2 * t + r] = src == 0 ? o_nu[0] : o_nu[1];
+                } else {
+                  const double sg = fmax(sep[r] - sp.dmin, sp.bound_push);
+                  m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = mu / sg; m[L.nuc + 2 * t + r] = -mu / sg;
+                }
               }
             }
+          } else {
+            rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c1, sep, nullptr);
           }
-        } else {
-          rows_for<true>(A, b, V, x, y, cn, sn, sp.g, c1, sep, gr);
+          for (int r = 0; r < 2; ++r) {
+            const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
+            m[L.cj + 2 * t + r] = c;
+            cmax = fmax(cmax, fabs(c)); csum += fabs(c);
+          }
         }
-        for (int r = 0; r < 2; ++r) {
-          const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
-          m[L.cj + 2 * t + r] = c;
-          cmax = fmax(cmax, fabs(c)); csum += fabs(c);
-        }
-      }
-      m[L.red + 2 * 64 + lane] = cmax; m[L.red + 3 * 64 + lane] = csum;
-    CFZ_END
-    CFZ_STAMP(9);  // working set + rows
-    CFZ_LANES(lane)
-      double cmax = m[L.red + 2 * 64 + lane], csum = m[L.red + 3 * 64 + lane];
-      if (lane == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
-      if (lane + 1 < N) {
-        const int k = lane;
-        double F[5], S[3][5];
-        const double *pk = m + L.p + k * kNP;
-        rk4_step<true>(pk, pk[5], pk[6], sp.dt, sp.wb, sp.rk_substeps, F, S);
-        for (int r = 0; r < 3; ++r) for (int q = 0; q < 5; ++q) m[L.ab + k * 15 + r * 5 + q] = S[r][q];
-        for (int i = 0; i < 5; ++i) {
-          const double d = F[i] - m[L.p + (k + 1) * kNP + i];
-          m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
+        if (tid == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
+        if (k + 1 < N) {
+          // the quad integrates the stage together: lane sub carries sensitivity column sub, every lane column 4
+          double F[5], Sa[3], Sb[3];
+          rk4_sens2(pk, pk[5], pk[6], sp.dt, sp.wb, sp.rk_substeps, sub, F, Sa, Sb);
+          for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
+          if (sub == 0) {
+            for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
+            for (int i = 0; i < 5; ++i) {
+              const double d = F[i] - m[L.p + (k + 1) * kNP + i];
+              m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
+            }
+          }
         }
       }
-      m[L.red + 0 * 64 + lane] = cmax; m[L.red + 1 * 64 + lane] = csum;
+      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax;
     CFZ_END
-    const double cviol = red_max(m, L, 0), theta = red_sum(m, L, 1);
+    CFZ_REDUCE(1, 1, 0, rd, ro);
+    const double theta = ro[0], cviol = ro[1];
     CFZ_STAMP(1);  // working set, rows, dynamics
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
-    CFZ_LANES(lane)
-      double dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, fv = 0.0, lprod = 1.0;
-      if (lane == 0) for (int i = 0; i < 5; ++i) snu += fabs(m[L.pi0 + i]);
-      if (lane < N) {
-        const int k = lane;
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      double r0 = 0.0, r1 = 0.0, r2 = 0.0, dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, lprod = 1.0;
+      if (k < N) {
         const double *pk = m + L.p + k * kNP;
-        double r[kNP];
-        stage_grad(sp, refg, k, pk, r);
-        fv = stage_cost(sp, refg, k, pk);
         const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
-        for (int jb = 0; jb < nb; ++jb) {
+        for (int jb = sub; jb < nb; jb += kLPS) {
           double a0, a1, ap[2];
           block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cpsi, spsi, a0, a1, ap);
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
-            r[0] += a0 * nu; r[1] += a1 * nu; r[2] += ap[r_] * nu;
+            r0 += a0 * nu; r1 += a1 * nu; r2 += ap[r_] * nu;
             dinf = fmax(dinf, fabs(-nu - zs));
             snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lprod *= sg;
           }
         }
+      }
+      CFZ_P(qx, 0) = r0; CFZ_P(qx, 1) = r1; CFZ_P(qx, 2) = r2;
+      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 3) = lprod; CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0;
+    CFZ_MID
+      const int k = tid >> 2, sub = tid & 3;
+      double snu = CFZ_P(rd, 0), sz = CFZ_P(rd, 1), lprod = CFZ_P(rd, 3), dinf = CFZ_P(rd, 4), c0 = CFZ_P(rd, 5), fv = 0.0;
+      if (k < N) {
+        const bool first = sub == 0;  // the stage's own terms enter the sums once, through the quad's first lane
+        const double *pk = m + L.p + k * kNP;
+        double r[kNP];
+        stage_grad(sp, refg, k, pk, r);
+        r[0] += CFZ_QSUM(qx, 0); r[1] += CFZ_QSUM(qx, 1); r[2] += CFZ_QSUM(qx, 2);
+        if (first) fv = stage_cost(sp, refg, k, pk);
+        if (tid == 0) for (int i = 0; i < 5; ++i) snu += fabs(m[L.pi0 + i]);
         if (k + 1 < N) {
           double A[5][5], B[5][2];
           load_AB(m, L, k, sp.dt, A, B);
           for (int i = 0; i < 5; ++i) {
             const double pi = m[L.pi + k * 5 + i];
-            snu += fabs(pi);
+            if (first) snu += fabs(pi);
             for (int q = 0; q < 5; ++q) r[q] += A[i][q] * pi;
             r[5] += B[i][0] * pi; r[6] += B[i][1] * pi;
           }
@@ -725,18 +1040,17 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         else for (int i = 0; i < 5; ++i) r[i] -= m[L.pi + (k - 1) * 5 + i];
         for (int q = 0; q < 6; ++q) {
           const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
-          r[bcol(q)] += -zl + zu_; sz += zl + zu_;
+          r[bcol(q)] += -zl + zu_;
           const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
           c0 = fmax(c0, fmax(fabs(dl * zl), fabs(du * zu_)));
-          lprod *= dl * du;
+          if (first) { sz += zl + zu_; lprod *= dl * du; }
         }
         for (int i = 0; i < kNP; ++i) dinf = fmax(dinf, fabs(r[i]));
       }
-      m[L.red + 0 * 64 + lane] = dinf; m[L.red + 1 * 64 + lane] = snu; m[L.red + 2 * 64 + lane] = sz;
-      m[L.red + 3 * 64 + lane] = c0; m[red_at(L, 4) + lane] = fv; m[red_at(L, 5) + lane] = log(lprod);
+      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 2) = fv; CFZ_P(rd, 3) = log(lprod); CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0;
     CFZ_END
-    const double dual_inf = red_max(m, L, 0), sum_nu = red_sum(m, L, 1), sum_z = red_sum(m, L, 2);
-    const double cmp0 = red_max(m, L, 3), fval = red_sum(m, L, 4), logsum = red_sum(m, L, 5);
+    CFZ_REDUCE(4, 2, 0, rd, ro);
+    const double sum_nu = ro[0], sum_z = ro[1], fval = ro[2], logsum = ro[3], dual_inf = ro[4], cmp0 = ro[5];
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max;
     const double s_c = fmax(sp.s_max, sum_z / (double)n_bnd) / sp.s_max;
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
@@ -750,29 +1064,69 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
     while (mu > mu_floor) {
-      CFZ_LANES(lane)
+      CFZ_LANES(tid)
+        const int k = tid >> 2, sub = tid & 3;
         double cm = 0.0;
-        if (lane < N) {
-          const int k = lane;
-          for (int j = 0; j < nr; ++j) cm = fmax(cm, fabs(m[L.sg + k * nr + j] * m[L.zs + k * nr + j] - mu));
+        if (k < N) {
+          for (int jb = sub; jb < nb; jb += kLPS)
+            for (int r_ = 0; r_ < 2; ++r_) { const int t = k * nr + 2 * jb + r_; cm = fmax(cm, fabs(m[L.sg + t] * m[L.zs + t] - mu)); }
           for (int q = 0; q < 6; ++q) {
             const double v = m[L.p + k * kNP + bcol(q)];
             cm = fmax(cm, fmax(fabs((v - sp.bounds[2 * q]) * m[L.zl + k * 6 + q] - mu),
                                fabs((sp.bounds[2 * q + 1] - v) * m[L.zu + k * 6 + q] - mu)));
           }
         }
-        m[L.red + 0 * 64 + lane] = cm;
+        CFZ_P(rd, 0) = cm;
       CFZ_END
-      const double emu = fmax(dual_inf / s_d, fmax(cviol, red_max(m, L, 0) / s_c));
+      CFZ_REDUCE(0, 1, 0, rd, ro);
+      const double emu = fmax(dual_inf / s_d, fmax(cviol, ro[0] / s_c));
       if (emu <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
       else break;
     }
     const double tau = fmax(sp.tau_min, 1.0 - mu);
     CFZ_STAMP(3);  // barrier update
     // ---- condensed stage QP: H_k (compact), g_k ---------------------------------------------------
-    CFZ_LANES(lane)
-      if (lane < N) {
-        const int k = lane;
+    // rows: g += a (S c - mu / sigma), H += S a a' and the curvature of the separation rows weighted with their multipliers,
+    // sum_r nu_r d2 sep_r / d(x,y,psi)^2 = [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature):
+    //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
+    //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      double ac[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc
+      if (k < N) {
+        const double *pk = m + L.p + k * kNP;
+        const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
+        for (int jb = sub; jb < nb; jb += kLPS) {
+          const int sl = sel_ptr(m, L)[k * nb + jb];
+          double a0, a1, bap[2];
+          block_grad(sp, m, L, k, jb, sl, pk[0], pk[1], cpsi, spsi, a0, a1, bap);
+          for (int r_ = 0; r_ < 2; ++r_) {
+            const int t = k * nr + 2 * jb + r_;
+            const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
+            const double coef = S * m[L.cj + t] - mu * isg;
+            const double a2 = bap[r_];
+            ac[0] += a0 * coef; ac[1] += a1 * coef; ac[2] += a2 * coef;
+            ac[3] += S * a0 * a0; ac[4] += S * a1 * a1; ac[5] += S * a2 * a2;
+            ac[6] += S * a0 * a1; ac[7] += S * a0 * a2; ac[8] += S * a1 * a2;
+            if (sp.row_curvature) {
+              const int f = (sl >> 4) & 3, v = r_ ? (sl & 3) : ((sl >> 2) & 3);
+              const double nu = m[L.nuc + t];
+              if ((sl >> 6) == 1) {
+                const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
+                ac[11] -= nu * (a0 * (cpsi * bx - spsi * by) + a1 * (spsi * bx + cpsi * by));
+              } else {
+                const double gf = f == 0 ? sp.g[0] : (f == 1 ? sp.g[1] : (f == 2 ? sp.g[2] : sp.g[3]));
+                ac[9] -= nu * a1; ac[10] += nu * a0;
+                ac[11] -= nu * (m[L.cj + t] + sp.dmin + m[L.sg + t] + gf);
+              }
+            }
+          }
+        }
+      }
+      for (int i = 0; i < 12; ++i) CFZ_P(qx, i) = ac[i];
+    CFZ_MID
+      const int k = tid >> 2, sub = tid & 3;
+      if (k < N) {
         const double *w = sp.weights; const double *pk = m + L.p + k * kNP;
         double g[kNP], h[11];
         stage_grad(sp, refg, k, pk, g);
@@ -785,37 +1139,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           h[bcol(q)] += m[L.zl + k * 6 + q] * il + m[L.zu + k * 6 + q] * iu;
           g[bcol(q)] += mu * (iu - il);
         }
-        // curvature of the separation rows weighted with their multipliers, sum_r nu_r d2 sep_r / d(x,y,psi)^2 =
-        // [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature), rebuilt from the row gradients:
-        //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
-        //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
-        double ca = 0.0, cb = 0.0, cc = 0.0;
-        const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
-        double ba0 = 0.0, ba1 = 0.0, bap[2] = {0.0, 0.0};
-        for (int j = 0; j < nr; ++j) {
-          const int t = k * nr + j;
-          const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
-          const double coef = S * m[L.cj + t] - mu * isg;
-          const int sl = sel_ptr(m, L)[t >> 1];
-          if ((j & 1) == 0) block_grad(sp, m, L, k, j >> 1, sl, pk[0], pk[1], cpsi, spsi, ba0, ba1, bap);
-          const double a0 = ba0, a1 = ba1, a2 = bap[j & 1];
-          g[0] += a0 * coef; g[1] += a1 * coef; g[2] += a2 * coef;
-          h[0] += S * a0 * a0; h[1] += S * a1 * a1; h[2] += S * a2 * a2;
-          h[7] += S * a0 * a1; h[8] += S * a0 * a2; h[9] += S * a1 * a2;
-          if (sp.row_curvature) {
-            const int f = (sl >> 4) & 3, v = (t & 1) ? (sl & 3) : ((sl >> 2) & 3);
-            const double nu = m[L.nuc + t];
-            if ((sl >> 6) == 1) {
-              const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
-              cc -= nu * (a0 * (cpsi * bx - spsi * by) + a1 * (spsi * bx + cpsi * by));
-            } else {
-              const double gf = f == 0 ? sp.g[0] : (f == 1 ? sp.g[1] : (f == 2 ? sp.g[2] : sp.g[3]));
-              ca -= nu * a1; cb += nu * a0;
-              cc -= nu * (m[L.cj + t] + sp.dmin + m[L.sg + t] + gf);
-            }
-          }
-        }
+        g[0] += CFZ_QSUM(qx, 0); g[1] += CFZ_QSUM(qx, 1); g[2] += CFZ_QSUM(qx, 2);
+        h[0] += CFZ_QSUM(qx, 3); h[1] += CFZ_QSUM(qx, 4); h[2] += CFZ_QSUM(qx, 5);
+        h[7] += CFZ_QSUM(qx, 6); h[8] += CFZ_QSUM(qx, 7); h[9] += CFZ_QSUM(qx, 8);
         if (sp.row_curvature) {
+          const double ca = CFZ_QSUM(qx, 9), cb = CFZ_QSUM(qx, 10), cc = CFZ_QSUM(qx, 11);
           // convexity safeguard: scale by th in {1, 1/2, .., 2^-9, 0} until diag(2w) + th C keeps the margin 0.2 min(w)
           const double mg = 0.2 * fmin(w[0], fmin(w[1], w[2]));
           const double q0 = 2 * w[0] - mg, q1 = 2 * w[1] - mg, q2 = 2 * w[2] - mg;
@@ -828,138 +1156,23 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           }
           h[2] += th * cc; h[8] += th * ca; h[9] += th * cb;
         }
-        for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
-        for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];
+        if (sub == 0) {
+          for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
+          for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];
+        }
       }
     CFZ_END
     CFZ_STAMP(4);  // assembly
-    // ---- Riccati backward sweep (lane 0; the 5x5 value function stays in registers) -------------------
-    // Structure used: A_k = I + [0 0 s00 s01 s02; 0 0 s10 s11 s12; 0 0 0 s21 s22; 0; 0] (s20 = 1),
-    // B_k = [s03 s04; s13 s14; s23 s24; dt 0; 0 dt]; H_k = diag(h0..h6) + pose off-diagonals
-    // h7 (0,1), h8 (0,2), h9 (1,2) + the v-w cross term h10 (3,6).  A lane-parallel variant (matrix
-    // entries spread over lanes, exchange through LDS) measured 2.2x slower: every exchange is a
-    // dependent LDS round trip of a lone wavefront.
-    double *const rP = m + L.rP, *const rp = rP + 25;  // value function of stage 0 handed to the forward sweep
-    CFZ_LANES(lane)
-      if (lane == 0) {
-        const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
-        const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP;
-        double *K = m + L.kk + k * 12;
-        for (int q = 0; q < 10; ++q) K[q] = 0.0;
-        K[5 + 3] = -h[10] / h[6]; K[10] = -gk[5] / h[5]; K[11] = -gk[6] / h[6];
-        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = 0.0; rP[i * 6] = h[i]; rp[i] = gk[i]; }
-        rP[1] = rP[5] = h[7]; rP[2] = rP[10] = h[8]; rP[7] = rP[11] = h[9];
-        rP[18] += h[10] * K[5 + 3]; rp[3] += h[10] * K[11];
-      }
-    CFZ_END
-    CFZ_LANES(lane)
-      if (lane == 0) {  // backward sweep on one lane, P in registers
-        const double dt = sp.dt;
-        double P[5][5], pv[5];
-        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) P[i][q] = rP[i * 5 + q]; pv[i] = rp[i]; }
-        for (int k = N - 2; k >= 0; --k) {
-          const double *s = m + L.ab + k * 15, *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *dk = m + L.d + k * 5;
-          const double s00 = s[0], s01 = s[1], s02 = s[2], s03 = s[3], s04 = s[4];
-          const double s10 = s[5], s11 = s[6], s12 = s[7], s13 = s[8], s14 = s[9];
-          const double s21 = s[11], s22 = s[12], s23 = s[13], s24 = s[14];
-          double M[5][5], PB[5][2], Pd[5];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            M[i][0] = P[i][0]; M[i][1] = P[i][1];
-            M[i][2] = P[i][2] + s00 * P[i][0] + s10 * P[i][1];
-            M[i][3] = P[i][3] + s01 * P[i][0] + s11 * P[i][1] + s21 * P[i][2];
-            M[i][4] = P[i][4] + s02 * P[i][0] + s12 * P[i][1] + s22 * P[i][2];
-            PB[i][0] = s03 * P[i][0] + s13 * P[i][1] + s23 * P[i][2] + dt * P[i][3];
-            PB[i][1] = s04 * P[i][0] + s14 * P[i][1] + s24 * P[i][2] + dt * P[i][4];
-            Pd[i] = pv[i] + P[i][0] * dk[0] + P[i][1] * dk[1] + P[i][2] * dk[2] + P[i][3] * dk[3] + P[i][4] * dk[4];
-          }
-          double Hxx[5][5], hx[5];
-#pragma unroll
-          for (int j = 0; j < 5; ++j) {
-            Hxx[0][j] = M[0][j]; Hxx[1][j] = M[1][j];
-            Hxx[2][j] = M[2][j] + s00 * M[0][j] + s10 * M[1][j];
-            Hxx[3][j] = M[3][j] + s01 * M[0][j] + s11 * M[1][j] + s21 * M[2][j];
-            Hxx[4][j] = M[4][j] + s02 * M[0][j] + s12 * M[1][j] + s22 * M[2][j];
-          }
-          Hxx[0][0] += h[0]; Hxx[1][1] += h[1]; Hxx[2][2] += h[2]; Hxx[3][3] += h[3]; Hxx[4][4] += h[4];
-          Hxx[0][1] += h[7]; Hxx[1][0] += h[7]; Hxx[0][2] += h[8]; Hxx[2][0] += h[8]; Hxx[1][2] += h[9]; Hxx[2][1] += h[9];
-          hx[0] = gk[0] + Pd[0]; hx[1] = gk[1] + Pd[1];
-          hx[2] = gk[2] + Pd[2] + s00 * Pd[0] + s10 * Pd[1];
-          hx[3] = gk[3] + Pd[3] + s01 * Pd[0] + s11 * Pd[1] + s21 * Pd[2];
-          hx[4] = gk[4] + Pd[4] + s02 * Pd[0] + s12 * Pd[1] + s22 * Pd[2];
-          double Hux[2][5], hu[2];
-#pragma unroll
-          for (int j = 0; j < 5; ++j) {
-            Hux[0][j] = s03 * M[0][j] + s13 * M[1][j] + s23 * M[2][j] + dt * M[3][j];
-            Hux[1][j] = s04 * M[0][j] + s14 * M[1][j] + s24 * M[2][j] + dt * M[4][j];
-          }
-          Hux[1][3] += h[10];
-          const double a00 = h[5] + s03 * PB[0][0] + s13 * PB[1][0] + s23 * PB[2][0] + dt * PB[3][0];
-          const double a01 = s03 * PB[0][1] + s13 * PB[1][1] + s23 * PB[2][1] + dt * PB[3][1];
-          const double a11 = h[6] + s04 * PB[0][1] + s14 * PB[1][1] + s24 * PB[2][1] + dt * PB[4][1];
-          hu[0] = gk[5] + s03 * Pd[0] + s13 * Pd[1] + s23 * Pd[2] + dt * Pd[3];
-          hu[1] = gk[6] + s04 * Pd[0] + s14 * Pd[1] + s24 * Pd[2] + dt * Pd[4];
-          const double idet = 1.0 / (a00 * a11 - a01 * a01);
-          const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
-          double t0[6], t1[6];  // Huu^{-1} [Hux hu]
-#pragma unroll
-          for (int q = 0; q < 5; ++q) { t0[q] = i00 * Hux[0][q] + i01 * Hux[1][q]; t1[q] = i01 * Hux[0][q] + i11 * Hux[1][q]; }
-          t0[5] = i00 * hu[0] + i01 * hu[1]; t1[5] = i01 * hu[0] + i11 * hu[1];
-          double *K = m + L.kk + k * 12;
-          for (int q = 0; q < 5; ++q) { K[q] = -t0[q]; K[5 + q] = -t1[q]; }
-          K[10] = -t0[5]; K[11] = -t1[5];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-#pragma unroll
-            for (int q = i; q < 5; ++q) {
-              const double v = 0.5 * (Hxx[i][q] + Hxx[q][i]) - (Hux[0][i] * t0[q] + Hux[1][i] * t1[q]);
-              P[i][q] = v; P[q][i] = v;
-            }
-            pv[i] = hx[i] - (Hux[0][i] * t0[5] + Hux[1][i] * t1[5]);
-          }
-        }
-        for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = P[i][q]; rp[i] = pv[i]; }
-      }
-    CFZ_END
+    // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
+    CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
-    // ---- forward step and costates (lane 0) -----------------------------------------------------------
-    CFZ_LANES(lane)
-      if (lane == 0) {
-        const double dt = sp.dt;
-        const double *pv = rp;
-        double P[5][5];
-        for (int i = 0; i < 5; ++i) for (int q = 0; q < 5; ++q) P[i][q] = rP[i * 5 + q];
-        // forward sweep
-        double *dp = m + L.dp;
-        for (int i = 0; i < 5; ++i) dp[i] = m[L.x0 + i] - m[L.p + i];
-        // multiplier of the initial-state row from the value function at stage 0
-        for (int i = 0; i < 5; ++i) { double s_ = pv[i]; for (int q = 0; q < 5; ++q) s_ += P[i][q] * dp[q]; m[L.dpi0 + i] = -s_ - m[L.pi0 + i]; }
-        double z0 = dp[0], z1 = dp[1], z2 = dp[2], z3 = dp[3], z4 = dp[4];  // current dz kept in registers
-#pragma unroll 5
-        for (int k = 0; k < N; ++k) {  // unrolled so that the gain/dynamics loads of later stages are in flight early
-          const double *K = m + L.kk + k * 12;
-          const double u0 = K[10] + K[0] * z0 + K[1] * z1 + K[2] * z2 + K[3] * z3 + K[4] * z4;
-          const double u1 = K[11] + K[5] * z0 + K[6] * z1 + K[7] * z2 + K[8] * z3 + K[9] * z4;
-          dp[k * kNP + 5] = u0; dp[k * kNP + 6] = u1;
-          if (k + 1 < N) {
-            const double *s = m + L.ab + k * 15, *dk = m + L.d + k * 5;
-            const double n0 = dk[0] + z0 + s[0] * z2 + s[1] * z3 + s[2] * z4 + s[3] * u0 + s[4] * u1;
-            const double n1 = dk[1] + z1 + s[5] * z2 + s[6] * z3 + s[7] * z4 + s[8] * u0 + s[9] * u1;
-            const double n2 = dk[2] + z2 + s[11] * z3 + s[12] * z4 + s[13] * u0 + s[14] * u1;
-            const double n3 = dk[3] + z3 + dt * u0, n4 = dk[4] + z4 + dt * u1;
-            z0 = n0; z1 = n1; z2 = n2; z3 = n3; z4 = n4;
-            double *zn = dp + (k + 1) * kNP;
-            zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
-          }
-        }
-      }
-    CFZ_END
+    CFZ_SERIAL(riccati_forward(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows).  The stage-local
-    // part (H dp + g)_z is formed by one lane per stage into the slot of d(pi_{k-1}); only the 5-vector recursion
-    // through A_k' stays on lane 0.
-    CFZ_LANES(lane)
-      if (lane >= 1 && lane < N) {
-        const int k = lane;
+    // part (H dp + g)_z is formed by the stage's quad into the slot of d(pi_{k-1}); only the 5-vector recursion through
+    // A_k' stays on lane 0.
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      if (k >= 1 && k < N && sub == 0) {
         const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *z = m + L.dp + k * kNP;
         double *q = m + L.dpi + (k - 1) * 5;
         q[0] = gk[0] + h[0] * z[0] + h[7] * z[1] + h[8] * z[2];
@@ -969,80 +1182,67 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         q[4] = gk[4] + h[4] * z[4];
       }
     CFZ_END
-    CFZ_LANES(lane)
-      if (lane == 0) {
-        double lam[5] = {0, 0, 0, 0, 0};
-#pragma unroll 5
-        for (int k = N - 1; k >= 1; --k) {
-          double *q = m + L.dpi + (k - 1) * 5;
-          double nl[5] = {q[0], q[1], q[2], q[3], q[4]};
-          if (k + 1 < N) {
-            const double *s = m + L.ab + k * 15;
-            nl[0] += lam[0]; nl[1] += lam[1];
-            nl[2] += lam[2] + s[0] * lam[0] + s[5] * lam[1];
-            nl[3] += lam[3] + s[1] * lam[0] + s[6] * lam[1] + s[11] * lam[2];
-            nl[4] += lam[4] + s[2] * lam[0] + s[7] * lam[1] + s[12] * lam[2];
-          }
-          for (int i = 0; i < 5; ++i) { lam[i] = nl[i]; q[i] = nl[i] - m[L.pi + (k - 1) * 5 + i]; }
-        }
-      }
-    CFZ_END
-    CFZ_STAMP(5);  // Riccati
+    CFZ_SERIAL(costate_sweep(CFZ_WSP(m), N, L.ab, L.dpi, L.pi));
+    CFZ_STAMP(5);  // Riccati forward + costates
     // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
     // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
     // per bound and reused (a DP division is ~12 dependent instructions on this pipe).
-    CFZ_LANES(lane)
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
       double rpri = 0.0, rdual = 0.0, dphi = 0.0;  // max of -dx/dist and -dz/z
-      if (lane < N) {
-        const int k = lane;
+      if (k < N) {
         const double *pk = m + L.p + k * kNP, *dpk = m + L.dp + k * kNP;
-        double g[kNP];
-        stage_grad(sp, refg, k, pk, g);
-        for (int q = 0; q < 6; ++q) {
-          const double dx = dpk[bcol(q)];
-          const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
-          const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
-          g[bcol(q)] += mu * (iu - il);
-          const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
-          rpri = fmax(rpri, fmax(-dx * il, dx * iu));
-          rdual = fmax(rdual, fmax(-dzl / zl, -dzu / zu_));
-        }
-        for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
-        double ba0 = 0.0, ba1 = 0.0, bap[2] = {0.0, 0.0};
         // heading of the current iterate again: its cos/sin slots carried the value function through the Riccati sweeps
         double sps, cps;
-        sincos(m[L.p + k * kNP + 2], &sps, &cps);
-        for (int j = 0; j < nr; ++j) {
-          const int t = k * nr + j;
-          const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
-          if ((j & 1) == 0) block_grad(sp, m, L, k, j >> 1, sel_ptr(m, L)[t >> 1], m[L.p + k * kNP], m[L.p + k * kNP + 1], cps, sps, ba0, ba1, bap);
-          const double ds = m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[j & 1] * dpk[2];
-          m[L.dsg + t] = ds;
-          const double dzs = mu * isg - zs - zs * isg * ds;
-          dphi -= mu * isg * ds;
-          rpri = fmax(rpri, -ds * isg);
-          rdual = fmax(rdual, -dzs / zs);
+        sincos(pk[2], &sps, &cps);
+        for (int jb = sub; jb < nb; jb += kLPS) {
+          double ba0, ba1, bap[2];
+          block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cps, sps, ba0, ba1, bap);
+          for (int r_ = 0; r_ < 2; ++r_) {
+            const int t = k * nr + 2 * jb + r_;
+            const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
+            const double ds = m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[r_] * dpk[2];
+            m[L.dsg + t] = ds;
+            const double dzs = mu * isg - zs - zs * isg * ds;
+            dphi -= mu * isg * ds;
+            rpri = fmax(rpri, -ds * isg);
+            rdual = fmax(rdual, -dzs / zs);
+          }
+        }
+        if (sub == 0) {
+          double g[kNP];
+          stage_grad(sp, refg, k, pk, g);
+          for (int q = 0; q < 6; ++q) {
+            const double dx = dpk[bcol(q)];
+            const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
+            const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
+            g[bcol(q)] += mu * (iu - il);
+            const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
+            rpri = fmax(rpri, fmax(-dx * il, dx * iu));
+            rdual = fmax(rdual, fmax(-dzl / zl, -dzu / zu_));
+          }
+          for (int i = 0; i < kNP; ++i) dphi += g[i] * dpk[i];
         }
       }
-      m[L.red + 0 * 64 + lane] = rpri; m[L.red + 1 * 64 + lane] = rdual; m[L.red + 2 * 64 + lane] = dphi;
+      CFZ_P(rd, 0) = dphi; CFZ_P(rd, 1) = rpri; CFZ_P(rd, 2) = rdual;
     CFZ_END
-    const double rp_max = red_max(m, L, 0), rd_max = red_max(m, L, 1);
+    CFZ_REDUCE(1, 2, 0, rd, ro);
+    const double dphi = ro[0], rp_max = ro[1], rd_max = ro[2];
     const double a_pri = (rp_max > tau) ? tau / rp_max : 1.0, a_dual = (rd_max > tau) ? tau / rd_max : 1.0;
-    const double dphi = red_sum(m, L, 2);
     CFZ_STAMP(6);  // step
     // ---- filter line search --------------------------------------------------------------------------------
     const double phi0 = fval - mu * logsum;
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; int accepted = 0, f_type = 0;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
-      CFZ_LANES(lane)
-        if (lane < N) sincos(m[L.p + lane * kNP + 2] + alpha * m[L.dp + lane * kNP + 2], &m[L.cs + 2 * lane + 1], &m[L.cs + 2 * lane]);
+      CFZ_LANES(tid)
+        double th_, ph_, ll_, bad_;
+        merit_partials(sp, refg, m, L, alpha, tid, th_, ph_, ll_, bad_);
+        CFZ_P(rd, 0) = th_; CFZ_P(rd, 1) = ph_; CFZ_P(rd, 2) = ll_; CFZ_P(rd, 3) = bad_;
       CFZ_END
-      CFZ_LANES(lane)
-        merit_partials(sp, refg, m, L, alpha, lane);
-      CFZ_END
-      const double th_t = red_sum(m, L, 0), ph_t = red_sum(m, L, 1) - mu * red_sum(m, L, 2);
-      int ok = (red_max(m, L, 3) == 0.0) && isfinite(th_t) && isfinite(ph_t) && th_t <= theta_max;
+      CFZ_REDUCE(3, 1, 0, rd, ro);
+      const double th_t = ro[0], ph_t = ro[1] - mu * ro[2];
+      int ok = (ro[3] == 0.0) && isfinite(th_t) && isfinite(ph_t) && th_t <= theta_max;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= m[L.filt + 2 * q] && ph_t >= m[L.filt + 2 * q + 1]) { ok = 0; break; }
       f_type = 0;
       if (ok) {
@@ -1056,8 +1256,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_STAMP(7);  // line search
     if (!accepted) { status = 2; break; }
     if (!f_type) {
-      CFZ_LANES(lane)
-        if (lane == 0) {
+      CFZ_LANES(tid)
+        if (tid == 0) {
           int n = nfilt;
           if (n == sp.filter_cap) { for (int q = 0; q + 1 < n; ++q) { m[L.filt + 2 * q] = m[L.filt + 2 * q + 2]; m[L.filt + 2 * q + 1] = m[L.filt + 2 * q + 3]; } n--; }
           m[L.filt + 2 * n] = (1.0 - sp.gamma_theta) * theta; m[L.filt + 2 * n + 1] = phi0 - sp.gamma_phi * theta;
@@ -1066,34 +1266,37 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       nfilt = (nfilt == sp.filter_cap) ? nfilt : nfilt + 1;
     }
     // ---- update ------------------------------------------------------------------------------------------------
-    CFZ_LANES(lane)
-      if (lane < 5) m[L.pi0 + lane] += alpha * m[L.dpi0 + lane];
-      if (lane < N) {
-        const int k = lane;
-        double *pk = m + L.p + k * kNP; const double *dpk = m + L.dp + k * kNP;
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      if (tid < 5) m[L.pi0 + tid] += alpha * m[L.dpi0 + tid];
+      if (k < N) {
         const double ks = sp.kappa_sigma, iks = 1.0 / sp.kappa_sigma;
-        for (int q = 0; q < 6; ++q) {
-          const double dx = dpk[bcol(q)];
-          const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
-          const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
-          const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
-          const double xn = pk[bcol(q)] + alpha * dx;
-          const double mln = mu / (xn - sp.bounds[2 * q]), mun = mu / (sp.bounds[2 * q + 1] - xn);  // mu / new distance
-          m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mln * iks), ks * mln);
-          m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mun * iks), ks * mun);
+        for (int jb = sub; jb < nb; jb += kLPS)
+          for (int r_ = 0; r_ < 2; ++r_) {
+            const int t = k * nr + 2 * jb + r_;
+            const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t], isg = 1.0 / sg;
+            const double S = zs * isg + sp.reg_primal;
+            const double dnu = S * ds - mu * isg - m[L.nuc + t];
+            const double dzs = mu * isg - zs - zs * isg * ds;
+            const double sgn = sg + alpha * ds, msn = mu / sgn;
+            m[L.sg + t] = sgn; m[L.nuc + t] += alpha * dnu;
+            m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, msn * iks), ks * msn);
+          }
+        if (sub == 0) {
+          double *pk = m + L.p + k * kNP; const double *dpk = m + L.dp + k * kNP;
+          for (int q = 0; q < 6; ++q) {
+            const double dx = dpk[bcol(q)];
+            const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
+            const double zl = m[L.zl + k * 6 + q], zu_ = m[L.zu + k * 6 + q];
+            const double dzl = mu * il - zl - zl * il * dx, dzu = mu * iu - zu_ + zu_ * iu * dx;
+            const double xn = pk[bcol(q)] + alpha * dx;
+            const double mln = mu / (xn - sp.bounds[2 * q]), mun = mu / (sp.bounds[2 * q + 1] - xn);  // mu / new distance
+            m[L.zl + k * 6 + q] = fmin(fmax(zl + a_dual * dzl, mln * iks), ks * mln);
+            m[L.zu + k * 6 + q] = fmin(fmax(zu_ + a_dual * dzu, mun * iks), ks * mun);
+          }
+          for (int i = 0; i < kNP; ++i) pk[i] += alpha * dpk[i];
+          if (k + 1 < N) for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] += alpha * m[L.dpi + k * 5 + i];
         }
-        for (int j = 0; j < nr; ++j) {
-          const int t = k * nr + j;
-          const double sg = m[L.sg + t], zs = m[L.zs + t], ds = m[L.dsg + t], isg = 1.0 / sg;
-          const double S = zs * isg + sp.reg_primal;
-          const double dnu = S * ds - mu * isg - m[L.nuc + t];
-          const double dzs = mu * isg - zs - zs * isg * ds;
-          const double sgn = sg + alpha * ds, msn = mu / sgn;
-          m[L.sg + t] = sgn; m[L.nuc + t] += alpha * dnu;
-          m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, msn * iks), ks * msn);
-        }
-        for (int i = 0; i < kNP; ++i) pk[i] += alpha * dpk[i];
-        if (k + 1 < N) for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] += alpha * m[L.dpi + k * 5 + i];
       }
     CFZ_END
     CFZ_STAMP(8);  // update
@@ -1101,10 +1304,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
 
   CFZ_STAMP(10);
   // ---- write back: trajectory, separations, dual certificates ---------------------------------------------------
-  CFZ_LANES(lane)
-    for (int i = lane; i < N * kNP; i += 64) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
+  CFZ_LANES(tid)
+    for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
     double smin = INFINITY;
-    for (int t = lane; t < N * nb; t += 64) {
+    for (int t = tid; t < N * nb; t += kNL) {
       const int k = t / nb, j = t - k * nb;
       double A[4][2], b[4], V[4][2], sep2[2];
       block_polygon(sp, m, L, k, j, A, b, V);
@@ -1166,21 +1369,22 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         }
       }
     }
-    m[L.red + 0 * 64 + lane] = smin;
+    CFZ_P(rd, 0) = smin;
   CFZ_END
-  out_d[0] = fval_last; out_d[1] = err0; out_d[2] = red_min(m, L, 0);
+  CFZ_REDUCE(0, 0, 1, rd, ro);
+  out_d[0] = fval_last; out_d[1] = err0; out_d[2] = ro[0];
   out_i[0] = iter; out_i[1] = status;
   if (wst) {  // leave the multipliers for the next MPC iteration of this vehicle, or say that there are none
-    CFZ_LANES(lane)
+    CFZ_LANES(tid)
       if (status == 0) {
-        for (int i = lane; i < N * nr; i += 64) wst[CL.z + i] = m[L.zs + i];
-        for (int i = lane; i < N * 6; i += 64) { wst[CL.zl + i] = m[L.zl + i]; wst[CL.zu + i] = m[L.zu + i]; }
-        for (int i = lane; i < N * 5; i += 64) wst[CL.pi + i] = i < (N - 1) * 5 ? m[L.pi + i] : 0.0;
-        if (lane < 5) wst[CL.pi0 + lane] = m[L.pi0 + lane];
+        for (int i = tid; i < N * nr; i += kNL) wst[CL.z + i] = m[L.zs + i];
+        for (int i = tid; i < N * 6; i += kNL) { wst[CL.zl + i] = m[L.zl + i]; wst[CL.zu + i] = m[L.zu + i]; }
+        for (int i = tid; i < N * 5; i += kNL) wst[CL.pi + i] = i < (N - 1) * 5 ? m[L.pi + i] : 0.0;
+        if (tid < 5) wst[CL.pi0 + tid] = m[L.pi0 + tid];
         unsigned char *ws = reinterpret_cast<unsigned char *>(wst + CL.sel);
-        for (int i = lane; i < N * nb; i += 64) ws[i] = sel_ptr(m, L)[i];
-        if (lane == 0) { wst[CL.mu] = mu; wst[CL.valid] = 1.0; }
-      } else if (lane == 0) {
+        for (int i = tid; i < N * nb; i += kNL) ws[i] = sel_ptr(m, L)[i];
+        if (tid == 0) { wst[CL.mu] = mu; wst[CL.valid] = 1.0; }
+      } else if (tid == 0) {
         wst[CL.valid] = 0.0;
       }
     CFZ_END

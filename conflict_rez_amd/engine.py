@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconfrez_hip.so")
-MAX_OBS, MAX_NBR, MAX_N = 8, 7, 64
+MAX_OBS, MAX_NBR, MAX_N = 8, 7, 32
 
 STATUS_NAMES = {0: "converged", 1: "iteration limit", 2: "line search failed", 3: "non-finite iterate",
                 4: "measured state in collision (infeasible)", 5: "constraint violation stalled (locally infeasible)"}

@@ -29,7 +29,7 @@ extern "C" {
 
 #define CFZ_MAX_OBS 8   /* static obstacles (reference: 6, compute_sets.py:259-330) */
 #define CFZ_MAX_NBR 7   /* neighbouring vehicles (reference: 3) */
-#define CFZ_MAX_N 64    /* horizon stages (reference: 30, vehicle_follower.py:146) */
+#define CFZ_MAX_N 32    /* horizon stages (reference: 30, vehicle_follower.py:146); four lanes of a 128-lane workgroup per stage */
 
 /* Constants of the MPC-step NLP: what `setup_controller(dt, N, dmin)` bakes into the CasADi
  * graph (vehicle_follower.py:146-368). */
