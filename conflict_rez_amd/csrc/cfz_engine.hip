@@ -45,7 +45,10 @@ constexpr int kPlantSubsteps = 10;
 
 struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 
-__global__ __launch_bounds__(cfz::kNL, 2) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
+#ifndef CFZ_WAVES_PER_SIMD
+#define CFZ_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
                                                    int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
                                                    double *wst, int wst_stride, const int32_t *carry, int carry_all,
@@ -166,11 +169,11 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
 #else
 #define CFZ_MARK(c) do { } while (0)
 #endif
-__global__ __launch_bounds__(cfz::kNL, 2) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
                                                         const double *ref_table, const int32_t *kidx0, int t_base,
                                                         double *pred, double *state, double *scratch, int32_t *qbuf,
                                                         int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
-                                                        double *stats, int32_t *iter_sum, double *wst, int wst_stride) {
+                                                        double *stats, int32_t *iter_sum, double *wst, int wst_stride, int prio_lag) {
   extern __shared__ double smem[];
   const int N = sp.N, nn = sp.n_nbr, B = S * V, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,6 +227,12 @@ __global__ __launch_bounds__(cfz::kNL, 2) void loop_kernel(const cfz::KSpec sp, 
     const int t = cmd[0], b = cmd[1];
     if (t < 0) break;
     CFZ_MARK(2);
+    // The launch ends with its slowest scenario (a chain of K dependent iterations).  A workgroup serving the oldest open
+    // iteration is on that critical path: its two wavefronts take issue priority over the wavefronts they share their
+    // SIMDs with (VALU issue is arbitrated by priority, then age), the others give way.
+    if (prio_lag >= 0) {
+      if (t <= CFZ_LD(&ctrl[0]) + prio_lag) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    }
     const int s = b / V, v = b - s * V;
     const double *pin = pred + (size_t)(t & 1) * B * 7 * N;   // predictions after iteration t-1
     double *pout = pred + (size_t)((t + 1) & 1) * B * 7 * N;
@@ -1196,7 +1205,8 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
                      h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
-                     h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride);
+                     h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride,
+                     std::getenv("CFZ_LOOP_PRIO_LAG") ? std::atoi(std::getenv("CFZ_LOOP_PRIO_LAG")) : 0);
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   // predictions after K iterations live in parity K%2; advance the scenario clocks by K

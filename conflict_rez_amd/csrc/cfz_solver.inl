@@ -635,7 +635,10 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
 // B_k = [s03 s04; s13 s14; s23 s24; dt 0; 0 dt]; H_k = diag(h0..h6) + pose off-diagonals h7 (0,1), h8 (0,2), h9 (1,2) +
 // the v-w cross term h10 (3,6).  A lane-parallel variant (matrix entries spread over lanes, exchange through LDS) measured
 // 2.2x slower: every exchange is a dependent LDS round trip.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CFZ_SWEEP_INLINE)
+#define CFZ_SWEEP __device__ __forceinline__ void
+#define CFZ_SWEEP_GUARD if (threadIdx.x != 0) return;
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define CFZ_SWEEP __device__ __attribute__((noinline)) void
 #define CFZ_SWEEP_GUARD if (threadIdx.x != 0) return;
 #else
@@ -643,87 +646,138 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
 #define CFZ_SWEEP_GUARD
 #endif
 
-// backward sweep: gains K_k (12 per stage) into kk, value function of stage 0 into rP (25) and rP + 25 (5)
+// All three sweeps are software-pipelined by hand: the loads of the NEXT stage are issued before the stores of this one.
+// The compiler cannot do that itself (loads and stores go through the same workspace pointer, so it must assume that a
+// store may feed a later load) and without it every stage waits for an LDS round trip per operand group.
+
+// backward sweep: gains K_k (12 per stage) into kk, value function of stage 0 into rP (25) and rP + 25 (5).
+// P is kept as its upper triangle.  With W = B'P:  Hux = W A,  Huu = R + W B,  hu = g_u + B'(p + P d);  M = P A,
+// Hxx = Q + A'M (upper triangle only);  K = -Huu^-1 [Hux hu];  P <- Hxx - Hux' Huu^-1 Hux,  p <- hx - Hux' Huu^-1 hu.
 CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
   CFZ_SWEEP_GUARD
-  double P[5][5], pv[5];
+  // upper triangle of P: P00 P01 P02 P03 P04 | P11 P12 P13 P14 | P22 P23 P24 | P33 P34 | P44
+  double P00, P01, P02, P03 = 0.0, P04 = 0.0, P11, P12, P13 = 0.0, P14 = 0.0, P22, P23 = 0.0, P24 = 0.0, P33, P34 = 0.0, P44;
+  double p0, p1, p2, p3, p4;
   {
     const int k = N - 1;  // terminal stage: its inputs a,w are costed but drive no dynamics
     const wsp_f64 *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
     wsp_f64 *K = m + o_kk + k * 12;
+    const double h10 = h[10], h6 = h[6];
+    const double k53 = -h10 / h6, k10 = -gk[5] / h[5], k11 = -gk[6] / h6;
+    P00 = h[0]; P11 = h[1]; P22 = h[2]; P33 = h[3] + h10 * k53; P44 = h[4];
+    P01 = h[7]; P02 = h[8]; P12 = h[9];
+    p0 = gk[0]; p1 = gk[1]; p2 = gk[2]; p3 = gk[3] + h10 * k11; p4 = gk[4];
     for (int q = 0; q < 10; ++q) K[q] = 0.0;
-    const double k53 = -h[10] / h[6], k10 = -gk[5] / h[5], k11 = -gk[6] / h[6];
     K[5 + 3] = k53; K[10] = k10; K[11] = k11;
-    for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) P[i][q] = 0.0; P[i][i] = h[i]; pv[i] = gk[i]; }
-    P[0][1] = P[1][0] = h[7]; P[0][2] = P[2][0] = h[8]; P[1][2] = P[2][1] = h[9];
-    P[3][3] += h[10] * k53; pv[3] += h[10] * k11;
+  }
+  // dynamics data (s, d: needed first) of the stage being processed are loaded one stage ahead; its cost data (h, g: needed
+  // later in the stage) at the top of the stage, where their latency hides behind the first hundred multiply-adds
+  double sc[15], dc[5];
+  if (N >= 2) {
+    const int k = N - 2;
+    const wsp_f64 *s = m + o_ab + k * 15, *d = m + o_d + k * 5;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) sc[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dc[i] = d[i];
   }
   for (int k = N - 2; k >= 0; --k) {
-    const wsp_f64 *s = m + o_ab + k * 15, *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP, *dk = m + o_d + k * 5;
-    const double s00 = s[0], s01 = s[1], s02 = s[2], s03 = s[3], s04 = s[4];
-    const double s10 = s[5], s11 = s[6], s12 = s[7], s13 = s[8], s14 = s[9];
-    const double s21 = s[11], s22 = s[12], s23 = s[13], s24 = s[14];
-    const double d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3], d4 = dk[4];
-    double M[5][5], PB[5][2], Pd[5];
+    double hc_[11], gc[7];
+    {
+      const wsp_f64 *h = m + o_hc + k * 11, *g = m + o_gk + k * kNP;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      M[i][0] = P[i][0]; M[i][1] = P[i][1];
-      M[i][2] = P[i][2] + s00 * P[i][0] + s10 * P[i][1];
-      M[i][3] = P[i][3] + s01 * P[i][0] + s11 * P[i][1] + s21 * P[i][2];
-      M[i][4] = P[i][4] + s02 * P[i][0] + s12 * P[i][1] + s22 * P[i][2];
-      PB[i][0] = s03 * P[i][0] + s13 * P[i][1] + s23 * P[i][2] + dt * P[i][3];
-      PB[i][1] = s04 * P[i][0] + s14 * P[i][1] + s24 * P[i][2] + dt * P[i][4];
-      Pd[i] = pv[i] + P[i][0] * d0 + P[i][1] * d1 + P[i][2] * d2 + P[i][3] * d3 + P[i][4] * d4;
-    }
-    double Hxx[5][5], hx[5];
+      for (int i = 0; i < 11; ++i) hc_[i] = h[i];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      Hxx[0][j] = M[0][j]; Hxx[1][j] = M[1][j];
-      Hxx[2][j] = M[2][j] + s00 * M[0][j] + s10 * M[1][j];
-      Hxx[3][j] = M[3][j] + s01 * M[0][j] + s11 * M[1][j] + s21 * M[2][j];
-      Hxx[4][j] = M[4][j] + s02 * M[0][j] + s12 * M[1][j] + s22 * M[2][j];
+      for (int i = 0; i < 7; ++i) gc[i] = g[i];
     }
-    const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7], h8 = h[8], h9 = h[9], h10 = h[10];
-    Hxx[0][0] += h0; Hxx[1][1] += h1; Hxx[2][2] += h2; Hxx[3][3] += h3; Hxx[4][4] += h4;
-    Hxx[0][1] += h7; Hxx[1][0] += h7; Hxx[0][2] += h8; Hxx[2][0] += h8; Hxx[1][2] += h9; Hxx[2][1] += h9;
-    hx[0] = gk[0] + Pd[0]; hx[1] = gk[1] + Pd[1];
-    hx[2] = gk[2] + Pd[2] + s00 * Pd[0] + s10 * Pd[1];
-    hx[3] = gk[3] + Pd[3] + s01 * Pd[0] + s11 * Pd[1] + s21 * Pd[2];
-    hx[4] = gk[4] + Pd[4] + s02 * Pd[0] + s12 * Pd[1] + s22 * Pd[2];
-    double Hux[2][5], hu[2];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      Hux[0][j] = s03 * M[0][j] + s13 * M[1][j] + s23 * M[2][j] + dt * M[3][j];
-      Hux[1][j] = s04 * M[0][j] + s14 * M[1][j] + s24 * M[2][j] + dt * M[4][j];
-    }
-    Hux[1][3] += h10;
-    const double a00 = h5 + s03 * PB[0][0] + s13 * PB[1][0] + s23 * PB[2][0] + dt * PB[3][0];
-    const double a01 = s03 * PB[0][1] + s13 * PB[1][1] + s23 * PB[2][1] + dt * PB[3][1];
-    const double a11 = h6 + s04 * PB[0][1] + s14 * PB[1][1] + s24 * PB[2][1] + dt * PB[4][1];
-    hu[0] = gk[5] + s03 * Pd[0] + s13 * Pd[1] + s23 * Pd[2] + dt * Pd[3];
-    hu[1] = gk[6] + s04 * Pd[0] + s14 * Pd[1] + s24 * Pd[2] + dt * Pd[4];
+    const double s00 = sc[0], s01 = sc[1], s02 = sc[2], s03 = sc[3], s04 = sc[4];
+    const double s10 = sc[5], s11 = sc[6], s12 = sc[7], s13 = sc[8], s14 = sc[9];
+    const double s21 = sc[11], s22 = sc[12], s23 = sc[13], s24 = sc[14];
+    // W = B'P (2 x 5); rows of B': (s03 s13 s23 dt 0), (s04 s14 s24 0 dt)
+    const double W00 = s03 * P00 + s13 * P01 + s23 * P02 + dt * P03;
+    const double W01 = s03 * P01 + s13 * P11 + s23 * P12 + dt * P13;
+    const double W02 = s03 * P02 + s13 * P12 + s23 * P22 + dt * P23;
+    const double W03 = s03 * P03 + s13 * P13 + s23 * P23 + dt * P33;
+    const double W04 = s03 * P04 + s13 * P14 + s23 * P24 + dt * P34;
+    const double W10 = s04 * P00 + s14 * P01 + s24 * P02 + dt * P04;
+    const double W11 = s04 * P01 + s14 * P11 + s24 * P12 + dt * P14;
+    const double W12 = s04 * P02 + s14 * P12 + s24 * P22 + dt * P24;
+    const double W13 = s04 * P03 + s14 * P13 + s24 * P23 + dt * P34;
+    const double W14 = s04 * P04 + s14 * P14 + s24 * P24 + dt * P44;
+    // Hux = W A (+ the v-w cross term of the stage cost)
+    const double X00 = W00, X01 = W01, X02 = W02 + s00 * W00 + s10 * W01;
+    const double X03 = W03 + s01 * W00 + s11 * W01 + s21 * W02, X04 = W04 + s02 * W00 + s12 * W01 + s22 * W02;
+    const double X10 = W10, X11 = W11, X12 = W12 + s00 * W10 + s10 * W11;
+    const double X13 = W13 + s01 * W10 + s11 * W11 + s21 * W12 + hc_[10], X14 = W14 + s02 * W10 + s12 * W11 + s22 * W12;
+    // Huu = R + W B
+    const double a00 = hc_[5] + s03 * W00 + s13 * W01 + s23 * W02 + dt * W03;
+    const double a01 = s04 * W00 + s14 * W01 + s24 * W02 + dt * W04;
+    const double a11 = hc_[6] + s04 * W10 + s14 * W11 + s24 * W12 + dt * W14;
+    // Pd = p + P d
+    const double d0 = dc[0], d1 = dc[1], d2 = dc[2], d3 = dc[3], d4 = dc[4];
+    const double e0 = p0 + P00 * d0 + P01 * d1 + P02 * d2 + P03 * d3 + P04 * d4;
+    const double e1 = p1 + P01 * d0 + P11 * d1 + P12 * d2 + P13 * d3 + P14 * d4;
+    const double e2 = p2 + P02 * d0 + P12 * d1 + P22 * d2 + P23 * d3 + P24 * d4;
+    const double e3 = p3 + P03 * d0 + P13 * d1 + P23 * d2 + P33 * d3 + P34 * d4;
+    const double e4 = p4 + P04 * d0 + P14 * d1 + P24 * d2 + P34 * d3 + P44 * d4;
+    const double hu0 = gc[5] + s03 * e0 + s13 * e1 + s23 * e2 + dt * e3;
+    const double hu1 = gc[6] + s04 * e0 + s14 * e1 + s24 * e2 + dt * e4;
+    const double hx0 = gc[0] + e0, hx1 = gc[1] + e1;
+    const double hx2 = gc[2] + e2 + s00 * e0 + s10 * e1;
+    const double hx3 = gc[3] + e3 + s01 * e0 + s11 * e1 + s21 * e2;
+    const double hx4 = gc[4] + e4 + s02 * e0 + s12 * e1 + s22 * e2;
+    // M = P A: columns 0, 1 are P's; columns 2..4 of every row
+    const double M02 = P02 + s00 * P00 + s10 * P01, M03 = P03 + s01 * P00 + s11 * P01 + s21 * P02, M04 = P04 + s02 * P00 + s12 * P01 + s22 * P02;
+    const double M12 = P12 + s00 * P01 + s10 * P11, M13 = P13 + s01 * P01 + s11 * P11 + s21 * P12, M14 = P14 + s02 * P01 + s12 * P11 + s22 * P12;
+    const double M22 = P22 + s00 * P02 + s10 * P12, M23 = P23 + s01 * P02 + s11 * P12 + s21 * P22, M24 = P24 + s02 * P02 + s12 * P12 + s22 * P22;
+    const double M33 = P33 + s01 * P03 + s11 * P13 + s21 * P23, M34 = P34 + s02 * P03 + s12 * P13 + s22 * P23;
+    const double M43 = P34 + s01 * P04 + s11 * P14 + s21 * P24, M44 = P44 + s02 * P04 + s12 * P14 + s22 * P24;
+    // Hxx = Q + A'M, upper triangle
+    const double H00 = P00 + hc_[0], H01 = P01 + hc_[7], H02 = M02 + hc_[8], H03 = M03, H04 = M04;
+    const double H11 = P11 + hc_[1], H12 = M12 + hc_[9], H13 = M13, H14 = M14;
+    const double H22 = M22 + s00 * M02 + s10 * M12 + hc_[2], H23 = M23 + s00 * M03 + s10 * M13, H24 = M24 + s00 * M04 + s10 * M14;
+    const double H33 = M33 + s01 * M03 + s11 * M13 + s21 * M23 + hc_[3], H34 = M34 + s01 * M04 + s11 * M14 + s21 * M24;
+    const double H44 = M44 + s02 * M04 + s12 * M14 + s22 * M24 + hc_[4];
+    (void)M43;
     const double idet = 1.0 / (a00 * a11 - a01 * a01);
     const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
-    double t0[6], t1[6];  // Huu^{-1} [Hux hu]
+    // t = Huu^-1 [Hux hu]
+    const double t00 = i00 * X00 + i01 * X10, t01 = i00 * X01 + i01 * X11, t02 = i00 * X02 + i01 * X12, t03 = i00 * X03 + i01 * X13,
+                 t04 = i00 * X04 + i01 * X14, t05 = i00 * hu0 + i01 * hu1;
+    const double t10 = i01 * X00 + i11 * X10, t11 = i01 * X01 + i11 * X11, t12 = i01 * X02 + i11 * X12, t13 = i01 * X03 + i11 * X13,
+                 t14 = i01 * X04 + i11 * X14, t15 = i01 * hu0 + i11 * hu1;
+    // new value function (registers), then the loads of the next stage, then this stage's gains: in that order, see above
+    const double N00 = H00 - (X00 * t00 + X10 * t10), N01 = H01 - (X00 * t01 + X10 * t11), N02 = H02 - (X00 * t02 + X10 * t12);
+    const double N03 = H03 - (X00 * t03 + X10 * t13), N04 = H04 - (X00 * t04 + X10 * t14);
+    const double N11 = H11 - (X01 * t01 + X11 * t11), N12 = H12 - (X01 * t02 + X11 * t12), N13 = H13 - (X01 * t03 + X11 * t13);
+    const double N14 = H14 - (X01 * t04 + X11 * t14);
+    const double N22 = H22 - (X02 * t02 + X12 * t12), N23 = H23 - (X02 * t03 + X12 * t13), N24 = H24 - (X02 * t04 + X12 * t14);
+    const double N33 = H33 - (X03 * t03 + X13 * t13), N34 = H34 - (X03 * t04 + X13 * t14);
+    const double N44 = H44 - (X04 * t04 + X14 * t14);
+    p0 = hx0 - (X00 * t05 + X10 * t15); p1 = hx1 - (X01 * t05 + X11 * t15); p2 = hx2 - (X02 * t05 + X12 * t15);
+    p3 = hx3 - (X03 * t05 + X13 * t15); p4 = hx4 - (X04 * t05 + X14 * t15);
+    P00 = N00; P01 = N01; P02 = N02; P03 = N03; P04 = N04; P11 = N11; P12 = N12; P13 = N13; P14 = N14;
+    P22 = N22; P23 = N23; P24 = N24; P33 = N33; P34 = N34; P44 = N44;
+    {
+      const int kn = k > 0 ? k - 1 : 0;  // the last pass re-reads stage 0 (harmless) so that the loop body has no branch here
+      const wsp_f64 *s = m + o_ab + kn * 15, *d = m + o_d + kn * 5;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { t0[q] = i00 * Hux[0][q] + i01 * Hux[1][q]; t1[q] = i01 * Hux[0][q] + i11 * Hux[1][q]; }
-    t0[5] = i00 * hu[0] + i01 * hu[1]; t1[5] = i01 * hu[0] + i11 * hu[1];
-    wsp_f64 *K = m + o_kk + k * 12;
+      for (int i = 0; i < 15; ++i) sc[i] = s[i];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { K[q] = -t0[q]; K[5 + q] = -t1[q]; }
-    K[10] = -t0[5]; K[11] = -t1[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-      for (int q = i; q < 5; ++q) {
-        const double v = 0.5 * (Hxx[i][q] + Hxx[q][i]) - (Hux[0][i] * t0[q] + Hux[1][i] * t1[q]);
-        P[i][q] = v; P[q][i] = v;
-      }
-      pv[i] = hx[i] - (Hux[0][i] * t0[5] + Hux[1][i] * t1[5]);
+      for (int i = 0; i < 5; ++i) dc[i] = d[i];
     }
+    wsp_f64 *K = m + o_kk + k * 12;
+    K[0] = -t00; K[1] = -t01; K[2] = -t02; K[3] = -t03; K[4] = -t04;
+    K[5] = -t10; K[6] = -t11; K[7] = -t12; K[8] = -t13; K[9] = -t14;
+    K[10] = -t05; K[11] = -t15;
   }
   wsp_f64 *rP = m + o_rP;
-  for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) rP[i * 5 + q] = P[i][q]; rP[25 + i] = pv[i]; }
+  rP[0] = P00; rP[1] = P01; rP[2] = P02; rP[3] = P03; rP[4] = P04;
+  rP[5] = P01; rP[6] = P11; rP[7] = P12; rP[8] = P13; rP[9] = P14;
+  rP[10] = P02; rP[11] = P12; rP[12] = P22; rP[13] = P23; rP[14] = P24;
+  rP[15] = P03; rP[16] = P13; rP[17] = P23; rP[18] = P33; rP[19] = P34;
+  rP[20] = P04; rP[21] = P14; rP[22] = P24; rP[23] = P34; rP[24] = P44;
+  rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
 }
 
 // forward sweep: dp (all stages) and the step of the initial-state multiplier from the value function at stage 0
@@ -734,27 +788,56 @@ CFZ_SWEEP riccati_forward(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o
   wsp_f64 *dp = m + o_dp;
   double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
          z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
-  dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
+  double dl[5];
+#pragma unroll
   for (int i = 0; i < 5; ++i) {
     const double s_ = pv[i] + rP[i * 5 + 0] * z0 + rP[i * 5 + 1] * z1 + rP[i * 5 + 2] * z2 + rP[i * 5 + 3] * z3 + rP[i * 5 + 4] * z4;
-    m[o_dpi0 + i] = -s_ - m[o_pi0 + i];
+    dl[i] = -s_ - m[o_pi0 + i];
   }
-#pragma unroll 5
-  for (int k = 0; k < N; ++k) {  // unrolled so that the gain/dynamics loads of later stages are in flight early
-    const wsp_f64 *K = m + o_kk + k * 12;
-    const double u0 = K[10] + K[0] * z0 + K[1] * z1 + K[2] * z2 + K[3] * z3 + K[4] * z4;
-    const double u1 = K[11] + K[5] * z0 + K[6] * z1 + K[7] * z2 + K[8] * z3 + K[9] * z4;
+  double Kc[12], sc[15], dc[5];
+  {
+    const wsp_f64 *K = m + o_kk, *s = m + o_ab, *d = m + o_d;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Kc[i] = K[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) sc[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dc[i] = d[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) m[o_dpi0 + i] = dl[i];
+  dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
+  for (int k = 0; k < N; ++k) {
+    double Kn[12], sn[15], dn[5];
+    {
+      const int kn = k + 1 < N ? k + 1 : k;  // the dynamics of the last stage are never used (its slots hold whatever)
+      const wsp_f64 *K = m + o_kk + kn * 12, *s = m + o_ab + kn * 15, *d = m + o_d + kn * 5;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Kn[i] = K[i];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) sn[i] = s[i];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) dn[i] = d[i];
+    }
+    // two partial sums per input so that the dependent chain behind z is short
+    const double u0 = (Kc[10] + Kc[0] * z0 + Kc[1] * z1) + (Kc[2] * z2 + Kc[3] * z3 + Kc[4] * z4);
+    const double u1 = (Kc[11] + Kc[5] * z0 + Kc[6] * z1) + (Kc[7] * z2 + Kc[8] * z3 + Kc[9] * z4);
     dp[k * kNP + 5] = u0; dp[k * kNP + 6] = u1;
     if (k + 1 < N) {
-      const wsp_f64 *s = m + o_ab + k * 15, *dk = m + o_d + k * 5;
-      const double n0 = dk[0] + z0 + s[0] * z2 + s[1] * z3 + s[2] * z4 + s[3] * u0 + s[4] * u1;
-      const double n1 = dk[1] + z1 + s[5] * z2 + s[6] * z3 + s[7] * z4 + s[8] * u0 + s[9] * u1;
-      const double n2 = dk[2] + z2 + s[11] * z3 + s[12] * z4 + s[13] * u0 + s[14] * u1;
-      const double n3 = dk[3] + z3 + dt * u0, n4 = dk[4] + z4 + dt * u1;
+      const double n0 = (dc[0] + z0 + sc[0] * z2 + sc[1] * z3 + sc[2] * z4) + (sc[3] * u0 + sc[4] * u1);
+      const double n1 = (dc[1] + z1 + sc[5] * z2 + sc[6] * z3 + sc[7] * z4) + (sc[8] * u0 + sc[9] * u1);
+      const double n2 = (dc[2] + z2 + sc[11] * z3 + sc[12] * z4) + (sc[13] * u0 + sc[14] * u1);
+      const double n3 = dc[3] + z3 + dt * u0, n4 = dc[4] + z4 + dt * u1;
       z0 = n0; z1 = n1; z2 = n2; z3 = n3; z4 = n4;
       wsp_f64 *zn = dp + (k + 1) * kNP;
       zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Kc[i] = Kn[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) sc[i] = sn[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dc[i] = dn[i];
   }
 }
 
@@ -762,21 +845,38 @@ CFZ_SWEEP riccati_forward(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o
 // it into d(pi_{k-1}) = pi_new - pi
 CFZ_SWEEP costate_sweep(wsp_f64 *m, int N, int o_ab, int o_dpi, int o_pi) {
   CFZ_SWEEP_GUARD
+  if (N < 2) return;
   double l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
-#pragma unroll 5
+  double qc[5], pc[5], sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // s00 s01 s02 s10 s11 s12 s21 s22 of stage k
+  {
+    const int k = N - 1;
+    const wsp_f64 *q = m + o_dpi + (k - 1) * 5, *pi = m + o_pi + (k - 1) * 5;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { qc[i] = q[i]; pc[i] = pi[i]; }
+  }
   for (int k = N - 1; k >= 1; --k) {
-    wsp_f64 *q = m + o_dpi + (k - 1) * 5;
-    const wsp_f64 *pi = m + o_pi + (k - 1) * 5;
-    double n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3], n4 = q[4];
+    double qn[5], pn[5], sn[8];
+    {
+      const int kn = k > 1 ? k - 1 : 1;
+      const wsp_f64 *q = m + o_dpi + (kn - 1) * 5, *pi = m + o_pi + (kn - 1) * 5, *s = m + o_ab + kn * 15;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { qn[i] = q[i]; pn[i] = pi[i]; }
+      sn[0] = s[0]; sn[1] = s[1]; sn[2] = s[2]; sn[3] = s[5]; sn[4] = s[6]; sn[5] = s[7]; sn[6] = s[11]; sn[7] = s[12];
+    }
+    double n0 = qc[0], n1 = qc[1], n2 = qc[2], n3 = qc[3], n4 = qc[4];
     if (k + 1 < N) {
-      const wsp_f64 *s = m + o_ab + k * 15;
       n0 += l0; n1 += l1;
-      n2 += l2 + s[0] * l0 + s[5] * l1;
-      n3 += l3 + s[1] * l0 + s[6] * l1 + s[11] * l2;
-      n4 += l4 + s[2] * l0 + s[7] * l1 + s[12] * l2;
+      n2 += l2 + sc[0] * l0 + sc[3] * l1;
+      n3 += l3 + sc[1] * l0 + sc[4] * l1 + sc[6] * l2;
+      n4 += l4 + sc[2] * l0 + sc[5] * l1 + sc[7] * l2;
     }
     l0 = n0; l1 = n1; l2 = n2; l3 = n3; l4 = n4;
-    q[0] = n0 - pi[0]; q[1] = n1 - pi[1]; q[2] = n2 - pi[2]; q[3] = n3 - pi[3]; q[4] = n4 - pi[4];
+    wsp_f64 *q = m + o_dpi + (k - 1) * 5;
+    q[0] = n0 - pc[0]; q[1] = n1 - pc[1]; q[2] = n2 - pc[2]; q[3] = n3 - pc[3]; q[4] = n4 - pc[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { qc[i] = qn[i]; pc[i] = pn[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sc[i] = sn[i];
   }
 }
 
@@ -1167,6 +1267,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
     CFZ_SERIAL(riccati_forward(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
+    CFZ_STAMP(9);  // Riccati forward sweep
     // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows).  The stage-local
     // part (H dp + g)_z is formed by the stage's quad into the slot of d(pi_{k-1}); only the 5-vector recursion through
     // A_k' stays on lane 0.
@@ -1183,7 +1284,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       }
     CFZ_END
     CFZ_SERIAL(costate_sweep(CFZ_WSP(m), N, L.ab, L.dpi, L.pi));
-    CFZ_STAMP(5);  // Riccati forward + costates
+    CFZ_STAMP(5);  // costates
     // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
     // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
     // per bound and reused (a DP division is ~12 dependent instructions on this pipe).

@@ -19,7 +19,7 @@ table, _ = scenarios.load_reference_table()
 k0, noise = scenarios.sample_scenarios(S, table, seed=2024)
 eng = engine.Engine(spec, max_batch=S * 4)
 eng.loop_init(table, k0, noise)
-names = ["wall(10ns)", "dynamics", "residuals", "barrier", "assembly", "ric_fwd+co", "step", "linesearch", "update", "ws+rows", "output", "ric_bwd"]
+names = ["wall(10ns)", "rows+dyn", "residuals", "barrier", "assembly", "costates", "step", "linesearch", "update", "ric_fwd", "output", "ric_bwd"]
 for t in range(K):
     eng.loop_step()
 B = S * 4
