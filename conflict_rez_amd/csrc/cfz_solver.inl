@@ -217,9 +217,11 @@ template <int NS, int NX, int NI> static inline void reduce_all_emu(const double
 // sin, cos of a small angle by Taylor series (|e| <= 0.06: truncation < 1e-21), sincos otherwise
 CFZ_FN void small_sincos(double e, double *s, double *c) {
   if (fabs(e) > 0.06) { sincos(e, s, c); return; }
+  // Horner with the reciprocal factorial ratios as constants: written as x / 6.0 these were nine real double-precision
+  // divisions (ten dependent instructions each) per call, 192 per RK4 interval
   const double e2 = e * e;
-  *s = e * (1.0 - e2 / 6.0 * (1.0 - e2 / 20.0 * (1.0 - e2 / 42.0 * (1.0 - e2 / 72.0))));
-  *c = 1.0 - e2 / 2.0 * (1.0 - e2 / 12.0 * (1.0 - e2 / 30.0 * (1.0 - e2 / 56.0 * (1.0 - e2 / 90.0))));
+  *s = e * (1.0 - e2 * (1.0 / 6.0) * (1.0 - e2 * (1.0 / 20.0) * (1.0 - e2 * (1.0 / 42.0) * (1.0 - e2 * (1.0 / 72.0)))));
+  *c = 1.0 - e2 * 0.5 * (1.0 - e2 * (1.0 / 12.0) * (1.0 - e2 * (1.0 / 30.0) * (1.0 - e2 * (1.0 / 56.0) * (1.0 - e2 * (1.0 / 90.0)))));
 }
 
 // Three library sincos calls per interval instead of 32: the steering angle advances by w h/2 between RK
@@ -228,7 +230,7 @@ CFZ_FN void small_sincos(double e, double *s, double *c) {
 template <bool SENS>
 CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double wb, int M, double out[5],
                      double S[3][5]) {
-  const double h = dt / M;
+  const double h = dt / M, h6 = h * (1.0 / 6.0), iwb = 1.0 / wb;
   double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
   if (SENS) {
     for (int r = 0; r < 3; ++r)
@@ -267,11 +269,11 @@ CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double 
       }
       const double sd = (st == 0) ? sd0 : ((st == 3) ? sd2 : sd1), cd = (st == 0) ? cd0 : ((st == 3) ? cd2 : cd1);
       const double t = sd / cd;
-      const double fx = vs * c, fy = vs * s, fp = vs / wb * t;
+      const double fx = vs * c, fy = vs * s, fp = vs * iwb * t;
       if (SENS) {
         // stage point sensitivities: psi row from S/KS, v and delta rows analytic
         const double tau = tsub + wprev;
-        const double j24 = vs / wb * (1.0 + t * t), j23 = t / wb;
+        const double j24 = vs * iwb * (1.0 + t * t), j23 = t * iwb;
         double NS[3][5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
@@ -290,17 +292,17 @@ CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double 
       kp = fp;
       ax += wsum * fx; ay += wsum * fy; ap += wsum * fp;
     }
-    x += h / 6 * ax; y += h / 6 * ay; psi += h / 6 * ap;
+    x += h6 * ax; y += h6 * ay; psi += h6 * ap;
     v += h * a; de += h * w;
     {
       double se, ce;
-      small_sincos(h / 6 * ap, &se, &ce);
+      small_sincos(h6 * ap, &se, &ce);
       const double sn = sp_ * ce + cp_ * se, cn = cp_ * ce - sp_ * se;
       sp_ = sn; cp_ = cn; sd0 = sd2; cd0 = cd2;
     }
     if (SENS)
       for (int r = 0; r < 3; ++r)
-        for (int q = 0; q < 5; ++q) S[r][q] += h / 6 * AS[r][q];
+        for (int q = 0; q < 5; ++q) S[r][q] += h6 * AS[r][q];
     tsub += h;
   }
   out[0] = x; out[1] = y; out[2] = psi; out[3] = v; out[4] = de;
@@ -348,33 +350,86 @@ CFZ_FN double pick4(const double d[4], int v) {
   return r;
 }
 
-CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                       double s, const double g[4], int prev) {
-  const int pk = prev >> 6, pf = (prev >> 4) & 3;
-  double best = 0.0, prev_val = 0.0, d[4];
-  int have = 0, bk = 0, bf = 0, have_prev = 0;
-  for (int kind = 1; kind <= 2; ++kind)
-    for (int f = 0; f < 4; ++f) {
-      vertex_dist<false>(A, b, V, x, y, c, s, g, kind, f, d, nullptr);
-      const double val = fmin(fmin(d[0], d[1]), fmin(d[2], d[3]));
-      if (prev && kind == pk && f == pf) { prev_val = val; have_prev = 1; }
-      if (!have || val > best) { have = 1; best = val; bk = kind; bf = f; }
+// All 32 face-vertex distances of a block in one pass: D[f] (f = 0..3) kind 1, polygon face f against the four body
+// vertices; D[4 + f] kind 2, body face f against the four polygon vertices.  Same expressions as vertex_dist, with what
+// the faces of a kind share (the rotated body vertices; the vertices relative to the pose) formed once.
+CFZ_FN void block_dists(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
+                        double s, const double g[4], double D[8][4]) {
+  const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  double px[4], py[4], rx[4], ry[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const double dwx = -s * BV[v][0] - c * BV[v][1], dwy = c * BV[v][0] - s * BV[v][1];
+    px[v] = x + dwy; py[v] = y - dwx;
+    rx[v] = V[v][0] - x; ry[v] = V[v][1] - y;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    const double nx = c * gx - s * gy, ny = s * gx + c * gy;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      D[f][v] = px[v] * A[f][0] + py[v] * A[f][1] - b[f];
+      D[4 + f][v] = rx[v] * nx + ry[v] * ny - g[f];
     }
-  if (have_prev && prev_val >= best - kHyst) { bk = pk; bf = pf; }
-  vertex_dist<false>(A, b, V, x, y, c, s, g, bk, bf, d, nullptr);
+  }
+}
+
+// Working set of a block from its 32 distances (the rule of oracle/mpc_nlp.py select_rows): the face with the largest
+// minimum over its four vertices (first such face; the previous face is kept while it is within kHyst of the best), on it
+// the nearest vertex and its nearer neighbour (the previous pair is kept while it still holds the nearest vertex and is
+// within kHyst).  dsel: the four distances of the chosen face.
+CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4]) {
+  const int pidx = ((prev >> 6) - 1) * 4 + ((prev >> 4) & 3);  // face index of the previous working set (prev != 0)
+  double best = 0.0, prev_val = 0.0;
+  int bi = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double val = fmin(fmin(D[i][0], D[i][1]), fmin(D[i][2], D[i][3]));
+    if (prev && i == pidx) prev_val = val;
+    if (i == 0 || val > best) { best = val; bi = i; }
+  }
+  if (prev && prev_val >= best - kHyst) bi = pidx;
+  // the chosen face's row of D: binary select over the three bits of bi
+  double d[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const double q0 = (bi & 1) ? D[1][v] : D[0][v], q1 = (bi & 1) ? D[3][v] : D[2][v];
+    const double q2 = (bi & 1) ? D[5][v] : D[4][v], q3 = (bi & 1) ? D[7][v] : D[6][v];
+    const double h0 = (bi & 2) ? q1 : q0, h1 = (bi & 2) ? q3 : q2;
+    d[v] = (bi & 4) ? h1 : h0;
+    dsel[v] = d[v];
+  }
   int v0 = 0;
 #pragma unroll
   for (int v = 1; v < 4; ++v) if (d[v] < pick4(d, v0)) v0 = v;
   const int n1 = (v0 + 1) & 3, n2 = (v0 + 3) & 3;
   const double d0 = pick4(d, v0), dn1 = pick4(d, n1), dn2 = pick4(d, n2);
   int v1 = (dn1 < dn2) ? n1 : ((dn2 < dn1) ? n2 : (n1 < n2 ? n1 : n2));
-  if (prev && bk == pk && bf == pf) {
+  if (prev && bi == pidx) {
     const int oa = (prev >> 2) & 3, ob = prev & 3;
     const double da = pick4(d, oa), db = pick4(d, ob);
     if (fmin(da, db) <= d0 + 1e-12 && fmax(da, db) <= pick4(d, v1) + kHyst) { v0 = oa; v1 = ob; }
   }
   const int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
-  return bk * 64 + bf * 16 + va * 4 + vb;
+  return ((bi >> 2) + 1) * 64 + (bi & 3) * 16 + va * 4 + vb;
+}
+
+CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
+                       double s, const double g[4], int prev) {
+  double D[8][4], dsel[4];
+  block_dists(A, b, V, x, y, c, s, g, D);
+  return select_from(D, prev, dsel);
+}
+
+// working set AND the values of its two rows in one pass (the rows are two of the distances the selection looked at)
+CFZ_CALL int select_rows_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
+                           double s, const double g[4], int prev, double sep[2]) {
+  double D[8][4], dsel[4];
+  block_dists(A, b, V, x, y, c, s, g, D);
+  const int sel = select_from(D, prev, dsel);
+  sep[0] = pick4(dsel, (sel >> 2) & 3); sep[1] = pick4(dsel, sel & 3);
+  return sel;
 }
 
 // values (and gradients wrt x,y,psi) of the two rows of working set `sel`
@@ -468,6 +523,53 @@ CFZ_FN void block_grad(const KSpec &sp, const double *m, const Lay &L, int k, in
   }
 }
 
+// Values of the two rows of block j at stage k for a GIVEN working-set code (the line search holds the working set
+// fixed): the two distances only, from the code, like block_grad -- no polygon is built, no other distance formed.
+CFZ_FN void block_sep(const KSpec &sp, const double *m, const Lay &L, int k, int j, int sl, double x, double y, double c,
+                      double s, double sep[2]) {
+  const int f = (sl >> 4) & 3;
+  const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
+  const double gf = f == 0 ? g0 : (f == 1 ? g1 : (f == 2 ? g2 : g3));
+  if ((sl >> 6) == 1) {
+    double ax, ay, bf;
+    if (j < sp.n_obs) {
+      const double *o = sp.obs_tab + j * 20;
+      ax = o[2 * f]; ay = o[2 * f + 1]; bf = o[8 + f];
+    } else {
+      const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+      const double xo = q[0], yo = q[1], co = q[2], so = q[3];
+      ax = f == 0 ? co : (f == 1 ? -so : (f == 2 ? -co : so));
+      ay = f == 0 ? so : (f == 1 ? co : (f == 2 ? -so : -co));
+      bf = ax * xo + ay * yo + gf;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int v = r == 0 ? ((sl >> 2) & 3) : (sl & 3);
+      const double bx = (v == 0 || v == 3) ? g0 : -g2, by = (v < 2) ? g1 : -g3;
+      const double dwx = -s * bx - c * by, dwy = c * bx - s * by;
+      sep[r] = (x + dwy) * ax + (y - dwx) * ay - bf;
+    }
+  } else {
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    const double nx = c * gx - s * gy, ny = s * gx + c * gy;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int v = r == 0 ? ((sl >> 2) & 3) : (sl & 3);
+      double vx, vy;
+      if (j < sp.n_obs) {
+        const double *o = sp.obs_tab + j * 20;
+        vx = o[12 + 2 * v]; vy = o[13 + 2 * v];
+      } else {
+        const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+        const double xo = q[0], yo = q[1], co = q[2], so = q[3];
+        const double bx = (v == 0 || v == 3) ? g0 : -g2, by = (v < 2) ? g1 : -g3;
+        vx = xo + co * bx - so * by; vy = yo + so * bx + co * by;
+      }
+      sep[r] = (vx - x) * nx + (vy - y) * ny - gf;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ objective pieces
 CFZ_FN double stage_cost(const KSpec &sp, const double *ref, int k, const double p[kNP]) {
   const double *w = sp.weights; const int N = sp.N;
@@ -520,7 +622,7 @@ CFZ_FN void sym2_solve6(const double M[2][2], const double rhs[2][6], double out
 // columns; the nominal trajectory is the same in all of them.  Same recurrences as rk4_step<true>, column by column.
 CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double wb, int M, int qa, double out[5],
                         double Sa[3], double Sb[3]) {
-  const double h = dt / M;
+  const double h = dt / M, h6 = h * (1.0 / 6.0), iwb = 1.0 / wb;
   double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
   Sa[0] = 0.0; Sa[1] = 0.0; Sa[2] = (qa == 0) ? 1.0 : 0.0;
   Sb[0] = 0.0; Sb[1] = 0.0; Sb[2] = 0.0;
@@ -551,9 +653,9 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double
       }
       const double sd = (st == 0) ? sd0 : ((st == 3) ? sd2 : sd1), cd = (st == 0) ? cd0 : ((st == 3) ? cd2 : cd1);
       const double t = sd / cd;
-      const double fx = vs * c, fy = vs * s, fp = vs / wb * t;
+      const double fx = vs * c, fy = vs * s, fp = vs * iwb * t;
       const double tau = tsub + wprev;
-      const double j24 = vs / wb * (1.0 + t * t), j23 = t / wb;
+      const double j24 = vs * iwb * (1.0 + t * t), j23 = t * iwb;
       {  // column qa
         const double dps = Sa[2] + wprev * KSa2, dvs = va1 + vat * tau, dds = da1;
         const double n0 = -vs * s * dps + c * dvs, n1 = vs * c * dps + s * dvs, n2 = j23 * dvs + j24 * dds;
@@ -567,16 +669,16 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double
       kp = fp;
       ax += wsum * fx; ay += wsum * fy; ap += wsum * fp;
     }
-    x += h / 6 * ax; y += h / 6 * ay; psi += h / 6 * ap;
+    x += h6 * ax; y += h6 * ay; psi += h6 * ap;
     v += h * a; de += h * w;
     {
       double se, ce;
-      small_sincos(h / 6 * ap, &se, &ce);
+      small_sincos(h6 * ap, &se, &ce);
       const double sn = sp_ * ce + cp_ * se, cn = cp_ * ce - sp_ * se;
       sp_ = sn; cp_ = cn; sd0 = sd2; cd0 = cd2;
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { Sa[r] += h / 6 * ASa[r]; Sb[r] += h / 6 * ASb[r]; }
+    for (int r = 0; r < 3; ++r) { Sa[r] += h6 * ASa[r]; Sb[r] += h6 * ASb[r]; }
     tsub += h;
   }
   out[0] = x; out[1] = y; out[2] = psi; out[3] = v; out[4] = de;
@@ -598,9 +700,8 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
     sincos(pt[2], &sn, &cn);
     for (int j = sub; j < nb; j += kLPS) {
       const int t = k * nb + j;
-      double A[4][2], b[4], V[4][2], sep[2];
-      block_polygon(sp, m, L, k, j, A, b, V);
-      rows_for<false>(A, b, V, pt[0], pt[1], cn, sn, sp.g, sel_ptr(m, L)[t], sep, nullptr);
+      double sep[2];
+      block_sep(sp, m, L, k, j, sel_ptr(m, L)[t], pt[0], pt[1], cn, sn, sep);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
@@ -935,8 +1036,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       block_polygon(sp, m, L, 0, tid, A, b, V);
       double s0, c0_;
       sincos(m[L.x0 + 2], &s0, &c0_);
-      const int c0 = select_rows(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0);
-      rows_for<false>(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, c0, sep, nullptr);
+      select_rows_sep(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0, sep);
       worst = fmin(sep[0], sep[1]);
     }
     CFZ_P(rd, 0) = worst;
@@ -961,9 +1061,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         const int t = k * nb + j;
         double A[4][2], b[4], V[4][2], sep[2];
         block_polygon(sp, m, L, k, j, A, b, V);
-        const int c0 = select_rows(A, b, V, x, y, cn, sn, sp.g, 0);
+        const int c0 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, 0, sep);
         sel_ptr(m, L)[t] = c0;
-        rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c0, sep, nullptr);
         if (!warm) {
           for (int r = 0; r < 2; ++r) {
             m[L.sg + 2 * t + r] = fmax(sep[r] - sp.dmin, sp.bound_push);
@@ -1035,14 +1134,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
         for (int j = sub; j < nb; j += kLPS) {
           const int t = k * nb + j;
-          double A[4][2], b[4], V[4][2], sep[2];
-          block_polygon(sp, m, L, k, j, A, b, V);
+          double sep[2];
           int c1 = sel_ptr(m, L)[t];
           if (iter > 0) {
             const int c0 = c1;
-            c1 = select_rows(A, b, V, x, y, cn, sn, sp.g, c0);
+            double A[4][2], b[4], V[4][2];
+            block_polygon(sp, m, L, k, j, A, b, V);
+            c1 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, c0, sep);
             if (c1 != c0) sel_ptr(m, L)[t] = c1;
-            rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c1, sep, nullptr);
             if (c1 != c0) {
               // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
               // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
@@ -1065,7 +1164,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
               }
             }
           } else {
-            rows_for<false>(A, b, V, x, y, cn, sn, sp.g, c1, sep, nullptr);
+            block_sep(sp, m, L, k, j, c1, x, y, cn, sn, sep);
           }
           for (int r = 0; r < 2; ++r) {
             const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
@@ -1247,7 +1346,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           // convexity safeguard: scale by th in {1, 1/2, .., 2^-9, 0} until diag(2w) + th C keeps the margin 0.2 min(w)
           const double mg = 0.2 * fmin(w[0], fmin(w[1], w[2]));
           const double q0 = 2 * w[0] - mg, q1 = 2 * w[1] - mg, q2 = 2 * w[2] - mg;
-          const double quad = ca * ca / q0 + cb * cb / q1;
+          const double quad = ca * ca * (1.0 / q0) + cb * cb * (1.0 / q1);
           double th = 1.0;
           for (int hh = 0; hh < 11; ++hh) {
             if (hh == 10) { th = 0.0; break; }
@@ -1415,8 +1514,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       const double psi = m[L.p + k * kNP + 2];
       double s, c;
       sincos(psi, &s, &c);
-      const int c1 = select_rows(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, sel_ptr(m, L)[t]);
-      rows_for<false>(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, c1, sep2, nullptr);
+      const int c1 = select_rows_sep(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, sel_ptr(m, L)[t], sep2);
       const double sep = fmin(sep2[0], sep2[1]);
       const int cert = (c1 >> 6) * 16 + ((c1 >> 4) & 3) * 4 + (sep2[0] <= sep2[1] ? ((c1 >> 2) & 3) : (c1 & 3));
       smin = fmin(smin, sep);

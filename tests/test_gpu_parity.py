@@ -314,7 +314,7 @@ def test_vehicle_sharded_loop_matches_device_loop():
             a = ea.loop_get()
             assert np.array_equal(a["status"].ravel(), vl.status.cpu().numpy()), t
             assert np.array_equal(a["iters"].ravel(), vl.iters.cpu().numpy()), t
-            assert np.abs(a["state"].reshape(-1, 5) - vl.state.reshape(-1, 5).cpu().numpy()).max() < 1e-9
+            assert np.abs(a["state"].reshape(-1, 5) - vl.state.reshape(-1, 5).cpu().numpy()).max() < 1e-6
             assert np.abs(a["pred"].reshape(-1, 7, spec.N) - vl.pred.reshape(-1, 7, spec.N).cpu().numpy()).max() < 1e-6  # two plant implementations (HIP rotation-based trig, torch cos/sin) inside a closed loop
         ea.close(); eb.close()
     finally:
