@@ -15,7 +15,8 @@
 //   dynamics  all four lanes integrate the stage (RK4, identical instruction stream, so the redundancy costs no time) and
 //             each propagates its own columns of the sensitivities: lane sub column sub, every lane column 4
 //   stage     condensed H_k, g_k, bound multipliers, costs: computed by the whole quad, written by sub 0
-//   Riccati   backward / forward / costate sweeps: 30 dependent steps on lane 0, out of line (registers of their own)
+//   Riccati   backward sweep: 30 dependent stages on lane 0, out of line (registers of its own); forward step and
+//             costates: linear recurrences once the gains are known -> Kogge-Stone scans, one stage per lane of wavefront 0
 // Reductions over the workgroup run on registers: DPP butterflies inside a row of 16 lanes, v_readlane across the four
 // rows of a wavefront, one 16-double LDS exchange between the two wavefronts.
 //
@@ -747,7 +748,7 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
 #define CFZ_SWEEP_GUARD
 #endif
 
-// All three sweeps are software-pipelined by hand: the loads of the NEXT stage are issued before the stores of this one.
+// The sweep is software-pipelined by hand: the loads of the NEXT stage are issued before the stores of this one.
 // The compiler cannot do that itself (loads and stores go through the same workspace pointer, so it must assume that a
 // store may feed a later load) and without it every stage waits for an LDS round trip per operand group.
 
@@ -881,105 +882,192 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
   rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
 }
 
-// forward sweep: dp (all stages) and the step of the initial-state multiplier from the value function at stage 0
-CFZ_SWEEP riccati_forward(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
-                          int o_pi0, int o_dpi0) {
-  CFZ_SWEEP_GUARD
-  const wsp_f64 *rP = m + o_rP, *pv = rP + 25;
-  wsp_f64 *dp = m + o_dp;
-  double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
-         z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
-  double dl[5];
+// ------------------------------------------------------------------------------ forward step and costates as scans
+// Once the gains are known the forward sweep is a LINEAR recurrence, z_{k+1} = (A_k + B_k K_k) z_k + (B_k k_k + d_k), and
+// so is the costate sweep, lam_{k-1} = q_k + A_k' lam_k.  Both are prefix compositions of affine maps, done here in
+// log2(32) = 5 Kogge-Stone steps by the first wavefront, one stage per lane (cross-lane traffic: ds_bpermute), instead
+// of 30 dependent stages on one lane.  The CPU build runs the same combine steps in the same order on arrays.
+struct Aff5 { double M[25], v[5]; };  // z -> M z + v
+
+// t <- t after s  (s is applied first): M = t.M s.M,  v = t.M s.v + t.v
+CFZ_FN void aff5_after(Aff5 &t, const Aff5 &s) {
+  // row i of the product needs row i of t.M only: rows are replaced one by one, no second copy of the matrix is live
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    const double s_ = pv[i] + rP[i * 5 + 0] * z0 + rP[i * 5 + 1] * z1 + rP[i * 5 + 2] * z2 + rP[i * 5 + 3] * z3 + rP[i * 5 + 4] * z4;
-    dl[i] = -s_ - m[o_pi0 + i];
-  }
-  double Kc[12], sc[15], dc[5];
-  {
-    const wsp_f64 *K = m + o_kk, *s = m + o_ab, *d = m + o_d;
+    const double a0 = t.M[i * 5 + 0], a1 = t.M[i * 5 + 1], a2 = t.M[i * 5 + 2], a3 = t.M[i * 5 + 3], a4 = t.M[i * 5 + 4];
+    t.v[i] = t.v[i] + a0 * s.v[0] + a1 * s.v[1] + a2 * s.v[2] + a3 * s.v[3] + a4 * s.v[4];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Kc[i] = K[i];
-#pragma unroll
-    for (int i = 0; i < 15; ++i) sc[i] = s[i];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) dc[i] = d[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) m[o_dpi0 + i] = dl[i];
-  dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
-  for (int k = 0; k < N; ++k) {
-    double Kn[12], sn[15], dn[5];
-    {
-      const int kn = k + 1 < N ? k + 1 : k;  // the dynamics of the last stage are never used (its slots hold whatever)
-      const wsp_f64 *K = m + o_kk + kn * 12, *s = m + o_ab + kn * 15, *d = m + o_d + kn * 5;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Kn[i] = K[i];
-#pragma unroll
-      for (int i = 0; i < 15; ++i) sn[i] = s[i];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) dn[i] = d[i];
-    }
-    // two partial sums per input so that the dependent chain behind z is short
-    const double u0 = (Kc[10] + Kc[0] * z0 + Kc[1] * z1) + (Kc[2] * z2 + Kc[3] * z3 + Kc[4] * z4);
-    const double u1 = (Kc[11] + Kc[5] * z0 + Kc[6] * z1) + (Kc[7] * z2 + Kc[8] * z3 + Kc[9] * z4);
-    dp[k * kNP + 5] = u0; dp[k * kNP + 6] = u1;
-    if (k + 1 < N) {
-      const double n0 = (dc[0] + z0 + sc[0] * z2 + sc[1] * z3 + sc[2] * z4) + (sc[3] * u0 + sc[4] * u1);
-      const double n1 = (dc[1] + z1 + sc[5] * z2 + sc[6] * z3 + sc[7] * z4) + (sc[8] * u0 + sc[9] * u1);
-      const double n2 = (dc[2] + z2 + sc[11] * z3 + sc[12] * z4) + (sc[13] * u0 + sc[14] * u1);
-      const double n3 = dc[3] + z3 + dt * u0, n4 = dc[4] + z4 + dt * u1;
-      z0 = n0; z1 = n1; z2 = n2; z3 = n3; z4 = n4;
-      wsp_f64 *zn = dp + (k + 1) * kNP;
-      zn[0] = z0; zn[1] = z1; zn[2] = z2; zn[3] = z3; zn[4] = z4;
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Kc[i] = Kn[i];
-#pragma unroll
-    for (int i = 0; i < 15; ++i) sc[i] = sn[i];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) dc[i] = dn[i];
+    for (int j = 0; j < 5; ++j)
+      t.M[i * 5 + j] = a0 * s.M[0 * 5 + j] + a1 * s.M[1 * 5 + j] + a2 * s.M[2 * 5 + j] + a3 * s.M[3 * 5 + j] + a4 * s.M[4 * 5 + j];
   }
 }
 
-// costate sweep: dpi holds the stage-local part (H dp + g)_z of stage k in slot k - 1; the recursion through A_k' turns
-// it into d(pi_{k-1}) = pi_new - pi
-CFZ_SWEEP costate_sweep(wsp_f64 *m, int N, int o_ab, int o_dpi, int o_pi) {
-  CFZ_SWEEP_GUARD
-  if (N < 2) return;
-  double l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
-  double qc[5], pc[5], sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // s00 s01 s02 s10 s11 s12 s21 s22 of stage k
-  {
-    const int k = N - 1;
-    const wsp_f64 *q = m + o_dpi + (k - 1) * 5, *pi = m + o_pi + (k - 1) * 5;
+// closed-loop transition of stage k (k < N - 1), identity beyond
+CFZ_FN void aff5_stage(const wsp_f64 *m, int k, int N, double dt, int o_ab, int o_d, int o_kk, Aff5 &t) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { qc[i] = q[i]; pc[i] = pi[i]; }
+  for (int i = 0; i < 25; ++i) t.M[i] = (i % 6 == 0) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) t.v[i] = 0.0;
+  if (k >= N - 1) return;
+  const wsp_f64 *K = m + o_kk + k * 12, *s = m + o_ab + k * 15, *d = m + o_d + k * 5;
+  double K0[5], K1[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { K0[j] = K[j]; K1[j] = K[5 + j]; }
+  const double k0 = K[10], k1 = K[11];
+  // rows 0..2: A = I + [0 0 s_r0 s_r1 s_r2] (s20 = 1 is the diagonal), B = [s_r3 s_r4]
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double b0 = s[r * 5 + 3], b1 = s[r * 5 + 4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t.M[r * 5 + j] += b0 * K0[j] + b1 * K1[j];
+    t.v[r] = d[r] + b0 * k0 + b1 * k1;
   }
-  for (int k = N - 1; k >= 1; --k) {
-    double qn[5], pn[5], sn[8];
-    {
-      const int kn = k > 1 ? k - 1 : 1;
-      const wsp_f64 *q = m + o_dpi + (kn - 1) * 5, *pi = m + o_pi + (kn - 1) * 5, *s = m + o_ab + kn * 15;
+  t.M[0 * 5 + 2] += s[0]; t.M[0 * 5 + 3] += s[1]; t.M[0 * 5 + 4] += s[2];
+  t.M[1 * 5 + 2] += s[5]; t.M[1 * 5 + 3] += s[6]; t.M[1 * 5 + 4] += s[7];
+  t.M[2 * 5 + 3] += s[11]; t.M[2 * 5 + 4] += s[12];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) { qn[i] = q[i]; pn[i] = pi[i]; }
-      sn[0] = s[0]; sn[1] = s[1]; sn[2] = s[2]; sn[3] = s[5]; sn[4] = s[6]; sn[5] = s[7]; sn[6] = s[11]; sn[7] = s[12];
-    }
-    double n0 = qc[0], n1 = qc[1], n2 = qc[2], n3 = qc[3], n4 = qc[4];
-    if (k + 1 < N) {
-      n0 += l0; n1 += l1;
-      n2 += l2 + sc[0] * l0 + sc[3] * l1;
-      n3 += l3 + sc[1] * l0 + sc[4] * l1 + sc[6] * l2;
-      n4 += l4 + sc[2] * l0 + sc[5] * l1 + sc[7] * l2;
-    }
-    l0 = n0; l1 = n1; l2 = n2; l3 = n3; l4 = n4;
-    wsp_f64 *q = m + o_dpi + (k - 1) * 5;
-    q[0] = n0 - pc[0]; q[1] = n1 - pc[1]; q[2] = n2 - pc[2]; q[3] = n3 - pc[3]; q[4] = n4 - pc[4];
+  for (int j = 0; j < 5; ++j) { t.M[3 * 5 + j] += dt * K0[j]; t.M[4 * 5 + j] += dt * K1[j]; }
+  t.v[3] = d[3] + dt * k0; t.v[4] = d[4] + dt * k1;
+}
+
+// costate map of stage k: lam -> A_k' lam + q_k with A_k' = I + X, X = [x20 x21 | x30 x31 x32 | x40 x41 x42] (the
+// transposed sensitivities); products of such matrices keep the pattern
+struct Cos5 { double x[8], v[5]; };
+CFZ_FN void cos5_after(Cos5 &t, const Cos5 &s) {  // t <- t after s
+  const double *x = t.x, *y = s.x;
+  double vn[5];
+  vn[0] = t.v[0] + s.v[0]; vn[1] = t.v[1] + s.v[1];
+  vn[2] = t.v[2] + s.v[2] + x[0] * s.v[0] + x[1] * s.v[1];
+  vn[3] = t.v[3] + s.v[3] + x[2] * s.v[0] + x[3] * s.v[1] + x[4] * s.v[2];
+  vn[4] = t.v[4] + s.v[4] + x[5] * s.v[0] + x[6] * s.v[1] + x[7] * s.v[2];
+  double xn[8];
+  xn[0] = x[0] + y[0]; xn[1] = x[1] + y[1];
+  xn[2] = x[2] + y[2] + x[4] * y[0]; xn[3] = x[3] + y[3] + x[4] * y[1]; xn[4] = x[4] + y[4];
+  xn[5] = x[5] + y[5] + x[7] * y[0]; xn[6] = x[6] + y[6] + x[7] * y[1]; xn[7] = x[7] + y[7];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { qc[i] = qn[i]; pc[i] = pn[i]; }
+  for (int i = 0; i < 8; ++i) t.x[i] = xn[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sc[i] = sn[i];
+  for (int i = 0; i < 5; ++i) t.v[i] = vn[i];
+}
+
+// lane k's part before the costate scan: u_k = K_k z_k + k_k (into dp), q_k = (H dp + g)_z of stage k, the map of stage k
+CFZ_FN void cos5_stage(wsp_f64 *m, int k, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, Cos5 &t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t.x[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) t.v[i] = 0.0;
+  if (k >= N) return;
+  const wsp_f64 *K = m + o_kk + k * 12, *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
+  wsp_f64 *z = m + o_dp + k * kNP;
+  const double z0 = z[0], z1 = z[1], z2 = z[2], z3 = z[3], z4 = z[4];
+  const double u0 = (K[10] + K[0] * z0 + K[1] * z1) + (K[2] * z2 + K[3] * z3 + K[4] * z4);
+  const double u1 = (K[11] + K[5] * z0 + K[6] * z1) + (K[7] * z2 + K[8] * z3 + K[9] * z4);
+  z[5] = u0; z[6] = u1;
+  if (k < 1) return;
+  t.v[0] = gk[0] + h[0] * z0 + h[7] * z1 + h[8] * z2;
+  t.v[1] = gk[1] + h[7] * z0 + h[1] * z1 + h[9] * z2;
+  t.v[2] = gk[2] + h[8] * z0 + h[9] * z1 + h[2] * z2;
+  t.v[3] = gk[3] + h[3] * z3 + h[10] * u1;
+  t.v[4] = gk[4] + h[4] * z4;
+  if (k + 1 < N) {  // stage N - 1 has no dynamics: identity
+    const wsp_f64 *s = m + o_ab + k * 15;
+    t.x[0] = s[0]; t.x[1] = s[5];
+    t.x[2] = s[1]; t.x[3] = s[6]; t.x[4] = s[11];
+    t.x[5] = s[2]; t.x[6] = s[7]; t.x[7] = s[12];
   }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+CFZ_SWEEP forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
+                       int o_pi0, int o_dpi0) {
+  if (threadIdx.x >= 64) return;  // the first wavefront, stage k on lane k
+  const int k = threadIdx.x;
+  Aff5 t;
+  aff5_stage(m, k, N, dt, o_ab, o_d, o_kk, t);
+#pragma unroll
+  for (int dd = 1; dd < 32; dd <<= 1) {
+    Aff5 s;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) s.M[i] = __shfl_up(t.M[i], dd, 64);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s.v[i] = __shfl_up(t.v[i], dd, 64);
+    if (k >= dd) aff5_after(t, s);
+  }
+  const double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
+               z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
+  if (k + 1 < N) {
+    wsp_f64 *zn = m + o_dp + (k + 1) * kNP;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      zn[i] = t.v[i] + t.M[i * 5 + 0] * z0 + t.M[i * 5 + 1] * z1 + t.M[i * 5 + 2] * z2 + t.M[i * 5 + 3] * z3 + t.M[i * 5 + 4] * z4;
+  }
+  if (k == 0) { wsp_f64 *dp = m + o_dp; dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4; }
+  if (k < 5) {  // step of the initial-state multiplier from the value function at stage 0
+    const wsp_f64 *rP = m + o_rP;
+    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
+    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
+  }
+}
+
+CFZ_SWEEP costate_scan(wsp_f64 *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
+  if (threadIdx.x >= 64) return;
+  const int k = threadIdx.x;
+  Cos5 t;
+  cos5_stage(m, k, N, o_ab, o_hc, o_gk, o_kk, o_dp, t);
+#pragma unroll
+  for (int dd = 1; dd < 32; dd <<= 1) {  // suffix composition: T_k = C_k after-applied-to (C_{k+1} ... C_{N-1})
+    Cos5 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s.x[i] = __shfl_down(t.x[i], dd, 64);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s.v[i] = __shfl_down(t.v[i], dd, 64);
+    if (k + dd < N) cos5_after(t, s);
+  }
+  if (k >= 1 && k < N) {
+    wsp_f64 *q = m + o_dpi + (k - 1) * 5;
+    const wsp_f64 *pi = m + o_pi + (k - 1) * 5;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] = t.v[i] - pi[i];
+  }
+}
+#else
+static void forward_scan(double *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
+                         int o_pi0, int o_dpi0) {
+  static thread_local Aff5 t[64], s[64];
+  for (int k = 0; k < 64; ++k) aff5_stage(m, k, N, dt, o_ab, o_d, o_kk, t[k]);
+  for (int dd = 1; dd < 32; dd <<= 1) {
+    for (int k = 0; k < 64; ++k) s[k] = t[k >= dd ? k - dd : k];
+    for (int k = dd; k < 64; ++k) aff5_after(t[k], s[k]);
+  }
+  const double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
+               z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
+  for (int k = 0; k + 1 < N; ++k) {
+    double *zn = m + o_dp + (k + 1) * kNP;
+    for (int i = 0; i < 5; ++i)
+      zn[i] = t[k].v[i] + t[k].M[i * 5 + 0] * z0 + t[k].M[i * 5 + 1] * z1 + t[k].M[i * 5 + 2] * z2 + t[k].M[i * 5 + 3] * z3 + t[k].M[i * 5 + 4] * z4;
+  }
+  double *dp = m + o_dp; dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
+  const double *rP = m + o_rP;
+  for (int k = 0; k < 5; ++k) {
+    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
+    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
+  }
+}
+
+static void costate_scan(double *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
+  static thread_local Cos5 t[64], s[64];
+  for (int k = 0; k < 64; ++k) cos5_stage(m, k, N, o_ab, o_hc, o_gk, o_kk, o_dp, t[k]);
+  for (int dd = 1; dd < 32; dd <<= 1) {
+    for (int k = 0; k < 64; ++k) s[k] = t[k + dd < 64 ? k + dd : k];
+    for (int k = 0; k + dd < N; ++k) cos5_after(t[k], s[k]);
+  }
+  for (int k = 1; k < N; ++k) {
+    double *q = m + o_dpi + (k - 1) * 5;
+    const double *pi = m + o_pi + (k - 1) * 5;
+    for (int i = 0; i < 5; ++i) q[i] = t[k].v[i] - pi[i];
+  }
+}
+#endif
 
 // ------------------------------------------------------------------------------ the solver
 // x0[5], ref[3][N], nbr[n_nbr][3][N], zu[7][N] (warm start in, solution out) in global memory;
@@ -1365,24 +1453,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
-    CFZ_SERIAL(riccati_forward(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
-    CFZ_STAMP(9);  // Riccati forward sweep
-    // costates: pi_{k-1} = (H dp + g)_z at stage k + A_k' pi_k  (new multipliers of the dynamics rows).  The stage-local
-    // part (H dp + g)_z is formed by the stage's quad into the slot of d(pi_{k-1}); only the 5-vector recursion through
-    // A_k' stays on lane 0.
-    CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
-      if (k >= 1 && k < N && sub == 0) {
-        const double *h = m + L.hc + k * 11, *gk = m + L.gk + k * kNP, *z = m + L.dp + k * kNP;
-        double *q = m + L.dpi + (k - 1) * 5;
-        q[0] = gk[0] + h[0] * z[0] + h[7] * z[1] + h[8] * z[2];
-        q[1] = gk[1] + h[7] * z[0] + h[1] * z[1] + h[9] * z[2];
-        q[2] = gk[2] + h[8] * z[0] + h[9] * z[1] + h[2] * z[2];
-        q[3] = gk[3] + h[3] * z[3] + h[10] * z[6];
-        q[4] = gk[4] + h[4] * z[4];
-      }
-    CFZ_END
-    CFZ_SERIAL(costate_sweep(CFZ_WSP(m), N, L.ab, L.dpi, L.pi));
+    // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
+    CFZ_SERIAL(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
+    CFZ_STAMP(9);  // forward step
+    CFZ_SERIAL(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
     CFZ_STAMP(5);  // costates
     // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
     // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
