@@ -11,8 +11,9 @@ region.  N GPUs = N independent shards of scenarios (weak scaling, no data-path 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, `roofline`
-(algorithmic HBM bytes of SURVEY.md 8d / measured solver-kernel time) and `cpu_baseline`
-(oracle/cfz_port.c, the plain-C port, timed on this host; N=1 only).
+(algorithmic HBM bytes of SURVEY.md 8d / measured solver-kernel time, plus the FP64 and VALU-active fractions),
+`value_converged` (status-0 solves only), `cold_step` (the first MPC iteration, cold multipliers) and `cpu_baseline`
+(oracle/cfz_port.c, the plain-C port, running the SAME closed loop on this host's cores; N=1 only).
 """
 import argparse
 import json
@@ -29,65 +30,88 @@ ALG_BYTES_PER_SOLVE = 8 * (365 + 2 * 2550)  # parameters + warm 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def _cpu_worker(args):
-    """One process of the all-core CPU baseline: solves its slice with the oracle's C port (its buffers are static,
-    hence processes, not threads)."""
-    lo, hi, seconds = args
+FLOP_PER_IPM_ITERATION = 0.75e6  # ~25 kflop per stage and iteration x 30 stages (blocks, RK4 + sensitivities, Riccati)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+
+
+def _cpu_closed_loop_worker(args):
+    """One process of the CPU baseline: the SAME closed loop the GPU runs (`warmup` + `steps` MPC iterations, multipliers
+    carried from one iteration to the next) for `n_scen` scenarios of the same sampler, through the oracle's plain-C port
+    (oracle/closed_loop.py).  Returns solves, IPM iterations and converged solves of the timed iterations, and their time."""
+    seed, n_scen, warmup, steps = args
     from conflict_rez_amd import scenarios
-    from oracle import port
+    from oracle.closed_loop import replay
     from oracle.mpc_nlp import MpcSpec
 
     spec = scenarios.parking_lot_spec()
     table, _ = scenarios.load_reference_table()
     ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
-    k0, noise = scenarios.sample_scenarios(4096 // (spec.n_nbr + 1), table, seed=2024)
-    x0, ref, nbr, zu = scenarios.mpc_batch_from_table(spec, table, k0, noise)
-    port.solve(ospec, x0[0], ref[0], nbr[0], zu[0].T)  # load + warm
-    n, its, t0 = 0, 0, time.perf_counter()
-    for b in range(lo, hi):
-        if time.perf_counter() - t0 > seconds:
-            break
-        its += port.solve(ospec, x0[b], ref[b], nbr[b], zu[b].T)["iters"]
-        n += 1
-    return n, its, time.perf_counter() - t0
+    k0, noise = scenarios.sample_scenarios(n_scen, table, seed=seed)
+    n = its = ok = 0
+    cold = None
+    t0 = time.perf_counter()
+    for t, (_, _, status, iters) in enumerate(replay(ospec, table, k0, noise, warmup + steps, dt=spec.dt, wb=spec.wb)):
+        if t == 0:
+            cold = (status.size, int(iters.sum()), time.perf_counter() - t0)
+        if t == warmup - 1:
+            t0 = time.perf_counter()
+        if t >= warmup:
+            n += status.size; its += int(iters.sum()); ok += int((status == 0).sum())
+    return n, its, ok, time.perf_counter() - t0, cold
 
 
-def cpu_baseline(spec, table, seconds=12.0, max_solves=4096):
-    """Same workload (cold first step of the same scenario sampler) through the oracle's C port: one core, then one
-    process per host core (at most 64) over the same 4096 instances.  Bounded: every leg stops after `seconds`."""
+def casadi_probe():
+    """the reference's own CPU path is CasADi + IPOPT.  Report what importing it on THIS host does."""
+    try:
+        import casadi  # noqa: F401
+
+        return f"casadi {casadi.__version__} importable on this host (the reference NLP is not timed here: no recorded strategy file)"
+    except Exception as e:  # noqa: BLE001
+        return f"CasADi unavailable on this host: {type(e).__name__}: {e}"
+
+
+def cpu_baseline(warmup, steps, n_scen_per_core=8, max_cores=16):
+    """`cpu_baseline` of the bench line: the oracle's C port ("kind": "port") on the host cores, like for like with the
+    GPU's timed region -- the closed loop after `warmup` iterations, carried multipliers -- on a bounded sample of the same
+    scenario sampler (8 scenarios x 4 vehicles per process; about 10-30 s).  One process per usable core (the job's CPU
+    quota is usually far below the logical core count: the affinity mask says what is usable), at most `max_cores`."""
     import concurrent.futures as cf
     import multiprocessing as mp
 
-    n1, its1, dt1 = _cpu_worker((0, max_solves, seconds / 2))
-    single = {"value": n1 / dt1, "unit": "solves/s", "cores": 1, "kind": "port",
-              "sample": f"{n1} cold first-step solves of the same scenario sampler in {dt1:.1f} s, single thread "
-                        f"({os.cpu_count()} host cores present), mean {its1 / max(n1, 1):.1f} IPM iterations"}
-    # The box reports 256 logical cores but the job may own fewer (cgroup quota): try 8, 16, 32, 64 processes over the
-    # same 4096 instances, a few seconds each, and report the best.
-    best = None
-    try:  # spawn: this process already holds a GPU context; a worker that dies breaks the pool instead of hanging it
-        for cores in [c for c in (8, 16, 32, 64) if c <= (os.cpu_count() or 1)] or [1]:
-            per = (max_solves + cores - 1) // cores
-            jobs = [(i * per, min((i + 1) * per, max_solves), seconds / 4) for i in range(cores) if i * per < max_solves]
-            with cf.ProcessPoolExecutor(len(jobs), mp_context=mp.get_context("spawn")) as pool:
-                res = list(pool.map(_cpu_worker, jobs, timeout=seconds + 120))
-            rate = sum(r[0] for r in res) / max(r[2] for r in res)  # slowest worker; start-up (imports) not counted
-            if best is None or rate > best[0]:
-                best = (rate, len(jobs), per, res)
-    except Exception as e:  # noqa: BLE001 - the baseline is reporting only; fall back to the single-core figure
-        single["note"] = f"all-core leg failed ({type(e).__name__}); single core only"
-        return single
-    _, ncores, per, res = best
-    jobs = [None] * ncores
-    wall = max(r[2] for r in res)  # slowest worker; process start-up (imports) is not counted
-    n = sum(r[0] for r in res)
-    return {"value": n / wall, "unit": "solves/s", "cores": len(jobs), "kind": "port",
-            "single_core": n1 / dt1,
-            "sample": f"{n} cold first-step solves of the same scenario sampler, {len(jobs)} processes x "
-                      f"{per} instances, slowest worker {wall:.1f} s (mean {sum(r[1] for r in res) / max(n, 1):.1f} IPM "
-                      f"iterations); single core: {n1} solves in {dt1:.1f} s; {os.cpu_count()} host cores present",
-            "note": "CasADi/IPOPT (the reference's CPU path) is not installable here; its implied range is "
-                    "10-90 ms per solve = 11-100 solves/s per core (BASELINE.md, unpublished)"}
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    cores = max(1, min(max_cores, usable))
+    jobs = [(2024 + 1000 * i, n_scen_per_core, warmup, steps) for i in range(cores)]
+    t_wall = time.perf_counter()
+    try:
+        with cf.ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:  # spawn: this process holds a GPU context
+            res = list(pool.map(_cpu_closed_loop_worker, jobs, timeout=600))
+    except Exception as e:  # noqa: BLE001 - reporting only
+        res = [_cpu_closed_loop_worker(jobs[0])]
+        cores = 1
+        note = f"process pool failed ({type(e).__name__}); one process"
+    else:
+        note = None
+    t_wall = time.perf_counter() - t_wall
+    n = sum(r[0] for r in res); its = sum(r[1] for r in res); ok = sum(r[2] for r in res)
+    slow = max(r[3] for r in res)  # the slowest worker sets the rate (start-up and imports are not counted)
+    cn = sum(r[4][0] for r in res); ci = sum(r[4][1] for r in res); ct = max(r[4][2] for r in res)
+    out = {"value": n / slow, "unit": "solves/s", "cores": cores, "kind": "port",
+           "value_converged": ok / slow, "mean_ipm_iters": its / max(n, 1), "ipm_iterations_per_s": its / slow,
+           "per_core": n / slow / cores,
+           "sample": f"closed loop, {cores} processes x {n_scen_per_core} scenarios x 4 vehicles, {warmup} warm-up + {steps} timed MPC "
+                     f"iterations with carried multipliers = {n} timed solves, slowest worker {slow:.1f} s (wall incl. start-up {t_wall:.0f} s); "
+                     f"{os.cpu_count()} logical cores on the host, {usable} usable by this job",
+           "cold_step": {"value": cn / ct, "unit": "solves/s", "mean_ipm_iters": ci / max(cn, 1),
+                         "sample": f"first MPC iteration of the same scenarios (cold multipliers), {cn} solves"},
+           "casadi": casadi_probe(),
+           "note": "the reference's CasADi/IPOPT/MA97 path cannot travel to this host (not installable: no network); its implied range "
+                   "is 10-90 ms per solve = 11-100 solves/s per core (BASELINE.md, unpublished, read off plot limits)"}
+    if note:
+        out["note"] = note + "; " + out["note"]
+    return out
 
 
 def profiled_traffic(kernel):
@@ -112,6 +136,29 @@ def profiled_traffic(kernel):
     return (tot or None), os.path.basename(tag)
 
 
+def profiled_sq(kernel):
+    """VALU-active fraction of `kernel` from the committed SQ pass of this same command (profiles/*_pmc_SQ.csv):
+    SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD executes a vector instruction, summed over SIMDs) x 4 /
+    (GRBM_GUI_ACTIVE (cycles, summed over the 8 XCDs) / 8 x 1024 SIMDs), timed (last) dispatch.  (None, None) if absent."""
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    tags = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_SQ.csv")))
+    if not tags:
+        return None, None
+    vals = {}
+    try:
+        for line in open(tags[-1]):
+            f = line.rstrip("\n").split(",")
+            if f[0] == kernel:
+                vals[f[1]] = float(f[4].split()[-1])
+        raw = vals["SQ_ACTIVE_INST_VALU"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    except (OSError, ValueError, IndexError, KeyError, ZeroDivisionError):
+        return None, None
+    # MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles, so busy cycles = 4 x the counter; `raw` is the plain quotient
+    return {"frac": 4.0 * raw, "raw_quotient": raw}, os.path.basename(tags[-1])[: -len("_pmc_SQ.csv")]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +179,9 @@ def main():
                          "vehicles of all scenarios and all-gathers the predictions over RCCL every iteration (the reference's ROS "
                          "deployment; needs torch.distributed, --gpus dividing 4, one launch per iteration)")
     ap.add_argument("--count-iters", action="store_true", help="step mode: also sum the IPM iterations (adds a read-back)")
+    ap.add_argument("--reference", choices=["package", "planned"], default="package",
+                    help="package: conflict_rez_amd/data/refs_4v.npz, the state_ws plans of the synthetic strategy; planned: build the "
+                         "table at start-up with the GPU planning chain (state_ws -> collocation plan, plan_single_path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +204,14 @@ def main():
     single = args.workload == "single"
     spec = scenarios.parking_lot_spec(n_obs=4 if single else args.n_obs, n_nbr=0 if single else 3)
     V = spec.n_nbr + 1
-    table, _ = scenarios.load_reference_table()
+    if args.reference == "planned":
+        table, _, plan_info = scenarios.planned_reference_table(device=local_rank)
+        ref_desc = ("built at start-up by the GPU planning chain (cfz_state_ws -> cfz_colloc, VehicleFollower.plan_single_path): "
+                    + ", ".join(f"{a} {i['t_end']:.1f} s" for a, i in plan_info.items()))
+    else:
+        table, _ = scenarios.load_reference_table()
+        ref_desc = ("conflict_rez_amd/data/refs_4v.npz: the four vehicles' Vehicle.state_ws plans of the synthetic strategy "
+                    "(tube-constrained warm-start trajectories, 18-30 s)")
     if single:
         table = table[rank % table.shape[0]][None].copy()  # every scenario follows one vehicle's plan, alone on the map
     S = args.scenarios
@@ -165,9 +222,12 @@ def main():
             raise SystemExit("--parallelism vehicle needs torch.distributed (torchrun, or CFZ_BENCH_FORCE_DIST=1) and the mpc4 workload")
         from conflict_rez_amd.distributed import VehicleShardedExchange, VehicleShardedLoop
 
-        S = args.scenarios * world  # all scenarios on every rank, a share of the vehicles each: same solves per GPU
-        k0, noise = scenarios.sample_scenarios(S, table, seed=2024)
+        # scenarios x world in total: every rank steps its vehicles (V / world of them, or one vehicle of a scenario shard when
+        # there are more ranks than vehicles) -> the same number of solves per GPU as in scenario sharding
+        S_total = args.scenarios * world
+        k0, noise = scenarios.sample_scenarios(S_total, table, seed=2024)
         ex = VehicleShardedExchange(V)
+        S = len(range(S_total)[ex.scenarios(S_total)])
         eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)
         vloop = VehicleShardedLoop(eng, ex, table, k0, noise, device=f"cuda:{local_rank}")
         args.mode = "step"
@@ -183,12 +243,19 @@ def main():
             torch.cuda.synchronize()
 
     persistent = args.mode == "persistent"
+    cold = None
     if vehicle_sharded:
         for _ in range(args.warmup):
-            vloop.step()
+            vloop.step(sync=True)
     elif persistent:
         if args.warmup > 0:
-            eng.loop_run(args.warmup)  # blocks until all scenarios have done `warmup` iterations
+            # the first iteration on its own: cold multipliers, nothing carried (report step 1 separately)
+            it1 = eng.loop_run(1)
+            cold = {"value": S * V / (eng.last_solve_ms() / 1e3), "unit": "solves/s", "mean_ipm_iters": it1 / (S * V),
+                    "kernel_ms": eng.last_solve_ms(), "converged": eng.loop_last_converged() / (S * V),
+                    "what": "first MPC iteration after loop_init on this GPU (cold multipliers), one launch, kernel time"}
+            if args.warmup > 1:
+                eng.loop_run(args.warmup - 1)  # blocks until all scenarios have done `warmup` iterations
     else:
         for _ in range(args.warmup):
             eng.loop_step()  # blocks until the step is complete on the device
@@ -196,15 +263,18 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = 0.0
     n_ok = 0
+    n_conv = None  # converged solves of the timed region (persistent mode counts them on the device)
     if vehicle_sharded:
         ipm_iterations = 0
         for _ in range(args.steps):
-            vloop.step()
+            vloop.step(sync=True)
             kernel_ms += vloop.solve_ms
+            ipm_iterations += int(vloop.iters.sum())
         launches = args.steps
     elif persistent:
         ipm_iterations = eng.loop_run(args.steps)  # K iterations of every scenario, one launch
         kernel_ms = eng.last_solve_ms()
+        n_conv = eng.loop_last_converged()
         launches = 1
     else:
         ipm_iterations = 0
@@ -231,9 +301,10 @@ def main():
         t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
-        c = torch.tensor([n_ok], device="cuda", dtype=torch.int64)
+        c = torch.tensor([n_ok, -1 if n_conv is None else n_conv], device="cuda", dtype=torch.int64)
         dist.all_reduce(c)
         n_ok = int(c[0])
+        n_conv = None if n_conv is None else int(c[1])
 
     if rank == 0:
         B = S * V_local  # solves per iteration on one GPU
@@ -242,11 +313,15 @@ def main():
         solves_per_launch = B * args.steps // launches
         achieved = solves_per_launch * ALG_BYTES_PER_SOLVE / kern_s / 1e9
         traffic, traffic_src = (None, None)
-        if persistent and not vehicle_sharded and args.steps == 20 and S == 1024:  # the committed PMC passes are of the default command
+        valu_frac, valu_src = (None, None)
+        if persistent and not vehicle_sharded and args.steps == 20 and S == 1024 and not single:  # the committed PMC passes are of the default command
             traffic, traffic_src = profiled_traffic("loop_kernel")
+            valu_frac, valu_src = profiled_sq("loop_kernel")
+        fp64_tflops = (ipm_iterations * FLOP_PER_IPM_ITERATION / (kernel_ms / 1e3) / 1e12) if ipm_iterations else None
         line = {
             "metric": "OBCA MPC-step solves/sec (4 vehicles, N=30)",
             "value": solves / elapsed,
+            "value_converged": (n_conv / elapsed) if n_conv is not None else None,
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -262,10 +337,14 @@ def main():
                                    ("BASELINE.json configs[2]: 4-vehicle distributed MPC (VehicleFollower.step), "
                                     "N=30, 6 obstacles, closed loop on device"), "scenarios_per_gpu": S,
                        "solves_per_step_per_gpu": B,
-                       "parallelism": (f"vehicle-sharded x{world}, all-gather of predictions per iteration" if vehicle_sharded
+                       "parallelism": (f"vehicle-sharded x{world} ({len(ex.owned)} vehicle(s) x 1/{ex.n_shards} of the scenarios per rank), "
+                                       f"RCCL all-gather of predictions inside groups of {ex.group_size} ranks per iteration" if vehicle_sharded
                                        else f"scenario-sharded x{world}"),
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
+                       "converged_timed_region": (n_conv / solves) if n_conv is not None else None,
+                       "reference_plan": ref_desc,
                        "ipm_iterations_rank0": ipm_iterations,
+                       "mean_ipm_iters_timed_region": (ipm_iterations / (B * args.steps)) if ipm_iterations else None,
                        "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
                        "lds_bytes_per_instance": eng.kernel_info()[0], "instances_per_cu": eng.kernel_info()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -273,11 +352,24 @@ def main():
                          "kernel": "loop_kernel" if persistent and not vehicle_sharded else "solve_kernel",
                          "kernel_ms_per_launch": kern_s * 1e3, "solves_per_launch": solves_per_launch,
                          "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                         "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                         "fp64_frac": (fp64_tflops / FP64_VECTOR_PEAK_TFLOPS) if fp64_tflops else None,
+                         "flop_per_ipm_iteration": FLOP_PER_IPM_ITERATION,
+                         "valu_active_frac": valu_frac["frac"] if valu_frac else None,
+                         "valu_active_raw_quotient": valu_frac["raw_quotient"] if valu_frac else None, "valu_active_source": valu_src,
                          "note": "latency/FP64-issue bound: the iterate lives in LDS, so algorithmic HBM bytes "
                                  "are ~1e-5 of peak by construction (SURVEY.md 8d); see DESIGN.md"},
         }
+        if cold is not None:
+            line["cold_step"] = cold
         if world == 1 and not args.no_cpu_baseline and not single:
-            line["cpu_baseline"] = cpu_baseline(spec, table)
+            line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps)
+            cb = line["cpu_baseline"]
+            if ipm_iterations:  # like for like: IPM iterations per second, GPU : all usable host cores : one core
+                line["gpu_vs_cpu"] = {"ipm_iterations_per_s_gpu": ipm_iterations * world / elapsed,
+                                      "ipm_iterations_per_s_cpu": cb["ipm_iterations_per_s"],
+                                      "ratio_same_cores": ipm_iterations * world / elapsed / cb["ipm_iterations_per_s"],
+                                      "ratio_per_core": ipm_iterations * world / elapsed / (cb["ipm_iterations_per_s"] / cb["cores"])}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

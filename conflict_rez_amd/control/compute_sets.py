@@ -95,3 +95,24 @@ def compute_obstacles(L: float = 2.5, vb: VehicleBody = None) -> List[Polytope]:
     """The six static boxes of the parking lot (rows of parked cars)."""
     hw = (vb or VehicleBody()).w / 2
     return [Polytope.from_box(x0 * L - hw, x1 * L + hw, y0 * L, y1 * L) for x0, x1, y0, y1 in _OBSTACLE_CELLS]
+
+
+# parked cars drawn by the visualiser: (slot index, randomly set back?) per lane; reference compute_sets.py:349-433
+_PARKED_LOWER = ((1, True), (2, True), (3, True), (4, True), (5, False), (7, False), (9, True), (10, True), (11, True), (12, True))
+_PARKED_UPPER = ((1, True), (2, True), (3, True), (4, True), (5, False), (7, False), (8, False), (10, True), (11, True), (12, True))
+
+
+def compute_static_vehicles(L: float = 2.5, vb: VehicleBody = None) -> List[Polytope]:
+    """The parked cars the reference's visualiser draws into the slots (cosmetics: no NLP sees them).  What matters to the
+    path: the reference builds them at import of `vehicle_follower` right after `np.random.seed(0)` and so consumes
+    FIFTEEN `np.random.sample()` draws (one per randomly set-back car, lower lane first, in slot order) before any
+    vehicle draws its first dual guesses (vehicle_follower.py:29-31, :401-402).  Same draws, same order."""
+    vb = vb or VehicleBody()
+    out = []
+    for lane, edge, sign in ((_PARKED_LOWER, 5.5 * L, -1.0), (_PARKED_UPPER, 8.5 * L, 1.0)):
+        for slot, randomised in lane:
+            near = edge + sign * (np.random.sample() * 0.7 * L if randomised else 0.0)  # the car's end at the lane side
+            far = near + sign * vb.l
+            xc = (slot + 0.5) * L
+            out.append(Polytope.from_box(xc - vb.w / 2, xc + vb.w / 2, min(near, far), max(near, far)))
+    return out

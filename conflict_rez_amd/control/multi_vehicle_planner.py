@@ -63,21 +63,20 @@ class MultiVehiclePlanner:
         duals are not needed by the kernel (the vehicle-vehicle duals are eliminated like the obstacle duals).  Fills
         `final_results[agent]` = the plan interpolated on the common time grid (:466-480), `final_dt`, `final_stats`;
         raises RuntimeError when the solver does not converge, as `opti.solve()` does."""
-        from ..engine import joint_colloc
+        from .joint_problem import JointOpti
 
         self.joint_dual_ws(K=K)
         print("Solving joint final problem with obca...")
-        dt0 = float(np.mean([self.single_results[agent].dt for agent in self.agents]))
-        probs = []
-        for agent in self.agents:
-            vehicle = self.vehicles[agent]
-            probs.append(vehicle.setup_single_final_problem(zu0=self.single_results[agent], init_offset=self.init_offsets[agent],
-                                                            final_heading=self.final_headings[agent], K=K, N_per_set=N_per_set,
-                                                            dmin=dmin, shrink_tube=shrink_tube))
+        dt0 = float(np.mean([self.single_results[agent].dt for agent in self.agents]))  # (:360)
+        opti = JointOpti()      # (:365)
+        dt = opti.variable()    # (:366)
+        opti.set_initial(dt, dt0)
+        for agent in self.agents:  # (:371-386) every vehicle adds its collocation problem, on the shared dt
+            self.vehicles[agent].setup_single_final_problem(zu0=self.single_results[agent], init_offset=self.init_offsets[agent],
+                                                            final_heading=self.final_headings[agent], opti=opti, dt=dt, K=K,
+                                                            N_per_set=N_per_set, dmin=dmin, shrink_tube=shrink_tube)
         index = {a: i for i, a in enumerate(self.agents)}
-        res = joint_colloc(probs[0]["spec"], [p["init_pose"] for p in probs], [p["tube"] for p in probs], [p["guess"] for p in probs], dt0,
-                           [p["final_heading"] for p in probs], pairs=[(index[a], index[b]) for a, b in self.agent_pairs],
-                           N_per_set=N_per_set, shrink_tube=shrink_tube)
+        res = opti.solve(pairs=[(index[a], index[b]) for a, b in self.agent_pairs])  # (:389-466)
         self.final_stats = dict(status=res["status"], iters=res["iters"], cost=res["cost"])
         if res["status"] != 0:
             raise RuntimeError(f"joint final problem did not converge (status {res['status']} after {res['iters']} iterations)")
@@ -95,6 +94,12 @@ class MultiVehiclePlanner:
             sol["dt"] = res["dt"]
             self.vehicles[agent].get_solution(sol=sol)
             self.final_results[agent] = self.vehicles[agent].interpolate_states(final_t)
+
+    def dump_results(self, rl_file_name: str = None):
+        """`dill.dump(planner.final_results, open(f"{rl_file_name}_opt.pkl", "wb"))` of the reference's `main` (:668)."""
+        from ..results import dump
+
+        return dump(self.final_results, f"{rl_file_name or self.rl_file_name}_opt.pkl")
 
     def joint_dual_ws(self, K: int = 5, verbose: int = 0):
         """warm starting the dual multipliers for joint collision avoidance (:208-341): for every pair of vehicles and

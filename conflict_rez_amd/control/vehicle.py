@@ -125,10 +125,12 @@ class Vehicle:
         cost sum B_k (a^2 + v^2 w^2 + delta^2) dt + (N dt)^2.  `zu0`: guess at the collocation points
         (`interp_ws_for_collocation`); its l, m are not used: the OBCA duals are eliminated in the kernel
         (csrc/cfz_colloc.inl) and rebuilt from the poses by `get_solution`.  Returns the problem description that
-        `solve_single_final_problem` hands to `cfz_colloc` (the reference returns its `ca.Opti`)."""
-        if opti is not None or dt is not None:
-            raise NotImplementedError("a shared Opti / shared dt belongs to the joint multi-vehicle problem: "
-                                      "MultiVehiclePlanner.solve_final_problem_obca assembles it for cfz_joint_colloc")
+        `solve_single_final_problem` hands to `cfz_colloc` (the reference returns its `ca.Opti`).
+        `opti`, `dt` (:364-366, :386-389): a shared problem (`joint_problem.JointOpti`) and its shared interval length
+        (`opti.variable()`), as `MultiVehiclePlanner.solve_final_problem_obca` passes them: the vehicle's problem is then
+        added to the shared one, to be solved with the other vehicles' (`opti.solve`), and `self.opti` is that object."""
+        if (opti is None) != (dt is None):
+            raise TypeError("opti and dt come together: dt is the shared variable of opti (JointOpti.variable())")
         if K != 5:
             raise NotImplementedError("cfz_colloc is built for K = 5 (CFZ_COLLOC_K), the reference's only caller value")
         from ..engine import ProblemSpec
@@ -144,6 +146,10 @@ class Vehicle:
             init_pose=[s0.x.x + off.x.x, s0.x.y + off.x.y, s0.e.psi + off.e.psi], final_heading=final_heading,
             tube=[((st["back"].A, st["back"].b), (st["front"].A, st["front"].b)) for st in self.rl_tube[1:]],
             guess=guess, dt0=float(zu0.t[-1]) / N, N_per_set=N_per_set, shrink_tube=shrink_tube)
+        if opti is not None:
+            opti.add(self.final_problem, dt)
+            self.opti = opti
+            return opti
         return self.final_problem
 
     def solve_single_final_problem(self, verbose: int = 0):
@@ -195,6 +201,14 @@ class Vehicle:
         result.m = [[np.array(M[i, k]) for k in range(K1)] for i in range(N)]
         self.get_interpolator(K=self.K, N=N, dt=dt, opt=result)
         return result
+
+    def dump_plan(self, zu0: VehiclePrediction, result: VehiclePrediction, rl_file_name: str = None):
+        """The two files the reference's `main` leaves behind (vehicle.py:927-928): the warm start on the collocation grid
+        and the collocation plan, as `<rl_file_name>_<agent>_zu0.pkl` / `_zufinal.pkl`.  Returns the two paths."""
+        from ..results import dump
+
+        stem = f"{rl_file_name or self.rl_file_name}_{self.agent}"
+        return dump(zu0, stem + "_zu0.pkl"), dump(result, stem + "_zufinal.pkl")
 
     # ---- resampling of a warm start onto the collocation grid ---------------------------------
     def interp_ws_for_collocation(self, zu0: VehiclePrediction, K: int = 5, N_per_set: int = 5):

@@ -21,11 +21,12 @@ from ..engine import Engine, ProblemSpec
 from ..obstacle_types import GeofenceRegion
 from ..pytypes import VehiclePrediction, VehicleState
 from ..vehicle_types import VehicleBody, VehicleConfig
-from .compute_sets import compute_obstacles, compute_sets
+from .compute_sets import compute_obstacles, compute_sets, compute_static_vehicles
 from .dynamic_model import simulator
 from .vehicle import Vehicle
 
 np.random.seed(0)  # reference vehicle_follower.py:29 (seeds the first dual guesses :401-402)
+static_vehicles = compute_static_vehicles()  # :31 -- cosmetics, but its 15 draws come BEFORE the vehicles' first dual guesses
 
 _PRIMAL = ("x", "y", "psi", "v", "u_steer", "u_a", "u_steer_dot")  # zu rows: x y psi v delta a w
 
@@ -70,17 +71,18 @@ class VehicleFollower(Vehicle):
 
     # ---- reference path ---------------------------------------------------------------------
     def plan_single_path(self, N_ws=30, dt_ws=0.1, K=5, N_per_set=5, shrink_tube=0.5, dmin=0.05, spline_ws=True,
-                         interp_dt=0.01):
+                         interp_dt=0.01, strict=False):
         """plan a single vehicle reference path (:91-138): state_ws -> dual_ws -> resampling onto the collocation grid ->
         collocation plan -> `reference_traj` sampled every `interp_dt` from the collocation interpolant.
         `self.plan_refined` is True when the reference is the collocation plan.  Two fallbacks the reference does not
         have (it would raise): a final heading the warm start cannot meet is retried without it, and if the collocation
-        solve fails the warm start itself becomes the reference (`plan_refined` False)."""
+        solve fails the warm start itself becomes the reference (`plan_refined` False).  `strict=True` switches both off:
+        any solver failure raises RuntimeError, as `opti.solve()` does in the reference (vehicle.py:216, :658)."""
         try:
             zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=self.final_heading,
                                 shrink_tube=shrink_tube, spline_ws=spline_ws)
         except RuntimeError:
-            if self.final_heading is None:
+            if self.final_heading is None or strict:
                 raise
             zu0 = self.state_ws(N=N_ws, dt=dt_ws, init_offset=self.init_offset, final_heading=None,
                                 shrink_tube=shrink_tube, spline_ws=spline_ws)
@@ -91,6 +93,8 @@ class VehicleFollower(Vehicle):
         try:
             sol = self.solve_single_final_problem()
         except RuntimeError as e:
+            if strict:
+                raise
             self.print(f"{self.agent}: {e}; following the warm start")
             self.plan_refined = False
             self.set_reference(zu0, interp_dt=interp_dt)
@@ -274,10 +278,8 @@ class MultiDistributedFollower:
             self.final_results[v.agent] = v.final_traj
         print(f"Mean iteration time = {[np.mean(self.iter_time[a]) for a in self.agents]}")
         print(f"Max iteration time = {[np.amax(self.iter_time[a]) for a in self.agents]}")
-        if dump:  # same file names as the reference (:665-670); pickle instead of dill
-            import pickle
+        if dump:  # same file names as the reference (:665-670)
+            from ..results import dump as dump_file
 
-            with open(f"{self.rl_file_name}_follower_final.pkl", "wb") as f:
-                pickle.dump(self.final_results, f)
-            with open(f"{self.rl_file_name}_follower_iter_time.pkl", "wb") as f:
-                pickle.dump(self.iter_time, f)
+            dump_file(self.final_results, f"{self.rl_file_name}_follower_final.pkl")
+            dump_file(self.iter_time, f"{self.rl_file_name}_follower_iter_time.pkl")

@@ -129,6 +129,52 @@ __global__ void loop_post(int S, int V, int N, double dt, double wb, int plant_s
   if (b % V == 0) kidx[b / V] += 1;
 }
 
+// ---- vehicle-sharded closed loop (partitioning B: a rank owns n_own vehicles of S scenarios) ------------------------
+// The glue of one MPC iteration around the solve, on the caller's stream: instances are ordered [s][o] (o = index into the
+// owned vehicles).  allpred[S][V][3][N] holds x, y, psi of EVERY vehicle's last prediction (gathered over RCCL by the
+// caller), pred[S][n_own][7][N] this rank's own predictions, table[n_own][T][7] the owned vehicles' plans.
+// vs_prep: parameters and shifted warm start (vehicle_follower.py:432-476).  One thread per (instance, stage).
+__global__ void vs_prep(int S, int V, int n_own, int N, int T, const int32_t *own, const double *table, const int32_t *k0, int t,
+                        const double *allpred, const double *pred, const double *state, double *x0, double *ref, double *nbr,
+                        double *zu) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)S * n_own * N) return;
+  const int k = (int)(tid % N);
+  const int b = (int)(tid / N);
+  const int s = b / n_own, o = b - s * n_own, v = own[o];
+  const int ka = (k + 1 < N) ? k + 1 : N - 1;  // _adv_onestep (:413-426)
+  if (k < 5) x0[b * 5 + k] = state[b * 5 + k];
+  int kr = k0[s] + t + k; if (kr > T - 1) kr = T - 1;
+  for (int c = 0; c < 3; ++c) ref[((size_t)b * 3 + c) * N + k] = table[((size_t)o * T + kr) * 7 + c];
+  for (int c = 0; c < 7; ++c) zu[((size_t)b * 7 + c) * N + k] = pred[((size_t)b * 7 + c) * N + ka];
+  int q = 0;
+  for (int u = 0; u < V; ++u) {
+    if (u == v) continue;
+    for (int c = 0; c < 3; ++c) nbr[(((size_t)b * (V - 1) + q) * 3 + c) * N + k] = allpred[(((size_t)s * V + u) * 3 + c) * N + ka];
+    ++q;
+  }
+}
+
+// vs_post: read-back or shift fallback (:484-524), plant (:528-543), and the carry flag of the next iteration (a vehicle
+// whose solve converged starts its next one from these multipliers).  One thread per instance.
+__global__ void vs_post(int B, int N, double dt, double wb, int plant_substeps, const int32_t *status, const double *zu,
+                        double *pred, double *state, int32_t *carry) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double *pb = pred + (size_t)b * 7 * N;
+  if (status[b] == 0) {
+    for (int i = 0; i < 7 * N; ++i) pb[i] = zu[(size_t)b * 7 * N + i];
+  } else {
+    for (int c = 0; c < 7; ++c)
+      for (int k = 0; k + 1 < N; ++k) pb[c * N + k] = pb[c * N + k + 1];
+  }
+  double z[5], out[5];
+  for (int i = 0; i < 5; ++i) z[i] = state[b * 5 + i];
+  cfz::rk4_step<false>(z, pb[5 * N], pb[6 * N], dt, wb, plant_substeps, out, nullptr);
+  for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
+  carry[b] = status[b] == 0;
+}
+
 // Longest-processing-time-first dispatch order for the next step: instances sorted by the iteration count of
 // the step just finished, descending (counting sort, one workgroup).  The solve of an instance does not depend
 // on where it runs, only the makespan of the launch does.
@@ -275,6 +321,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
       status[b] = oi[1]; iters[b] = oi[0];
       stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
       atomicAdd(iter_sum, oi[0]);
+      if (oi[1] == 0) atomicAdd(iter_sum + 1, 1);  // converged solves of this launch
     }
     // release: prediction and state of (s, v, t).  Every storing wavefront drains its stores, the workgroup meets, one
     // lane writes the XCD's L2 back and only then signals (the asm wait keeps the compiler from dropping the drain).
@@ -458,7 +505,7 @@ struct cfz_handle {
   double *pred2 = nullptr, *scratch = nullptr;
   int32_t *queue = nullptr, *ctrl = nullptr, *done = nullptr, *iter_sum = nullptr;
   int queue_cap = 0, grid_blocks = 0, steps_done = 0;
-  long last_iter_sum = 0;
+  long last_iter_sum = 0, last_converged = 0;
 };
 
 namespace {
@@ -781,6 +828,27 @@ int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double 
   if (!d_x0 || !d_ref || !d_zu || !d_status || !d_iters || !d_stats) return fail("null device pointer");
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   return launch_solve(h, B, d_x0, d_ref, d_nbr ? d_nbr : h->nbr, d_zu, d_status, d_iters, d_stats, false, st);
+}
+
+int cfz_vsl_step(cfz_handle *h, int S, int V, int n_own, const int32_t *d_own, int T, const double *d_table, const int32_t *d_k0,
+                 int t, const double *d_allpred, double *d_pred, double *d_state, int32_t *d_status, int32_t *d_iters,
+                 double *d_stats, int32_t *d_carry, void *stream) {
+  if (S < 1 || n_own < 1 || check(h, S * n_own)) return fail("S * n_own outside the handle's batch");
+  if (V != h->ks.n_nbr + 1) return fail("V must be n_nbr + 1 of the handle's spec");
+  if (!d_own || !d_table || !d_k0 || !d_allpred || !d_pred || !d_state || !d_status || !d_iters || !d_stats || !d_carry)
+    return fail("null device pointer");
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const int N = h->ks.N, B = S * n_own;
+  const long nt = (long)B * N;
+  hipLaunchKernelGGL(vs_prep, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, S, V, n_own, N, T, d_own, d_table, d_k0, t, d_allpred,
+                     d_pred, d_state, h->x0, h->ref, h->nbr, h->zu);
+  HIP_OK(hipGetLastError());
+  h->carry_ext = t > 0 ? d_carry : nullptr;  // iteration 0 has nothing to carry
+  if (launch_solve(h, B, h->x0, h->ref, h->nbr, h->zu, d_status, d_iters, d_stats, false, st)) return -1;
+  hipLaunchKernelGGL(vs_post, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, B, N, h->ks.dt, h->ks.wb, kPlantSubsteps, d_status, h->zu,
+                     d_pred, d_state, d_carry);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
@@ -1176,7 +1244,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;
   if (!h->pred2) {
     HIP_OK(hipMalloc(&h->pred2, (size_t)2 * B * 7 * N * 8)); HIP_OK(hipMalloc(&h->ctrl, (4 + 1024) * 4));
-    HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 4));
+    HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 8));
   }
   if (h->grid_blocks < grid) {
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1199,7 +1267,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
     const int32_t ctrl0[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof ctrl0, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipMemsetAsync(h->done, 0, (size_t)S * 4, h->stream));
-    HIP_OK(hipMemsetAsync(h->iter_sum, 0, 4, h->stream));
+    HIP_OK(hipMemsetAsync(h->iter_sum, 0, 8, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
   }
   HIP_OK(hipEventRecord(h->ev0, h->stream));
@@ -1241,16 +1309,17 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   h->ms_pending = false;
-  int32_t ctrl[4] = {0, 0, 0, 0}, isum = 0;
+  int32_t ctrl[4] = {0, 0, 0, 0}, isum[2] = {0, 0};
   HIP_OK(hipMemcpy(ctrl, h->ctrl, sizeof ctrl, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(&isum, h->iter_sum, 4, hipMemcpyDeviceToHost));
-  h->last_iter_sum = isum;
+  HIP_OK(hipMemcpy(isum, h->iter_sum, 8, hipMemcpyDeviceToHost));
+  h->last_iter_sum = isum[0]; h->last_converged = isum[1];
   h->have_order = false;
   if (ctrl[2]) return fail("persistent loop kernel timed out waiting for a work item");
   return 0;
 }
 
 long cfz_loop_last_iterations(const cfz_handle *h) { return h ? h->last_iter_sum : -1; }
+long cfz_loop_last_converged(const cfz_handle *h) { return h ? h->last_converged : -1; }
 
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters) {
   if (!h || !h->pred) return fail("cfz_loop_init has not been called");

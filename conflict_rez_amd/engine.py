@@ -138,6 +138,9 @@ def load_library(path=None):
     lib.cfz_loop_run.argtypes = [vp, C.c_int]
     lib.cfz_loop_last_iterations.argtypes = [vp]
     lib.cfz_loop_last_iterations.restype = C.c_long
+    lib.cfz_vsl_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cfz_loop_last_converged.argtypes = [vp]
+    lib.cfz_loop_last_converged.restype = C.c_long
     lib.cfz_loop_get.argtypes = [vp, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -145,7 +148,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations "
+    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -388,6 +391,13 @@ class Engine:
                                                ptr(d_status), ptr(d_iters), ptr(d_stats),
                                                None if stream is None else C.c_void_p(int(stream))), "cfz_mpc_solve_device")
 
+    def vsl_step(self, S, V, d_own, T, d_table, d_k0, t, d_allpred, d_pred, d_state, d_status, d_iters, d_stats, d_carry, stream=None):
+        """`cfz_vsl_step`: one iteration of the vehicle-sharded closed loop on device tensors, no host synchronisation."""
+        ptr = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._ck(self.lib.cfz_vsl_step(self._h, int(S), int(V), int(d_own.numel()), ptr(d_own), int(T), ptr(d_table), ptr(d_k0), int(t),
+                                       ptr(d_allpred), ptr(d_pred), ptr(d_state), ptr(d_status), ptr(d_iters), ptr(d_stats), ptr(d_carry),
+                                       None if stream is None else C.c_void_p(int(stream))), "cfz_vsl_step")
+
     # ---- dual warm start (Vehicle.dual_ws) ------------------------------------------------------------
     def dual_ws(self, poses):
         """poses [n,3] (x,y,psi) -> (l [n,4 n_obs], m [n,4 n_obs], d [n,n_obs])."""
@@ -428,6 +438,10 @@ class Engine:
         """K closed-loop iterations in one persistent launch (same results as K x loop_step)."""
         self._ck(self.lib.cfz_loop_run(self._h, int(K)), "cfz_loop_run")
         return int(self.lib.cfz_loop_last_iterations(self._h))
+
+    def loop_last_converged(self):
+        """Solves of the last `loop_run` that converged (status 0)."""
+        return int(self.lib.cfz_loop_last_converged(self._h))
 
     def loop_get(self):
         S, V, N = self._S, self._V, self.spec.N

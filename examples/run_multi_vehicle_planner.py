@@ -10,7 +10,6 @@ four-vehicle joint solve takes about a minute, two vehicles a few seconds).  The
 (`plot_results`) is not reproduced."""
 import argparse
 import os
-import pickle
 import sys
 import tempfile
 import time
@@ -55,9 +54,7 @@ def main():
     for i, a in enumerate(agents):
         for b in agents[i + 1:]:
             print(f"  {a} - {b}: closest rear axles {np.hypot(fr[a].x - fr[b].x, fr[a].y - fr[b].y).min():.2f} m")
-    with open(stem + "_opt.pkl", "wb") as f:
-        pickle.dump(fr, f)
-    print("results in", stem + "_opt.pkl")
+    print("results in", planner.dump_results(stem))
 
 
 if __name__ == "__main__":

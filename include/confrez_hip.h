@@ -136,6 +136,21 @@ double cfz_last_solve_ms(const cfz_handle *h);
 int cfz_mpc_solve_device(cfz_handle *h, int B, const double *d_x0, const double *d_ref, const double *d_nbr,
                          double *d_zu, int32_t *d_status, int32_t *d_iters, double *d_stats, void *stream);
 
+/* ---- vehicle-sharded closed loop (SURVEY.md 8e partitioning B; the reference's ROS deployment runs one process per vehicle
+ * and exchanges predictions as messages, ros2_ws/src/confrez_ros/src/vehicle_node.py:111-189) --------------------------------
+ * One MPC iteration of the n_own vehicles this rank owns in S scenarios, entirely on `stream` (NULL = the handle's), no host
+ * synchronisation: parameters + shifted warm start from the gathered predictions (:432-476), solve started from the carried
+ * multipliers, read-back or shift fallback (:484-524), plant (:528-543).  Instances are ordered [s][o].  All pointers are HIP
+ * device pointers:
+ *   d_own[n_own]            global indices of the owned vehicles, ascending
+ *   d_table[n_own][T][7]    their plans sampled every dt; d_k0[S] start sample of every scenario; t = iteration number
+ *   d_allpred[S][V][3][N]   x, y, psi of every vehicle's last prediction, vehicle order (the caller's all-gather)
+ *   d_pred[S][n_own][7][N], d_state[S][n_own][5]   in/out;  d_status, d_iters int32[S n_own], d_stats fp64[S n_own][3] out
+ *   d_carry int32[S n_own]  in/out: written with status == 0, read by the next call (t > 0) as cfz_mpc_set_carry_device */
+int cfz_vsl_step(cfz_handle *h, int S, int V, int n_own, const int32_t *d_own, int T, const double *d_table, const int32_t *d_k0,
+                 int t, const double *d_allpred, double *d_pred, double *d_state, int32_t *d_status, int32_t *d_iters,
+                 double *d_stats, int32_t *d_carry, void *stream);
+
 /* ---- dual warm start ----------------------------------------------------------------------
  * Vehicle.dual_ws (confrez/control/vehicle.py:233-296): for n fixed poses[n][3] = (x, y, psi) the duals
  * l, m [n][4*n_obs] that certify the separation d[n][n_obs] (may be NULL) of the vehicle body from every
@@ -247,6 +262,8 @@ int cfz_loop_step(cfz_handle *h);
  * as K calls of cfz_loop_step.  cfz_loop_last_iterations: IPM iterations summed over all solves of that call. */
 int cfz_loop_run(cfz_handle *h, int K);
 long cfz_loop_last_iterations(const cfz_handle *h);
+/* solves of that call that converged (status 0); the others took the reference's shift fallback (:501-524) */
+long cfz_loop_last_converged(const cfz_handle *h);
 /* state[S][V][5], pred[S][V][7][N], status int32[S][V] of the last step; NULL to skip. */
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters);
 

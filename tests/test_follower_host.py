@@ -195,3 +195,83 @@ def test_node_loop_over_in_process_bus(follower_setup):
     back = VehiclePrediction()
     unpack_msg(msg, back)
     assert np.allclose(back.u_steer, v0.pred.u_steer) and back.l is None
+
+
+def test_rng_stream_matches_the_reference(follower_setup):
+    """the reference seeds numpy at import of vehicle_follower (:29), `compute_static_vehicles()` consumes 15
+    draws (:31), then each vehicle's first `get_current_ref` draws 0.1 rand(30, 24) for l, then m, in sorted-agent order
+    (:399-402).  The fixture has just done exactly that in this process order only if nothing else drew in between, so the
+    stream is replayed here from the seed."""
+    import importlib
+
+    import conflict_rez_amd.control.vehicle_follower as vf
+
+    importlib.reload(vf)  # np.random.seed(0) + the 15 draws of the parked cars, as at first import
+    assert len(vf.static_vehicles) == 20
+    l, m = 0.1 * np.random.rand(30, 24), 0.1 * np.random.rand(30, 24)
+    assert np.allclose(l[0, :3], [0.00871293, 0.00202184, 0.08326198], atol=1e-8)
+    assert np.allclose(m[0, :3], [0.06817399, 0.02773403, 0.05243798], atol=1e-8)
+    assert abs(l.sum() - 35.38388644) < 1e-7 and abs(m.sum() - 36.52575055) < 1e-7
+    # the parked cars themselves: 1.8 m wide, 3.9 m long boxes inside the slots, set back from the lane by < 0.7 cell
+    for p in vf.static_vehicles:
+        V = np.asarray(p.V)
+        assert np.isclose(np.ptp(V[:, 0]), 1.8) and np.isclose(np.ptp(V[:, 1]), 3.9)
+        assert V[:, 1].max() <= 13.75 + 1e-9 or V[:, 1].min() >= 21.25 - 1e-9
+
+
+def test_result_files_round_trip(follower_setup, tmp_path):
+    """The reference's result files under its names (vehicle.py:927-928, multi_vehicle_planner.py:668,
+    vehicle_follower.py:665-670): written by the package, read back equal."""
+    from conflict_rez_amd import results
+    from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
+
+    mdf = follower_setup
+    mdf.rl_file_name = str(tmp_path / "4v_rl_traj")
+    mdf.solve(num_iter=2, dump=True)
+    fin = results.load(mdf.rl_file_name + "_follower_final.pkl")
+    it = results.load(mdf.rl_file_name + "_follower_iter_time.pkl")
+    assert sorted(fin) == [f"vehicle_{i}" for i in range(4)] and len(fin["vehicle_2"].x) == 3 and len(it["vehicle_0"]) == 2
+    assert fin["vehicle_1"].x == mdf.vehicles[1].final_traj.x
+    # a single plan's two files: the warm start on the collocation grid (nested l, m) and the plan
+    veh = mdf.vehicles[0]
+    zu0, plan = VehiclePrediction(), VehiclePrediction()
+    zu0.t, zu0.x = np.linspace(0, 1, 12), np.arange(12.0)
+    zu0.l = [[np.full(24, i + 0.1 * k) for k in range(6)] for i in range(2)]
+    plan.t, plan.x, plan.dt = np.linspace(0, 2, 12), -np.arange(12.0), 0.25
+    p0, p1 = veh.dump_plan(zu0, plan, rl_file_name=str(tmp_path / "4v_rl_traj"))
+    assert p0.endswith("4v_rl_traj_vehicle_0_zu0.pkl") and p1.endswith("4v_rl_traj_vehicle_0_zufinal.pkl")
+    a, b = results.load(p0), results.load(p1)
+    assert np.array_equal(a.x, zu0.x) and a.l[1][3][5] == 1.3 and b.dt == 0.25 and np.array_equal(b.x, plan.x)
+    # the planner's joint result file
+    mvp = MultiVehiclePlanner.__new__(MultiVehiclePlanner)
+    mvp.rl_file_name, mvp.final_results = str(tmp_path / "4v_rl_traj"), {"vehicle_0": plan, "vehicle_1": zu0}
+    back = results.load(mvp.dump_results())
+    assert sorted(back) == ["vehicle_0", "vehicle_1"] and back["vehicle_0"].dt == 0.25
+
+
+def test_joint_problem_surface(follower_setup):
+    """`setup_single_final_problem(opti=, dt=)` as `MultiVehiclePlanner.solve_final_problem_obca` calls it
+    (multi_vehicle_planner.py:365-386): the vehicle's collocation problem joins the shared one; opti and dt come together
+    and dt must be THAT problem's variable."""
+    from conflict_rez_amd.control.joint_problem import JointOpti
+
+    veh = follower_setup.vehicles[0]
+    zuc = veh.interp_ws_for_collocation(_references()["vehicle_0"], K=5, N_per_set=5)
+    opti = JointOpti()
+    dt = opti.variable()
+    with pytest.raises(RuntimeError, match="one shared variable"):
+        opti.variable()
+    opti.set_initial(dt, 0.4)
+    out = veh.setup_single_final_problem(zu0=zuc, opti=opti, dt=dt, K=5, N_per_set=5, shrink_tube=0.5)
+    N = 5 * (veh.num_sets - 1)
+    assert out is opti and veh.opti is opti and len(opti.problems) == 1 and (veh.N, veh.K) == (N, 5)
+    prob = opti.problems[0]
+    assert prob["guess"].shape == (6 * N, 7) and len(prob["tube"]) == veh.num_sets - 1 and prob["shrink_tube"] == 0.5
+    with pytest.raises(TypeError, match="come together"):
+        veh.setup_single_final_problem(zu0=zuc, opti=opti)
+    with pytest.raises(ValueError, match="this problem"):
+        veh.setup_single_final_problem(zu0=zuc, opti=JointOpti(), dt=dt)
+    with pytest.raises(RuntimeError, match="set_initial"):
+        other = JointOpti(); d2 = other.variable(); other.add(prob, d2); other.solve()
+    # without opti/dt: the single-vehicle problem description, as before
+    assert veh.setup_single_final_problem(zu0=zuc)["dt0"] > 0

@@ -103,39 +103,6 @@ def test_full_batch_properties(eng):
     assert np.array_equal(out2["zu"], out["zu"][perm])
 
 
-def _host_replay(spec, ospec, table, k0, noise, steps):
-    """The Jacobi iteration of `MultiDistributedFollower.solve` (vehicle_follower.py:630-663) on the host with the oracle's
-    C port: `_adv_onestep` shift of every prediction (:413-426, 444-476), solve with the multipliers carried from the
-    vehicle's previous solve (oracle/mpc_nlp.py warm_from_carry), read-back or shift fallback (:484-524), plant
-    (:528-543).  Yields (state, pred, status, iters) after every iteration."""
-    from oracle import port
-    from oracle.dynamics import plant_step
-
-    S, V, T, N = len(k0), table.shape[0], table.shape[1], spec.N
-    state = np.zeros((S, V, 5)); pred = np.zeros((S, V, 7, N))
-    for s in range(S):
-        for v in range(V):
-            pred[s, v] = table[v, np.minimum(k0[s] + np.arange(N), T - 1), :].T
-            state[s, v] = table[v, k0[s], :5] + noise[s, v]
-    carry = [[None] * V for _ in range(S)]
-    adv = np.minimum(np.arange(N) + 1, N - 1)
-    for t in range(steps):
-        newp = pred.copy()
-        status = np.zeros((S, V), int); iters = np.zeros((S, V), int)
-        for s in range(S):
-            for v in range(V):
-                kr = np.minimum(k0[s] + t + np.arange(N), T - 1)
-                nb = np.stack([pred[s, u][:3][:, adv] for u in range(V) if u != v])
-                w = pred[s, v][:, adv]
-                r = port.solve(ospec, state[s, v], table[v, kr, :3].T, nb, w.T.copy(), carry=carry[s][v])
-                carry[s][v] = r["carry"]
-                newp[s, v] = r["p"].T if r["status"] == 0 else w
-                state[s, v] = plant_step(state[s, v], newp[s, v][5:7, 0], spec.dt, spec.wb)
-                status[s, v], iters[s, v] = r["status"], r["iters"]
-        pred = newp
-        yield state.copy(), pred.copy(), status, iters
-
-
 def test_closed_loop_on_device(eng, ospec):
     """cfz_loop_step (loop_prep / solve_kernel / loop_post) AND cfz_loop_run (the persistent loop_kernel, what bench.py
     times) against a host replay of the same Jacobi iteration with the oracle's C port: reference-table indexing,
@@ -147,7 +114,9 @@ def test_closed_loop_on_device(eng, ospec):
     S, steps = 8, 5
     k0, noise = scenarios.sample_scenarios(S, table, seed=3)
     eng.loop_init(table, k0, noise)
-    replay = list(_host_replay(eng.spec, ospec, table, k0, noise, steps))
+    from oracle.closed_loop import replay as host_replay
+
+    replay = list(host_replay(ospec, table, k0, noise, steps, dt=eng.spec.dt, wb=eng.spec.wb))
     n_fallback = 0
     for t, (state, pred, status, iters) in enumerate(replay):
         eng.loop_step()
@@ -286,8 +255,9 @@ def test_other_shapes_and_error_paths():
 
 
 def test_vehicle_sharded_loop_matches_device_loop():
-    """Partitioning B (distributed.VehicleShardedLoop: RCCL all-gather of the predictions, `solve_device` on torch
-    tensors, plant in torch) with a single rank owning all four vehicles = the device-resident loop, step for step."""
+    """Partitioning B (distributed.VehicleShardedLoop: RCCL all-gather of the predictions, then `cfz_vsl_step` -- prep,
+    solve, read-back / fallback, plant as HIP kernels on torch's stream) with a single rank owning all four vehicles = the
+    device-resident loop `cfz_loop_step`, step for step and bit for bit."""
     import socket
 
     import torch
@@ -310,12 +280,13 @@ def test_vehicle_sharded_loop_matches_device_loop():
         vl = VehicleShardedLoop(eb, VehicleShardedExchange(4), table, k0, noise)
         for t in range(K):
             ea.loop_step()
-            vl.step()
+            vl.step(sync=True)
             a = ea.loop_get()
             assert np.array_equal(a["status"].ravel(), vl.status.cpu().numpy()), t
             assert np.array_equal(a["iters"].ravel(), vl.iters.cpu().numpy()), t
-            assert np.abs(a["state"].reshape(-1, 5) - vl.state.reshape(-1, 5).cpu().numpy()).max() < 1e-6
-            assert np.abs(a["pred"].reshape(-1, 7, spec.N) - vl.pred.reshape(-1, 7, spec.N).cpu().numpy()).max() < 1e-6  # two plant implementations (HIP rotation-based trig, torch cos/sin) inside a closed loop
+            # the same kernels on both sides (solve_kernel, the same RK4 plant): bit for bit
+            assert np.array_equal(a["state"].reshape(-1, 5), vl.state.reshape(-1, 5).cpu().numpy())
+            assert np.array_equal(a["pred"].reshape(-1, 7, spec.N), vl.pred.reshape(-1, 7, spec.N).cpu().numpy())
         ea.close(); eb.close()
     finally:
         dist.destroy_process_group()
