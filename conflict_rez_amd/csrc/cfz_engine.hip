@@ -9,6 +9,8 @@
 //                  previous predictions (reference vehicle_follower.py:432-476, 636-637)
 //   loop_post      closed loop: read-back or shift fallback, plant integration, clock
 //                  (reference :484-563)
+// The planning kernels (state_ws, collocation plans) and their entry points live in cfz_planning.hip: a translation unit
+// of its own because the two halves want different optimisation levels on this toolchain (see __graft_entry__.build).
 // Host side: a handle owns all device buffers, one stream and two events.
 
 #include <hip/hip_runtime.h>
@@ -25,19 +27,11 @@
 
 #include "../../include/confrez_hip.h"
 #include "cfz_solver.inl"
-#include "cfz_plan.inl"
-#include "cfz_colloc.inl"
+#include "cfz_common.h"
+
+thread_local std::string cfz_g_err;  // cfz_last_error(); shared with cfz_planning.hip (cfz_common.h)
 
 namespace {
-
-thread_local std::string g_err;
-
-int fail(const char *what, hipError_t e = hipSuccess) {
-  g_err = what;
-  if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
-  return -1;
-}
-#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(#call, e_); } while (0)
 
 // Plant (vehicle_follower.py:528-543, CasADi integrator "idas"): RK4 with this many sub-steps per dt.  10 sub-steps are
 // within 6e-11 of the converged solution over the whole input range, tighter than IDAS's default tolerances.
@@ -48,7 +42,7 @@ struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
 #ifndef CFZ_WAVES_PER_SIMD
 #define CFZ_WAVES_PER_SIMD 2
 #endif
-__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(const cfz::KSpec sp, const cfz::Lay L, int B, const double *x0,
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(const cfz::KSpec sp, const cfz::KDer dv, const cfz::Lay L, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
                                                    int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
                                                    double *wst, int wst_stride, const int32_t *carry, int carry_all,
@@ -71,7 +65,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(con
   // carry record of the instance's slot (default: slot b): used when the caller says that this solve is the successor of
   // the previous one in that slot
   const int slot = slots ? slots[b] : b;
-  cfz::solve_instance(sp, x0 + (size_t)b * 5, ref + (size_t)b * 3 * N, nbr + (size_t)b * nn * 3 * N,
+  cfz::solve_instance(sp, dv, x0 + (size_t)b * 5, ref + (size_t)b * 3 * N, nbr + (size_t)b * nn * 3 * N,
                       zu + (size_t)b * 7 * N, smem, L, oi, od, duo, wst ? wst + (size_t)slot * wst_stride : nullptr,
                       carry_all || (carry && carry[b]));
   if (threadIdx.x == 0) {
@@ -215,7 +209,7 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
 #else
 #define CFZ_MARK(c) do { } while (0)
 #endif
-__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(const cfz::KSpec sp, const cfz::Lay L, int S, int V, int K, int T,
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(const cfz::KSpec sp, const cfz::KDer dv, const cfz::Lay L, int S, int V, int K, int T,
                                                         const double *ref_table, const int32_t *kidx0, int t_base,
                                                         double *pred, double *state, double *scratch, int32_t *qbuf,
                                                         int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
@@ -301,7 +295,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
     CFZ_MARK(3);
     int oi[2]; double od[3];
     cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cfz::solve_instance(sp, x0, ref, nbr, zu, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1);
+    cfz::solve_instance(sp, dv, x0, ref, nbr, zu, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1);
     __syncthreads();
     CFZ_MARK(4);
     // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
@@ -344,40 +338,58 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
   CFZ_MARK(9);
 }
 
-// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
-// bound 512 = at most 256 VGPRs, no AGPRs: see colloc_kernel
-__global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
-                                const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
-  const int b = blockIdx.x;
-  extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
-  if (b >= B) return;
-  // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
-  cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
+// ---- dual warm starts: exact separation of two convex quadrilaterals and the duals that certify it ------------------
+// The reference maximises d over the OBCA duals (vehicle.py:233-296, multi_vehicle_planner.py:208-341); the optimum is
+// the Euclidean distance of the two polygons and the optimal duals encode the unit direction n* between their closest
+// points: lam >= 0 with A'lam = n* (two faces of the polygon through its support vertex), mu >= 0 with G'mu = -R'n*
+// (the body rectangle's normals are +-e_x, +-e_y, so mu is the positive/negative part).  Closest points of two disjoint
+// convex polygons: a vertex of one and a point of an edge of the other (possibly its end point, the vertex-vertex case),
+// so 2 x 4 x 4 point-segment distances decide.  If the polygons touch or overlap, the best face normal stands in (its
+// value is then <= 0; the reference's optimum with |A'lam| <= 1 would be 0 at lam = mu = 0).
+__device__ inline void point_segment(double qx, double qy, double ax, double ay, double bx, double by, double &dist2, double &nx, double &ny) {
+  const double ex = bx - ax, ey = by - ay, wx = qx - ax, wy = qy - ay;
+  double t = (wx * ex + wy * ey) / (ex * ex + ey * ey);
+  t = fmin(fmax(t, 0.0), 1.0);
+  nx = wx - t * ex; ny = wy - t * ey;  // from the segment's closest point to q
+  dist2 = nx * nx + ny * ny;
 }
 
-// single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
-// cfz_colloc.inl.
-// One wavefront runs it, but the bound is 512: with 64 (or 256) the register allocator may use AGPRs beyond 256 VGPRs, and
-// every such build of this kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950 / ROCm 7.2 while the
-// 256-VGPR builds of the same source run (measured, tools/colloc_timing_one.sh).
-#ifndef CFZC_BOUNDS
-#define CFZC_BOUNDS 512
-#endif
-// MODE 1: single-vehicle plans, one wavefront each, elimination in the LDS window; MODE 2: joint plans, 512 threads each,
-// elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
-template <int MODE>
-__global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
-                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles) {
-  const int b = blockIdx.x;
-  // dynamic LDS: MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2 one
-  // right-hand side of the substitution (lds_doubles of them, 0 = none)
-  if (b >= B) return;
-  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles);
+// unit direction n from polygon P (vertices PV, counter-clockwise) towards polygon Q and their distance; false if they
+// are not strictly apart
+__device__ inline bool polygon_gap(const double PV[4][2], const double QV[4][2], double &nx, double &ny, double &dist) {
+  double best = INFINITY, bx = 0.0, by = 0.0;
+  for (int v = 0; v < 4; ++v)
+    for (int e = 0; e < 4; ++e) {
+      double d2, ux, uy;
+      point_segment(QV[v][0], QV[v][1], PV[e][0], PV[e][1], PV[(e + 1) & 3][0], PV[(e + 1) & 3][1], d2, ux, uy);  // P's edge -> Q's vertex
+      if (d2 < best) { best = d2; bx = ux; by = uy; }
+      point_segment(PV[v][0], PV[v][1], QV[e][0], QV[e][1], QV[(e + 1) & 3][0], QV[(e + 1) & 3][1], d2, ux, uy);  // Q's edge -> P's vertex
+      if (d2 < best) { best = d2; bx = -ux; by = -uy; }
+    }
+  dist = sqrt(best);
+  if (!(dist > 1e-12)) return false;
+  nx = bx / dist; ny = by / dist;
+  return true;
 }
 
-// dual_ws (reference vehicle.py:233-296): for fixed poses, the dual certificate of every (pose, obstacle)
-// pair and the separation it certifies -- closed form over the face normals of both polygons (the
-// reference maximises the same separation with IPOPT over lambda, mu).  One thread per pair.
+// lam >= 0 on the faces of {A p <= b} (vertices V) with A'lam = n: the two faces through the support vertex in direction n
+__device__ inline void cone_duals(const double A[4][2], const double b[4], const double V[4][2], double nx, double ny, double lam[4]) {
+  int v = 0; double sup = -INFINITY;
+  for (int i = 0; i < 4; ++i) { const double h = nx * V[i][0] + ny * V[i][1]; if (h > sup) { sup = h; v = i; } }
+  int i0 = 0, i1 = 1; double r0 = INFINITY, r1 = INFINITY;
+  for (int i = 0; i < 4; ++i) {
+    const double r = fabs(A[i][0] * V[v][0] + A[i][1] * V[v][1] - b[i]);
+    if (r < r0) { r1 = r0; i1 = i0; r0 = r; i0 = i; } else if (r < r1) { r1 = r; i1 = i; }
+  }
+  const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
+  const double det = A[ia][0] * A[ib][1] - A[ib][0] * A[ia][1];
+  for (int i = 0; i < 4; ++i) lam[i] = 0.0;
+  lam[ia] = fmax((A[ib][1] * nx - A[ib][0] * ny) / det, 0.0);
+  lam[ib] = fmax((-A[ia][1] * nx + A[ia][0] * ny) / det, 0.0);
+}
+
+// dual_ws (reference vehicle.py:233-296): for fixed poses, the optimal dual certificate of every (pose, obstacle) pair and
+// the separation it certifies.  One thread per pair.
 __global__ void dual_ws_kernel(const cfz::KSpec sp, int n, const double *poses, double *l, double *mu_out, double *d) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int no = sp.n_obs;
@@ -389,39 +401,39 @@ __global__ void dual_ws_kernel(const cfz::KSpec sp, int n, const double *poses, 
     V[i][0] = sp.V_obs[j][i][0]; V[i][1] = sp.V_obs[j][i][1];
   }
   const double x = poses[k * 3], y = poses[k * 3 + 1], psi = poses[k * 3 + 2];
-  double s, c, sep2[2];
+  double s, c;
   sincos(psi, &s, &c);
-  const int sel = cfz::select_rows(A, b, V, x, y, c, s, sp.g, 0);
-  cfz::rows_for<false>(A, b, V, x, y, c, s, sp.g, sel, sep2, nullptr);
-  const int kind = sel >> 6, f = (sel >> 4) & 3, v = sep2[0] <= sep2[1] ? (sel >> 2) & 3 : sel & 3;
-  double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
-  if (kind == 1) {  // n = A_f ; G' mu = -R' n
-    lam[f] = 1.0;
-    const double mx = -(c * A[f][0] + s * A[f][1]), my = -(-s * A[f][0] + c * A[f][1]);
+  const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
+  const double BV[4][2] = {{g0, g1}, {-g2, g1}, {-g2, -g3}, {g0, -g3}};
+  double W[4][2];  // body vertices in the world frame, counter-clockwise
+  for (int i = 0; i < 4; ++i) { W[i][0] = x + c * BV[i][0] - s * BV[i][1]; W[i][1] = y + s * BV[i][0] + c * BV[i][1]; }
+  double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0}, nx, ny, dist;
+  if (polygon_gap(V, W, nx, ny, dist)) {  // n: from the obstacle towards the vehicle
+    cone_duals(A, b, V, nx, ny, lam);
+    const double mx = -(c * nx + s * ny), my = -(-s * nx + c * ny);  // G'mu = -R'n
     muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
-  } else {  // n = -R G_f ; A' lam = n from the two obstacle faces through vertex v
-    muv[f] = 1.0;
-    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
-    const double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
-    int i0 = 0, i1 = 1; double r0 = INFINITY, r1 = INFINITY;
-    for (int i = 0; i < 4; ++i) {
-      const double r = fabs(A[i][0] * V[v][0] + A[i][1] * V[v][1] - b[i]);
-      if (r < r0) { r1 = r0; i1 = i0; r0 = r; i0 = i; } else if (r < r1) { r1 = r; i1 = i; }
-    }
-    const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
-    const double det = A[ia][0] * A[ib][1] - A[ib][0] * A[ia][1];
-    lam[ia] = fmax((A[ib][1] * nx - A[ib][0] * ny) / det, 0.0);
-    lam[ib] = fmax((-A[ia][1] * nx + A[ia][0] * ny) / det, 0.0);
+  } else {  // touching or overlapping: the best face normal
+    double sep2[2];
+    const int sel = cfz::select_rows_sep(A, b, V, x, y, c, s, sp.g, 0, sep2);
+    const int kind = sel >> 6, f = (sel >> 4) & 3;
+    if (kind == 1) { nx = A[f][0]; ny = A[f][1]; }
+    else { const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3); nx = -(c * gx - s * gy); ny = -(s * gx + c * gy); }
+    cone_duals(A, b, V, nx, ny, lam);
+    const double mx = -(c * nx + s * ny), my = -(-s * nx + c * ny);
+    muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
   }
   for (int i = 0; i < 4; ++i) { l[(size_t)k * 4 * no + 4 * j + i] = lam[i]; mu_out[(size_t)k * 4 * no + 4 * j + i] = muv[i]; }
-  if (d) d[(size_t)k * no + j] = fmin(sep2[0], sep2[1]);
+  if (d) {  // the value the rows certify: -g'mu + (A t - b)'lam  (:276)
+    double v = 0.0;
+    for (int i = 0; i < 4; ++i) v += -sp.g[i] * muv[i] + (A[i][0] * x + A[i][1] * y - b[i]) * lam[i];
+    d[(size_t)k * no + j] = v;
+  }
 }
 
 // joint_dual_ws (reference multi_vehicle_planner.py:208-341): for n pairs of fixed poses of two vehicles, the duals
-// lam (faces of the first), mu (faces of the second), s and the certified separation d of the rows
+// lam (faces of the first), mu (faces of the second), s and the separation d of the rows
 //   -b_this'lam - b_other'mu = d,  A_this'lam + s = 0,  A_other'mu - s = 0,  |s| <= 1,  lam, mu >= 0   (:292-295)
-// The reference maximises d with IPOPT; here it is the closed-form maximum over the face normals of both rectangles
-// (exact whenever the closest features are a face and a vertex), built like the neighbour blocks of the MPC kernel.
+// at the optimum: d = the distance of the two bodies, s = -w with w the unit direction from this vehicle to the other.
 __global__ void joint_dual_ws_kernel(const cfz::KSpec sp, int n, const double *pa, const double *pb, double *lam_o,
                                      double *mu_o, double *s_o, double *d_o) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,30 +442,36 @@ __global__ void joint_dual_ws_kernel(const cfz::KSpec sp, int n, const double *p
   double s, c, so, co;
   sincos(pa[3 * k + 2], &s, &c); sincos(pb[3 * k + 2], &so, &co);
   const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
-  double A[4][2] = {{co, so}, {-so, co}, {-co, -so}, {so, -co}}, b[4], V[4][2];
-  for (int i = 0; i < 4; ++i) b[i] = A[i][0] * xo + A[i][1] * yo + sp.g[i];
   const double BV[4][2] = {{g0, g1}, {-g2, g1}, {-g2, -g3}, {g0, -g3}};
-  for (int i = 0; i < 4; ++i) { V[i][0] = xo + co * BV[i][0] - so * BV[i][1]; V[i][1] = yo + so * BV[i][0] + co * BV[i][1]; }
-  double sep2[2];
-  const int sel = cfz::select_rows(A, b, V, x, y, c, s, sp.g, 0);
-  cfz::rows_for<false>(A, b, V, x, y, c, s, sp.g, sel, sep2, nullptr);
-  const int kind = sel >> 6, f = (sel >> 4) & 3;
-  const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
-  double lam[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, wx, wy;  // w: unit direction from this vehicle towards the other
-  if (kind == 1) {  // a face of the OTHER vehicle separates: its outward normal points at this vehicle, w = -Ro G_f
-    mu[f] = 1.0;
-    wx = -(co * gx - so * gy); wy = -(so * gx + co * gy);
-    const double lx = c * wx + s * wy, ly = -s * wx + c * wy;  // R' w = G' lam
-    lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
-  } else {  // a face of THIS vehicle separates: w = R G_f
-    lam[f] = 1.0;
-    wx = c * gx - s * gy; wy = s * gx + c * gy;
-    const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);  // Ro' (-w) = G' mu
-    mu[0] = fmax(mx, 0.0); mu[1] = fmax(my, 0.0); mu[2] = fmax(-mx, 0.0); mu[3] = fmax(-my, 0.0);
+  double W[4][2], V[4][2];
+  for (int i = 0; i < 4; ++i) {
+    W[i][0] = x + c * BV[i][0] - s * BV[i][1]; W[i][1] = y + s * BV[i][0] + c * BV[i][1];
+    V[i][0] = xo + co * BV[i][0] - so * BV[i][1]; V[i][1] = yo + so * BV[i][0] + co * BV[i][1];
   }
+  double wx, wy, dist;  // w: unit direction from this vehicle towards the other
+  if (!polygon_gap(W, V, wx, wy, dist)) {  // touching or overlapping: the best face normal of either body
+    double A[4][2] = {{co, so}, {-so, co}, {-co, -so}, {so, -co}}, b[4], sep2[2];
+    for (int i = 0; i < 4; ++i) b[i] = A[i][0] * xo + A[i][1] * yo + sp.g[i];
+    const int sel = cfz::select_rows_sep(A, b, V, x, y, c, s, sp.g, 0, sep2);
+    const int kind = sel >> 6, f = (sel >> 4) & 3;
+    const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
+    if (kind == 1) { wx = -(co * gx - so * gy); wy = -(so * gx + co * gy); }  // a face of the other body, normal towards this one
+    else { wx = c * gx - s * gy; wy = s * gx + c * gy; }
+  }
+  double lam[4], mu[4];
+  const double lx = c * wx + s * wy, ly = -s * wx + c * wy;          // R' w = G' lam
+  lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
+  const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);  // Ro' (-w) = G' mu
+  mu[0] = fmax(mx, 0.0); mu[1] = fmax(my, 0.0); mu[2] = fmax(-mx, 0.0); mu[3] = fmax(-my, 0.0);
   for (int i = 0; i < 4; ++i) { lam_o[4 * k + i] = lam[i]; mu_o[4 * k + i] = mu[i]; }
   s_o[2 * k] = -wx; s_o[2 * k + 1] = -wy;  // s = -A_this' lam = A_other' mu
-  if (d_o) d_o[k] = fmin(sep2[0], sep2[1]);
+  if (d_o) {  // -b_this'lam - b_other'mu with b = G R(-psi) t + g   (:292)
+    const double tl = c * x + s * y, tm = -s * x + c * y, ol = co * xo + so * yo, om = -so * xo + co * yo;
+    const double bt[4] = {tl + g0, tm + g1, -tl + g2, -tm + g3}, bo[4] = {ol + g0, om + g1, -ol + g2, -om + g3};
+    double v = 0.0;
+    for (int i = 0; i < 4; ++i) v -= bt[i] * lam[i] + bo[i] * mu[i];
+    d_o[k] = v;
+  }
 }
 
 // first prediction = the planned trajectory at the horizon times, as get_current_ref seeds it
@@ -510,31 +528,6 @@ struct cfz_handle {
 
 namespace {
 
-// vertices of {A p <= b} for a bounded quadrilateral
-bool quad_vertices(const double A[4][2], const double b[4], double V[4][2]) {
-  int n = 0;
-  for (int i = 0; i < 4; ++i)
-    for (int j = i + 1; j < 4; ++j) {
-      const double det = A[i][0] * A[j][1] - A[i][1] * A[j][0];
-      if (std::fabs(det) < 1e-9) continue;
-      const double px = (b[i] * A[j][1] - A[i][1] * b[j]) / det, py = (A[i][0] * b[j] - b[i] * A[j][0]) / det;
-      bool in = true;
-      for (int q = 0; q < 4; ++q) in = in && (A[q][0] * px + A[q][1] * py <= b[q] + 1e-9);
-      if (in) { if (n == 4) return false; V[n][0] = px; V[n][1] = py; ++n; }
-    }
-  if (n != 4) return false;
-  // counter-clockwise around the polygon, starting from the first vertex found: v-1 and v+1 (mod 4) are then the
-  // neighbours of v, which cfz::select_rows relies on
-  const double cx = 0.25 * (V[0][0] + V[1][0] + V[2][0] + V[3][0]), cy = 0.25 * (V[0][1] + V[1][1] + V[2][1] + V[3][1]);
-  const double two_pi = 6.283185307179586, a0 = std::atan2(V[0][1] - cy, V[0][0] - cx);
-  double key[4], W[4][2];
-  int ord[4] = {0, 1, 2, 3};
-  for (int i = 0; i < 4; ++i) { double a = std::atan2(V[i][1] - cy, V[i][0] - cx) - a0; while (a < 0.0) a += two_pi; while (a >= two_pi) a -= two_pi; key[i] = a; }
-  for (int i = 1; i < 4; ++i) for (int q = i; q > 0 && key[ord[q]] < key[ord[q - 1]]; --q) { const int t = ord[q]; ord[q] = ord[q - 1]; ord[q - 1] = t; }
-  for (int i = 0; i < 4; ++i) { W[i][0] = V[ord[i]][0]; W[i][1] = V[ord[i]][1]; }
-  memcpy(V, W, sizeof W);
-  return true;
-}
 
 int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, const double *nbr, double *zu,
                  int32_t *status, int32_t *iters, double *stats, bool duals, hipStream_t st,
@@ -543,7 +536,7 @@ int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, cons
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
   if ((h->carry_set || h->slots_set) && st != h->stream) HIP_OK(hipStreamWaitEvent(st, h->ev_stage, 0));  // staged on the handle's stream
   HIP_OK(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(cfz::kNL), h->lds_bytes, st, h->ks, h->lay, B, x0, ref, nbr, zu, status,
+  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(cfz::kNL), h->lds_bytes, st, h->ks, cfz::derive(h->ks), h->lay, B, x0, ref, nbr, zu, status,
                      iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      h->carry_ext ? h->carry_ext : (h->carry_set ? h->carry : nullptr), carry_all, h->slots_set ? h->slots : nullptr);
   h->carry_set = false; h->slots_set = false; h->carry_ext = nullptr;  // the flags of cfz_mpc_set_carry / cfz_mpc_set_slots hold for one solve
@@ -566,7 +559,7 @@ int check(cfz_handle *h, int B) {
 
 extern "C" {
 
-const char *cfz_last_error(void) { return g_err.c_str(); }
+const char *cfz_last_error(void) { return cfz_g_err.c_str(); }
 
 void cfz_default_spec(cfz_spec *s) {
   memset(s, 0, sizeof *s);
@@ -851,287 +844,6 @@ int cfz_vsl_step(cfz_handle *h, int S, int V, int n_own, const int32_t *d_own, i
   return 0;
 }
 
-int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
-                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
-                 int32_t *iters, double *cost) {
-  if (B < 1 || !po || !n_sets || !init_pose || !tube || !traj) return fail("bad argument");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
-  if (device < 0 || device >= ndev) return fail("device index out of range");
-  HIP_OK(hipSetDevice(device));
-  std::vector<cfzp::PSpec> specs(B);
-  std::vector<long long> toff(B), xoff(B), soff(B);
-  long long nt = 0, nx = 0, ns = 0, npts = 0;
-  for (int b = 0; b < B; ++b) {
-    if (n_sets[b] < 2 || po->N < 1) return fail("a plan needs at least two strategy steps");
-    cfzp::PSpec &p = specs[b];
-    memset(&p, 0, sizeof p);
-    p.N = po->N; p.n_chk = n_sets[b] - 1; p.T = po->N * p.n_chk;
-    p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
-    p.bounded_input = po->bounded_input;
-    p.max_iter = po->max_iter; p.max_backtrack = 25; p.filter_cap = 16; p.stall_iters = 0;
-    p.dt = po->dt; p.wb = po->wb; p.shrink = po->shrink_tube;
-    for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
-    memcpy(p.bounds, po->bounds, sizeof p.bounds);
-    p.tol = po->tol; p.constr_viol_tol = po->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = po->mu_init;
-    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
-    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
-    p.reg_primal = 1e-8; p.reg_dual = 1e-9; p.curv_kappa = po->curv_kappa; p.stall_kappa = 0.9;
-    toff[b] = nt; xoff[b] = nx; soff[b] = ns;
-    nt += (long long)p.n_chk * 24; nx += cfzp::dims(p).n; ns += (long long)cfzp::work_doubles(p); npts += p.T + 1;
-  }
-  // initial guess: x, y, psi of every stage (vehicle.py:199-205), everything else zero
-  std::vector<double> X((size_t)nx, 0.0);
-  long long g0 = 0;
-  for (int b = 0; b < B; ++b) {
-    const int T = specs[b].T;
-    if (guess) {
-      for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
-      // The reference seeds x, y, psi only.  With v = 0 everywhere the heading rows of the linearisation have no control
-      // authority (rank deficient once a terminal heading is fixed); the signed speed along the guessed path costs
-      // nothing and takes the solver from 14-150 iterations (one failure) to 8-35 on the four-vehicle strategy.
-      for (int k = 1; k < T; ++k) {
-        const double *p0 = guess + (size_t)(g0 + k) * 3, *p1 = p0 + 3;
-        const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], along = dx * cos(p0[2]) + dy * sin(p0[2]);
-        X[(size_t)xoff[b] + 7 * k + 3] = (along > 0.0 ? 1.0 : (along < 0.0 ? -1.0 : 0.0)) * sqrt(dx * dx + dy * dy) / po->dt;
-      }
-    } else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
-    g0 += T + 1;
-  }
-  cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;
-  long long *doff = nullptr; int32_t *doi = nullptr;
-  HIP_OK(hipMalloc(&dspec, sizeof(cfzp::PSpec) * B)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8));
-  HIP_OK(hipMalloc(&dslab, (size_t)ns * 8)); HIP_OK(hipMalloc(&doff, (size_t)B * 3 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4));
-  HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
-  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzp::PSpec) * B, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff, toff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
-  HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
-  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
-  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
-  for (void *p : {(void *)dspec, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
-  long long o = 0;
-  for (int b = 0; b < B; ++b) {
-    const int T = specs[b].T;
-    for (int k = 0; k <= T; ++k) {
-      const int ku = k < T ? k : T - 1;  // the last input is repeated (vehicle.py:226-229)
-      for (int c = 0; c < 5; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * k + c];
-      for (int c = 5; c < 7; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * ku + c];
-    }
-    o += T + 1;
-    if (status) status[b] = oi[2 * b + 1];
-    if (iters) iters[b] = oi[2 * b];
-    if (cost) cost[b] = od[3 * b];
-  }
-  return 0;
-}
-
-// Lagrange basis on tau = [0, Radau IIA points of degree 5]: A[j][k] = l_j'(tau_k), B[j] = int_0^1 l_j (vehicle.py:54-97)
-static void radau5_tables(double A[6][6], double B[6]) {
-  const double tau[6] = {0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0};
-  for (int j = 0; j < 6; ++j) {
-    double c[7] = {1.0, 0, 0, 0, 0, 0, 0};  // coefficients of l_j, ascending powers
-    int deg = 0;
-    for (int m = 0; m < 6; ++m) {
-      if (m == j) continue;
-      const double den = tau[j] - tau[m];
-      for (int q = deg + 1; q >= 0; --q) c[q] = ((q > 0 ? c[q - 1] : 0.0) - tau[m] * (q <= deg ? c[q] : 0.0)) / den;
-      ++deg;
-    }
-    B[j] = 0.0;
-    for (int q = 0; q <= deg; ++q) B[j] += c[q] / (q + 1);
-    for (int k = 0; k < 6; ++k) {
-      double dv = 0.0, pw = 1.0;
-      for (int q = 1; q <= deg; ++q) { dv += q * c[q] * pw; pw *= tau[k]; }
-      A[j][k] = dv;
-    }
-  }
-}
-
-// B collocation problems in one launch; problem b plans nveh[b] vehicles with one shared dt (1: the single-vehicle plan).
-// Vehicles are numbered through all problems: n_sets, init_pose, final_heading, tube, guess and traj are per vehicle,
-// dt0, dt, status, iters, cost per problem; pairs[b]: vehicle pairs (local indices) with a separation row, per problem.
-static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<std::vector<std::pair<int, int>>> &pairs, const cfz_spec *spec,
-                      const cfz_colloc_options *co, const int32_t *n_sets, const double *init_pose, const double *final_heading,
-                      const double *tube, const double *guess, const double *dt0, double *traj, double *dt, int32_t *status,
-                      int32_t *iters, double *cost) {
-  if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
-  if (device < 0 || device >= ndev) return fail("device index out of range");
-  HIP_OK(hipSetDevice(device));
-  std::vector<double> tab((size_t)std::max(spec->n_obs, 1) * 20, 0.0);
-  for (int j = 0; j < spec->n_obs; ++j) {
-    double V[4][2];
-    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], V)) return fail("obstacle is not a bounded quadrilateral");
-    double *o = tab.data() + (size_t)j * 20;
-    for (int i = 0; i < 4; ++i) { o[2 * i] = spec->A_obs[j][i][0]; o[2 * i + 1] = spec->A_obs[j][i][1]; o[8 + i] = spec->b_obs[j][i];
-                                  o[12 + 2 * i] = V[i][0]; o[13 + 2 * i] = V[i][1]; }
-  }
-  int nv_total = 0;
-  long long nt = 0;
-  for (int b = 0; b < B; ++b) {
-    if (nveh[b] < 1 || nveh[b] > cfzc::kMaxVeh || (int)pairs[b].size() > cfzc::kMaxPairs) return fail("problem size outside compiled limits");
-    for (int a = 0; a < nveh[b]; ++a) { if (n_sets[nv_total + a] < 2) return fail("a plan needs at least two strategy steps"); nt += (long long)(n_sets[nv_total + a] - 1) * 24; }
-    nv_total += nveh[b];
-  }
-  double *dtab = nullptr, *dtube = nullptr;
-  HIP_OK(hipMalloc(&dtab, tab.size() * 8)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8));
-  HIP_OK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
-  std::vector<cfzc::CSpec> specs(B);
-  std::vector<long long> xoff(B), soff(B);
-  std::vector<int32_t> kbs(B);
-  long long nx = 0, ns = 0, to = 0;
-  int v0 = 0;
-  for (int b = 0; b < B; ++b) {
-    cfzc::CSpec &p = specs[b];
-    memset(&p, 0, sizeof p);
-    p.V = nveh[b]; p.Nps = co->N_per_set; p.n_obs = spec->n_obs; p.n_pairs = (int)pairs[b].size();
-    long long npts = 0;
-    for (int a = 0; a < p.V; ++a) {
-      const int v = v0 + a;
-      p.n_chk[a] = n_sets[v] - 1; p.N[a] = p.Nps * p.n_chk[a];
-      p.has_final[a] = final_heading && final_heading[v] == final_heading[v]; p.final_heading[a] = p.has_final[a] ? final_heading[v] : 0.0;
-      for (int i = 0; i < 3; ++i) p.init_pose[a][i] = init_pose[v * 3 + i];
-      p.tube[a] = dtube + to; to += (long long)p.n_chk[a] * 24;
-      npts += (long long)p.N[a] * cfzc::kPts;
-    }
-    for (int e = 0; e < p.n_pairs; ++e) {
-      p.pair_a[e] = pairs[b][e].first; p.pair_b[e] = pairs[b][e].second;
-      if (p.pair_a[e] < 0 || p.pair_b[e] >= p.V || p.pair_a[e] >= p.pair_b[e]) return fail("bad vehicle pair");
-    }
-    p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
-    p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
-    memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
-    radau5_tables(p.A, p.B);
-    p.tol = co->tol; p.constr_viol_tol = co->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = co->mu_init;
-    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
-    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
-    // delta_c = 1e-7 of proximal type (cfz_colloc.inl): while a vehicle stands still with its heading along an axis, the
-    // six ODE rows of x (or y) of an interval only see the rank-5 derivative matrix and their multipliers are not
-    // determined.  Measured on the synthetic strategy: IPOPT's form of delta_c needs 288 iterations at 1e-9, 38 at 1e-7
-    // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
-    // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
-    // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = 1e-7; p.curv_kappa = co->curv_kappa;
-    p.obs_tab = dtab;
-    {  // half-bandwidth of this problem's ordering (51 for one vehicle)
-      const cfzc::CDims d = cfzc::cdims(p);
-      std::vector<int> pos((size_t)d.n + d.m);
-      if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
-      kbs[b] = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
-    }
-    xoff[b] = nx; nx += 7 * npts + 1;
-    soff[b] = ns; ns += (long long)cfzc::work_doubles(p, kbs[b]);
-    v0 += p.V;
-  }
-  std::vector<double> X((size_t)nx);
-  long long g0 = 0;
-  for (int b = 0; b < B; ++b) {  // guess: x, y, psi, v, delta, a, w at every point (:629-636), dt0 (:388-389)
-    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
-    memcpy(X.data() + xoff[b], guess + g0 * 7, (size_t)np_ * 7 * 8);
-    X[(size_t)(xoff[b] + 7 * np_)] = dt0[b];
-    g0 += np_;
-  }
-  cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr, *dkb = nullptr;
-  HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
-  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * cfzc::kOutD * 8));
-  HIP_OK(hipMalloc(&dkb, (size_t)B * 4));
-  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
-  // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
-  // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
-  bool wide = false;
-  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
-  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: single plans through the wide path
-  if (!wide) {
-    const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
-    HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
-  } else {
-    int nk_max = 0;  // the right-hand side of the largest instance in LDS if it fits beside the static arrays of the elimination
-    for (int b = 0; b < B; ++b) nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk);
-    const int lds_doubles = (size_t)nk_max * 8 <= 120 * 1024 ? nk_max : 0;
-    if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
-  }
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
-  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
-  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost));
-  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod, (void *)dkb}) (void)hipFree(p);
-  g0 = 0;
-  for (int b = 0; b < B; ++b) {
-    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
-    memcpy(traj + g0 * 7, X.data() + xoff[b], (size_t)np_ * 7 * 8);
-    dt[b] = X[(size_t)(xoff[b] + 7 * np_)];
-    g0 += np_;
-    if (status) status[b] = oi[2 * b + 1];
-    if (iters) iters[b] = oi[2 * b];
-    if (cost) cost[b] = od[(size_t)cfzc::kOutD * b];
-    if (std::getenv("CFZ_COLLOC_PROFILE")) {  // milliseconds per phase (100 MHz device clock)
-      const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
-      fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
-              b, specs[b].V, kbs[b], oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
-    }
-  }
-  return 0;
-}
-
-int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
-               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
-               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
-  if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
-  std::vector<int32_t> one((size_t)B, 1);
-  std::vector<std::vector<std::pair<int, int>>> none((size_t)B);
-  return colloc_run(device, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
-}
-
-int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
-                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
-                     int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
-  if (B < 1 || V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt || n_pairs < 0) return fail("bad argument");
-  std::vector<std::pair<int, int>> pr;
-  if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
-  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});  // :56-58 all pairs
-  std::vector<std::vector<std::pair<int, int>>> all((size_t)B, pr);
-  std::vector<int32_t> nv((size_t)B, V);
-  return colloc_run(device, B, nv.data(), all, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
-}
-
-void cfz_default_colloc_options(cfz_colloc_options *o) {
-  memset(o, 0, sizeof *o);
-  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5;
-  // mu_init: IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations
-  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1; o->curv_kappa = 1e-8;
-}
-
-void cfz_default_plan_options(cfz_plan_options *o) {
-  memset(o, 0, sizeof *o);
-  o->N = 30; o->max_iter = 500; o->bounded_input = 0;
-  o->dt = 0.1; o->wb = 2.5; o->shrink_tube = 0.5;
-  const double bd[12] = {2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0};
-  memcpy(o->bounds, bd, sizeof bd);
-  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 1e-3; o->curv_kappa = 1e-8;
-}
-
 int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d) {
   if (!h) return fail("null handle");
   if (n < 1 || !poses || !l || !m) return fail("bad argument");
@@ -1271,7 +983,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
     HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
   }
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->ks, h->lay, S, V, K, h->T,
+  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->ks, cfz::derive(h->ks), h->lay, S, V, K, h->T,
                      h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
                      h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      std::getenv("CFZ_LOOP_PRIO_LAG") ? std::atoi(std::getenv("CFZ_LOOP_PRIO_LAG")) : 0);

@@ -1,0 +1,342 @@
+// cfz_planning.hip -- the planning half of libconfrez_hip.so: Vehicle.state_ws (reference confrez/control/vehicle.py:99-231),
+// the single-vehicle collocation plan (vehicle.py:360-661) and the joint plan of several vehicles
+// (multi_vehicle_planner.py:343-480) as gfx950 kernels, with their C ABI entry points (include/confrez_hip.h).
+// Kernel bodies: cfz_plan.inl, cfz_colloc.inl, cfz_band.inl; the separation-certificate geometry is shared with the MPC
+// step (cfz_solver.inl).  Built at -O3 (the MPC half at -O2, see __graft_entry__.build).
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/confrez_hip.h"
+#include "cfz_common.h"
+#include "cfz_solver.inl"
+#include "cfz_plan.inl"
+#include "cfz_colloc.inl"
+
+namespace {
+
+// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
+// bound 512 = at most 256 VGPRs, no AGPRs: see colloc_kernel
+__global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
+                                const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
+  const int b = blockIdx.x;
+  extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
+  if (b >= B) return;
+  // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
+  cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
+}
+
+// single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
+// cfz_colloc.inl.
+// One wavefront runs it, but the bound is 512: with 64 (or 256) the register allocator may use AGPRs beyond 256 VGPRs, and
+// every such build of this kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950 / ROCm 7.2 while the
+// 256-VGPR builds of the same source run (measured, tools/colloc_timing_one.sh).
+#ifndef CFZC_BOUNDS
+#define CFZC_BOUNDS 512
+#endif
+// MODE 1: single-vehicle plans, one wavefront each, elimination in the LDS window; MODE 2: joint plans, 512 threads each,
+// elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
+template <int MODE>
+__global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
+                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles) {
+  const int b = blockIdx.x;
+  // dynamic LDS: MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2 one
+  // right-hand side of the substitution (lds_doubles of them, 0 = none)
+  if (b >= B) return;
+  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
+                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                 int32_t *iters, double *cost) {
+  if (B < 1 || !po || !n_sets || !init_pose || !tube || !traj) return fail("bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  HIP_OK(hipSetDevice(device));
+  std::vector<cfzp::PSpec> specs(B);
+  std::vector<long long> toff(B), xoff(B), soff(B);
+  long long nt = 0, nx = 0, ns = 0, npts = 0;
+  for (int b = 0; b < B; ++b) {
+    if (n_sets[b] < 2 || po->N < 1) return fail("a plan needs at least two strategy steps");
+    cfzp::PSpec &p = specs[b];
+    memset(&p, 0, sizeof p);
+    p.N = po->N; p.n_chk = n_sets[b] - 1; p.T = po->N * p.n_chk;
+    p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
+    p.bounded_input = po->bounded_input;
+    p.max_iter = po->max_iter; p.max_backtrack = 25; p.filter_cap = 16; p.stall_iters = 0;
+    p.dt = po->dt; p.wb = po->wb; p.shrink = po->shrink_tube;
+    for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
+    memcpy(p.bounds, po->bounds, sizeof p.bounds);
+    p.tol = po->tol; p.constr_viol_tol = po->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = po->mu_init;
+    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
+    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
+    p.reg_primal = 1e-8; p.reg_dual = 1e-9; p.curv_kappa = po->curv_kappa; p.stall_kappa = 0.9;
+    toff[b] = nt; xoff[b] = nx; soff[b] = ns;
+    nt += (long long)p.n_chk * 24; nx += cfzp::dims(p).n; ns += (long long)cfzp::work_doubles(p); npts += p.T + 1;
+  }
+  // initial guess: x, y, psi of every stage (vehicle.py:199-205), everything else zero
+  std::vector<double> X((size_t)nx, 0.0);
+  long long g0 = 0;
+  for (int b = 0; b < B; ++b) {
+    const int T = specs[b].T;
+    if (guess) {
+      for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
+      // The reference seeds x, y, psi only.  With v = 0 everywhere the heading rows of the linearisation have no control
+      // authority (rank deficient once a terminal heading is fixed); the signed speed along the guessed path costs
+      // nothing and takes the solver from 14-150 iterations (one failure) to 8-35 on the four-vehicle strategy.
+      for (int k = 1; k < T; ++k) {
+        const double *p0 = guess + (size_t)(g0 + k) * 3, *p1 = p0 + 3;
+        const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], along = dx * cos(p0[2]) + dy * sin(p0[2]);
+        X[(size_t)xoff[b] + 7 * k + 3] = (along > 0.0 ? 1.0 : (along < 0.0 ? -1.0 : 0.0)) * sqrt(dx * dx + dy * dy) / po->dt;
+      }
+    } else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
+    g0 += T + 1;
+  }
+  cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;
+  long long *doff = nullptr; int32_t *doi = nullptr;
+  HIP_OK(hipMalloc(&dspec, sizeof(cfzp::PSpec) * B)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8));
+  HIP_OK(hipMalloc(&dslab, (size_t)ns * 8)); HIP_OK(hipMalloc(&doff, (size_t)B * 3 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4));
+  HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
+  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzp::PSpec) * B, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff, toff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
+  HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
+  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
+  for (void *p : {(void *)dspec, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
+  long long o = 0;
+  for (int b = 0; b < B; ++b) {
+    const int T = specs[b].T;
+    for (int k = 0; k <= T; ++k) {
+      const int ku = k < T ? k : T - 1;  // the last input is repeated (vehicle.py:226-229)
+      for (int c = 0; c < 5; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * k + c];
+      for (int c = 5; c < 7; ++c) traj[(size_t)(o + k) * 7 + c] = X[(size_t)xoff[b] + 7 * ku + c];
+    }
+    o += T + 1;
+    if (status) status[b] = oi[2 * b + 1];
+    if (iters) iters[b] = oi[2 * b];
+    if (cost) cost[b] = od[3 * b];
+  }
+  return 0;
+}
+
+// Lagrange basis on tau = [0, Radau IIA points of degree 5]: A[j][k] = l_j'(tau_k), B[j] = int_0^1 l_j (vehicle.py:54-97)
+static void radau5_tables(double A[6][6], double B[6]) {
+  const double tau[6] = {0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0};
+  for (int j = 0; j < 6; ++j) {
+    double c[7] = {1.0, 0, 0, 0, 0, 0, 0};  // coefficients of l_j, ascending powers
+    int deg = 0;
+    for (int m = 0; m < 6; ++m) {
+      if (m == j) continue;
+      const double den = tau[j] - tau[m];
+      for (int q = deg + 1; q >= 0; --q) c[q] = ((q > 0 ? c[q - 1] : 0.0) - tau[m] * (q <= deg ? c[q] : 0.0)) / den;
+      ++deg;
+    }
+    B[j] = 0.0;
+    for (int q = 0; q <= deg; ++q) B[j] += c[q] / (q + 1);
+    for (int k = 0; k < 6; ++k) {
+      double dv = 0.0, pw = 1.0;
+      for (int q = 1; q <= deg; ++q) { dv += q * c[q] * pw; pw *= tau[k]; }
+      A[j][k] = dv;
+    }
+  }
+}
+
+// B collocation problems in one launch; problem b plans nveh[b] vehicles with one shared dt (1: the single-vehicle plan).
+// Vehicles are numbered through all problems: n_sets, init_pose, final_heading, tube, guess and traj are per vehicle,
+// dt0, dt, status, iters, cost per problem; pairs[b]: vehicle pairs (local indices) with a separation row, per problem.
+static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<std::vector<std::pair<int, int>>> &pairs, const cfz_spec *spec,
+                      const cfz_colloc_options *co, const int32_t *n_sets, const double *init_pose, const double *final_heading,
+                      const double *tube, const double *guess, const double *dt0, double *traj, double *dt, int32_t *status,
+                      int32_t *iters, double *cost) {
+  if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  HIP_OK(hipSetDevice(device));
+  std::vector<double> tab((size_t)std::max(spec->n_obs, 1) * 20, 0.0);
+  for (int j = 0; j < spec->n_obs; ++j) {
+    double V[4][2];
+    if (!quad_vertices(spec->A_obs[j], spec->b_obs[j], V)) return fail("obstacle is not a bounded quadrilateral");
+    double *o = tab.data() + (size_t)j * 20;
+    for (int i = 0; i < 4; ++i) { o[2 * i] = spec->A_obs[j][i][0]; o[2 * i + 1] = spec->A_obs[j][i][1]; o[8 + i] = spec->b_obs[j][i];
+                                  o[12 + 2 * i] = V[i][0]; o[13 + 2 * i] = V[i][1]; }
+  }
+  int nv_total = 0;
+  long long nt = 0;
+  for (int b = 0; b < B; ++b) {
+    if (nveh[b] < 1 || nveh[b] > cfzc::kMaxVeh || (int)pairs[b].size() > cfzc::kMaxPairs) return fail("problem size outside compiled limits");
+    for (int a = 0; a < nveh[b]; ++a) { if (n_sets[nv_total + a] < 2) return fail("a plan needs at least two strategy steps"); nt += (long long)(n_sets[nv_total + a] - 1) * 24; }
+    nv_total += nveh[b];
+  }
+  double *dtab = nullptr, *dtube = nullptr;
+  HIP_OK(hipMalloc(&dtab, tab.size() * 8)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8));
+  HIP_OK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
+  std::vector<cfzc::CSpec> specs(B);
+  std::vector<long long> xoff(B), soff(B);
+  std::vector<int32_t> kbs(B);
+  long long nx = 0, ns = 0, to = 0;
+  int v0 = 0;
+  for (int b = 0; b < B; ++b) {
+    cfzc::CSpec &p = specs[b];
+    memset(&p, 0, sizeof p);
+    p.V = nveh[b]; p.Nps = co->N_per_set; p.n_obs = spec->n_obs; p.n_pairs = (int)pairs[b].size();
+    long long npts = 0;
+    for (int a = 0; a < p.V; ++a) {
+      const int v = v0 + a;
+      p.n_chk[a] = n_sets[v] - 1; p.N[a] = p.Nps * p.n_chk[a];
+      p.has_final[a] = final_heading && final_heading[v] == final_heading[v]; p.final_heading[a] = p.has_final[a] ? final_heading[v] : 0.0;
+      for (int i = 0; i < 3; ++i) p.init_pose[a][i] = init_pose[v * 3 + i];
+      p.tube[a] = dtube + to; to += (long long)p.n_chk[a] * 24;
+      npts += (long long)p.N[a] * cfzc::kPts;
+    }
+    for (int e = 0; e < p.n_pairs; ++e) {
+      p.pair_a[e] = pairs[b][e].first; p.pair_b[e] = pairs[b][e].second;
+      if (p.pair_a[e] < 0 || p.pair_b[e] >= p.V || p.pair_a[e] >= p.pair_b[e]) return fail("bad vehicle pair");
+    }
+    p.max_iter = co->max_iter; p.max_backtrack = 25; p.filter_cap = 16;
+    p.wb = spec->wb; p.dmin = spec->dmin; p.shrink = co->shrink_tube; p.dt0 = dt0[b];
+    memcpy(p.bounds, spec->bounds, sizeof p.bounds); memcpy(p.g, spec->g, sizeof p.g);
+    radau5_tables(p.A, p.B);
+    p.tol = co->tol; p.constr_viol_tol = co->constr_viol_tol; p.dual_inf_tol = 1.0; p.compl_inf_tol = 1e-4; p.mu_init = co->mu_init;
+    p.kappa_eps = 10.0; p.kappa_mu = 0.2; p.theta_mu = 1.5; p.tau_min = 0.99; p.bound_push = 1e-2; p.bound_frac = 1e-2; p.s_max = 100.0;
+    p.kappa_sigma = 1e10; p.eta_phi = 1e-8; p.gamma_theta = 1e-5; p.gamma_phi = 1e-8; p.delta_sw = 1.0; p.s_theta = 1.1; p.s_phi = 2.3;
+    // delta_c = 1e-7 of proximal type (cfz_colloc.inl): while a vehicle stands still with its heading along an axis, the
+    // six ODE rows of x (or y) of an interval only see the rank-5 derivative matrix and their multipliers are not
+    // determined.  Measured on the synthetic strategy: IPOPT's form of delta_c needs 288 iterations at 1e-9, 38 at 1e-7
+    // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
+    // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
+    // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
+    p.reg_primal = 1e-8; p.reg_dual = 1e-7; p.curv_kappa = co->curv_kappa;
+    p.obs_tab = dtab;
+    {  // half-bandwidth of this problem's ordering (51 for one vehicle)
+      const cfzc::CDims d = cfzc::cdims(p);
+      std::vector<int> pos((size_t)d.n + d.m);
+      if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
+      kbs[b] = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
+    }
+    xoff[b] = nx; nx += 7 * npts + 1;
+    soff[b] = ns; ns += (long long)cfzc::work_doubles(p, kbs[b]);
+    v0 += p.V;
+  }
+  std::vector<double> X((size_t)nx);
+  long long g0 = 0;
+  for (int b = 0; b < B; ++b) {  // guess: x, y, psi, v, delta, a, w at every point (:629-636), dt0 (:388-389)
+    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
+    memcpy(X.data() + xoff[b], guess + g0 * 7, (size_t)np_ * 7 * 8);
+    X[(size_t)(xoff[b] + 7 * np_)] = dt0[b];
+    g0 += np_;
+  }
+  cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr, *dkb = nullptr;
+  HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
+  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * cfzc::kOutD * 8));
+  HIP_OK(hipMalloc(&dkb, (size_t)B * 4));
+  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
+  // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
+  bool wide = false;
+  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
+  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: single plans through the wide path
+  if (!wide) {
+    const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
+    HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
+  } else {
+    int nk_max = 0;  // the right-hand side of the largest instance in LDS if it fits beside the static arrays of the elimination
+    for (int b = 0; b < B; ++b) nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk);
+    const int lds_doubles = (size_t)nk_max * 8 <= 120 * 1024 ? nk_max : 0;
+    if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
+  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost));
+  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod, (void *)dkb}) (void)hipFree(p);
+  g0 = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long np_ = (long long)cfzc::cdims(specs[b]).np;
+    memcpy(traj + g0 * 7, X.data() + xoff[b], (size_t)np_ * 7 * 8);
+    dt[b] = X[(size_t)(xoff[b] + 7 * np_)];
+    g0 += np_;
+    if (status) status[b] = oi[2 * b + 1];
+    if (iters) iters[b] = oi[2 * b];
+    if (cost) cost[b] = od[(size_t)cfzc::kOutD * b];
+    if (std::getenv("CFZ_COLLOC_PROFILE")) {  // milliseconds per phase (100 MHz device clock)
+      const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
+      fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
+              b, specs[b].V, kbs[b], oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
+    }
+  }
+  return 0;
+}
+
+int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+               const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+               const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
+  std::vector<int32_t> one((size_t)B, 1);
+  std::vector<std::vector<std::pair<int, int>>> none((size_t)B);
+  return colloc_run(device, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+}
+
+int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+                     const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
+                     int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  if (B < 1 || V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt || n_pairs < 0) return fail("bad argument");
+  std::vector<std::pair<int, int>> pr;
+  if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});  // :56-58 all pairs
+  std::vector<std::vector<std::pair<int, int>>> all((size_t)B, pr);
+  std::vector<int32_t> nv((size_t)B, V);
+  return colloc_run(device, B, nv.data(), all, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+}
+
+void cfz_default_colloc_options(cfz_colloc_options *o) {
+  memset(o, 0, sizeof *o);
+  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5;
+  // mu_init: IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1; o->curv_kappa = 1e-8;
+}
+
+void cfz_default_plan_options(cfz_plan_options *o) {
+  memset(o, 0, sizeof *o);
+  o->N = 30; o->max_iter = 500; o->bounded_input = 0;
+  o->dt = 0.1; o->wb = 2.5; o->shrink_tube = 0.5;
+  const double bd[12] = {2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0};
+  memcpy(o->bounds, bd, sizeof bd);
+  o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 1e-3; o->curv_kappa = 1e-8;
+}
+
+}  // extern "C"

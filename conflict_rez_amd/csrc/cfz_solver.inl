@@ -57,6 +57,7 @@ constexpr int kMaxN = kNL / kLPS;
 // the sweeps run on lane 0 of the workgroup, out of line; every lane calls (uniform control flow), lane 0 works
 #define CFZ_SERIAL(call) do { call; __syncthreads(); } while (0)
 #define CFZ_WSP(p) ((cfz::wsp_f64 *)(p))
+#define CFZ_UNIFORM(v) cfz::uniform_value(v)
 #else
 #define CFZ_LANES(tid) for (int tid = 0; tid < cfz::kNL; ++tid) {
 #define CFZ_MID } for (int tid = 0; tid < cfz::kNL; ++tid) {
@@ -67,6 +68,7 @@ constexpr int kMaxN = kNL / kLPS;
 #define CFZ_REDUCE(NS, NX, NI, part, out) cfz::reduce_all_emu<NS, NX, NI>(part, out)
 #define CFZ_SERIAL(call) do { call; } while (0)
 #define CFZ_WSP(p) (p)
+#define CFZ_UNIFORM(v) (v)
 #endif
 
 // Diagnostic build only (-DCFZ_STAMPS): shader-clock cycles per phase of the solver, summed over the
@@ -99,6 +101,32 @@ struct KSpec {
   // (L1/L2-resident; indexing the arrays above with a lane-varying j would copy this struct to scratch)
   const double *obs_tab;
 };
+
+// Constants derived from the spec, formed on the HOST and passed to the kernel beside it (scalar registers).  Formed in the
+// kernel they are loop-invariant vector-pipe results: the compiler hoists them out of the iteration loop into VGPR pairs,
+// two dozen of them, and spills them to scratch.
+struct KDer {
+  double w2[6];        // 2 w_i
+  double hb[5];        // constant part of the stage Hessian diagonal: 2 w0 + reg, 2 w1 + reg, 2 w2 + reg, 2 w5 + reg, 2 w3 + reg
+  double mg, q0, q1, q2, iq0, iq1;  // convexity safeguard of the row curvature (assembly)
+  double iks;          // 1 / kappa_sigma
+  double rk_h, rk_hh, rk_h6, iwb;   // dt / M, half of it, a sixth of it, 1 / wheelbase
+  double mu_floor;
+};
+CFZ_FN KDer derive(const KSpec &sp) {
+  KDer d;
+  const double *w = sp.weights;
+  for (int i = 0; i < 6; ++i) d.w2[i] = 2 * w[i];
+  d.hb[0] = 2 * w[0] + sp.reg_primal; d.hb[1] = 2 * w[1] + sp.reg_primal; d.hb[2] = 2 * w[2] + sp.reg_primal;
+  d.hb[3] = 2 * w[5] + sp.reg_primal; d.hb[4] = 2 * w[3] + sp.reg_primal;
+  d.mg = 0.2 * fmin(w[0], fmin(w[1], w[2]));
+  d.q0 = 2 * w[0] - d.mg; d.q1 = 2 * w[1] - d.mg; d.q2 = 2 * w[2] - d.mg;
+  d.iq0 = 1.0 / d.q0; d.iq1 = 1.0 / d.q1;
+  d.iks = 1.0 / sp.kappa_sigma;
+  d.rk_h = sp.dt / sp.rk_substeps; d.rk_hh = 0.5 * d.rk_h; d.rk_h6 = d.rk_h * (1.0 / 6.0); d.iwb = 1.0 / sp.wb;
+  d.mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
+  return d;
+}
 
 // Workspace layout (offsets in doubles) for one instance.
 struct Lay {
@@ -161,6 +189,11 @@ __device__ __forceinline__ double quad_sum(double v) {
 __device__ __forceinline__ double lane_value(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// a value every lane holds identically -> scalar registers (the compiler cannot know it is uniform after an LDS read; as a
+// vector value each of the solver's two dozen scalars would occupy a VGPR pair for the whole iteration and spill)
+__device__ __forceinline__ double uniform_value(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <int OP> __device__ __forceinline__ double wave_reduce(double v) {
   v = op2<OP>(v, dpp_mov<0xB1>(v));
   v = op2<OP>(v, dpp_mov<0x4E>(v));
@@ -185,7 +218,8 @@ __device__ __forceinline__ void reduce_all(double *m, const Lay &L, int &xpar, c
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < n; ++i) out[i] = i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i]));
+  for (int i = 0; i < n; ++i)
+    out[i] = uniform_value(i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i])));
   xpar ^= 1;
 }
 #else
@@ -229,9 +263,18 @@ CFZ_FN void small_sincos(double e, double *s, double *c) {
 // stage points (one fixed rotation), the heading by small increments (|h psi'| <= 0.03 rad inside the
 // actuator limits), so the stage-point sines/cosines come from rotating the previous ones.
 template <bool SENS>
+CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double hh, double h6, double iwb, int M, double out[5],
+                       double S[3][5]);
+template <bool SENS>
 CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double wb, int M, double out[5],
                      double S[3][5]) {
-  const double h = dt / M, h6 = h * (1.0 / 6.0), iwb = 1.0 / wb;
+  const double h = dt / M;
+  rk4_step_h<SENS>(z, a, w, h, 0.5 * h, h * (1.0 / 6.0), 1.0 / wb, M, out, S);
+}
+// the same with the step constants formed by the caller (the solver passes host-derived ones, KDer)
+template <bool SENS>
+CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double hh, double h6, double iwb, int M, double out[5],
+                       double S[3][5]) {
   double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
   if (SENS) {
     for (int r = 0; r < 3; ++r)
@@ -241,7 +284,7 @@ CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double 
   double sp_, cp_, sd0, cd0, sh, ch;  // heading and steering angle at the sub-step start, half-step steering rotation
   sincos(psi, &sp_, &cp_);
   sincos(de, &sd0, &cd0);
-  small_sincos(0.5 * h * w, &sh, &ch);
+  small_sincos(hh * w, &sh, &ch);
   double tsub = 0.0;  // time since the start of the interval: dv/da = ddelta/dw = tsub
   for (int m = 0; m < M; ++m) {
     double ax = 0, ay = 0, ap = 0;  // weighted stage sums
@@ -259,7 +302,7 @@ CFZ_CALL void rk4_step(const double z[5], double a, double w, double dt, double 
     const double sd2 = sd1 * ch + cd1 * sh, cd2 = cd1 * ch - sd1 * sh;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : hh);
       const double wsum = (st == 0 || st == 3) ? 1.0 : 2.0;
       const double vs = v + wprev * a;
       double s = sp_, c = cp_;
@@ -345,10 +388,10 @@ CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[
 }
 
 CFZ_FN double pick4(const double d[4], int v) {
-  double r = d[0];
-#pragma unroll
-  for (int i = 1; i < 4; ++i) if (i == v) r = d[i];
-  return r;
+  // two levels of selects on the bits of v (written as a loop over the array the compiler turned the choice into a stack
+  // array and an indexed scratch load)
+  const double lo = (v & 1) ? d[1] : d[0], hi = (v & 1) ? d[3] : d[2];
+  return (v & 2) ? hi : lo;
 }
 
 // All 32 face-vertex distances of a block in one pass: D[f] (f = 0..3) kind 1, polygon face f against the four body
@@ -578,15 +621,15 @@ CFZ_FN double stage_cost(const KSpec &sp, const double *ref, int k, const double
   return w[0] * ex * ex + w[1] * ey * ey + w[2] * ep * ep + w[3] * p[5] * p[5] + w[4] * p[3] * p[3] * p[6] * p[6] +
          w[5] * p[4] * p[4];
 }
-CFZ_FN void stage_grad(const KSpec &sp, const double *ref, int k, const double p[kNP], double gr[kNP]) {
-  const double *w = sp.weights; const int N = sp.N;
-  gr[0] = 2 * w[0] * (p[0] - ref[k]);
-  gr[1] = 2 * w[1] * (p[1] - ref[N + k]);
-  gr[2] = 2 * w[2] * (p[2] - ref[2 * N + k]);
-  gr[3] = 2 * w[4] * p[3] * p[6] * p[6];
-  gr[4] = 2 * w[5] * p[4];
-  gr[5] = 2 * w[3] * p[5];
-  gr[6] = 2 * w[4] * p[3] * p[3] * p[6];
+CFZ_FN void stage_grad(const KSpec &sp, const KDer &dv, const double *ref, int k, const double p[kNP], double gr[kNP]) {
+  const double *w2 = dv.w2; const int N = sp.N;
+  gr[0] = w2[0] * (p[0] - ref[k]);
+  gr[1] = w2[1] * (p[1] - ref[N + k]);
+  gr[2] = w2[2] * (p[2] - ref[2 * N + k]);
+  gr[3] = w2[4] * p[3] * p[6] * p[6];
+  gr[4] = w2[5] * p[4];
+  gr[5] = w2[3] * p[5];
+  gr[6] = w2[4] * p[3] * p[3] * p[6];
 }
 
 // dense views of the compact stage storage
@@ -621,9 +664,8 @@ CFZ_FN void sym2_solve6(const double M[2][2], const double rhs[2][6], double out
 // RK4 with the sensitivities of (x, y, psi) for TWO columns of (psi0, v0, delta0, a, w): column qa (0..3, chosen by the
 // lane) and column 4.  The four lanes of a stage's quad run this in lockstep with qa = 0, 1, 2, 3 and so cover all five
 // columns; the nominal trajectory is the same in all of them.  Same recurrences as rk4_step<true>, column by column.
-CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double wb, int M, int qa, double out[5],
-                        double Sa[3], double Sb[3]) {
-  const double h = dt / M, h6 = h * (1.0 / 6.0), iwb = 1.0 / wb;
+CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double h, double hh, double h6, double iwb, int M, int qa,
+                        double out[5], double Sa[3], double Sb[3]) {
   double x = z[0], y = z[1], psi = z[2], v = z[3], de = z[4];
   Sa[0] = 0.0; Sa[1] = 0.0; Sa[2] = (qa == 0) ? 1.0 : 0.0;
   Sb[0] = 0.0; Sb[1] = 0.0; Sb[2] = 0.0;
@@ -634,7 +676,7 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double
   double sp_, cp_, sd0, cd0, sh, ch;
   sincos(psi, &sp_, &cp_);
   sincos(de, &sd0, &cd0);
-  small_sincos(0.5 * h * w, &sh, &ch);
+  small_sincos(hh * w, &sh, &ch);
   double tsub = 0.0;
   for (int m_ = 0; m_ < M; ++m_) {
     double ax = 0, ay = 0, ap = 0, kp = 0;
@@ -643,7 +685,7 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double
     const double sd2 = sd1 * ch + cd1 * sh, cd2 = cd1 * ch - sd1 * sh;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+      const double wprev = (st == 0) ? 0.0 : ((st == 3) ? h : hh);
       const double wsum = (st == 0 || st == 3) ? 1.0 : 2.0;
       const double vs = v + wprev * a;
       double s = sp_, c = cp_;
@@ -688,7 +730,7 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double dt, double
 // ------------------------------------------------------------------------------ trial-point evaluation
 // theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lane partials: part 0 theta, 1 phi without the
 // log terms, 2 sum of logs, 3 = 1 if a bound or a slack is not strictly inside.
-CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, const Lay &L, double alpha, int tid,
+CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg, double *m, const Lay &L, double alpha, int tid,
                              double &th_o, double &ph_o, double &ll_o, double &bad_o) {
   const int N = sp.N, nb = L.nb;
   const int k = tid >> 2, sub = tid & 3;
@@ -719,7 +761,7 @@ CFZ_CALL void merit_partials(const KSpec &sp, const double *refg, double *m, con
       if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
       if (k + 1 < N) {
         double F[5];
-        rk4_step<false>(pt, pt[5], pt[6], sp.dt, sp.wb, sp.rk_substeps, F, nullptr);
+        rk4_step_h<false>(pt, pt[5], pt[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, F, nullptr);
         for (int i = 0; i < 5; ++i)
           th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
       }
@@ -1089,12 +1131,12 @@ CFZ_FN CarryLay carry_layout(int N, int nb) {
 
 // wst: this instance's carry record (nullptr: none kept).  carry_in != 0: start from it if it is valid
 // (oracle/mpc_nlp.py warm_from_carry).  A converged solve refreshes the record, any other outcome invalidates it.
-CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *refg, const double *nbrg, double *zu,
+CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, const double *refg, const double *nbrg, double *zu,
                            double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo, double *wst = nullptr,
                            int carry_in = 0) {
   const int N = sp.N, nb = L.nb, nr = L.nr, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
   const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
-  const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
+  const double mu_floor = dv.mu_floor;
   double stall_ref = 0.0;
   int stall_cnt = 0;
   int xpar = 0;  // which half of the wavefront exchange buffer the next reduction uses
@@ -1136,8 +1178,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
     return;
   }
-  const bool warm = wst != nullptr && carry_in != 0 && wst[CL.valid] != 0.0;
-  const double mu0 = warm ? fmin(fmax(wst[CL.mu], mu_floor), sp.mu_init) : sp.mu_init;
+  const bool warm = wst != nullptr && carry_in != 0 && CFZ_UNIFORM(wst[CL.valid]) != 0.0;
+  const double mu0 = CFZ_UNIFORM(warm ? fmin(fmax(CFZ_UNIFORM(wst[CL.mu]), mu_floor), sp.mu_init) : sp.mu_init);
   CFZ_LANES(tid)
     const int k = tid >> 2, sub = tid & 3;
     if (k < N) {
@@ -1264,7 +1306,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         if (k + 1 < N) {
           // the quad integrates the stage together: lane sub carries sensitivity column sub, every lane column 4
           double F[5], Sa[3], Sb[3];
-          rk4_sens2(pk, pk[5], pk[6], sp.dt, sp.wb, sp.rk_substeps, sub, F, Sa, Sb);
+          rk4_sens2(pk, pk[5], pk[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
           for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
           if (sub == 0) {
             for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
@@ -1280,7 +1322,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_REDUCE(1, 1, 0, rd, ro);
     const double theta = ro[0], cviol = ro[1];
     CFZ_STAMP(1);  // working set, rows, dynamics
-    if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+    if (theta_min < 0.0) { theta_min = CFZ_UNIFORM(1e-4 * fmax(1.0, theta)); theta_max = CFZ_UNIFORM(1e4 * fmax(1.0, theta)); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
@@ -1309,7 +1351,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         const bool first = sub == 0;  // the stage's own terms enter the sums once, through the quad's first lane
         const double *pk = m + L.p + k * kNP;
         double r[kNP];
-        stage_grad(sp, refg, k, pk, r);
+        stage_grad(sp, dv, refg, k, pk, r);
         r[0] += CFZ_QSUM(qx, 0); r[1] += CFZ_QSUM(qx, 1); r[2] += CFZ_QSUM(qx, 2);
         if (first) fv = stage_cost(sp, refg, k, pk);
         if (tid == 0) for (int i = 0; i < 5; ++i) snu += fabs(m[L.pi0 + i]);
@@ -1338,9 +1380,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_END
     CFZ_REDUCE(4, 2, 0, rd, ro);
     const double sum_nu = ro[0], sum_z = ro[1], fval = ro[2], logsum = ro[3], dual_inf = ro[4], cmp0 = ro[5];
-    const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max;
-    const double s_c = fmax(sp.s_max, sum_z / (double)n_bnd) / sp.s_max;
-    err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
+    // scalars every lane computes identically go back to scalar registers: a double computed on the vector pipe lives in a
+    // VGPR pair, and two dozen of them live across the whole iteration were what spilled to scratch
+    const double s_d = CFZ_UNIFORM(fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max);
+    const double s_c = CFZ_UNIFORM(fmax(sp.s_max, sum_z / (double)n_bnd) / sp.s_max);
+    err0 = CFZ_UNIFORM(fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c)));
     CFZ_STAMP(2);  // residuals
     fval_last = fval;
     if (!isfinite(err0)) { status = 3; break; }
@@ -1367,10 +1411,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       CFZ_END
       CFZ_REDUCE(0, 1, 0, rd, ro);
       const double emu = fmax(dual_inf / s_d, fmax(cviol, ro[0] / s_c));
-      if (emu <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
+      if (emu <= sp.kappa_eps * mu) mu = CFZ_UNIFORM(fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))));
       else break;
     }
-    const double tau = fmax(sp.tau_min, 1.0 - mu);
+    const double tau = CFZ_UNIFORM(fmax(sp.tau_min, 1.0 - mu));
     CFZ_STAMP(3);  // barrier update
     // ---- condensed stage QP: H_k (compact), g_k ---------------------------------------------------
     // rows: g += a (S c - mu / sigma), H += S a a' and the curvature of the separation rows weighted with their multipliers,
@@ -1414,13 +1458,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_MID
       const int k = tid >> 2, sub = tid & 3;
       if (k < N) {
-        const double *w = sp.weights; const double *pk = m + L.p + k * kNP;
+        const double *pk = m + L.p + k * kNP;
         double g[kNP], h[11];
-        stage_grad(sp, refg, k, pk, g);
-        h[0] = 2 * w[0]; h[1] = 2 * w[1]; h[2] = 2 * w[2]; h[3] = 2 * w[4] * pk[6] * pk[6]; h[4] = 2 * w[5];
-        h[5] = 2 * w[3]; h[6] = 2 * w[4] * pk[3] * pk[3]; h[7] = 0.0; h[8] = 0.0; h[9] = 0.0;
-        h[10] = 2 * w[4] * pk[3] * pk[6];
-        for (int i = 0; i < kNP; ++i) h[i] += sp.reg_primal;
+        stage_grad(sp, dv, refg, k, pk, g);
+        const double w42 = dv.w2[4];
+        h[0] = dv.hb[0]; h[1] = dv.hb[1]; h[2] = dv.hb[2]; h[3] = w42 * pk[6] * pk[6] + sp.reg_primal; h[4] = dv.hb[3];
+        h[5] = dv.hb[4]; h[6] = w42 * pk[3] * pk[3] + sp.reg_primal; h[7] = 0.0; h[8] = 0.0; h[9] = 0.0;
+        h[10] = w42 * pk[3] * pk[6];
         for (int q = 0; q < 6; ++q) {
           const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
           h[bcol(q)] += m[L.zl + k * 6 + q] * il + m[L.zu + k * 6 + q] * iu;
@@ -1432,9 +1476,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         if (sp.row_curvature) {
           const double ca = CFZ_QSUM(qx, 9), cb = CFZ_QSUM(qx, 10), cc = CFZ_QSUM(qx, 11);
           // convexity safeguard: scale by th in {1, 1/2, .., 2^-9, 0} until diag(2w) + th C keeps the margin 0.2 min(w)
-          const double mg = 0.2 * fmin(w[0], fmin(w[1], w[2]));
-          const double q0 = 2 * w[0] - mg, q1 = 2 * w[1] - mg, q2 = 2 * w[2] - mg;
-          const double quad = ca * ca * (1.0 / q0) + cb * cb * (1.0 / q1);
+          const double q2 = dv.q2;
+          const double quad = ca * ca * dv.iq0 + cb * cb * dv.iq1;
           double th = 1.0;
           for (int hh = 0; hh < 11; ++hh) {
             if (hh == 10) { th = 0.0; break; }
@@ -1485,7 +1528,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         }
         if (sub == 0) {
           double g[kNP];
-          stage_grad(sp, refg, k, pk, g);
+          stage_grad(sp, dv, refg, k, pk, g);
           for (int q = 0; q < 6; ++q) {
             const double dx = dpk[bcol(q)];
             const double il = 1.0 / (pk[bcol(q)] - sp.bounds[2 * q]), iu = 1.0 / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
@@ -1502,20 +1545,20 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
     CFZ_END
     CFZ_REDUCE(1, 2, 0, rd, ro);
     const double dphi = ro[0], rp_max = ro[1], rd_max = ro[2];
-    const double a_pri = (rp_max > tau) ? tau / rp_max : 1.0, a_dual = (rd_max > tau) ? tau / rd_max : 1.0;
+    const double a_pri = CFZ_UNIFORM((rp_max > tau) ? tau / rp_max : 1.0), a_dual = CFZ_UNIFORM((rd_max > tau) ? tau / rd_max : 1.0);
     CFZ_STAMP(6);  // step
     // ---- filter line search --------------------------------------------------------------------------------
-    const double phi0 = fval - mu * logsum;
+    const double phi0 = CFZ_UNIFORM(fval - mu * logsum);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; int accepted = 0, f_type = 0;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
       CFZ_LANES(tid)
         double th_, ph_, ll_, bad_;
-        merit_partials(sp, refg, m, L, alpha, tid, th_, ph_, ll_, bad_);
+        merit_partials(sp, dv, refg, m, L, alpha, tid, th_, ph_, ll_, bad_);
         CFZ_P(rd, 0) = th_; CFZ_P(rd, 1) = ph_; CFZ_P(rd, 2) = ll_; CFZ_P(rd, 3) = bad_;
       CFZ_END
       CFZ_REDUCE(3, 1, 0, rd, ro);
-      const double th_t = ro[0], ph_t = ro[1] - mu * ro[2];
+      const double th_t = ro[0], ph_t = CFZ_UNIFORM(ro[1] - mu * ro[2]);
       int ok = (ro[3] == 0.0) && isfinite(th_t) && isfinite(ph_t) && th_t <= theta_max;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= m[L.filt + 2 * q] && ph_t >= m[L.filt + 2 * q + 1]) { ok = 0; break; }
       f_type = 0;
@@ -1525,7 +1568,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
       }
       if (ok) { accepted = 1; break; }
-      alpha *= 0.5;
+      alpha = CFZ_UNIFORM(alpha * 0.5);
     }
     CFZ_STAMP(7);  // line search
     if (!accepted) { status = 2; break; }
@@ -1544,7 +1587,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
       const int k = tid >> 2, sub = tid & 3;
       if (tid < 5) m[L.pi0 + tid] += alpha * m[L.dpi0 + tid];
       if (k < N) {
-        const double ks = sp.kappa_sigma, iks = 1.0 / sp.kappa_sigma;
+        const double ks = sp.kappa_sigma, iks = dv.iks;
         for (int jb = sub; jb < nb; jb += kLPS)
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
@@ -1596,25 +1639,39 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
         const int kind = cert >> 4, f = (cert >> 2) & 3;
         double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
         if (j < n_obs) {
+          // (every index into A, V, lam, mu below is resolved by selects: a runtime index would put the arrays in scratch)
           if (kind == 1) {  // n = A_f ; G' mu = -R' n
-            lam[f] = 1.0;
-            const double mx = -(c * A[f][0] + s * A[f][1]), my = -(-s * A[f][0] + c * A[f][1]);
+            double af0 = A[0][0], af1 = A[0][1];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) if (i == f) { af0 = A[i][0]; af1 = A[i][1]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam[i] = (i == f) ? 1.0 : 0.0;
+            const double mx = -(c * af0 + s * af1), my = -(-s * af0 + c * af1);
             muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
           } else {  // n = -R G_f ; A' lam = n from the two obstacle faces through vertex v
-            muv[f] = 1.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) muv[i] = (i == f) ? 1.0 : 0.0;
             const int v = cert & 3;
             const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
             const double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
+            double vx = V[0][0], vy = V[0][1];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) if (i == v) { vx = V[i][0]; vy = V[i][1]; }
             // the two faces active at vertex v: those with |A_i.V_v - b_i| smallest
             int i0 = 0, i1 = 1; double r0 = INFINITY, r1 = INFINITY;
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const double r = fabs(A[i][0] * V[v][0] + A[i][1] * V[v][1] - b[i]);
+              const double r = fabs(A[i][0] * vx + A[i][1] * vy - b[i]);
               if (r < r0) { r1 = r0; i1 = i0; r0 = r; i0 = i; } else if (r < r1) { r1 = r; i1 = i; }
             }
             const int ia = i0 < i1 ? i0 : i1, ib = i0 < i1 ? i1 : i0;
-            const double det = A[ia][0] * A[ib][1] - A[ib][0] * A[ia][1];
-            lam[ia] = fmax((A[ib][1] * nx - A[ib][0] * ny) / det, 0.0);
-            lam[ib] = fmax((-A[ia][1] * nx + A[ia][0] * ny) / det, 0.0);
+            double a0x = 0, a0y = 0, a1x = 0, a1y = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { if (i == ia) { a0x = A[i][0]; a0y = A[i][1]; } if (i == ib) { a1x = A[i][0]; a1y = A[i][1]; } }
+            const double det = a0x * a1y - a1x * a0y;
+            const double la = fmax((a1y * nx - a1x * ny) / det, 0.0), lb = fmax((-a0y * nx + a0x * ny) / det, 0.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam[i] = (i == ia) ? la : ((i == ib) ? lb : 0.0);
           }
           for (int i = 0; i < 4; ++i) { duo.l[k * 4 * n_obs + 4 * j + i] = lam[i]; duo.mm[k * 4 * n_obs + 4 * j + i] = muv[i]; }
         } else {
@@ -1625,12 +1682,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const double *x0g, const double *ref
           const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
           if (kind == 1) {  // a face of the OTHER vehicle: w = -Ro G_f, mu = e_f, lam = posneg(R' w)
             wx = -(co * gx - so * gy); wy = -(so * gx + co * gy);
-            muv[f] = 1.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) muv[i] = (i == f) ? 1.0 : 0.0;
             const double lx = c * wx + s * wy, ly = -s * wx + c * wy;
             lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
           } else {  // a face of this vehicle: w = R G_f, lam = e_f, mu = posneg(-Ro' w)
             wx = c * gx - s * gy; wy = s * gx + c * gy;
-            lam[f] = 1.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lam[i] = (i == f) ? 1.0 : 0.0;
             const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);
             muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
           }

@@ -155,16 +155,17 @@ int cfz_vsl_step(cfz_handle *h, int S, int V, int n_own, const int32_t *d_own, i
  * Vehicle.dual_ws (confrez/control/vehicle.py:233-296): for n fixed poses[n][3] = (x, y, psi) the duals
  * l, m [n][4*n_obs] that certify the separation d[n][n_obs] (may be NULL) of the vehicle body from every
  * static obstacle of the handle's spec.  The reference maximises that separation with IPOPT
- * (tol 1e-8); here it is the closed-form maximum over the face normals of both polygons, which
- * satisfies the same rows (:276-280) exactly and equals the optimum whenever the closest features
- * are a face and a vertex. */
+ * (tol 1e-8); here it is the optimum in closed form: d = the Euclidean distance of the two polygons, the duals
+ * encode the unit direction between their closest points (face-vertex and vertex-vertex cases alike) and satisfy
+ * the rows (:276-280) exactly.  Polygons that touch or overlap get their best face normal (d <= 0). */
 int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m, double *d);
 
 /* MultiVehiclePlanner.joint_dual_ws (confrez/control/multi_vehicle_planner.py:208-341): for n pairs of fixed poses
  * poses_this[n][3], poses_other[n][3] of two vehicles the duals lam[n][4] (faces of the first), mu[n][4] (faces of the
  * second), s[n][2] of the rows -b_this'lam - b_other'mu = d, A_this'lam + s = 0, A_other'mu - s = 0, |s| <= 1,
  * lam, mu >= 0 (:292-295) and the separation d[n] they certify (may be NULL).  The reference maximises d with IPOPT;
- * here: closed-form maximum over the face normals of both rectangles (exact for face-vertex closest features). */
+ * here: the optimum in closed form, d = the Euclidean distance of the two bodies, s = minus the unit direction between
+ * their closest points (vertex-vertex closest features included). */
 int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const double *poses_other, double *lam, double *mu,
                       double *s, double *d);
 

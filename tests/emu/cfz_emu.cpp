@@ -23,7 +23,7 @@ int cfz_emu_solve(const cfz::KSpec *sp, const double *x0, const double *ref, con
   double *m = (double *)calloc((size_t)L.total, sizeof(double));
   if (!m) return -1;
   cfz::DualOut duo = {l, mm, lam_ij, lam_ji, s, nullptr};
-  cfz::solve_instance(*sp, x0, ref, nbr, zu, m, L, out_i, out_d, duo, wst, carry_in);
+  cfz::solve_instance(*sp, cfz::derive(*sp), x0, ref, nbr, zu, m, L, out_i, out_d, duo, wst, carry_in);
   free(m);
   return L.total;
 }

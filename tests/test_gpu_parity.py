@@ -304,15 +304,30 @@ def test_joint_dual_ws_certificates(eng, tmp_path):
     pb = pa + np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-3.2, 3.2, n)], 1)
     lam, mu, s, d = eng.joint_dual_ws(pa, pb)
     G, g = np.array([[1.0, 0], [0, 1], [-1, 0], [0, -1]]), np.asarray(eng.spec.g, float)
+    from oracle.geometry import body_polygon_world, polygon_distance
+
+    n_vv = 0
     for k in range(n):
         tA = G @ rot(-pa[k, 2]); tb = tA @ pa[k, :2] + g
         oA = G @ rot(-pb[k, 2]); ob = oA @ pb[k, :2] + g
         assert (lam[k] >= 0).all() and (mu[k] >= 0).all() and s[k] @ s[k] <= 1 + 1e-12
         assert np.abs(tA.T @ lam[k] + s[k]).max() < 1e-12 and np.abs(oA.T @ mu[k] - s[k]).max() < 1e-12
         assert abs(-tb @ lam[k] - ob @ mu[k] - d[k]) < 1e-10
+        # the reference MAXIMISES d (:296): the optimum is the distance of the two bodies.  Feasible duals certify
+        # d <= distance (weak duality); equality with an independently computed distance proves optimality.
+        dist, _, _ = polygon_distance(body_polygon_world(pa[k], g), body_polygon_world(pb[k], g))
+        if dist > 1e-6:
+            assert abs(d[k] - dist) < 1e-7, (k, d[k], dist)
+            n_vv += (lam[k] > 1e-9).sum() == 2 and (mu[k] > 1e-9).sum() == 2  # a direction between face normals on both bodies
+        else:
+            assert d[k] <= 1e-9
+    assert n_vv >= 10  # vertex-vertex closest features are among the cases
     # two parallel vehicles side by side, 3 m apart centre to centre: 3 - 0.9 - 0.9; nose to tail on one line: gap 2
     lam, mu, s, d = eng.joint_dual_ws([[10.0, 15.0, 0.0], [10.0, 15.0, 0.0]], [[10.0, 18.0, 0.0], [15.9, 15.0, 0.0]])
     assert abs(d[0] - 1.2) < 1e-12 and abs(d[1] - (15.9 - 0.6 - 10.0 - 3.3)) < 1e-12
+    # corner to corner: front-left corner of the first (13.3, 15.9) and rear-right corner of the second (15.3, 16.9)
+    lam, mu, s, d = eng.joint_dual_ws([[10.0, 15.0, 0.0]], [[15.9, 17.8, 0.0]])
+    assert abs(d[0] - np.hypot(2.0, 1.0)) < 1e-12 and np.allclose(s[0], -np.array([2.0, 1.0]) / np.hypot(2.0, 1.0), atol=1e-12)
     # the planner surface
     from conflict_rez_amd import strategy as strat
     from conflict_rez_amd.control.multi_vehicle_planner import MultiVehiclePlanner
@@ -379,30 +394,105 @@ def test_python_shim_closed_loop_on_gpu(tmp_path):
                 assert separated(poly(mdf.vehicles[a], i), poly(mdf.vehicles[b], i)), (i, a, b)
 
 
+def test_node_loop_on_gpu(tmp_path):
+    """The reference's ROS2 deployment protocol (ros2_ws/src/confrez_ros/src/vehicle_node.py:111-190) without ROS, against
+    the real engine: four `VehicleNode`s over the in-process bus, every node stepping ITS vehicle with a batch of one in
+    its own carry slot of the shared engine.  30 ticks: every node steps, solves converge from the carried multipliers
+    in a few iterations, the vehicles never overlap and follow their plans."""
+    from conflict_rez_amd import strategy as strat
+    from conflict_rez_amd.control.vehicle_follower import MultiDistributedFollower
+    from conflict_rez_amd.node import InProcessBus, VehicleNode
+    from conflict_rez_amd.pytypes import VehicleState
+    from test_follower_host import _references
+
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    names = [f"vehicle_{i}" for i in range(4)]
+    mdf = MultiDistributedFollower(fn, {a: True for a in names}, {a: {"front": (1, 0, 0), "back": (0, 1, 0)} for a in names},
+                                   {a: VehicleState() for a in names}, {a: None for a in names})
+    mdf.setup_multi_vehicles(references=_references())
+    assert [v.slot for v in mdf.vehicles] == [0, 1, 2, 3]
+    iters = {a: [] for a in names}
+    orig = mdf.engine.solve
+
+    def counting(*args, **kw):
+        out = orig(*args, **kw)
+        iters[names[int(kw["slots"][0])]].append((int(out["status"][0]), int(out["iters"][0])))
+        return out
+
+    mdf.engine.solve = counting
+    bus = InProcessBus()
+    nodes = [VehicleNode(v, 4, bus) for v in mdf.vehicles]
+    for n in nodes:
+        n.publish_prediction()
+    ticks = 30
+    for _ in range(ticks):
+        for n in nodes:
+            n.timer_callback()
+    assert [n.steps for n in nodes] == [ticks - 1] * 3 + [ticks]  # in the first round only the last node has heard everybody
+    for a in names:
+        st = np.array(iters[a])
+        assert (st[:, 0] == 0).mean() > 0.85, (a, st[:, 0])
+        assert np.median(st[1:, 1]) <= 4, (a, st[:, 1])  # carried multipliers: a few iterations per step
+    g = np.array([3.3, 0.9, 0.6, 0.9])
+    corners = np.array([[g[0], g[1]], [-g[2], g[1]], [-g[2], -g[3]], [g[0], -g[3]]])
+
+    def poly(v, i):
+        c, s = np.cos(v.final_traj.psi[i]), np.sin(v.final_traj.psi[i])
+        return np.array([v.final_traj.x[i], v.final_traj.y[i]]) + corners @ np.array([[c, s], [-s, c]])
+
+    def separated(P, Q):
+        for poly_ in (P, Q):
+            for a_, b_ in zip(poly_, np.roll(poly_, -1, 0)):
+                n_ = np.array([b_[1] - a_[1], a_[0] - b_[0]])
+                if (P @ n_).max() < (Q @ n_).min() or (Q @ n_).max() < (P @ n_).min():
+                    return True
+        return False
+
+    for i in range(ticks - 1):
+        for a in range(4):
+            for b in range(a + 1, 4):
+                assert separated(poly(mdf.vehicles[a], i), poly(mdf.vehicles[b], i)), (i, a, b)
+    for v in mdf.vehicles:
+        ref = v.interpolate_states([v.state.t])
+        assert np.hypot(v.state.x.x - ref.x[0], v.state.x.y - ref.y[0]) < 0.5
+
+
 def test_dual_ws_certificates(eng, ospec):
-    """`cfz_dual_ws` (reference Vehicle.dual_ws, vehicle.py:233-296): every returned (lambda, mu) satisfies the
-    reference's rows (:276-280) for its pose, d equals the oracle's closed-form separation, and for
-    face-to-face configurations the geometric rectangle-box distance."""
+    """`cfz_dual_ws` (reference Vehicle.dual_ws, vehicle.py:233-296: maximise d over the duals): every returned (lambda, mu)
+    satisfies the reference's rows (:276-280) for its pose with |A'lambda| = 1, and d IS the optimum: the Euclidean distance
+    of body and obstacle from an independent computation (a QP over the vertices, oracle/geometry.py) -- face-vertex and
+    vertex-vertex closest features alike."""
     from conflict_rez_amd import scenarios
-    from oracle.mpc_nlp import body_vertices, polytope_vertices, rot, rows_for, select_rows
+    from oracle.geometry import body_polygon_world, polygon_distance
+    from oracle.mpc_nlp import polytope_vertices, rot
 
     table, _ = scenarios.load_reference_table()
-    poses = table[:, ::7, :3].reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    poses = np.concatenate([table[:, ::7, :3].reshape(-1, 3)[::5],
+                            np.stack([rng.uniform(3, 32, 80), rng.uniform(14.5, 20.5, 80), rng.uniform(-3.2, 3.2, 80)], 1)])
     l, m, d = eng.dual_ws(poses)
     G, g = ospec.G, ospec.g
-    BV = body_vertices(g)
-    for k in range(0, len(poses), 5):
+    n_vv = 0
+    for k in range(len(poses)):
         t, R = poses[k, :2], rot(poses[k, 2])
+        W = body_polygon_world(poses[k], g)
         for j in range(ospec.n_obs):
             A, b = ospec.A_obs[j], ospec.b_obs[j]
             lj, mj = l[k, 4 * j:4 * j + 4], m[k, 4 * j:4 * j + 4]
             assert lj.min() >= 0 and mj.min() >= 0
             assert np.abs(G.T @ mj + R.T @ A.T @ lj).max() < 1e-12
-            assert np.dot(A.T @ lj, A.T @ lj) <= 1 + 1e-12
+            assert abs(np.dot(A.T @ lj, A.T @ lj) - 1.0) < 1e-12
             assert abs(np.dot(-g, mj) + np.dot(A @ t - b, lj) - d[k, j]) < 1e-10
-            PV, _ = polytope_vertices(A, b)
-            sel = select_rows(A, b, PV, t, poses[k, 2], g, BV, 0)
-            assert abs(rows_for(A, b, PV, t, poses[k, 2], g, BV, sel)[0].min() - d[k, j]) < 1e-12
-    # known answer: axis-aligned vehicle beside obstacle 0 (box x in [2.85,14.65], y in [7.5,13.75])
-    _, _, d0 = eng.dual_ws(np.array([[8.0, 16.25, 0.0], [20.0, 10.0, 0.0]]))
+            dist, _, _ = polygon_distance(polytope_vertices(A, b)[0], W)
+            if dist > 1e-6:
+                assert abs(d[k, j] - dist) < 1e-7, (k, j, d[k, j], dist)
+                n_vv += (lj > 1e-9).sum() == 2 and (mj > 1e-9).sum() == 2
+            else:
+                assert d[k, j] <= 1e-9
+    assert n_vv >= 10
+    # known answers: axis-aligned vehicle beside obstacle 0 (box x in [2.85,14.65], y in [7.5,13.75]); and diagonally off
+    # its corner (14.65, 13.75): rear-left body corner at (15.65, 15.75) -> distance hypot(1, 2)
+    _, _, d0 = eng.dual_ws(np.array([[8.0, 16.25, 0.0], [20.0, 10.0, 0.0], [16.25, 16.65, 0.0]]))
     assert abs(d0[0, 0] - (16.25 - 0.9 - 13.75)) < 1e-12 and abs(d0[1, 0] - (20.0 - 0.6 - 14.65)) < 1e-12
+    assert abs(d0[2, 0] - np.hypot(1.0, 2.0)) < 1e-12
