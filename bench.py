@@ -70,10 +70,11 @@ def casadi_probe():
         return f"CasADi unavailable on this host: {type(e).__name__}: {e}"
 
 
-def cpu_baseline(warmup, steps, n_scen_per_core=8, max_cores=16):
+def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16):
     """`cpu_baseline` of the bench line: the oracle's C port ("kind": "port") on the host cores, like for like with the
     GPU's timed region -- the closed loop after `warmup` iterations, carried multipliers -- on a bounded sample of the same
-    scenario sampler (8 scenarios x 4 vehicles per process; about 10-30 s).  One process per usable core (the job's CPU
+    scenario sampler (32 scenarios x 4 vehicles per process; about 40 s of CPU time in all).  16 processes: the job's CPU
+    quota on the GPU boxes is about that (measured: 16 processes 17.4 k solves/s, 64 processes 15.6 k).  One process per usable core (the job's CPU
     quota is usually far below the logical core count: the affinity mask says what is usable), at most `max_cores`."""
     import concurrent.futures as cf
     import multiprocessing as mp
