@@ -524,6 +524,7 @@ struct cfz_handle {
   int32_t *queue = nullptr, *ctrl = nullptr, *done = nullptr, *iter_sum = nullptr;
   int queue_cap = 0, grid_blocks = 0, steps_done = 0;
   long last_iter_sum = 0, last_converged = 0;
+  CfzArena arena;  // device buffers of cfz_dual_ws / cfz_joint_dual_ws, kept between calls
 };
 
 namespace {
@@ -687,6 +688,7 @@ int cfz_destroy(cfz_handle *h) {
                   h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
                   h->iter_sum, h->obs_tab, h->wst, h->carry, h->slots};
   for (void *p : bufs) if (p) hipFree(p);
+  arena_destroy(h->arena);
   if (h->stage_host) hipHostFree(h->stage_host);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -851,17 +853,17 @@ int cfz_dual_ws(cfz_handle *h, int n, const double *poses, double *l, double *m,
   const size_t no = h->ks.n_obs;
   if (no == 0) return 0;
   double *dp = nullptr, *dl = nullptr, *dm = nullptr, *dd = nullptr;
-  HIP_OK(hipMalloc(&dp, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dl, (size_t)n * 4 * no * 8));
-  HIP_OK(hipMalloc(&dm, (size_t)n * 4 * no * 8)); HIP_OK(hipMalloc(&dd, (size_t)n * no * 8));
-  HIP_OK(hipMemcpy(dp, poses, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
+  if (arena_reset(h->arena)) return -1;
+  ARENA_ALLOC(h->arena, dp, (size_t)n * 3 * 8); ARENA_ALLOC(h->arena, dl, (size_t)n * 4 * no * 8);
+  ARENA_ALLOC(h->arena, dm, (size_t)n * 4 * no * 8); ARENA_ALLOC(h->arena, dd, (size_t)n * no * 8);
+  HIP_OK(hipMemcpyAsync(dp, poses, (size_t)n * 3 * 8, hipMemcpyHostToDevice, h->stream));
   const int nt = n * (int)no;
   hipLaunchKernelGGL(dual_ws_kernel, dim3((nt + 127) / 128), dim3(128), 0, h->stream, h->ks, n, dp, dl, dm, dd);
   HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(l, dl, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(m, dm, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost, h->stream));
+  if (d) HIP_OK(hipMemcpyAsync(d, dd, (size_t)n * no * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipMemcpy(l, dl, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(m, dm, (size_t)n * 4 * no * 8, hipMemcpyDeviceToHost));
-  if (d) HIP_OK(hipMemcpy(d, dd, (size_t)n * no * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(dp); (void)hipFree(dl); (void)hipFree(dm); (void)hipFree(dd);
   return 0;
 }
 
@@ -871,17 +873,17 @@ int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const doub
   if (n < 1 || !poses_this || !poses_other || !lam || !mu || !s) return fail("bad argument");
   HIP_OK(hipSetDevice(h->device));
   double *dpa = nullptr, *dpb = nullptr, *dout = nullptr;
-  HIP_OK(hipMalloc(&dpa, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dpb, (size_t)n * 3 * 8)); HIP_OK(hipMalloc(&dout, (size_t)n * 11 * 8));
-  HIP_OK(hipMemcpy(dpa, poses_this, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dpb, poses_other, (size_t)n * 3 * 8, hipMemcpyHostToDevice));
+  if (arena_reset(h->arena)) return -1;
+  ARENA_ALLOC(h->arena, dpa, (size_t)n * 3 * 8); ARENA_ALLOC(h->arena, dpb, (size_t)n * 3 * 8); ARENA_ALLOC(h->arena, dout, (size_t)n * 11 * 8);
+  HIP_OK(hipMemcpyAsync(dpa, poses_this, (size_t)n * 3 * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(dpb, poses_other, (size_t)n * 3 * 8, hipMemcpyHostToDevice, h->stream));
   double *dl = dout, *dm = dout + (size_t)n * 4, *ds = dout + (size_t)n * 8, *dd = dout + (size_t)n * 10;
   hipLaunchKernelGGL(joint_dual_ws_kernel, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->ks, n, dpa, dpb, dl, dm, ds, dd);
   HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(lam, dl, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, h->stream)); HIP_OK(hipMemcpyAsync(mu, dm, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(s, ds, (size_t)n * 2 * 8, hipMemcpyDeviceToHost, h->stream));
+  if (d) HIP_OK(hipMemcpyAsync(d, dd, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipMemcpy(lam, dl, (size_t)n * 4 * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(mu, dm, (size_t)n * 4 * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(s, ds, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
-  if (d) HIP_OK(hipMemcpy(d, dd, (size_t)n * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(dpa); (void)hipFree(dpb); (void)hipFree(dout);
   return 0;
 }
 
@@ -904,13 +906,12 @@ int cfz_loop_init(cfz_handle *h, int S, int T, const double *ref_table, const in
   HIP_OK(hipMemcpy(h->ref_table, ref_table, (size_t)V * T * 7 * 8, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->kidx, k0, (size_t)S * 4, hipMemcpyHostToDevice));
   double *dn = nullptr;
-  if (noise) { HIP_OK(hipMalloc(&dn, B * 5 * 8)); HIP_OK(hipMemcpy(dn, noise, B * 5 * 8, hipMemcpyHostToDevice)); }
+  if (noise) { if (arena_reset(h->arena)) return -1; ARENA_ALLOC(h->arena, dn, B * 5 * 8); HIP_OK(hipMemcpy(dn, noise, B * 5 * 8, hipMemcpyHostToDevice)); }
   const long nt = (long)B * N;
   hipLaunchKernelGGL(loop_seed, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, S, V, N, T, h->ref_table,
                      h->kidx, dn, h->pred, h->state);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(h->stream));
-  if (dn) hipFree(dn);
   return 0;
 }
 

@@ -56,16 +56,63 @@ __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::
 
 }  // namespace
 
+struct cfz_plan_ws {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  CfzArena arena;
+};
+
+namespace {
+// the workspace behind the handle-less entry points: one per (thread, device), created on first use, kept for the life of
+// the thread (so that a caller of the plain signatures also stops paying hipMalloc/hipFree per call)
+cfz_plan_ws *default_ws(int device) {
+  thread_local std::vector<cfz_plan_ws *> cache;
+  if ((int)cache.size() <= device) cache.resize(device + 1, nullptr);
+  if (!cache[device] && cfz_plan_ws_create(device, &cache[device]) != 0) return nullptr;
+  return cache[device];
+}
+}  // namespace
+
 extern "C" {
 
-int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
-                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
-                 int32_t *iters, double *cost) {
-  if (B < 1 || !po || !n_sets || !init_pose || !tube || !traj) return fail("bad argument");
+int cfz_plan_ws_create(int device, cfz_plan_ws **out) {
+  if (!out) return fail("null argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
   if (device < 0 || device >= ndev) return fail("device index out of range");
   HIP_OK(hipSetDevice(device));
+  cfz_plan_ws *w = new cfz_plan_ws();
+  w->device = device;
+  if (hipStreamCreate(&w->stream) != hipSuccess) { delete w; return fail("hipStreamCreate"); }
+  *out = w;
+  return 0;
+}
+
+int cfz_plan_ws_destroy(cfz_plan_ws *w) {
+  if (!w) return 0;
+  (void)hipSetDevice(w->device);
+  arena_destroy(w->arena);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+  return 0;
+}
+
+int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
+                 const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                 int32_t *iters, double *cost) {
+  cfz_plan_ws *w = default_ws(device);
+  if (!w) return -1;
+  return cfz_state_ws_w(w, B, po, n_sets, init_pose, final_heading, tube, guess, traj, status, iters, cost);
+}
+
+int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
+                   const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                   int32_t *iters, double *cost) {
+  if (!w) return fail("null workspace");
+  if (B < 1 || !po || !n_sets || !init_pose || !tube || !traj) return fail("bad argument");
+  HIP_OK(hipSetDevice(w->device));
+  if (arena_reset(w->arena)) return -1;
+  hipStream_t st = w->stream;
   std::vector<cfzp::PSpec> specs(B);
   std::vector<long long> toff(B), xoff(B), soff(B);
   long long nt = 0, nx = 0, ns = 0, npts = 0;
@@ -107,26 +154,26 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n
   }
   cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;
   long long *doff = nullptr; int32_t *doi = nullptr;
-  HIP_OK(hipMalloc(&dspec, sizeof(cfzp::PSpec) * B)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8));
-  HIP_OK(hipMalloc(&dslab, (size_t)ns * 8)); HIP_OK(hipMalloc(&doff, (size_t)B * 3 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4));
-  HIP_OK(hipMalloc(&dod, (size_t)B * 3 * 8));
-  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzp::PSpec) * B, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff, toff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  ARENA_ALLOC(w->arena, dspec, sizeof(cfzp::PSpec) * B); ARENA_ALLOC(w->arena, dtube, (size_t)nt * 8); ARENA_ALLOC(w->arena, dX, (size_t)nx * 8);
+  ARENA_ALLOC(w->arena, dslab, (size_t)ns * 8); ARENA_ALLOC(w->arena, doff, (size_t)B * 3 * 8); ARENA_ALLOC(w->arena, doi, (size_t)B * 2 * 4);
+  ARENA_ALLOC(w->arena, dod, (size_t)B * 3 * 8);
+  // everything on the workspace's stream (the host arrays are pageable: each copy returns when its source is free again)
+  HIP_OK(hipMemcpyAsync(dspec, specs.data(), sizeof(cfzp::PSpec) * B, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(doff, toff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
   const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
   HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, 0, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
-  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost));
-  for (void *p : {(void *)dspec, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod}) (void)hipFree(p);
+  HIP_OK(hipMemcpyAsync(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(od.data(), dod, (size_t)B * 3 * 8, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));  // this stream only: other streams of the process (torch's) keep running
   long long o = 0;
   for (int b = 0; b < B; ++b) {
     const int T = specs[b].T;
@@ -168,15 +215,15 @@ static void radau5_tables(double A[6][6], double B[6]) {
 // B collocation problems in one launch; problem b plans nveh[b] vehicles with one shared dt (1: the single-vehicle plan).
 // Vehicles are numbered through all problems: n_sets, init_pose, final_heading, tube, guess and traj are per vehicle,
 // dt0, dt, status, iters, cost per problem; pairs[b]: vehicle pairs (local indices) with a separation row, per problem.
-static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<std::vector<std::pair<int, int>>> &pairs, const cfz_spec *spec,
+static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vector<std::vector<std::pair<int, int>>> &pairs, const cfz_spec *spec,
                       const cfz_colloc_options *co, const int32_t *n_sets, const double *init_pose, const double *final_heading,
                       const double *tube, const double *guess, const double *dt0, double *traj, double *dt, int32_t *status,
                       int32_t *iters, double *cost) {
+  if (!w) return fail("null workspace");
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device: libconfrez_hip has no CPU path");
-  if (device < 0 || device >= ndev) return fail("device index out of range");
-  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipSetDevice(w->device));
+  if (arena_reset(w->arena)) return -1;
+  hipStream_t st = w->stream;
   std::vector<double> tab((size_t)std::max(spec->n_obs, 1) * 20, 0.0);
   for (int j = 0; j < spec->n_obs; ++j) {
     double V[4][2];
@@ -193,9 +240,9 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
     nv_total += nveh[b];
   }
   double *dtab = nullptr, *dtube = nullptr;
-  HIP_OK(hipMalloc(&dtab, tab.size() * 8)); HIP_OK(hipMalloc(&dtube, (size_t)nt * 8));
-  HIP_OK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice));
+  ARENA_ALLOC(w->arena, dtab, tab.size() * 8); ARENA_ALLOC(w->arena, dtube, (size_t)nt * 8);
+  HIP_OK(hipMemcpyAsync(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dtube, tube, (size_t)nt * 8, hipMemcpyHostToDevice, st));
   std::vector<cfzc::CSpec> specs(B);
   std::vector<long long> xoff(B), soff(B);
   std::vector<int32_t> kbs(B);
@@ -252,15 +299,15 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
     g0 += np_;
   }
   cfzc::CSpec *dspec = nullptr; double *dX = nullptr, *dslab = nullptr, *dod = nullptr; long long *doff = nullptr; int32_t *doi = nullptr, *dkb = nullptr;
-  HIP_OK(hipMalloc(&dspec, sizeof(cfzc::CSpec) * B)); HIP_OK(hipMalloc(&dX, (size_t)nx * 8)); HIP_OK(hipMalloc(&dslab, (size_t)ns * 8));
-  HIP_OK(hipMalloc(&doff, (size_t)B * 2 * 8)); HIP_OK(hipMalloc(&doi, (size_t)B * 2 * 4)); HIP_OK(hipMalloc(&dod, (size_t)B * cfzc::kOutD * 8));
-  HIP_OK(hipMalloc(&dkb, (size_t)B * 4));
-  HIP_OK(hipMemcpy(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(dslab, 0, (size_t)ns * 8));
+  ARENA_ALLOC(w->arena, dspec, sizeof(cfzc::CSpec) * B); ARENA_ALLOC(w->arena, dX, (size_t)nx * 8); ARENA_ALLOC(w->arena, dslab, (size_t)ns * 8);
+  ARENA_ALLOC(w->arena, doff, (size_t)B * 2 * 8); ARENA_ALLOC(w->arena, doi, (size_t)B * 2 * 4); ARENA_ALLOC(w->arena, dod, (size_t)B * cfzc::kOutD * 8);
+  ARENA_ALLOC(w->arena, dkb, (size_t)B * 4);
+  HIP_OK(hipMemcpyAsync(dspec, specs.data(), sizeof(cfzc::CSpec) * B, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dX, X.data(), (size_t)nx * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(doff, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemcpyAsync(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
   // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
   // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
   bool wide = false;
@@ -269,21 +316,20 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
   if (!wide) {
     const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
     HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
+    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
   } else {
     int nk_max = 0;  // the right-hand side of the largest instance in LDS if it fits beside the static arrays of the elimination
     for (int b = 0; b < B; ++b) nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk);
     const int lds_doubles = (size_t)nk_max * 8 <= 120 * 1024 ? nk_max : 0;
     if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, 0, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
   }
   HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
-  HIP_OK(hipMemcpy(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost));
-  for (void *p : {(void *)dspec, (void *)dtab, (void *)dtube, (void *)dX, (void *)dslab, (void *)doff, (void *)doi, (void *)dod, (void *)dkb}) (void)hipFree(p);
+  HIP_OK(hipMemcpyAsync(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(oi.data(), doi, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(od.data(), dod, (size_t)B * cfzc::kOutD * 8, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
   g0 = 0;
   for (int b = 0; b < B; ++b) {
     const long long np_ = (long long)cfzc::cdims(specs[b]).np;
@@ -305,22 +351,38 @@ static int colloc_run(int device, int B, const int32_t *nveh, const std::vector<
 int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
                const double *init_pose, const double *final_heading, const double *tube, const double *guess,
                const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  cfz_plan_ws *w = default_ws(device);
+  if (!w) return -1;
+  return cfz_colloc_w(w, B, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+}
+
+int cfz_colloc_w(cfz_plan_ws *w, int B, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+                 const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+                 const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
   if (B < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt) return fail("bad argument");
   std::vector<int32_t> one((size_t)B, 1);
   std::vector<std::vector<std::pair<int, int>>> none((size_t)B);
-  return colloc_run(device, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+  return colloc_run(w, B, one.data(), none, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
 }
 
 int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
                      const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
                      int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
+  cfz_plan_ws *w = default_ws(device);
+  if (!w) return -1;
+  return cfz_joint_colloc_w(w, B, V, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, n_pairs, pairs, traj, dt, status, iters, cost);
+}
+
+int cfz_joint_colloc_w(cfz_plan_ws *w, int B, int V, const cfz_spec *spec, const cfz_colloc_options *co, const int32_t *n_sets,
+                       const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
+                       int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
   if (B < 1 || V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt || n_pairs < 0) return fail("bad argument");
   std::vector<std::pair<int, int>> pr;
   if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
   else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});  // :56-58 all pairs
   std::vector<std::vector<std::pair<int, int>>> all((size_t)B, pr);
   std::vector<int32_t> nv((size_t)B, V);
-  return colloc_run(device, B, nv.data(), all, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
+  return colloc_run(w, B, nv.data(), all, spec, co, n_sets, init_pose, final_heading, tube, guess, dt0, traj, dt, status, iters, cost);
 }
 
 void cfz_default_colloc_options(cfz_colloc_options *o) {

@@ -120,9 +120,14 @@ def load_library(path=None):
     lib.cfz_joint_dual_ws.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.cfz_default_plan_options.argtypes = [C.POINTER(_CPlanOptions)]
     lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
+    lib.cfz_state_ws_w.argtypes = [vp, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
+    lib.cfz_plan_ws_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.cfz_plan_ws_destroy.argtypes = [vp]
     lib.cfz_default_colloc_options.argtypes = [C.POINTER(_CCollocOptions)]
     lib.cfz_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
+    lib.cfz_colloc_w.argtypes = [vp, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
     lib.cfz_joint_colloc.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 6 + [C.c_int] + [vp] * 6
+    lib.cfz_joint_colloc_w.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 6 + [C.c_int] + [vp] * 6
     lib.cfz_mpc_set_carry.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_set_carry_device.argtypes = [vp, C.c_int, vp]
     lib.cfz_mpc_set_slots.argtypes = [vp, C.c_int, vp]
@@ -148,7 +153,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
+    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -175,7 +180,29 @@ def _f64(a, shape):
     return a
 
 
-def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, **options):
+class PlanWorkspace:
+    """`cfz_plan_ws`: a stream and the device buffers of the planning calls, kept between calls.  Pass as `ws=` to
+    `state_ws`, `colloc`, `joint_colloc_batch`; without it those use a per-thread workspace inside the library."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self._w = C.c_void_p()
+        if self.lib.cfz_plan_ws_create(int(device), C.byref(self._w)) != 0:
+            raise RuntimeError("cfz_plan_ws_create: " + self.lib.cfz_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_w", None):
+            self.lib.cfz_plan_ws_destroy(self._w)
+            self._w = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=None, **options):
     """`cfz_state_ws`: the warm-start plans of several vehicles in one launch.
     init_poses [B][3]; tubes: per vehicle a list over strategy steps 1.. of ((A_back, b_back), (A_front, b_front));
     guesses: per vehicle an array [T+1, 3] of x, y, psi or None; final_headings: per vehicle a float or None.
@@ -202,8 +229,9 @@ def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, **o
         assert guess.shape[0] == int((T + 1).sum())
     traj = np.zeros((int((T + 1).sum()), 7))
     status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
-    rc = lib.cfz_state_ws(int(device), B, C.byref(po), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(np.ascontiguousarray(tube)), _ptr(guess),
-                          _ptr(traj), _ptr(status), _ptr(iters), _ptr(cost))
+    args = (B, C.byref(po), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(np.ascontiguousarray(tube)), _ptr(guess),
+            _ptr(traj), _ptr(status), _ptr(iters), _ptr(cost))
+    rc = lib.cfz_state_ws(int(device), *args) if ws is None else lib.cfz_state_ws_w(ws._w, *args)
     if rc != 0:
         raise RuntimeError("cfz_state_ws: " + lib.cfz_last_error().decode())
     out, o = [], 0
@@ -218,7 +246,7 @@ class _CCollocOptions(C.Structure):
                 ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
 
 
-def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0, **options):
+def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0, ws=None, **options):
     """`cfz_colloc`: the collocation plans (vehicle.py:360-661) of several vehicles in one launch.
     spec: ProblemSpec (wb, dmin, body, bounds, static obstacles); init_poses [B][3]; tubes as in `state_ws`;
     guesses: per vehicle an array [6 N, 7] of x, y, psi, v, delta, a, w at the collocation points; dt0s [B];
@@ -243,8 +271,9 @@ def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0
     traj, dt = np.zeros((int(Np.sum()), 7)), np.zeros(B)
     status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
     cs = spec.to_c()
-    rc = lib.cfz_colloc(int(device), B, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
-                        _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
+    args = (B, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
+            _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
+    rc = lib.cfz_colloc(int(device), *args) if ws is None else lib.cfz_colloc_w(ws._w, *args)
     if rc != 0:
         raise RuntimeError("cfz_colloc: " + lib.cfz_last_error().decode())
     out, o = [], 0
@@ -254,7 +283,7 @@ def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0
     return out
 
 
-def joint_colloc_batch(spec, scenarios, pairs=None, device=0, **options):
+def joint_colloc_batch(spec, scenarios, pairs=None, device=0, ws=None, **options):
     """`cfz_joint_colloc`: B joint collocation plans (one workgroup each) of V vehicles with one shared dt per plan and pairwise
     separation rows (multi_vehicle_planner.py:343-480).  scenarios: list of dict(init_poses [V][3], tubes, guesses, dt0,
     final_headings) with per-vehicle entries as in `colloc`, the same V in every scenario; pairs: list of (a, b) vehicle
@@ -283,8 +312,9 @@ def joint_colloc_batch(spec, scenarios, pairs=None, device=0, **options):
     traj, dt = np.zeros((int(Np.sum()), 7)), np.zeros(B)
     status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)
     cs = spec.to_c()
-    rc = lib.cfz_joint_colloc(int(device), B, V, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
-                              0 if pr is None else len(pr), _ptr(pr), _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
+    args = (B, V, C.byref(cs), C.byref(co), _ptr(n_sets), _ptr(init), _ptr(fh), _ptr(tube), _ptr(guess), _ptr(dt0),
+            0 if pr is None else len(pr), _ptr(pr), _ptr(traj), _ptr(dt), _ptr(status), _ptr(iters), _ptr(cost))
+    rc = lib.cfz_joint_colloc(int(device), *args) if ws is None else lib.cfz_joint_colloc_w(ws._w, *args)
     if rc != 0:
         raise RuntimeError("cfz_joint_colloc: " + lib.cfz_last_error().decode())
     out, o = [], 0

@@ -197,6 +197,18 @@ typedef struct cfz_plan_options {
 } cfz_plan_options;
 
 void cfz_default_plan_options(cfz_plan_options *opt);
+
+/* Workspace of the planning entry points: one HIP stream and the device buffers of the last call, kept and reused (a
+ * planning call used to hipMalloc / hipFree seven to nine buffers and end in hipDeviceSynchronize, stalling every other
+ * stream of the process).  The `_w` forms run on the workspace's stream and wait for that stream only; the plain forms
+ * (cfz_state_ws, cfz_colloc, cfz_joint_colloc) use a workspace of their own per calling thread and device.  A workspace
+ * is not thread-safe (one call at a time), like a handle. */
+typedef struct cfz_plan_ws cfz_plan_ws;
+int cfz_plan_ws_create(int device, cfz_plan_ws **out);
+int cfz_plan_ws_destroy(cfz_plan_ws *ws);
+int cfz_state_ws_w(cfz_plan_ws *ws, int B, const cfz_plan_options *opt, const int32_t *n_sets, const double *init_pose,
+                   const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
+                   int32_t *iters, double *cost);
 int cfz_state_ws(int device, int B, const cfz_plan_options *opt, const int32_t *n_sets, const double *init_pose,
                  const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
                  int32_t *iters, double *cost);
@@ -225,6 +237,9 @@ typedef struct cfz_colloc_options {
 } cfz_colloc_options;
 
 void cfz_default_colloc_options(cfz_colloc_options *opt);
+int cfz_colloc_w(cfz_plan_ws *ws, int B, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
+                 const double *init_pose, const double *final_heading, const double *tube, const double *guess,
+                 const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
 int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
                const double *init_pose, const double *final_heading, const double *tube, const double *guess,
                const double *dt0, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
@@ -242,6 +257,9 @@ int cfz_colloc(int device, int B, const cfz_spec *spec, const cfz_colloc_options
  * The vehicle-vehicle OBCA duals (:404-431) are eliminated like the obstacle duals (two smooth rows per pair and point over a
  * working set) and rebuilt from the poses by cfz_joint_dual_ws.  The vehicles' interval blocks are interleaved in time, which
  * widens the band to ~100 V; the elimination then runs from global memory (csrc/cfz_colloc.inl). */
+int cfz_joint_colloc_w(cfz_plan_ws *ws, int B, int V, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
+                       const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
+                       int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
 int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_colloc_options *opt, const int32_t *n_sets,
                      const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
                      int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);

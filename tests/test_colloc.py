@@ -359,6 +359,28 @@ def test_colloc_source_reproduces_fixture(plans):
 
 
 @pytest.mark.gpu
+def test_planning_workspace_reuse(plans):
+    """`cfz_plan_ws` (the `_w` entry points): repeated calls on one workspace -- its stream, its kept device buffers, a
+    smaller problem after a larger one and back -- give the results of the plain entry points, bit for bit."""
+    from conflict_rez_amd import engine
+
+    agents = sorted(plans)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    fhs = [float(plans[a][1][-1, 2]) for a in agents]
+    args = ([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], fhs)
+    plain = engine.state_ws(*args, shrink_tube=0.5)
+    ws = engine.PlanWorkspace()
+    first = engine.state_ws(*args, shrink_tube=0.5, ws=ws)
+    one = engine.state_ws(args[0][1:2], tubes[1:2], args[2][1:2], fhs[1:2], shrink_tube=0.5, ws=ws)
+    again = engine.state_ws(*args, shrink_tube=0.5, ws=ws)
+    for a, b, c in zip(plain, first, again):
+        assert a["status"] == b["status"] == c["status"] == 0 and a["iters"] == b["iters"] == c["iters"]
+        assert np.array_equal(a["traj"], b["traj"]) and np.array_equal(a["traj"], c["traj"])
+    assert np.array_equal(one[0]["traj"], plain[1]["traj"])
+    ws.close()
+
+
+@pytest.mark.gpu
 def test_colloc_fixture_on_gpu(plans):
     """The same fixture through the C ABI: cfz_colloc and cfz_joint_colloc from the stored guesses."""
     from conflict_rez_amd import engine

