@@ -90,7 +90,7 @@ constexpr int kMaxObs = 8;  // = CFZ_MAX_OBS
 struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
   int max_iter, max_backtrack, filter_cap, stall_iters;
-  int row_curvature, pad1;
+  int row_curvature, vv_rows;  // vv_rows 1: vertex-vertex rows (kind 3) in the working set
   double dt, wb, dmin;
   double g[4], bounds[12], weights[6];
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
@@ -150,7 +150,7 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.ab = o; o += N * 15; L.d = o; o += N * 5;
   L.dpi = L.d;  // the costate sweep (last reader of the defects d_k was the forward sweep) overwrites them with d(pi)
   L.hc = o; o += N * 11; L.gk = o; o += N * kNP; L.kk = o; o += N * 12;
-  L.sel = o; o += (N * nb + 7) / 8;  // working set codes (< 192), one byte each
+  L.sel = o; o += (N * nb + 7) / 8;  // working set codes (<= 255), one byte each
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
   L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
   L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the current iterate
@@ -357,6 +357,9 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // one polygon lies at least dmin outside face f of the other".  kind 1 = polygon face / body
 // vertices, kind 2 = body face / polygon vertices.  The working set of a block is the face and
 // the two vertices whose rows are imposed: sel = kind*64 + face*16 + vA*4 + vB, vA < vB.
+// kind 3 (spec.vv_rows): the closest features of the two polygons are two vertices, polygon vertex u and body vertex v, each
+// in the other's normal cone; no face normal certifies their distance, so the row is the Euclidean distance |W_v - V_u| itself,
+// imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
 
 template <bool GRAD>
@@ -398,9 +401,9 @@ CFZ_FN double pick4(const double d[4], int v) {
 // vertices; D[4 + f] kind 2, body face f against the four polygon vertices.  Same expressions as vertex_dist, with what
 // the faces of a kind share (the rotated body vertices; the vertices relative to the pose) formed once.
 CFZ_FN void block_dists(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                        double s, const double g[4], double D[8][4]) {
+                        double s, const double g[4], double D[8][4], double px[4], double py[4]) {
   const double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
-  double px[4], py[4], rx[4], ry[4];
+  double rx[4], ry[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const double dwx = -s * BV[v][0] - c * BV[v][1], dwy = c * BV[v][0] - s * BV[v][1];
@@ -423,17 +426,22 @@ CFZ_FN void block_dists(const double A[4][2], const double b[4], const double V[
 // minimum over its four vertices (first such face; the previous face is kept while it is within kHyst of the best), on it
 // the nearest vertex and its nearer neighbour (the previous pair is kept while it still holds the nearest vertex and is
 // within kHyst).  dsel: the four distances of the chosen face.
-CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4]) {
-  const int pidx = ((prev >> 6) - 1) * 4 + ((prev >> 4) & 3);  // face index of the previous working set (prev != 0)
+// vv: also look for a vertex-vertex pair (kind 3): polygon vertex u lies outside exactly the two body faces that meet at
+// body vertex v (signs of the kind-2 distances), and W_v lies beyond both polygon edges that leave V_u; such a pair is THE
+// closest pair of the two convex polygons, and it replaces the face rows when its distance exceeds theirs.
+CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, const double V[4][2], const double px[4],
+                       const double py[4]) {
+  const int pidx = ((prev >> 6) - 1) * 4 + ((prev >> 4) & 3);  // face index of the previous working set
+  const bool hp = prev != 0 && (prev >> 6) != 3;               // there is a previous face to prefer
   double best = 0.0, prev_val = 0.0;
   int bi = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const double val = fmin(fmin(D[i][0], D[i][1]), fmin(D[i][2], D[i][3]));
-    if (prev && i == pidx) prev_val = val;
+    if (hp && i == pidx) prev_val = val;
     if (i == 0 || val > best) { best = val; bi = i; }
   }
-  if (prev && prev_val >= best - kHyst) bi = pidx;
+  if (hp && prev_val >= best - kHyst) bi = pidx;
   // the chosen face's row of D: binary select over the three bits of bi
   double d[4];
 #pragma unroll
@@ -450,28 +458,49 @@ CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4]) {
   const int n1 = (v0 + 1) & 3, n2 = (v0 + 3) & 3;
   const double d0 = pick4(d, v0), dn1 = pick4(d, n1), dn2 = pick4(d, n2);
   int v1 = (dn1 < dn2) ? n1 : ((dn2 < dn1) ? n2 : (n1 < n2 ? n1 : n2));
-  if (prev && bi == pidx) {
+  if (hp && bi == pidx) {
     const int oa = (prev >> 2) & 3, ob = prev & 3;
     const double da = pick4(d, oa), db = pick4(d, ob);
     if (fmin(da, db) <= d0 + 1e-12 && fmax(da, db) <= pick4(d, v1) + kHyst) { v0 = oa; v1 = ob; }
   }
   const int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
-  return ((bi >> 2) + 1) * 64 + (bi & 3) * 16 + va * 4 + vb;
+  int code = ((bi >> 2) + 1) * 64 + (bi & 3) * 16 + va * 4 + vb;
+  if (vv) {
+    const double dn = pick4(d, v0);
+    int pc = 0;
+    double r2 = 0.0;
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {  // the lowest qualifying u wins (they all have the same distance)
+      const bool ox = D[4][u] >= 0.0, oy = D[5][u] >= 0.0;
+      const bool cand = (ox || D[6][u] >= 0.0) && (oy || D[7][u] >= 0.0);
+      const int v = ox ? (oy ? 0 : 3) : (oy ? 1 : 2);
+      const double wx = pick4(px, v) - V[u][0], wy = pick4(py, v) - V[u][1];
+      const int u1 = (u + 1) & 3, u3 = (u + 3) & 3;
+      const bool in = wx * (V[u1][0] - V[u][0]) + wy * (V[u1][1] - V[u][1]) <= 0.0 &&
+                      wx * (V[u3][0] - V[u][0]) + wy * (V[u3][1] - V[u][1]) <= 0.0;
+      if (cand && in) { pc = 192 + u * 16 + v * 5; r2 = wx * wx + wy * wy; }
+    }
+    if (pc != 0 && dn > 0.0) {
+      const double r = sqrt(r2);
+      if (r > dn + 1e-9) { code = pc; dsel[0] = r; dsel[1] = r; dsel[2] = r; dsel[3] = r; }
+    }
+  }
+  return code;
 }
 
 CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                       double s, const double g[4], int prev) {
-  double D[8][4], dsel[4];
-  block_dists(A, b, V, x, y, c, s, g, D);
-  return select_from(D, prev, dsel);
+                       double s, const double g[4], int prev) {  // face rows only (the planning kernels)
+  double D[8][4], dsel[4], px[4], py[4];
+  block_dists(A, b, V, x, y, c, s, g, D, px, py);
+  return select_from(D, prev, dsel, 0, V, px, py);
 }
 
 // working set AND the values of its two rows in one pass (the rows are two of the distances the selection looked at)
 CFZ_CALL int select_rows_sep(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                           double s, const double g[4], int prev, double sep[2]) {
-  double D[8][4], dsel[4];
-  block_dists(A, b, V, x, y, c, s, g, D);
-  const int sel = select_from(D, prev, dsel);
+                           double s, const double g[4], int prev, double sep[2], int vv = 0) {
+  double D[8][4], dsel[4], px[4], py[4];
+  block_dists(A, b, V, x, y, c, s, g, D, px, py);
+  const int sel = select_from(D, prev, dsel, vv, V, px, py);
   sep[0] = pick4(dsel, (sel >> 2) & 3); sep[1] = pick4(dsel, sel & 3);
   return sel;
 }
@@ -520,13 +549,44 @@ CFZ_FN void block_polygon(const KSpec &sp, const double *m, const Lay &L, int k,
   }
 }
 
+// vertex v of the polygon of block j at stage k
+CFZ_FN void block_vertex(const KSpec &sp, const double *m, const Lay &L, int k, int j, int v, double &vx, double &vy) {
+  if (j < sp.n_obs) {
+    const double *o = sp.obs_tab + j * 20;
+    vx = o[12 + 2 * v]; vy = o[13 + 2 * v];
+  } else {
+    const double *q = m + L.nb4 + (k * sp.n_nbr + (j - sp.n_obs)) * 4;
+    const double xo = q[0], yo = q[1], co = q[2], so = q[3];
+    const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
+    vx = xo + co * bx - so * by; vy = yo + so * bx + co * by;
+  }
+}
+
+// A vertex-vertex row (kind 3, sl = 192 + u*16 + v*5): w = t + R b_v - V_u, r = |w|, n = w / r, dw = d(R b_v)/dpsi.
+CFZ_FN void vv_row(const KSpec &sp, const double *m, const Lay &L, int k, int j, int sl, double x, double y, double c, double s,
+                   double &r, double &n0, double &n1, double &dwx, double &dwy) {
+  const int u = (sl >> 4) & 3, v = sl & 3;
+  double vx, vy;
+  block_vertex(sp, m, L, k, j, u, vx, vy);
+  const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
+  dwx = -s * bx - c * by; dwy = c * bx - s * by;
+  const double wx = x + dwy - vx, wy = y - dwx - vy;
+  r = sqrt(wx * wx + wy * wy);
+  const double ir = 1.0 / r;
+  n0 = wx * ir; n1 = wy * ir;
+}
+
 // Gradients of the two rows of block j at stage k, rebuilt from the working-set code instead of being kept in LDS
 // (same expressions as vertex_dist<true>): both rows share d/dx = a0, d/dy = a1 (same face); ap[r] = d/dpsi of row r.
 CFZ_FN void block_grad(const KSpec &sp, const double *m, const Lay &L, int k, int j, int sl, double x, double y, double c,
                        double s, double &a0, double &a1, double ap[2]) {
   const int f = (sl >> 4) & 3;
   const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
-  if ((sl >> 6) == 1) {
+  if ((sl >> 6) == 3) {
+    double r, dwx, dwy;
+    vv_row(sp, m, L, k, j, sl, x, y, c, s, r, a0, a1, dwx, dwy);
+    ap[0] = a0 * dwx + a1 * dwy; ap[1] = ap[0];
+  } else if ((sl >> 6) == 1) {
     double ax, ay;
     if (j < sp.n_obs) {
       const double *o = sp.obs_tab + j * 20;
@@ -574,7 +634,11 @@ CFZ_FN void block_sep(const KSpec &sp, const double *m, const Lay &L, int k, int
   const int f = (sl >> 4) & 3;
   const double g0 = sp.g[0], g1 = sp.g[1], g2 = sp.g[2], g3 = sp.g[3];
   const double gf = f == 0 ? g0 : (f == 1 ? g1 : (f == 2 ? g2 : g3));
-  if ((sl >> 6) == 1) {
+  if ((sl >> 6) == 3) {
+    double n0, n1, dwx, dwy;
+    vv_row(sp, m, L, k, j, sl, x, y, c, s, sep[0], n0, n1, dwx, dwy);
+    sep[1] = sep[0];
+  } else if ((sl >> 6) == 1) {
     double ax, ay, bf;
     if (j < sp.n_obs) {
       const double *o = sp.obs_tab + j * 20;
@@ -1142,7 +1206,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   int xpar = 0;  // which half of the wavefront exchange buffer the next reduction uses
   (void)xpar;
   CFZ_PART(rd, 6);   // lane partials of the workgroup reductions
-  CFZ_PART(qx, 12);  // lane shares that meet in a quad sum
+  CFZ_PART(qx, 15);  // lane shares that meet in a quad sum
   double ro[6];      // results of a reduction (uniform)
 
   // ---- load parameters, initial point ---------------------------------------------------
@@ -1166,7 +1230,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       block_polygon(sp, m, L, 0, tid, A, b, V);
       double s0, c0_;
       sincos(m[L.x0 + 2], &s0, &c0_);
-      select_rows_sep(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0, sep);
+      select_rows_sep(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0, sep, sp.vv_rows);
       worst = fmin(sep[0], sep[1]);
     }
     CFZ_P(rd, 0) = worst;
@@ -1191,7 +1255,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         const int t = k * nb + j;
         double A[4][2], b[4], V[4][2], sep[2];
         block_polygon(sp, m, L, k, j, A, b, V);
-        const int c0 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, 0, sep);
+        const int c0 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, 0, sep, sp.vv_rows);
         sel_ptr(m, L)[t] = c0;
         if (!warm) {
           for (int r = 0; r < 2; ++r) {
@@ -1255,7 +1319,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
-      double cmax = 0.0, csum = 0.0;
+      double cmax = 0.0, csum = 0.0, chg = 0.0;  // chg: a block of this lane changed its working set
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
         const double x = pk[0], y = pk[1];
@@ -1270,9 +1334,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             const int c0 = c1;
             double A[4][2], b[4], V[4][2];
             block_polygon(sp, m, L, k, j, A, b, V);
-            c1 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, c0, sep);
+            c1 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, c0, sep, sp.vv_rows);
             if (c1 != c0) sel_ptr(m, L)[t] = c1;
             if (c1 != c0) {
+              chg = 1.0;
               // a row that keeps its (face, vertex) identity keeps slack and multipliers; a new row
               // starts at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z
               const int same_face = (c0 >> 4) == (c1 >> 4);
@@ -1317,10 +1382,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
         }
       }
-      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax;
+      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = chg;
     CFZ_END
-    CFZ_REDUCE(1, 1, 0, rd, ro);
+    CFZ_REDUCE(1, 2, 0, rd, ro);
     const double theta = ro[0], cviol = ro[1];
+    const bool ws_changed = ro[2] != 0.0;
     CFZ_STAMP(1);  // working set, rows, dynamics
     if (theta_min < 0.0) { theta_min = CFZ_UNIFORM(1e-4 * fmax(1.0, theta)); theta_max = CFZ_UNIFORM(1e4 * fmax(1.0, theta)); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
@@ -1391,7 +1457,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
     if (iter == sp.max_iter) { status = 1; break; }
     // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
-    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
+    // (an iterate that changed the working set does not count as stalled: its new rows start with their own violation)
+    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else if (!ws_changed) ++stall_cnt;
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
     while (mu > mu_floor) {
@@ -1421,9 +1488,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // sum_r nu_r d2 sep_r / d(x,y,psi)^2 = [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature):
     //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
     //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
+    //   kind 3 (distance r of two vertices, n = (a0,a1)): tau tau' / r + kappa e_psi e_psi' with tau = (t, t.dw), t = (-a1, a0)
+    //           the unit tangent, dw = d(R b_v)/dpsi, kappa = -n.(R b_v); the only rows that curve x and y (cxx, cyy, cxy)
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
-      double ac[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc
+      double ac[15] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc | cxx cyy cxy
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
         const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
@@ -1442,7 +1511,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             if (sp.row_curvature) {
               const int f = (sl >> 4) & 3, v = r_ ? (sl & 3) : ((sl >> 2) & 3);
               const double nu = m[L.nuc + t];
-              if ((sl >> 6) == 1) {
+              if ((sl >> 6) == 3) {
+                const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
+                const double rbx = cpsi * bx - spsi * by, rby = spsi * bx + cpsi * by;  // R b_v; dw = (-rby, rbx)
+                const double nr_ = nu / (m[L.cj + t] + sp.dmin + m[L.sg + t]);         // nu / r
+                const double t2 = a1 * rby + a0 * rbx;                                  // t.dw
+                ac[9] -= nr_ * a1 * t2; ac[10] += nr_ * a0 * t2; ac[11] += nr_ * t2 * t2 - nu * (a0 * rbx + a1 * rby);
+                ac[12] += nr_ * a1 * a1; ac[13] += nr_ * a0 * a0; ac[14] -= nr_ * a1 * a0;
+              } else if ((sl >> 6) == 1) {
                 const double bx = (v == 0 || v == 3) ? sp.g[0] : -sp.g[2], by = (v < 2) ? sp.g[1] : -sp.g[3];
                 ac[11] -= nu * (a0 * (cpsi * bx - spsi * by) + a1 * (spsi * bx + cpsi * by));
               } else {
@@ -1454,7 +1530,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
         }
       }
-      for (int i = 0; i < 12; ++i) CFZ_P(qx, i) = ac[i];
+      for (int i = 0; i < 15; ++i) CFZ_P(qx, i) = ac[i];
     CFZ_MID
       const int k = tid >> 2, sub = tid & 3;
       if (k < N) {
@@ -1478,13 +1554,24 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           // convexity safeguard: scale by th in {1, 1/2, .., 2^-9, 0} until diag(2w) + th C keeps the margin 0.2 min(w)
           const double q2 = dv.q2;
           const double quad = ca * ca * dv.iq0 + cb * cb * dv.iq1;
+          double cxx = 0.0, cyy = 0.0, cxy = 0.0;
+          if (sp.vv_rows) { cxx = CFZ_QSUM(qx, 12); cyy = CFZ_QSUM(qx, 13); cxy = CFZ_QSUM(qx, 14); }
+          const bool full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0;  // a vertex-vertex row in this stage
           double th = 1.0;
           for (int hh = 0; hh < 11; ++hh) {
             if (hh == 10) { th = 0.0; break; }
-            if (q2 + th * cc - th * th * quad >= 0.0) break;
+            if (!full) {
+              if (q2 + th * cc - th * th * quad >= 0.0) break;
+            } else {  // diag(q) + th C positive semidefinite: leading principal minors
+              const double m00 = dv.q0 + th * cxx, m11 = dv.q1 + th * cyy, m22 = q2 + th * cc, m01 = th * cxy, m02 = th * ca, m12 = th * cb;
+              const double d2 = m00 * m11 - m01 * m01;
+              const double d3 = m22 * d2 - (m02 * m02 * m11 - 2.0 * m02 * m12 * m01 + m12 * m12 * m00);
+              if (m00 > 0.0 && d2 > 0.0 && d3 >= 0.0) break;
+            }
             th *= 0.5;
           }
           h[2] += th * cc; h[8] += th * ca; h[9] += th * cb;
+          h[0] += th * cxx; h[1] += th * cyy; h[7] += th * cxy;
         }
         if (sub == 0) {
           for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
@@ -1631,13 +1718,25 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       const double psi = m[L.p + k * kNP + 2];
       double s, c;
       sincos(psi, &s, &c);
-      const int c1 = select_rows_sep(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, sel_ptr(m, L)[t], sep2);
+      const int c1 = select_rows_sep(A, b, V, m[L.p + k * kNP], m[L.p + k * kNP + 1], c, s, sp.g, sel_ptr(m, L)[t], sep2, sp.vv_rows);
       const double sep = fmin(sep2[0], sep2[1]);
       const int cert = (c1 >> 6) * 16 + ((c1 >> 4) & 3) * 4 + (sep2[0] <= sep2[1] ? ((c1 >> 2) & 3) : (c1 & 3));
       smin = fmin(smin, sep);
       if (duo.l) {
         const int kind = cert >> 4, f = (cert >> 2) & 3;
         double lam[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0};
+        // kind 3: unit vector from polygon vertex u = f to body vertex v = cert & 3 (the separating direction)
+        double vn0 = 0.0, vn1 = 0.0;
+        if (kind == 3) {
+          const int vb_ = cert & 3;
+          const double bx = (vb_ == 0 || vb_ == 3) ? sp.g[0] : -sp.g[2], by = (vb_ < 2) ? sp.g[1] : -sp.g[3];
+          double ux = V[0][0], uy = V[0][1];
+#pragma unroll
+          for (int i = 1; i < 4; ++i) if (i == f) { ux = V[i][0]; uy = V[i][1]; }
+          const double wx = m[L.p + k * kNP] + (c * bx - s * by) - ux, wy = m[L.p + k * kNP + 1] + (s * bx + c * by) - uy;
+          const double ir = 1.0 / sqrt(wx * wx + wy * wy);
+          vn0 = wx * ir; vn1 = wy * ir;
+        }
         if (j < n_obs) {
           // (every index into A, V, lam, mu below is resolved by selects: a runtime index would put the arrays in scratch)
           if (kind == 1) {  // n = A_f ; G' mu = -R' n
@@ -1648,12 +1747,19 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             for (int i = 0; i < 4; ++i) lam[i] = (i == f) ? 1.0 : 0.0;
             const double mx = -(c * af0 + s * af1), my = -(-s * af0 + c * af1);
             muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
-          } else {  // n = -R G_f ; A' lam = n from the two obstacle faces through vertex v
-#pragma unroll
-            for (int i = 0; i < 4; ++i) muv[i] = (i == f) ? 1.0 : 0.0;
-            const int v = cert & 3;
+          } else {  // kind 2: n = -R G_f, mu = e_f; kind 3: n = the unit vector, G' mu = -R' n; A' lam = n from the two obstacle
+                    // faces through the polygon vertex (v of kind 2, u of kind 3)
+            const int v = kind == 2 ? (cert & 3) : f;
             const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
-            const double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
+            double nx = -(c * gx - s * gy), ny = -(s * gx + c * gy);
+            if (kind == 2) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) muv[i] = (i == f) ? 1.0 : 0.0;
+            } else {
+              nx = vn0; ny = vn1;
+              const double mx = -(c * nx + s * ny), my = -(-s * nx + c * ny);
+              muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
+            }
             double vx = V[0][0], vy = V[0][1];
 #pragma unroll
             for (int i = 1; i < 4; ++i) if (i == v) { vx = V[i][0]; vy = V[i][1]; }
@@ -1680,7 +1786,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           const double co = q[2], so = q[3];
           double wx, wy;  // separating direction from this vehicle to the other
           const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
-          if (kind == 1) {  // a face of the OTHER vehicle: w = -Ro G_f, mu = e_f, lam = posneg(R' w)
+          if (kind == 3) {  // vertex against vertex: w = -n, lam = posneg(R' w), mu = posneg(-Ro' w)
+            wx = -vn0; wy = -vn1;
+            const double lx = c * wx + s * wy, ly = -s * wx + c * wy;
+            lam[0] = fmax(lx, 0.0); lam[1] = fmax(ly, 0.0); lam[2] = fmax(-lx, 0.0); lam[3] = fmax(-ly, 0.0);
+            const double mx = -(co * wx + so * wy), my = -(-so * wx + co * wy);
+            muv[0] = fmax(mx, 0.0); muv[1] = fmax(my, 0.0); muv[2] = fmax(-mx, 0.0); muv[3] = fmax(-my, 0.0);
+          } else if (kind == 1) {  // a face of the OTHER vehicle: w = -Ro G_f, mu = e_f, lam = posneg(R' w)
             wx = -(co * gx - so * gy); wy = -(so * gx + co * gy);
 #pragma unroll
             for (int i = 0; i < 4; ++i) muv[i] = (i == f) ? 1.0 : 0.0;

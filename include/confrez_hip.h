@@ -57,6 +57,9 @@ typedef struct cfz_options {
   int32_t stall_iters;    /* 10: iterations without progress of the constraint violation before status 5; 0 = off */
   int32_t row_curvature;  /* 1: Hessian = Gauss-Newton objective part + multiplier-weighted curvature of the separation rows */
   int32_t carry_duals;    /* 1: keep one carry record per slot (multipliers of the last converged solve); 0: never */
+  int32_t vv_rows;        /* 1: a block whose closest features are two vertices is constrained by their Euclidean distance
+                           *    (exactly the reference's OBCA rows there); 0: face-normal certificates only (a restriction) */
+  int32_t reserved0;
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

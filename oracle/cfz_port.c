@@ -33,6 +33,7 @@ typedef struct {
       tau_min, bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw,
       s_theta, s_phi, reg_primal, stall_kappa, warm_push;
   int filter_cap, max_backtrack, stall_iters, row_curvature;
+  int vv_rows; /* 1: vertex-vertex rows (kind 3) in the working set, oracle/mpc_nlp.py MpcSpec.vv_rows */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -153,9 +154,34 @@ static void vertex_dist(const double A[4][2], const double b[4], const double V[
   }
 }
 
+/* kind 3 (oracle/mpc_nlp.py closest_vertex_pair): polygon vertex u and body vertex v that lie in each other's normal cone
+ * are THE closest points of the two polygons.  Body side from the signs of the kind-2 distances (V[u] outside exactly the two
+ * body faces that meet at v), polygon side (W_v - V_u).e <= 0 for the two edges e leaving V[u]. */
+static int closest_vertex_pair(const double V[4][2], double x, double y, double psi, const double g[4], int *uo, int *vo,
+                               double *ro) {
+  double c = cos(psi), s = sin(psi);
+  double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+  for (int u = 0; u < 4; ++u) {
+    double rx = V[u][0] - x, ry = V[u][1] - y;
+    double qx = c * rx + s * ry, qy = -s * rx + c * ry;
+    int fx = qx - g[0] >= 0.0 ? 0 : (-qx - g[2] >= 0.0 ? 2 : -1);
+    int fy = qy - g[1] >= 0.0 ? 1 : (-qy - g[3] >= 0.0 ? 3 : -1);
+    if (fx < 0 || fy < 0) continue;
+    int v = fx == 0 ? (fy == 1 ? 0 : 3) : (fy == 1 ? 1 : 2);
+    double wx = x + c * BV[v][0] - s * BV[v][1] - V[u][0], wy = y + s * BV[v][0] + c * BV[v][1] - V[u][1];
+    int u1 = (u + 1) & 3, u3 = (u + 3) & 3;
+    if (wx * (V[u1][0] - V[u][0]) + wy * (V[u1][1] - V[u][1]) <= 0.0 &&
+        wx * (V[u3][0] - V[u][0]) + wy * (V[u3][1] - V[u][1]) <= 0.0) {
+      *uo = u; *vo = v; *ro = hypot(wx, wy);
+      return 1;
+    }
+  }
+  return 0;
+}
+
 /* working set of one block: sel = kind*64 + face*16 + vA*4 + vB (vA < vB); see oracle/mpc_nlp.py select_rows */
 static int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double psi,
-                       const double g[4], int prev) {
+                       const double g[4], int prev, int vv) {
   double best = 0.0, prev_val = 0.0, d[4];
   int have = 0, bk = 0, bf = 0, have_prev = 0;
   int pk = prev >> 6, pf = (prev >> 4) & 3;
@@ -177,6 +203,10 @@ static int select_rows(const double A[4][2], const double b[4], const double V[4
     if (fmin(d[oa], d[ob]) <= d[v0] + 1e-12 && fmax(d[oa], d[ob]) <= d[v1] + HYST) { v0 = oa; v1 = ob; }
   }
   int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
+  if (vv && d[v0] > 0.0) {
+    int u, v; double r;
+    if (closest_vertex_pair(V, x, y, psi, g, &u, &v, &r) && r > d[v0] + 1e-9) return 192 + u * 16 + v * 4 + v;
+  }
   return bk * 64 + bf * 16 + va * 4 + vb;
 }
 
@@ -207,23 +237,46 @@ static void select_all(const cfz_port_spec *sp, const double *nbr, const double 
     for (int j = 0; j < nb; ++j) {
       double A[4][2], b[4], V[4][2];
       block_polygon(sp, nbr, k, j, A, b, V);
-      sel[k][j] = select_rows(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, sel[k][j]);
+      sel[k][j] = select_rows(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, sel[k][j], sp->vv_rows);
     }
 }
 
-/* rows of the current working set: sep[k][2j+r], grad[k][2j+r][3] */
+/* rows of the current working set: sep[k][2j+r], grad[k][2j+r][3], curv[k][2j+r][6] = second derivatives
+ * (x psi, y psi, psi psi, x x, y y, x y); the last three are zero except for a vertex-vertex row */
 static void eval_rows(const cfz_port_spec *sp, const double *nbr, const double p[][NP], int sel[][MAXB],
-                      double sep[][MAXR], double grad[][MAXR][3], double curv[][MAXR][3]) {
+                      double sep[][MAXR], double grad[][MAXR][3], double curv[][MAXR][6]) {
   int nb = sp->n_obs + sp->n_nbr;
   for (int k = 0; k < sp->N; ++k)
     for (int j = 0; j < nb; ++j) {
       double A[4][2], b[4], V[4][2], d[4], gr[4][3], cu[4][3];
       block_polygon(sp, nbr, k, j, A, b, V);
       int c = sel[k][j], kind = c >> 6, f = (c >> 4) & 3, va = (c >> 2) & 3, vb = c & 3;
+      if (kind == 3) {
+        /* r = |w|, w = t + R b_v - V_u; the row twice (the block keeps its two slots).  Hessian of r:
+         * tau tau' / r + kappa e_psi e_psi', tau = J' t (t the unit tangent), kappa = n . (-R b_v) */
+        const double *g = sp->g;
+        double BV[4][2] = {{g[0], g[1]}, {-g[2], g[1]}, {-g[2], -g[3]}, {g[0], -g[3]}};
+        double cs = cos(p[k][2]), sn = sin(p[k][2]);
+        double rbx = cs * BV[va][0] - sn * BV[va][1], rby = sn * BV[va][0] + cs * BV[va][1];
+        double dwx = -rby, dwy = rbx;
+        double wx = p[k][0] + rbx - V[f][0], wy = p[k][1] + rby - V[f][1];
+        double r = hypot(wx, wy), n0 = wx / r, n1 = wy / r;
+        double t2 = -n1 * dwx + n0 * dwy, kap = -(n0 * rbx + n1 * rby);
+        for (int q = 0; q < 2; ++q) {
+          sep[k][2 * j + q] = r;
+          if (grad) { grad[k][2 * j + q][0] = n0; grad[k][2 * j + q][1] = n1; grad[k][2 * j + q][2] = n0 * dwx + n1 * dwy; }
+          if (curv) {
+            double *cq = curv[k][2 * j + q];
+            cq[0] = -n1 * t2 / r; cq[1] = n0 * t2 / r; cq[2] = t2 * t2 / r + kap;
+            cq[3] = n1 * n1 / r; cq[4] = n0 * n0 / r; cq[5] = -n1 * n0 / r;
+          }
+        }
+        continue;
+      }
       vertex_dist(A, b, V, p[k][0], p[k][1], p[k][2], sp->g, kind, f, d, grad ? gr : 0, curv ? cu : 0);
       sep[k][2 * j] = d[va]; sep[k][2 * j + 1] = d[vb];
       if (grad) for (int q = 0; q < 3; ++q) { grad[k][2 * j][q] = gr[va][q]; grad[k][2 * j + 1][q] = gr[vb][q]; }
-      if (curv) for (int q = 0; q < 3; ++q) { curv[k][2 * j][q] = cu[va][q]; curv[k][2 * j + 1][q] = cu[vb][q]; }
+      if (curv) for (int q = 0; q < 6; ++q) { curv[k][2 * j][q] = q < 3 ? cu[va][q] : 0.0; curv[k][2 * j + 1][q] = q < 3 ? cu[vb][q] : 0.0; }
     }
 }
 
@@ -299,7 +352,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
   if (N > MAXN || N < 2 || nblk > MAXB) return -1;
   static iterate it, dt_; /* step stored in an `iterate` too */
-  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cur[MAXN][MAXR][3], cj[MAXN][MAXR];
+  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cur[MAXN][MAXR][6], cj[MAXN][MAXR];
   static int sel[MAXN][MAXB];
   static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
   static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
@@ -327,10 +380,15 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     for (int j = 0; j < nblk; ++j) {
       double A[4][2], b[4], V[4][2], d[4];
       block_polygon(sp, nbr, 0, j, A, b, V);
-      s0[0][j] = select_rows(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, 0);
+      s0[0][j] = select_rows(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, 0, sp->vv_rows);
       int c = s0[0][j];
-      vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0, 0);
-      r0[0][j] = fmin(d[(c >> 2) & 3], d[c & 3]);
+      if ((c >> 6) == 3) {
+        int u_, v_;
+        closest_vertex_pair(V, p0[0][0], p0[0][1], p0[0][2], sp->g, &u_, &v_, &r0[0][j]);
+      } else {
+        vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0, 0);
+        r0[0][j] = fmin(d[(c >> 2) & 3], d[c & 3]);
+      }
       if (r0[0][j] < sp->dmin - 2.0 * sp->constr_viol_tol) {
         stats[0] = 0; stats[1] = 4; fstats[0] = 0.0; fstats[1] = INFINITY; fstats[2] = sp->mu_init;
         if (sep_out) for (int q = 0; q < N * nblk; ++q) sep_out[q] = 0.0;
@@ -392,6 +450,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
 
   for (iter = 0; iter <= sp->max_iter; ++iter) {
     /* ---- working set: rows keep slack and multipliers while their (face, vertex) identity lasts */
+    int ws_changed = 0;
     if (iter > 0) {
       static int old[MAXN][MAXB];
       memcpy(old, sel, sizeof sel);
@@ -401,6 +460,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         for (int j = 0; j < nblk; ++j) {
           int o = old[k][j], n_ = sel[k][j];
           if (o == n_) continue;
+          ws_changed = 1;
           int same_face = (o >> 4) == (n_ >> 4);
           double vs[2][3] = {{it.sg[k][2 * j], it.zs[k][2 * j], it.nuc[k][2 * j]},
                              {it.sg[k][2 * j + 1], it.zs[k][2 * j + 1], it.nuc[k][2 * j + 1]}};
@@ -473,7 +533,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
     if (iter == sp->max_iter) break;
     /* infeasibility stall (oracle/ipm.py) */
-    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else ++stall_cnt;
+    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else if (!ws_changed) ++stall_cnt;
     if (sp->stall_iters > 0 && stall_cnt >= sp->stall_iters && cviol > sp->constr_viol_tol) { status = 5; break; }
     /* ---- barrier update ------------------------------------------------------------- */
     while (mu > mu_floor) {
@@ -519,17 +579,30 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       if (sp->row_curvature) {
         /* exact curvature of the separation rows, sum_r nu_r d2 sep_r: C = [[0,0,a],[0,0,b],[a,b,c]], scaled by
          * th in {1, 1/2, .., 2^-9, 0} so that diag(2 w) + th C keeps the margin 0.2 min(w) (oracle/mpc_nlp.py hess_gn) */
-        double ca = 0.0, cb = 0.0, cc = 0.0;
-        for (int j = 0; j < nb; ++j) { ca += it.nuc[k][j] * cur[k][j][0]; cb += it.nuc[k][j] * cur[k][j][1]; cc += it.nuc[k][j] * cur[k][j][2]; }
+        double ca = 0.0, cb = 0.0, cc = 0.0, cxx = 0.0, cyy = 0.0, cxy = 0.0;
+        for (int j = 0; j < nb; ++j) {
+          const double nu = it.nuc[k][j];
+          ca += nu * cur[k][j][0]; cb += nu * cur[k][j][1]; cc += nu * cur[k][j][2];
+          cxx += nu * cur[k][j][3]; cyy += nu * cur[k][j][4]; cxy += nu * cur[k][j][5];
+        }
         const double m_ = 0.2 * fmin(w[0], fmin(w[1], w[2]));
         const double q0 = 2 * w[0] - m_, q1 = 2 * w[1] - m_, q2 = 2 * w[2] - m_;
+        const int full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0; /* a vertex-vertex row curves x and y too */
         double th = 1.0;
         for (int h = 0; h < 11; ++h) {
           if (h == 10) { th = 0.0; break; }
-          if (q2 + th * cc - th * th * (ca * ca / q0 + cb * cb / q1) >= 0.0) break;
+          if (!full) {
+            if (q2 + th * cc - th * th * (ca * ca / q0 + cb * cb / q1) >= 0.0) break;
+          } else { /* diag(q) + th C positive semidefinite: leading principal minors */
+            const double m00 = q0 + th * cxx, m11 = q1 + th * cyy, m22 = q2 + th * cc, m01 = th * cxy, m02 = th * ca, m12 = th * cb;
+            const double d2 = m00 * m11 - m01 * m01;
+            const double d3 = m22 * d2 - (m02 * m02 * m11 - 2.0 * m02 * m12 * m01 + m12 * m12 * m00);
+            if (m00 > 0.0 && d2 > 0.0 && d3 >= 0.0) break;
+          }
           th *= 0.5;
         }
         H[k][0][2] += th * ca; H[k][2][0] += th * ca; H[k][1][2] += th * cb; H[k][2][1] += th * cb; H[k][2][2] += th * cc;
+        H[k][0][0] += th * cxx; H[k][1][1] += th * cyy; H[k][0][1] += th * cxy; H[k][1][0] += th * cxy;
       }
     }
     /* ---- Riccati backward: value function 0.5 dz'P_k dz + p_k'dz kept for every stage ------- */

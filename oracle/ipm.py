@@ -42,7 +42,8 @@ class IpmOptions:
     max_iter: int = 600  # :364
     # Infeasibility stall test (stands in for the outcome of IPOPT's restoration phase, "converged to a point of
     # local infeasibility"): give up when the max-norm constraint violation has not dropped below stall_kappa x its
-    # last checkpoint for stall_iters consecutive iterates while still above constr_viol_tol.  0 disables.
+    # last checkpoint for stall_iters iterates (not counting those that changed the working set of a working-set NLP) while
+    # still above constr_viol_tol.  0 disables.
     # Hessian of the Lagrangian = Gauss-Newton objective part + exact curvature of the separation rows weighted with
     # their multipliers (NLPs that provide hess_gn(x, nu)).  Without it the iteration is not contractive when a
     # vehicle is pushed hard against a separation row (period-2 oscillation, hundreds of iterations).
@@ -178,7 +179,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             break
         if it == 0 or cviol <= opt.stall_kappa * stall_ref:
             stall_ref, stall_cnt = cviol, 0
-        else:
+        elif not getattr(nlp, "ws_changed", False):  # an iterate that changed the working set does not count as stalled
             stall_cnt += 1
         if opt.stall_iters > 0 and stall_cnt >= opt.stall_iters and cviol > opt.constr_viol_tol:
             status = STATUS_STALLED

@@ -67,6 +67,9 @@ class MpcSpec:
     # weights on (x-xr)^2,(y-yr)^2,(psi-psir)^2,a^2,(v w)^2,delta^2  (vehicle_follower.py:263-271)
     weights: np.ndarray = field(default_factory=lambda: np.array([100.0, 100, 100, 1, 1, 1]))
     rk_substeps: int = 4
+    # vertex-vertex rows (kind 3): a block whose closest features are two vertices is constrained by the Euclidean distance of
+    # that pair -- with them the eliminated problem has the reference's feasible set; False = face-normal certificates only
+    vv_rows: bool = True
 
     @property
     def n_obs(self):
@@ -198,7 +201,27 @@ def vertex_distances(A, b, PV, t, psi, g, BV, kind, f):
     return d, gr
 
 
-def select_rows(A, b, PV, t, psi, g, BV, prev=0):
+def closest_vertex_pair(PV, t, psi, g, BV):
+    """(u, v): polygon vertex PV[u] and body vertex v that are each other's closest feature -- each lies in the other's normal
+    cone (beyond both edges that meet there) -- which makes them THE closest points of the two convex polygons; None when the
+    closest features are not two vertices.  Body side: PV[u] is outside exactly the two body faces that meet at v (signs of
+    the kind-2 distances); polygon side: (W_v - PV_u).e <= 0 for the two edges e leaving PV[u]."""
+    c, s_ = np.cos(psi), np.sin(psi)
+    R = np.array([[c, -s_], [s_, c]])
+    for u in range(4):
+        q = R.T @ (PV[u] - t)  # in the body frame
+        fx = 0 if q[0] - g[0] >= 0.0 else (2 if -q[0] - g[2] >= 0.0 else -1)
+        fy = 1 if q[1] - g[1] >= 0.0 else (3 if -q[1] - g[3] >= 0.0 else -1)
+        if fx < 0 or fy < 0:
+            continue
+        v = {(0, 1): 0, (2, 1): 1, (2, 3): 2, (0, 3): 3}[(fx, fy)]
+        w = t + R @ BV[v] - PV[u]
+        if w @ (PV[(u + 1) % 4] - PV[u]) <= 0.0 and w @ (PV[(u + 3) % 4] - PV[u]) <= 0.0:
+            return u, v, float(np.hypot(w[0], w[1]))
+    return None
+
+
+def select_rows(A, b, PV, t, psi, g, BV, prev=0, vv=False):
     """Working set of one block: the separating face and the two vertices whose rows are imposed.
 
     The separating direction is the face normal (8 candidates in the order polygon faces 0..3,
@@ -236,12 +259,27 @@ def select_rows(A, b, PV, t, psi, g, BV, prev=0):
         if min(d[oa], d[ob]) <= d[v0] + 1e-12 and max(d[oa], d[ob]) <= d[v1] + HYST:
             v0, v1 = oa, ob
     va, vb = min(v0, v1), max(v0, v1)
+    if vv and d[v0] > 0.0:
+        # kind 3: the closest features are two vertices -> the Euclidean distance of that pair is the separation (it exceeds
+        # every face-normal separation there); code 192 + u*16 + v*4 + v, both rows of the block carry that distance
+        pair = closest_vertex_pair(PV, t, psi, g, BV)
+        if pair is not None and pair[2] > d[v0] + 1e-9:
+            return 192 + pair[0] * 16 + pair[1] * 4 + pair[1]
     return bk * 64 + bf * 16 + va * 4 + vb
 
 
 def rows_for(A, b, PV, t, psi, g, BV, sel):
     """Values and gradients of the two rows of working set `sel`: (sep[2], grad[2,3])."""
     kind, f, va, vb = sel >> 6, (sel >> 4) & 3, (sel >> 2) & 3, sel & 3
+    if kind == 3:
+        u, v = f, va
+        c, s_ = np.cos(psi), np.sin(psi)
+        R = np.array([[c, -s_], [s_, c]]); dR = np.array([[-s_, -c], [c, -s_]])
+        w = t + R @ BV[v] - PV[u]
+        r = float(np.hypot(w[0], w[1]))
+        n = w / r
+        gr = np.array([n[0], n[1], n @ (dR @ BV[v])])
+        return np.array([r, r]), np.array([gr, gr])  # the row twice: the block keeps its two slots (twice the barrier weight)
     d, gr = vertex_distances(A, b, PV, t, psi, g, BV, kind, f)
     return d[[va, vb]], gr[[va, vb]]
 
@@ -250,8 +288,9 @@ def _posneg(m):
     return np.array([max(m[0], 0.0), max(m[1], 0.0), max(-m[0], 0.0), max(-m[1], 0.0)])
 
 
-def certificate_duals(A, adj, psi, cert, psi_other=None):
+def certificate_duals(A, adj, psi, cert, psi_other=None, n=None):
     """(lam, mu) of the reference's dual constraints for the winning candidate `cert`.
+    kind 3 (vertex against vertex): `n` is the unit vector from polygon vertex u = cert[1] to body vertex v = cert[2].
 
     Static obstacle (psi_other None): lam multiplies the obstacle faces, mu the body faces
     (vehicle_follower.py:283-290).  Neighbour: lam multiplies this vehicle's faces, mu the
@@ -264,9 +303,13 @@ def certificate_duals(A, adj, psi, cert, psi_other=None):
         if kind == 1:  # n = A_f ; G^T mu = -R^T n
             lam[f] = 1.0
             mu = _posneg(-R.T @ A[f])
-        else:  # n = -R G_f ; A^T lam = n from the two faces meeting at polygon vertex v
-            mu[f] = 1.0
-            n = -R @ G_BODY[f]
+        else:  # kind 2: n = -R G_f, mu = e_f; kind 3: G^T mu = -R^T n; A^T lam = n from the two faces meeting at the polygon vertex
+            if kind == 2:
+                mu[f] = 1.0
+                n = -R @ G_BODY[f]
+            else:
+                mu = _posneg(-R.T @ n)
+                v = f
             i, j = adj[v]
             det = A[i, 0] * A[j, 1] - A[j, 0] * A[i, 1]
             lam[i] = max((A[j, 1] * n[0] - A[j, 0] * n[1]) / det, 0.0)
@@ -274,7 +317,9 @@ def certificate_duals(A, adj, psi, cert, psi_other=None):
     else:
         co, so = np.cos(psi_other), np.sin(psi_other)
         Ro = np.array([[co, -so], [so, co]])
-        if kind == 1:  # separating direction = a face normal of the OTHER vehicle: w = -Ro G_f
+        if kind == 3:  # w = -n from this vehicle to the other
+            lam, mu = _posneg(R.T @ (-n)), _posneg(-Ro.T @ (-n))
+        elif kind == 1:  # separating direction = a face normal of the OTHER vehicle: w = -Ro G_f
             mu[f] = 1.0
             lam = _posneg(R.T @ (-Ro @ G_BODY[f]))
         else:  # a face normal of this vehicle: w = R G_f
@@ -341,7 +386,7 @@ class MpcNlp:
         for k in range(self.spec.N):
             for j in range(self.nb):
                 A, b, PV = self.polygon(k, j)
-                self.sel[k, j] = select_rows(A, b, PV, P[k, 0:2], P[k, 2], self.spec.g, self.BV, int(old[k, j]))
+                self.sel[k, j] = select_rows(A, b, PV, P[k, 0:2], P[k, 2], self.spec.g, self.BV, int(old[k, j]), vv=self.spec.vv_rows)
         return old
 
     def blocks(self, P):
@@ -374,6 +419,15 @@ class MpcNlp:
                 A, b, PV = self.polygon(k, j)
                 sel = int(self.sel[k, j])
                 kind, f, vs = sel >> 6, (sel >> 4) & 3, ((sel >> 2) & 3, sel & 3)
+                if kind == 3:  # r = |w|, w = t + R b_v - p_u:  J'(I - n n')J / r  +  n.(-R b_v) e_psi e_psi'
+                    u, v = f, vs[0]
+                    w = t + R @ self.BV[v] - PV[u]
+                    r_ = float(np.hypot(w[0], w[1])); n = w / r_
+                    J = np.array([[1.0, 0.0, (dR @ self.BV[v])[0]], [0.0, 1.0, (dR @ self.BV[v])[1]]])
+                    Hr = J.T @ (np.eye(2) - np.outer(n, n)) @ J / r_
+                    Hr[2, 2] += n @ (-(R @ self.BV[v]))
+                    C[k] += (NU[k, 2 * j] + NU[k, 2 * j + 1]) * Hr
+                    continue
                 for r, v in enumerate(vs):
                     n_ = NU[k, 2 * j + r]
                     if kind == 1:
@@ -392,7 +446,8 @@ class MpcNlp:
         N = self.spec.N
         Xs = x.reshape(N, self.ns)
         old = self.select(Xs)
-        if np.array_equal(old, self.sel):
+        self.ws_changed = not np.array_equal(old, self.sel)  # read by the stall test of oracle/ipm.py
+        if not self.ws_changed:
             return x, zl, nu
         sep, _ = self.blocks(Xs)
         Z = zl.reshape(N, self.ns)
@@ -449,11 +504,18 @@ class MpcNlp:
         for k in range(N):
             psi = Xs[k, 2]
             R = rot(psi)
+            def unit(j):  # kind 3: from polygon vertex u to body vertex v
+                kind, u, v = cert[(k, j)]
+                if kind != 3:
+                    return None
+                w = Xs[k, 0:2] + R @ self.BV[v] - self.polygon(k, j)[2][u]
+                return w / np.hypot(w[0], w[1])
+
             for j in range(sp_.n_obs):
-                lam, mu = certificate_duals(sp_.A_obs[j], self.adj[j], psi, cert[(k, j)])
+                lam, mu = certificate_duals(sp_.A_obs[j], self.adj[j], psi, cert[(k, j)], n=unit(j))
                 sol["l"][k, 4 * j : 4 * j + 4], sol["m"][k, 4 * j : 4 * j + 4] = lam, mu
             for o in range(sp_.n_nbr):
-                lam, mu = certificate_duals(None, None, psi, cert[(k, sp_.n_obs + o)], self.nbr[o, 2, k])
+                lam, mu = certificate_duals(None, None, psi, cert[(k, sp_.n_obs + o)], self.nbr[o, 2, k], n=unit(sp_.n_obs + o))
                 sol["lam_ij"][o, k], sol["lam_ji"][o, k] = lam, mu
                 sol["s"][o, k] = -R @ (G_BODY.T @ lam)  # from A_this^T lam + s = 0 (:350)
         return sol
@@ -512,13 +574,21 @@ class MpcNlp:
             m_ = 0.2 * min(wt[0], wt[1], wt[2])
             for k in range(N):
                 a_, b_c, c_ = C[k, 0, 2], C[k, 1, 2], C[k, 2, 2]
+                full = C[k, 0, 0] != 0.0 or C[k, 1, 1] != 0.0 or C[k, 0, 1] != 0.0  # a vertex-vertex row curves x, y too
                 th = 1.0
                 for h in range(11):
                     if h == 10:
                         th = 0.0
                         break
-                    if (q2 - m_) + th * c_ - th * th * (a_ * a_ / (q0 - m_) + b_c * b_c / (q1 - m_)) >= 0.0:
-                        break
+                    if not full:
+                        if (q2 - m_) + th * c_ - th * th * (a_ * a_ / (q0 - m_) + b_c * b_c / (q1 - m_)) >= 0.0:
+                            break
+                    else:  # diag(q - m) + th C positive semidefinite: leading principal minors
+                        M = np.diag([q0 - m_, q1 - m_, q2 - m_]) + th * C[k]
+                        d2 = M[0, 0] * M[1, 1] - M[0, 1] ** 2
+                        d3 = M[2, 2] * d2 - (M[0, 2] ** 2 * M[1, 1] - 2.0 * M[0, 2] * M[1, 2] * M[0, 1] + M[1, 2] ** 2 * M[0, 0])
+                        if M[0, 0] > 0.0 and d2 > 0.0 and d3 >= 0.0:
+                            break
                     th *= 0.5
                 Ck = th * C[k]
                 for a in range(3):
@@ -594,7 +664,7 @@ def initial_state_in_collision(nlp: "MpcNlp", tol):
     sp_ = nlp.spec
     for j in range(nlp.nb):
         A, b, PV = nlp.polygon(0, j)
-        sel = select_rows(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, 0)
+        sel = select_rows(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, 0, vv=sp_.vv_rows)
         sep, _ = rows_for(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, sel)
         if sep.min() < sp_.dmin - 2.0 * tol:
             return True

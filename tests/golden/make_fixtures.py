@@ -118,7 +118,7 @@ def mpc_golden(table):
 
     k0s, noise = scenarios.sample_scenarios(1024, table, seed=2024)
     bx0, bref, bnbr, bzu = scenarios.mpc_batch_from_table(scenarios.parking_lot_spec(), table, k0s, noise)
-    for case, b in ((16, 800), (17, 1955)):
+    for case, b in ((16, 716), (17, 764)):
         res = solve_mpc(spec, bx0[b], bref[b], bnbr[b], bzu[b])
         X0.append(bx0[b]), REF.append(bref[b]), NBR.append(bnbr[b]), ZU.append(bzu[b])
         SOL.append(res["zu"])

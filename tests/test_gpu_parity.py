@@ -398,8 +398,8 @@ def test_python_shim_closed_loop_on_gpu(tmp_path):
 def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
     """The HIP engine through the C ABI against optima of the reference's NLP computed by an INDEPENDENT solver on an
     independent statement (polygon distances instead of OBCA duals, scipy SLSQP; tests/golden/mpc_independent.npz,
-    N = 30, six obstacles, three neighbours): same optimum wherever no vertex-vertex pair is active, feasible for the
-    reference's constraints everywhere, measured gap where the face-normal certificates are a strict restriction.
+    N = 30, six obstacles, three neighbours): feasible for the reference's constraints everywhere and the same optimum,
+    vertex-vertex contacts included (one instance ends at another stationary point of the same problem, +0.27 %).
     The assertions are tests/test_independent_solver.py:check_against_independent, shared with the CPU test of the port."""
     from conflict_rez_amd import engine, scenarios
     from test_independent_solver import TIGHT_FULL, _independent_fixture, check_against_independent
@@ -410,10 +410,7 @@ def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
     out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
 
     def solve(b, x0, ref, nbr, zu):
-        st = int(out["status"][b])
-        # at 1e-8 a line search that finds no further decrease (status 2) is the floating-point end of the road; whether the
-        # point IS the optimum is what the shared assertions check (feasibility 1e-6, cost gap 1e-6, poses 1e-4)
-        return (0 if (st == 2 and not prod) else st), out["zu"][b]
+        return int(out["status"][b]), out["zu"][b]
 
     check_against_independent(solve, 1e-4, prod)
     e.close()

@@ -200,23 +200,25 @@ def _independent_fixture():
 
 def check_against_independent(solve, tight_tol, prod):
     """Shared by the CPU test (C port) and the GPU test (HIP engine): `solve(b, x0, ref, nbr, zu) -> (status, zu [7, N])`.
-    What is asserted, per instance class (fixture flags from the independent optimum):
-      * always: the engine's trajectory satisfies the GEOMETRIC statement of the reference's constraints (polygon distance
-        >= dmin, dynamics, initial state) -- i.e. it is feasible for the reference's NLP -- and cannot beat the independent
-        optimum;
-      * no vertex-vertex pair active (instances 0-6): same optimum -- cost to 1e-6 (tight) / 1e-4 (production tolerances),
-        poses to 1e-4 m / rad (tight) and inside the claimed band 5e-2 m, 5e-2 rad at the production tolerance 1e-2;
-      * a vertex-vertex pair active (instances 8-11): the engine's face-normal certificates are a strict restriction there
-        (DESIGN.md): measured cost gap 0.19-0.78 %, poses within 1.1 cm;
-      * instance 7 (nine active rows): the engine converges to ANOTHER stationary point of its restricted problem (cost 2.0 x
-        the independent optimum); started from the independent optimum it stays there.  Kept in the fixture on purpose."""
+    What is asserted per instance of the fixture:
+      * the engine's trajectory satisfies the GEOMETRIC statement of the reference's constraints (polygon distance >= dmin,
+        dynamics, initial state) -- i.e. it is feasible for the reference's NLP -- and cannot beat the independent optimum;
+      * same optimum as the independent solver: cost to 1e-6 (tight) / 1e-4 (production tolerances), poses to 1e-4 m / rad
+        (tight) and inside the claimed band 5e-2 m, 5e-2 rad at the production tolerance 1e-2.  That holds with a
+        vertex-vertex pair active too (instances 8-11: the working set then carries the Euclidean distance of the pair,
+        kind 3) and for instance 7 (nine active rows; 63 iterations at the production tolerance);
+      * instance 10 is the exception kept on purpose: the engine ends at ANOTHER Karush-Kuhn-Tucker point of the same problem
+        (two active vertex-vertex rows at stages 11, 12 instead of 9-11), cost 0.27 % above, poses within 1.6 cm; SLSQP
+        started there walks to the fixture's optimum, so it is a saddle the convexified Newton steps do not leave.
+    Tight mode accepts status 2 (line search exhausted at the rounding floor of the merit function) next to 0: what says
+    "optimal" here are the comparisons, not the engine's own verdict."""
     from oracle import independent_mpc as im
 
     d, ospec = _independent_fixture()
     gaps = []
     for b in range(len(d["x0"])):
         status, z = solve(b, d["x0"][b], d["ref"][b], d["nbr"][b], d["zu"][b])
-        assert status == 0, (b, status)
+        assert status == 0 or (status == 2 and not prod), (b, status)
         nlp = im.GeometricMpc(ospec, d["x0"][b], d["ref"][b], d["nbr"][b])
         X = z.T.ravel()
         assert np.abs(nlp.eq(X)).max() < (1e-6 if not prod else 1e-2), b
@@ -224,16 +226,13 @@ def check_against_independent(solve, tight_tol, prod):
         cost, ref_cost = nlp.cost(X), d["cost"][b]
         gap = (cost - ref_cost) / ref_cost
         gaps.append(gap)
-        assert gap > -(1e-6 if not prod else 1e-3), (b, gap)  # its feasible set is contained in the reference's
+        assert gap > -(1e-6 if not prod else 1e-3), (b, gap)  # feasible for the reference's NLP: cannot be cheaper
         dpose = np.abs(z[:3] - d["sol"][b][:3]).max()
-        if b == 7:
-            assert 0.9 < gap < 1.1 and dpose > 0.1
-        elif d["n_vv"][b] == 0:
+        if b == 10:
+            assert 1e-3 < gap < 5e-3 and dpose < 2e-2, (gap, dpose)
+        else:
             assert gap < (1e-6 if not prod else 1e-4), (b, gap)
             assert dpose < (tight_tol if not prod else 5e-2), (b, dpose)
-        else:
-            assert 1e-4 < gap < 1e-2, (b, gap)       # the restriction is visible and small
-            assert dpose < 1.5e-2, (b, dpose)
     return gaps
 
 
@@ -251,14 +250,30 @@ def test_full_size_instances_against_the_independent_solver(prod):
 
     def solve(b, x0, ref, nbr, zu):
         r = port.solve(ospec, x0, ref, nbr, zu.T.copy(), opt)
-        return (0 if (r["status"] == 2 and b == 11 and not prod) else r["status"]), r["p"].T  # 11: line search exhausts at 1e-8, at the optimum
+        return r["status"], r["p"].T
 
     check_against_independent(solve, 1e-4, prod)
-    # started from the independent optimum of instance 7 the engine stays there: the optimum is a stationary point of the
-    # engine's problem too, the warm start just leads it to another one
+    # started from the independent optimum of instance 10 the engine stays there: it is a stationary point of the engine's
+    # problem too, the warm start just leads it to another one
     d, _ = _independent_fixture()
-    r = port.solve(ospec, d["x0"][7], d["ref"][7], d["nbr"][7], d["sol"][7].T.copy(), opt)
-    assert r["status"] == 0 and np.abs(r["p"].T[:3] - d["sol"][7][:3]).max() < (1e-5 if not prod else 5e-3)
+    r = port.solve(ospec, d["x0"][10], d["ref"][10], d["nbr"][10], d["sol"][10].T.copy(), opt)
+    assert r["status"] in ((0,) if prod else (0, 2)) and np.abs(r["p"].T[:3] - d["sol"][10][:3]).max() < (1e-5 if not prod else 5e-3)
+
+
+def test_face_normal_certificates_alone_are_a_restriction():
+    """vv_rows = 0 (face-normal certificates only, round 1's formulation): with a vertex-vertex pair active the feasible set
+    is strictly smaller than the reference's -- cost 0.2-0.8 % above the independent optimum on instances 8, 9, 11, and on
+    instance 7 another stationary point at twice the cost.  Pins what the vertex-vertex rows are for."""
+    from oracle import independent_mpc as im
+    from oracle import port
+
+    d, ospec = _independent_fixture()
+    ospec.vv_rows = False
+    for b, lo, hi in ((7, 0.9, 1.1), (8, 1e-4, 1e-2), (9, 1e-4, 1e-2), (11, 1e-4, 1e-2)):
+        r = port.solve(ospec, d["x0"][b], d["ref"][b], d["nbr"][b], d["zu"][b].T.copy(), ipm.IpmOptions())
+        nlp = im.GeometricMpc(ospec, d["x0"][b], d["ref"][b], d["nbr"][b])
+        gap = (nlp.cost(r["p"].ravel()) - d["cost"][b]) / d["cost"][b]
+        assert r["status"] == 0 and lo < gap < hi, (b, r["status"], gap)
 
 
 def test_independent_fixture_is_reproducible():
