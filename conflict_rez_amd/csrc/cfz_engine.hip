@@ -38,17 +38,21 @@ namespace {
 constexpr int kPlantSubsteps = 10;
 
 struct DualPtrs { double *l, *m, *lam_ij, *lam_ji, *s; };
+// spec, derived constants and workspace layout in device memory: the solver kernels read the fields where they use them
+// (scalar loads, scalar cache) instead of holding all ~200 of them in scalar registers from the kernel's first instruction
+struct KArgs { cfz::KSpec sp; cfz::KDer dv; cfz::Lay L; };
 
 #ifndef CFZ_WAVES_PER_SIMD
 #define CFZ_WAVES_PER_SIMD 2
 #endif
-__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(const cfz::KSpec sp, const cfz::KDer dv, const cfz::Lay L, int B, const double *x0,
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(const KArgs *__restrict__ ka, int B, const double *x0,
                                                    const double *ref, const double *nbr, double *zu, int32_t *status,
                                                    int32_t *iters, double *stats, DualPtrs du, const int32_t *order,
                                                    double *wst, int wst_stride, const int32_t *carry, int carry_all,
                                                    const int32_t *slots) {
   extern __shared__ double smem[];
   if ((int)blockIdx.x >= B) return;
+  const cfz::KSpec &sp = ka->sp; const cfz::KDer &dv = ka->dv; const cfz::Lay &L = ka->L;
   // workgroups are dispatched in index order: `order` puts the instances expected to run longest first
   const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
   const int N = sp.N, no = sp.n_obs, nn = sp.n_nbr;
@@ -209,12 +213,13 @@ __global__ __launch_bounds__(1024) void order_by_iters(int B, const int32_t *ite
 #else
 #define CFZ_MARK(c) do { } while (0)
 #endif
-__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(const cfz::KSpec sp, const cfz::KDer dv, const cfz::Lay L, int S, int V, int K, int T,
+__global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(const KArgs *__restrict__ ka, int S, int V, int K, int T,
                                                         const double *ref_table, const int32_t *kidx0, int t_base,
                                                         double *pred, double *state, double *scratch, int32_t *qbuf,
                                                         int32_t *ctrl, int32_t *done, int32_t *status, int32_t *iters,
                                                         double *stats, int32_t *iter_sum, double *wst, int wst_stride, int prio_lag) {
   extern __shared__ double smem[];
+  const cfz::KSpec &sp = ka->sp; const cfz::KDer &dv = ka->dv; const cfz::Lay &L = ka->L;
   const int N = sp.N, nn = sp.n_nbr, B = S * V, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
@@ -502,6 +507,7 @@ struct cfz_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   double *obs_tab = nullptr;  // n_obs x 20: A[4][2], b[4], V[4][2] (KSpec::obs_tab)
+  KArgs *kargs = nullptr;     // device copy of {ks, derive(ks), lay}
   // carry records (multipliers handed from one MPC iteration to the next), one per slot; per-solve flags
   double *wst = nullptr;
   int32_t *carry = nullptr, *slots = nullptr;   // device: per-solve flags and slot ids
@@ -537,7 +543,7 @@ int launch_solve(cfz_handle *h, int B, const double *x0, const double *ref, cons
   if (duals) du = {h->l, h->m, h->lam_ij, h->lam_ji, h->s};
   if ((h->carry_set || h->slots_set) && st != h->stream) HIP_OK(hipStreamWaitEvent(st, h->ev_stage, 0));  // staged on the handle's stream
   HIP_OK(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(cfz::kNL), h->lds_bytes, st, h->ks, cfz::derive(h->ks), h->lay, B, x0, ref, nbr, zu, status,
+  hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(cfz::kNL), h->lds_bytes, st, h->kargs, B, x0, ref, nbr, zu, status,
                      iters, stats, du, order, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      h->carry_ext ? h->carry_ext : (h->carry_set ? h->carry : nullptr), carry_all, h->slots_set ? h->slots : nullptr);
   h->carry_set = false; h->slots_set = false; h->carry_ext = nullptr;  // the flags of cfz_mpc_set_carry / cfz_mpc_set_slots hold for one solve
@@ -659,6 +665,9 @@ int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
     HIP_OK(hipMalloc(&h->obs_tab, tab.size() * 8));
     HIP_OK(hipMemcpy(h->obs_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     h->ks.obs_tab = h->obs_tab;
+    KArgs host_args = {h->ks, cfz::derive(h->ks), h->lay};
+    HIP_OK(hipMalloc(&h->kargs, sizeof(KArgs)));
+    HIP_OK(hipMemcpy(h->kargs, &host_args, sizeof(KArgs), hipMemcpyHostToDevice));
   }
   h->carry_duals = opt->carry_duals;
   h->wst_stride = cfz::carry_layout(k.N, k.n_obs + k.n_nbr).stride;
@@ -686,7 +695,7 @@ int cfz_destroy(cfz_handle *h) {
   hipSetDevice(h->device);
   void *bufs[] = {h->x0, h->ref, h->nbr, h->zu, h->stats, h->status, h->iters, h->l, h->m, h->lam_ij, h->lam_ji, h->s,
                   h->ref_table, h->pred, h->state, h->kidx, h->order, h->pred2, h->scratch, h->queue, h->ctrl, h->done,
-                  h->iter_sum, h->obs_tab, h->wst, h->carry, h->slots};
+                  h->iter_sum, h->obs_tab, h->wst, h->carry, h->slots, h->kargs};
   for (void *p : bufs) if (p) hipFree(p);
   arena_destroy(h->arena);
   if (h->stage_host) hipHostFree(h->stage_host);
@@ -984,7 +993,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
     HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
   }
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->ks, cfz::derive(h->ks), h->lay, S, V, K, h->T,
+  hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(cfz::kNL), h->lds_bytes, h->stream, h->kargs, S, V, K, h->T,
                      h->ref_table, h->kidx, 0, h->pred2, h->state, h->scratch, h->queue, h->ctrl, h->done, h->status,
                      h->iters, h->stats, h->iter_sum, h->carry_duals ? h->wst : nullptr, h->wst_stride,
                      std::getenv("CFZ_LOOP_PRIO_LAG") ? std::atoi(std::getenv("CFZ_LOOP_PRIO_LAG")) : 0);

@@ -391,9 +391,10 @@ CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[
 }
 
 CFZ_FN double pick4(const double d[4], int v) {
-  // two levels of selects on the bits of v (written as a loop over the array the compiler turned the choice into a stack
-  // array and an indexed scratch load)
-  const double lo = (v & 1) ? d[1] : d[0], hi = (v & 1) ? d[3] : d[2];
+  // two levels of selects on the bits of v, between four values loaded unconditionally first: written `c ? d[1] : d[0]` the
+  // compiler folds the choice into the address (one load at d + (v & 1)), the array has a runtime index and lives in scratch
+  const double a = d[0], b = d[1], c = d[2], e = d[3];
+  const double lo = (v & 1) ? b : a, hi = (v & 1) ? e : c;
   return (v & 2) ? hi : lo;
 }
 
@@ -446,8 +447,8 @@ CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, c
   double d[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    const double q0 = (bi & 1) ? D[1][v] : D[0][v], q1 = (bi & 1) ? D[3][v] : D[2][v];
-    const double q2 = (bi & 1) ? D[5][v] : D[4][v], q3 = (bi & 1) ? D[7][v] : D[6][v];
+    const double e0 = D[0][v], e1 = D[1][v], e2 = D[2][v], e3 = D[3][v], e4 = D[4][v], e5 = D[5][v], e6 = D[6][v], e7 = D[7][v];
+    const double q0 = (bi & 1) ? e1 : e0, q1 = (bi & 1) ? e3 : e2, q2 = (bi & 1) ? e5 : e4, q3 = (bi & 1) ? e7 : e6;
     const double h0 = (bi & 2) ? q1 : q0, h1 = (bi & 2) ? q3 : q2;
     d[v] = (bi & 4) ? h1 : h0;
     dsel[v] = d[v];
