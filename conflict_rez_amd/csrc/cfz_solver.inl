@@ -56,6 +56,7 @@ constexpr int kMaxN = kNL / kLPS;
 #define CFZ_REDUCE(NS, NX, NI, part, out) cfz::reduce_all<NS, NX, NI>(m, L, xpar, part, out)
 // the sweeps run on lane 0 of the workgroup, out of line; every lane calls (uniform control flow), lane 0 works
 #define CFZ_SERIAL(call) do { call; __syncthreads(); } while (0)
+#define CFZ_WAVE0(call) do { if (threadIdx.x < cfz::kMaxN) { call; } __syncthreads(); } while (0)  // the lanes that own a stage
 #define CFZ_WSP(p) ((cfz::wsp_f64 *)(p))
 #define CFZ_UNIFORM(v) cfz::uniform_value(v)
 #else
@@ -67,6 +68,7 @@ constexpr int kMaxN = kNL / kLPS;
 #define CFZ_QSUM(name, i) cfz::quad_sum_emu(name[i], tid)
 #define CFZ_REDUCE(NS, NX, NI, part, out) cfz::reduce_all_emu<NS, NX, NI>(part, out)
 #define CFZ_SERIAL(call) do { call; } while (0)
+#define CFZ_WAVE0(call) do { call; } while (0)
 #define CFZ_WSP(p) (p)
 #define CFZ_UNIFORM(v) (v)
 #endif
@@ -1085,7 +1087,14 @@ CFZ_FN void cos5_stage(wsp_f64 *m, int k, int N, int o_ab, int o_hc, int o_gk, i
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-CFZ_SWEEP forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
+// The scans are out of line like the backward sweep (inlined they cost 11 % of the throughput: the kernel's register
+// allocation suffers), but only the first 32 lanes call them (CFZ_WAVE0; one stage per lane, N <= 32): the prologue of
+// forward_scan saves 37 callee-saved registers of every calling lane to scratch, and every finished solve's release writes
+// that back to HBM.
+#ifndef CFZ_SCAN
+#define CFZ_SCAN __device__ __attribute__((noinline)) void
+#endif
+CFZ_SCAN forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk, int o_rP, int o_p, int o_dp, int o_x0,
                        int o_pi0, int o_dpi0) {
   if (threadIdx.x >= 64) return;  // the first wavefront, stage k on lane k
   const int k = threadIdx.x;
@@ -1116,7 +1125,7 @@ CFZ_SWEEP forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk
   }
 }
 
-CFZ_SWEEP costate_scan(wsp_f64 *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
+CFZ_SCAN costate_scan(wsp_f64 *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
   if (threadIdx.x >= 64) return;
   const int k = threadIdx.x;
   Cos5 t;
@@ -1585,9 +1594,9 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
     // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
-    CFZ_SERIAL(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
+    CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_STAMP(9);  // forward step
-    CFZ_SERIAL(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
+    CFZ_WAVE0(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
     CFZ_STAMP(5);  // costates
     // ---- slack step, fraction to the boundary, directional derivative ------------------------------------
     // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
