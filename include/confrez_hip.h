@@ -231,7 +231,9 @@ int cfz_state_ws(int device, int B, const cfz_plan_options *opt, const int32_t *
 typedef struct cfz_colloc_options {
   int32_t N_per_set;      /* :368 5 */
   int32_t max_iter;       /* IPOPT default 3000 (:652 leaves it unset) */
-  int32_t reserved[2];
+  int32_t exact_rows;     /* 0: dual regularisation of proximal type, delta_c = 1e-7 (rows met to delta_c x multiplier, robust where
+                           *    the reference's rows lose rank); 1: IPOPT's form, delta_c = 1e-9 (exact optimum at tight tolerances) */
+  int32_t reserved;
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */

@@ -12,7 +12,10 @@ as oracle/independent_mpc.py).  No duals, no working sets, no slacks, no condens
   inequalities  tube rows at every N_per_set-th interval start and at the end state (:570-617); obstacle distances at every
                 point; boxes on x, y, v, delta, a, w (:439-478)
   cost          sum B_k (a^2 + v^2 w^2 + delta^2) dt + (N dt)^2 (:512-521, :638)
-Solver: scipy's SLSQP with analytic Jacobians (distances: central differences in the pose they depend on).
+Solvers: `solve` = scipy's SLSQP with analytic Jacobians (distances: central differences in the pose they depend on) -- fine on
+short tubes, but at the reference's size (1261 variables, 1128 inequality rows) its dense QP does not finish within an hour;
+`solve_ipm` = oracle/ipm.py (sparse full-KKT interior point, SuperLU) on the same statement in slack form with its own exact
+Hessian (`GeometricCollocIpm`), 90 s at full size: what tests/golden/make_independent_colloc.py runs.
 """
 import numpy as np
 from scipy.optimize import minimize
@@ -183,3 +186,145 @@ def solve(nlp: GeometricColloc, guess, dt0, maxiter=300, ftol=1e-12, verbose=Fal
     P, dt = nlp.split(out.x)
     return dict(traj=P, dt=dt, cost=float(out.fun), status=int(out.status), iters=int(out.nit),
                 eq=float(np.abs(nlp.eq(out.x)).max()), ineq=float(nlp.ineq(out.x).min()))
+
+
+# ---- the same statement in the form oracle/ipm.py solves (sparse full-KKT interior point, exact Hessian) ----------------------
+class GeometricCollocIpm:
+    """`GeometricColloc` as  min f(X) s.t. c(X) = 0, XL <= X <= XU  with X = [z | slacks of the inequality rows]:
+    c = [eq(z); ineq(z) - s], s >= 0.  Distance rows further than `prune` from their obstacle at the guess are left out (and
+    checked afterwards by `solve_ipm`).  Hessian of the Lagrangian: cost, ODE and tube rows analytically, distance rows by
+    second-order central differences in the three pose variables they depend on -- nothing of the kernels' working sets,
+    certificates, condensation or band ordering is used, and the linear algebra is scipy's SuperLU on the full KKT matrix."""
+
+    def __init__(self, g: GeometricColloc, z_guess, prune=3.0):
+        import scipy.sparse as sp_
+
+        self.sp_, self.g = sp_, g
+        P, _ = g.split(z_guess)
+        sep = g.separations(P.reshape(-1, 7)[:, :3])
+        self.keep = np.argwhere(sep < prune)                  # (point, obstacle) pairs with a distance row
+        self.n_tube = 8 * g.n_chk
+        self.mi = self.n_tube + len(self.keep)
+        self.n0 = g.n
+        self.n = self.n0 + self.mi
+        self.me = len(g.eq(z_guess))
+        self.m = self.me + self.mi
+        lo = np.array([b[0] if b[0] is not None else -np.inf for b in g.bounds()], float)
+        hi = np.array([b[1] if b[1] is not None else np.inf for b in g.bounds()], float)
+        self.xl = np.concatenate([lo, np.zeros(self.mi)])
+        self.xu = np.concatenate([hi, np.full(self.mi, np.inf)])
+
+    def _ineq(self, z):
+        P, _ = self.g.split(z)
+        full = self.g.ineq(z)
+        sep = full[self.n_tube:].reshape(self.g.np_, -1)
+        return np.concatenate([full[: self.n_tube], sep[self.keep[:, 0], self.keep[:, 1]]])
+
+    def initial(self, z_guess):
+        return np.concatenate([z_guess, np.maximum(self._ineq(z_guess), 1e-2)])
+
+    def f(self, X):
+        return self.g.cost(X[: self.n0])
+
+    def grad(self, X):
+        return np.concatenate([self.g.cost_grad(X[: self.n0]), np.zeros(self.mi)])
+
+    def cons(self, X):
+        z = X[: self.n0]
+        return np.concatenate([self.g.eq(z), self._ineq(z) - X[self.n0:]])
+
+    def jac(self, X):
+        sp_, g, z = self.sp_, self.g, X[: self.n0]
+        Ji = g.ineq_jac(z)
+        no = len(g.obs)
+        rows = np.concatenate([np.arange(self.n_tube), self.n_tube + self.keep[:, 0] * no + self.keep[:, 1]])
+        top = sp_.hstack([sp_.csr_matrix(g.eq_jac(z)), sp_.csr_matrix((self.me, self.mi))])
+        bot = sp_.hstack([sp_.csr_matrix(Ji[rows]), -sp_.eye(self.mi)])
+        return sp_.vstack([top, bot]).tocsr()
+
+    def _cons_jac(self, X, want_jac=True):
+        return self.cons(X), (self.jac(X) if want_jac else None)
+
+    def hess_exact(self, X, nu):
+        sp_, g = self.sp_, self.g
+        z = X[: self.n0]
+        P, dt = g.split(z)
+        N, n0 = g.N, self.n0
+        H = np.zeros((n0, n0))
+        idt = n0 - 1
+        # cost
+        for i in range(N):
+            for k in range(K_PTS):
+                b = g.idx(i, k, 0); Bk = g.B[k]
+                v, de, a, w = P[i, k, 3], P[i, k, 4], P[i, k, 5], P[i, k, 6]
+                H[b + 3, b + 3] += dt * Bk * 2 * w * w; H[b + 6, b + 6] += dt * Bk * 2 * v * v
+                H[b + 3, b + 6] += dt * Bk * 4 * v * w; H[b + 6, b + 3] += dt * Bk * 4 * v * w
+                H[b + 4, b + 4] += dt * Bk * 2; H[b + 5, b + 5] += dt * Bk * 2
+                for c, val in ((3, 2 * v * w * w), (4, 2 * de), (5, 2 * a), (6, 2 * v * v * w)):
+                    H[b + c, idt] += Bk * val; H[idt, b + c] += Bk * val
+        H[idt, idt] += 2.0 * N * N
+        # ODE rows: order of g.eq: 7 initial rows, then [N, 6, 5] ODE rows
+        nu_ode = nu[7: 7 + N * K_PTS * 5].reshape(N, K_PTS, 5)
+        for i in range(N):
+            for k in range(K_PTS):
+                b = g.idx(i, k, 0)
+                psi, v, de = P[i, k, 2], P[i, k, 3], P[i, k, 4]
+                c, s, t = np.cos(psi), np.sin(psi), np.tan(de)
+                n0_, n1_, n2_, n3_, n4_ = nu_ode[i, k]
+                # -dt * d2 f
+                H[b + 2, b + 2] += -dt * (n0_ * (-v * c) + n1_ * (-v * s))
+                H[b + 2, b + 3] += -dt * (n0_ * (-s) + n1_ * c); H[b + 3, b + 2] += -dt * (n0_ * (-s) + n1_ * c)
+                H[b + 3, b + 4] += -dt * n2_ * (1 + t * t) / g.wb; H[b + 4, b + 3] += -dt * n2_ * (1 + t * t) / g.wb
+                H[b + 4, b + 4] += -dt * n2_ * v / g.wb * 2 * t * (1 + t * t)
+                # cross with dt: -grad f
+                for col, val in ((2, n0_ * (-v * s) + n1_ * (v * c)), (3, n0_ * c + n1_ * s + n2_ * t / g.wb),
+                                 (4, n2_ * v * (1 + t * t) / g.wb), (5, n3_), (6, n4_)):
+                    H[b + col, idt] += -val; H[idt, b + col] += -val
+        # tube rows (b - shrink) - A front: d2/dpsi2 = wb A.(cos, sin)
+        nu_in = nu[self.me:]
+        for q in range(1, g.n_chk + 1):
+            rows = nu_in[8 * (q - 1) + 4: 8 * (q - 1) + 8]
+            Af = np.asarray(g.tube[q]["front"][0])
+            if q < g.n_chk:
+                pts = [(g.idx(q * g.Nps, 0, 2), 1.0)]
+                psi = P[q * g.Nps, 0, 2]
+            else:
+                pts = [(g.idx(N - 1, j, 2), g.D[j]) for j in range(K_PTS) if g.D[j] != 0.0]
+                psi = float(g.D @ P[-1][:, 2])
+            d2 = float(rows @ (Af @ (g.wb * np.array([np.cos(psi), np.sin(psi)]))))
+            for (ia, wa) in pts:
+                for (ib, wb_) in pts:
+                    H[ia, ib] += wa * wb_ * d2
+        # distance rows: central second differences
+        poses = P.reshape(-1, 7)[:, :3]
+        h = 1e-4
+        d0 = g.separations(poses)
+        nu_d = np.zeros((g.np_, len(g.obs)))
+        nu_d[self.keep[:, 0], self.keep[:, 1]] = nu_in[self.n_tube:]
+        E = np.eye(3) * h
+        for a in range(3):
+            dp, dm = g.separations(poses + E[a]), g.separations(poses - E[a])
+            haa = ((dp - 2 * d0 + dm) / (h * h) * nu_d).sum(1)
+            for q in range(g.np_):
+                H[7 * q + a, 7 * q + a] += haa[q]
+            for b_ in range(a + 1, 3):
+                hab = ((g.separations(poses + E[a] + E[b_]) - g.separations(poses + E[a] - E[b_])
+                        - g.separations(poses - E[a] + E[b_]) + g.separations(poses - E[a] - E[b_])) / (4 * h * h) * nu_d).sum(1)
+                for q in range(g.np_):
+                    H[7 * q + a, 7 * q + b_] += hab[q]; H[7 * q + b_, 7 * q + a] += hab[q]
+        return sp_.block_diag([sp_.csr_matrix(H), sp_.csr_matrix((self.mi, self.mi))]).tocsr()
+
+
+def solve_ipm(g: GeometricColloc, guess, dt0, opt=None, prune=3.0):
+    """oracle/ipm.py on the geometric statement.  Returns dict(traj [N, 6, 7], dt, cost, status, iters, eq, ineq)."""
+    from . import ipm
+
+    z0 = np.append(np.asarray(guess, float).ravel(), dt0)
+    nlp = GeometricCollocIpm(g, z0, prune)
+    opt = opt or ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8, constr_viol_tol=1e-9,
+                                compl_inf_tol=1e-9, dual_inf_tol=1e-6)
+    r = ipm.solve(nlp, nlp.initial(z0), opt)
+    z = r["X"][: g.n]
+    P, dt = g.split(z)
+    return dict(traj=P, dt=dt, cost=g.cost(z), status=int(r["status"]), iters=int(r["iters"]), eq=float(np.abs(g.eq(z)).max()),
+                ineq=float(g.ineq(z).min()), rows=len(nlp.keep))

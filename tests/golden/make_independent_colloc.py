@@ -1,0 +1,50 @@
+"""Generates tests/golden/colloc_independent.npz (run from the repo root: `python tests/golden/make_independent_colloc.py`,
+about 90 s): the single-vehicle collocation plan of vehicle_1 of the synthetic strategy at the reference's size (N = 30
+intervals, 180 collocation points, six obstacles, free dt; vehicle.py:360-661) solved INDEPENDENTLY of the planning kernel --
+oracle/independent_colloc.py: polygon distances instead of OBCA duals or working sets, no condensation, no bordering of dt,
+derivatives of its own (distance rows by finite differences), scipy's SuperLU on the full KKT matrix (oracle/ipm.py) -- to
+tol 1e-8.  Stored: the guess both solvers start from (points + dt), the optimal trajectory, dt and cost."""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def problem(agent="vehicle_1"):
+    """(tube, path, final heading, obstacle spec) of one vehicle of the synthetic strategy."""
+    from conflict_rez_amd import scenarios, strategy as strat
+    from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+    from conflict_rez_amd.vehicle_types import VehicleBody
+
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    tube = [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[agent]]
+    p = paths[agent]
+    return tube, p, float(p[-1, 2]), scenarios.parking_lot_spec()
+
+
+if __name__ == "__main__":
+    import test_colloc as tc
+    from oracle.colloc_nlp import CollocNlp
+    from oracle.independent_colloc import GeometricColloc, solve_ipm
+
+    tube, p, fh, sp = problem()
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    X0 = tc.colloc_guess(nlp, tc.warm_start(tube, p, fh))  # state_ws -> interpolation: what plan_single_path hands over
+    g = GeometricColloc(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    t0 = time.time()
+    r = solve_ipm(g, X0[: nlp.iDt].reshape(-1, 7), X0[nlp.iDt])
+    print({k: v for k, v in r.items() if k != "traj"}, "%.0f s" % (time.time() - t0))
+    assert r["status"] == 0 and r["eq"] < 1e-8 and r["ineq"] > -1e-8
+    np.savez_compressed(os.path.join(HERE, "colloc_independent.npz"), guess=X0[: nlp.iDt + 1], traj=r["traj"], dt=r["dt"], cost=r["cost"],
+                        iters=r["iters"])

@@ -292,3 +292,84 @@ def test_independent_fixture_is_reproducible():
     W = body_polygon_world(d["sol"][8][:3, k], ospec.g)
     Q = nlp.obs[j] if j < ospec.n_obs else body_polygon_world(d["nbr"][8][j - ospec.n_obs, :, k], ospec.g)
     assert abs(polygon_distance(Q, W)[0] - sep[k, j]) < 1e-7 and abs(sep[k, j] - ospec.dmin) < 1e-6
+
+
+# ---- full size collocation plan (tests/golden/colloc_independent.npz, make_independent_colloc.py) -----------------------------
+def _colloc_fixture():
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_independent_colloc import problem
+    from oracle.independent_colloc import GeometricColloc
+
+    d = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
+    tube, p, fh, sp = problem()
+    return {k: d[k] for k in d.files}, GeometricColloc(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh), (tube, p, fh, sp)
+
+
+def check_plan_against_independent(traj, dt, tight):
+    """Shared by the CPU test (kernel source compiled for the host) and the GPU test (`cfz_colloc`): the plan [N, 6, 7] + dt
+    satisfies the GEOMETRIC statement of the reference's rows (ODE at all points, continuity, tube, polygon distances >= dmin,
+    boxes; oracle/independent_colloc.py) and is the independent optimum: cost to 1e-8 / poses to 1e-6 m at tight tolerances;
+    at the reference's tolerance 1e-2 the rows hold to 1e-2, the cost is within 1e-3 (below: the rows are relaxed by the
+    tolerance) and the poses within 5 mm."""
+    d, g, _ = _colloc_fixture()
+    z = np.append(np.asarray(traj, float).ravel(), float(dt))
+    eq, ineq = np.abs(g.eq(z)).max(), g.ineq(z).min()
+    gap = (g.cost(z) - float(d["cost"])) / float(d["cost"])
+    dpose, ddt = np.abs(np.asarray(traj)[..., :3] - d["traj"][..., :3]).max(), abs(float(dt) - float(d["dt"]))
+    if tight:
+        assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 1e-8 and dpose < 1e-6 and ddt < 1e-8, (eq, ineq, gap, dpose, ddt)
+    else:
+        assert eq < 1e-2 and ineq > -1e-2 and -1e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (eq, ineq, gap, dpose, ddt)
+    return gap, dpose
+
+
+@pytest.mark.parametrize("tight", [True, False])
+def test_full_size_collocation_plan_against_the_independent_solver(tight):
+    """The planning kernel's source (CPU build) from the fixture's guess against the independent optimum of the geometric
+    statement, at tight tolerances (unregularised rows) and at the reference's tolerance."""
+    import colloc_emu_binding as ce
+    import test_colloc as tc
+    from oracle.colloc_nlp import CollocNlp
+
+    d, g, (tube, p, fh, sp) = _colloc_fixture()
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    X0 = np.zeros(nlp.n)
+    X0[: nlp.iDt + 1] = d["guess"]
+    X0 = nlp.pack({k: X0[: nlp.iDt].reshape(-1, 7)[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}, float(d["guess"][-1]))
+    if tight:
+        opt = ipm.IpmOptions(max_iter=800, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
+        opt.no_prox = 1
+    else:
+        opt = ipm.IpmOptions(**tc.COLLOC_OPT)
+    r = ce.solve(nlp, X0, opt)
+    assert r["status"] == 0
+    P, dt = g.split(r["X"][: nlp.iDt + 1])
+    check_plan_against_independent(P, dt, tight)
+
+
+def test_independent_collocation_fixture_is_a_kkt_point():
+    """Certificate of the fixture that needs no solver: at the stored plan the gradient of the cost is a combination of the
+    gradients of the equality rows and of the ACTIVE inequality rows and bounds of the geometric statement with multipliers of
+    the right sign (least squares: residual 1e-6 of the gradient's size), and every row holds to 1e-8."""
+    from scipy.optimize import lsq_linear
+
+    d, g, _ = _colloc_fixture()
+    z = np.append(d["traj"].ravel(), float(d["dt"]))
+    assert np.abs(g.eq(z)).max() < 1e-8 and g.ineq(z).min() > -1e-8 and abs(g.cost(z) - float(d["cost"])) < 1e-9
+    act = np.nonzero(g.ineq(z) < 1e-6)[0]
+    lo = np.array([b[0] if b[0] is not None else -np.inf for b in g.bounds()])
+    hi = np.array([b[1] if b[1] is not None else np.inf for b in g.bounds()])
+    at_lo, at_hi = np.nonzero(z - lo < 1e-6)[0], np.nonzero(hi - z < 1e-6)[0]
+    Je, Ji = g.eq_jac(z), g.ineq_jac(z)[act]
+    Eb = np.zeros((len(at_lo) + len(at_hi), g.n))
+    Eb[np.arange(len(at_lo)), at_lo] = 1.0
+    Eb[len(at_lo) + np.arange(len(at_hi)), at_hi] = -1.0
+    # grad f = Je' a + Ji' b + Eb' c with b, c >= 0 (inequalities are >= 0 rows, so their multipliers pull the cost up)
+    A = np.vstack([Je, Ji, Eb]).T
+    lb = np.concatenate([np.full(len(Je), -np.inf), np.zeros(len(Ji) + len(Eb))])
+    r = lsq_linear(A, g.cost_grad(z), bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=500)
+    assert len(act) >= 3 and np.abs(A @ r.x - g.cost_grad(z)).max() < 1e-5 * np.abs(g.cost_grad(z)).max(), (len(act), np.abs(A @ r.x - g.cost_grad(z)).max())
