@@ -7,7 +7,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | grep -E "passed|failed|rror" | tail -3
 timeout 600 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 1500 $O/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_$tag
