@@ -193,7 +193,7 @@ def main():
 
     dist = None
     # CFZ_BENCH_FORCE_DIST=1: go through torch.distributed even with one rank (exercises the N > 1 code path on one GPU)
-    if world > 1 or os.environ.get("CFZ_BENCH_FORCE_DIST") == "1":
+    if world > 1 or os.environ.get("CFZ_BENCH_FORCE_DIST") == "1" or (args.parallelism == "vehicle" and "RANK" in os.environ):
         import torch
         import torch.distributed as dist
 
