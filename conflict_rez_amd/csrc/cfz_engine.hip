@@ -223,7 +223,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
   const int N = sp.N, nn = sp.n_nbr, B = S * V, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *my = scratch + (size_t)blockIdx.x * (5 + 3 * N + nn * 3 * N + 7 * N);
-  double *x0 = my, *ref = x0 + 5, *nbr = ref + 3 * N, *zu = nbr + nn * 3 * N;
+  double *ref = my + 5;  // (the record keeps the layout x0 | ref | nbr | zu of the stepwise path; only ref is used here)
   int32_t *head = qbuf, *tail = qbuf + K, *slots = qbuf + 2 * K;
   // what wavefront 0 popped, for wavefront 1: {iteration t (-1: leave), instance b}.  Lives in the reduction exchange
   // area of the workspace, which is idle between two solves.
@@ -281,18 +281,22 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
     const int s = b / V, v = b - s * V;
     const double *pin = pred + (size_t)(t & 1) * B * 7 * N;   // predictions after iteration t-1
     double *pout = pred + (size_t)((t + 1) & 1) * B * 7 * N;
-    // ---- parameters and shifted warm start (vehicle_follower.py:432-476) -------------------------------
-    if (tid < 5) x0[tid] = state[b * 5 + tid];
+    // ---- parameters and shifted warm start (vehicle_follower.py:432-476), straight into the solver's workspace: measured
+    // state, neighbours' poses with cos / sin, warm start (solve_instance's `preloaded` form); only the reference goes through
+    // a global record (the solver reads it from there in every iteration)
+    if (tid < 5) smem[L.x0 + tid] = state[b * 5 + tid];
     for (int k = tid; k < N; k += cfz::kNL) {
       const int ka = (k + 1 < N) ? k + 1 : N - 1;
       int kr = kidx0[s] + t_base + t + k; if (kr > T - 1) kr = T - 1;
       for (int c = 0; c < 3; ++c) ref[c * N + k] = ref_table[((size_t)v * T + kr) * 7 + c];
-      for (int c = 0; c < 7; ++c) zu[c * N + k] = pin[((size_t)b * 7 + c) * N + ka];
+      for (int c = 0; c < 7; ++c) smem[L.p + k * cfz::kNP + c] = pin[((size_t)b * 7 + c) * N + ka];
       int o = 0;
       for (int u = 0; u < V; ++u) {
         if (u == v) continue;
         const size_t bo = (size_t)s * V + u;
-        for (int c = 0; c < 3; ++c) nbr[(o * 3 + c) * N + k] = pin[(bo * 7 + c) * N + ka];
+        double *q = smem + L.nb4 + (k * nn + o) * 4;
+        const double po = pin[(bo * 7 + 2) * N + ka];
+        q[0] = pin[(bo * 7 + 0) * N + ka]; q[1] = pin[(bo * 7 + 1) * N + ka]; q[2] = cos(po); q[3] = sin(po);
         ++o;
       }
     }
@@ -300,21 +304,21 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
     CFZ_MARK(3);
     int oi[2]; double od[3];
     cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cfz::solve_instance(sp, dv, x0, ref, nbr, zu, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1);
+    cfz::solve_instance(sp, dv, nullptr, ref, nullptr, nullptr, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1, 1);
     __syncthreads();
     CFZ_MARK(4);
-    // ---- read-back or shift fallback (:484-524), plant (:528-543) ------------------------------------------
+    // ---- read-back (the solution is still in the workspace) or shift fallback (:484-524), plant (:528-543) ------------
     for (int i = tid; i < 7 * N; i += cfz::kNL) {
       const int c = i / N, k = i - c * N;
       const int ka = (k + 1 < N) ? k + 1 : N - 1;
-      pout[(size_t)b * 7 * N + i] = (oi[1] == 0) ? zu[i] : pin[((size_t)b * 7 + c) * N + ka];
+      pout[(size_t)b * 7 * N + i] = (oi[1] == 0) ? smem[L.p + k * cfz::kNP + c] : pin[((size_t)b * 7 + c) * N + ka];
     }
     CFZ_MARK(5);
     if (tid == 0) {
-      const double a0 = (oi[1] == 0) ? zu[5 * N] : pin[((size_t)b * 7 + 5) * N + 1];
-      const double w0 = (oi[1] == 0) ? zu[6 * N] : pin[((size_t)b * 7 + 6) * N + 1];
+      const double a0 = (oi[1] == 0) ? smem[L.p + 5] : pin[((size_t)b * 7 + 5) * N + 1];
+      const double w0 = (oi[1] == 0) ? smem[L.p + 6] : pin[((size_t)b * 7 + 6) * N + 1];
       double z[5], out[5];
-      for (int i = 0; i < 5; ++i) z[i] = x0[i];
+      for (int i = 0; i < 5; ++i) z[i] = smem[L.x0 + i];
       cfz::rk4_step<false>(z, a0, w0, sp.dt, sp.wb, kPlantSubsteps, out, nullptr);
       for (int i = 0; i < 5; ++i) state[b * 5 + i] = out[i];
       status[b] = oi[1]; iters[b] = oi[0];

@@ -1205,9 +1205,12 @@ CFZ_FN CarryLay carry_layout(int N, int nb) {
 
 // wst: this instance's carry record (nullptr: none kept).  carry_in != 0: start from it if it is valid
 // (oracle/mpc_nlp.py warm_from_carry).  A converged solve refreshes the record, any other outcome invalidates it.
+// preloaded != 0 (the persistent loop): the caller has already put the measured state (L.x0), the neighbours' poses with
+// cos / sin (L.nb4) and the warm start (L.p) into the workspace and reads the solution from L.p afterwards; x0g, nbrg and zu
+// are then not touched (zu may be null).
 CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, const double *refg, const double *nbrg, double *zu,
                            double *m, const Lay &L, int *out_i, double *out_d, const DualOut &duo, double *wst = nullptr,
-                           int carry_in = 0) {
+                           int carry_in = 0, int preloaded = 0) {
   const int N = sp.N, nb = L.nb, nr = L.nr, n_obs = sp.n_obs, n_nbr = sp.n_nbr;
   const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
   const double mu_floor = dv.mu_floor;
@@ -1221,14 +1224,17 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
 
   // ---- load parameters, initial point ---------------------------------------------------
   CFZ_LANES(tid)
-    for (int t = tid; t < N * n_nbr; t += kNL) {
-      const int k = t / n_nbr, o = t - k * n_nbr;
-      const double po = nbrg[(o * 3 + 2) * N + k];
-      double *q = m + L.nb4 + t * 4;
-      q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
+    if (!preloaded) {
+      for (int t = tid; t < N * n_nbr; t += kNL) {
+        const int k = t / n_nbr, o = t - k * n_nbr;
+        const double po = nbrg[(o * 3 + 2) * N + k];
+        double *q = m + L.nb4 + t * 4;
+        q[0] = nbrg[(o * 3 + 0) * N + k]; q[1] = nbrg[(o * 3 + 1) * N + k]; q[2] = cos(po); q[3] = sin(po);
+      }
+      if (tid < 5) m[L.x0 + tid] = x0g[tid];
+      for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
     }
-    if (tid < 5) { m[L.x0 + tid] = x0g[tid]; m[L.pi0 + tid] = 0.0; }
-    for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; m[L.p + i] = zu[c * N + k]; }
+    if (tid < 5) m[L.pi0 + tid] = 0.0;
     for (int i = tid; i < N * 5; i += kNL) m[L.pi + i] = 0.0;
   CFZ_END
   // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
@@ -1719,7 +1725,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_STAMP(10);
   // ---- write back: trajectory, separations, dual certificates ---------------------------------------------------
   CFZ_LANES(tid)
-    for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
+    if (!preloaded) for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
     double smin = INFINITY;
     for (int t = tid; t < N * nb; t += kNL) {
       const int k = t / nb, j = t - k * nb;
