@@ -166,6 +166,51 @@ def test_config3_four_vehicle_joint_plans(lot):
     eng.close()
 
 
+def test_config3_at_batch_256(lot):
+    """configs[3] at its named batch: 256 four-vehicle scenarios (start poses scattered by +-3 cm), their 1024 single plans in
+    one launch each of `cfz_state_ws` / `cfz_colloc`, then all joint plans in ONE launch of `cfz_joint_colloc`.  Every joint plan
+    whose four single plans converged converges; the reference's rows (per vehicle, and the six pairs through the product
+    path's duals) are checked on a sample of four plans."""
+    from conflict_rez_amd import engine
+
+    agents, B = lot["agents"], 256
+    rng = np.random.default_rng(1)
+    who = [a for _ in range(B) for a in agents]
+    init = [lot["paths"][a][0] + (np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] if i >= 4 else 0.0) for i, a in enumerate(who)]
+    ws, good, plans = _single_plans(lot, who, init)
+    ok = [b for b in range(B) if all(4 * b + i in plans and plans[4 * b + i]["status"] == 0 for i in range(4))]
+    assert len(ok) >= B - 2
+    scen = []
+    for b in ok:
+        sing = [plans[4 * b + i] for i in range(4)]
+        scen.append(dict(init_poses=[init[4 * b + i] for i in range(4)], tubes=[lot["tubes"][a] for a in agents],
+                         guesses=[s["traj"].reshape(-1, 7) for s in sing], dt0=float(np.mean([s["dt"] for s in sing])),
+                         final_headings=[lot["fh"][a] for a in agents]))
+    sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    rj = engine.joint_colloc_batch(sp0, scen, max_iter=300)
+    assert [r["status"] for r in rj] == [0] * len(scen), [(i, r["status"], r["iters"]) for i, r in enumerate(rj) if r["status"]]
+    sp = scenarios.parking_lot_spec()
+    eng = engine.Engine(sp0, max_batch=1)
+    for q in range(0, len(scen), max(1, len(scen) // 4))[:4]:
+        b, r = ok[q], rj[q]
+        jn = JointCollocNlp([dict(init_pose=init[4 * b + i], tube=lot["otubes"][a], final_heading=lot["fh"][a]) for i, a in enumerate(agents)],
+                            sp.A_obs, sp.b_obs, N_per_set=5)
+        sols = [_sol_of(r["traj"][i], r["dt"], eng) for i in range(4)]
+        for i in range(4):
+            rr = reference_residuals(jn, sols[i], i)
+            assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9, (b, i, rr)
+        duals = []
+        for (ia, ib) in jn.pairs:
+            nmin = min(jn.N[ia], jn.N[ib])
+            pa, pb = r["traj"][ia][:nmin].reshape(-1, 7)[:, :3], r["traj"][ib][:nmin].reshape(-1, 7)[:, :3]
+            lam, mu, s_, d = eng.joint_dual_ws(pa, pb)
+            assert d.min() > sp.dmin - 1e-2
+            duals.append(dict(lam=lam.reshape(nmin, 6, 4), mu=mu.reshape(nmin, 6, 4), s=s_.reshape(nmin, 6, 2)))
+        pr = pair_residuals(jn, sols, duals)
+        assert pr["eq"] < 1e-9 and pr["ineq"] < 1e-2 and pr["bound"] == 0.0, (b, pr)
+    eng.close()
+
+
 def test_planner_surface_four_vehicles(tmp_path):
     """`MultiVehiclePlanner` as the reference's `main` drives it (multi_vehicle_planner.py:609-668) with all four agents:
     solve_single_problems -> joint_dual_ws -> solve_final_problem_obca; results on the common clock never overlap."""
