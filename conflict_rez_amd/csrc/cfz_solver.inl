@@ -469,7 +469,7 @@ CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, c
   const int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
   int code = ((bi >> 2) + 1) * 64 + (bi & 3) * 16 + va * 4 + vb;
   if (vv) {
-    const double dn = pick4(d, v0);
+    const double dn = fmin(pick4(d, v0), pick4(d, v1));  // the separation this face certifies (a kept pair is not ordered by distance)
     int pc = 0;
     double r2 = 0.0;
 #pragma unroll
@@ -1653,6 +1653,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- filter line search --------------------------------------------------------------------------------
     const double phi0 = CFZ_UNIFORM(fval - mu * logsum);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
+    if (ws_changed) nfilt = 0;  // the entries belong to the problem with the previous working set
     double alpha = a_pri; int accepted = 0, f_type = 0;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
       CFZ_LANES(tid)

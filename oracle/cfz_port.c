@@ -203,9 +203,10 @@ static int select_rows(const double A[4][2], const double b[4], const double V[4
     if (fmin(d[oa], d[ob]) <= d[v0] + 1e-12 && fmax(d[oa], d[ob]) <= d[v1] + HYST) { v0 = oa; v1 = ob; }
   }
   int va = v0 < v1 ? v0 : v1, vb = v0 < v1 ? v1 : v0;
-  if (vv && d[v0] > 0.0) {
+  const double dn = fmin(d[v0], d[v1]); /* the separation this face certifies (a kept pair is not ordered by distance) */
+  if (vv && dn > 0.0) {
     int u, v; double r;
-    if (closest_vertex_pair(V, x, y, psi, g, &u, &v, &r) && r > d[v0] + 1e-9) return 192 + u * 16 + v * 4 + v;
+    if (closest_vertex_pair(V, x, y, psi, g, &u, &v, &r) && r > dn + 1e-9) return 192 + u * 16 + v * 4 + v;
   }
   return bk * 64 + bf * 16 + va * 4 + vb;
 }
@@ -693,6 +694,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       if (!merit_terms(sp, x0, ref, nbr, it.p, it.sg, sel, mu, &th_dummy, &phi0)) { status = 3; break; }
     }
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
+    if (ws_changed) nfilt = 0; /* the entries belong to the problem with the previous working set (oracle/ipm.py) */
     double alpha = a_pri; int accepted = 0, f_type = 0;
     for (int bt = 0; bt < sp->max_backtrack; ++bt) {
       for (int k = 0; k < N; ++k) {

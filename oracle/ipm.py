@@ -237,6 +237,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         dphi = float(gphi @ dx)
         if filt is None or filt_mu != mu:  # the filter is re-initialised for every barrier problem
             filt, filt_mu = [], mu
+        if getattr(nlp, "ws_changed", False):  # ... and when the working set (hence the problem the entries belong to) changed
+            filt = []
         alpha = a_pri
         accepted = False
         for _ in range(opt.max_backtrack):

@@ -259,11 +259,12 @@ def select_rows(A, b, PV, t, psi, g, BV, prev=0, vv=False):
         if min(d[oa], d[ob]) <= d[v0] + 1e-12 and max(d[oa], d[ob]) <= d[v1] + HYST:
             v0, v1 = oa, ob
     va, vb = min(v0, v1), max(v0, v1)
-    if vv and d[v0] > 0.0:
+    dn = min(d[v0], d[v1])  # the separation this face certifies (a kept pair is not ordered by distance)
+    if vv and dn > 0.0:
         # kind 3: the closest features are two vertices -> the Euclidean distance of that pair is the separation (it exceeds
         # every face-normal separation there); code 192 + u*16 + v*4 + v, both rows of the block carry that distance
         pair = closest_vertex_pair(PV, t, psi, g, BV)
-        if pair is not None and pair[2] > d[v0] + 1e-9:
+        if pair is not None and pair[2] > dn + 1e-9:
             return 192 + pair[0] * 16 + pair[1] * 4 + pair[1]
     return bk * 64 + bf * 16 + va * 4 + vb
 

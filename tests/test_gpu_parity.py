@@ -398,8 +398,8 @@ def test_python_shim_closed_loop_on_gpu(tmp_path):
 def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
     """The HIP engine through the C ABI against optima of the reference's NLP computed by an INDEPENDENT solver on an
     independent statement (polygon distances instead of OBCA duals, scipy SLSQP; tests/golden/mpc_independent.npz,
-    N = 30, six obstacles, three neighbours): feasible for the reference's constraints everywhere and the same optimum,
-    vertex-vertex contacts included (one instance ends at another stationary point of the same problem, +0.27 %).
+    N = 30, six obstacles, three neighbours): feasible for the reference's constraints and the same optimum on all twelve
+    instances, vertex-vertex contacts included.
     The assertions are tests/test_independent_solver.py:check_against_independent, shared with the CPU test of the port."""
     from conflict_rez_amd import engine, scenarios
     from test_independent_solver import TIGHT_FULL, _independent_fixture, check_against_independent
@@ -413,6 +413,22 @@ def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
         return int(out["status"][b]), out["zu"][b]
 
     check_against_independent(solve, 1e-4, prod)
+    e.close()
+
+
+@pytest.mark.parametrize("prod", [False, True])
+def test_population_against_the_independent_solver_on_gpu(prod):
+    """The 32-instance population of tests/test_independent_solver.py (active rows from the bench's sampler, intruder corners
+    with vertex-vertex contacts) in one batch through the C ABI, same assertions as the CPU test of the port."""
+    from conflict_rez_amd import engine, scenarios
+    from test_independent_solver import MORE_BETTER, TIGHT_FULL, _fixture_file, check_against_independent
+
+    d, _ = _fixture_file("mpc_independent_more.npz")
+    opts = {} if prod else dict(**TIGHT_FULL, stall_iters=0)
+    e = engine.Engine(scenarios.parking_lot_spec(), max_batch=len(d["x0"]), **opts)
+    out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
+    check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture="mpc_independent_more.npz",
+                              better=MORE_BETTER)
     e.close()
 
 

@@ -192,29 +192,31 @@ def test_collocation_plan_is_stationary_for_slsqp():
 
 # ---- full size: N = 30, six obstacles, three neighbours (tests/golden/mpc_independent.npz, make_independent.py) --------------
 def _independent_fixture():
+    return _fixture_file("mpc_independent.npz")
+
+
+def _fixture_file(name):
     import os
 
-    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_independent.npz"))
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
     return {k: d[k] for k in d.files}, MpcSpec(N=30, dt=0.1, A_obs=d["A_obs"], b_obs=d["b_obs"], n_nbr=3)
 
 
-def check_against_independent(solve, tight_tol, prod):
-    """Shared by the CPU test (C port) and the GPU test (HIP engine): `solve(b, x0, ref, nbr, zu) -> (status, zu [7, N])`.
-    What is asserted per instance of the fixture:
+def check_against_independent(solve, tight_tol, prod, fixture="mpc_independent.npz", better=()):
+    """Shared by the CPU tests (C port) and the GPU tests (HIP engine): `solve(b, x0, ref, nbr, zu) -> (status, zu [7, N])`.
+    Asserted for every instance of the fixture:
       * the engine's trajectory satisfies the GEOMETRIC statement of the reference's constraints (polygon distance >= dmin,
-        dynamics, initial state) -- i.e. it is feasible for the reference's NLP -- and cannot beat the independent optimum;
-      * same optimum as the independent solver: cost to 1e-6 (tight) / 1e-4 (production tolerances), poses to 1e-4 m / rad
-        (tight) and inside the claimed band 5e-2 m, 5e-2 rad at the production tolerance 1e-2.  That holds with a
-        vertex-vertex pair active too (instances 8-11: the working set then carries the Euclidean distance of the pair,
-        kind 3) and for instance 7 (nine active rows; 63 iterations at the production tolerance);
-      * instance 10 is the exception kept on purpose: the engine ends at ANOTHER Karush-Kuhn-Tucker point of the same problem
-        (two active vertex-vertex rows at stages 11, 12 instead of 9-11), cost 0.27 % above, poses within 1.6 cm; SLSQP
-        started there walks to the fixture's optimum, so it is a saddle the convexified Newton steps do not leave.
+        dynamics, initial state) -- i.e. it is feasible for the reference's NLP;
+      * it is the independent solver's optimum: cost to 1e-6 (tight) / 2e-4 (production tolerances), poses to 1e-4 m / rad
+        (tight) and inside the claimed band 5e-2 m, 5e-2 rad at the production tolerance 1e-2 -- with vertex-vertex contacts
+        (kind 3 rows), with nine active rows (instance 7 of the first fixture), with an intruder's corner in the path;
+      * `better`: instances where the engine ends at a DIFFERENT local optimum that is cheaper than the independent solver's
+        (the problems are not convex; SLSQP started at the engine's point stays there): only feasibility is asserted.
     Tight mode accepts status 2 (line search exhausted at the rounding floor of the merit function) next to 0: what says
     "optimal" here are the comparisons, not the engine's own verdict."""
     from oracle import independent_mpc as im
 
-    d, ospec = _independent_fixture()
+    d, ospec = _fixture_file(fixture)
     gaps = []
     for b in range(len(d["x0"])):
         status, z = solve(b, d["x0"][b], d["ref"][b], d["nbr"][b], d["zu"][b])
@@ -226,13 +228,13 @@ def check_against_independent(solve, tight_tol, prod):
         cost, ref_cost = nlp.cost(X), d["cost"][b]
         gap = (cost - ref_cost) / ref_cost
         gaps.append(gap)
+        if b in better:
+            assert gap < 0.0, (b, gap)
+            continue
         assert gap > -(1e-6 if not prod else 1e-3), (b, gap)  # feasible for the reference's NLP: cannot be cheaper
         dpose = np.abs(z[:3] - d["sol"][b][:3]).max()
-        if b == 10:
-            assert 1e-3 < gap < 5e-3 and dpose < 2e-2, (gap, dpose)
-        else:
-            assert gap < (1e-6 if not prod else 1e-4), (b, gap)
-            assert dpose < (tight_tol if not prod else 5e-2), (b, dpose)
+        assert gap < (1e-6 if not prod else 2e-4), (b, gap)
+        assert dpose < (tight_tol if not prod else 5e-2), (b, dpose)
     return gaps
 
 
@@ -253,11 +255,28 @@ def test_full_size_instances_against_the_independent_solver(prod):
         return r["status"], r["p"].T
 
     check_against_independent(solve, 1e-4, prod)
-    # started from the independent optimum of instance 10 the engine stays there: it is a stationary point of the engine's
-    # problem too, the warm start just leads it to another one
-    d, _ = _independent_fixture()
-    r = port.solve(ospec, d["x0"][10], d["ref"][10], d["nbr"][10], d["sol"][10].T.copy(), opt)
-    assert r["status"] in ((0,) if prod else (0, 2)) and np.abs(r["p"].T[:3] - d["sol"][10][:3]).max() < (1e-5 if not prod else 5e-3)
+
+
+MORE_BETTER = (18, 25)  # the engine's local optimum is 0.44 % / 2.7 % cheaper than the independent solver's
+
+
+@pytest.mark.parametrize("prod", [False, True])
+def test_population_against_the_independent_solver(prod):
+    """32 more full-size instances (tests/golden/mpc_independent_more.npz, make_independent_more.py): 16 from the bench's
+    scenario sampler with active collision rows, 16 with a parked intruder's corner in the ego's path (vertex-vertex contacts).
+    30 are solved to the independent optimum; on two the engine ends at a cheaper local optimum.  (This population is what
+    found two defects of the first vertex-vertex implementation: the kept vertex pair of a face was compared by its first entry
+    instead of its minimum, and the filter kept entries of the previous working set.)"""
+    from oracle import port
+
+    _, ospec = _fixture_file("mpc_independent_more.npz")
+    opt = ipm.IpmOptions() if prod else ipm.IpmOptions(**TIGHT_FULL, stall_iters=0)
+
+    def solve(b, x0, ref, nbr, zu):
+        r = port.solve(ospec, x0, ref, nbr, zu.T.copy(), opt)
+        return r["status"], r["p"].T
+
+    check_against_independent(solve, 1e-4, prod, fixture="mpc_independent_more.npz", better=MORE_BETTER)
 
 
 def test_face_normal_certificates_alone_are_a_restriction():
