@@ -251,26 +251,27 @@ def test_planner_surface_four_vehicles(tmp_path):
                 assert separated(poly(fr[agents[ia]], i), poly(fr[agents[ib]], i)), (i, ia, ib)
 
 
-def test_collocation_plan_against_the_independent_solver_on_gpu():
+@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_2", "vehicle_3"])
+def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     """`cfz_colloc` (HIP, through the C ABI) from the fixture's guess against the optimum an INDEPENDENT solver found on an
     independent statement of the reference's single-vehicle plan (tests/golden/colloc_independent.npz: polygon distances, no
-    working sets, no condensation, SuperLU on the full KKT system; vehicle.py:360-661, N = 30 intervals, free dt) -- not
-    against the CPU compile of the kernel's own source.  At the reference's tolerance 1e-2: rows of the geometric statement to
-    1e-2, cost within 1e-3 of the optimum, poses within 5 mm, dt within 1e-3 s; at tight tolerances the optimum itself.
-    Assertions shared with the CPU test
-    (tests/test_independent_solver.py:check_plan_against_independent)."""
+    working sets, no condensation, SuperLU on the full KKT system; vehicle.py:360-661, N = 30 / 30 / 40 intervals, free dt) --
+    not against the CPU compile of the kernel's own source.  At the reference's tolerance 1e-2: rows of the geometric statement to
+    1e-2, cost within 3e-3 of the optimum, poses within 5 mm, dt within 1e-3 s; at tight tolerances (`exact_rows`) the optimum
+    itself.  Assertions shared with the CPU test (tests/test_independent_solver.py:check_plan_against_independent)."""
     from conflict_rez_amd import engine
     from test_independent_solver import _colloc_fixture, check_plan_against_independent
 
-    d, g, (tube, p, fh, sp) = _colloc_fixture()
+    d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
     tb = [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in tube[1:]]
     guess = d["guess"][:-1].reshape(-1, 7)
     r = engine.colloc(scenarios.parking_lot_spec(n_nbr=0, N=2), [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=400)[0]
     assert r["status"] == 0 and r["iters"] < 60
-    gap, dpose = check_plan_against_independent(r["traj"], r["dt"], tight=False)
+    check_plan_against_independent(r["traj"], r["dt"], False, agent)
     # the same kernel at tight tolerances with IPOPT's form of the dual regularisation (`exact_rows`): the independent optimum
-    # itself -- cost to 1e-8, poses to 1e-6 m, dt to 1e-8 s
+    # itself (vehicle_1: status 0, cost to 1e-8, poses to 1e-6 m; vehicles 2, 3: the unregularised rows lose rank where the vehicle
+    # waits and the solve ends with status 2 / 3 at the optimum, cost to 1e-6, poses to 1e-5 m)
     r2 = engine.colloc(scenarios.parking_lot_spec(n_nbr=0, N=2), [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8,
                        constr_viol_tol=1e-9, exact_rows=1)[0]
-    assert r2["status"] == 0, (r2["status"], r2["iters"])
-    check_plan_against_independent(r2["traj"], r2["dt"], tight=True)
+    assert r2["status"] == 0 or (agent != "vehicle_1" and r2["status"] in (2, 3)), (r2["status"], r2["iters"])
+    check_plan_against_independent(r2["traj"], r2["dt"], True, agent)

@@ -416,19 +416,20 @@ def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
     e.close()
 
 
+@pytest.mark.parametrize("fixture", ["mpc_independent_more.npz", "mpc_independent_obs.npz"])
 @pytest.mark.parametrize("prod", [False, True])
-def test_population_against_the_independent_solver_on_gpu(prod):
-    """The 32-instance population of tests/test_independent_solver.py (active rows from the bench's sampler, intruder corners
-    with vertex-vertex contacts) in one batch through the C ABI, same assertions as the CPU test of the port."""
+def test_population_against_the_independent_solver_on_gpu(prod, fixture):
+    """The populations of tests/test_independent_solver.py (active rows from the bench's sampler, intruder corners with
+    vertex-vertex contacts, static obstacles squeezed past) in one batch each through the C ABI, same assertions as the CPU
+    test of the port."""
     from conflict_rez_amd import engine, scenarios
-    from test_independent_solver import MORE_BETTER, TIGHT_FULL, _fixture_file, check_against_independent
+    from test_independent_solver import POPULATIONS, TIGHT_FULL, _fixture_file, check_against_independent
 
-    d, _ = _fixture_file("mpc_independent_more.npz")
+    d, _ = _fixture_file(fixture)
     opts = {} if prod else dict(**TIGHT_FULL, stall_iters=0)
     e = engine.Engine(scenarios.parking_lot_spec(), max_batch=len(d["x0"]), **opts)
     out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
-    check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture="mpc_independent_more.npz",
-                              better=MORE_BETTER)
+    check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture])
     e.close()
 
 

@@ -257,26 +257,31 @@ def test_full_size_instances_against_the_independent_solver(prod):
     check_against_independent(solve, 1e-4, prod)
 
 
-MORE_BETTER = (18, 25)  # the engine's local optimum is 0.44 % / 2.7 % cheaper than the independent solver's
+# fixture -> instances where the engine's local optimum is CHEAPER than the independent solver's (0.44 %, 2.7 %)
+POPULATIONS = {"mpc_independent_more.npz": (18, 25), "mpc_independent_obs.npz": ()}
 
 
+@pytest.mark.parametrize("fixture", sorted(POPULATIONS))
 @pytest.mark.parametrize("prod", [False, True])
-def test_population_against_the_independent_solver(prod):
-    """32 more full-size instances (tests/golden/mpc_independent_more.npz, make_independent_more.py): 16 from the bench's
-    scenario sampler with active collision rows, 16 with a parked intruder's corner in the ego's path (vertex-vertex contacts).
-    30 are solved to the independent optimum; on two the engine ends at a cheaper local optimum.  (This population is what
-    found two defects of the first vertex-vertex implementation: the kept vertex pair of a face was compared by its first entry
-    instead of its minimum, and the filter kept entries of the previous working set.)"""
+def test_population_against_the_independent_solver(prod, fixture):
+    """Two populations of full-size instances with the independent solver's optimum each:
+      mpc_independent_more.npz (make_independent_more.py): 16 from the bench's scenario sampler with active collision rows, 16 with
+        a parked intruder's corner in the ego's path (vertex-vertex contacts);
+      mpc_independent_obs.npz (make_independent_obs.py): 24 with reference, warm start and state pushed 0.2-0.9 m sideways into the
+        parking-lot furniture (static obstacles active).
+    54 of 56 are solved to the independent optimum; on two the engine ends at a cheaper local optimum.  (The first population is
+    what found two defects of the first vertex-vertex implementation: the kept vertex pair of a face was compared by its first
+    entry instead of its minimum, and the filter kept entries of the previous working set.)"""
     from oracle import port
 
-    _, ospec = _fixture_file("mpc_independent_more.npz")
+    _, ospec = _fixture_file(fixture)
     opt = ipm.IpmOptions() if prod else ipm.IpmOptions(**TIGHT_FULL, stall_iters=0)
 
     def solve(b, x0, ref, nbr, zu):
         r = port.solve(ospec, x0, ref, nbr, zu.T.copy(), opt)
         return r["status"], r["p"].T
 
-    check_against_independent(solve, 1e-4, prod, fixture="mpc_independent_more.npz", better=MORE_BETTER)
+    check_against_independent(solve, 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture])
 
 
 def test_face_normal_certificates_alone_are_a_restriction():
@@ -313,8 +318,11 @@ def test_independent_fixture_is_reproducible():
     assert abs(polygon_distance(Q, W)[0] - sep[k, j]) < 1e-7 and abs(sep[k, j] - ospec.dmin) < 1e-6
 
 
-# ---- full size collocation plan (tests/golden/colloc_independent.npz, make_independent_colloc.py) -----------------------------
-def _colloc_fixture():
+# ---- full size collocation plans (tests/golden/colloc_independent.npz, make_independent_colloc.py) ----------------------------
+COLLOC_AGENTS = ("vehicle_1", "vehicle_2", "vehicle_3")
+
+
+def _colloc_fixture(agent="vehicle_1"):
     import os
     import sys
 
@@ -323,62 +331,66 @@ def _colloc_fixture():
     from make_independent_colloc import problem
     from oracle.independent_colloc import GeometricColloc
 
-    d = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
-    tube, p, fh, sp = problem()
-    return {k: d[k] for k in d.files}, GeometricColloc(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh), (tube, p, fh, sp)
+    f = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
+    d = {k: f[f"{agent}_{k}"] for k in ("guess", "traj", "dt", "cost")}
+    tube, p, fh, sp = problem(agent)
+    return d, GeometricColloc(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh), (tube, p, fh, sp)
 
 
-def check_plan_against_independent(traj, dt, tight):
+def check_plan_against_independent(traj, dt, tight, agent="vehicle_1"):
     """Shared by the CPU test (kernel source compiled for the host) and the GPU test (`cfz_colloc`): the plan [N, 6, 7] + dt
     satisfies the GEOMETRIC statement of the reference's rows (ODE at all points, continuity, tube, polygon distances >= dmin,
-    boxes; oracle/independent_colloc.py) and is the independent optimum: cost to 1e-8 / poses to 1e-6 m at tight tolerances;
-    at the reference's tolerance 1e-2 the rows hold to 1e-2, the cost is within 1e-3 (below: the rows are relaxed by the
-    tolerance) and the poses within 5 mm."""
-    d, g, _ = _colloc_fixture()
+    boxes; oracle/independent_colloc.py) and is the independent optimum: cost to 1e-6 / poses to 1e-5 m at tight tolerances
+    (vehicle_1: 1e-8 / 1e-6); at the reference's tolerance 1e-2 the rows hold to 1e-2, the cost is within 3e-3 (below: the
+    rows are relaxed by the tolerance) and the poses within 5 mm."""
+    d, g, _ = _colloc_fixture(agent)
     z = np.append(np.asarray(traj, float).ravel(), float(dt))
     eq, ineq = np.abs(g.eq(z)).max(), g.ineq(z).min()
     gap = (g.cost(z) - float(d["cost"])) / float(d["cost"])
     dpose, ddt = np.abs(np.asarray(traj)[..., :3] - d["traj"][..., :3]).max(), abs(float(dt) - float(d["dt"]))
     if tight:
-        assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 1e-8 and dpose < 1e-6 and ddt < 1e-8, (eq, ineq, gap, dpose, ddt)
+        lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else (1e-6, 1e-5, 1e-7)
+        assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < lim[0] and dpose < lim[1] and ddt < lim[2], (agent, eq, ineq, gap, dpose, ddt)
     else:
-        assert eq < 1e-2 and ineq > -1e-2 and -1e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (eq, ineq, gap, dpose, ddt)
+        assert eq < 1e-2 and ineq > -1e-2 and -3e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (agent, eq, ineq, gap, dpose, ddt)
     return gap, dpose
 
 
+@pytest.mark.parametrize("agent", COLLOC_AGENTS)
 @pytest.mark.parametrize("tight", [True, False])
-def test_full_size_collocation_plan_against_the_independent_solver(tight):
+def test_full_size_collocation_plan_against_the_independent_solver(tight, agent):
     """The planning kernel's source (CPU build) from the fixture's guess against the independent optimum of the geometric
-    statement, at tight tolerances (unregularised rows) and at the reference's tolerance."""
+    statement, at tight tolerances (unregularised rows) and at the reference's tolerance, for three vehicles of the synthetic
+    strategy.  At tight tolerances the verdict is the comparison: the kernel source ends with status 2 (vehicle_2, 561
+    iterations) or 3 (vehicle_3, at iteration 57) AT the optimum -- the unregularised rows lose rank where a vehicle waits."""
     import colloc_emu_binding as ce
     import test_colloc as tc
     from oracle.colloc_nlp import CollocNlp
 
-    d, g, (tube, p, fh, sp) = _colloc_fixture()
+    d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
     nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
-    X0 = np.zeros(nlp.n)
-    X0[: nlp.iDt + 1] = d["guess"]
-    X0 = nlp.pack({k: X0[: nlp.iDt].reshape(-1, 7)[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}, float(d["guess"][-1]))
+    X0 = nlp.pack({k: d["guess"][:-1].reshape(-1, 7)[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}, float(d["guess"][-1]))
     if tight:
         opt = ipm.IpmOptions(max_iter=800, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
         opt.no_prox = 1
     else:
         opt = ipm.IpmOptions(**tc.COLLOC_OPT)
     r = ce.solve(nlp, X0, opt)
-    assert r["status"] == 0
+    assert r["status"] == 0 or (tight and agent != "vehicle_1" and r["status"] in (2, 3)), r["status"]
     P, dt = g.split(r["X"][: nlp.iDt + 1])
-    check_plan_against_independent(P, dt, tight)
+    check_plan_against_independent(P, dt, tight, agent)
 
 
-def test_independent_collocation_fixture_is_a_kkt_point():
-    """Certificate of the fixture that needs no solver: at the stored plan the gradient of the cost is a combination of the
+@pytest.mark.parametrize("agent", COLLOC_AGENTS)
+def test_independent_collocation_fixture_is_a_kkt_point(agent):
+    """Certificate of the fixtures that needs no solver: at the stored plan the gradient of the cost is a combination of the
     gradients of the equality rows and of the ACTIVE inequality rows and bounds of the geometric statement with multipliers of
-    the right sign (least squares: residual 1e-6 of the gradient's size), and every row holds to 1e-8."""
+    the right sign (bounded least squares: residual 1e-5 of the gradient's size), and every row holds to 2e-8."""
     from scipy.optimize import lsq_linear
 
-    d, g, _ = _colloc_fixture()
+    d, g, _ = _colloc_fixture(agent)
     z = np.append(d["traj"].ravel(), float(d["dt"]))
-    assert np.abs(g.eq(z)).max() < 1e-8 and g.ineq(z).min() > -1e-8 and abs(g.cost(z) - float(d["cost"])) < 1e-9
+    assert np.abs(g.eq(z)).max() < 2e-8 and g.ineq(z).min() > -1e-8 and abs(g.cost(z) - float(d["cost"])) < 1e-9
     act = np.nonzero(g.ineq(z) < 1e-6)[0]
     lo = np.array([b[0] if b[0] is not None else -np.inf for b in g.bounds()])
     hi = np.array([b[1] if b[1] is not None else np.inf for b in g.bounds()])
@@ -390,5 +402,5 @@ def test_independent_collocation_fixture_is_a_kkt_point():
     # grad f = Je' a + Ji' b + Eb' c with b, c >= 0 (inequalities are >= 0 rows, so their multipliers pull the cost up)
     A = np.vstack([Je, Ji, Eb]).T
     lb = np.concatenate([np.full(len(Je), -np.inf), np.zeros(len(Ji) + len(Eb))])
-    r = lsq_linear(A, g.cost_grad(z), bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=500)
+    r = lsq_linear(A, g.cost_grad(z), bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=800)
     assert len(act) >= 3 and np.abs(A @ r.x - g.cost_grad(z)).max() < 1e-5 * np.abs(g.cost_grad(z)).max(), (len(act), np.abs(A @ r.x - g.cost_grad(z)).max())
