@@ -402,5 +402,8 @@ def test_independent_collocation_fixture_is_a_kkt_point(agent):
     # grad f = Je' a + Ji' b + Eb' c with b, c >= 0 (inequalities are >= 0 rows, so their multipliers pull the cost up)
     A = np.vstack([Je, Ji, Eb]).T
     lb = np.concatenate([np.full(len(Je), -np.inf), np.zeros(len(Ji) + len(Eb))])
-    r = lsq_linear(A, g.cost_grad(z), bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=800)
+    from threadpoolctl import threadpool_limits
+
+    with threadpool_limits(limits=1):  # BVLS makes thousands of small BLAS calls: threads only contend (minutes under pytest-xdist)
+        r = lsq_linear(A, g.cost_grad(z), bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=800)
     assert len(act) >= 3 and np.abs(A @ r.x - g.cost_grad(z)).max() < 1e-5 * np.abs(g.cost_grad(z)).max(), (len(act), np.abs(A @ r.x - g.cost_grad(z)).max())
