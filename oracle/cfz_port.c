@@ -172,7 +172,7 @@ static int closest_vertex_pair(const double V[4][2], double x, double y, double 
     int u1 = (u + 1) & 3, u3 = (u + 3) & 3;
     if (wx * (V[u1][0] - V[u][0]) + wy * (V[u1][1] - V[u][1]) <= 0.0 &&
         wx * (V[u3][0] - V[u][0]) + wy * (V[u3][1] - V[u][1]) <= 0.0) {
-      *uo = u; *vo = v; *ro = hypot(wx, wy);
+      *uo = u; *vo = v; *ro = sqrt(wx * wx + wy * wy);
       return 1;
     }
   }
@@ -261,7 +261,7 @@ static void eval_rows(const cfz_port_spec *sp, const double *nbr, const double p
         double rbx = cs * BV[va][0] - sn * BV[va][1], rby = sn * BV[va][0] + cs * BV[va][1];
         double dwx = -rby, dwy = rbx;
         double wx = p[k][0] + rbx - V[f][0], wy = p[k][1] + rby - V[f][1];
-        double r = hypot(wx, wy), n0 = wx / r, n1 = wy / r;
+        double r = sqrt(wx * wx + wy * wy), ir = 1.0 / r, n0 = wx * ir, n1 = wy * ir; /* as the kernel forms them */
         double t2 = -n1 * dwx + n0 * dwy, kap = -(n0 * rbx + n1 * rby);
         for (int q = 0; q < 2; ++q) {
           sep[k][2 * j + q] = r;
