@@ -416,7 +416,7 @@ def test_full_size_instances_against_the_independent_solver_on_gpu(prod):
     e.close()
 
 
-@pytest.mark.parametrize("fixture", ["mpc_independent_more.npz", "mpc_independent_obs.npz"])
+@pytest.mark.parametrize("fixture", ["mpc_independent_more.npz", "mpc_independent_obs.npz", "mpc_independent_turn.npz"])
 @pytest.mark.parametrize("prod", [False, True])
 def test_population_against_the_independent_solver_on_gpu(prod, fixture):
     """The populations of tests/test_independent_solver.py (active rows from the bench's sampler, intruder corners with
@@ -429,7 +429,8 @@ def test_population_against_the_independent_solver_on_gpu(prod, fixture):
     opts = {} if prod else dict(**TIGHT_FULL, stall_iters=0)
     e = engine.Engine(scenarios.parking_lot_spec(), max_batch=len(d["x0"]), **opts)
     out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
-    check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture])
+    check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture][0],
+                              fails=POPULATIONS[fixture][1])
     e.close()
 
 
