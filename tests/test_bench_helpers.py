@@ -1,0 +1,19 @@
+"""bench.py's host-side pieces that need no GPU: the committed profile summaries parse into the `roofline` fields, the CPU
+baseline leg (the same closed loop through the oracle's C port) runs on a tiny sample, the CasADi probe reports a real import
+outcome.  (The GPU leg of bench.py is what the driver runs.)"""
+import bench
+
+
+def test_profile_summaries_parse():
+    traffic, tag = bench.profiled_traffic("loop_kernel")
+    assert tag is not None and 1e8 < traffic < 1e11   # bytes per launch of the default command
+    sq, tag2 = bench.profiled_sq("loop_kernel")
+    assert tag2 == tag and 0.0 < sq["raw_quotient"] < 1.0 and abs(sq["frac"] - 4.0 * sq["raw_quotient"]) < 1e-12
+    assert bench.profiled_traffic("no_such_kernel") == (None, tag)
+
+
+def test_cpu_closed_loop_worker_and_probe():
+    n, its, ok, secs, cold = bench._cpu_closed_loop_worker((0, 2, 1, 2))   # seed 0, 2 scenarios, 1 warm-up + 2 timed iterations
+    assert n == 2 * 4 * 2 and 0 < ok <= n and its >= ok and secs > 0.0
+    assert cold[0] == 8 and cold[1] >= 8
+    assert "casadi" in bench.casadi_probe().lower()
