@@ -307,6 +307,7 @@ def main():
         n_ok = int(c[0])
         n_conv = None if n_conv is None else int(c[1])
 
+    out_line = None
     if rank == 0:
         B = S * V_local  # solves per iteration on one GPU
         solves = B * world * args.steps
@@ -371,9 +372,16 @@ def main():
                                       "ipm_iterations_per_s_cpu": cb["ipm_iterations_per_s"],
                                       "ratio_same_cores": ipm_iterations * world / elapsed / cb["ipm_iterations_per_s"],
                                       "ratio_per_core": ipm_iterations * world / elapsed / (cb["ipm_iterations_per_s"] / cb["cores"])}
-        print(json.dumps(line), flush=True)
+        out_line = json.dumps(line)
     if dist is not None:
         dist.destroy_process_group()
+    # the ONE line goes out last: RCCL writes its version banner through C stdio, which a pipe only sees at exit unless it is
+    # flushed here
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    if out_line is not None:
+        print(out_line, flush=True)
 
 
 if __name__ == "__main__":
