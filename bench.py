@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--scenarios", type=int, default=1024, help="scenarios per GPU (x4 vehicles)")
     ap.add_argument("--max-iter", type=int, default=600, help="IPM iteration limit (reference: 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=2024, help="scenario sampler seed of rank 0 (rank r uses seed + r)")
     ap.add_argument("--n-obs", type=int, default=6, help="static obstacles (reference map: 6); fewer = experiments only")
     ap.add_argument("--workload", choices=["mpc4", "single"], default="mpc4",
                     help="mpc4: BASELINE.json configs[2], 4-vehicle distributed MPC (the metric); single: configs[1] in MPC form, "
@@ -216,7 +217,7 @@ def main():
     if single:
         table = table[rank % table.shape[0]][None].copy()  # every scenario follows one vehicle's plan, alone on the map
     S = args.scenarios
-    k0, noise = scenarios.sample_scenarios(S, table, seed=2024 + rank)
+    k0, noise = scenarios.sample_scenarios(S, table, seed=args.seed + rank)
     vehicle_sharded = args.parallelism == "vehicle"
     if vehicle_sharded:
         if dist is None or single:
@@ -226,7 +227,7 @@ def main():
         # scenarios x world in total: every rank steps its vehicles (V / world of them, or one vehicle of a scenario shard when
         # there are more ranks than vehicles) -> the same number of solves per GPU as in scenario sharding
         S_total = args.scenarios * world
-        k0, noise = scenarios.sample_scenarios(S_total, table, seed=2024)
+        k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed)
         ex = VehicleShardedExchange(V)
         S = len(range(S_total)[ex.scenarios(S_total)])
         eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)

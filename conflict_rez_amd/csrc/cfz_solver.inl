@@ -363,6 +363,7 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // in the other's normal cone; no face normal certifies their distance, so the row is the Euclidean distance |W_v - V_u| itself,
 // imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
+constexpr int kWsStallDiv = 4;  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
 
 template <bool GRAD>
 CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
@@ -1215,7 +1216,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   const int m_eq = 5 + 5 * (N - 1) + nr * N, n_bnd = N * (12 + nr);
   const double mu_floor = dv.mu_floor;
   double stall_ref = 0.0;
-  int stall_cnt = 0;
+  int stall_cnt = 0, stall_ws = 0;
   int xpar = 0;  // which half of the wavefront exchange buffer the next reduction uses
   (void)xpar;
   CFZ_PART(rd, 6);   // lane partials of the workgroup reductions
@@ -1473,8 +1474,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
     if (iter == sp.max_iter) { status = 1; break; }
     // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
-    // (an iterate that changed the working set does not count as stalled: its new rows start with their own violation)
-    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else if (!ws_changed) ++stall_cnt;
+    // (an iterate that changed the working set counts a quarter: its new rows start with their own violation -- but a solve that
+    // changes it at every iterate is cycling and has to end)
+    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
+    else if (!ws_changed) ++stall_cnt;
+    else if (++stall_ws >= kWsStallDiv) { stall_ws = 0; ++stall_cnt; }
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
     while (mu > mu_floor) {

@@ -54,8 +54,8 @@ typedef struct cfz_options {
   int32_t max_iter;       /* :364 600 */
   int32_t max_backtrack;  /* line-search halvings before status 2 */
   int32_t filter_cap;     /* filter entries kept per barrier problem */
-  int32_t stall_iters;    /* 10: iterations without progress of the constraint violation (not counting those that changed the
-                           *     working set of the separation rows) before status 5; 0 = off */
+  int32_t stall_iters;    /* 10: iterations without progress of the constraint violation (those that changed the working set
+                           *     of the separation rows count a quarter) before status 5; 0 = off */
   int32_t row_curvature;  /* 1: Hessian = Gauss-Newton objective part + multiplier-weighted curvature of the separation rows */
   int32_t carry_duals;    /* 1: keep one carry record per slot (multipliers of the last converged solve); 0: never */
   int32_t vv_rows;        /* 1: a block whose closest features are two vertices is constrained by their Euclidean distance

@@ -127,6 +127,7 @@ static void rk4_sens(const double z[5], const double u[2], double dt, double wb,
 
 /* ---------------------------------------------------------------- separation certificates */
 #define HYST 1e-3 /* m: a block keeps its separating face until another one is better by this much */
+#define WS_STALL_DIV 4 /* iterates that change the working set count 1 / WS_STALL_DIV towards the stall test */
 
 /* signed distances of the 4 vertices of one polygon to face f of the other (+ gradients wrt x,y,psi).
  * kind 1 = polygon face / body vertices, kind 2 = body face / polygon vertices. */
@@ -363,7 +364,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   double theta_min = -1.0, theta_max = -1.0;
   const double mu_floor = fmin(sp->tol, sp->compl_inf_tol) / (sp->kappa_eps + 1.0);
   double stall_ref = 0.0;
-  int stall_cnt = 0;
+  int stall_cnt = 0, stall_ws = 0;
   double mu = sp->mu_init;
   int status = 1, iter = 0;
   double err0 = INFINITY;
@@ -534,7 +535,11 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
     if (iter == sp->max_iter) break;
     /* infeasibility stall (oracle/ipm.py) */
-    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; } else if (!ws_changed) ++stall_cnt;
+    /* an iterate that changed the working set counts a quarter (its new rows start with their own violation; but a solve that
+     * changes it at EVERY iterate cycles, and must end) */
+    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
+    else if (!ws_changed) ++stall_cnt;
+    else if (++stall_ws >= WS_STALL_DIV) { stall_ws = 0; ++stall_cnt; }
     if (sp->stall_iters > 0 && stall_cnt >= sp->stall_iters && cviol > sp->constr_viol_tol) { status = 5; break; }
     /* ---- barrier update ------------------------------------------------------------- */
     while (mu > mu_floor) {

@@ -42,7 +42,7 @@ class IpmOptions:
     max_iter: int = 600  # :364
     # Infeasibility stall test (stands in for the outcome of IPOPT's restoration phase, "converged to a point of
     # local infeasibility"): give up when the max-norm constraint violation has not dropped below stall_kappa x its
-    # last checkpoint for stall_iters iterates (not counting those that changed the working set of a working-set NLP) while
+    # last checkpoint for stall_iters iterates (those that changed the working set of a working-set NLP count a quarter) while
     # still above constr_viol_tol.  0 disables.
     # Hessian of the Lagrangian = Gauss-Newton objective part + exact curvature of the separation rows weighted with
     # their multipliers (NLPs that provide hess_gn(x, nu)).  Without it the iteration is not contractive when a
@@ -94,6 +94,9 @@ def push_to_interior(x, xl, xu, opt: IpmOptions):
     x = np.where(hasl, np.maximum(x, xl + pl), x)
     x = np.where(hasu, np.minimum(x, xu - pu), x)
     return x
+
+
+WS_STALL_DIV = 4
 
 
 def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
@@ -178,9 +181,13 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         if it == opt.max_iter:
             break
         if it == 0 or cviol <= opt.stall_kappa * stall_ref:
-            stall_ref, stall_cnt = cviol, 0
-        elif not getattr(nlp, "ws_changed", False):  # an iterate that changed the working set does not count as stalled
+            stall_ref, stall_cnt, stall_ws = cviol, 0, 0
+        elif not getattr(nlp, "ws_changed", False):
             stall_cnt += 1
+        else:  # an iterate that changed the working set counts a quarter: its new rows start with their own violation, but a
+            stall_ws += 1  # solve that changes it at EVERY iterate cycles and must end
+            if stall_ws >= WS_STALL_DIV:
+                stall_ws, stall_cnt = 0, stall_cnt + 1
         if opt.stall_iters > 0 and stall_cnt >= opt.stall_iters and cviol > opt.constr_viol_tol:
             status = STATUS_STALLED
             break
