@@ -93,6 +93,7 @@ struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
   int max_iter, max_backtrack, filter_cap, stall_iters;
   int row_curvature, vv_rows;  // vv_rows 1: vertex-vertex rows (kind 3) in the working set
+  int shift_after, pad0;       // iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
   double dt, wb, dmin;
   double g[4], bounds[12], weights[6];
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
@@ -391,6 +392,29 @@ CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[
       if (GRAD) { gr[v][0] = -nx; gr[v][1] = -ny; gr[v][2] = dnx * (V[v][0] - x) + dny * (V[v][1] - y); }
     }
   }
+}
+
+// max(0, -lambda_min) of the symmetric 3 x 3 [[a00 a01 a02] [a01 a11 a12] [a02 a12 a22]] (trigonometric closed form;
+// oracle/mpc_nlp.py pose_shift).  Only reached from iteration spec.shift_after on.
+#if defined(__HIPCC__)
+static __host__ __device__ __attribute__((noinline))  // cold: kept out of the assembly stage's register allocation
+#else
+static
+#endif
+double pose_shift(double a00, double a11, double a22, double a01, double a02, double a12) {
+  const double d2 = a00 * a11 - a01 * a01;
+  const double d3 = a22 * d2 - (a02 * a02 * a11 - 2.0 * a02 * a12 * a01 + a12 * a12 * a00);
+  if (a00 > 0.0 && d2 > 0.0 && d3 >= 0.0) return 0.0;
+  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const double qm = (a00 + a11 + a22) * (1.0 / 3.0);
+  const double b00 = a00 - qm, b11 = a11 - qm, b22 = a22 - qm;
+  const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1) * (1.0 / 6.0));
+  const double ip = 1.0 / p;
+  const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+  double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+  r = fmin(1.0, fmax(-1.0, r));
+  const double lam = qm + 2.0 * p * cos(acos(r) * (1.0 / 3.0) + 2.0943951023931953);
+  return fmax(0.0, -lam);
 }
 
 CFZ_FN double pick4(const double d[4], int v) {
@@ -1589,6 +1613,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
               if (m00 > 0.0 && d2 > 0.0 && d3 >= 0.0) break;
             }
             th *= 0.5;
+          }
+          if (sp.shift_after > 0 && iter >= sp.shift_after && th < 1.0) {
+            // late in a long solve the scaled model cycles: whole curvature + the smallest identity shift that keeps the margin
+            const double dl = pose_shift(dv.q0 + cxx, dv.q1 + cyy, q2 + cc, cxy, ca, cb);
+            h[0] += dl; h[1] += dl; h[2] += dl;
+            th = 1.0;
           }
           h[2] += th * cc; h[8] += th * ca; h[9] += th * cb;
           h[0] += th * cxx; h[1] += th * cyy; h[7] += th * cxy;

@@ -60,7 +60,9 @@ typedef struct cfz_options {
   int32_t carry_duals;    /* 1: keep one carry record per slot (multipliers of the last converged solve); 0: never */
   int32_t vv_rows;        /* 1: a block whose closest features are two vertices is constrained by their Euclidean distance
                            *    (exactly the reference's OBCA rows there); 0: face-normal certificates only (a restriction) */
-  int32_t reserved0;
+  int32_t shift_after;    /* 60: from this iteration on a stage whose row curvature the convexity safeguard would scale keeps it
+                           *     whole and is shifted by the smallest multiple of the identity instead (a scaled model can
+                           *     cycle for hundreds of iterations on a vehicle pressed into a corner); 0 = never */
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

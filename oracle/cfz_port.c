@@ -34,6 +34,7 @@ typedef struct {
       s_theta, s_phi, reg_primal, stall_kappa, warm_push;
   int filter_cap, max_backtrack, stall_iters, row_curvature;
   int vv_rows; /* 1: vertex-vertex rows (kind 3) in the working set, oracle/mpc_nlp.py MpcSpec.vv_rows */
+  int shift_after; /* oracle/ipm.py IpmOptions.shift_after */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -333,6 +334,23 @@ static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *
 }
 
 /* ---------------------------------------------------------------- small dense helpers */
+/* max(0, -lambda_min) of the symmetric 3 x 3 [[a00 a01 a02] [a01 a11 a12] [a02 a12 a22]] */
+static double pose_shift(double a00, double a11, double a22, double a01, double a02, double a12) {
+  const double d2 = a00 * a11 - a01 * a01;
+  const double d3 = a22 * d2 - (a02 * a02 * a11 - 2.0 * a02 * a12 * a01 + a12 * a12 * a00);
+  if (a00 > 0.0 && d2 > 0.0 && d3 >= 0.0) return 0.0;
+  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const double qm = (a00 + a11 + a22) / 3.0;
+  const double b00 = a00 - qm, b11 = a11 - qm, b22 = a22 - qm;
+  const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1) / 6.0);
+  const double ip = 1.0 / p;
+  const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+  double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+  r = fmin(1.0, fmax(-1.0, r));
+  const double lam = qm + 2.0 * p * cos(acos(r) / 3.0 + 2.0943951023931953);
+  return fmax(0.0, -lam);
+}
+
 static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *out) {
   /* out = M^{-1} rhs for nr right-hand sides stored as rhs[2][nr] (row-major) via Cholesky */
   double l00 = sqrt(M[0][0]), l10 = M[1][0] / l00, l11 = sqrt(M[1][1] - l10 * l10);
@@ -606,6 +624,12 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
             if (m00 > 0.0 && d2 > 0.0 && d3 >= 0.0) break;
           }
           th *= 0.5;
+        }
+        if (sp->shift_after > 0 && iter >= sp->shift_after && th < 1.0) {
+          /* late in a long solve the scaled model cycles: whole curvature + smallest identity shift (hess_gn shift=True) */
+          const double dl_ = pose_shift(q0 + cxx, q1 + cyy, q2 + cc, cxy, ca, cb);
+          H[k][0][0] += dl_; H[k][1][1] += dl_; H[k][2][2] += dl_;
+          th = 1.0;
         }
         H[k][0][2] += th * ca; H[k][2][0] += th * ca; H[k][1][2] += th * cb; H[k][2][1] += th * cb; H[k][2][2] += th * cc;
         H[k][0][0] += th * cxx; H[k][1][1] += th * cyy; H[k][0][1] += th * cxy; H[k][1][0] += th * cxy;

@@ -48,6 +48,10 @@ class IpmOptions:
     # their multipliers (NLPs that provide hess_gn(x, nu)).  Without it the iteration is not contractive when a
     # vehicle is pushed hard against a separation row (period-2 oscillation, hundreds of iterations).
     row_curvature: bool = True
+    # The convexity safeguard scales a stage's row curvature (hess_gn).  A scaled model can cycle for hundreds of iterations
+    # on a vehicle pressed deep into a corner; from iteration shift_after on such a stage keeps the whole curvature and
+    # is shifted by the smallest multiple of the identity instead (0 = never).  Solves that end earlier are untouched.
+    shift_after: int = 60
     warm_push: float = 1e-6  # distance from a bound kept by a start that carries the previous solve's multipliers
     stall_kappa: float = 0.9
     stall_iters: int = 10
@@ -200,7 +204,11 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         gphi = g - mu / dl * hasl + mu / du * hasu  # gradient of the barrier objective
         rhs = -np.concatenate([gphi + J.T @ nu, c])
         if opt.hessian == "gn":
-            H = (nlp.hess_gn(x, nu) if opt.row_curvature and getattr(nlp, "has_row_curvature", False) else nlp.hess_gn(x)) + sp.diags(sig + opt.reg_primal)
+            if opt.row_curvature and getattr(nlp, "has_row_curvature", False):
+                H = nlp.hess_gn(x, nu, shift=0 < opt.shift_after <= it)
+            else:
+                H = nlp.hess_gn(x)
+            H = H + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
             sol = spla.splu(K).solve(rhs)
             dx, dnu = sol[:n], sol[n:]

@@ -201,6 +201,25 @@ def vertex_distances(A, b, PV, t, psi, g, BV, kind, f):
     return d, gr
 
 
+def pose_shift(a00, a11, a22, a01, a02, a12):
+    """max(0, -lambda_min) of the symmetric 3 x 3 [[a00 a01 a02] [a01 a11 a12] [a02 a12 a22]]: zero when the leading
+    minors pass, else the trigonometric closed form of the smallest eigenvalue (same arithmetic as the kernel)."""
+    d2 = a00 * a11 - a01 * a01
+    d3 = a22 * d2 - (a02 * a02 * a11 - 2.0 * a02 * a12 * a01 + a12 * a12 * a00)
+    if a00 > 0.0 and d2 > 0.0 and d3 >= 0.0:
+        return 0.0
+    p1 = a01 * a01 + a02 * a02 + a12 * a12
+    qm = (a00 + a11 + a22) / 3.0
+    b00, b11, b22 = a00 - qm, a11 - qm, a22 - qm
+    p = np.sqrt((b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1) / 6.0)
+    ip = 1.0 / p
+    c00, c11, c22, c01, c02, c12 = b00 * ip, b11 * ip, b22 * ip, a01 * ip, a02 * ip, a12 * ip
+    r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02))
+    r = min(1.0, max(-1.0, r))
+    lam = qm + 2.0 * p * np.cos(np.arccos(r) / 3.0 + 2.0943951023931953)
+    return max(0.0, -lam)
+
+
 def closest_vertex_pair(PV, t, psi, g, BV):
     """(u, v): polygon vertex PV[u] and body vertex v that are each other's closest feature -- each lies in the other's normal
     cone (beyond both edges that meet there) -- which makes them THE closest points of the two convex polygons; None when the
@@ -549,10 +568,11 @@ class MpcNlp:
         Gd[:, 6] = 2 * wt[4] * P[:, 3] ** 2 * P[:, 6]
         return Gd.ravel()
 
-    def hess_gn(self, X, nu=None):
+    def hess_gn(self, X, nu=None, shift=False):
         """Gauss-Newton Hessian of the Lagrangian: objective curvature with the (v w)^2 term taken as the
         square of the residual r = v*w (PSD); with `nu`, plus the exact curvature of the separation rows
-        sum_r nu_r d2 sep_r / d(x,y,psi)^2 (`row_curvature`)."""
+        sum_r nu_r d2 sep_r / d(x,y,psi)^2 (`row_curvature`).  `shift`: a stage whose curvature would be scaled
+        keeps it whole and gets the smallest multiple of the identity on (x, y, psi) that restores the margin."""
         N, ns = self.spec.N, self.ns
         P = X.reshape(N, ns)
         wt = self.spec.weights
@@ -591,6 +611,11 @@ class MpcNlp:
                         if M[0, 0] > 0.0 and d2 > 0.0 and d3 >= 0.0:
                             break
                     th *= 0.5
+                if shift and th < 1.0:
+                    dl = pose_shift(q0 - m_ + C[k, 0, 0], q1 - m_ + C[k, 1, 1], q2 - m_ + C[k, 2, 2], C[k, 0, 1], a_, b_c)
+                    th = 1.0
+                    for a in range(3):
+                        rows.append(np.array([k * ns + a])), cols.append(np.array([k * ns + a])), vals.append(np.array([dl]))
                 Ck = th * C[k]
                 for a in range(3):
                     for b_ in range(3):

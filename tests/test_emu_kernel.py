@@ -96,3 +96,29 @@ print('sanitized ok')
     env = dict(**__import__("os").environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sanitized ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_late_shift_ends_the_cycle_of_the_scaled_curvature(ospec):
+    """tests/golden/mpc_late_shift.npz: solves that run into max_iter while the convexity safeguard scales the row
+    curvature (IpmOptions.shift_after = 0) end within ~80 iterations when, from iteration 60 on, the stage keeps the
+    whole curvature and is shifted instead.  The C port and the kernel source reproduce the full-KKT oracle's iteration
+    counts and solutions, and (first instance) the full-KKT oracle itself regenerates the stored vector."""
+    import os
+
+    from oracle.mpc_nlp import solve_mpc
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_late_shift.npz"))
+    opt, off = ipm.IpmOptions(), ipm.IpmOptions(shift_after=0)
+    assert opt.shift_after == 60
+    for b in range(len(g["x0"])):
+        args = (g["x0"][b], g["ref"][b], g["nbr"][b], g["zu"][b])
+        re_ = emu.solve(ospec, opt, *args, want_duals=False)
+        rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
+        assert (re_["status"], re_["iters"]) == (0, int(g["iters_shift"][b])) == (rp["status"], rp["iters"]), b
+        assert 60 < re_["iters"] < 100
+        assert np.abs(re_["zu"] - g["sol"][b]).max() < 1e-6 and np.abs(rp["p"].T - g["sol"][b]).max() < 1e-6
+        if b < 2:
+            r0 = emu.solve(ospec, off, *args, want_duals=False)
+            assert r0["iters"] == int(g["iters_noshift"][b]) == 600 and r0["status"] == 1
+    full = solve_mpc(ospec, *[g[k][0] for k in ("x0", "ref", "nbr", "zu")])
+    assert (full["status"], full["iters"]) == (0, int(g["iters_shift"][0])) and np.abs(full["zu"] - g["sol"][0]).max() < 1e-9

@@ -536,3 +536,22 @@ def test_dual_ws_certificates(eng, ospec):
     _, _, d0 = eng.dual_ws(np.array([[8.0, 16.25, 0.0], [20.0, 10.0, 0.0], [16.25, 16.65, 0.0]]))
     assert abs(d0[0, 0] - (16.25 - 0.9 - 13.75)) < 1e-12 and abs(d0[1, 0] - (20.0 - 0.6 - 14.65)) < 1e-12
     assert abs(d0[2, 0] - np.hypot(1.0, 2.0)) < 1e-12
+
+
+def test_late_shift_fixture(eng):
+    """tests/golden/mpc_late_shift.npz (full-KKT oracle): solves that pass iteration 60 with a scaled row curvature switch to
+    the shifted one (cfz_options.shift_after) and converge; with shift_after = 0 the same solves run into max_iter."""
+    import os
+
+    from conflict_rez_amd import engine
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_late_shift.npz"))
+    out = eng.solve(g["x0"], g["ref"], g["nbr"], g["zu"])
+    assert out["status"].tolist() == [0] * len(g["x0"]) and out["iters"].tolist() == g["iters_shift"].tolist()
+    assert np.abs(out["zu"][:, :5] - g["sol"][:, :5]).max() < 1e-6 and np.abs(out["zu"][:, 5:] - g["sol"][:, 5:]).max() < 1e-4
+    e0 = engine.Engine(eng.spec, max_batch=16, shift_after=0)
+    try:
+        o0 = e0.solve(g["x0"], g["ref"], g["nbr"], g["zu"])
+    finally:
+        e0.close()
+    assert o0["iters"].tolist() == g["iters_noshift"].tolist() and (o0["status"] == 1).all()
