@@ -660,10 +660,16 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
   constexpr int NB = 16;
   const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   int ju = 0;
+#ifdef CFZ_WIDE_STATS
+  double s_nq = 0, s_nc = 0, s_nr = 0, s_km = 0, s_sw = 0, s_lastc = 0, s_lastr = 0, s_upd = 0;
+#endif
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
     glb_f64 *cj = ab + (size_t)j * ld;
     long long tp0 = tick();
+#ifdef CFZ_WIDE_STATS
+    if (tid == 0) { pj[14] = 0; pj[15] = 0; }
+#endif
     // (1) pivot search; thread i keeps row j+i of the pivot column
     const double own = tid <= km ? cj[kv + tid] : 0.0, diag = cj[kv];
     double best = tid <= km ? fabs(own) : -1.0, bv = own;
@@ -694,6 +700,9 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
       if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt + 1, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (l != 0.0) { const int at = base + __popcll(mask & ((1ull << lane) - 1ull)); lrow[at] = tid; lval[at] = l; }
+#ifdef CFZ_WIDE_STATS
+      if (l != 0.0) __hip_atomic_fetch_max(pj + 14, tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
     // (2b) trailing columns: swap rows j and j+jp, u = new row j; the value now in row j+jp goes to LDS as well
     for (int t0 = 0; t0 < nq; t0 += nt) {
@@ -711,11 +720,17 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
       if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+#ifdef CFZ_WIDE_STATS
+      if (u != 0.0) __hip_atomic_fetch_max(pj + 15, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
     lds_barrier();
     { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
     // (3) rank-1 update of (nonzero rows) x (nonzero columns)
     const int nc = cnt[0], nr = cnt[1];
+#ifdef CFZ_WIDE_STATS
+    s_nq += nq; s_nc += nc; s_nr += nr; s_km += km; s_sw += jp != 0; s_lastc += pj[15]; s_lastr += pj[14]; s_upd += (double)nc * nr;
+#endif
     for (int r0 = 0; r0 < nr; r0 += 64) {
       const bool mine = r0 + lane < nr;
       const int i = mine ? lrow[r0 + lane] : 0;
@@ -742,6 +757,11 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
     __syncthreads();
     { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
   }
+#ifdef CFZ_WIDE_STATS
+  if (tid == 0 && blockIdx.x == 0)
+    printf("wide LU n %d kb %d: per pivot nq %.1f nonzero-u %.1f (last at %.1f) km %.1f nonzero-l %.1f (last at %.1f) swaps %.2f update entries %.0f\n", n, kb,
+           s_nq / n, s_nc / n, s_lastc / n, s_km / n, s_nr / n, s_lastr / n, s_sw / n, s_upd / n);
+#endif
   return 0;
 }
 
@@ -755,6 +775,218 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
   __syncthreads();
   const int fail = band_factor_wide2_core((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)ulds, (lds_f64 *)alds, (lds_f64 *)lval, (lds_i32 *)cols, (lds_i32 *)lrow,
                                           (lds_f64 *)pb, (lds_f64 *)pbv, (lds_i32 *)pj, (lds_i32 *)cnt, (lds_f64 *)tks);
+  __syncthreads();
+  for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
+  return fail;
+}
+
+// The same elimination P pivots at a time (same pivots, same arithmetic per entry as band_factor_wide2, so the factor is the
+// same).  What bounds a batch of joint plans is the number of cache lines a pivot touches (255 plans share the L2s and the
+// MALL): one pivot at a time reads row j of every column within reach (one line per column) and updates ~60 columns.
+// Here (1) the P panel columns are brought into LDS (rows j0 .. j0+P-1+kl), (2) factored there -- pivot search, swap, scale
+// and update of the later panel columns cost LDS round trips only -- and written back; (3) of the trailing columns within
+// reach only the 2 P entries the panel's swaps and pivot rows can touch are gathered (64 / 2P columns per load, all loads of a
+// wavefront in flight together); (4) a column with a nonzero among them is read ONCE (each lane rows lane + 64 s), taken
+// through the P swaps and updates in registers (shuffles; multipliers from the panel in LDS) and written ONCE, the next
+// flagged column already in flight.  PL: P x (kb + P) doubles of LDS.
+__device__ __forceinline__ double lane_get(double v, int l) {  // v of lane l (l uniform): v_readlane, no LDS round trip
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double lane_set(double v, int l, double x) {  // v with lane l replaced by the uniform x
+  return (int)(threadIdx.x & 63) == l ? x : v;
+}
+template <int P, int SMAX>
+__device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *PL, lds_f64 *pb,
+                                                                lds_i32 *pj, lds_i32 *meta, lds_f64 *ptk) {
+  constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 4;
+  constexpr unsigned long long TMASK = T == 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);
+  const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  lds_i32 *jps = meta, *juk = meta + P, *kms = meta + 2 * P;
+  lds_f64 *rowp = pb + 16, *rowk = pb + 16 + P;  // the two rows of a pivot step that change places
+  int ju = 0;
+  for (int j0 = 0; j0 < n; j0 += P) {
+    const int pw = P < n - j0 ? P : n - j0;
+    long long tp0 = tick();
+    // (1) the panel in registers: thread i holds row j0+i of the P panel columns
+    double v[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) v[k] = (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ? ab[(size_t)(j0 + k) * ld + kv + tid - k] : 0.0;
+    // (2) the panel's P pivot steps: search by DPP + one LDS exchange between the wavefronts, the two rows that change
+    // places go through LDS (everybody needs the new pivot row anyway), the update stays in registers
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < pw) {
+        const int j = j0 + k, km = (kl < n - 1 - j) ? kl : n - 1 - j;
+        const double a = (tid >= k && tid <= k + km) ? fabs(v[k]) : -1.0;
+        const double wb = cfz::wave_reduce<1>(a);
+        const unsigned long long hit = __ballot(a == wb && a >= 0.0);
+        if (lane == 0) { pb[wave] = wb; pj[wave] = hit ? wave * 64 + __ffsll((long long)hit) - 1 : 0x7fffffff; }
+        lds_barrier();
+        double best = pb[0];
+        int p = pj[0];  // row of the pivot, relative to j0: the first of the largest
+        for (int i = 1; i < nw; ++i) if (pb[i] > best) { best = pb[i]; p = pj[i]; }
+        if (tid == 0) ipiv[j] = j0 + p;
+        if (!(best > 0.0)) return 1;
+        const int jp = p - k;
+        const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
+        ju = ju > reach ? ju : reach;
+        if (tid == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
+        if (tid == p) {
+#pragma unroll
+          for (int c = k; c < P; ++c) rowp[c] = v[c];
+        }
+        if (tid == k && jp) {
+#pragma unroll
+          for (int c = k; c < P; ++c) rowk[c] = v[c];
+        }
+        lds_barrier();
+        double u[P];
+#pragma unroll
+        for (int c = k; c < P; ++c) u[c] = rowp[c];
+        if (tid == k) {
+#pragma unroll
+          for (int c = k; c < P; ++c) v[c] = u[c];
+        } else if (tid == p) {
+#pragma unroll
+          for (int c = k; c < P; ++c) v[c] = rowk[c];
+        }
+        if (tid > k && tid <= k + km) {
+          const double inv = 1.0 / u[k];
+          const double l = v[k] * inv;
+          v[k] = l;
+#pragma unroll
+          for (int c = k + 1; c < P; ++c) v[c] = v[c] - l * u[c];
+        }
+      }
+    }
+    // multipliers (and the rest of the panel) to LDS for the trailing columns, the panel itself back to the band
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < pw && tid < RS) PL[k * RS + tid] = v[k];
+      if (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ab[(size_t)(j0 + k) * ld + kv + tid - k] = v[k];
+    }
+    lds_barrier();
+    { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
+    // (3), (4) trailing columns c0 .. ju
+    const int c0 = j0 + pw, ncol = ju - c0 + 1;
+    if (ncol > 0) {
+      const int G = (ncol + CG - 1) / CG, q = lane / T, e = lane % T, ek = e < P ? e : e - P;
+      const int ejp = ek < pw ? jps[ek] : 0;
+      const bool eok = ek < pw && (e < P || ejp != 0);
+      const int er = j0 + (e < P ? ek : ek + ejp);  // absolute row of this lane's test entry
+      // swap / reach / rows of step k in lane k
+      const int mjp = lane < pw ? jps[lane] : 0, mju = lane < pw ? juk[lane] : 0, mkm = lane < pw ? kms[lane] : 0;
+      for (int g0 = wave; g0 < G; g0 += nw * NCH) {
+        double tv[NCH];
+#pragma unroll
+        for (int mm = 0; mm < NCH; ++mm) {
+          const int gi = g0 + mm * nw, c = c0 + gi * CG + q;
+          const bool ok = eok && gi < G && c <= ju && er >= c - kv;
+          tv[mm] = ok ? ab[(size_t)c * ld + kv + er - c] : 0.0;
+        }
+        unsigned long long flag = 0ull;
+#pragma unroll
+        for (int mm = 0; mm < NCH; ++mm) {
+          const unsigned long long mask = __ballot(tv[mm] != 0.0);
+#pragma unroll
+          for (int qq = 0; qq < CG; ++qq) if ((mask >> (qq * T)) & TMASK) flag |= 1ull << (mm * CG + qq);
+        }
+        { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
+        // flagged columns, CB at a time, the next CB in flight
+        double cur[CB][SMAX], nxt[CB][SMAX];
+        int cc[CB], nc[CB];
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+          cc[x] = -1;
+          if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
+#pragma unroll
+          for (int s_ = 0; s_ < SMAX; ++s_) {
+            const int i = lane + 64 * s_, r = j0 + i, c = cc[x];
+            cur[x][s_] = (c >= 0 && i < pw + kl && r < n && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
+          }
+        }
+        while (cc[0] >= 0) {
+#pragma unroll
+          for (int x = 0; x < CB; ++x) {
+            nc[x] = -1;
+            if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; nc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
+#pragma unroll
+            for (int s_ = 0; s_ < SMAX; ++s_) {
+              const int i = lane + 64 * s_, r = j0 + i, c = nc[x];
+              nxt[x][s_] = (c >= 0 && i < pw + kl && r < n && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
+            }
+          }
+          bool dirty[CB];
+#pragma unroll
+          for (int x = 0; x < CB; ++x) dirty[x] = false;
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            if (k < pw) {
+              const int jp = __builtin_amdgcn_readlane(mjp, k), jk = __builtin_amdgcn_readlane(mju, k), km = __builtin_amdgcn_readlane(mkm, k);
+              double Lk[SMAX];  // multipliers of step k for this lane's rows (zero outside k+1 .. k+km)
+#pragma unroll
+              for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; Lk[s_] = (i > k && i <= k + km) ? PL[k * RS + i] : 0.0; }
+#pragma unroll
+              for (int x = 0; x < CB; ++x) {
+                if (cc[x] < 0 || cc[x] > jk) continue;  // beyond the reach of this pivot step: untouched by it
+                double u = lane_get(cur[x][0], k);
+                if (jp) {  // rows j0+k and j0+k+jp change places
+                  const int p = k + jp, ps = p >> 6, pl = p & 63;
+                  double vp = 0.0;
+#pragma unroll
+                  for (int s_ = 0; s_ < SMAX; ++s_) if (ps == s_) { vp = lane_get(cur[x][s_], pl); cur[x][s_] = lane_set(cur[x][s_], pl, u); }
+                  cur[x][0] = lane_set(cur[x][0], k, vp);
+                  dirty[x] = dirty[x] || vp != u;
+                  u = vp;
+                }
+                if (u != 0.0) {
+#pragma unroll
+                  for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = cur[x][s_] - Lk[s_] * u;
+                  dirty[x] = true;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < CB; ++x) {
+            if (cc[x] >= 0 && dirty[x]) {
+              const int c = cc[x];
+#pragma unroll
+              for (int s_ = 0; s_ < SMAX; ++s_) {
+                const int i = lane + 64 * s_, r = j0 + i;
+                if (i < pw + kl && r < n && r >= c - kv) ab[(size_t)c * ld + kv + r - c] = cur[x][s_];
+              }
+            }
+            cc[x] = nc[x];
+#pragma unroll
+            for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = nxt[x][s_];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
+  }
+  return 0;
+}
+
+#ifndef CFZ_PANEL
+#define CFZ_PANEL 8
+#endif
+#ifndef CFZ_NO_PANEL
+#define CFZ_NO_PANEL 0
+#endif
+// lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
+__device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
+  __shared__ double pb[16 + 2 * CFZ_PANEL], tks[3];
+  __shared__ int pj[16], meta[3 * CFZ_PANEL];
+  if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
+  __syncthreads();
+  constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
+  const int fail = B.kb + CFZ_PANEL <= 320
+      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_f64 *)tks)
+      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_f64 *)tks);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
   return fail;
@@ -813,17 +1045,16 @@ __device__ inline void band_substitute_wide(const Band &B, int n, const int *ipi
       for (int c = 0; c < CH; ++c) {
         const int j = j1 - c;
         if (j >= 0) {
-          const double bj = wlds[j] / dg[c];
-          lds_barrier();
-          if (tid == 0) wlds[j] = bj;
+          const double bj = wlds[j] / dg[c];  // row j: final since the barrier of the step before; rewritten (x_j) after this step's
           if (bj != 0.0) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               const int off = tid + nt * t, i = j - kv + off;
               if (off < kv && i >= 0) wlds[i] -= Ur[c][t] * bj;
             }
+            lds_barrier();
+            if (tid == 0) wlds[j] = bj;
           }
-          lds_barrier();
         }
       }
     }
@@ -1018,7 +1249,10 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
-      else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else
+      else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL) {
+        extern __shared__ double wlds[];
+        fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds);
+      } else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
       tk[2] += tick() - ta; ta = tick();
