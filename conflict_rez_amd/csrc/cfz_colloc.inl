@@ -660,16 +660,10 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
   constexpr int NB = 16;
   const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   int ju = 0;
-#ifdef CFZ_WIDE_STATS
-  double s_nq = 0, s_nc = 0, s_nr = 0, s_km = 0, s_sw = 0, s_lastc = 0, s_lastr = 0, s_upd = 0;
-#endif
   for (int j = 0; j < n; ++j) {
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
     glb_f64 *cj = ab + (size_t)j * ld;
     long long tp0 = tick();
-#ifdef CFZ_WIDE_STATS
-    if (tid == 0) { pj[14] = 0; pj[15] = 0; }
-#endif
     // (1) pivot search; thread i keeps row j+i of the pivot column
     const double own = tid <= km ? cj[kv + tid] : 0.0, diag = cj[kv];
     double best = tid <= km ? fabs(own) : -1.0, bv = own;
@@ -700,9 +694,6 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
       if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt + 1, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (l != 0.0) { const int at = base + __popcll(mask & ((1ull << lane) - 1ull)); lrow[at] = tid; lval[at] = l; }
-#ifdef CFZ_WIDE_STATS
-      if (l != 0.0) __hip_atomic_fetch_max(pj + 14, tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
     }
     // (2b) trailing columns: swap rows j and j+jp, u = new row j; the value now in row j+jp goes to LDS as well
     for (int t0 = 0; t0 < nq; t0 += nt) {
@@ -720,17 +711,11 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
       if (lane == 0 && mask) base = __hip_atomic_fetch_add(cnt, (int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       base = __shfl(base, 0);
       if (u != 0.0) cols[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
-#ifdef CFZ_WIDE_STATS
-      if (u != 0.0) __hip_atomic_fetch_max(pj + 15, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
     }
     lds_barrier();
     { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
     // (3) rank-1 update of (nonzero rows) x (nonzero columns)
     const int nc = cnt[0], nr = cnt[1];
-#ifdef CFZ_WIDE_STATS
-    s_nq += nq; s_nc += nc; s_nr += nr; s_km += km; s_sw += jp != 0; s_lastc += pj[15]; s_lastr += pj[14]; s_upd += (double)nc * nr;
-#endif
     for (int r0 = 0; r0 < nr; r0 += 64) {
       const bool mine = r0 + lane < nr;
       const int i = mine ? lrow[r0 + lane] : 0;
@@ -757,11 +742,6 @@ __device__ __attribute__((noinline)) int band_factor_wide2_core(glb_f64 *ab, int
     __syncthreads();
     { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
   }
-#ifdef CFZ_WIDE_STATS
-  if (tid == 0 && blockIdx.x == 0)
-    printf("wide LU n %d kb %d: per pivot nq %.1f nonzero-u %.1f (last at %.1f) km %.1f nonzero-l %.1f (last at %.1f) swaps %.2f update entries %.0f\n", n, kb,
-           s_nq / n, s_nc / n, s_lastc / n, s_km / n, s_nr / n, s_lastr / n, s_sw / n, s_upd / n);
-#endif
   return 0;
 }
 
@@ -780,15 +760,19 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
   return fail;
 }
 
-// The same elimination P pivots at a time (same pivots, same arithmetic per entry as band_factor_wide2, so the factor is the
-// same).  What bounds a batch of joint plans is the number of cache lines a pivot touches (255 plans share the L2s and the
-// MALL): one pivot at a time reads row j of every column within reach (one line per column) and updates ~60 columns.
-// Here (1) the P panel columns are brought into LDS (rows j0 .. j0+P-1+kl), (2) factored there -- pivot search, swap, scale
-// and update of the later panel columns cost LDS round trips only -- and written back; (3) of the trailing columns within
-// reach only the 2 P entries the panel's swaps and pivot rows can touch are gathered (64 / 2P columns per load, all loads of a
-// wavefront in flight together); (4) a column with a nonzero among them is read ONCE (each lane rows lane + 64 s), taken
-// through the P swaps and updates in registers (shuffles; multipliers from the panel in LDS) and written ONCE, the next
-// flagged column already in flight.  PL: P x (kb + P) doubles of LDS.
+// The same elimination P pivots at a time: same pivots, same arithmetic per entry as band_factor_wide2, so the same factor.
+// One pivot at a time costs three dependent global round trips and reads row j of every column within reach (a cache line
+// per column).  Here, per panel:
+// (1) thread i takes row j0+i of the P panel columns into registers;
+// (2) the P pivot steps run there: search by DPP + one LDS exchange between the wavefronts, the two rows of a swap pass
+//     through LDS (everybody needs the new pivot row), scale and update in registers; the panel goes back to the band and
+//     its multipliers to LDS (PL: P x (kb + P) doubles of the kernel's dynamic LDS);
+// (3) of the trailing columns only the 2 P entries the panel's pivot rows and swaps can touch are gathered (64 / 2P columns
+//     per load, all loads of a wavefront in flight together), and only as far right as the row at that position reaches
+//     (ext[], below: a third of the band's reach on the joint plan);
+// (4) a column with a nonzero among them is read ONCE (each lane rows lane + 64 s, only down to the last row a multiplier
+//     or swap of the panel touches), taken through the P swaps and updates in registers (v_readlane; multipliers from PL)
+//     and written ONCE, eight columns in flight per wavefront.
 __device__ __forceinline__ double lane_get(double v, int l) {  // v of lane l (l uniform): v_readlane, no LDS round trip
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -797,23 +781,58 @@ __device__ __forceinline__ double lane_set(double v, int l, double x) {  // v wi
 }
 template <int P, int SMAX>
 __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *PL, lds_f64 *pb,
-                                                                lds_i32 *pj, lds_i32 *meta, lds_f64 *ptk) {
-  constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 4;
+                                                                lds_i32 *pj, lds_i32 *meta, lds_i32 *ext, lds_f64 *ptk) {
+  constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 8, RPW = (P + 7) / 8;  // RPW: needs >= 8 wavefronts
   constexpr unsigned long long TMASK = T == 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);
   const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   lds_i32 *jps = meta, *juk = meta + P, *kms = meta + 2 * P;
   lds_f64 *rowp = pb + 16, *rowk = pb + 16 + P;  // the two rows of a pivot step that change places
+  lds_i32 *extp = meta + 3 * P, *extk = meta + 3 * P + 1, *rtop = meta + 3 * P + 2;
+  // ext[r & 1023]: no entry of the row now at position r lies right of this column.  A row enters with the extent of the
+  // assembled matrix, read off its COLUMN (the matrix is symmetric: put() writes both triangles) SC columns ahead of the
+  // elimination, where no update or swap has reached yet; swaps exchange extents, an updated row inherits the pivot row's.
+  const int SC = 2 * kl + 2 * P;
+  auto scan_rows = [&](int r0, int r1) {
+    for (int r = r0 + wave; r < r1; r += nw) {
+      if (r >= n) break;
+      int last = 0;
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) {
+        const int o = 1 + lane + 64 * s_;
+        const double x = (o <= kl && r + o < n) ? ab[(size_t)r * ld + kv + o] : 0.0;
+        const unsigned long long mk = __ballot(x != 0.0);
+        if (mk) last = 64 * s_ + 64 - __clzll((long long)mk);
+      }
+      if (lane == 0) ext[r & 1023] = r + last;
+    }
+  };
+  scan_rows(0, SC);
+  __syncthreads();
   int ju = 0;
   for (int j0 = 0; j0 < n; j0 += P) {
     const int pw = P < n - j0 ? P : n - j0;
     long long tp0 = tick();
+    int myext = (tid < RS && j0 + tid < n) ? ext[(j0 + tid) & 1023] : 0;
+    if (tid == 0) *rtop = 0;
+    // columns of the rows that come within reach with the next panel: fetched now, looked at after the panel's pivot steps
+    double sx[RPW][SMAX];
+#pragma unroll
+    for (int q_ = 0; q_ < RPW; ++q_) {
+      const int r = j0 + SC + wave + nw * q_;
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) {
+        const int o = 1 + lane + 64 * s_;
+        sx[q_][s_] = (wave + nw * q_ < P && o <= kl && r + o < n) ? ab[(size_t)r * ld + kv + o] : 0.0;
+      }
+    }
     // (1) the panel in registers: thread i holds row j0+i of the P panel columns
     double v[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) v[k] = (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ? ab[(size_t)(j0 + k) * ld + kv + tid - k] : 0.0;
     // (2) the panel's P pivot steps: search by DPP + one LDS exchange between the wavefronts, the two rows that change
     // places go through LDS (everybody needs the new pivot row anyway), the update stays in registers
+    bool touched = tid < pw;
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       if (k < pw) {
@@ -835,21 +854,26 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
         if (tid == p) {
 #pragma unroll
           for (int c = k; c < P; ++c) rowp[c] = v[c];
+          *extp = myext;
         }
         if (tid == k && jp) {
 #pragma unroll
           for (int c = k; c < P; ++c) rowk[c] = v[c];
+          *extk = myext;
         }
         lds_barrier();
+        const int ek_ = *extp;  // extent of the pivot row
         double u[P];
 #pragma unroll
         for (int c = k; c < P; ++c) u[c] = rowp[c];
         if (tid == k) {
 #pragma unroll
           for (int c = k; c < P; ++c) v[c] = u[c];
+          myext = ek_;
         } else if (tid == p) {
 #pragma unroll
           for (int c = k; c < P; ++c) v[c] = rowk[c];
+          myext = *extk;
         }
         if (tid > k && tid <= k + km) {
           const double inv = 1.0 / u[k];
@@ -857,8 +881,14 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
           v[k] = l;
 #pragma unroll
           for (int c = k + 1; c < P; ++c) v[c] = v[c] - l * u[c];
+          if (l != 0.0) { myext = myext > ek_ ? myext : ek_; touched = true; }
         }
+        if (tid == p) touched = true;
       }
+    }
+    {  // rows beyond the last one a multiplier or a swap of this panel touches are left alone by the trailing columns
+      const unsigned long long tm = __ballot(touched);
+      if (lane == 0 && tm) __hip_atomic_fetch_max(rtop, wave * 64 + 63 - __clzll((long long)tm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // multipliers (and the rest of the panel) to LDS for the trailing columns, the panel itself back to the band
 #pragma unroll
@@ -869,12 +899,26 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     lds_barrier();
     { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
     // (3), (4) trailing columns c0 .. ju
-    const int c0 = j0 + pw, ncol = ju - c0 + 1;
+#pragma unroll
+    for (int q_ = 0; q_ < RPW; ++q_) {  // extents of the rows that come within reach with the next panel
+      const int r = j0 + SC + wave + nw * q_;
+      int last = 0;
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) {
+        const unsigned long long mk = __ballot(sx[q_][s_] != 0.0);
+        if (mk) last = 64 * s_ + 64 - __clzll((long long)mk);
+      }
+      if (lane == 0 && wave + nw * q_ < P && r < n) ext[r & 1023] = r + last;
+    }
+    const int c0 = j0 + pw, q = lane / T, e = lane % T, ek = e < P ? e : e - P;
+    const int ejp = ek < pw ? jps[ek] : 0;
+    const bool eok = ek < pw && (e < P || ejp != 0);
+    const int er = j0 + (e < P ? ek : ek + ejp);  // absolute row of this lane's test entry
+    const int eext = eok ? ext[er & 1023] : -1;   // ... and where that row ended when the panel began
+    const int cend = (int)cfz::wave_reduce<1>((double)eext), cmax = cend < ju ? cend : ju, ncol = cmax - c0 + 1;
+    const int rt = *rtop;
     if (ncol > 0) {
-      const int G = (ncol + CG - 1) / CG, q = lane / T, e = lane % T, ek = e < P ? e : e - P;
-      const int ejp = ek < pw ? jps[ek] : 0;
-      const bool eok = ek < pw && (e < P || ejp != 0);
-      const int er = j0 + (e < P ? ek : ek + ejp);  // absolute row of this lane's test entry
+      const int G = (ncol + CG - 1) / CG;
       // swap / reach / rows of step k in lane k
       const int mjp = lane < pw ? jps[lane] : 0, mju = lane < pw ? juk[lane] : 0, mkm = lane < pw ? kms[lane] : 0;
       for (int g0 = wave; g0 < G; g0 += nw * NCH) {
@@ -882,7 +926,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #pragma unroll
         for (int mm = 0; mm < NCH; ++mm) {
           const int gi = g0 + mm * nw, c = c0 + gi * CG + q;
-          const bool ok = eok && gi < G && c <= ju && er >= c - kv;
+          const bool ok = gi < G && c <= eext && er >= c - kv;
           tv[mm] = ok ? ab[(size_t)c * ld + kv + er - c] : 0.0;
         }
         unsigned long long flag = 0ull;
@@ -893,28 +937,19 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
           for (int qq = 0; qq < CG; ++qq) if ((mask >> (qq * T)) & TMASK) flag |= 1ull << (mm * CG + qq);
         }
         { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
-        // flagged columns, CB at a time, the next CB in flight
-        double cur[CB][SMAX], nxt[CB][SMAX];
-        int cc[CB], nc[CB];
-#pragma unroll
-        for (int x = 0; x < CB; ++x) {
-          cc[x] = -1;
-          if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
-#pragma unroll
-          for (int s_ = 0; s_ < SMAX; ++s_) {
-            const int i = lane + 64 * s_, r = j0 + i, c = cc[x];
-            cur[x][s_] = (c >= 0 && i < pw + kl && r < n && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
-          }
-        }
-        while (cc[0] >= 0) {
+        // flagged columns, CB at a time: all their loads in flight together (a wavefront usually gets all its columns of a
+        // panel into one batch, so that a panel costs it one round trip for the test and one for the columns)
+        while (flag) {
+          double cur[CB][SMAX];
+          int cc[CB];
 #pragma unroll
           for (int x = 0; x < CB; ++x) {
-            nc[x] = -1;
-            if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; nc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
+            cc[x] = -1;
+            if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
 #pragma unroll
             for (int s_ = 0; s_ < SMAX; ++s_) {
-              const int i = lane + 64 * s_, r = j0 + i, c = nc[x];
-              nxt[x][s_] = (c >= 0 && i < pw + kl && r < n && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
+              const int i = lane + 64 * s_, r = j0 + i, c = cc[x];
+              cur[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
             }
           }
           bool dirty[CB];
@@ -955,24 +990,23 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #pragma unroll
               for (int s_ = 0; s_ < SMAX; ++s_) {
                 const int i = lane + 64 * s_, r = j0 + i;
-                if (i < pw + kl && r < n && r >= c - kv) ab[(size_t)c * ld + kv + r - c] = cur[x][s_];
+                if (i <= rt && r >= c - kv) ab[(size_t)c * ld + kv + r - c] = cur[x][s_];
               }
             }
-            cc[x] = nc[x];
-#pragma unroll
-            for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = nxt[x][s_];
           }
         }
       }
     }
     __syncthreads();
+    if (tid >= pw && tid < RS && j0 + tid < n) ext[(j0 + tid) & 1023] = myext;
+    lds_barrier();
     { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
   }
   return 0;
 }
 
 #ifndef CFZ_PANEL
-#define CFZ_PANEL 8
+#define CFZ_PANEL 16  // pivots per panel (8: 7 % slower on the four-vehicle plan, 32: registers)
 #endif
 #ifndef CFZ_NO_PANEL
 #define CFZ_NO_PANEL 0
@@ -980,13 +1014,13 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 // lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
 __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
   __shared__ double pb[16 + 2 * CFZ_PANEL], tks[3];
-  __shared__ int pj[16], meta[3 * CFZ_PANEL];
+  __shared__ int pj[16], meta[3 * CFZ_PANEL + 4], ext[1024];
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
   const int fail = B.kb + CFZ_PANEL <= 320
-      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_f64 *)tks)
-      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_f64 *)tks);
+      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
+      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
   return fail;
@@ -1249,7 +1283,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
-      else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL) {
+      else if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL) {
         extern __shared__ double wlds[];
         fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds);
       } else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else

@@ -341,7 +341,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     if (cost) cost[b] = od[(size_t)cfzc::kOutD * b];
     if (std::getenv("CFZ_COLLOC_PROFILE")) {  // milliseconds per phase (100 MHz device clock)
       const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
-      fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: pivot+swap %.2f update %.2f refill %.2f)\n",
+      fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: panel / pivot search %.2f test / swap %.2f trailing columns / update %.2f)\n",
               b, specs[b].V, kbs[b], oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
     }
   }
