@@ -1096,6 +1096,114 @@ __device__ inline void band_substitute_wide(const Band &B, int n, const int *ipi
     __syncthreads();
   }
 }
+// Both right-hand sides in one sweep, the rows a chunk of CH pivots works on in REGISTERS (thread i = row j0+i; the backward
+// sweep's window is kv + CH rows, two per thread): a pivot step is one LDS write by the thread that owns the pivot row, one
+// barrier and one broadcast read, instead of a read-modify-write of the whole window in LDS and two barriers, per right-hand
+// side.  Between chunks the rows move CH threads along through a staging array; the right-hand sides themselves stay in
+// global memory (CH rows enter and leave per chunk).  Same operations in the same order as band_substitute.
+// Needs blockDim.x >= kb + CH and 2 blockDim.x >= 2 kb + CH.
+template <int CH>
+__device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f64 *ab, int kb, int ld, int n, const glb_i32 *ipiv, glb_f64 *b1,
+                                                                    glb_f64 *b2, lds_f64 *slot, lds_f64 *stage) {
+  const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x;
+  {  // L y = P b
+    const int RS = kl + CH;
+    double y1 = (tid < RS && tid < n) ? b1[tid] : 0.0, y2 = (tid < RS && tid < n) ? b2[tid] : 0.0;
+    for (int j0 = 0; j0 < n; j0 += CH) {
+      double Lc[CH]; int pv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j0 + c, km = j < n ? ((kl < n - 1 - j) ? kl : n - 1 - j) : 0, o = tid - c;  // row j0+tid = j + o
+        Lc[c] = (o >= 1 && o <= km) ? ab[(size_t)j * ld + kv + o] : 0.0;
+        pv[c] = j < n ? ipiv[j] : j;
+      }
+      const int rn = j0 + CH + tid;  // this thread's row in the next chunk; the last CH threads fetch theirs now
+      double f1 = 0.0, f2 = 0.0;
+      if (tid >= RS - CH && tid < RS && rn < n) { f1 = b1[rn]; f2 = b2[rn]; }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (j0 + c < n) {
+          const int rel = pv[c] - j0;
+          if (tid == rel) { slot[4 * c] = y1; slot[4 * c + 1] = y2; }
+          if (tid == c && rel != c) { slot[4 * c + 2] = y1; slot[4 * c + 3] = y2; }
+          lds_barrier();
+          const double a1 = slot[4 * c], a2 = slot[4 * c + 1];
+          if (tid == c) { y1 = a1; y2 = a2; }
+          else if (tid == rel) { y1 = slot[4 * c + 2]; y2 = slot[4 * c + 3]; }
+          y1 = y1 - Lc[c] * a1; y2 = y2 - Lc[c] * a2;  // Lc is zero outside rows j+1 .. j+km
+        }
+      }
+      if (tid < CH && j0 + tid < n) { b1[j0 + tid] = y1; b2[j0 + tid] = y2; }
+      if (tid < RS) { stage[tid] = y1; stage[RS + tid] = y2; }
+      lds_barrier();
+      if (tid < RS - CH) { y1 = stage[tid + CH]; y2 = stage[RS + tid + CH]; } else { y1 = f1; y2 = f2; }
+    }
+  }
+  __syncthreads();  // y is read back from global memory by other threads
+  {  // U x = y: chunk columns j1, j1-1, ..; window position i = row - lo, lo = j1 - CH + 1 - kv; positions tid and tid + nt
+    const int W = kv + CH;
+    double z1[2], z2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + nt * t, r = n - 1 - CH + 1 - kv + i;
+      z1[t] = (i < W && r >= 0 && r < n) ? b1[r] : 0.0; z2[t] = (i < W && r >= 0 && r < n) ? b2[r] : 0.0;
+    }
+    for (int j1 = n - 1; j1 >= 0; j1 -= CH) {
+      const int lo = j1 - CH + 1 - kv;
+      double Uc[CH][2], dg[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j1 - c;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int i = tid + nt * t, r = lo + i;
+          Uc[c][t] = (j >= 0 && i < W && r >= 0 && r >= j - kv && r < j) ? ab[(size_t)j * ld + kv + r - j] : 0.0;
+        }
+        dg[c] = j >= 0 ? ab[(size_t)j * ld + kv] : 1.0;
+      }
+      const int rf = lo - CH + tid;  // the rows that enter with the next chunk: positions 0 .. CH-1 of its window
+      double g1 = 0.0, g2 = 0.0;
+      if (tid < CH && rf >= 0) { g1 = b1[rf]; g2 = b2[rf]; }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j1 - c;
+        if (j >= 0) {
+          const int ij = kv + CH - 1 - c, ot = ij >= nt ? 1 : 0, otid = ij - nt * ot;  // who owns row j
+          if (tid == otid) {
+            const double x1 = (ot ? z1[1] : z1[0]) / dg[c], x2 = (ot ? z2[1] : z2[0]) / dg[c];
+            slot[2 * c] = x1; slot[2 * c + 1] = x2;
+            if (ot) { z1[1] = x1; z2[1] = x2; } else { z1[0] = x1; z2[0] = x2; }
+          }
+          lds_barrier();
+          const double a1 = slot[2 * c], a2 = slot[2 * c + 1];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) { z1[t] = z1[t] - Uc[c][t] * a1; z2[t] = z2[t] - Uc[c][t] * a2; }  // Uc is zero from row j on
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + nt * t, r = lo + i;
+        if (i >= kv && i < W && r >= 0) { b1[r] = z1[t]; b2[r] = z2[t]; }  // the chunk's own rows: final
+        if (i < W) { stage[i] = z1[t]; stage[W + i] = z2[t]; }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + nt * t;
+        if (i >= CH && i < W) { z1[t] = stage[i - CH]; z2[t] = stage[W + i - CH]; }
+        else if (i < CH) { z1[t] = g1; z2[t] = g2; }
+      }
+      lds_barrier();
+    }
+  }
+  __syncthreads();
+}
+
+__device__ inline void band_substitute_regs(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+  constexpr int CH = 16;
+  __shared__ double slot[4 * CH], stage[2 * (2 * kWideMaxKb + CH)];
+  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage);
+}
 #endif
 
 CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b, double *b2) {
@@ -1293,6 +1401,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
+        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_doubles) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
