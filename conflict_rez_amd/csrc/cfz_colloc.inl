@@ -787,8 +787,8 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
   const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   lds_i32 *jps = meta, *juk = meta + P, *kms = meta + 2 * P;
-  lds_f64 *rowp = pb + 16, *rowk = pb + 16 + P;  // the two rows of a pivot step that change places
-  lds_i32 *extp = meta + 3 * P, *extk = meta + 3 * P + 1, *rtop = meta + 3 * P + 2;
+  lds_f64 *cand = pb + 16;  // [2][9][P]: per parity, the candidate row of each wavefront and row k
+  lds_i32 *cint = pj, *rtop = meta + 3 * P;
   // ext[r & 1023]: no entry of the row now at position r lies right of this column.  A row enters with the extent of the
   // assembled matrix, read off its COLUMN (the matrix is symmetric: put() writes both triangles) SC columns ahead of the
   // elimination, where no update or swap has reached yet; swaps exchange extents, an updated row inherits the pivot row's.
@@ -833,52 +833,67 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     // (2) the panel's P pivot steps: search by DPP + one LDS exchange between the wavefronts, the two rows that change
     // places go through LDS (everybody needs the new pivot row anyway), the update stays in registers
     bool touched = tid < pw;
+    double vt[P];  // vt[c], c < k: the multipliers of step c in the row order after ALL swaps so far (the band keeps them unswapped)
+#pragma unroll
+    for (int k = 0; k < P; ++k) vt[k] = 0.0;
+#ifdef CFZ_PANEL_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
+#endif
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       if (k < pw) {
         const int j = j0 + k, km = (kl < n - 1 - j) ? kl : n - 1 - j;
+        // one barrier per step: every wavefront posts its candidate (largest entry, its row of the panel, its extent) and row k
+        // posts itself, then everybody picks the winner; the buffers alternate with the parity of k
+        lds_f64 *cd = cand + (k & 1) * 9 * P, *pbk = pb + (k & 1) * 8;
+        lds_i32 *ci = cint + (k & 1) * 32;
         const double a = (tid >= k && tid <= k + km) ? fabs(v[k]) : -1.0;
         const double wb = cfz::wave_reduce<1>(a);
         const unsigned long long hit = __ballot(a == wb && a >= 0.0);
-        if (lane == 0) { pb[wave] = wb; pj[wave] = hit ? wave * 64 + __ffsll((long long)hit) - 1 : 0x7fffffff; }
+        const int fl = hit ? __ffsll((long long)hit) - 1 : -1;
+        if (lane == fl) {
+#pragma unroll
+          for (int c = 0; c < P; ++c) cd[wave * P + c] = c < k ? vt[c] : v[c];
+          ci[8 + wave] = myext;
+        }
+        if (lane == 0) { pbk[wave] = wb; ci[wave] = hit ? wave * 64 + fl : 0x7fffffff; }
+        if (tid == k) {
+#pragma unroll
+          for (int c = 0; c < P; ++c) cd[8 * P + c] = c < k ? vt[c] : v[c];
+          ci[16] = myext;
+        }
         lds_barrier();
-        double best = pb[0];
-        int p = pj[0];  // row of the pivot, relative to j0: the first of the largest
-        for (int i = 1; i < nw; ++i) if (pb[i] > best) { best = pb[i]; p = pj[i]; }
+        double best = pbk[0];
+        int p = ci[0], ws = 0;  // row of the pivot, relative to j0: the first of the largest; the wavefront it is in
+        for (int i = 1; i < nw; ++i) if (pbk[i] > best) { best = pbk[i]; p = ci[i]; ws = i; }
         if (tid == 0) ipiv[j] = j0 + p;
         if (!(best > 0.0)) return 1;
         const int jp = p - k;
         const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
         ju = ju > reach ? ju : reach;
         if (tid == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
-        if (tid == p) {
-#pragma unroll
-          for (int c = k; c < P; ++c) rowp[c] = v[c];
-          *extp = myext;
-        }
-        if (tid == k && jp) {
-#pragma unroll
-          for (int c = k; c < P; ++c) rowk[c] = v[c];
-          *extk = myext;
-        }
-        lds_barrier();
-        const int ek_ = *extp;  // extent of the pivot row
+        const int ek_ = ci[8 + ws];  // extent of the pivot row
         double u[P];
 #pragma unroll
-        for (int c = k; c < P; ++c) u[c] = rowp[c];
+        for (int c = k; c < P; ++c) u[c] = cd[ws * P + c];
         if (tid == k) {
 #pragma unroll
           for (int c = k; c < P; ++c) v[c] = u[c];
+#pragma unroll
+          for (int c = 0; c < k; ++c) vt[c] = cd[ws * P + c];
           myext = ek_;
         } else if (tid == p) {
 #pragma unroll
-          for (int c = k; c < P; ++c) v[c] = rowk[c];
-          myext = *extk;
+          for (int c = k; c < P; ++c) v[c] = cd[8 * P + c];
+#pragma unroll
+          for (int c = 0; c < k; ++c) vt[c] = cd[8 * P + c];
+          myext = ci[16];
         }
         if (tid > k && tid <= k + km) {
           const double inv = 1.0 / u[k];
           const double l = v[k] * inv;
-          v[k] = l;
+          v[k] = l; vt[k] = l;
 #pragma unroll
           for (int c = k + 1; c < P; ++c) v[c] = v[c] - l * u[c];
           if (l != 0.0) { myext = myext > ek_ ? myext : ek_; touched = true; }
@@ -886,6 +901,9 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
         if (tid == p) touched = true;
       }
     }
+#ifdef CFZ_PANEL_TIMING
+    { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
+#endif
     {  // rows beyond the last one a multiplier or a swap of this panel touches are left alone by the trailing columns
       const unsigned long long tm = __ballot(touched);
       if (lane == 0 && tm) __hip_atomic_fetch_max(rtop, wave * 64 + 63 - __clzll((long long)tm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -893,11 +911,15 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     // multipliers (and the rest of the panel) to LDS for the trailing columns, the panel itself back to the band
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-      if (k < pw && tid < RS) PL[k * RS + tid] = v[k];
+      if (k < pw && tid < RS) PL[k * RS + tid] = tid > k ? vt[k] : 0.0;  // multipliers in final row order, zero from the pivot row up
       if (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ab[(size_t)(j0 + k) * ld + kv + tid - k] = v[k];
     }
     lds_barrier();
+#ifdef CFZ_PANEL_TIMING
+    { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); tp0 = t1; }
+#else
     { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
+#endif
     // (3), (4) trailing columns c0 .. ju
 #pragma unroll
     for (int q_ = 0; q_ < RPW; ++q_) {  // extents of the rows that come within reach with the next panel
@@ -919,8 +941,23 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     const int rt = *rtop;
     if (ncol > 0) {
       const int G = (ncol + CG - 1) / CG;
-      // swap / reach / rows of step k in lane k
-      const int mjp = lane < pw ? jps[lane] : 0, mju = lane < pw ? juk[lane] : 0, mkm = lane < pw ? kms[lane] : 0;
+      // where the content of each row comes from once all swaps of the panel are done (the same for every column): the
+      // identity taken through the P swaps, position i = lane + 64 s
+      const int mjp = lane < pw ? jps[lane] : 0;
+      int src[SMAX];
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) src[s_] = lane + 64 * s_;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int jp = __builtin_amdgcn_readlane(mjp, k);
+        if (k < pw && jp) {
+          const int pp = k + jp, ps = pp >> 6, pl = pp & 63, sk = __builtin_amdgcn_readlane(src[0], k);
+#pragma unroll
+          for (int s_ = 0; s_ < SMAX; ++s_) {
+            if (ps == s_) { const int sp_ = __builtin_amdgcn_readlane(src[s_], pl); if (lane == pl) src[s_] = sk; if (lane == k) src[0] = sp_; }
+          }
+        }
+      }
       for (int g0 = wave; g0 < G; g0 += nw * NCH) {
         double tv[NCH];
 #pragma unroll
@@ -936,7 +973,9 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #pragma unroll
           for (int qq = 0; qq < CG; ++qq) if ((mask >> (qq * T)) & TMASK) flag |= 1ull << (mm * CG + qq);
         }
+#ifndef CFZ_PANEL_TIMING
         { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
+#endif
         // flagged columns, CB at a time: all their loads in flight together (a wavefront usually gets all its columns of a
         // panel into one batch, so that a panel costs it one round trip for the test and one for the columns)
         while (flag) {
@@ -948,44 +987,29 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
             if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
 #pragma unroll
             for (int s_ = 0; s_ < SMAX; ++s_) {
-              const int i = lane + 64 * s_, r = j0 + i, c = cc[x];
+              const int i = lane + 64 * s_, r = j0 + src[s_], c = cc[x];  // read through the panel's row permutation
               cur[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
             }
           }
-          bool dirty[CB];
-#pragma unroll
-          for (int x = 0; x < CB; ++x) dirty[x] = false;
 #pragma unroll
           for (int k = 0; k < P; ++k) {
             if (k < pw) {
-              const int jp = __builtin_amdgcn_readlane(mjp, k), jk = __builtin_amdgcn_readlane(mju, k), km = __builtin_amdgcn_readlane(mkm, k);
-              double Lk[SMAX];  // multipliers of step k for this lane's rows (zero outside k+1 .. k+km)
+              double Lk[SMAX];  // multipliers of step k for this lane's rows, in the row order after all swaps
 #pragma unroll
-              for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; Lk[s_] = (i > k && i <= k + km) ? PL[k * RS + i] : 0.0; }
+              for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; Lk[s_] = i < RS ? PL[k * RS + i] : 0.0; }
 #pragma unroll
               for (int x = 0; x < CB; ++x) {
-                if (cc[x] < 0 || cc[x] > jk) continue;  // beyond the reach of this pivot step: untouched by it
-                double u = lane_get(cur[x][0], k);
-                if (jp) {  // rows j0+k and j0+k+jp change places
-                  const int p = k + jp, ps = p >> 6, pl = p & 63;
-                  double vp = 0.0;
-#pragma unroll
-                  for (int s_ = 0; s_ < SMAX; ++s_) if (ps == s_) { vp = lane_get(cur[x][s_], pl); cur[x][s_] = lane_set(cur[x][s_], pl, u); }
-                  cur[x][0] = lane_set(cur[x][0], k, vp);
-                  dirty[x] = dirty[x] || vp != u;
-                  u = vp;
-                }
-                if (u != 0.0) {
+                const double u = lane_get(cur[x][0], k);
+                if (cc[x] >= 0 && u != 0.0) {
 #pragma unroll
                   for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = cur[x][s_] - Lk[s_] * u;
-                  dirty[x] = true;
                 }
               }
             }
           }
 #pragma unroll
           for (int x = 0; x < CB; ++x) {
-            if (cc[x] >= 0 && dirty[x]) {
+            if (cc[x] >= 0) {
               const int c = cc[x];
 #pragma unroll
               for (int s_ = 0; s_ < SMAX; ++s_) {
@@ -1000,7 +1024,9 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     __syncthreads();
     if (tid >= pw && tid < RS && j0 + tid < n) ext[(j0 + tid) & 1023] = myext;
     lds_barrier();
+#ifndef CFZ_PANEL_TIMING
     { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
+#endif
   }
   return 0;
 }
@@ -1013,8 +1039,8 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #endif
 // lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
 __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
-  __shared__ double pb[16 + 2 * CFZ_PANEL], tks[3];
-  __shared__ int pj[16], meta[3 * CFZ_PANEL + 4], ext[1024];
+  __shared__ double pb[16 + 18 * CFZ_PANEL], tks[3];
+  __shared__ int pj[64], meta[3 * CFZ_PANEL + 4], ext[1024];
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
