@@ -787,7 +787,8 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
   const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   lds_i32 *jps = meta, *juk = meta + P, *kms = meta + 2 * P;
-  lds_f64 *cand = pb + 16;  // [2][9][P]: per parity, the candidate row of each wavefront and row k
+  lds_f64 *cand = pb + 16;  // [2][9][P + 1]: per parity, the candidate row of each wavefront (+ 1 / its entry) and row k
+  const int nwa = (RS + 63) >> 6;  // wavefronts that hold rows of a panel
   lds_i32 *cint = pj, *rtop = meta + 3 * P;
   // ext[r & 1023]: no entry of the row now at position r lies right of this column.  A row enters with the extent of the
   // assembled matrix, read off its COLUMN (the matrix is symmetric: put() writes both triangles) SC columns ahead of the
@@ -833,93 +834,80 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     // (2) the panel's P pivot steps: search by DPP + one LDS exchange between the wavefronts, the two rows that change
     // places go through LDS (everybody needs the new pivot row anyway), the update stays in registers
     bool touched = tid < pw;
-    double vt[P];  // vt[c], c < k: the multipliers of step c in the row order after ALL swaps so far (the band keeps them unswapped)
-#pragma unroll
-    for (int k = 0; k < P; ++k) vt[k] = 0.0;
-#ifdef CFZ_PANEL_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
-#endif
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-      if (k < pw) {
-        const int j = j0 + k, km = (kl < n - 1 - j) ? kl : n - 1 - j;
-        // one barrier per step: every wavefront posts its candidate (largest entry, its row of the panel, its extent) and row k
-        // posts itself, then everybody picks the winner; the buffers alternate with the parity of k
-        lds_f64 *cd = cand + (k & 1) * 9 * P, *pbk = pb + (k & 1) * 8;
-        lds_i32 *ci = cint + (k & 1) * 32;
-        const double a = (tid >= k && tid <= k + km) ? fabs(v[k]) : -1.0;
+    // A rolled loop (unrolled, this function is larger than the instruction cache): v[] is shifted down after every step, so
+    // that v[0] is always the column being eliminated, and what is final leaves the registers at once -- the pivot row (U) and
+    // the multipliers to the band, the multipliers also to PL, where later swaps of the panel are applied to them (the
+    // trailing columns want them in the row order after all swaps; the band keeps them unswapped for the substitution).
+#pragma nounroll
+    for (int k = 0; k < pw; ++k) {
+      const int j = j0 + k, km = (kl < n - 1 - j) ? kl : n - 1 - j;
+      // one barrier per step: every wavefront posts its candidate (largest entry, its row of the panel, the reciprocal, its
+      // extent) and row k posts itself, then everybody picks the winner; the buffers alternate with the parity of k
+      lds_f64 *cd = cand + (k & 1) * 9 * (P + 1), *pbk = pb + (k & 1) * 8;
+      lds_i32 *ci = cint + (k & 1) * 32;
+      if (wave < nwa) {  // wavefronts without rows of the panel only keep the barriers company
+        const double a = (tid >= k && tid <= k + km) ? fabs(v[0]) : -1.0;
         const double wb = cfz::wave_reduce<1>(a);
         const unsigned long long hit = __ballot(a == wb && a >= 0.0);
         const int fl = hit ? __ffsll((long long)hit) - 1 : -1;
         if (lane == fl) {
 #pragma unroll
-          for (int c = 0; c < P; ++c) cd[wave * P + c] = c < k ? vt[c] : v[c];
+          for (int c = 0; c < P; ++c) cd[wave * (P + 1) + c] = v[c];
+          cd[wave * (P + 1) + P] = 1.0 / v[0];
           ci[8 + wave] = myext;
         }
         if (lane == 0) { pbk[wave] = wb; ci[wave] = hit ? wave * 64 + fl : 0x7fffffff; }
         if (tid == k) {
 #pragma unroll
-          for (int c = 0; c < P; ++c) cd[8 * P + c] = c < k ? vt[c] : v[c];
+          for (int c = 0; c < P; ++c) cd[8 * (P + 1) + c] = v[c];
           ci[16] = myext;
         }
-        lds_barrier();
-        double best = pbk[0];
-        int p = ci[0], ws = 0;  // row of the pivot, relative to j0: the first of the largest; the wavefront it is in
-        for (int i = 1; i < nw; ++i) if (pbk[i] > best) { best = pbk[i]; p = ci[i]; ws = i; }
-        if (tid == 0) ipiv[j] = j0 + p;
-        if (!(best > 0.0)) return 1;
-        const int jp = p - k;
-        const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
-        ju = ju > reach ? ju : reach;
-        if (tid == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
-        const int ek_ = ci[8 + ws];  // extent of the pivot row
-        double u[P];
-#pragma unroll
-        for (int c = k; c < P; ++c) u[c] = cd[ws * P + c];
-        if (tid == k) {
-#pragma unroll
-          for (int c = k; c < P; ++c) v[c] = u[c];
-#pragma unroll
-          for (int c = 0; c < k; ++c) vt[c] = cd[ws * P + c];
-          myext = ek_;
-        } else if (tid == p) {
-#pragma unroll
-          for (int c = k; c < P; ++c) v[c] = cd[8 * P + c];
-#pragma unroll
-          for (int c = 0; c < k; ++c) vt[c] = cd[8 * P + c];
-          myext = ci[16];
-        }
-        if (tid > k && tid <= k + km) {
-          const double inv = 1.0 / u[k];
-          const double l = v[k] * inv;
-          v[k] = l; vt[k] = l;
-#pragma unroll
-          for (int c = k + 1; c < P; ++c) v[c] = v[c] - l * u[c];
-          if (l != 0.0) { myext = myext > ek_ ? myext : ek_; touched = true; }
-        }
-        if (tid == p) touched = true;
       }
+      lds_barrier();
+      double best = pbk[0];
+      int p = ci[0], ws = 0;  // row of the pivot, relative to j0: the first of the largest; the wavefront it is in
+      for (int i = 1; i < nwa; ++i) if (pbk[i] > best) { best = pbk[i]; p = ci[i]; ws = i; }
+      if (tid == 0) ipiv[j] = j0 + p;
+      if (!(best > 0.0)) return 1;
+      const int jp = p - k;
+      const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
+      ju = ju > reach ? ju : reach;
+      if (tid == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
+      if (wave >= nwa) continue;
+      const int ek_ = ci[8 + ws];  // extent of the pivot row
+      double u[P];
+#pragma unroll
+      for (int c = 0; c < P; ++c) u[c] = cd[ws * (P + 1) + c];
+      // the pivot row is final: entry (j, j + t) by thread t
+      if (tid < pw - k) ab[(size_t)(j + tid) * ld + kv - tid] = cd[ws * (P + 1) + tid];
+      // multipliers of the earlier steps follow the swap (thread c: column c of PL)
+      if (tid < k && jp) { const double t_ = PL[tid * RS + k]; PL[tid * RS + k] = PL[tid * RS + p]; PL[tid * RS + p] = t_; }
+      if (tid == k) myext = ek_;
+      else if (tid == p) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) v[c] = cd[8 * (P + 1) + c];
+        myext = ci[16];
+      }
+      double l = 0.0;
+      if (tid > k && tid <= k + km) {
+        l = v[0] * cd[ws * (P + 1) + P];
+        ab[(size_t)j * ld + kv + tid - k] = l;
+#pragma unroll
+        for (int c = 1; c < P; ++c) v[c] = v[c] - l * u[c];
+        if (l != 0.0) { myext = myext > ek_ ? myext : ek_; touched = true; }
+      }
+      if (tid < RS) PL[k * RS + tid] = l;
+      if (tid == p) touched = true;
+#pragma unroll
+      for (int c = 0; c < P - 1; ++c) v[c] = v[c + 1];
+      v[P - 1] = 0.0;
     }
-#ifdef CFZ_PANEL_TIMING
-    { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
-#endif
     {  // rows beyond the last one a multiplier or a swap of this panel touches are left alone by the trailing columns
       const unsigned long long tm = __ballot(touched);
       if (lane == 0 && tm) __hip_atomic_fetch_max(rtop, wave * 64 + 63 - __clzll((long long)tm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // multipliers (and the rest of the panel) to LDS for the trailing columns, the panel itself back to the band
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-      if (k < pw && tid < RS) PL[k * RS + tid] = tid > k ? vt[k] : 0.0;  // multipliers in final row order, zero from the pivot row up
-      if (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ab[(size_t)(j0 + k) * ld + kv + tid - k] = v[k];
-    }
     lds_barrier();
-#ifdef CFZ_PANEL_TIMING
-    { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); tp0 = t1; }
-#else
     { const long long t1 = tick(); if (tid == 0) ptk[0] += (double)(t1 - tp0); tp0 = t1; }
-#endif
     // (3), (4) trailing columns c0 .. ju
 #pragma unroll
     for (int q_ = 0; q_ < RPW; ++q_) {  // extents of the rows that come within reach with the next panel
@@ -947,10 +935,10 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
       int src[SMAX];
 #pragma unroll
       for (int s_ = 0; s_ < SMAX; ++s_) src[s_] = lane + 64 * s_;
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
+#pragma nounroll
+      for (int k = 0; k < pw; ++k) {  // (rolled: the unrolled body of this function does not fit the instruction cache)
         const int jp = __builtin_amdgcn_readlane(mjp, k);
-        if (k < pw && jp) {
+        if (jp) {
           const int pp = k + jp, ps = pp >> 6, pl = pp & 63, sk = __builtin_amdgcn_readlane(src[0], k);
 #pragma unroll
           for (int s_ = 0; s_ < SMAX; ++s_) {
@@ -973,9 +961,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #pragma unroll
           for (int qq = 0; qq < CG; ++qq) if ((mask >> (qq * T)) & TMASK) flag |= 1ull << (mm * CG + qq);
         }
-#ifndef CFZ_PANEL_TIMING
         { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
-#endif
         // flagged columns, CB at a time: all their loads in flight together (a wavefront usually gets all its columns of a
         // panel into one batch, so that a panel costs it one round trip for the test and one for the columns)
         while (flag) {
@@ -991,19 +977,17 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
               cur[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
             }
           }
+#pragma nounroll
+          for (int k = 0; k < pw; ++k) {
+            double Lk[SMAX];  // multipliers of step k for this lane's rows, in the row order after all swaps
 #pragma unroll
-          for (int k = 0; k < P; ++k) {
-            if (k < pw) {
-              double Lk[SMAX];  // multipliers of step k for this lane's rows, in the row order after all swaps
+            for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; Lk[s_] = i < RS ? PL[k * RS + i] : 0.0; }
 #pragma unroll
-              for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; Lk[s_] = i < RS ? PL[k * RS + i] : 0.0; }
+            for (int x = 0; x < CB; ++x) {
+              const double u = lane_get(cur[x][0], k);
+              if (cc[x] >= 0 && u != 0.0) {
 #pragma unroll
-              for (int x = 0; x < CB; ++x) {
-                const double u = lane_get(cur[x][0], k);
-                if (cc[x] >= 0 && u != 0.0) {
-#pragma unroll
-                  for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = cur[x][s_] - Lk[s_] * u;
-                }
+                for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = cur[x][s_] - Lk[s_] * u;
               }
             }
           }
@@ -1024,9 +1008,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     __syncthreads();
     if (tid >= pw && tid < RS && j0 + tid < n) ext[(j0 + tid) & 1023] = myext;
     lds_barrier();
-#ifndef CFZ_PANEL_TIMING
     { const long long t1 = tick(); if (tid == 0) ptk[2] += (double)(t1 - tp0); }
-#endif
   }
   return 0;
 }
@@ -1039,7 +1021,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #endif
 // lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
 __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
-  __shared__ double pb[16 + 18 * CFZ_PANEL], tks[3];
+  __shared__ double pb[16 + 18 * (CFZ_PANEL + 1)], tks[3];
   __shared__ int pj[64], meta[3 * CFZ_PANEL + 4], ext[1024];
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
