@@ -929,6 +929,16 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     const int rt = *rtop;
     if (ncol > 0) {
       const int G = (ncol + CG - 1) / CG;
+      double tv[NCH];
+      auto gather = [&](int g0) {  // the test entries of NCH groups of columns, all in flight together
+#pragma unroll
+        for (int mm = 0; mm < NCH; ++mm) {
+          const int gi = g0 + mm * nw, c = c0 + gi * CG + q;
+          const bool ok = gi < G && c <= eext && er >= c - kv;
+          tv[mm] = ok ? ab[(size_t)c * ld + kv + er - c] : 0.0;
+        }
+      };
+      gather(wave);  // ... while the row permutation is built
       // where the content of each row comes from once all swaps of the panel are done (the same for every column): the
       // identity taken through the P swaps, position i = lane + 64 s
       const int mjp = lane < pw ? jps[lane] : 0;
@@ -947,13 +957,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
         }
       }
       for (int g0 = wave; g0 < G; g0 += nw * NCH) {
-        double tv[NCH];
-#pragma unroll
-        for (int mm = 0; mm < NCH; ++mm) {
-          const int gi = g0 + mm * nw, c = c0 + gi * CG + q;
-          const bool ok = gi < G && c <= eext && er >= c - kv;
-          tv[mm] = ok ? ab[(size_t)c * ld + kv + er - c] : 0.0;
-        }
+        if (g0 != wave) gather(g0);
         unsigned long long flag = 0ull;
 #pragma unroll
         for (int mm = 0; mm < NCH; ++mm) {
