@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HERE = os.path.dirname(os.path.abspath(__file__))
-AGENTS = ("vehicle_2", "vehicle_3")
+AGENTS = ("vehicle_2", "vehicle_3")  # default: joint_independent.npz; `... vehicle_0 vehicle_2` -> joint_independent_02.npz
 
 
 def plans_of_strategy():
@@ -38,6 +38,9 @@ if __name__ == "__main__":
     from oracle.independent_colloc import GeometricColloc
     from oracle.independent_joint import solve_joint_ipm
 
+    if len(sys.argv) == 3:
+        AGENTS = (sys.argv[1], sys.argv[2])
+    out_name = "joint_independent.npz" if AGENTS == ("vehicle_2", "vehicle_3") else "joint_independent_%s%s.npz" % (AGENTS[0][-1], AGENTS[1][-1])
     plans = plans_of_strategy()
     jn, sp = tc._joint_problem(plans, list(AGENTS), [0, 0], nps=5)
     X0, _ = tc._joint_guess(plans, list(AGENTS), jn, sp, 5)
@@ -47,5 +50,5 @@ if __name__ == "__main__":
     r = solve_joint_ipm(gs, [(0, 1)], guesses, float(X0[jn.iDt]))
     print({k: v for k, v in r.items() if k != "trajs"}, "%.0f s" % (time.time() - t0), flush=True)
     assert r["status"] in (0, 2) and r["eq"] < 2e-8 and r["ineq"] > -1e-8
-    np.savez_compressed(os.path.join(HERE, "joint_independent.npz"), guess0=guesses[0], guess1=guesses[1], dt0=float(X0[jn.iDt]),
+    np.savez_compressed(os.path.join(HERE, out_name), guess0=guesses[0], guess1=guesses[1], dt0=float(X0[jn.iDt]),
                         traj0=r["trajs"][0], traj1=r["trajs"][1], dt=r["dt"], cost=r["cost"], iters=r["iters"], status=r["status"], pair=r["pair"])
