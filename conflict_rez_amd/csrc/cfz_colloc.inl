@@ -1023,6 +1023,9 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #ifndef CFZ_NO_PANEL
 #define CFZ_NO_PANEL 0
 #endif
+#ifndef CFZ_FORCE_SBIG
+#define CFZ_FORCE_SBIG 0  // diagnostic builds: the wide-register instantiation (kb > 304) whatever kb is; passes the planning GPU tests
+#endif
 // lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
 __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
   __shared__ double pb[16 + 18 * (CFZ_PANEL + 1)], tks[3];
@@ -1030,7 +1033,7 @@ __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long lo
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
-  const int fail = B.kb + CFZ_PANEL <= 320
+  const int fail = (B.kb + CFZ_PANEL <= 320 && !CFZ_FORCE_SBIG)
       ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
       : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks);
   __syncthreads();
