@@ -816,7 +816,12 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     long long tp0 = tick();
     int myext = (tid < RS && j0 + tid < n) ? ext[(j0 + tid) & 1023] : 0;
     if (tid == 0) *rtop = 0;
-    // columns of the rows that come within reach with the next panel: fetched now, looked at after the panel's pivot steps
+    // (1) the panel in registers: thread i holds row j0+i of the P panel columns
+    double v[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) v[k] = (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ? ab[(size_t)(j0 + k) * ld + kv + tid - k] : 0.0;
+    // columns of the rows that come within reach with the next panel: fetched now (after the panel's own
+    // columns: these lines come from HBM, and loads return in order), looked at after the panel's pivot steps
     double sx[RPW][SMAX];
 #pragma unroll
     for (int q_ = 0; q_ < RPW; ++q_) {
@@ -827,10 +832,6 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
         sx[q_][s_] = (wave + nw * q_ < P && o <= kl && r + o < n) ? ab[(size_t)r * ld + kv + o] : 0.0;
       }
     }
-    // (1) the panel in registers: thread i holds row j0+i of the P panel columns
-    double v[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) v[k] = (k < pw && tid < RS && tid <= k + kl && j0 + tid < n) ? ab[(size_t)(j0 + k) * ld + kv + tid - k] : 0.0;
     // (2) the panel's P pivot steps: search by DPP + one LDS exchange between the wavefronts, the two rows that change
     // places go through LDS (everybody needs the new pivot row anyway), the update stays in registers
     bool touched = tid < pw;
