@@ -107,7 +107,7 @@ constexpr int kMaxVeh = 4, kMaxPairs = 6;
 // plan the two bodies at least dmin apart (:389-456) -- again as two smooth rows per (pair, point) over a working set.
 struct CSpec {
   int V, Nps, n_obs, n_pairs;
-  int max_iter, max_backtrack, filter_cap, no_prox;
+  int max_iter, max_backtrack, filter_cap, no_prox;  // no_prox: bit 0 = no proximal term, bit 1 = eliminate one pivot at a time
   int N[kMaxVeh], n_chk[kMaxVeh], has_final[kMaxVeh];
   int pair_a[kMaxPairs], pair_b[kMaxPairs];
   double wb, dmin, shrink, dt0;
@@ -466,7 +466,7 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
 // so the pose block gains D g g' and the pose right-hand side loses D t g; g, D, t are kept in w.cond for `recover`.
 CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
   const CDims d = cdims(sp);
-  const double prox = sp.no_prox ? 0.0 : 1.0;
+  const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   const int *px = w.posx, *pc = w.posc;
   const double *X = w.x, *nu = w.nu;
   const double dt = X[d.iDt];
@@ -1321,7 +1321,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   const CWork w = carve(sp, kb, slab);
   const Band Bd = {w.ab, kb, 3 * kb + 1};
   const int n = d.n, m = d.m;
-  const double prox = sp.no_prox ? 0.0 : 1.0;
+  const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
@@ -1407,7 +1407,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
-      else if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL) {
+      else if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];
         fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds);
       } else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else
@@ -1417,7 +1417,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
-        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
+        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_doubles) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);

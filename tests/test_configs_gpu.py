@@ -299,3 +299,21 @@ def test_joint_plan_against_the_independent_solver_on_gpu():
     r2 = engine.joint_colloc(*args, max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)
     assert r2["status"] in (0, 1, 2, 3), r2["status"]  # ends AT the optimum with the iteration limit or the line search exhausted
     check_joint_against_independent(r2["traj"], r2["dt"], True)
+
+
+def test_panel_elimination_equals_one_pivot_at_a_time(lot):
+    """The joint plan's band is eliminated a panel of sixteen pivots at a time and both right-hand sides are substituted in one
+    sweep (cfz_colloc.inl: band_factor_panel, band_substitute_regs); `one_pivot = 1` takes the one-pivot elimination and the
+    LDS-resident substitution they replaced.  Same pivots and the same operations per entry in the same order: the four-vehicle
+    plan comes out with the same iteration count and the same numbers."""
+    from conflict_rez_amd import engine
+
+    agents = lot["agents"]
+    ws, good, plans = _single_plans(lot, agents, [lot["paths"][a][0] for a in agents])
+    assert good == list(range(4))
+    args = (scenarios.parking_lot_spec(n_nbr=0, N=2), [lot["paths"][a][0] for a in agents], [lot["tubes"][a] for a in agents],
+            [plans[i]["traj"].reshape(-1, 7) for i in range(4)], float(np.mean([plans[i]["dt"] for i in range(4)])), [lot["fh"][a] for a in agents])
+    r = engine.joint_colloc(*args, max_iter=300)
+    r1 = engine.joint_colloc(*args, max_iter=300, one_pivot=1)
+    assert r["status"] == r1["status"] == 0 and r["iters"] == r1["iters"]
+    assert r["cost"] == r1["cost"] and r["dt"] == r1["dt"] and all(np.array_equal(a, b) for a, b in zip(r["traj"], r1["traj"]))
