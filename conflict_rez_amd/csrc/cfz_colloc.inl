@@ -1019,7 +1019,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 }
 
 #ifndef CFZ_PANEL
-#define CFZ_PANEL 16  // pivots per panel (8: 7 % slower on the four-vehicle plan, 32: registers)
+#define CFZ_PANEL 16  // pivots per panel (four-vehicle plan: 8 is 7 % slower, 32 is 14 % slower: every pivot step carries 32-wide rows)
 #endif
 #ifndef CFZ_NO_PANEL
 #define CFZ_NO_PANEL 0
@@ -1036,6 +1036,8 @@ __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long lo
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
   const int fail = (B.kb + CFZ_PANEL <= 320 && !CFZ_FORCE_SBIG)
       ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
+      : (B.kb + CFZ_PANEL <= 384 && !CFZ_FORCE_SBIG)
+      ? band_factor_panel_core<CFZ_PANEL, 6>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
       : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
