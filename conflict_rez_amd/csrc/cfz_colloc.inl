@@ -1036,8 +1036,6 @@ __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long lo
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
   const int fail = (B.kb + CFZ_PANEL <= 320 && !CFZ_FORCE_SBIG)
       ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
-      : (B.kb + CFZ_PANEL <= 384 && !CFZ_FORCE_SBIG)
-      ? band_factor_panel_core<CFZ_PANEL, 6>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
       : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
