@@ -782,7 +782,7 @@ __device__ __forceinline__ double lane_set(double v, int l, double x) {  // v wi
 template <int P, int SMAX>
 __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *PL, lds_f64 *pb,
                                                                 lds_i32 *pj, lds_i32 *meta, lds_i32 *ext, lds_f64 *ptk) {
-  constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 8, RPW = (P + 7) / 8;  // RPW: needs >= 8 wavefronts
+  constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 4, RPW = (P + 7) / 8;  // RPW: needs >= 8 wavefronts
   constexpr unsigned long long TMASK = T == 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);
   const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -967,19 +967,28 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
           for (int qq = 0; qq < CG; ++qq) if ((mask >> (qq * T)) & TMASK) flag |= 1ull << (mm * CG + qq);
         }
         { const long long t1 = tick(); if (tid == 0) ptk[1] += (double)(t1 - tp0); tp0 = t1; }
-        // flagged columns, CB at a time: all their loads in flight together (a wavefront usually gets all its columns of a
-        // panel into one batch, so that a panel costs it one round trip for the test and one for the columns)
-        while (flag) {
-          double cur[CB][SMAX];
-          int cc[CB];
+        // flagged columns, CB at a time, the next CB in flight while these are updated
+        double cur[CB][SMAX], nxt[CB][SMAX];
+        int cc[CB], nc[CB];
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+          cc[x] = -1;
+          if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
+#pragma unroll
+          for (int s_ = 0; s_ < SMAX; ++s_) {
+            const int i = lane + 64 * s_, r = j0 + src[s_], c = cc[x];  // read through the panel's row permutation
+            cur[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
+          }
+        }
+        while (cc[0] >= 0) {
 #pragma unroll
           for (int x = 0; x < CB; ++x) {
-            cc[x] = -1;
-            if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; cc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
+            nc[x] = -1;
+            if (flag) { const int b = __ffsll((long long)flag) - 1; flag &= flag - 1ull; nc[x] = c0 + (g0 + (b / CG) * nw) * CG + (b % CG); }
 #pragma unroll
             for (int s_ = 0; s_ < SMAX; ++s_) {
-              const int i = lane + 64 * s_, r = j0 + src[s_], c = cc[x];  // read through the panel's row permutation
-              cur[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
+              const int i = lane + 64 * s_, r = j0 + src[s_], c = nc[x];
+              nxt[x][s_] = (c >= 0 && i <= rt && r >= c - kv) ? ab[(size_t)c * ld + kv + r - c] : 0.0;
             }
           }
 #pragma nounroll
@@ -1006,6 +1015,9 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
                 if (i <= rt && r >= c - kv) ab[(size_t)c * ld + kv + r - c] = cur[x][s_];
               }
             }
+            cc[x] = nc[x];
+#pragma unroll
+            for (int s_ = 0; s_ < SMAX; ++s_) cur[x][s_] = nxt[x][s_];
           }
         }
       }
