@@ -789,6 +789,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
   lds_i32 *jps = meta, *juk = meta + P, *kms = meta + 2 * P;
   lds_f64 *cand = pb + 16;  // [2][9][P + 1]: per parity, the candidate row of each wavefront (+ 1 / its entry) and row k
   const int nwa = (RS + 63) >> 6;  // wavefronts that hold rows of a panel
+  const int hw = nwa < nw ? nw - 1 : 0;  // the helper wavefront: the last one if it holds no rows, else the first
   lds_i32 *cint = pj, *rtop = meta + 3 * P;
   // ext[r & 1023]: no entry of the row now at position r lies right of this column.  A row enters with the extent of the
   // assembled matrix, read off its COLUMN (the matrix is symmetric: put() writes both triangles) SC columns ahead of the
@@ -868,21 +869,22 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
       double best = pbk[0];
       int p = ci[0], ws = 0;  // row of the pivot, relative to j0: the first of the largest; the wavefront it is in
       for (int i = 1; i < nwa; ++i) if (pbk[i] > best) { best = pbk[i]; p = ci[i]; ws = i; }
-      if (tid == 0) ipiv[j] = j0 + p;
+      const int ht = tid - hw * 64;  // the chores of a step (nothing here needs a row of the panel) go to a wavefront without rows
+      if (ht == 0) ipiv[j] = j0 + p;
       if (!(best > 0.0)) return 1;
       const int jp = p - k;
       const int reach = j + kl + jp < n - 1 ? j + kl + jp : n - 1;
       ju = ju > reach ? ju : reach;
-      if (tid == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
+      if (ht == 0) { jps[k] = jp; juk[k] = ju; kms[k] = km; }
+      // the pivot row is final: entry (j, j + t) by helper thread t
+      if (ht >= 0 && ht < pw - k) ab[(size_t)(j + ht) * ld + kv - ht] = cd[ws * (P + 1) + ht];
+      // multipliers of the earlier steps follow the swap (helper thread c: column c of PL)
+      if (ht >= 0 && ht < k && jp) { const double t_ = PL[ht * RS + k]; PL[ht * RS + k] = PL[ht * RS + p]; PL[ht * RS + p] = t_; }
       if (wave >= nwa) continue;
       const int ek_ = ci[8 + ws];  // extent of the pivot row
       double u[P];
 #pragma unroll
       for (int c = 0; c < P; ++c) u[c] = cd[ws * (P + 1) + c];
-      // the pivot row is final: entry (j, j + t) by thread t
-      if (tid < pw - k) ab[(size_t)(j + tid) * ld + kv - tid] = cd[ws * (P + 1) + tid];
-      // multipliers of the earlier steps follow the swap (thread c: column c of PL)
-      if (tid < k && jp) { const double t_ = PL[tid * RS + k]; PL[tid * RS + k] = PL[tid * RS + p]; PL[tid * RS + p] = t_; }
       if (tid == k) myext = ek_;
       else if (tid == p) {
 #pragma unroll
