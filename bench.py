@@ -121,7 +121,7 @@ def profiled_traffic(kernel):
     import glob
 
     here = os.path.dirname(os.path.abspath(__file__))
-    tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_FETCH_SIZE.csv")) if "_planning_" not in os.path.basename(t))
+    tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_FETCH_SIZE.csv")) if os.path.basename(t).count("_") == 3)  # <tag>_pmc_FETCH_SIZE.csv: the MPC bench's tags, not <tag>_planning_.. / <tag>_jointbatch_..
     if not tags:
         return None, None
     tag = tags[-1][: -len("_pmc_FETCH_SIZE.csv")]
@@ -144,7 +144,7 @@ def profiled_sq(kernel):
     import glob
 
     here = os.path.dirname(os.path.abspath(__file__))
-    tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_SQ.csv")) if "_planning_" not in os.path.basename(t))
+    tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_SQ.csv")) if os.path.basename(t).count("_") == 2)
     if not tags:
         return None, None
     vals = {}
