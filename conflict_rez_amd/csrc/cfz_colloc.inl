@@ -23,7 +23,9 @@
 // iterate; every collision pair (slack, multiplier) is condensed into the poses it touches (assemble); a primal-dual
 // merit takes over when the filter line search fails (solve_colloc).  One workgroup per plan, workspace in global
 // memory; every thread runs the scalar logic, the marked loops are shared.  One vehicle: one wavefront, elimination in
-// an LDS window (cfz_band.inl).  Several vehicles: eight wavefronts, elimination from global memory (band_factor_wide).
+// an LDS window (cfz_band.inl).  Several vehicles: eight wavefronts, band in global memory, eliminated a panel of sixteen pivots at
+// a time (band_factor_panel; band_factor_wide2, one pivot at a time, is its check and fallback), both right-hand sides
+// substituted in one sweep (band_substitute_regs).
 #pragma once
 #include "cfz_solver.inl"
 #include "cfz_plan.inl"
