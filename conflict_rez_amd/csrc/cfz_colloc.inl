@@ -472,7 +472,19 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
   const int *px = w.posx, *pc = w.posc;
   const double *X = w.x, *nu = w.nu;
   const double dt = X[d.iDt];
+#if defined(__HIP_DEVICE_COMPILE__)
+  {  // the band is cleared with 16-byte stores (88 MB per assembly of the four-vehicle plan)
+    double *z = Bd.ab;
+    const int tot = d.nk * Bd.ld, head = (int)(((size_t)z >> 3) & 1);
+    if (threadIdx.x == 0 && head) z[0] = 0.0;
+    double2 *z2 = reinterpret_cast<double2 *>(z + head);
+    const int n2 = (tot - head) >> 1;
+    for (int t = (int)threadIdx.x; t < n2; t += (int)blockDim.x) z2[t] = make_double2(0.0, 0.0);
+    if (threadIdx.x == 0 && ((tot - head) & 1)) z[tot - 1] = 0.0;
+  }
+#else
   CFZP_LANE_FOR(t, 0, d.nk * Bd.ld - 1) Bd.ab[t] = 0.0;
+#endif
   CFZP_LANE_FOR(col, 0, d.nk - 1) w.bord[col] = 0.0;
   CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, d.n - 1) if (px[i] >= 0) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
