@@ -795,7 +795,7 @@ __device__ __forceinline__ double lane_set(double v, int l, double x) {  // v wi
 }
 template <int P, int SMAX>
 __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int kb, int ld, int n, glb_i32 *ipiv, lds_f64 *PL, lds_f64 *pb,
-                                                                lds_i32 *pj, lds_i32 *meta, lds_i32 *ext, lds_f64 *ptk) {
+                                                                lds_i32 *pj, lds_i32 *meta, lds_i32 *ext, lds_f64 *ptk, glb_f64 *b1, glb_f64 *b2) {
   constexpr int T = 2 * P, CG = 64 / T, NCH = 64 / CG < 16 ? 64 / CG : 16, CB = 4, RPW = (P + 7) / 8;  // RPW: needs >= 8 wavefronts
   constexpr unsigned long long TMASK = T == 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);
   const int kl = kb, kv = 2 * kb, RS = kb + P;  // needs RS <= 64 SMAX and RS <= blockDim.x
@@ -944,8 +944,8 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
     const int eext = eok ? ext[er & 1023] : -1;   // ... and where that row ended when the panel began
     const int cend = (int)cfz::wave_reduce<1>((double)eext), cmax = cend < ju ? cend : ju, ncol = cmax - c0 + 1;
     const int rt = *rtop;
-    if (ncol > 0) {
-      const int G = (ncol + CG - 1) / CG;
+    {
+      const int G = ncol > 0 ? (ncol + CG - 1) / CG : 0;  // (0: no trailing columns left; the right-hand sides below still go through)
       double tv[NCH];
       auto gather = [&](int g0) {  // the test entries of NCH groups of columns, all in flight together
 #pragma unroll
@@ -972,6 +972,14 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
             if (ps == s_) { const int sp_ = __builtin_amdgcn_readlane(src[s_], pl); if (lane == pl) src[s_] = sk; if (lane == k) src[0] = sp_; }
           }
         }
+      }
+      // (the right-hand sides taken along, see below: requested here, used after the columns)
+      glb_f64 *bx = b1 != nullptr && wave >= nw - 2 ? (wave == nw - 1 ? b1 : b2) : nullptr;
+      double y[SMAX];
+#pragma unroll
+      for (int s_ = 0; s_ < SMAX; ++s_) {
+        const int i = lane + 64 * s_, r = j0 + src[s_];
+        y[s_] = (bx != nullptr && i <= rt && r < n) ? bx[r] : 0.0;
       }
       for (int g0 = wave; g0 < G; g0 += nw * NCH) {
         if (g0 != wave) gather(g0);
@@ -1037,6 +1045,23 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
           }
         }
       }
+      // The two right-hand sides of the solve that follows (b1, b2; may be null) are taken along as two more columns: L^-1 P is
+      // applied to them panel by panel, and the substitution is left with the backward sweep.
+      if (bx != nullptr) {  // (one each for the last two wavefronts)
+#pragma nounroll
+        for (int k = 0; k < pw; ++k) {
+          const double u = lane_get(y[0], k);
+          if (u != 0.0) {
+#pragma unroll
+            for (int s_ = 0; s_ < SMAX; ++s_) { const int i = lane + 64 * s_; y[s_] = y[s_] - (i < RS ? PL[k * RS + i] : 0.0) * u; }
+          }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < SMAX; ++s_) {
+          const int i = lane + 64 * s_, r = j0 + i;
+          if (i <= rt && r < n) bx[r] = y[s_];
+        }
+      }
     }
     __syncthreads();
     if (tid >= pw && tid < RS && j0 + tid < n) ext[(j0 + tid) & 1023] = myext;
@@ -1056,15 +1081,15 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
 #define CFZ_FORCE_SBIG 0  // diagnostic builds: the wide-register instantiation (kb > 304) whatever kb is; passes the planning GPU tests
 #endif
 // lds: the kernel's dynamic LDS (free during the elimination; the substitution keeps its right-hand side there)
-__device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds) {
+__device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long long *ptk, double *lds, double *b1, double *b2) {
   __shared__ double pb[16 + 18 * (CFZ_PANEL + 1)], tks[3];
   __shared__ int pj[64], meta[3 * CFZ_PANEL + 4], ext[1024];
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
   const int fail = (B.kb + CFZ_PANEL <= 320 && !CFZ_FORCE_SBIG)
-      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks)
-      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks);
+      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks, (glb_f64 *)b1, (glb_f64 *)b2)
+      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks, (glb_f64 *)b1, (glb_f64 *)b2);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
   return fail;
@@ -1148,9 +1173,9 @@ __device__ inline void band_substitute_wide(const Band &B, int n, const int *ipi
 // Needs blockDim.x >= kb + CH and 2 blockDim.x >= 2 kb + CH.
 template <int CH>
 __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f64 *ab, int kb, int ld, int n, const glb_i32 *ipiv, glb_f64 *b1,
-                                                                    glb_f64 *b2, lds_f64 *slot, lds_f64 *stage) {
+                                                                    glb_f64 *b2, lds_f64 *slot, lds_f64 *stage, bool fwd_done) {
   const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x;
-  {  // L y = P b
+  if (!fwd_done) {  // L y = P b
     const int RS = kl + CH;
     double y1 = (tid < RS && tid < n) ? b1[tid] : 0.0, y2 = (tid < RS && tid < n) ? b2[tid] : 0.0;
     for (int j0 = 0; j0 < n; j0 += CH) {
@@ -1243,10 +1268,10 @@ __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f6
   __syncthreads();
 }
 
-__device__ inline void band_substitute_regs(const Band &B, int n, const int *ipiv, double *b, double *b2) {
+__device__ inline void band_substitute_regs(const Band &B, int n, const int *ipiv, double *b, double *b2, bool fwd_done) {
   constexpr int CH = 16;
   __shared__ double slot[4 * CH], stage[2 * (2 * kWideMaxKb + CH)];
-  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage);
+  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage, fwd_done);
 }
 #endif
 
@@ -1433,11 +1458,13 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       CFZP_SYNC();
       tk[1] += tick() - ta; ta = tick();
       int fail;
+      bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
       else if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];
-        fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds);
+        fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds, w.rhs, w.rhs2);
+        fwd_done = true;
       } else if (MODE == 2 && blockDim.x > kb && kb <= kWideMaxKb) fail = band_factor_wide2(Bd, d.nk, w.ipiv, tk + 6); else
 #endif
       fail = band_factor(Bd, d.nk, w.ipiv);
@@ -1445,7 +1472,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
-        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
+        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2, fwd_done);
         else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_doubles) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
