@@ -1173,7 +1173,7 @@ __device__ inline void band_substitute_wide(const Band &B, int n, const int *ipi
 // Needs blockDim.x >= kb + CH and 2 blockDim.x >= 2 kb + CH.
 template <int CH>
 __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f64 *ab, int kb, int ld, int n, const glb_i32 *ipiv, glb_f64 *b1,
-                                                                    glb_f64 *b2, lds_f64 *slot, lds_f64 *stage, bool fwd_done) {
+                                                                    glb_f64 *b2, lds_f64 *slot, lds_f64 *stage, lds_f64 *tri, bool fwd_done) {
   const int kl = kb, kv = 2 * kb, tid = threadIdx.x, nt = blockDim.x;
   if (!fwd_done) {  // L y = P b
     const int RS = kl + CH;
@@ -1233,21 +1233,43 @@ __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f6
       const int rf = lo - CH + tid;  // the rows that enter with the next chunk: positions 0 .. CH-1 of its window
       double g1 = 0.0, g2 = 0.0;
       if (tid < CH && rf >= 0) { g1 = b1[rf]; g2 = b2[rf]; }
+      // The CH x CH triangle of the chunk's own rows is solved by one wavefront (lane c = row j1 - c: the owners hand their rows of
+      // the triangle and their right-hand sides over through LDS), then every row above takes its CH updates at once: two barriers
+      // per chunk instead of one per pivot.  Same operations in the same order as one pivot at a time.
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + nt * t;
+        if (i >= kv && i < W) {
+          const int c = W - 1 - i;
+#pragma unroll
+          for (int c2 = 0; c2 < CH; ++c2) tri[c * CH + c2] = Uc[c2][t];
+          tri[CH * CH + c] = z1[t]; tri[CH * CH + CH + c] = z2[t];
+        }
+      }
+      lds_barrier();
+      if (tid < 64) {
+        const int c = tid < CH ? tid : 0;
+        double Tc[CH], y1 = tid < CH ? tri[CH * CH + c] : 0.0, y2 = tid < CH ? tri[CH * CH + CH + c] : 0.0, dd = dg[0];
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) { Tc[c2] = tid < CH ? tri[c * CH + c2] : 0.0; if (tid == c2) dd = dg[c2]; }
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+          const double x1 = lane_get(y1 / dd, c2), x2 = lane_get(y2 / dd, c2);
+          y1 = y1 - Tc[c2] * x1; y2 = y2 - Tc[c2] * x2;  // Tc[c2] is zero from row c2 on
+        }
+        if (tid < CH) { tri[CH * CH + 2 * CH + c] = y1 / dd; tri[CH * CH + 3 * CH + c] = y2 / dd; }
+      }
+      lds_barrier();
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const int j = j1 - c;
-        if (j >= 0) {
-          const int ij = kv + CH - 1 - c, ot = ij >= nt ? 1 : 0, otid = ij - nt * ot;  // who owns row j
-          if (tid == otid) {
-            const double x1 = (ot ? z1[1] : z1[0]) / dg[c], x2 = (ot ? z2[1] : z2[0]) / dg[c];
-            slot[2 * c] = x1; slot[2 * c + 1] = x2;
-            if (ot) { z1[1] = x1; z2[1] = x2; } else { z1[0] = x1; z2[0] = x2; }
-          }
-          lds_barrier();
-          const double a1 = slot[2 * c], a2 = slot[2 * c + 1];
+        const double a1 = tri[CH * CH + 2 * CH + c], a2 = tri[CH * CH + 3 * CH + c];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) { z1[t] = z1[t] - Uc[c][t] * a1; z2[t] = z2[t] - Uc[c][t] * a2; }  // Uc is zero from row j on
-        }
+        for (int t = 0; t < 2; ++t) { z1[t] = z1[t] - Uc[c][t] * a1; z2[t] = z2[t] - Uc[c][t] * a2; }  // Uc is zero from row j on
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + nt * t;
+        if (i >= kv && i < W) { const int c = W - 1 - i; z1[t] = tri[CH * CH + 2 * CH + c]; z2[t] = tri[CH * CH + 3 * CH + c]; }
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1270,8 +1292,8 @@ __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f6
 
 __device__ inline void band_substitute_regs(const Band &B, int n, const int *ipiv, double *b, double *b2, bool fwd_done) {
   constexpr int CH = 16;
-  __shared__ double slot[4 * CH], stage[2 * (2 * kWideMaxKb + CH)];
-  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage, fwd_done);
+  __shared__ double slot[4 * CH], stage[2 * (2 * kWideMaxKb + CH)], tri[CH * CH + 4 * CH];
+  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage, (lds_f64 *)tri, fwd_done);
 }
 #endif
 
