@@ -308,11 +308,18 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   HIP_OK(hipMemcpyAsync(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
-  // one wavefront per single-vehicle plan (LDS-window elimination); the joint plan's band is too wide for LDS: its
-  // elimination runs from global memory and the whole solver is spread over eight wavefronts to hide the latency
+  // Two kernels.  colloc_kernel<2>: eight wavefronts per plan, band in global memory, panel elimination -- the only one for the
+  // joint plan (its band does not fit LDS) and 2-2.6x faster per plan for single plans too (vehicle 0: 0.96 -> 0.37 s), but one
+  // plan per CU.  colloc_kernel<1>: one wavefront per single plan, elimination in an LDS window, four plans per CU: taken when
+  // the batch is larger than two rounds of the wide kernel (B > 2 CUs), or on request (`one_pivot`, the check of the other).
   bool wide = false;
   for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
-  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: single plans through the wide path
+  if (!wide && !co->one_pivot) {
+    int cus = 0;
+    HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
+    wide = B <= 2 * cus;
+  }
+  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: every batch through the wide kernel
   if (!wide) {
     const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
     HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));

@@ -236,8 +236,9 @@ typedef struct cfz_colloc_options {
   int32_t max_iter;       /* IPOPT default 3000 (:652 leaves it unset) */
   int32_t exact_rows;     /* 0: dual regularisation of proximal type, delta_c = 1e-7 (rows met to delta_c x multiplier, robust where
                            *    the reference's rows lose rank); 1: IPOPT's form, delta_c = 1e-9 (exact optimum at tight tolerances) */
-  int32_t one_pivot;      /* 0: the joint plan's band is eliminated a panel of 16 pivots at a time; 1: one pivot at a time (same pivots,
-                           *    same arithmetic per entry, same factor: kept as the check of the panel version, ~2x slower) */
+  int32_t one_pivot;      /* 0: the band is eliminated a panel of 16 pivots at a time (single plans: for batches up to two per CU);
+                           *    1: one pivot at a time -- joint plan: same pivots, same arithmetic per entry, same factor; single
+                           *    plans: the one-wavefront kernel with its LDS window.  Kept as the check of the panel version, ~2x slower */
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */
