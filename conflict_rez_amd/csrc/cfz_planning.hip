@@ -123,7 +123,7 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
     p.N = po->N; p.n_chk = n_sets[b] - 1; p.T = po->N * p.n_chk;
     p.has_final = final_heading && final_heading[b] == final_heading[b]; p.final_heading = p.has_final ? final_heading[b] : 0.0;
     p.bounded_input = po->bounded_input;
-    p.max_iter = po->max_iter; p.max_backtrack = 25; p.filter_cap = 16; p.stall_iters = 0;
+    p.max_iter = po->max_iter; p.max_backtrack = 25; p.filter_cap = 16; p.stall_iters = po->stall_iters;
     p.dt = po->dt; p.wb = po->wb; p.shrink = po->shrink_tube;
     for (int i = 0; i < 3; ++i) p.init_pose[i] = init_pose[b * 3 + i];
     memcpy(p.bounds, po->bounds, sizeof p.bounds);

@@ -32,7 +32,7 @@ _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps k
 
 
 class _CPlanOptions(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("N", "max_iter", "bounded_input", "reserved")] + [
+    _fields_ = [(k, C.c_int32) for k in ("N", "max_iter", "bounded_input", "stall_iters")] + [
         ("dt", C.c_double), ("wb", C.c_double), ("shrink_tube", C.c_double), ("bounds", C.c_double * 12),
         ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
 

@@ -191,7 +191,8 @@ typedef struct cfz_plan_options {
   int32_t N;              /* :100 steps per strategy step, 30 */
   int32_t max_iter;       /* :210 500 */
   int32_t bounded_input;  /* :104, :155-167 */
-  int32_t reserved;
+  int32_t stall_iters;    /* 0 (as the reference: an infeasible plan runs to max_iter); n > 0: status 5 after n iterations without
+                           *   progress of the constraint violation, as in the MPC step -- a batch then does not wait for such a plan */
   double dt;              /* :101 0.1 */
   double wb;              /* wheelbase */
   double shrink_tube;     /* :106 0.5 in the callers */
