@@ -974,7 +974,7 @@ __device__ __attribute__((noinline)) int band_factor_panel_core(glb_f64 *ab, int
         }
       }
       // (the right-hand sides taken along, see below: requested here, used after the columns)
-      glb_f64 *bx = b1 != nullptr && wave >= nw - 2 ? (wave == nw - 1 ? b1 : b2) : nullptr;
+      glb_f64 *bx = wave == nw - 1 ? b1 : (wave == nw - 2 ? b2 : nullptr);  // (either may be null)
       double y[SMAX];
 #pragma unroll
       for (int s_ = 0; s_ < SMAX; ++s_) {

@@ -57,6 +57,30 @@ CFZP_FN double wmin(double v) {
   return v;
 }
 
+// The same over a workgroup of several wavefronts (the eight-wavefront kernels: every thread runs the scalar logic, the marked
+// loops are split over all threads); the per-wavefront values are combined through LDS in a fixed order, so that every thread
+// gets the same bits.  With one wavefront they are wsum / wmax / wmin.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline double pcombine(double v, int op) {  // op 0 sum, 1 max, 2 min
+  __shared__ double part[16];
+  const int nw = (int)(blockDim.x >> 6);
+  if (nw <= 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = part[0];
+  for (int i = 1; i < nw; ++i) r = op == 0 ? r + part[i] : (op == 1 ? fmax(r, part[i]) : fmin(r, part[i]));
+  return r;
+}
+CFZP_FN double psum(double v) { return pcombine(wsum(v), 0); }
+CFZP_FN double pmax(double v) { return pcombine(wmax(v), 1); }
+CFZP_FN double pmin(double v) { return pcombine(wmin(v), 2); }
+#else
+CFZP_FN double psum(double v) { return v; }
+CFZP_FN double pmax(double v) { return v; }
+CFZP_FN double pmin(double v) { return v; }
+#endif
+
 constexpr int kKB = 40;               // half-bandwidth of the permuted KKT matrix (asserted at set-up)
 constexpr int kLd = 3 * kKB + 1;      // band storage rows (LAPACK gb layout with room for the pivoting fill-in)
 
@@ -107,7 +131,7 @@ CFZP_FN const double *cell(const double *tube, int i, int front) { return tube +
 CFZP_FN double objective(const PSpec &sp, const double *X) {
   double f = 0.0;
   CFZP_LANE_FOR(k, 0, sp.T - 1) f += X[7 * k + 5] * X[7 * k + 5] + X[7 * k + 6] * X[7 * k + 6];
-  return wsum(f);
+  return psum(f);
 }
 
 CFZP_FN void constraints(const PSpec &sp, const double *tube, const double *X, double *c) {
@@ -236,7 +260,7 @@ CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const
     }
     band(w.ab, px[b + 2], px[b + 2]) += curv;
   }
-  if (sp.has_final) put(w.ab, pc[d.m - 1], px[7 * sp.T + 2], 1.0);
+  CFZP_LANE_FOR(one, 0, 0) if (sp.has_final) put(w.ab, pc[d.m - 1], px[7 * sp.T + 2], 1.0);  // (one thread: += is not idempotent)
   CFZP_SYNC();
 }
 
@@ -338,11 +362,22 @@ CFZP_FN double barrier_obj(const PSpec &sp, const PWork &w, const double *X, dou
     if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) bad = 1.0; else s += log(dl); }
     if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) bad = 1.0; else s += log(du); }
   }
-  if (wmax(bad) > 0.0) return INFINITY;
-  return objective(sp, X) - mu * wsum(s);
+  if (pmax(bad) > 0.0) return INFINITY;
+  return objective(sp, X) - mu * psum(s);
 }
 
-template <bool WIN>
+}  // namespace cfzp
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace cfzc {  // the eight-wavefront elimination and substitution of cfz_colloc.inl (defined there, after this file)
+__device__ inline int band_factor_panel(const cfzb::Band &B, int n, int *ipiv, long long *ptk, double *lds, double *b1, double *b2);
+__device__ inline void band_substitute_regs(const cfzb::Band &B, int n, const int *ipiv, double *b, double *b2, bool fwd_done);
+}
+#endif
+namespace cfzp {
+
+// WIDE: eight wavefronts per plan, band eliminated from global memory a panel at a time (cfz_colloc.inl) -- faster per plan than
+// the one-wavefront LDS window, one plan per CU instead of two.
+template <bool WIN, bool WIDE = false>
 CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d,
                             double *win) {
   const PDims d = dims(sp);
@@ -371,7 +406,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     if (hu) w.x[i] = fmin(w.x[i], w.xu[i] - pu);
     w.zl[i] = hl ? 1.0 : 0.0; w.zu[i] = hu ? 1.0 : 0.0; nbd += hl + hu;
   }
-  const int nb = (int)wsum(nbd);
+  const int nb = (int)psum(nbd);
   CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] = 0.0;
   CFZP_SYNC();
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
@@ -385,17 +420,17 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     jt_nu(sp, tube, w.x, w.nu, w.r1);  // J' nu (ends with a barrier)
     double theta = 0.0, cviol = 0.0, sum_nu = 0.0, sum_z = 0.0, dual_inf = 0.0;
     CFZP_LANE_FOR(i, 0, m - 1) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
-    theta = wsum(theta); cviol = wmax(cviol); sum_nu = wsum(sum_nu);
+    theta = psum(theta); cviol = pmax(cviol); sum_nu = psum(sum_nu);
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
-    sum_z = wsum(sum_z); dual_inf = wmax(dual_inf);
+    sum_z = psum(sum_z); dual_inf = pmax(dual_inf);
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
     double cmp0 = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
       if (w.xl[i] > -1e300) cmp0 = fmax(cmp0, fabs((w.x[i] - w.xl[i]) * w.zl[i]));
       if (w.xu[i] < 1e300) cmp0 = fmax(cmp0, fabs((w.xu[i] - w.x[i]) * w.zu[i]));
     }
-    cmp0 = wmax(cmp0);
+    cmp0 = pmax(cmp0);
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
@@ -408,7 +443,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         if (w.xl[i] > -1e300) cm = fmax(cm, fabs((w.x[i] - w.xl[i]) * w.zl[i] - mu));
         if (w.xu[i] < 1e300) cm = fmax(cm, fabs((w.xu[i] - w.x[i]) * w.zu[i] - mu));
       }
-      cm = wmax(cm);
+      cm = pmax(cm);
       if (fmax(dual_inf / s_d, fmax(cviol, cm / s_c)) <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
       else break;
     }
@@ -431,7 +466,12 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       CFZP_SYNC();
       int fail;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (WIN && d.nk <= kWinCols * kLd) {  // the batched LDS elimination of cfz_band.inl; the right-hand side follows in LDS
+      if (WIDE) {
+        const cfzb::Band Bd = {w.ab, kKB, kLd};
+        long long unused[3] = {0, 0, 0};
+        fail = cfzc::band_factor_panel(Bd, d.nk, w.ipiv, unused, win, w.rhs, nullptr);  // the right-hand side rides along
+        if (!fail) cfzc::band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs, true);
+      } else if (WIN && d.nk <= kWinCols * kLd) {  // the batched LDS elimination of cfz_band.inl; the right-hand side follows in LDS
         const cfzb::Band Bd = {w.ab, kKB, kLd};
         long long unused[3] = {0, 0, 0};
         fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, unused);
@@ -443,7 +483,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         double curv = 0.0, dd = 0.0, bad = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
         CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.rhs[w.posx[i]]; if (!isfinite(v)) bad = 1.0; w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v; }
         CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.rhs[w.posc[i]]; if (!isfinite(v)) bad = 1.0; w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v; }
-        curv = wsum(curv); dd = wsum(dd); bad = wmax(bad);
+        curv = psum(curv); dd = psum(dd); bad = pmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
       }
@@ -469,7 +509,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         if (w.dzu[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zu[i] / w.dzu[i]);
       }
     }
-    a_pri = wmin(a_pri); a_dual = wmin(a_dual); dphi = wsum(dphi);
+    a_pri = pmin(a_pri); a_dual = pmin(a_dual); dphi = psum(dphi);
     CFZP_SYNC();
     const double phi0 = barrier_obj(sp, w, w.x, mu);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
@@ -480,7 +520,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       constraints(sp, tube, w.xt, w.ct);
       double th_t = 0.0;
       CFZP_LANE_FOR(i, 0, m - 1) th_t += fabs(w.ct[i]);
-      th_t = wsum(th_t);
+      th_t = psum(th_t);
       const double ph_t = barrier_obj(sp, w, w.xt, mu);
       bool ok = isfinite(ph_t) && isfinite(th_t) && th_t <= theta_max;
       if (ok) for (int q = 0; q < nfilt; ++q) if (th_t >= filt[q][0] && ph_t >= filt[q][1]) { ok = false; break; }

@@ -15,6 +15,9 @@
 #include <string>
 #include <vector>
 
+#ifndef CFZ_PANEL
+#define CFZ_PANEL 16  // pivots per panel of the eight-wavefront elimination (cfz_colloc.inl; the host sizes its LDS)
+#endif
 #include "../../include/confrez_hip.h"
 #include "cfz_common.h"
 #include "cfz_solver.inl"
@@ -32,6 +35,15 @@ __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec 
   if (b >= B) return;
   // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
   cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
+}
+
+// the same with eight wavefronts per plan and the panel elimination of cfz_colloc.inl (dynamic LDS: the panel's multipliers)
+__global__ __launch_bounds__(512) void state_ws_kernel_wide(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
+                                     const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
+  const int b = blockIdx.x;
+  extern __shared__ double plan_win[];
+  if (b >= B) return;
+  cfzp::solve_state_ws<true, true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
 }
 
 // single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
@@ -165,9 +177,16 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   HIP_OK(hipMemcpyAsync(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
-  const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
-  HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-  hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  int cus = 0;
+  HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
+  if (B <= 2 * cus && !std::getenv("CFZ_STATE_WS_NARROW")) {  // one plan per CU, faster per plan: up to two rounds of it
+    const size_t pl_bytes = (size_t)CFZ_PANEL * (cfzp::kKB + CFZ_PANEL) * sizeof(double);
+    hipLaunchKernelGGL(state_ws_kernel_wide, dim3(B), dim3(512), pl_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  } else {
+    const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
+    HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+    hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
   HIP_OK(hipMemcpyAsync(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost, st));
