@@ -59,9 +59,15 @@ def test_plan_kernel_source_matches_oracle(plans):
 
 
 @pytest.mark.gpu
-def test_state_ws_on_gpu_matches_oracle(plans):
-    """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory."""
+@pytest.mark.parametrize("narrow", [False, True])
+def test_state_ws_on_gpu_matches_oracle(plans, narrow, monkeypatch):
+    """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory -- with both
+    kernels: eight wavefronts + panel elimination (what a batch this small gets) and one wavefront + LDS window (larger batches;
+    here forced through the environment switch the library reads at every call)."""
     from conflict_rez_amd import engine
+
+    if narrow:
+        monkeypatch.setenv("CFZ_STATE_WS_NARROW", "1")
 
     agents = sorted(plans)
     tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
