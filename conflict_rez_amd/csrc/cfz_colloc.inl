@@ -110,6 +110,7 @@ constexpr int kMaxVeh = 4, kMaxPairs = 6;
 struct CSpec {
   int V, Nps, n_obs, n_pairs;
   int max_iter, max_backtrack, filter_cap, no_prox;  // no_prox: bit 0 = no proximal term, bit 1 = eliminate one pivot at a time
+  int vv_rows, pad0;  // vv_rows 1: vertex-vertex rows (kind 3, cfz_solver.inl) in the working sets of obstacle and pair blocks
   int N[kMaxVeh], n_chk[kMaxVeh], has_final[kMaxVeh];
   int pair_a[kMaxPairs], pair_b[kMaxPairs];
   double wb, dmin, shrink, dt0;
@@ -161,6 +162,7 @@ CFZP_FN int veh_of_chk(const CDims &d, int T) { int a = 0; while (a + 1 < d.V &&
 // half-bandwidth of the ordering of build_order: the 30 ODE rows of an interval sit between its third and fourth point
 constexpr int kCB = 51, kCLd = 3 * kCB + 1, kCWin = 2 * kCB + 1;
 constexpr int kCLdsDoubles = kCWin * kCLd + 64;  // the window and one spare slot per lane behind it
+constexpr int kWideMaxKb = 448;  // widest half-bandwidth the eight-wavefront eliminations are compiled for (the host sizes LDS with it)
 // point of tube checkpoint T (global index): start of interval (t+1) Nps of its vehicle, or the vehicle's very last point
 CFZP_FN int chk_point(const CSpec &sp, const CDims &d, int T) {
   const int a = veh_of_chk(d, T), t = T - d.coff[a];
@@ -190,9 +192,30 @@ CFZP_FN void veh_polygon(const double *q, const double g[4], double A[4][2], dou
 // One separation row of a pair of vehicles a, b (poses pa, pb = x, y, psi), as seen from a like the rows of an obstacle:
 // kind 1 = face f of b against body vertex v of a, kind 2 = face f of a against body vertex v of b.  With F the vehicle that
 // owns the face and W the one that owns the vertex:  val = n.(t_W + R_W b_v - t_F) - g_f,  n = R_F G_f.
+// kind 3 = body vertex f of b against body vertex v of a, each the other's closest feature: val = |w|,
+// w = t_a + R_a b_v - t_b - R_b b_f (the reference's rows admit any unit direction, multi_vehicle_planner.py:419-451).
 // gr, H: derivatives with respect to (a: x, y, psi | b: x, y, psi).
 template <bool DER>
 CFZP_FN double pair_row(const double *pa, const double *pb, const double g[4], int kind, int f, int v, double gr[6], double H[6][6]) {
+  if (kind == 3) {
+    const double ca = cos(pa[2]), sa = sin(pa[2]), cb = cos(pb[2]), sb = sin(pb[2]);
+    const double ax = (v == 0 || v == 3) ? g[0] : -g[2], ay = (v < 2) ? g[1] : -g[3];
+    const double ux = (f == 0 || f == 3) ? g[0] : -g[2], uy = (f < 2) ? g[1] : -g[3];
+    const double rax = ca * ax - sa * ay, ray = sa * ax + ca * ay, rbx = cb * ux - sb * uy, rby = sb * ux + cb * uy;  // R_a b_v, R_b b_f
+    const double wx = pa[0] + rax - pb[0] - rbx, wy = pa[1] + ray - pb[1] - rby;
+    const double r = sqrt(wx * wx + wy * wy);
+    if (DER) {
+      const double ir = 1.0 / r, n0 = wx * ir, n1 = wy * ir;
+      // d(R b)/dpsi = (-Rb_y, Rb_x); tangent t = (-n1, n0);  H = tau tau' / r + n.w'' with tau = (dw/dz)' t
+      const double nda = -n0 * ray + n1 * rax, ndb = -n0 * rby + n1 * rbx, tda = n1 * ray + n0 * rax, tdb = n1 * rby + n0 * rbx;
+      gr[0] = n0; gr[1] = n1; gr[2] = nda; gr[3] = -n0; gr[4] = -n1; gr[5] = -ndb;
+      const double tau[6] = {-n1, n0, tda, n1, -n0, -tdb};
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[i][j] = tau[i] * tau[j] * ir;
+      H[2][2] -= n0 * rax + n1 * ray;
+      H[5][5] += n0 * rbx + n1 * rby;
+    }
+    return r;
+  }
   const double *pF = kind == 1 ? pb : pa, *pW = kind == 1 ? pa : pb;
   const int oF = kind == 1 ? 3 : 0, oW = kind == 1 ? 0 : 3;
   const double gx = (f == 0) - (f == 2), gy = (f == 1) - (f == 3);
@@ -214,6 +237,11 @@ CFZP_FN double pair_row(const double *pa, const double *pb, const double g[4], i
     H[oF + 2][oF] = H[oF][oF + 2] = -dnx; H[oF + 2][oF + 1] = H[oF + 1][oF + 2] = -dny;
   }
   return nx * wx + ny * wy - gf;
+}
+// value of row rr of a pair block with working-set code sl; the second slot of a vertex-vertex block is inert (cfz::kVvInert)
+CFZP_FN double pair_value(const double *pa, const double *pb, const double g[4], int sl, int rr) {
+  const double v = pair_row<false>(pa, pb, g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, nullptr, nullptr);
+  return ((sl >> 6) == 3 && rr == 1) ? v + cfz::kVvInert : v;
 }
 // the two points of pair point r of pair e: same interval and collocation index in both vehicles' plans
 CFZP_FN void pair_points(const CSpec &sp, const CDims &d, int e, int r, int *qa, int *qb) {
@@ -276,8 +304,7 @@ CFZC_PIECE void constraints(const CSpec &sp, const unsigned char *sel, const dou
       pair_points(sp, d, e, r, &qa, &qb);
       const int pp = d.poff[e] + r, sl = sel[d.np * sp.n_obs + pp];
       for (int rr = 0; rr < 2; ++rr)
-        c[d.rP + 2 * pp + rr] = pair_row<false>(X + 7 * qa, X + 7 * qb, sp.g, sl >> 6, (sl >> 4) & 3, rr == 0 ? (sl >> 2) & 3 : sl & 3, nullptr, nullptr) -
-                                sp.dmin - X[d.sP + 2 * pp + rr];
+        c[d.rP + 2 * pp + rr] = pair_value(X + 7 * qa, X + 7 * qb, sp.g, sl, rr) - sp.dmin - X[d.sP + 2 * pp + rr];
     }
   }
   CFZP_SYNC();
@@ -541,7 +568,14 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
         }
         const double nr_ = nu[row];
         const int vtx = rr == 0 ? ((sl >> 2) & 3) : (sl & 3);
-        if ((sl >> 6) == 1) {  // polygon face (a0,a1), body vertex: d2/dpsi2 = -A_f.(R b_v)
+        if ((sl >> 6) == 3) {  // distance r of two vertices, n = (a0,a1): tau tau' / r - n.(R b_v) e_psi e_psi', tau = (-a1, a0, t.dw)
+          const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
+          const double rbx = cs * bx - sn * by, rby = sn * bx + cs * by, a0 = gr[rr][0], a1 = gr[rr][1];
+          const double nq = nr_ / sep[0], t2 = a1 * rby + a0 * rbx;  // sep[0] = r (the second slot's value carries the margin)
+          bnd(Bd, px[b], px[b]) += nq * a1 * a1; bnd(Bd, px[b + 1], px[b + 1]) += nq * a0 * a0; put(Bd, px[b], px[b + 1], -nq * a1 * a0);
+          put(Bd, px[b], px[b + 2], -nq * a1 * t2); put(Bd, px[b + 1], px[b + 2], nq * a0 * t2);
+          bnd(Bd, px[b + 2], px[b + 2]) += nq * t2 * t2 - nr_ * (a0 * rbx + a1 * rby);
+        } else if ((sl >> 6) == 1) {  // polygon face (a0,a1), body vertex: d2/dpsi2 = -A_f.(R b_v)
           const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
           bnd(Bd, px[b + 2], px[b + 2]) += nr_ * -(gr[rr][0] * (cs * bx - sn * by) + gr[rr][1] * (sn * bx + cs * by));
         } else {  // body face: d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
@@ -653,7 +687,6 @@ CFZC_PIECE int band_factor(const Band &B, int n, int *ipiv) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // The elimination for a band too wide for LDS (the joint plan: half-bandwidth ~100 per vehicle), from global memory with all
 // wavefronts of the workgroup.
-constexpr int kWideMaxKb = 448;
 // barrier that orders LDS traffic only: the global stores still in flight are not waited for (what is read after it was
 // either not written in this phase or is forwarded through LDS)
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1339,9 +1372,37 @@ CFZC_PIECE double barrier_obj(const CSpec &sp, const CWork &w, const double *X, 
   return objective(sp, X) - mu * bsum(s);
 }
 
-// refresh the working set at the poses of X; a block whose (face, vertices) change restarts its two rows
-CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
+// Hand-over of a block's two (slack, bound multiplier, row multiplier) triples when its working set changes from code o to
+// code n (sep: the values of the new rows).  The block stands for ONE constraint of the reference, dist(body, polygon) >= dmin,
+// whose value is continuous across a change of the closest features; restarting its rows at every change (slack pushed to
+// bound_push, z = mu / slack) made an active contact that flips between two certificates jump by bound_push in violation and
+// lose its multiplier each time: a limit cycle (vehicle_2 past a pillar corner, period 7, measured).  So:
+//   a row that keeps its (face, vertex) identity keeps its triple;
+//   else the tighter of the new rows takes over the triple of the tighter old row if the residual that leaves is small;
+//   any other row starts afresh at slack = max(sep - dmin, min(bound_push, max(mu, 1e-8))), z = mu / slack, nu = -z.
+constexpr double kHandover = 1e-2;
+CFZP_FN void handover(int o, int n, const double sep[2], double dmin, double mu, double bound_push, double s[2], double z[2], double nu[2]) {
+  const double so[2] = {s[0], s[1]}, zo[2] = {z[0], z[1]}, no[2] = {nu[0], nu[1]};
+  const int ov[2] = {(o >> 2) & 3, o & 3}, nv[2] = {(n >> 2) & 3, n & 3};
+  int src[2] = {-1, -1};
+  bool used[2] = {false, false};
+  if ((o >> 4) == (n >> 4) && (n >> 6) != 3)
+    for (int r = 0; r < 2; ++r)
+      for (int q = 0; q < 2; ++q) if (src[r] < 0 && !used[q] && nv[r] == ov[q]) { src[r] = q; used[q] = true; }
+  const int io = so[0] <= so[1] ? 0 : 1, in = sep[0] <= sep[1] ? 0 : 1;
+  if (src[in] < 0 && !used[io] && fabs(sep[in] - dmin - so[io]) <= kHandover) { src[in] = io; used[io] = true; }
+  const double push = fmin(bound_push, fmax(mu, 1e-8));
+  for (int r = 0; r < 2; ++r) {
+    if (src[r] >= 0) { s[r] = so[src[r]]; z[r] = zo[src[r]]; nu[r] = no[src[r]]; }
+    else { const double sg = fmax(sep[r] - dmin, push); s[r] = sg; z[r] = mu / sg; nu[r] = -mu / sg; }
+  }
+}
+
+// refresh the working set at the poses of X; a block whose (face, vertices) change hands its rows over (handover)
+// returns true if any block changed
+CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
   const CDims d = cdims(sp);
+  double chg = 0.0;
   CFZP_LANE_FOR(q, 0, d.np - 1) {
     const double *p = X + 7 * q;
     double sn, cs;
@@ -1350,14 +1411,17 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
       double A[4][2], b[4], V[4][2], sep[2];
       obstacle(sp, j, A, b, V);
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
-      const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old);
+      const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old, sp.vv_rows);
       if (nw != old) {
+        chg = 1.0;
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
         cfz::rows_for<false>(A, b, V, p[0], p[1], cs, sn, sp.g, nw, sep, nullptr);
-        for (int r = 0; r < 2; ++r) {
-          const int sk = d.sO + q * d.nr + 2 * j + r;
-          if (first) X[sk] = sep[r] - sp.dmin;  // pushed inside the bound afterwards
-          else { const double sg = fmax(sep[r] - sp.dmin, sp.bound_push); X[sk] = sg; w.zl[sk] = mu / sg; w.nu[d.rR + q * d.nr + 2 * j + r] = -mu / sg; }
+        const int sk = d.sO + q * d.nr + 2 * j, rk = d.rR + q * d.nr + 2 * j;
+        if (first) { X[sk] = sep[0] - sp.dmin; X[sk + 1] = sep[1] - sp.dmin; }  // pushed inside the bound afterwards
+        else {
+          double s_[2] = {X[sk], X[sk + 1]}, z_[2] = {w.zl[sk], w.zl[sk + 1]}, n_[2] = {w.nu[rk], w.nu[rk + 1]};
+          handover(old, nw, sep, sp.dmin, mu, sp.bound_push, s_, z_, n_);
+          for (int r = 0; r < 2; ++r) { X[sk + r] = s_[r]; w.zl[sk + r] = z_[r]; w.nu[rk + r] = n_[r]; }
         }
       }
     }
@@ -1371,27 +1435,33 @@ CFZC_PIECE void refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
     double A[4][2], b[4], V[4][2];
     veh_polygon(pb, sp.g, A, b, V);
     const int old = first ? 0 : w.sel[d.np * sp.n_obs + pp];
-    const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old);
+    const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old, sp.vv_rows);
     if (nw != old) {
+      chg = 1.0;
       w.sel[d.np * sp.n_obs + pp] = (unsigned char)nw;
-      for (int r = 0; r < 2; ++r) {
-        const double sep = pair_row<false>(pa, pb, sp.g, nw >> 6, (nw >> 4) & 3, r == 0 ? (nw >> 2) & 3 : nw & 3, nullptr, nullptr);
-        const int sk = d.sP + 2 * pp + r;
-        if (first) X[sk] = sep - sp.dmin;
-        else { const double sg = fmax(sep - sp.dmin, sp.bound_push); X[sk] = sg; w.zl[sk] = mu / sg; w.nu[d.rP + 2 * pp + r] = -mu / sg; }
+      double sep[2];
+      for (int r = 0; r < 2; ++r) sep[r] = pair_value(pa, pb, sp.g, nw, r);
+      const int sk = d.sP + 2 * pp, rk = d.rP + 2 * pp;
+      if (first) { X[sk] = sep[0] - sp.dmin; X[sk + 1] = sep[1] - sp.dmin; }
+      else {
+        double s_[2] = {X[sk], X[sk + 1]}, z_[2] = {w.zl[sk], w.zl[sk + 1]}, n_[2] = {w.nu[rk], w.nu[rk + 1]};
+        handover(old, nw, sep, sp.dmin, mu, sp.bound_push, s_, z_, n_);
+        for (int r = 0; r < 2; ++r) { X[sk + r] = s_[r]; w.zl[sk + r] = z_[r]; w.nu[rk + r] = n_[r]; }
       }
     }
   }
   CFZP_SYNC();
+  return bmax(chg) != 0.0;
 }
 
 // X: guess for the 7 variables of every point (vehicles back to back) followed by dt; solution out (same layout).
 // out_i = iterations, status; out_d = cost, err, mu, phase timers.  kb: half-bandwidth the caller sized the slab for
 // (half_bandwidth() of the ordering).  MODE (GPU only; 0 = the generic elimination everywhere): 1 = one wavefront, kb == kCB:
 // the kernel's dynamic LDS (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; 2 = several
-// wavefronts, band_factor_wide2 and, if the right-hand side fits the dynamic LDS (lds_doubles), band_substitute_wide.
+// wavefronts: the panel elimination if its multipliers fit the dynamic LDS (lds_doubles), else band_factor_wide2; lds_rhs: doubles
+// of the dynamic LDS a right-hand side may occupy (band_substitute_wide, the fallback substitution), 0 = it does not fit.
 template <int MODE>
-CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles) {
+CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles, int lds_rhs = 0) {
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
   const Band Bd = {w.ab, kb, 3 * kb + 1};
@@ -1429,7 +1499,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     ta = tick();
-    if (iter > 0) refresh_working_set(sp, w, w.x, mu, false);
+    // rows of a changed working set belong to another problem: the filter starts afresh (as in the MPC step)
+    if (iter > 0 && refresh_working_set(sp, w, w.x, mu, false)) nfilt = 0;
     constraints(sp, w.sel, w.x, w.c);
     gradient(sp, w.x, w.g);
     jt_nu(sp, w.sel, w.x, w.nu, w.r1);
@@ -1495,7 +1566,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
 #if defined(__HIP_DEVICE_COMPILE__)
         if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2, fwd_done);
-        else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_doubles) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
+        else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_rhs) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
         tk[3] += tick() - ta;
@@ -1576,6 +1647,9 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
       }
       if (ok) { accepted = true; break; }
+#if defined(CFZC_TRACE)
+      if (bt < 6 || bt == sp.max_backtrack - 1) printf("   bt %d alpha %.3e th_t %.6e (theta %.6e) ph_t %.10e (phi0 %.10e) dphi %.3e nfilt %d\n", bt, alpha, th_t, theta, ph_t, phi0, dphi, nfilt);
+#endif
       alpha *= 0.5;
     }
     bool nu_done = false;

@@ -58,12 +58,13 @@ __global__ __launch_bounds__(512) void state_ws_kernel_wide(int B, const cfzp::P
 // elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
 template <int MODE>
 __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
-                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles) {
+                              const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles, int lds_rhs) {
   const int b = blockIdx.x;
-  // dynamic LDS: MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2 one
-  // right-hand side of the substitution (lds_doubles of them, 0 = none)
+  // dynamic LDS (lds_doubles): MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2
+  // the multipliers of a panel during the elimination; lds_rhs (<= lds_doubles, 0 = none): room for one right-hand side of the
+  // fallback substitution
   if (b >= B) return;
-  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles);
+  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles, lds_rhs);
 }
 
 }  // namespace
@@ -79,6 +80,9 @@ namespace {
 // the thread (so that a caller of the plain signatures also stops paying hipMalloc/hipFree per call)
 cfz_plan_ws *default_ws(int device) {
   thread_local std::vector<cfz_plan_ws *> cache;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fail("no HIP device: libconfrez_hip has no CPU path"); return nullptr; }
+  if (device < 0 || device >= ndev) { fail("device index out of range"); return nullptr; }
   if ((int)cache.size() <= device) cache.resize(device + 1, nullptr);
   if (!cache[device] && cfz_plan_ws_create(device, &cache[device]) != 0) return nullptr;
   return cache[device];
@@ -297,7 +301,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
     // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
     // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0); p.curv_kappa = co->curv_kappa;
+    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);
@@ -342,13 +346,27 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   if (!wide) {
     const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
     HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles);
+    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles, 0);
   } else {
-    int nk_max = 0;  // the right-hand side of the largest instance in LDS if it fits beside the static arrays of the elimination
-    for (int b = 0; b < B; ++b) nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk);
-    const int lds_doubles = (size_t)nk_max * 8 <= 120 * 1024 ? nk_max : 0;
+    // Dynamic LDS beside the kernel's static arrays (read from the code object, not assumed): the panel's multipliers
+    // (CFZ_PANEL x (kb + CFZ_PANEL) doubles, <= 58 KB) must fit; a right-hand side of the largest instance rides along only if it
+    // fits as well (it serves band_substitute_wide, the fallback substitution) -- the panel path does not depend on it.
+    int nk_max = 0, kb_max = 0, lds_max = 0;
+    for (int b = 0; b < B; ++b) { nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk); kb_max = std::max(kb_max, (int)kbs[b]); }
+    hipFuncAttributes fa;
+    HIP_OK(hipFuncGetAttributes(&fa, (const void *)colloc_kernel<2>));
+    HIP_OK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, w->device));
+    {  // gfx950: a workgroup may own the whole LDS of its CU (160 KB); some runtimes report the smaller legacy figure per block
+      int per_cu = 0;
+      if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, w->device) == hipSuccess) lds_max = std::max(lds_max, per_cu);
+    }
+    if (std::getenv("CFZ_COLLOC_PROFILE")) fprintf(stderr, "cfz_colloc: LDS per workgroup %d B, static %zu B\n", lds_max, (size_t)fa.sharedSizeBytes);
+    const long long avail = ((long long)lds_max - (long long)fa.sharedSizeBytes) / 8;
+    const long long pl = kb_max <= cfzc::kWideMaxKb ? (long long)CFZ_PANEL * (kb_max + CFZ_PANEL) : 0;
+    const int lds_rhs = nk_max <= avail ? nk_max : 0;
+    const int lds_doubles = (int)std::max<long long>(pl <= avail ? pl : 0, lds_rhs);
     if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles);
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs);
   }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
@@ -413,7 +431,7 @@ int cfz_joint_colloc_w(cfz_plan_ws *w, int B, int V, const cfz_spec *spec, const
 
 void cfz_default_colloc_options(cfz_colloc_options *o) {
   memset(o, 0, sizeof *o);
-  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5;
+  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5; o->vv_rows = 1;
   // mu_init: IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations
   o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1; o->curv_kappa = 1e-8;
 }

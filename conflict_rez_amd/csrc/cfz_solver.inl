@@ -364,6 +364,7 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // in the other's normal cone; no face normal certifies their distance, so the row is the Euclidean distance |W_v - V_u| itself,
 // imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
+constexpr double kVvInert = 1.0;  // m: margin of the second slot of a vertex-vertex block in the planning kernels (rows_for)
 constexpr int kWsStallDiv = 4;  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
 
 template <bool GRAD>
@@ -517,10 +518,10 @@ CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, c
 }
 
 CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                       double s, const double g[4], int prev) {  // face rows only (the planning kernels)
+                       double s, const double g[4], int prev, int vv = 0) {  // the planning kernels (values come from rows_for)
   double D[8][4], dsel[4], px[4], py[4];
   block_dists(A, b, V, x, y, c, s, g, D, px, py);
-  return select_from(D, prev, dsel, 0, V, px, py);
+  return select_from(D, prev, dsel, vv, V, px, py);
 }
 
 // working set AND the values of its two rows in one pass (the rows are two of the distances the selection looked at)
@@ -534,9 +535,27 @@ CFZ_CALL int select_rows_sep(const double A[4][2], const double b[4], const doub
 }
 
 // values (and gradients wrt x,y,psi) of the two rows of working set `sel`
+// (the MPC solver itself imposes a vertex-vertex row twice, block_sep / block_grad below; the planning kernels, through rows_for,
+// keep the second slot inert: value r + kVvInert, same gradient)
 template <bool GRAD>
 CFZ_CALL void rows_for(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
                      double s, const double g[4], int sel, double sep[2], double grad[2][3]) {
+  if ((sel >> 6) == 3) {  // vertex-vertex: polygon vertex u, body vertex v, the row is their distance (twice)
+    const int u = (sel >> 4) & 3, v = sel & 3;
+    double ux = V[0][0], uy = V[0][1];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i == u) { ux = V[i][0]; uy = V[i][1]; }
+    const double bx = (v == 0 || v == 3) ? g[0] : -g[2], by = (v < 2) ? g[1] : -g[3];
+    const double dwx = -s * bx - c * by, dwy = c * bx - s * by;  // d(R b_v)/dpsi; R b_v = (dwy, -dwx)
+    const double wx = x + dwy - ux, wy = y - dwx - uy;
+    const double r = sqrt(wx * wx + wy * wy), ir = 1.0 / r;
+    sep[0] = r; sep[1] = r + kVvInert;  // the block's second slot restates the row with a margin: always inactive
+    if (GRAD) {
+      const double n0 = wx * ir, n1 = wy * ir, n2 = n0 * dwx + n1 * dwy;
+      grad[0][0] = n0; grad[0][1] = n1; grad[0][2] = n2; grad[1][0] = n0; grad[1][1] = n1; grad[1][2] = n2;
+    }
+    return;
+  }
   double d[4], gr[4][3];
   vertex_dist<GRAD>(A, b, V, x, y, c, s, g, sel >> 6, (sel >> 4) & 3, d, gr);
   const int va = (sel >> 2) & 3, vb = sel & 3;

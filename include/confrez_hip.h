@@ -240,6 +240,11 @@ typedef struct cfz_colloc_options {
   int32_t one_pivot;      /* 0: the band is eliminated a panel of 16 pivots at a time (single plans: for batches up to two per CU);
                            *    1: one pivot at a time -- joint plan: same pivots, same arithmetic per entry, same factor; single
                            *    plans: the one-wavefront kernel with its LDS window.  Kept as the check of the panel version, ~2x slower */
+  int32_t vv_rows;        /* 1 (default): a (point, obstacle) or (point, pair of vehicles) block whose closest features are two
+                           *    vertices is constrained by their Euclidean distance -- the reference's OBCA rows admit any unit
+                           *    direction (vehicle.py:523-541, multi_vehicle_planner.py:419-451); 0: face-normal certificates only
+                           *    (a restriction at corner-to-corner contacts, kept to show the gap) */
+  int32_t reserved0;
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */

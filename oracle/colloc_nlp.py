@@ -12,7 +12,19 @@ The single-vehicle collocation plan (reference confrez/control/vehicle.py:360-66
 """
 import numpy as np
 
-from .mpc_nlp import G_BODY, body_vertices, certificate_duals, polytope_vertices, rot, rows_for, select_rows
+from .mpc_nlp import G_BODY, body_vertices, certificate_duals, polytope_vertices, rot, select_rows
+from .mpc_nlp import rows_for as _mpc_rows_for
+
+VV_INERT = 1.0  # m: the second slot of a vertex-vertex block restates the row with this margin (cfz::kVvInert): always inactive
+
+
+def rows_for(A, b, PV, t, psi, g, BV, sel):
+    """The two rows of a block as the planning kernels impose them: oracle/mpc_nlp.py rows_for, except that a vertex-vertex block
+    (kind 3) carries its distance row once -- the second slot is the same row plus VV_INERT (the MPC step imposes it twice)."""
+    sep, gr = _mpc_rows_for(A, b, PV, t, psi, g, BV, sel)
+    if sel >> 6 == 3:
+        sep = sep + np.array([0.0, VV_INERT])
+    return sep, gr
 
 K_PTS = 6
 
@@ -48,10 +60,13 @@ class JointCollocNlp:
     c = [init 7 per vehicle | ODE | continuity | obstacle rows | tube rows | terminal 5 per vehicle | pair rows]."""
 
     def __init__(self, vehicles, A_obs, b_obs, N_per_set=5, K=5, dmin=0.05, shrink_tube=0.5, wb=2.5, g=(3.3, 0.9, 0.6, 0.9),
-                 bounds=None, pairs=None):
+                 bounds=None, pairs=None, vv=True):
         """vehicles: list of dict(init_pose, tube (list over strategy steps of dict(front=(A, b), back=(A, b))), final_heading);
-        pairs: list of (a, b) index pairs, default all (multi_vehicle_planner.py:56-58)."""
+        pairs: list of (a, b) index pairs, default all (multi_vehicle_planner.py:56-58); vv: vertex-vertex rows (kind 3 of
+        oracle/mpc_nlp.py select_rows) in the working sets of the obstacle and the pair blocks (the product's default,
+        cfz_colloc_options.vv_rows = 1; False = face-normal certificates only, a restriction)."""
         assert K == 5
+        self.vv = bool(vv)
         self.V, self.Nps, self.veh = len(vehicles), N_per_set, vehicles
         self.N = [N_per_set * (len(v["tube"]) - 1) for v in vehicles]
         self.n_chk = [len(v["tube"]) - 1 for v in vehicles]
@@ -97,13 +112,13 @@ class JointCollocNlp:
         prev = np.zeros_like(sel) if prev is None else np.asarray(prev).ravel()
         for q in range(self.np):
             for j in range(self.n_obs):
-                sel[q * self.n_obs + j] = select_rows(self.A_obs[j], self.b_obs[j], self.PV[j], P[q, :2], P[q, 2], self.g, self.BV, int(prev[q * self.n_obs + j]))
+                sel[q * self.n_obs + j] = select_rows(self.A_obs[j], self.b_obs[j], self.PV[j], P[q, :2], P[q, 2], self.g, self.BV, int(prev[q * self.n_obs + j]), vv=self.vv)
         for e in range(len(self.pairs)):
             for r in range(self.poff[e + 1] - self.poff[e]):
                 qa, qb = self.pair_points(e, r)
                 A, b, PV = body_polygon(P[qb, :3], self.g, self.BV)
                 i = self.np * self.n_obs + self.poff[e] + r
-                sel[i] = select_rows(A, b, PV, P[qa, :2], P[qa, 2], self.g, self.BV, int(prev[i]))
+                sel[i] = select_rows(A, b, PV, P[qa, :2], P[qa, 2], self.g, self.BV, int(prev[i]), vv=self.vv)
         return sel
 
     def f(self, X):
@@ -178,7 +193,11 @@ class JointCollocNlp:
                         c_ = int(sel[q * self.n_obs + j])
                         sep, _ = rows_for(self.A_obs[j], self.b_obs[j], self.PV[j], p[:2], p[2], self.g, self.BV, c_)
                         v = (c_ >> 2) & 3 if sep[0] <= sep[1] else c_ & 3
-                        l[il, k, 4 * j : 4 * j + 4], m[il, k, 4 * j : 4 * j + 4] = certificate_duals(self.A_obs[j], self.adj[j], p[2], (c_ >> 6, (c_ >> 4) & 3, v))
+                        nvec = None
+                        if c_ >> 6 == 3:  # unit vector from the obstacle's vertex to the body's
+                            w_ = p[:2] + rot(p[2]) @ self.BV[v] - self.PV[j][(c_ >> 4) & 3]
+                            nvec = w_ / np.hypot(*w_)
+                        l[il, k, 4 * j : 4 * j + 4], m[il, k, 4 * j : 4 * j + 4] = certificate_duals(self.A_obs[j], self.adj[j], p[2], (c_ >> 6, (c_ >> 4) & 3, v), n=nvec)
             sol["l"], sol["m"] = l, m
             sols.append(sol)
         duals = []
@@ -188,7 +207,11 @@ class JointCollocNlp:
             for r in range(nmin * K_PTS):
                 qa, qb = self.pair_points(e, r)
                 c_ = int(sel[self.np * self.n_obs + self.poff[e] + r])
-                la, mb = certificate_duals(None, None, P[qa, 2], (c_ >> 6, (c_ >> 4) & 3, 0), P[qb, 2])
+                nvec = None
+                if c_ >> 6 == 3:  # unit vector from vertex u of the second body to vertex v of the first
+                    w_ = P[qa, :2] + rot(P[qa, 2]) @ self.BV[c_ & 3] - P[qb, :2] - rot(P[qb, 2]) @ self.BV[(c_ >> 4) & 3]
+                    nvec = w_ / np.hypot(*w_)
+                la, mb = certificate_duals(None, None, P[qa, 2], (c_ >> 6, (c_ >> 4) & 3, 0), P[qb, 2], n=nvec)
                 lam[r // K_PTS, r % K_PTS], mu[r // K_PTS, r % K_PTS] = la, mb
                 sv[r // K_PTS, r % K_PTS] = -rot(P[qa, 2]) @ (G_BODY.T @ la)  # from A_this' lam + s = 0
             duals.append(dict(lam=lam, mu=mu, s=sv))
@@ -199,9 +222,9 @@ class CollocNlp(JointCollocNlp):
     """The single-vehicle plan (V = 1) with the constructor and result shapes of the first version of this module."""
 
     def __init__(self, init_pose, tube, A_obs, b_obs, N_per_set=5, K=5, dmin=0.05, shrink_tube=0.5, final_heading=None,
-                 wb=2.5, g=(3.3, 0.9, 0.6, 0.9), bounds=None):
+                 wb=2.5, g=(3.3, 0.9, 0.6, 0.9), bounds=None, vv=True):
         super().__init__([dict(init_pose=init_pose, tube=tube, final_heading=final_heading)], A_obs, b_obs, N_per_set=N_per_set, K=K,
-                         dmin=dmin, shrink_tube=shrink_tube, wb=wb, g=g, bounds=bounds, pairs=[])
+                         dmin=dmin, shrink_tube=shrink_tube, wb=wb, g=g, bounds=bounds, pairs=[], vv=vv)
         self.S, self.tube, self.init_pose, self.final_heading = len(tube), tube, np.asarray(init_pose, float), final_heading
         self.N1 = self.N[0]
 

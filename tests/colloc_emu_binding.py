@@ -13,7 +13,7 @@ MAX_VEH, MAX_PAIRS = 4, 6
 
 
 class CSpec(C.Structure):
-    _fields_ = ([(k, C.c_int) for k in "V Nps n_obs n_pairs max_iter max_backtrack filter_cap no_prox".split()] +
+    _fields_ = ([(k, C.c_int) for k in "V Nps n_obs n_pairs max_iter max_backtrack filter_cap no_prox vv_rows pad0".split()] +
                 [("N", C.c_int * MAX_VEH), ("n_chk", C.c_int * MAX_VEH), ("has_final", C.c_int * MAX_VEH),
                  ("pair_a", C.c_int * MAX_PAIRS), ("pair_b", C.c_int * MAX_PAIRS)] +
                 [(k, C.c_double) for k in "wb dmin shrink dt0".split()] +
@@ -48,6 +48,7 @@ def make_spec(nlp, opt):
     s.V, s.Nps, s.n_obs, s.n_pairs = nlp.V, nlp.Nps, nlp.n_obs, len(nlp.pairs)
     s.max_iter, s.max_backtrack, s.filter_cap = opt.max_iter, opt.max_backtrack, opt.filter_cap
     s.no_prox = int(getattr(opt, "no_prox", 0))  # 1: IPOPT's form of the dual regularisation (exact solutions at tight tolerances)
+    s.vv_rows = int(getattr(nlp, "vv", 0))  # vertex-vertex rows in the working sets, as the numpy statement selects them
     s.wb, s.dmin, s.shrink = nlp.wb, nlp.dmin, nlp.shrink
     keep = []
     for a, v in enumerate(nlp.veh):

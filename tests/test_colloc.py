@@ -54,14 +54,24 @@ def test_collocation_tables():
     assert np.allclose(A, A2) and np.allclose(B, B2) and np.allclose(D, D2)
 
 
-def test_colloc_source_values_and_derivatives(plans):
+def _corner_pose(corner, psi, v, off, g=(3.3, 0.9, 0.6, 0.9)):
+    """Pose whose body vertex v sits at corner + off: with off pointing out of the corner's quadrant and the corner inside the body
+    vertex's normal cone the two vertices are each other's closest feature (a kind-3 block)."""
+    bv = np.array([[g[0], g[1]], [-g[2], g[1]], [-g[2], -g[3]], [g[0], -g[3]]])[v]
+    c, s_ = np.cos(psi), np.sin(psi)
+    return np.array([corner[0] + off[0] - (c * bv[0] - s_ * bv[1]), corner[1] + off[1] - (s_ * bv[0] + c * bv[1]), psi])
+
+
+@pytest.mark.parametrize("vv", [False, True])
+def test_colloc_source_values_and_derivatives(plans, vv):
     """Objective and constraints equal the numpy statement; gradient, J'nu, the assembled Jacobian and the assembled
-    Hessian of the Lagrangian (dt border included) equal central differences; the permuted system is banded."""
+    Hessian of the Lagrangian (dt border included) equal central differences; the permuted system is banded.
+    vv: with vertex-vertex rows in the working set (three points posed corner to corner with an obstacle)."""
     import colloc_emu_binding as ce
 
     tube, p = plans["vehicle_0"]
     sp = scenarios.parking_lot_spec()
-    nlp = CollocNlp(p[0], tube[:3], sp.A_obs, sp.b_obs, N_per_set=2, final_heading=0.3)
+    nlp = CollocNlp(p[0], tube[:3], sp.A_obs, sp.b_obs, N_per_set=2, final_heading=0.3, vv=vv)
     opt = ipm.IpmOptions(**COLLOC_OPT)
     d = ce.dims(nlp, opt)
     assert (d["n"], d["m"], d["iDt"], d["sO"], d["sT"], d["rR"], d["rF"], d["rP"]) == (nlp.n, nlp.m, nlp.iDt, nlp.sO, nlp.sT, nlp.rR, nlp.rF, nlp.rP)
@@ -70,11 +80,17 @@ def test_colloc_source_values_and_derivatives(plans):
     P = X[: nlp.iDt].reshape(nlp.np, 7)
     P[:, :3] = p[np.linspace(0, 60, nlp.np).astype(int)] + 0.05 * rng.standard_normal((nlp.np, 3))
     P[:, 3:] = 0.3 * rng.standard_normal((nlp.np, 4))
+    if vv:  # rear-right, rear-left and front-left body corners against corners of obstacles 0, 3 and 4
+        P[3, :3] = _corner_pose((14.65, 13.75), 0.3, 2, (0.3, 0.25))
+        P[7, :3] = _corner_pose((14.65, 21.25), -0.4, 1, (0.2, -0.3))
+        P[10, :3] = _corner_pose((17.85, 21.25), 2.6, 0, (-0.15, -0.2))
     X[nlp.iDt] = 0.7
     X[nlp.sO :] = rng.uniform(0.1, 1.0, nlp.n - nlp.sO)
     nu = rng.standard_normal(nlp.m)
     sel = ce.select(nlp, opt, X)
-    assert (sel == nlp.select(X).ravel()).all() and len(set(sel.ravel() >> 6)) == 2  # both kinds of certificate are exercised
+    # all kinds of certificate are exercised
+    assert (sel == nlp.select(X).ravel()).all() and set((sel.ravel() >> 6).tolist()) == ({1, 2, 3} if vv else {1, 2})
+    assert not vv or (sel.ravel() >> 6 == 3).sum() >= 3
     f, c, g, jt = ce.evaluate(nlp, opt, sel, X, nu)
     assert abs(f - nlp.f(X)) < 1e-12 and np.abs(c - nlp.cons(X, sel)).max() < 1e-12
     h, n = 1e-6, nlp.n
@@ -191,7 +207,7 @@ def test_planner_single_problems_then_joint_dual_ws(tmp_path):
 
 
 # ---- the joint plan (multi_vehicle_planner.py:343-480): several vehicles, one shared dt, pairwise separation rows ----
-def _joint_problem(plans, agents, nsets, n_obs=6, nps=2, headings=None):
+def _joint_problem(plans, agents, nsets, n_obs=6, nps=2, headings=None, vv=True):
     from oracle.colloc_nlp import JointCollocNlp
 
     sp = scenarios.parking_lot_spec()
@@ -201,16 +217,18 @@ def _joint_problem(plans, agents, nsets, n_obs=6, nps=2, headings=None):
         tube = tube[:ns] if ns else tube
         fh = (float(p[-1, 2]) if not ns else 0.3) if headings is None else headings[i]
         vehs.append(dict(init_pose=p[0], tube=tube, final_heading=fh))
-    return JointCollocNlp(vehs, sp.A_obs[:n_obs], sp.b_obs[:n_obs], N_per_set=nps), sp
+    return JointCollocNlp(vehs, sp.A_obs[:n_obs], sp.b_obs[:n_obs], N_per_set=nps, vv=vv), sp
 
 
-def test_joint_source_values_and_derivatives(plans):
+@pytest.mark.parametrize("vv", [False, True])
+def test_joint_source_values_and_derivatives(plans, vv):
     """Three vehicles with plans of different lengths, one without terminal heading, all pairs: values against the numpy
     statement; gradient, J'nu and the assembled matrix (time-interleaved blocks, dt border, obstacle AND pair rows condensed,
-    6 x 6 pair curvature) against central differences / the Schur complement of the full KKT matrix."""
+    6 x 6 pair curvature) against central differences / the Schur complement of the full KKT matrix.
+    vv: with vertex-vertex rows (body corner against body corner) in the pair working sets."""
     import colloc_emu_binding as ce
 
-    nlp, _ = _joint_problem(plans, ["vehicle_0", "vehicle_1", "vehicle_3"], [3, 4, 3], n_obs=2, headings=[0.3, None, 0.3])
+    nlp, _ = _joint_problem(plans, ["vehicle_0", "vehicle_1", "vehicle_3"], [3, 4, 3], n_obs=2, headings=[0.3, None, 0.3], vv=vv)
     opt = ipm.IpmOptions(**COLLOC_OPT)
     d = ce.dims(nlp, opt)
     assert (d["n"], d["m"], d["sP"], d["rP"], d["rF"], d["npp"]) == (nlp.n, nlp.m, nlp.sP, nlp.rP, nlp.rF, nlp.npp) and nlp.npp == 72
@@ -228,7 +246,8 @@ def test_joint_source_values_and_derivatives(plans):
     nu = rng.standard_normal(nlp.m)
     nu[nlp.rF + 5 * 1 + 4] = 0.0  # the dead heading row of the vehicle without a terminal heading
     sel = ce.select(nlp, opt, X)
-    assert (sel == nlp.select(X)).all() and set((sel[nlp.np * nlp.n_obs :] >> 6).tolist()) == {1, 2}
+    kinds = (sel[nlp.np * nlp.n_obs :] >> 6).tolist()
+    assert (sel == nlp.select(X)).all() and set(kinds) == ({1, 2, 3} if vv else {1, 2}) and (not vv or kinds.count(3) >= 3)
     f, c, g, jt = ce.evaluate(nlp, opt, sel, X, nu)
     assert abs(f - nlp.f(X)) < 1e-11 and np.abs(c - nlp.cons(X, sel)).max() < 1e-11
     h, n = 1e-6, nlp.n

@@ -251,29 +251,38 @@ def test_planner_surface_four_vehicles(tmp_path):
                 assert separated(poly(fr[agents[ia]], i), poly(fr[agents[ib]], i)), (i, ia, ib)
 
 
-@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_2", "vehicle_3"])
+@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_2", "vehicle_3", "vehicle_1_pillar", "vehicle_2_pillar", "vehicle_3_pillar"])
 def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     """`cfz_colloc` (HIP, through the C ABI) from the fixture's guess against the optimum an INDEPENDENT solver found on an
     independent statement of the reference's single-vehicle plan (tests/golden/colloc_independent.npz: polygon distances, no
     working sets, no condensation, SuperLU on the full KKT system; vehicle.py:360-661, N = 30 / 30 / 40 intervals, free dt) --
     not against the CPU compile of the kernel's own source.  At the reference's tolerance 1e-2: rows of the geometric statement to
     1e-2, cost within 3e-3 of the optimum, poses within 5 mm, dt within 1e-3 s; at tight tolerances (`exact_rows`) the optimum
-    itself.  Assertions shared with the CPU test (tests/test_independent_solver.py:check_plan_against_independent)."""
+    itself.  Assertions shared with the CPU test (tests/test_independent_solver.py:check_plan_against_independent).
+    The `_pillar` plans (tests/golden/colloc_independent_vv.npz) carry a seventh obstacle whose corner is in contact with a corner of
+    the body at the optimum, multiplier 0.5 ... 23: there the kernel's vertex-vertex rows (`vv_rows`, the default) are what makes
+    its feasible set the reference's (vehicle.py:523-541); with `vv_rows = 0` the same launch ends feasible but dearer."""
+    import dataclasses
+
     from conflict_rez_amd import engine
     from test_independent_solver import _colloc_fixture, check_plan_against_independent
 
     d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
     tb = [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in tube[1:]]
     guess = d["guess"][:-1].reshape(-1, 7)
-    r = engine.colloc(scenarios.parking_lot_spec(n_nbr=0, N=2), [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=400)[0]
+    spec = dataclasses.replace(scenarios.parking_lot_spec(n_nbr=0, N=2), A_obs=sp.A_obs, b_obs=sp.b_obs)
+    r = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=400)[0]
     assert r["status"] == 0 and r["iters"] < 60
     check_plan_against_independent(r["traj"], r["dt"], False, agent)
+    if agent.endswith("_pillar"):  # the gap face-normal certificates leave (CPU twin: test_face_normal_rows_alone_restrict_...)
+        r0 = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1, vv_rows=0)[0]
+        z0 = np.append(r0["traj"].ravel(), r0["dt"])
+        assert np.abs(g.eq(z0)).max() < 1e-7 and g.ineq(z0).min() > -1e-7 and (g.cost(z0) - float(d["value"])) / float(d["value"]) > 2e-5
     # the same kernel at tight tolerances with IPOPT's form of the dual regularisation (`exact_rows`): the independent optimum
     # itself (vehicle_1: status 0, cost to 1e-8, poses to 1e-6 m; vehicles 2, 3: the unregularised rows lose rank where the vehicle
     # waits and the solve ends with status 2 / 3 at the optimum, cost to 1e-6, poses to 1e-5 m)
-    r2 = engine.colloc(scenarios.parking_lot_spec(n_nbr=0, N=2), [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8,
-                       constr_viol_tol=1e-9, exact_rows=1)[0]
-    assert r2["status"] == 0 or (agent != "vehicle_1" and r2["status"] in (2, 3)), (r2["status"], r2["iters"])
+    r2 = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)[0]
+    assert r2["status"] == 0 or (agent not in ("vehicle_1", "vehicle_1_pillar") and r2["status"] in (2, 3)), (r2["status"], r2["iters"])
     check_plan_against_independent(r2["traj"], r2["dt"], True, agent)
 
 

@@ -341,9 +341,18 @@ def _colloc_fixture(agent="vehicle_1"):
     from make_independent_colloc import problem
     from oracle.independent_colloc import GeometricColloc
 
-    f = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
-    d = {k: f[f"{agent}_{k}"] for k in ("guess", "traj", "dt", "cost")}
-    tube, p, fh, sp = problem(agent)
+    if agent.endswith("_pillar"):  # a plan with a corner-to-corner contact: seventh obstacle, make_independent_colloc_vv.py
+        import dataclasses
+
+        f = np.load(os.path.join(here, "golden", "colloc_independent_vv.npz"))
+        d = {k: f[f"{agent}_{k}"] for k in ("guess", "traj", "dt", "cost", "value", "contacts")}
+        tube, p, fh, sp = problem(agent[: -len("_pillar")])
+        sp = dataclasses.replace(sp, A_obs=np.concatenate([sp.A_obs, [f[f"{agent}_A"]]]), b_obs=np.concatenate([sp.b_obs, [f[f"{agent}_b"]]]))
+    else:
+        f = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
+        d = {k: f[f"{agent}_{k}"] for k in ("guess", "traj", "dt", "cost")}
+        d["value"] = d["cost"]
+        tube, p, fh, sp = problem(agent)
     return d, GeometricColloc(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh), (tube, p, fh, sp)
 
 
@@ -352,18 +361,67 @@ def check_plan_against_independent(traj, dt, tight, agent="vehicle_1"):
     satisfies the GEOMETRIC statement of the reference's rows (ODE at all points, continuity, tube, polygon distances >= dmin,
     boxes; oracle/independent_colloc.py) and is the independent optimum: cost to 1e-6 / poses to 1e-5 m at tight tolerances
     (vehicle_1: 1e-8 / 1e-6); at the reference's tolerance 1e-2 the rows hold to 1e-2, the cost is within 3e-3 (below: the
-    rows are relaxed by the tolerance) and the poses within 5 mm."""
+    rows are relaxed by the tolerance) and the poses within 5 mm.  The `_pillar` plans (corner-to-corner contact active at the
+    optimum) are compared with the fixture's `value` (the independent cost corrected to first order for its own row residuals):
+    1e-6; poses of vehicle_1_pillar to 5e-4 m (measured 5e-5: the independent solver stops with rows at 1e-8 there)."""
     d, g, _ = _colloc_fixture(agent)
     z = np.append(np.asarray(traj, float).ravel(), float(dt))
     eq, ineq = np.abs(g.eq(z)).max(), g.ineq(z).min()
-    gap = (g.cost(z) - float(d["cost"])) / float(d["cost"])
+    gap = (g.cost(z) - float(d["value"])) / float(d["value"])
     dpose, ddt = np.abs(np.asarray(traj)[..., :3] - d["traj"][..., :3]).max(), abs(float(dt) - float(d["dt"]))
     if tight:
-        lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else (1e-6, 1e-5, 1e-7)
+        lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else ((1e-6, 5e-4, 5e-6) if agent == "vehicle_1_pillar" else (1e-6, 1e-5, 1e-7))
         assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < lim[0] and dpose < lim[1] and ddt < lim[2], (agent, eq, ineq, gap, dpose, ddt)
     else:
         assert eq < 1e-2 and ineq > -1e-2 and -3e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (agent, eq, ineq, gap, dpose, ddt)
     return gap, dpose
+
+
+VV_PLANS = ("vehicle_1_pillar", "vehicle_2_pillar", "vehicle_3_pillar")  # tests/golden/make_independent_colloc_vv.py
+
+
+def _solve_plan_on_cpu(agent, tight, vv=True):
+    import colloc_emu_binding as ce
+    import test_colloc as tc
+    from oracle.colloc_nlp import CollocNlp
+
+    d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh, vv=vv)
+    X0 = nlp.pack({k: d["guess"][:-1].reshape(-1, 7)[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}, float(d["guess"][-1]))
+    if tight:
+        opt = ipm.IpmOptions(max_iter=800, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
+        opt.no_prox = 1
+    else:
+        opt = ipm.IpmOptions(**tc.COLLOC_OPT)
+    r = ce.solve(nlp, X0, opt)
+    P, dt = g.split(r["X"][: nlp.iDt + 1])
+    return r, P, dt, d, g
+
+
+@pytest.mark.parametrize("agent", VV_PLANS)
+@pytest.mark.parametrize("tight", [True, False])
+def test_corner_to_corner_plan_against_the_independent_solver(tight, agent):
+    """Plans whose optimum has an ACTIVE vertex-vertex contact (a pillar's corner against the outer front corner of the turning
+    body): the planning kernel's source (CPU build) with vertex-vertex rows, from the fixture's guess, ends at the optimum the
+    independent solver found on the geometric statement of the reference's rows (vehicle.py:523-541) -- the kernel's feasible set
+    is the reference's there, not a face-normal restriction of it."""
+    r, P, dt, d, _ = _solve_plan_on_cpu(agent, tight)
+    assert r["status"] == 0 or (tight and agent != "vehicle_1_pillar" and r["status"] in (2, 3)), r["status"]
+    assert not tight or r["status"] == 0 or agent == "vehicle_2_pillar"  # vehicle_2 waits at the start: rank loss, as without the pillar
+    assert (d["contacts"][:, 2] > 0.1).any()  # the fixture holds such a contact with a multiplier well above zero
+    check_plan_against_independent(P, dt, tight, agent)
+
+
+@pytest.mark.parametrize("agent,least", [("vehicle_1_pillar", 5e-5), ("vehicle_2_pillar", 2e-5), ("vehicle_3_pillar", 1e-3)])
+def test_face_normal_rows_alone_restrict_the_collocation_plan(agent, least):
+    """The gap `vv_rows = 0` leaves: with face-normal certificates only (round 2's planning kernels) the same instances end feasible
+    for the reference's rows but dearer than the optimum -- by 0.014 %, 0.004 % and 5.2 % (another local optimum) -- because at the corner-to-corner contact
+    the best face normal certifies less than the distance of the two corners."""
+    r, P, dt, d, g = _solve_plan_on_cpu(agent, True, vv=False)
+    z = np.append(P.ravel(), dt)
+    assert np.abs(g.eq(z)).max() < 1e-7 and g.ineq(z).min() > -1e-7
+    gap = (g.cost(z) - float(d["value"])) / float(d["value"])
+    assert gap > least, gap
 
 
 @pytest.mark.parametrize("agent", COLLOC_AGENTS)
@@ -378,7 +436,7 @@ def test_full_size_collocation_plan_against_the_independent_solver(tight, agent)
     from oracle.colloc_nlp import CollocNlp
 
     d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
-    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh, vv=True)
     X0 = nlp.pack({k: d["guess"][:-1].reshape(-1, 7)[:, c] for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))}, float(d["guess"][-1]))
     if tight:
         opt = ipm.IpmOptions(max_iter=800, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
@@ -391,7 +449,7 @@ def test_full_size_collocation_plan_against_the_independent_solver(tight, agent)
     check_plan_against_independent(P, dt, tight, agent)
 
 
-@pytest.mark.parametrize("agent", COLLOC_AGENTS)
+@pytest.mark.parametrize("agent", COLLOC_AGENTS + VV_PLANS)
 def test_independent_collocation_fixture_is_a_kkt_point(agent):
     """Certificate of the fixtures that needs no solver: at the stored plan the gradient of the cost is a combination of the
     gradients of the equality rows and of the ACTIVE inequality rows and bounds of the geometric statement with multipliers of
@@ -400,7 +458,7 @@ def test_independent_collocation_fixture_is_a_kkt_point(agent):
 
     d, g, _ = _colloc_fixture(agent)
     z = np.append(d["traj"].ravel(), float(d["dt"]))
-    assert np.abs(g.eq(z)).max() < 2e-8 and g.ineq(z).min() > -1e-8 and abs(g.cost(z) - float(d["cost"])) < 1e-9
+    assert np.abs(g.eq(z)).max() < (2e-8 if agent != "vehicle_1_pillar" else 5e-8) and g.ineq(z).min() > -1e-8 and abs(g.cost(z) - float(d["cost"])) < 1e-9
     act = np.nonzero(g.ineq(z) < 1e-6)[0]
     lo = np.array([b[0] if b[0] is not None else -np.inf for b in g.bounds()])
     hi = np.array([b[1] if b[1] is not None else np.inf for b in g.bounds()])
