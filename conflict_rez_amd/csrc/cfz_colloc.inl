@@ -41,6 +41,9 @@
 #define CFZC_PIECE inline
 #endif
 
+#ifndef CFZC_VV_TANGENTIAL
+#define CFZC_VV_TANGENTIAL 1.0
+#endif
 namespace cfzc {
 
 // Dual regularisation of proximal type: the constraint rows of the Newton system read  J dx - delta_c (nu + dnu) = -c
@@ -210,7 +213,7 @@ CFZP_FN double pair_row(const double *pa, const double *pb, const double g[4], i
       const double nda = -n0 * ray + n1 * rax, ndb = -n0 * rby + n1 * rbx, tda = n1 * ray + n0 * rax, tdb = n1 * rby + n0 * rbx;
       gr[0] = n0; gr[1] = n1; gr[2] = nda; gr[3] = -n0; gr[4] = -n1; gr[5] = -ndb;
       const double tau[6] = {-n1, n0, tda, n1, -n0, -tdb};
-      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[i][j] = tau[i] * tau[j] * ir;
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[i][j] = CFZC_VV_TANGENTIAL * tau[i] * tau[j] * ir;
       H[2][2] -= n0 * rax + n1 * ray;
       H[5][5] += n0 * rbx + n1 * rby;
     }
@@ -571,7 +574,7 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
         if ((sl >> 6) == 3) {  // distance r of two vertices, n = (a0,a1): tau tau' / r - n.(R b_v) e_psi e_psi', tau = (-a1, a0, t.dw)
           const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
           const double rbx = cs * bx - sn * by, rby = sn * bx + cs * by, a0 = gr[rr][0], a1 = gr[rr][1];
-          const double nq = nr_ / sep[0], t2 = a1 * rby + a0 * rbx;  // sep[0] = r (the second slot's value carries the margin)
+          const double nq = CFZC_VV_TANGENTIAL * nr_ / sep[0], t2 = a1 * rby + a0 * rbx;  // sep[0] = r (the second slot's value carries the margin)
           bnd(Bd, px[b], px[b]) += nq * a1 * a1; bnd(Bd, px[b + 1], px[b + 1]) += nq * a0 * a0; put(Bd, px[b], px[b + 1], -nq * a1 * a0);
           put(Bd, px[b], px[b + 2], -nq * a1 * t2); put(Bd, px[b + 1], px[b + 2], nq * a0 * t2);
           bnd(Bd, px[b + 2], px[b + 2]) += nq * t2 * t2 - nr_ * (a0 * rbx + a1 * rby);
@@ -1396,6 +1399,9 @@ CFZP_FN void handover(int o, int n, const double sep[2], double dmin, double mu,
     if (src[r] >= 0) { s[r] = so[src[r]]; z[r] = zo[src[r]]; nu[r] = no[src[r]]; }
     else { const double sg = fmax(sep[r] - dmin, push); s[r] = sg; z[r] = mu / sg; nu[r] = -mu / sg; }
   }
+#if defined(CFZC_TRACE)
+  if (fmax(zo[0], zo[1]) > 1e-2) printf("   handover %d -> %d  sep %.4e %.4e | old s %.3e %.3e z %.3e %.3e nu %.3e %.3e | src %d %d | new s %.3e %.3e z %.3e %.3e\n", o, n, sep[0] - dmin, sep[1] - dmin, so[0], so[1], zo[0], zo[1], no[0], no[1], src[0], src[1], s[0], s[1], z[0], z[1]);
+#endif
 }
 
 // refresh the working set at the poses of X; a block whose (face, vertices) change hands its rows over (handover)
@@ -1495,6 +1501,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
+  bool mu_forced = false;  // the last iteration ended without a step and lowered mu instead
   int status = 1, iter = 0;
   long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
@@ -1661,7 +1668,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       // starts afresh.
       const double e0 = fmax(dual_inf / s_d, cviol);
       double af = a_pri;
-      for (int k = 0; k < 4 && !accepted; ++k, af *= 0.5) {
+      for (int k = 0; k < 6 && !accepted; ++k, af *= 0.5) {
+        const double az = a_dual * (af / a_pri);  // the bound multipliers move in step with the point
         CFZP_LANE_FOR(i, 0, n - 1) w.xt[i] = w.x[i] + af * w.dx[i];
         CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += af * w.dnu[i];
         CFZP_SYNC();
@@ -1670,13 +1678,26 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         jt_nu(sp, w.sel, w.xt, w.nu, w.r1);
         double cv = 0.0, di = 0.0;
         CFZP_LANE_FOR(i, 0, m - 1) cv = fmax(cv, fabs(w.ct[i]));
-        CFZP_LANE_FOR(i, 0, n - 1) di = fmax(di, fabs(w.g[i] + w.r1[i] - (w.zl[i] + a_dual * w.dzl[i]) + (w.zu[i] + a_dual * w.dzu[i])));
+        CFZP_LANE_FOR(i, 0, n - 1) di = fmax(di, fabs(w.g[i] + w.r1[i] - (w.zl[i] + az * w.dzl[i]) + (w.zu[i] + az * w.dzu[i])));
         cv = bmax(cv); di = bmax(di);
-        if (isfinite(cv) && isfinite(di) && w.xt[d.iDt] > 0.0 && fmax(di / s_d, cv) <= 0.9 * e0) { accepted = true; alpha = af; nu_done = true; f_type = true; nfilt = 0; }
+#if defined(CFZC_TRACE)
+        printf("   fallback k %d af %.3e cv %.3e di/s_d %.3e (e0 %.3e: dinf/s_d %.3e cviol %.3e) delta %.2e\n", k, af, cv, di / s_d, e0, dual_inf / s_d, cviol, delta);
+#endif
+        if (isfinite(cv) && isfinite(di) && w.xt[d.iDt] > 0.0 && fmax(di / s_d, cv) <= 0.9 * e0) { accepted = true; alpha = af; a_dual = az; nu_done = true; f_type = true; nfilt = 0; }
         else { CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] -= af * w.dnu[i]; CFZP_SYNC(); }
       }
     }
-    if (!accepted) { status = 2; break; }
+    if (!accepted) {
+      // Neither the filter nor the merit accepts any step length.  If the barrier parameter can still fall, the barrier problem
+      // at hand is given up (typically it is solved to within a factor of two of its own stopping rule and the step is
+      // dominated by the regularisations): mu falls, the filter starts afresh and the iterate stays.  Otherwise status 2.
+      if (mu > mu_floor && !mu_forced) {
+        mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))); mu_forced = true; nfilt = 0; filt_mu = mu;
+        continue;
+      }
+      status = 2; break;
+    }
+    mu_forced = false;
 #if defined(CFZC_TRACE)  // CPU build only (tests/emu): g++ -DCFZC_TRACE -include stdio.h
     printf("it %3d mu %.2e err %.3e theta %.3e cviol %.2e dinf %.2e cmp %.2e delta %.1e alpha %.3e a_pri %.3e a_dual %.3e ftype %d dt %.5f f %.5f\n", iter, mu, err0, theta, cviol, dual_inf, cmp0, delta, alpha, a_pri, a_dual, (int)f_type, w.x[d.iDt], objective(sp, w.x));
 #endif

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # name -> (agent, body corner, collocation point of the unobstructed optimum, intrusion into the clearance [m])
-INSTANCES = {"vehicle_1_pillar": ("vehicle_1", 3, 130, 0.1), "vehicle_2_pillar": ("vehicle_2", 3, 60, 0.1), "vehicle_3_pillar": ("vehicle_3", 3, 210, 0.1)}
+INSTANCES = {"vehicle_1_pillar": ("vehicle_1", 3, 130, 0.2), "vehicle_2_pillar": ("vehicle_2", 3, 60, 0.1), "vehicle_3_pillar": ("vehicle_3", 3, 210, 0.1)}
 DMIN = 0.05
 G_BODY = np.array([3.3, 0.9, 0.6, 0.9])
 
@@ -108,7 +108,10 @@ if __name__ == "__main__":
         agent, tube, p, fh, A_obs, b_obs, X0 = instance(name)
         g = GeometricColloc(p[0], tube, A_obs, b_obs, N_per_set=5, final_heading=fh, dmin=DMIN)
         t0 = time.time()
-        r = solve_ipm(g, X0[:-1].reshape(-1, 7), X0[-1])
+        from oracle import ipm
+
+        r = solve_ipm(g, X0[:-1].reshape(-1, 7), X0[-1], opt=ipm.IpmOptions(max_iter=800, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8,
+                                                                               constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6))
         z = np.append(r["traj"].ravel(), r["dt"])
         res, lam_eq, lam_act, act = kkt_certificate(g, z)
         vc = vertex_contacts(g, z, lam_act, act)
@@ -116,7 +119,8 @@ if __name__ == "__main__":
         print(name, {k: v for k, v in r.items() if k != "traj"}, "certificate %.1e" % res, "vertex contacts", vc, "value %.9f" % value,
               "%.0f s" % (time.time() - t0), flush=True)
         # status 2 = the line search ran out at the rounding floor of the merit function (as for colloc_independent.npz)
-        assert r["status"] in (0, 2) and r["eq"] < 5e-8 and r["ineq"] > -1e-8 and res < 1e-8
+        # (1 = the iteration limit, reached by vehicle_1_pillar with the rows at 2e-9: what makes the point a fixture is the certificate)
+        assert r["status"] in (0, 1, 2) and r["eq"] < 5e-8 and r["ineq"] > -1e-8 and res < 1e-8
         assert any(lam > 0.1 for _, _, lam in vc), "no active corner-to-corner contact at the optimum"
         out.update({f"{name}_A": A_obs[6], f"{name}_b": b_obs[6], f"{name}_guess": X0, f"{name}_traj": r["traj"], f"{name}_dt": r["dt"],
                     f"{name}_cost": r["cost"], f"{name}_value": value, f"{name}_iters": r["iters"], f"{name}_status": r["status"],

@@ -277,7 +277,7 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     if agent.endswith("_pillar"):  # the gap face-normal certificates leave (CPU twin: test_face_normal_rows_alone_restrict_...)
         r0 = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1, vv_rows=0)[0]
         z0 = np.append(r0["traj"].ravel(), r0["dt"])
-        assert np.abs(g.eq(z0)).max() < 1e-7 and g.ineq(z0).min() > -1e-7 and (g.cost(z0) - float(d["value"])) / float(d["value"]) > 2e-5
+        assert np.abs(g.eq(z0)).max() < 1e-7 and g.ineq(z0).min() > -1e-7 and (g.cost(z0) - float(d["value"])) / float(d["value"]) > 5e-6
     # the same kernel at tight tolerances with IPOPT's form of the dual regularisation (`exact_rows`): the independent optimum
     # itself (vehicle_1: status 0, cost to 1e-8, poses to 1e-6 m; vehicles 2, 3: the unregularised rows lose rank where the vehicle
     # waits and the solve ends with status 2 / 3 at the optimum, cost to 1e-6, poses to 1e-5 m)

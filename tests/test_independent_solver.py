@@ -363,14 +363,14 @@ def check_plan_against_independent(traj, dt, tight, agent="vehicle_1"):
     (vehicle_1: 1e-8 / 1e-6); at the reference's tolerance 1e-2 the rows hold to 1e-2, the cost is within 3e-3 (below: the
     rows are relaxed by the tolerance) and the poses within 5 mm.  The `_pillar` plans (corner-to-corner contact active at the
     optimum) are compared with the fixture's `value` (the independent cost corrected to first order for its own row residuals):
-    1e-6; poses of vehicle_1_pillar to 5e-4 m (measured 5e-5: the independent solver stops with rows at 1e-8 there)."""
+    1e-6; poses of vehicle_1_pillar to 1e-4 m (measured 1.4e-5)."""
     d, g, _ = _colloc_fixture(agent)
     z = np.append(np.asarray(traj, float).ravel(), float(dt))
     eq, ineq = np.abs(g.eq(z)).max(), g.ineq(z).min()
     gap = (g.cost(z) - float(d["value"])) / float(d["value"])
     dpose, ddt = np.abs(np.asarray(traj)[..., :3] - d["traj"][..., :3]).max(), abs(float(dt) - float(d["dt"]))
     if tight:
-        lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else ((1e-6, 5e-4, 5e-6) if agent == "vehicle_1_pillar" else (1e-6, 1e-5, 1e-7))
+        lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else ((1e-6, 1e-4, 1e-6) if agent == "vehicle_1_pillar" else (1e-6, 1e-5, 1e-7))
         assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < lim[0] and dpose < lim[1] and ddt < lim[2], (agent, eq, ineq, gap, dpose, ddt)
     else:
         assert eq < 1e-2 and ineq > -1e-2 and -3e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (agent, eq, ineq, gap, dpose, ddt)
@@ -412,10 +412,10 @@ def test_corner_to_corner_plan_against_the_independent_solver(tight, agent):
     check_plan_against_independent(P, dt, tight, agent)
 
 
-@pytest.mark.parametrize("agent,least", [("vehicle_1_pillar", 5e-5), ("vehicle_2_pillar", 2e-5), ("vehicle_3_pillar", 1e-3)])
+@pytest.mark.parametrize("agent,least", [("vehicle_1_pillar", 5e-6), ("vehicle_2_pillar", 2e-5), ("vehicle_3_pillar", 1e-3)])
 def test_face_normal_rows_alone_restrict_the_collocation_plan(agent, least):
     """The gap `vv_rows = 0` leaves: with face-normal certificates only (round 2's planning kernels) the same instances end feasible
-    for the reference's rows but dearer than the optimum -- by 0.014 %, 0.004 % and 5.2 % (another local optimum) -- because at the corner-to-corner contact
+    for the reference's rows but dearer than the optimum -- by 0.0014 %, 0.004 % and 5.2 % (another local optimum) -- because at the corner-to-corner contact
     the best face normal certifies less than the distance of the two corners."""
     r, P, dt, d, g = _solve_plan_on_cpu(agent, True, vv=False)
     z = np.append(P.ravel(), dt)
