@@ -3,8 +3,9 @@
 
 A "step" is one closed-loop iteration of the distributed MPC (`MultiDistributedFollower.solve`,
 reference vehicle_follower.py:630-663) for S = 1024 scenarios x 4 vehicles = 4096 NLP solves
-per GPU, executed entirely on the device (`cfz_loop_step`: parameters + shifted warm start,
-solve, read-back / fallback, plant integration).  Inputs are resident in HBM before the timed
+per GPU, executed entirely on the device: the K timed steps are ONE persistent launch (`cfz_loop_run`: parameters +
+shifted warm start, solve, read-back / fallback, plant integration, Jacobi exchange inside each scenario; `--mode step`
+takes one `cfz_loop_step` launch per iteration instead).  Inputs are resident in HBM before the timed
 region.  N GPUs = N independent shards of scenarios (weak scaling, no data-path collective).
 
     python bench.py --gpus N --steps K --warmup W
@@ -38,15 +39,15 @@ def _cpu_closed_loop_worker(args):
     """One process of the CPU baseline: the SAME closed loop the GPU runs (`warmup` + `steps` MPC iterations, multipliers
     carried from one iteration to the next) for `n_scen` scenarios of the same sampler, through the oracle's plain-C port
     (oracle/closed_loop.py).  Returns solves, IPM iterations and converged solves of the timed iterations, and their time."""
-    seed, n_scen, warmup, steps = args
+    seed, n_scen, warmup, steps, ref_kind, feasible = args
     from conflict_rez_amd import scenarios
     from oracle.closed_loop import replay
     from oracle.mpc_nlp import MpcSpec
 
     spec = scenarios.parking_lot_spec()
-    table, _ = scenarios.load_reference_table()
+    table, _ = scenarios.load_reference_table(kind=ref_kind)
     ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
-    k0, noise = scenarios.sample_scenarios(n_scen, table, seed=seed)
+    k0, noise = scenarios.sample_scenarios(n_scen, table, seed=seed, spec=spec if feasible else None)
     n = its = ok = 0
     cold = None
     t0 = time.perf_counter()
@@ -70,7 +71,7 @@ def casadi_probe():
         return f"CasADi unavailable on this host: {type(e).__name__}: {e}"
 
 
-def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16):
+def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16, ref_kind="planned", feasible=True):
     """`cpu_baseline` of the bench line: the oracle's C port ("kind": "port") on the host cores, like for like with the
     GPU's timed region -- the closed loop after `warmup` iterations, carried multipliers -- on a bounded sample of the same
     scenario sampler (32 scenarios x 4 vehicles per process; about 40 s of CPU time in all).  16 processes: the job's CPU
@@ -84,7 +85,7 @@ def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16):
     except AttributeError:
         usable = os.cpu_count() or 1
     cores = max(1, min(max_cores, usable))
-    jobs = [(2024 + 1000 * i, n_scen_per_core, warmup, steps) for i in range(cores)]
+    jobs = [(2024 + 1000 * i, n_scen_per_core, warmup, steps, ref_kind, feasible) for i in range(cores)]
     t_wall = time.perf_counter()
     try:
         with cf.ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:  # spawn: this process holds a GPU context
@@ -181,9 +182,14 @@ def main():
                          "vehicles of all scenarios and all-gathers the predictions over RCCL every iteration (the reference's ROS "
                          "deployment; needs torch.distributed, --gpus dividing 4, one launch per iteration)")
     ap.add_argument("--count-iters", action="store_true", help="step mode: also sum the IPM iterations (adds a read-back)")
-    ap.add_argument("--reference", choices=["package", "planned"], default="package",
-                    help="package: conflict_rez_amd/data/refs_4v.npz, the state_ws plans of the synthetic strategy; planned: build the "
-                         "table at start-up with the GPU planning chain (state_ws -> collocation plan, plan_single_path)")
+    ap.add_argument("--reference", choices=["planned", "state_ws", "replan"], default="planned",
+                    help="planned (default): conflict_rez_amd/data/refs_4v_planned.npz, the build's own single-vehicle plans (state_ws -> "
+                         "collocation plan, VehicleFollower.plan_single_path) of the synthetic strategy, SURVEY.md 8d config 3; state_ws: "
+                         "data/refs_4v.npz, the slower state_ws warm-start plans (the table of rounds 1-2); replan: build the planned table "
+                         "at start-up with the GPU planning chain instead of loading it")
+    ap.add_argument("--raw-starts", action="store_true",
+                    help="take the sampler's starts as they come (rounds 1-2); default: a scenario whose noisy start state is already "
+                         "inside a clearance (an infeasible first NLP, status 4) is drawn again")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,18 +212,25 @@ def main():
     single = args.workload == "single"
     spec = scenarios.parking_lot_spec(n_obs=4 if single else args.n_obs, n_nbr=0 if single else 3)
     V = spec.n_nbr + 1
-    if args.reference == "planned":
+    if args.reference == "replan":
         table, _, plan_info = scenarios.planned_reference_table(device=local_rank)
         ref_desc = ("built at start-up by the GPU planning chain (cfz_state_ws -> cfz_colloc, VehicleFollower.plan_single_path): "
                     + ", ".join(f"{a} {i['t_end']:.1f} s" for a, i in plan_info.items()))
+    elif args.reference == "planned":
+        table, lengths = scenarios.load_reference_table(kind="planned")
+        ref_desc = ("conflict_rez_amd/data/refs_4v_planned.npz: the build's own single-vehicle plans of the synthetic strategy (cfz_state_ws -> "
+                    "cfz_colloc as in VehicleFollower.plan_single_path, free dt), sampled every 0.1 s: "
+                    + ", ".join(f"vehicle_{i} {0.1 * (n - 1):.1f} s" for i, n in enumerate(lengths)) + " (SURVEY.md 8d config 3)")
     else:
-        table, _ = scenarios.load_reference_table()
+        table, _ = scenarios.load_reference_table(kind="state_ws")
         ref_desc = ("conflict_rez_amd/data/refs_4v.npz: the four vehicles' Vehicle.state_ws plans of the synthetic strategy "
                     "(tube-constrained warm-start trajectories, 18-30 s)")
     if single:
         table = table[rank % table.shape[0]][None].copy()  # every scenario follows one vehicle's plan, alone on the map
     S = args.scenarios
-    k0, noise = scenarios.sample_scenarios(S, table, seed=args.seed + rank)
+    fspec = None if (args.raw_starts or single) else spec
+    k0, noise = scenarios.sample_scenarios(S, table, seed=args.seed + rank, spec=fspec)
+    infeasible_starts = None if single else int((scenarios.start_clearances(spec, table, k0, noise) < spec.dmin - 0.02).any(1).sum())
     vehicle_sharded = args.parallelism == "vehicle"
     if vehicle_sharded:
         if dist is None or single:
@@ -227,7 +240,7 @@ def main():
         # scenarios x world in total: every rank steps its vehicles (V / world of them, or one vehicle of a scenario shard when
         # there are more ranks than vehicles) -> the same number of solves per GPU as in scenario sharding
         S_total = args.scenarios * world
-        k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed)
+        k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed, spec=fspec)
         ex = VehicleShardedExchange(V)
         S = len(range(S_total)[ex.scenarios(S_total)])
         eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)
@@ -346,6 +359,8 @@ def main():
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
                        "converged_timed_region": (n_conv / solves) if n_conv is not None else None,
                        "reference_plan": ref_desc,
+                       "infeasible_starts": infeasible_starts,
+                       "starts": "raw sampler draws" if fspec is None else "scenarios whose noisy start state violates a clearance are drawn again",
                        "ipm_iterations_rank0": ipm_iterations,
                        "mean_ipm_iters_timed_region": (ipm_iterations / (B * args.steps)) if ipm_iterations else None,
                        "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
@@ -366,7 +381,8 @@ def main():
         if cold is not None:
             line["cold_step"] = cold
         if world == 1 and not args.no_cpu_baseline and not single:
-            line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps)
+            line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps, ref_kind="state_ws" if args.reference == "state_ws" else "planned",
+                                                feasible=fspec is not None)
             cb = line["cpu_baseline"]
             if ipm_iterations:  # like for like: IPM iterations per second, GPU : all usable host cores : one core
                 line["gpu_vs_cpu"] = {"ipm_iterations_per_s_gpu": ipm_iterations * world / elapsed,

@@ -93,7 +93,8 @@ struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
   int max_iter, max_backtrack, filter_cap, stall_iters;
   int row_curvature, vv_rows;  // vv_rows 1: vertex-vertex rows (kind 3) in the working set
-  int shift_after, pad0;       // iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
+  int shift_after, whole_first;  // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
+                                 // whole_first: the whole row curvature is tried first and kept when every stage's Huu is positive definite
   double dt, wb, dmin;
   double g[4], bounds[12], weights[6];
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
@@ -908,8 +909,10 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
 // backward sweep: gains K_k (12 per stage) into kk, value function of stage 0 into rP (25) and rP + 25 (5).
 // P is kept as its upper triangle.  With W = B'P:  Hux = W A,  Huu = R + W B,  hu = g_u + B'(p + P d);  M = P A,
 // Hxx = Q + A'M (upper triangle only);  K = -Huu^-1 [Hux hu];  P <- Hxx - Hux' Huu^-1 Hux,  p <- hx - Hux' Huu^-1 hu.
+// rP[30] = 1 if every stage's Huu is positive definite (the Newton system then has the inertia of a minimisation), else 0.
 CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
   CFZ_SWEEP_GUARD
+  double pd_ok = 1.0;
   // upper triangle of P: P00 P01 P02 P03 P04 | P11 P12 P13 P14 | P22 P23 P24 | P33 P34 | P44
   double P00, P01, P02, P03 = 0.0, P04 = 0.0, P11, P12, P13 = 0.0, P14 = 0.0, P22, P23 = 0.0, P24 = 0.0, P33, P34 = 0.0, P44;
   double p0, p1, p2, p3, p4;
@@ -918,6 +921,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const wsp_f64 *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
     wsp_f64 *K = m + o_kk + k * 12;
     const double h10 = h[10], h6 = h[6];
+    if (!(h[5] > 0.0 && h[5] * h6 > 0.0)) pd_ok = 0.0;
     const double k53 = -h10 / h6, k10 = -gk[5] / h[5], k11 = -gk[6] / h6;
     P00 = h[0]; P11 = h[1]; P22 = h[2]; P33 = h[3] + h10 * k53; P44 = h[4];
     P01 = h[7]; P02 = h[8]; P12 = h[9];
@@ -994,6 +998,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const double H33 = M33 + s01 * M03 + s11 * M13 + s21 * M23 + hc_[3], H34 = M34 + s01 * M04 + s11 * M14 + s21 * M24;
     const double H44 = M44 + s02 * M04 + s12 * M14 + s22 * M24 + hc_[4];
     (void)M43;
+    if (!(a00 > 0.0 && a00 * a11 - a01 * a01 > 0.0)) pd_ok = 0.0;
     const double idet = 1.0 / (a00 * a11 - a01 * a01);
     const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
     // t = Huu^-1 [Hux hu]
@@ -1033,6 +1038,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
   rP[15] = P03; rP[16] = P13; rP[17] = P23; rP[18] = P33; rP[19] = P34;
   rP[20] = P04; rP[21] = P14; rP[22] = P24; rP[23] = P34; rP[24] = P44;
   rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
+  rP[30] = pd_ok;
 }
 
 // ------------------------------------------------------------------------------ forward step and costates as scans
@@ -1374,6 +1380,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_STAMP_DECL
   CFZ_STAMP(0);  // setup
   int nfilt = 0, status = 1, iter = 0;
+  int whole_skip = 0;  // iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
 
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
@@ -1553,6 +1560,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
     //   kind 3 (distance r of two vertices, n = (a0,a1)): tau tau' / r + kappa e_psi e_psi' with tau = (t, t.dw), t = (-a1, a0)
     //           the unit tangent, dw = d(R b_v)/dpsi, kappa = -n.(R b_v); the only rows that curve x and y (cxx, cyy, cxy)
+    // The whole curvature of the separation rows first (oracle/ipm.py whole_curvature_first): kept if the backward sweep finds
+    // every stage's Huu positive definite; otherwise the stage-wise safeguarded model below (scaled, late in a solve shifted)
+    // is assembled and swept instead, and the next iteration does not try the whole curvature again.
+    bool use_whole = sp.whole_first != 0 && sp.row_curvature != 0 && whole_skip == 0;
+    for (;;) {
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
       double ac[15] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc | cxx cyy cxy
@@ -1621,7 +1633,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           if (sp.vv_rows) { cxx = CFZ_QSUM(qx, 12); cyy = CFZ_QSUM(qx, 13); cxy = CFZ_QSUM(qx, 14); }
           const bool full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0;  // a vertex-vertex row in this stage
           double th = 1.0;
-          for (int hh = 0; hh < 11; ++hh) {
+          for (int hh = 0; hh < 11 && !use_whole; ++hh) {
             if (hh == 10) { th = 0.0; break; }
             if (!full) {
               if (q2 + th * cc - th * th * quad >= 0.0) break;
@@ -1633,7 +1645,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             }
             th *= 0.5;
           }
-          if (sp.shift_after > 0 && iter >= sp.shift_after && th < 1.0) {
+          if (!use_whole && sp.shift_after > 0 && iter >= sp.shift_after && th < 1.0) {
             // late in a long solve the scaled model cycles: whole curvature + the smallest identity shift that keeps the margin
             const double dl = pose_shift(dv.q0 + cxx, dv.q1 + cyy, q2 + cc, cxy, ca, cb);
             h[0] += dl; h[1] += dl; h[2] += dl;
@@ -1652,6 +1664,17 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
+    if (use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0) {
+      use_whole = false; whole_skip = 2;
+      CFZ_LANES(tid)  // the sweep's value function sits where the assembly reads cos / sin of the headings (L.rP = L.cs): put them back
+        const int k = tid >> 2;
+        if (k < N && (tid & 3) == 0) { double sn, cn; sincos(m[L.p + k * kNP + 2], &sn, &cn); m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+      CFZ_END
+      continue;
+    }
+    break;
+    }
+    if (sp.row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
     // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_STAMP(9);  // forward step

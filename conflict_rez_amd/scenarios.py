@@ -3,11 +3,14 @@
 The 4-vehicle parking-lot scenario: the six static obstacle boxes of the reference
 (`compute_obstacles`), one planned reference trajectory per vehicle (a table sampled every
 dt = 0.1 s) and, per scenario, a random start time on those references plus state noise.
-The default reference table is package data, `conflict_rez_amd/data/refs_4v.npz`: the four vehicles' `Vehicle.state_ws`
-plans (vehicle.py:99-231, tube-constrained, 18-30 s long) of the synthetic strategy (`strategy.generate_strategy(4)`),
-sampled every dt.  `planned_reference_table` builds the table the way `VehicleFollower.plan_single_path` does
-(vehicle_follower.py:91-138): state_ws -> dual_ws -> collocation plan with free dt on the GPU planning kernels, then
-sampled every dt (8-16 s plans).  The MPC's own NLP never sees how a table was made.
+Two reference tables are package data (`load_reference_table(kind)`):
+  "planned"   `conflict_rez_amd/data/refs_4v_planned.npz`: what `VehicleFollower.plan_single_path` produces (vehicle_follower.py:91-138:
+              state_ws -> dual_ws -> collocation plan with free dt) for the four vehicles of the synthetic strategy
+              (`strategy.generate_strategy(4)`) on the GPU planning kernels, sampled every dt (7.8-15.7 s plans); written by
+              `planned_reference_table` on an MI355X and reproduced by it in the GPU tests.  SURVEY.md 8d config 3 names this table.
+  "state_ws"  `conflict_rez_amd/data/refs_4v.npz`: the four vehicles' `Vehicle.state_ws` warm-start plans (vehicle.py:99-231,
+              tube-constrained, 18-30 s long); the table of rounds 1-2, and the one the MPC goldens were generated on.
+The MPC's own NLP never sees how a table was made.
 """
 import os
 
@@ -18,7 +21,9 @@ from .engine import ProblemSpec
 from .obstacle_types import GeofenceRegion
 from .vehicle_types import VehicleBody, VehicleConfig
 
-_REFS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "refs_4v.npz")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_REFS = os.path.join(_DATA, "refs_4v.npz")
+_TABLES = {"state_ws": _REFS, "planned": os.path.join(_DATA, "refs_4v_planned.npz")}
 
 
 def parking_lot_spec(n_nbr=3, N=30, dt=0.1, n_obs=6, dmin=0.05):
@@ -32,9 +37,10 @@ def parking_lot_spec(n_nbr=3, N=30, dt=0.1, n_obs=6, dmin=0.05):
     return ProblemSpec.from_objects(obs, VehicleBody(), VehicleConfig(), GeofenceRegion(), n_nbr=n_nbr, N=N, dt=dt, dmin=dmin)
 
 
-def load_reference_table(path=None):
-    """[V, T, 7] planned trajectories (x,y,psi,v,delta,a,w) sampled every dt; held at the goal."""
-    d = np.load(path or _REFS)
+def load_reference_table(path=None, kind="state_ws"):
+    """[V, T, 7] planned trajectories (x,y,psi,v,delta,a,w) sampled every dt; held at the goal.  kind: "state_ws" or "planned"
+    (module docstring); `path` overrides."""
+    d = np.load(path or _TABLES[kind])
     return d["table"].copy(), d["lengths"].copy()
 
 
@@ -78,13 +84,73 @@ def planned_reference_table(dt=0.1, pad=30, device=0):
     return table, np.array([len(t) for t in trajs]), info
 
 
-def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0)):
+def _quad_distance(P, Q):
+    """Distance of convex quadrilaterals P, Q [..., 4, 2] (vertex arrays), 0 when they touch or overlap: the smallest
+    vertex-to-edge distance of the two boundaries, or 0 if a vertex of one lies inside the other / two edges cross."""
+    def point_edges(A, B):  # squared distance of every vertex of A to every edge of B -> [..., 4, 4]
+        b0, e = B, np.roll(B, -1, axis=-2) - B
+        w = A[..., :, None, :] - b0[..., None, :, :]
+        t = np.clip((w * e[..., None, :, :]).sum(-1) / np.maximum((e * e).sum(-1)[..., None, :], 1e-300), 0.0, 1.0)
+        d = w - t[..., None] * e[..., None, :, :]
+        return (d * d).sum(-1)
+
+    def inside(A, B):  # a vertex of A inside B (either orientation)
+        e = np.roll(B, -1, axis=-2) - B
+        w = A[..., :, None, :] - B[..., None, :, :]
+        cr = e[..., None, :, 0] * w[..., 1] - e[..., None, :, 1] * w[..., 0]
+        return ((cr >= 0).all(-1) | (cr <= 0).all(-1)).any(-1)
+
+    def edges_cross(A, B):
+        a0, a1, b0, b1 = A[..., :, None, :], np.roll(A, -1, axis=-2)[..., :, None, :], B[..., None, :, :], np.roll(B, -1, axis=-2)[..., None, :, :]
+        def orient(p, q, r):
+            return (q[..., 0] - p[..., 0]) * (r[..., 1] - p[..., 1]) - (q[..., 1] - p[..., 1]) * (r[..., 0] - p[..., 0])
+        return ((orient(a0, a1, b0) * orient(a0, a1, b1) < 0) & (orient(b0, b1, a0) * orient(b0, b1, a1) < 0)).any((-1, -2))
+
+    d = np.sqrt(np.minimum(point_edges(P, Q).min((-1, -2)), point_edges(Q, P).min((-1, -2))))
+    return np.where(inside(P, Q) | inside(Q, P) | edges_cross(P, Q), 0.0, d)
+
+
+def start_clearances(spec: ProblemSpec, table, k0, noise):
+    """[S, V]: distance of every vehicle's body at its measured start state (table pose at k0 + noise) from the nearest static
+    obstacle or other vehicle (0 = touching or overlapping).  A vehicle that starts closer than dmin - 2 constr_viol_tol has an
+    infeasible first NLP (status 4: the pose of stage 0 is pinned to the measured state, vehicle_follower.py:194-199, :280-290)."""
+    S, V = len(k0), table.shape[0]
+    x = table[np.arange(V)[None, :], np.asarray(k0)[:, None], :3] + noise[..., :3]  # [S, V, 3]
+    g = np.asarray(spec.g, float)
+    BV = np.array([[g[0], g[1]], [-g[2], g[1]], [-g[2], -g[3]], [g[0], -g[3]]])
+    c, s_ = np.cos(x[..., 2]), np.sin(x[..., 2])
+    W = x[..., None, :2] + np.stack([c[..., None] * BV[:, 0] - s_[..., None] * BV[:, 1], s_[..., None] * BV[:, 0] + c[..., None] * BV[:, 1]], -1)  # [S, V, 4, 2]
+    out = np.full((S, V), np.inf)
+    for j in range(spec.n_obs):  # static obstacles: vertices from the H-representation (4 half-planes, adjacent rows meet)
+        A, b = np.asarray(spec.A_obs[j], float), np.asarray(spec.b_obs[j], float)
+        ang = np.argsort(np.arctan2(A[:, 1], A[:, 0]))
+        PV = np.array([np.linalg.solve(A[[ang[i], ang[(i + 1) % 4]]], b[[ang[i], ang[(i + 1) % 4]]]) for i in range(4)])
+        out = np.minimum(out, _quad_distance(W, PV[None, None]))
+    for a in range(V):
+        for b_ in range(a + 1, V):
+            d = _quad_distance(W[:, a], W[:, b_])
+            out[:, a] = np.minimum(out[:, a], d); out[:, b_] = np.minimum(out[:, b_], d)
+    return out
+
+
+def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0), spec=None, margin=0.02):
     """Start sample k0[S] ~ U[0, T - margin) and state noise [S, V, 5] (sigma_xy 0.05 m,
-    sigma_psi 0.02 rad, sigma_v 0.05 m/s)."""
+    sigma_psi 0.02 rad, sigma_v 0.05 m/s).
+    spec (optional): only FEASIBLE starts -- a scenario in which some vehicle's measured state is closer than dmin - margin to an
+    obstacle or to another vehicle is drawn again (start time and noise, same generator, up to 50 times): such a state is not
+    one `VehicleFollower` can be in (its first NLP is infeasible, status 4).  Without spec: the draws of rounds 1-2 as they come
+    (the MPC goldens and the closed-loop tests were generated on those)."""
     rng = np.random.default_rng(seed)
     V, T = table.shape[0], table.shape[1]
     k0 = rng.integers(0, max(T - horizon_margin, 1), size=S).astype(np.int32)
     nz = rng.normal(0.0, 1.0, size=(S, V, 5)) * np.asarray(noise)
+    if spec is not None:
+        for _ in range(50):
+            bad = np.flatnonzero(start_clearances(spec, table, k0, nz).min(1) < spec.dmin - margin)
+            if not len(bad):
+                break
+            k0[bad] = rng.integers(0, max(T - horizon_margin, 1), size=len(bad)).astype(np.int32)
+            nz[bad] = rng.normal(0.0, 1.0, size=(len(bad), V, 5)) * np.asarray(noise)
     return k0, nz
 
 

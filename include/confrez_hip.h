@@ -63,6 +63,13 @@ typedef struct cfz_options {
   int32_t shift_after;    /* 60: from this iteration on a stage whose row curvature the convexity safeguard would scale keeps it
                            *     whole and is shifted by the smallest multiple of the identity instead (a scaled model can
                            *     cycle for hundreds of iterations on a vehicle pressed into a corner); 0 = never */
+  int32_t whole_curvature_first; /* 0 (default): the stage-wise safeguarded curvature model.  1 (experiment switch): every iteration
+                           *    first takes the WHOLE multiplier-weighted curvature of the separation rows and keeps it when the Riccati
+                           *    recursion finds every stage's Huu positive definite (IPOPT: the first trial of its inertia correction,
+                           *    delta_w = 0), else falls back to the safeguarded model.  Halves the 99th percentile of a scenario's
+                           *    iteration chain on the planned-table closed loop, but three instances of the independent-solver
+                           *    populations then end with status 5 (docs/notebook.md), so it is off */
+  int32_t reserved1;
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

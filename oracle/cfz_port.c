@@ -35,6 +35,7 @@ typedef struct {
   int filter_cap, max_backtrack, stall_iters, row_curvature;
   int vv_rows; /* 1: vertex-vertex rows (kind 3) in the working set, oracle/mpc_nlp.py MpcSpec.vv_rows */
   int shift_after; /* oracle/ipm.py IpmOptions.shift_after */
+  int whole_first; /* oracle/ipm.py IpmOptions.whole_curvature_first */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -385,6 +386,8 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   int stall_cnt = 0, stall_ws = 0;
   double mu = sp->mu_init;
   int status = 1, iter = 0;
+  int whole_skip = 0; /* iterations left in which the whole row curvature is not tried */
+  static double Ps[MAXN][5][5], ps[MAXN][5];
   double err0 = INFINITY;
   const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb); /* nb counts rows here */
 
@@ -577,7 +580,14 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     (void)cmpmu;
     double tau = fmax(sp->tau_min, 1.0 - mu);
     /* ---- condensed stage QP ----------------------------------------------------------- */
+    /* The whole curvature of the separation rows first (oracle/ipm.py whole_curvature_first): kept if every stage's Huu of the
+     * Riccati recursion below is positive definite (the Newton system then has the inertia of a minimisation); otherwise the
+     * stage-wise safeguarded model takes its place and the next iteration does not try again. */
     double dphi = 0.0;
+    int use_whole = sp->whole_first && sp->row_curvature && whole_skip == 0;
+    for (;;) {
+    int pd_ok = 1;
+    dphi = 0.0;
     for (int k = 0; k < N; ++k) {
       const double *w = sp->weights; const double *p = it.p[k];
       memset(H[k], 0, sizeof H[k]);
@@ -613,7 +623,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         const double q0 = 2 * w[0] - m_, q1 = 2 * w[1] - m_, q2 = 2 * w[2] - m_;
         const int full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0; /* a vertex-vertex row curves x and y too */
         double th = 1.0;
-        for (int h = 0; h < 11; ++h) {
+        for (int h = 0; h < 11 && !use_whole; ++h) {
           if (h == 10) { th = 0.0; break; }
           if (!full) {
             if (q2 + th * cc - th * th * (ca * ca / q0 + cb * cb / q1) >= 0.0) break;
@@ -625,7 +635,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
           }
           th *= 0.5;
         }
-        if (sp->shift_after > 0 && iter >= sp->shift_after && th < 1.0) {
+        if (!use_whole && sp->shift_after > 0 && iter >= sp->shift_after && th < 1.0) {
           /* late in a long solve the scaled model cycles: whole curvature + smallest identity shift (hess_gn shift=True) */
           const double dl_ = pose_shift(q0 + cxx, q1 + cyy, q2 + cc, cxy, ca, cb);
           H[k][0][0] += dl_; H[k][1][1] += dl_; H[k][2][2] += dl_;
@@ -636,10 +646,10 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       }
     }
     /* ---- Riccati backward: value function 0.5 dz'P_k dz + p_k'dz kept for every stage ------- */
-    static double Ps[MAXN][5][5], ps[MAXN][5];
     {
       int k = N - 1; /* terminal stage: its inputs a,w are costed but drive no dynamics */
       double R2[2][2] = {{H[k][5][5], H[k][5][6]}, {H[k][6][5], H[k][6][6]}};
+      if (!(R2[0][0] > 0.0 && R2[0][0] * R2[1][1] - R2[0][1] * R2[1][0] > 0.0)) pd_ok = 0;
       double rhs[2][6], sol[2][6];
       for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[k][5 + a][q]; rhs[a][5] = gk[k][5 + a]; }
       sym2_solve(R2, &rhs[0][0], 6, &sol[0][0]);
@@ -668,6 +678,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       }
       double rhs[2][6], sol[2][6];
       for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
+      if (!(Huu[0][0] > 0.0 && Huu[0][0] * Huu[1][1] - Huu[0][1] * Huu[1][0] > 0.0)) pd_ok = 0;
       sym2_solve(Huu, &rhs[0][0], 6, &sol[0][0]);
       for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
       for (int i = 0; i < 5; ++i) {
@@ -676,6 +687,10 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       }
       for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { double s = 0.5 * (Ps[k][i][q] + Ps[k][q][i]); Ps[k][i][q] = Ps[k][q][i] = s; }
     }
+    if (use_whole && !pd_ok) { use_whole = 0; whole_skip = 2; continue; }
+    break;
+    }
+    if (sp->row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
     /* ---- forward sweep: dp, new multipliers ------------------------------------------------ */
     for (int i = 0; i < 5; ++i) dt_.p[0][i] = x0[i] - it.p[0][i];
     for (int k = 0; k < N; ++k) {

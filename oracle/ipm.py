@@ -79,6 +79,37 @@ class IpmOptions:
     reg_dual: float = 0.0
     hessian: str = "gn"  # "gn" (kernel's choice) or "exact" (needs nlp.hess_exact; planning NLPs)
     curv_kappa: float = 1e-8  # exact Hessian: inertia-free curvature test d'(W+Sigma)d >= kappa d'd
+    # True: the whole (unsafeguarded) curvature of the separation rows is tried first and kept when the Newton system has the
+    # right inertia (see solve).  False (default): always the stage-wise safeguarded model.  Measured in round 3 (docs/notebook.md):
+    # on the planned-table closed loop the 99th percentile of a scenario's iteration chain halves with it, but three instances of
+    # the independent-solver populations then end with status 5 -- parity first, so it stays an experiment switch.
+    whole_curvature_first: bool = False
+    lower_mu_on_failure: bool = False  # a failed line search lowers mu once instead of ending the solve (independent solvers only)
+
+
+def kkt_inertia_ok(H, J, n, m):
+    """True if [[H, J'], [J, 0]] has n positive and m negative eigenvalues (H's reduced Hessian on the null space of J is positive
+    definite): dense LDL' (Bunch-Kaufman), eigenvalue signs of its 1 x 1 and 2 x 2 pivot blocks."""
+    from scipy.linalg import ldl
+
+    K = np.block([[H.toarray(), J.T.toarray()], [J.toarray(), np.zeros((m, m))]])
+    _, D, _ = ldl(K)
+    d0, d1 = np.diag(D).copy(), np.diag(D, -1)
+    neg = 0
+    i = 0
+    while i < n + m:
+        if i + 1 < n + m and d1[i] != 0.0:  # 2 x 2 block: one eigenvalue of each sign iff its determinant is negative
+            det, tr = d0[i] * d0[i + 1] - d1[i] * d1[i], d0[i] + d0[i + 1]
+            neg += 1 if det < 0 else (2 if tr < 0 else 0)
+            if det == 0.0:
+                return False
+            i += 2
+        else:
+            if d0[i] == 0.0:
+                return False
+            neg += d0[i] < 0
+            i += 1
+    return neg == m
 
 
 STATUS_OK, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NAN = 0, 1, 2, 3
@@ -142,6 +173,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
 
     it = 0
     err0 = np.inf
+    mu_forced = False
+    whole_skip = 0  # iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
     for it in range(opt.max_iter + 1):
         if it > 0 and hasattr(nlp, "new_iterate"):  # working-set NLPs refresh their rows here
             x, zl, nu = nlp.new_iterate(x, zl, nu, mu, opt.bound_push)
@@ -205,10 +238,23 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         rhs = -np.concatenate([gphi + J.T @ nu, c])
         if opt.hessian == "gn":
             if opt.row_curvature and getattr(nlp, "has_row_curvature", False):
-                H = nlp.hess_gn(x, nu, shift=0 < opt.shift_after <= it)
+                # The whole curvature of the separation rows first: with it the iteration converges quadratically at an active
+                # contact.  It is kept if the Newton system then has the inertia of a minimisation (n positive, m negative
+                # eigenvalues: the kernels read the same off their Riccati recursion, every stage's Huu positive definite);
+                # otherwise the stage-wise safeguarded model (scaled, from iteration shift_after on shifted) takes its place,
+                # and the next iteration does not try the whole curvature again.
+                H = None
+                if opt.whole_curvature_first and whole_skip == 0:
+                    Hw = nlp.hess_gn(x, nu, whole=True) + sp.diags(sig + opt.reg_primal)
+                    if (nlp.reduced_hessian_pd(Hw, J) if hasattr(nlp, "reduced_hessian_pd") else kkt_inertia_ok(Hw, J, n, m)):
+                        H = Hw
+                    else:
+                        whole_skip = 2
+                whole_skip = max(whole_skip - 1, 0)
+                if H is None:
+                    H = nlp.hess_gn(x, nu, shift=0 < opt.shift_after <= it) + sp.diags(sig + opt.reg_primal)
             else:
-                H = nlp.hess_gn(x)
-            H = H + sp.diags(sig + opt.reg_primal)
+                H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
             sol = spla.splu(K).solve(rhs)
             dx, dnu = sol[:n], sol[n:]
@@ -283,8 +329,16 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                 break
             alpha *= 0.5
         if not accepted:
+            # No restoration phase here.  The independent solvers of oracle/independent_*.py (`lower_mu_on_failure`) give up the
+            # barrier problem at hand instead: mu falls, the filter starts afresh, the iterate stays; a second failure in a row
+            # (or mu at its floor) ends the solve.  The kernels' oracle path (default) reports status 2 at once, like the kernels.
+            if opt.lower_mu_on_failure and mu > mu_floor and not mu_forced:
+                mu = max(mu_floor, min(opt.kappa_mu * mu, mu**opt.theta_mu))
+                mu_forced, filt, filt_mu = True, [], mu
+                continue
             status = STATUS_LINESEARCH
             break
+        mu_forced = False
         if not f_type:
             filt.append(((1.0 - opt.gamma_theta) * theta, phi0 - opt.gamma_phi * theta))
             if len(filt) > opt.filter_cap:

@@ -462,7 +462,10 @@ class MpcNlp:
     def new_iterate(self, x, zl, nu, mu, bound_push):
         """Hook of oracle/ipm.py, called with every accepted iterate: refresh the working set.
         A row that keeps its (face, vertex) identity keeps slack and multipliers; a new row starts
-        at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z."""
+        at sigma = max(sep - dmin, bound_push), z = mu / sigma, nu = -z.
+        (Round 3 tried sigma = max(sep - dmin, min(bound_push, max(mu, 1e-8))), the rule of the planning kernels' hand-over: it ends
+        a period-3 limit cycle of the closed loop on the planned table, but three instances of the independent-solver populations
+        then fail; docs/notebook.md.)"""
         N = self.spec.N
         Xs = x.reshape(N, self.ns)
         old = self.select(Xs)
@@ -568,11 +571,12 @@ class MpcNlp:
         Gd[:, 6] = 2 * wt[4] * P[:, 3] ** 2 * P[:, 6]
         return Gd.ravel()
 
-    def hess_gn(self, X, nu=None, shift=False):
+    def hess_gn(self, X, nu=None, shift=False, whole=False):
         """Gauss-Newton Hessian of the Lagrangian: objective curvature with the (v w)^2 term taken as the
         square of the residual r = v*w (PSD); with `nu`, plus the exact curvature of the separation rows
         sum_r nu_r d2 sep_r / d(x,y,psi)^2 (`row_curvature`).  `shift`: a stage whose curvature would be scaled
-        keeps it whole and gets the smallest multiple of the identity on (x, y, psi) that restores the margin."""
+        keeps it whole and gets the smallest multiple of the identity on (x, y, psi) that restores the margin.
+        `whole`: no safeguard at all -- the caller checks the inertia of the Newton system instead (oracle/ipm.py)."""
         N, ns = self.spec.N, self.ns
         P = X.reshape(N, ns)
         wt = self.spec.weights
@@ -597,7 +601,7 @@ class MpcNlp:
                 a_, b_c, c_ = C[k, 0, 2], C[k, 1, 2], C[k, 2, 2]
                 full = C[k, 0, 0] != 0.0 or C[k, 1, 1] != 0.0 or C[k, 0, 1] != 0.0  # a vertex-vertex row curves x, y too
                 th = 1.0
-                for h in range(11):
+                for h in range(0 if whole else 11):
                     if h == 10:
                         th = 0.0
                         break
@@ -611,7 +615,7 @@ class MpcNlp:
                         if M[0, 0] > 0.0 and d2 > 0.0 and d3 >= 0.0:
                             break
                     th *= 0.5
-                if shift and th < 1.0:
+                if shift and th < 1.0 and not whole:
                     dl = pose_shift(q0 - m_ + C[k, 0, 0], q1 - m_ + C[k, 1, 1], q2 - m_ + C[k, 2, 2], C[k, 0, 1], a_, b_c)
                     th = 1.0
                     for a in range(3):
@@ -624,6 +628,31 @@ class MpcNlp:
         return sp.csr_matrix(
             (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.n, self.n)
         )
+
+    def reduced_hessian_pd(self, H, J):
+        """True if H (Hessian of the Lagrangian + Sigma + reg, [n, n]) is positive definite on the null space of J -- i.e. the
+        Newton system has the inertia of a minimisation -- read off the stage structure the way the kernels do: slack rows
+        condensed into the pose blocks, then the backward Riccati recursion; the answer is "every stage's Huu = R + B'PB is
+        positive definite" (with x0 pinned that is equivalent to the reduced Hessian being positive definite)."""
+        N, ns, nr = self.spec.N, self.ns, self.nr
+        Hd, Jd = H.toarray(), J.toarray()
+        P = None
+        for k in range(N - 1, -1, -1):
+            b = k * ns
+            Hc = Hd[b : b + NP, b : b + NP].copy()
+            for j in range(nr):
+                g = Jd[self.c_blk0 + nr * k + j, b : b + 3]
+                Hc[:3, :3] += Hd[b + NP + j, b + NP + j] * np.outer(g, g)
+            if k == N - 1:  # terminal stage: its inputs are costed but drive no dynamics
+                Hxx, Hux, Huu = Hc[:5, :5], Hc[5:, :5], Hc[5:, 5:]
+            else:
+                A, B = Jd[5 + 5 * k : 10 + 5 * k, b : b + 5], Jd[5 + 5 * k : 10 + 5 * k, b + 5 : b + 7]
+                Hxx, Hux, Huu = Hc[:5, :5] + A.T @ P @ A, Hc[5:, :5] + B.T @ P @ A, Hc[5:, 5:] + B.T @ P @ B
+            if not (Huu[0, 0] > 0.0 and Huu[0, 0] * Huu[1, 1] - Huu[0, 1] * Huu[1, 0] > 0.0):
+                return False
+            P = Hxx - Hux.T @ np.linalg.solve(Huu, Hux)
+            P = 0.5 * (P + P.T)
+        return True
 
     # ---- constraints ---------------------------------------------------------------
     def cons(self, X):

@@ -1,0 +1,56 @@
+"""Generates tests/golden/carry_inputs.npz (`python tests/golden/make_carry_inputs.py`): the inputs (x0, ref, nbr, zu) of three
+consecutive MPC iterations of two vehicles of the benchmark's closed loop (planned reference table, sampler seed 2024, feasible
+starts), replayed on the CPU with the oracle's C port (oracle/closed_loop.py's loop): one vehicle working against active input
+bounds and a neighbour (10-25 iterations per solve from cold multipliers), one that merely tracks its reference.
+tests/golden/make_fixtures.py:carry_golden solves them with the full-KKT oracle, carried and cold."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+PICKS = ((117, 3, 4), (3, 1, 6))  # (scenario, vehicle, first of three consecutive MPC iterations)
+
+
+def record(scenario, vehicle, t0, n=3):
+    from conflict_rez_amd import scenarios
+    from oracle import port
+    from oracle.closed_loop import seed
+    from oracle.dynamics import plant_step
+    from oracle.mpc_nlp import MpcSpec
+
+    spec = scenarios.parking_lot_spec()
+    table, _ = scenarios.load_reference_table(kind="planned")
+    ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
+    k0, noise = scenarios.sample_scenarios(1024, table, seed=2024, spec=spec)
+    k0, noise = k0[scenario:scenario + 1], noise[scenario:scenario + 1]
+    N, V, T = ospec.N, table.shape[0], table.shape[1]
+    state, pred = seed(table, k0, noise, N)
+    carry = [None] * V
+    adv = np.minimum(np.arange(N) + 1, N - 1)
+    out = []
+    for t in range(t0 + n):
+        newp = pred.copy()
+        kr = np.minimum(k0[0] + t + np.arange(N), T - 1)
+        for v in range(V):
+            nb = np.stack([pred[0, u][:3][:, adv] for u in range(V) if u != v])
+            w = pred[0, v][:, adv]
+            args = (state[0, v].copy(), table[v, kr, :3].T.copy(), nb.copy(), w.copy())
+            r = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), carry=carry[v])
+            if v == vehicle and t >= t0:
+                out.append(args + (r["iters"], r["status"]))
+            carry[v] = r["carry"]
+            newp[0, v] = r["p"].T if r["status"] == 0 else w
+            state[0, v] = plant_step(state[0, v], newp[0, v][5:7, 0], spec.dt, spec.wb)
+        pred = newp
+    return out
+
+
+if __name__ == "__main__":
+    rec = [c for pick in PICKS for c in record(*pick)]
+    for c in rec:
+        print("iters (carried, closed loop)", c[4], "status", c[5])
+    np.savez_compressed(os.path.join(HERE, "carry_inputs.npz"), x0=np.array([c[0] for c in rec]), ref=np.array([c[1] for c in rec]),
+                        nbr=np.array([c[2] for c in rec]), zu=np.array([c[3] for c in rec]))

@@ -17,7 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HERE = os.path.dirname(os.path.abspath(__file__))
-AGENTS = ("vehicle_2", "vehicle_3")  # default: joint_independent.npz; `... vehicle_0 vehicle_2` -> joint_independent_02.npz
+AGENTS = ("vehicle_2", "vehicle_3")  # default: joint_independent.npz; `... vehicle_0 vehicle_2` -> joint_independent_02.npz (a corner of
+#   vehicle 0 against a corner of vehicle 2 at dmin: the vertex-vertex pair rows); `... vehicle_0 vehicle_2 vehicle_3` ->
+#   joint_independent_023.npz (three vehicles, three pairs: the shape of the reference's `main`, multi_vehicle_planner.py:605-642);
+#   all four -> joint_independent_0123.npz (BASELINE configs[3]: four vehicles, six pairs)
 
 
 def plans_of_strategy():
@@ -33,22 +36,106 @@ def plans_of_strategy():
     return {a: ([dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]], paths[a]) for a in sorted(hist)}
 
 
+def joint_kkt_certificate(nlp, z):
+    """Solver-free certificate of a joint plan z = [points of every vehicle | dt] on oracle/independent_joint.py's statement: bounded
+    least squares for multipliers (equality rows free; active inequality rows -- every vehicle's own and the pair distances -- and
+    active bounds >= 0) that combine the active gradients into the cost gradient.
+    Returns (relative residual, lambda_eq, c_eq, [(pair, point, multiplier)] of the active pair rows)."""
+    from scipy.optimize import lsq_linear
+    from threadpoolctl import threadpool_limits
+
+    gs, h = nlp.gs, 1e-6
+    Je, ce, Ji, Eb = [], [], [], []
+    for a, g in enumerate(gs):
+        za, cols = nlp.z_of(z, a), nlp.cols(a)
+        J = np.zeros((len(g.eq(za)), nlp.n0))
+        J[:, cols] = g.eq_jac(za)
+        Je.append(J); ce.append(g.eq(za))
+        act = np.nonzero(g.ineq(za) < 1e-6)[0]
+        if len(act):
+            J = np.zeros((len(act), nlp.n0))
+            J[:, cols] = g.ineq_jac(za)[act]
+            Ji.append(J)
+        bd = g.bounds()
+        lo = np.array([b[0] if b[0] is not None else -np.inf for b in bd]); hi = np.array([b[1] if b[1] is not None else np.inf for b in bd])
+        for i in np.nonzero(za - lo < 1e-6)[0]:
+            e = np.zeros(nlp.n0); e[cols[i]] = 1.0; Eb.append(e)
+        for i in np.nonzero(hi - za < 1e-6)[0]:
+            e = np.zeros(nlp.n0); e[cols[i]] = -1.0; Eb.append(e)
+    pair_rows = []
+    for e_, (a, b) in enumerate(nlp.pairs):  # active pair distances: gradient by central differences in the six pose variables
+        d0 = nlp.pair_dist(z, a, b)
+        for r in np.nonzero(d0 - nlp.dmin < 1e-6)[0]:
+            row = np.zeros(nlp.n0)
+            for veh, which in ((a, 0), (b, 1)):
+                for c in range(3):
+                    dlt = np.zeros((len(d0), 3)); dlt[r, c] = h
+                    dp = nlp.pair_dist(z, a, b, da=dlt if which == 0 else None, db=dlt if which == 1 else None)[r]
+                    dm = nlp.pair_dist(z, a, b, da=-dlt if which == 0 else None, db=-dlt if which == 1 else None)[r]
+                    row[nlp.off[veh] + 7 * r + c] = (dp - dm) / (2 * h)
+            Ji.append(row[None]); pair_rows.append((e_, int(r)))
+    Je, ce = np.vstack(Je), np.concatenate(ce)
+    Ji = np.vstack(Ji) if Ji else np.zeros((0, nlp.n0))
+    Eb = np.array(Eb).reshape(-1, nlp.n0)
+    gf = nlp.grad(np.concatenate([z, np.zeros(nlp.mi)]))[: nlp.n0]
+    A = np.vstack([Je, Ji, Eb]).T
+    lb = np.concatenate([np.full(len(Je), -np.inf), np.zeros(len(Ji) + len(Eb))])
+    with threadpool_limits(limits=1):
+        r = lsq_linear(A, gf, bounds=(lb, np.full(A.shape[1], np.inf)), method="bvls", max_iter=1500)
+    res = float(np.abs(A @ r.x - gf).max() / np.abs(gf).max())
+    lam_pairs = r.x[len(Je) + len(Ji) - len(pair_rows): len(Je) + len(Ji)] if pair_rows else np.zeros(0)
+    return res, r.x[: len(Je)], ce, [(e_, q, float(l)) for (e_, q), l in zip(pair_rows, lam_pairs)]
+
+
+def vertex_pair_contacts(nlp, z, active):
+    """Of the active pair rows [(pair, point, multiplier)] those whose closest features are two vertices."""
+    from oracle.independent_mpc import _body_vertices
+    from oracle.mpc_nlp import body_vertices, closest_vertex_pair
+
+    g = nlp.gs[0].g
+    out = []
+    for e_, q, lam in active:
+        a, b = nlp.pairs[e_]
+        pa, pb = nlp.poses(z, a, q + 1)[q], nlp.poses(z, b, q + 1)[q]
+        Wb = _body_vertices(pb[None, 0], pb[None, 1], pb[None, 2], g)[0]
+        if closest_vertex_pair(Wb, pa[:2], pa[2], g, body_vertices(g)) is not None:
+            out.append((e_, q, lam))
+    return out
+
+
 if __name__ == "__main__":
     import test_colloc as tc
     from oracle.independent_colloc import GeometricColloc
-    from oracle.independent_joint import solve_joint_ipm
+    from oracle.independent_joint import GeometricJointIpm, solve_joint_ipm
 
-    if len(sys.argv) == 3:
-        AGENTS = (sys.argv[1], sys.argv[2])
-    out_name = "joint_independent.npz" if AGENTS == ("vehicle_2", "vehicle_3") else "joint_independent_%s%s.npz" % (AGENTS[0][-1], AGENTS[1][-1])
+    DMIN = 0.05  # `--dmin 0.2`: a larger clearance (vehicle.py:369 / multi_vehicle_planner.py:343 take it as an argument); with 0.2 the
+    #              bodies of vehicles 2 and 3 are in contact (five ACTIVE pair rows) at the optimum -> joint_independent_23_d20.npz
+    args = sys.argv[1:]
+    if "--dmin" in args:
+        DMIN = float(args[args.index("--dmin") + 1])
+        del args[args.index("--dmin"): args.index("--dmin") + 2]
+    if len(args) >= 2:
+        AGENTS = tuple(args)
+    V = len(AGENTS)
+    out_name = "joint_independent.npz" if (AGENTS == ("vehicle_2", "vehicle_3") and DMIN == 0.05) else "joint_independent_%s%s.npz" % (
+        "".join(a[-1] for a in AGENTS), "" if DMIN == 0.05 else "_d%02d" % round(100 * DMIN))
     plans = plans_of_strategy()
-    jn, sp = tc._joint_problem(plans, list(AGENTS), [0, 0], nps=5)
-    X0, _ = tc._joint_guess(plans, list(AGENTS), jn, sp, 5)
-    guesses = [X0[7 * 6 * jn.off[a]: 7 * 6 * jn.off[a + 1]].reshape(-1, 7) for a in range(2)]
-    gs = [GeometricColloc(plans[a][1][0], plans[a][0], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=float(plans[a][1][-1, 2])) for a in AGENTS]
+    jn, sp = tc._joint_problem(plans, list(AGENTS), [0] * V, nps=5)
+    X0, _ = tc._joint_guess(plans, list(AGENTS), jn, sp, 5)  # the single plans (at the reference's dmin 0.05) on their mean dt
+    guesses = [X0[7 * 6 * jn.off[a]: 7 * 6 * jn.off[a + 1]].reshape(-1, 7) for a in range(V)]
+    gs = [GeometricColloc(plans[a][1][0], plans[a][0], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=float(plans[a][1][-1, 2]), dmin=DMIN) for a in AGENTS]
+    pairs = [(a, b) for a in range(V) for b in range(a + 1, V)]
     t0 = time.time()
-    r = solve_joint_ipm(gs, [(0, 1)], guesses, float(X0[jn.iDt]))
+    r = solve_joint_ipm(gs, pairs, guesses, float(X0[jn.iDt]))
     print({k: v for k, v in r.items() if k != "trajs"}, "%.0f s" % (time.time() - t0), flush=True)
-    assert r["status"] in (0, 2) and r["eq"] < 2e-8 and r["ineq"] > -1e-8
-    np.savez_compressed(os.path.join(HERE, out_name), guess0=guesses[0], guess1=guesses[1], dt0=float(X0[jn.iDt]),
-                        traj0=r["trajs"][0], traj1=r["trajs"][1], dt=r["dt"], cost=r["cost"], iters=r["iters"], status=r["status"], pair=r["pair"])
+    z = np.concatenate([t.ravel() for t in r["trajs"]] + [[r["dt"]]])
+    res, lam_eq, c_eq, active = joint_kkt_certificate(GeometricJointIpm(gs, pairs, z), z)
+    vc = vertex_pair_contacts(GeometricJointIpm(gs, pairs, z), z, active)
+    value = r["cost"] - float(lam_eq @ c_eq)  # first-order correction for the residual of the equality rows (make_independent_colloc_vv.py)
+    print("certificate %.1e" % res, "active pair rows", active, "vertex-vertex", vc, "value %.9f" % value, flush=True)
+    out = dict(dmin=DMIN, dt0=float(X0[jn.iDt]), dt=r["dt"], cost=r["cost"], value=value, iters=r["iters"], status=r["status"], pair=r["pair"],
+               contacts=np.array(vc, float).reshape(-1, 3), active=np.array(active, float).reshape(-1, 3), certificate=res)
+    for a in range(V):
+        out[f"guess{a}"], out[f"traj{a}"] = guesses[a], r["trajs"][a]
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+    assert r["status"] in (0, 1, 2) and r["eq"] < 5e-8 and r["ineq"] > -1e-8 and res < 1e-7

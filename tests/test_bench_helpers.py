@@ -13,7 +13,7 @@ def test_profile_summaries_parse():
 
 
 def test_cpu_closed_loop_worker_and_probe():
-    n, its, ok, secs, cold = bench._cpu_closed_loop_worker((0, 2, 1, 2))   # seed 0, 2 scenarios, 1 warm-up + 2 timed iterations
+    n, its, ok, secs, cold = bench._cpu_closed_loop_worker((0, 2, 1, 2, "planned", True))   # seed 0, 2 scenarios, 1 warm-up + 2 timed iterations
     assert n == 2 * 4 * 2 and 0 < ok <= n and its >= ok and secs > 0.0
     assert cold[0] == 8 and cold[1] >= 8
     assert "casadi" in bench.casadi_probe().lower()
