@@ -161,6 +161,138 @@ def profiled_sq(kernel):
     return {"frac": 4.0 * raw, "raw_quotient": raw}, os.path.basename(tags[-1])[: -len("_pmc_SQ.csv")]
 
 
+TAU5 = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])  # Radau-5 nodes
+
+
+def planning_extras(device=0, B=256, cpu=True):
+    """BASELINE.json configs[1] and configs[3], measured OUTSIDE the timed region of the headline (same process, same GPU):
+    configs[1]  B single-vehicle plans (`Vehicle.state_ws` -> collocation plan, vehicle.py:99-231, :360-661): the four vehicles of the
+                synthetic strategy in turn, start poses scattered by +-3 cm; one `cfz_state_ws` and one `cfz_colloc` launch;
+    configs[3]  B four-vehicle joint plans (`solve_final_problem_obca`, multi_vehicle_planner.py:343-480) from those single plans,
+                one `cfz_joint_colloc` launch (one workgroup per plan).
+    Times are wall-clock around the C-ABI calls (host buffers in and out: the transfers are megabytes, the launches seconds).
+    `roofline`: algorithmic HBM bytes = 3 x the band (cleared and assembled once, read and written once by the elimination) per
+    interior-point iteration, summed over the plans' iteration counts, over the launch time, against the 8 TB/s roof.
+    `cpu_baseline` ("port": the CPU build of the same kernel source, tests/emu, one core): one plan of every vehicle / one joint plan."""
+    import tempfile
+
+    from conflict_rez_amd import engine, scenarios, strategy as strat
+    from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+    from conflict_rez_amd.vehicle_types import VehicleBody
+
+    hist = strat.generate_strategy(4)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "4v_rl_traj")
+        strat.write_strategy(fn, hist)
+        sets, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+    agents = sorted(hist)
+    tubes = {a: [((s["back"].A, s["back"].b), (s["front"].A, s["front"].b)) for s in sets[a][1:]] for a in agents}
+    fh = {a: float(paths[a][-1, 2]) for a in agents}
+    sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    rng = np.random.default_rng(0)
+    who = [agents[i % 4] for i in range(4 * B)]  # B scenarios x 4 vehicles; the first B entries are configs[1]'s plans
+    init = [paths[a][0] + np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] for a in who]
+
+    def guess_of(ws, n_sets, nps=5):  # interp_ws_for_collocation (vehicle.py:298-358) + dt0 = t_end / N (:388)
+        N = nps * (n_sets - 1)
+        t = 0.1 * np.arange(len(ws))
+        ti = (np.arange(N)[:, None] + TAU5[None, :]).ravel() / N * t[-1]
+        return np.stack([np.interp(ti, t, ws[:, c]) for c in range(7)], 1), t[-1] / N
+
+    def single_plans(idx):
+        t0 = time.perf_counter()
+        ws = engine.state_ws([init[i] for i in idx], [tubes[who[i]] for i in idx], [paths[who[i]] for i in idx], [fh[who[i]] for i in idx],
+                             shrink_tube=0.5, device=device)
+        t1 = time.perf_counter()
+        good = [k for k, w in enumerate(ws) if w["status"] == 0]
+        gs = {k: guess_of(ws[k]["traj"], len(tubes[who[idx[k]]]) + 1) for k in good}
+        t2 = time.perf_counter()
+        rg = engine.colloc(sp0, [init[idx[k]] for k in good], [tubes[who[idx[k]]] for k in good], [gs[k][0] for k in good],
+                           [gs[k][1] for k in good], [fh[who[idx[k]]] for k in good], max_iter=400, device=device)
+        t3 = time.perf_counter()
+        return ws, good, dict(zip(good, rg)), t1 - t0, t3 - t2
+
+    out = {}
+    # ---- configs[1] ------------------------------------------------------------------------------------------------------------
+    single_plans(list(range(8)))  # warm-up: module load, workspace allocation
+    ws, good, plans, t_ws, t_col = single_plans(list(range(B)))
+    band = {a: engine.colloc_band_info([len(tubes[a]) + 1]) for a in agents}
+    alg = sum(3.0 * band[who[k]][2] * plans[k]["iters"] for k in plans)
+    ok = sum(r["status"] == 0 for r in plans.values())
+    out["configs[1]"] = {
+        "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5, 6 obstacles)",
+        "plans_per_s": B / (t_ws + t_col), "state_ws_s": t_ws, "colloc_s": t_col, "state_ws_converged": len(good), "colloc_converged": ok,
+        "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])),
+        "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg / t_col / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / t_col / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes": "3 x band bytes (nk x (3 kb + 1) x 8: %s) x iterations of every plan" % {a: band[a][2] for a in agents}}}
+    # ---- configs[3] ------------------------------------------------------------------------------------------------------------
+    idx = list(range(4 * B))
+    ws4, good4, plans4, _, _ = single_plans(idx)
+    scen = []
+    for b in range(B):
+        ks = [4 * b + i for i in range(4)]
+        if not all(k in plans4 and plans4[k]["status"] == 0 for k in ks):
+            continue
+        scen.append(dict(init_poses=[init[k] for k in ks], tubes=[tubes[a] for a in agents], guesses=[plans4[k]["traj"].reshape(-1, 7) for k in ks],
+                         dt0=float(np.mean([plans4[k]["dt"] for k in ks])), final_headings=[fh[a] for a in agents]))
+    t0 = time.perf_counter()
+    rj = engine.joint_colloc_batch(sp0, scen, max_iter=300, device=device)
+    t_joint = time.perf_counter() - t0
+    nk4, kb4, bb4 = engine.colloc_band_info([len(tubes[a]) + 1 for a in agents])
+    alg4 = sum(3.0 * bb4 * r["iters"] for r in rj)
+    out["configs[3]"] = {
+        "workload": f"BASELINE.json configs[3]: {len(scen)} centralised four-vehicle joint plans (six pairs, one shared dt) in one launch, one workgroup each",
+        "plans_per_s": len(scen) / t_joint, "joint_s": t_joint, "converged": sum(r["status"] == 0 for r in rj),
+        "iters_mean": float(np.mean([r["iters"] for r in rj])), "iters_max": int(max(r["iters"] for r in rj)),
+        "unknowns": nk4, "half_bandwidth": kb4, "band_bytes": bb4,
+        "roofline": {"bound": "hbm", "kernel": "colloc_kernel<2>", "achieved": alg4 / t_joint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg4 / t_joint / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes": "3 x band bytes x iterations of every plan"}}
+    if cpu:
+        try:
+            out["configs[1]"]["cpu_baseline"], out["configs[3]"]["cpu_baseline"] = planning_cpu_baseline(agents, sets, paths, fh)
+        except Exception as e:  # noqa: BLE001 - reporting only
+            out["configs[1]"]["cpu_baseline"] = out["configs[3]"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def planning_cpu_baseline(agents, sets, paths, fh):
+    """One core, the CPU build of the planning kernels' own source (tests/emu, "kind": "port"): the four vehicles' single plans
+    (state_ws + collocation) and ONE four-vehicle joint plan from them -- a bounded sample of configs[1] / configs[3]."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import colloc_emu_binding as ce
+    import plan_emu_binding as pe
+    from conflict_rez_amd import scenarios
+    from oracle import ipm
+    from oracle.colloc_nlp import CollocNlp, JointCollocNlp
+    from oracle.plan_nlp import StateWsNlp, speed_guess
+    from scipy.interpolate import interp1d
+
+    sp = scenarios.parking_lot_spec()
+    otubes = {a: [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in sets[a]] for a in agents}
+    opt = ipm.IpmOptions(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2, mu_init=0.1)
+    t0 = time.perf_counter()
+    singles = []
+    for a in agents:
+        p = paths[a]
+        ws = StateWsNlp(p[0], otubes[a], final_heading=fh[a], shrink_tube=0.5)
+        r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0))
+        z = ws.unpack(r["X"])
+        nlp = CollocNlp(p[0], otubes[a], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh[a])
+        N = nlp.N[0]
+        t_i = np.concatenate([i + nlp.tau for i in range(N)]) / N * z["t"][-1]
+        X0 = nlp.pack({k: interp1d(z["t"], z[k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")}, z["t"][-1] / N)
+        singles.append(nlp.unpack(ce.solve(nlp, X0, opt)["X"]))
+    t1 = time.perf_counter()
+    jn = JointCollocNlp([dict(init_pose=paths[a][0], tube=otubes[a], final_heading=fh[a]) for a in agents], sp.A_obs, sp.b_obs, N_per_set=5)
+    rj = ce.solve(jn, jn.pack(singles, float(np.mean([s["dt"] for s in singles]))), opt)
+    t2 = time.perf_counter()
+    return ({"value": 4 / (t1 - t0), "unit": "plans/s", "cores": 1, "kind": "port", "sample": f"the four vehicles' plans (state_ws + collocation), {t1 - t0:.1f} s"},
+            {"value": 1 / (t2 - t1), "unit": "plans/s", "cores": 1, "kind": "port",
+             "sample": f"one four-vehicle joint plan, {rj['iters']} iterations, status {rj['status']}, {t2 - t1:.1f} s"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +319,7 @@ def main():
                          "collocation plan, VehicleFollower.plan_single_path) of the synthetic strategy, SURVEY.md 8d config 3; state_ws: "
                          "data/refs_4v.npz, the slower state_ws warm-start plans (the table of rounds 1-2); replan: build the planned table "
                          "at start-up with the GPU planning chain instead of loading it")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] planning measurements after the timed region")
     ap.add_argument("--raw-starts", action="store_true",
                     help="take the sampler's starts as they come (rounds 1-2); default: a scenario whose noisy start state is already "
                          "inside a clearance (an infeasible first NLP, status 4) is drawn again")
@@ -380,6 +513,11 @@ def main():
         }
         if cold is not None:
             line["cold_step"] = cold
+        if world == 1 and not args.no_extras and not single and not vehicle_sharded:
+            try:
+                line["extra"] = planning_extras(device=local_rank, cpu=not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001 - the headline must go out whatever happens here
+                line["extra"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not single:
             line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps, ref_kind="state_ws" if args.reference == "state_ws" else "planned",
                                                 feasible=fspec is not None)

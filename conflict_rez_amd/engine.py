@@ -153,7 +153,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
+    "cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -282,6 +282,22 @@ def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0
         out.append(dict(traj=traj[o : o + Np[b]].reshape(-1, 6, 7).copy(), dt=float(dt[b]), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
         o += Np[b]
     return out
+
+
+def colloc_band_info(n_sets, N_per_set=5, n_obs=6, pairs=None, has_final=None):
+    """`cfz_colloc_band_info`: (unknowns nk, half-bandwidth kb, bytes of the band) of the banded system of one (joint) collocation
+    plan of len(n_sets) vehicles with n_sets[a] strategy steps each (host arithmetic, needs no GPU)."""
+    lib = load_library()
+    ns = np.ascontiguousarray(np.asarray(n_sets, np.int32))
+    hf = None if has_final is None else np.ascontiguousarray(np.asarray(has_final, np.int32))
+    pr = None if pairs is None else np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    nk, kb, bb = C.c_int32(), C.c_int32(), C.c_int64()
+    lib.cfz_colloc_band_info.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.cfz_colloc_band_info(len(ns), _ptr(ns), _ptr(hf), int(N_per_set), int(n_obs), 0 if pr is None else len(pr), _ptr(pr),
+                                  C.addressof(nk), C.addressof(kb), C.addressof(bb))
+    if rc != 0:
+        raise RuntimeError("cfz_colloc_band_info: " + lib.cfz_last_error().decode())
+    return int(nk.value), int(kb.value), int(bb.value)
 
 
 def joint_colloc_batch(spec, scenarios, pairs=None, device=0, ws=None, **options):

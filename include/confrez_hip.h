@@ -287,6 +287,13 @@ int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_c
                      const double *init_pose, const double *final_heading, const double *tube, const double *guess, const double *dt0,
                      int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost);
 
+/* Size of the banded primal-dual system one (joint) collocation plan is eliminated on (host arithmetic, no device): unknowns nk,
+ * half-bandwidth kb of the ordering, bytes of the band as stored (LAPACK general-band layout, nk x (3 kb + 1) doubles).  V vehicles
+ * with n_sets[V] strategy steps each, has_final[V] (NULL = all have a terminal heading), pairs as in cfz_joint_colloc (NULL = all
+ * pairs; V = 1: none).  bench.py prices the planning kernels' HBM traffic with it.  Any output pointer may be NULL. */
+int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs,
+                         const int32_t *pairs, int32_t *nk, int32_t *kb, int64_t *band_bytes);
+
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
  * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt

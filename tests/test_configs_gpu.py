@@ -286,28 +286,33 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     check_plan_against_independent(r2["traj"], r2["dt"], True, agent)
 
 
-def test_joint_plan_against_the_independent_solver_on_gpu():
+@pytest.mark.parametrize("name", ["23", "23_d20", "123_d20"])
+def test_joint_plan_against_the_independent_solver_on_gpu(name):
     """`cfz_joint_colloc` (HIP, through the C ABI) on the joint plan of vehicles 2 and 3 from the fixture's guess against the optimum
     an INDEPENDENT solver found on an independent statement of `solve_final_problem_obca` (tests/golden/joint_independent.npz:
     polygon distances between bodies and obstacles and between the two bodies, no working sets, no condensation, no band, SuperLU on
     the full KKT system; multi_vehicle_planner.py:343-480, 30 + 40 intervals, one shared free dt) -- not against the CPU compile of
     the kernel's own source.  At the reference's tolerance: rows of the geometric statement to 1e-2, cost within 1 %, poses within
     1 cm; at tight tolerances (`exact_rows`) the optimum itself, cost to 1e-6, poses to 5e-5 m.  Assertions shared with the CPU
-    test (tests/test_independent_solver.py:check_joint_against_independent)."""
+    test (tests/test_independent_solver.py:check_joint_against_independent).
+    `23_d20`, `123_d20` (dmin = 0.2; the latter three vehicles and three pairs, the shape of the reference's `main`,
+    multi_vehicle_planner.py:605-642): the bodies of vehicles 2 and 3 are in CONTACT at the optimum -- pair rows active with
+    multipliers 0.35 / 0.28 -- so the vehicle-vehicle rows decide the plan there."""
     from conflict_rez_amd import engine
-    from test_independent_solver import JOINT_AGENTS, _joint_fixture, check_joint_against_independent
+    from test_independent_solver import _joint_fixture, check_joint_against_independent
 
-    d, gs, plans, sp = _joint_fixture()
-    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in JOINT_AGENTS]
-    guesses = [d["guess0"], d["guess1"]]
-    args = (scenarios.parking_lot_spec(n_nbr=0, N=2), [plans[a][1][0] for a in JOINT_AGENTS], tubes, guesses, float(d["dt0"]),
-            [float(plans[a][1][-1, 2]) for a in JOINT_AGENTS])
+    d, gs, plans, sp = _joint_fixture(name)
+    agents = d["agents"]
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    guesses = [d[f"guess{a}"] for a in range(len(agents))]
+    args = (scenarios.parking_lot_spec(n_nbr=0, N=2, dmin=d["dmin_"]), [plans[a][1][0] for a in agents], tubes, guesses, float(d["dt0"]),
+            [float(plans[a][1][-1, 2]) for a in agents])
     r = engine.joint_colloc(*args, max_iter=400)
     assert r["status"] == 0 and r["iters"] < 60
-    check_joint_against_independent(r["traj"], r["dt"], False)
+    check_joint_against_independent(r["traj"], r["dt"], False, name)
     r2 = engine.joint_colloc(*args, max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)
     assert r2["status"] in (0, 1, 2, 3), r2["status"]  # ends AT the optimum with the iteration limit or the line search exhausted
-    check_joint_against_independent(r2["traj"], r2["dt"], True)
+    check_joint_against_independent(r2["traj"], r2["dt"], True, name)
 
 
 def test_panel_elimination_equals_one_pivot_at_a_time(lot):
