@@ -1409,6 +1409,11 @@ CFZP_FN void handover(int o, int n, const double sep[2], double dmin, double mu,
 CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, double mu, bool first) {
   const CDims d = cdims(sp);
   double chg = 0.0;
+  // In the joint plan a face block turns vertex-vertex only beyond a margin of 0.1 mm while the barrier parameter is coarse
+  // (cfz::select_from, vv_enter): measured on the 254-plan launch of configs[3], two plans whose blocks flipped between the two
+  // certificates of one contact at every iterate needed 160 and 174 iterations (the others at most 66) and tripled the launch.
+  // From mu < 1e-4 on (the last barrier problems), and in the single plans, a block changes at once.
+  const double vv_enter = (sp.V > 1 && mu >= 1e-4) ? 1e-4 : 0.0;
   CFZP_LANE_FOR(q, 0, d.np - 1) {
     const double *p = X + 7 * q;
     double sn, cs;
@@ -1417,7 +1422,7 @@ CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
       double A[4][2], b[4], V[4][2], sep[2];
       obstacle(sp, j, A, b, V);
       const int old = first ? 0 : w.sel[q * sp.n_obs + j];
-      const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old, sp.vv_rows);
+      const int nw = cfz::select_rows(A, b, V, p[0], p[1], cs, sn, sp.g, old, sp.vv_rows, vv_enter);
       if (nw != old) {
         chg = 1.0;
         w.sel[q * sp.n_obs + j] = (unsigned char)nw;
@@ -1441,7 +1446,7 @@ CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
     double A[4][2], b[4], V[4][2];
     veh_polygon(pb, sp.g, A, b, V);
     const int old = first ? 0 : w.sel[d.np * sp.n_obs + pp];
-    const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old, sp.vv_rows);
+    const int nw = cfz::select_rows(A, b, V, pa[0], pa[1], cos(pa[2]), sin(pa[2]), sp.g, old, sp.vv_rows, vv_enter);
     if (nw != old) {
       chg = 1.0;
       w.sel[d.np * sp.n_obs + pp] = (unsigned char)nw;

@@ -460,7 +460,7 @@ CFZ_FN void block_dists(const double A[4][2], const double b[4], const double V[
 // body vertex v (signs of the kind-2 distances), and W_v lies beyond both polygon edges that leave V_u; such a pair is THE
 // closest pair of the two convex polygons, and it replaces the face rows when its distance exceeds theirs.
 CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, const double V[4][2], const double px[4],
-                       const double py[4]) {
+                       const double py[4], double vv_enter = 0.0) {
   const int pidx = ((prev >> 6) - 1) * 4 + ((prev >> 4) & 3);  // face index of the previous working set
   const bool hp = prev != 0 && (prev >> 6) != 3;               // there is a previous face to prefer
   double best = 0.0, prev_val = 0.0;
@@ -512,17 +512,22 @@ CFZ_FN int select_from(const double D[8][4], int prev, double dsel[4], int vv, c
     }
     if (pc != 0 && dn > 0.0) {
       const double r = sqrt(r2);
-      if (r > dn + 1e-9) { code = pc; dsel[0] = r; dsel[1] = r; dsel[2] = r; dsel[3] = r; }
+      // vv_enter (the joint plan: 1e-4 while mu >= 1e-4): a FACE block turns into a vertex-vertex block only when the pair's
+      // distance exceeds the face's separation by that much -- near a transition of the closest features the two certificates
+      // differ by micrometres while their curvatures differ by multiplier / distance, and a block that flipped at every iterate
+      // took a joint plan from 55 to 157 iterations; the margin is dropped for the last barrier problems, so the limit is exact
+      const double enter = ((prev >> 6) != 3 && prev != 0 && vv_enter > 1e-9) ? vv_enter : 1e-9;
+      if (r > dn + enter) { code = pc; dsel[0] = r; dsel[1] = r; dsel[2] = r; dsel[3] = r; }
     }
   }
   return code;
 }
 
 CFZ_CALL int select_rows(const double A[4][2], const double b[4], const double V[4][2], double x, double y, double c,
-                       double s, const double g[4], int prev, int vv = 0) {  // the planning kernels (values come from rows_for)
+                       double s, const double g[4], int prev, int vv = 0, double vv_enter = 0.0) {  // the planning kernels (values come from rows_for)
   double D[8][4], dsel[4], px[4], py[4];
   block_dists(A, b, V, x, y, c, s, g, D, px, py);
-  return select_from(D, prev, dsel, vv, V, px, py);
+  return select_from(D, prev, dsel, vv, V, px, py, vv_enter);
 }
 
 // working set AND the values of its two rows in one pass (the rows are two of the distances the selection looked at)

@@ -105,20 +105,22 @@ class JointCollocNlp:
         a, b = self.pairs[e]
         return int(self.off[a]) * K_PTS + r, int(self.off[b]) * K_PTS + r
 
-    def select(self, X, prev=None):
-        """Working set codes: [np, n_obs] for the obstacles followed by npp for the pairs, flattened."""
+    def select(self, X, prev=None, vv_enter=0.0):
+        """Working set codes: [np, n_obs] for the obstacles followed by npp for the pairs, flattened.  vv_enter: margin by which
+        a vertex pair's distance must exceed a face block's separation before the block turns vertex-vertex (the kernel passes
+        1e-4 in the joint plan while mu >= 1e-4, cfz_colloc.inl refresh_working_set)."""
         P = X[: self.iDt].reshape(self.np, 7)
         sel = np.zeros(self.np * self.n_obs + self.npp, np.uint8)
         prev = np.zeros_like(sel) if prev is None else np.asarray(prev).ravel()
         for q in range(self.np):
             for j in range(self.n_obs):
-                sel[q * self.n_obs + j] = select_rows(self.A_obs[j], self.b_obs[j], self.PV[j], P[q, :2], P[q, 2], self.g, self.BV, int(prev[q * self.n_obs + j]), vv=self.vv)
+                sel[q * self.n_obs + j] = select_rows(self.A_obs[j], self.b_obs[j], self.PV[j], P[q, :2], P[q, 2], self.g, self.BV, int(prev[q * self.n_obs + j]), vv=self.vv, vv_enter=vv_enter)
         for e in range(len(self.pairs)):
             for r in range(self.poff[e + 1] - self.poff[e]):
                 qa, qb = self.pair_points(e, r)
                 A, b, PV = body_polygon(P[qb, :3], self.g, self.BV)
                 i = self.np * self.n_obs + self.poff[e] + r
-                sel[i] = select_rows(A, b, PV, P[qa, :2], P[qa, 2], self.g, self.BV, int(prev[i]), vv=self.vv)
+                sel[i] = select_rows(A, b, PV, P[qa, :2], P[qa, 2], self.g, self.BV, int(prev[i]), vv=self.vv, vv_enter=vv_enter)
         return sel
 
     def f(self, X):
@@ -228,8 +230,8 @@ class CollocNlp(JointCollocNlp):
         self.S, self.tube, self.init_pose, self.final_heading = len(tube), tube, np.asarray(init_pose, float), final_heading
         self.N1 = self.N[0]
 
-    def select(self, X, prev=None):
-        return super().select(X, prev).reshape(self.np, self.n_obs)
+    def select(self, X, prev=None, vv_enter=0.0):
+        return super().select(X, prev, vv_enter).reshape(self.np, self.n_obs)
 
     def pack(self, zu0, dt0):
         return super().pack([zu0], dt0)

@@ -240,7 +240,7 @@ def closest_vertex_pair(PV, t, psi, g, BV):
     return None
 
 
-def select_rows(A, b, PV, t, psi, g, BV, prev=0, vv=False):
+def select_rows(A, b, PV, t, psi, g, BV, prev=0, vv=False, vv_enter=0.0):
     """Working set of one block: the separating face and the two vertices whose rows are imposed.
 
     The separating direction is the face normal (8 candidates in the order polygon faces 0..3,
@@ -282,8 +282,10 @@ def select_rows(A, b, PV, t, psi, g, BV, prev=0, vv=False):
     if vv and dn > 0.0:
         # kind 3: the closest features are two vertices -> the Euclidean distance of that pair is the separation (it exceeds
         # every face-normal separation there); code 192 + u*16 + v*4 + v, both rows of the block carry that distance
+        # vv_enter (the joint plan's pair blocks: 1e-4 while mu >= 1e-4): a face block turns vertex-vertex only beyond that margin
         pair = closest_vertex_pair(PV, t, psi, g, BV)
-        if pair is not None and pair[2] > dn + 1e-9:
+        enter = vv_enter if (prev and (prev >> 6) != 3 and vv_enter > 1e-9) else 1e-9
+        if pair is not None and pair[2] > dn + enter:
             return 192 + pair[0] * 16 + pair[1] * 4 + pair[1]
     return bk * 64 + bf * 16 + va * 4 + vb
 
