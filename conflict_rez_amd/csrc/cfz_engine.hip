@@ -1,10 +1,12 @@
 // cfz_engine.hip -- libconfrez_hip.so: gfx950 kernels and the C ABI of include/confrez_hip.h.
 //
 // Kernels
-//   solve_kernel   one 64-lane workgroup (one wavefront) per MPC-step NLP; iterate, stage data
-//                  and reduction scratch in LDS (cfz_solver.inl); parameters, warm start and
-//                  solution are the only global-memory traffic (8*(5 + 3N + 3N n_nbr + 2*7N) B
-//                  per instance).
+//   solve_kernel   one 128-lane workgroup (two wavefronts; four lanes of a DPP quad per stage) per MPC-step NLP; iterate,
+//                  stage data and reduction scratch in LDS (cfz_solver.inl: 40,920 B per instance, four instances per CU);
+//                  parameters, warm start and solution are the only algorithmic global-memory traffic
+//                  (8*(5 + 3N + 3N n_nbr + 2*7N) B per instance) beside the carry record of the slot (8.8 KB)
+//   loop_kernel    the persistent closed loop (cfz_loop_run): the same solver body fed from per-iteration ticket queues of
+//                  (scenario, vehicle, iteration) work items, hand-offs between workgroups at agent scope
 //   loop_prep      closed loop: parameters and shifted warm start of every vehicle from the
 //                  previous predictions (reference vehicle_follower.py:432-476, 636-637)
 //   loop_post      closed loop: read-back or shift fallback, plant integration, clock
@@ -764,6 +766,10 @@ int cfz_mpc_set_slots(cfz_handle *h, int B, const int32_t *slots) {
   if (check(h, B)) return -1;
   if (!slots) { h->slots_set = false; return 0; }
   for (int b = 0; b < B; ++b) if (slots[b] < 0 || slots[b] >= h->max_batch) return fail("slot index out of range");
+  {  // two instances of one launch on the same carry record would race on it (and mix two vehicles' multipliers)
+    std::vector<char> seen((size_t)h->max_batch, 0);
+    for (int b = 0; b < B; ++b) { if (seen[slots[b]]) return fail("duplicate carry slot within one solve"); seen[slots[b]] = 1; }
+  }
   HIP_OK(hipStreamSynchronize(h->stream));
   int32_t *stage = h->stage_host + h->max_batch;
   memcpy(stage, slots, (size_t)B * 4);

@@ -118,7 +118,8 @@ int cfz_mpc_set_carry_device(cfz_handle *h, int B, const int32_t *d_carry);
 /* Which carry record each instance of the next solve reads and refreshes: slots[b] in [0, max_batch).  Default (no
  * call, or NULL): instance b uses record b.  Lets several callers share one handle without mixing their multipliers:
  * the reference's `for v in vehicles: v.step()` loop (:642-647) and the ROS nodes (vehicle_node.py:150-152) step ONE
- * vehicle at a time, so each vehicle solves a batch of one in its own slot.  Holds for one solve, like the flags. */
+ * vehicle at a time, so each vehicle solves a batch of one in its own slot.  Holds for one solve, like the flags.
+ * The slots of one call must be pairwise distinct (two instances on one record would race on it): duplicates are an API error. */
 int cfz_mpc_set_slots(cfz_handle *h, int B, const int32_t *slots);
 
 /* sol = opti.solve() (:479): runs the batched solver and blocks until done. */

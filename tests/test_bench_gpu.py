@@ -1,0 +1,39 @@
+"""bench.py on the GPU through its N > 1 code paths with one rank (`CFZ_BENCH_FORCE_DIST=1`: torch.distributed / RCCL initialised,
+barriers and all-reduces taken): scenario sharding and the vehicle-sharded exchange (`--parallelism vehicle`, the layout of
+BASELINE.json configs[4]).  The driver's own SCALE runs need an 8-GPU node; this keeps the code those runs take from rotting."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CFZ_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--scenarios", "64",
+                          "--no-cpu-baseline", "--no-extras"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [[], ["--parallelism", "vehicle"]])
+def test_bench_line_through_torch_distributed(extra):
+    b = _run(extra)
+    assert b["metric"].startswith("OBCA MPC-step solves/sec") and b["unit"] == "solves/s" and b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 2
+    assert b["value"] > 1e3 and b["scaling"] == "weak" and b["dtype"] == "f64" and b["vs_baseline"] is None
+    assert abs(b["value"] - 64 * 4 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value"]  # value = solves / elapsed
+    c = b["config"]
+    assert c["scenarios_per_gpu"] == 64 and c["solves_per_step_per_gpu"] == 256 and c["infeasible_starts"] == 0
+    assert ("vehicle-sharded" in c["parallelism"]) == bool(extra) and "refs_4v_planned" in c["reference_plan"]
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["kernel"] == ("solve_kernel" if extra else "loop_kernel")

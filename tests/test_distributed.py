@@ -1,7 +1,7 @@
 """Multi-process paths on CPU (`gloo`): the vehicle-sharded neighbour exchange reproduces the single-process Jacobi
 iteration -- world 2 (two vehicles per rank, one group) and world 4 over two vehicles (vehicle x scenario grid: two
-exchange groups of two ranks, the layout of BASELINE.json configs[4] in small); scenario sharding covers the batch
-exactly once."""
+exchange groups of two ranks, the layout of BASELINE.json configs[4] in small) and world 8 over four vehicles (that layout itself);
+scenario sharding covers the batch exactly once."""
 import os
 import socket
 
@@ -81,11 +81,13 @@ def _worker(rank, world, port, S, steps, q, V=4):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,V", [(2, 4), (4, 2)])
+@pytest.mark.parametrize("world,V", [(2, 4), (4, 2), (8, 4)])
 def test_vehicle_sharded_exchange_gloo(world, V):
+    """(8, 4): the grid of BASELINE.json configs[4] itself -- eight ranks, four vehicles, two scenario shards: rank pair (2v, 2v+1)
+    owns vehicle v, the exchange groups are the four ranks holding the same scenarios (`dist.new_group` x 2, all-gather inside)."""
     import torch.multiprocessing as mp
 
-    S, steps = 2, 3
+    S, steps = (4, 2) if world == 8 else (2, 3)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

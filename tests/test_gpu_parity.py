@@ -555,3 +555,27 @@ def test_late_shift_fixture(eng):
     finally:
         e0.close()
     assert o0["iters"].tolist() == g["iters_noshift"].tolist() and (o0["status"] == 1).all()
+
+
+def test_duplicate_carry_slots_are_refused(eng, golden):
+    """`cfz_mpc_set_slots`: two instances of one launch on the same carry record would race on it (and hand one vehicle the other's
+    multipliers), so a call with a repeated slot is an API error; distinct slots go through; and the whole-curvature experiment switch
+    (`whole_curvature_first`, off by default) takes the HIP build to the same status / iterations as the C port."""
+    from conflict_rez_amd import engine, scenarios
+    from oracle import ipm, port
+    from oracle.mpc_nlp import MpcSpec
+
+    a = slice(0, 3)
+    with pytest.raises(RuntimeError, match="duplicate carry slot"):
+        eng.solve(golden["x0"][a], golden["ref"][a], golden["nbr"][a], golden["zu"][a], want_duals=False, slots=[5, 7, 5])
+    out = eng.solve(golden["x0"][a], golden["ref"][a], golden["nbr"][a], golden["zu"][a], want_duals=False, slots=[5, 7, 9])
+    assert out["status"].tolist() == golden["meta"][a, 0].astype(int).tolist()
+    spec = scenarios.parking_lot_spec()
+    e2 = engine.Engine(spec, max_batch=8, whole_curvature_first=1)
+    ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
+    pick = [0, 7, 18, 19]
+    o2 = e2.solve(golden["x0"][pick], golden["ref"][pick], golden["nbr"][pick], golden["zu"][pick], want_duals=False)
+    for i, b in enumerate(pick):
+        r = port.solve(ospec, golden["x0"][b], golden["ref"][b], golden["nbr"][b], golden["zu"][b].T, ipm.IpmOptions(whole_curvature_first=True))
+        assert (r["status"], r["iters"]) == (int(o2["status"][i]), int(o2["iters"][i])) and np.abs(r["p"].T - o2["zu"][i]).max() < 1e-6
+    e2.close()
