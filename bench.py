@@ -116,7 +116,19 @@ def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16, ref_kind="plan
     return out
 
 
-def profiled_traffic(kernel):
+def profile_is_current(tag_path):
+    """True if profiles/<tag>_meta.json says the profile was taken on a library built from the same kernel sources as the one loaded
+    now (`cfz_source_hash`); a profile without meta file (rounds 1-2) or of other sources is stale: its counters are not quoted."""
+    try:
+        from conflict_rez_amd import engine
+
+        meta = json.load(open(tag_path + "_meta.json"))
+        return meta.get("csrc_sha16") == engine.source_hash() != "unknown"
+    except (OSError, ValueError):
+        return False
+
+
+def profiled_traffic(kernel, require_current=True):
     """HBM bytes per launch of `kernel` from the committed PMC summaries of this same command (profiles/, separate
     --pmc passes of rocprofv3): raw FETCH_SIZE + WRITE_SIZE in KiB of the timed (last) dispatch.  None if absent."""
     import glob
@@ -126,6 +138,8 @@ def profiled_traffic(kernel):
     if not tags:
         return None, None
     tag = tags[-1][: -len("_pmc_FETCH_SIZE.csv")]
+    if require_current and not profile_is_current(tag):
+        return None, os.path.basename(tag) + " (stale: taken on other kernel sources)"
     tot = 0.0
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -138,7 +152,7 @@ def profiled_traffic(kernel):
     return (tot or None), os.path.basename(tag)
 
 
-def profiled_sq(kernel):
+def profiled_sq(kernel, require_current=True):
     """VALU-active fraction of `kernel` from the committed SQ pass of this same command (profiles/*_pmc_SQ.csv):
     SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD executes a vector instruction, summed over SIMDs) x 4 /
     (GRBM_GUI_ACTIVE (cycles, summed over the 8 XCDs) / 8 x 1024 SIMDs), timed (last) dispatch.  (None, None) if absent."""
@@ -148,6 +162,8 @@ def profiled_sq(kernel):
     tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_SQ.csv")) if os.path.basename(t).count("_") == 2)
     if not tags:
         return None, None
+    if require_current and not profile_is_current(tags[-1][: -len("_pmc_SQ.csv")]):
+        return None, os.path.basename(tags[-1])[: -len("_pmc_SQ.csv")] + " (stale: taken on other kernel sources)"
     vals = {}
     try:
         for line in open(tags[-1]):

@@ -574,6 +574,11 @@ extern "C" {
 
 const char *cfz_last_error(void) { return cfz_g_err.c_str(); }
 
+#ifndef CFZ_SRC_HASH
+#define CFZ_SRC_HASH "unknown"
+#endif
+const char *cfz_source_hash(void) { return CFZ_SRC_HASH; }
+
 void cfz_default_spec(cfz_spec *s) {
   memset(s, 0, sizeof *s);
   s->N = 30; s->n_obs = 0; s->n_nbr = 0; s->rk_substeps = 4;

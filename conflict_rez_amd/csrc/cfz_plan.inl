@@ -336,19 +336,30 @@ CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
   }
 #undef CFZP_COL
 #undef CFZP_WIN_BASE
+  // the swap and the division are not idempotent: ONE thread does them (every thread runs this scalar code; inside one wavefront
+  // the lanes' redundant read-modify-writes happen to coincide, across wavefronts they would repeat -- the bug class that bit
+  // `assemble` when state_ws went to eight wavefronts)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool first = threadIdx.x == 0;
+#else
+  const bool first = true;
+#endif
   for (int j = 0; j < n; ++j) {  // L y = P b
     const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
-    if (p != j) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
+    if (p != j) {
+      if (first) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
+      CFZP_SYNC();
+    }
     const double bj = b[j];
     CFZP_SYNC();
     if (bj != 0.0) CFZP_LANE_FOR(i, 1, km) b[j + i] -= ab[(size_t)j * kLd + kv + i] * bj;
     CFZP_SYNC();
   }
   for (int j = n - 1; j >= 0; --j) {  // U x = y
-    b[j] /= ab[(size_t)j * kLd + kv];
-    const double bj = b[j];
-    const int lo = j - kv > 0 ? j - kv : 0;
+    const double bj = b[j] / ab[(size_t)j * kLd + kv];
     CFZP_SYNC();
+    if (first) b[j] = bj;
+    const int lo = j - kv > 0 ? j - kv : 0;
     if (bj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) b[i] -= ab[(size_t)j * kLd + kv + i - j] * bj;
     CFZP_SYNC();
   }

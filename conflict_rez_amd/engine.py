@@ -153,7 +153,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
+    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -282,6 +282,13 @@ def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0
         out.append(dict(traj=traj[o : o + Np[b]].reshape(-1, 6, 7).copy(), dt=float(dt[b]), status=int(status[b]), iters=int(iters[b]), cost=float(cost[b])))
         o += Np[b]
     return out
+
+
+def source_hash():
+    """`cfz_source_hash`: which kernel sources the loaded library was built from (16 hex digits, or "unknown")."""
+    lib = load_library()
+    lib.cfz_source_hash.restype = C.c_char_p
+    return lib.cfz_source_hash().decode()
 
 
 def colloc_band_info(n_sets, N_per_set=5, n_obs=6, pairs=None, has_final=None):

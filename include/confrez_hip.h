@@ -318,6 +318,9 @@ long cfz_loop_last_converged(const cfz_handle *h);
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters);
 
 const char *cfz_last_error(void);
+/* First 16 hex digits of the SHA-256 over the kernel sources this library was built from (__graft_entry__.source_hash; "unknown" for
+ * a build made by hand).  bench.py quotes profiler counters from profiles/ only if they were taken on a library with the same hash. */
+const char *cfz_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -4,12 +4,19 @@ outcome.  (The GPU leg of bench.py is what the driver runs.)"""
 import bench
 
 
-def test_profile_summaries_parse():
-    traffic, tag = bench.profiled_traffic("loop_kernel")
+def test_profile_summaries_parse(monkeypatch):
+    traffic, tag = bench.profiled_traffic("loop_kernel", require_current=False)
     assert tag is not None and 1e8 < traffic < 1e11   # bytes per launch of the default command
-    sq, tag2 = bench.profiled_sq("loop_kernel")
+    sq, tag2 = bench.profiled_sq("loop_kernel", require_current=False)
     assert tag2 == tag and 0.0 < sq["raw_quotient"] < 1.0 and abs(sq["frac"] - 4.0 * sq["raw_quotient"]) < 1e-12
-    assert bench.profiled_traffic("no_such_kernel") == (None, tag)
+    assert bench.profiled_traffic("no_such_kernel", require_current=False) == (None, tag)
+    # counters are quoted only when the profile was taken on a library built from the sources loaded now (profiles/<tag>_meta.json
+    # against cfz_source_hash): with another hash they are dropped and the line says why
+    from conflict_rez_amd import engine
+
+    monkeypatch.setattr(engine, "source_hash", lambda: "0123456789abcdef")
+    t2, why = bench.profiled_traffic("loop_kernel")
+    assert t2 is None and "stale" in why and bench.profiled_sq("loop_kernel")[0] is None
 
 
 def test_cpu_closed_loop_worker_and_probe():

@@ -112,3 +112,24 @@ def test_plan_single_path_then_follow_on_gpu(tmp_path):
     for v in mdf.vehicles:
         ref = v.interpolate_states([v.state.t])
         assert np.hypot(v.state.x.x - ref.x[0], v.state.x.y - ref.y[0]) < 0.5
+
+
+@pytest.mark.gpu
+def test_planned_reference_table_reproduces_the_package_data():
+    """`scenarios.planned_reference_table` (the build's own single-vehicle plans: `cfz_state_ws` -> `cfz_colloc` through
+    `VehicleFollower.plan_single_path`, sampled every 0.1 s) reproduces the table bench.py follows by default,
+    `conflict_rez_amd/data/refs_4v_planned.npz` (written by this function on an MI355X): same lengths, poses within 1 mm, inputs
+    within 1e-2 -- and the plans are the fast ones (7.8-15.7 s against the 18-30 s of the state_ws warm starts)."""
+    from conflict_rez_amd import scenarios
+
+    table, lengths, info = scenarios.planned_reference_table()
+    ref, ref_len = scenarios.load_reference_table(kind="planned")
+    assert table.shape == ref.shape and lengths.tolist() == ref_len.tolist()
+    assert np.abs(table[..., :3] - ref[..., :3]).max() < 1e-3 and np.abs(table[..., 3:] - ref[..., 3:]).max() < 1e-2
+    assert 7.0 < min(i["t_end"] for i in info.values()) and max(i["t_end"] for i in info.values()) < 16.5
+    ws, ws_len = scenarios.load_reference_table(kind="state_ws")
+    assert (ws_len > 1.7 * lengths).all()  # the warm-start plans take about twice as long
+    # every start the bench draws is feasible for the first NLP of every vehicle
+    spec = scenarios.parking_lot_spec()
+    k0, noise = scenarios.sample_scenarios(256, ref, seed=5, spec=spec)
+    assert (scenarios.start_clearances(spec, ref, k0, noise) >= spec.dmin - 0.02).all()

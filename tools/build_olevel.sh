@@ -1,0 +1,12 @@
+#!/bin/bash
+# Both translation units at ONE optimisation level (the shipped build takes cfz_engine.hip at -O2 and cfz_planning.hip at -O3, see
+# __graft_entry__.py): tools/build_olevel.sh -O3 tools/_libcfz_o3.so [extra flags]
+lvl=$1; out=$2; shift; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+C=$R/conflict_rez_amd/csrc
+T=$(mktemp -d)
+F="--offload-arch=gfx950 -std=c++17 -fPIC -Wno-unused-value"
+/opt/rocm/bin/hipcc $F $lvl "$@" -c -o $T/e.o $C/cfz_engine.hip &
+/opt/rocm/bin/hipcc $F $lvl "$@" -c -o $T/p.o $C/cfz_planning.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $T/e.o $T/p.o && rm -rf $T
