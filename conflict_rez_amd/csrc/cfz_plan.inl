@@ -423,6 +423,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
+  bool mu_forced = false;  // the last iteration ended without a step and lowered mu instead
   double stall_ref = 0.0; int stall_cnt = 0;
   int status = 1, iter = 0;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
@@ -544,7 +545,16 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
       if (ok) { accepted = true; break; }
       alpha *= 0.5;
     }
-    if (!accepted) { status = 2; break; }
+    if (!accepted) {
+      // No step length passes the filter.  As in cfz_colloc.inl: if the barrier parameter can still fall, the barrier problem at hand is
+      // given up -- mu falls, the filter starts afresh, the iterate stays -- once per failure; otherwise status 2.
+      if (mu > mu_floor && !mu_forced) {
+        mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))); mu_forced = true; nfilt = 0; filt_mu = mu;
+        continue;
+      }
+      status = 2; break;
+    }
+    mu_forced = false;
     if (!f_type) {
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;

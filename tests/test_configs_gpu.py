@@ -83,8 +83,10 @@ def test_config1_256_single_vehicle_plans(lot):
     who = [agents[i % 4] for i in range(B)]
     init = [lot["paths"][a][0] + np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] for a in who]
     ws, good, plans = _single_plans(lot, who, init)
-    assert len(good) >= B - 4, len(good)  # state_ws: the reference raises where IPOPT fails; <= 4 of 256 here
-    assert sum(r["status"] == 0 for r in plans.values()) >= len(good) - 2
+    # every warm start converges (round 2: 1-4 of 256 ended in the line search; since round 3 a failed line search lowers mu once
+    # before giving up, cfz_plan.inl) and every plan is refined
+    assert len(good) == B, len(good)
+    assert sum(r["status"] == 0 for r in plans.values()) == B
     sp = scenarios.parking_lot_spec()
     bd = sp.bounds
     D = None
