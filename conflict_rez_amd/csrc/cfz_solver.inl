@@ -93,6 +93,8 @@ struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
   int max_iter, max_backtrack, filter_cap, stall_iters;
   int row_curvature, vv_rows;  // vv_rows 1: vertex-vertex rows (kind 3) in the working set
+  int stag_win, pad1;            // stag_win: iterations without a halving of the error, at a feasible iterate, after which the late shift may start
+                                 // at iteration kShiftStagMin already (0: never; oracle/ipm.py shift_stagnation)
   int shift_after, whole_first;  // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
                                  // whole_first: the whole row curvature is tried first and kept when every stage's Huu is positive definite
   double dt, wb, dmin;
@@ -366,7 +368,8 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
 constexpr double kVvInert = 1.0;  // m: margin of the second slot of a vertex-vertex block in the planning kernels (rows_for)
-constexpr int kWsStallDiv = 4;  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
+constexpr int kWsStallDiv = 4;
+constexpr int kShiftStagMin = 40;  // earliest iteration of a stagnation-triggered curvature shift (KSpec::stag_win)  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
 
 template <bool GRAD>
 CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
@@ -1386,6 +1389,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_STAMP(0);  // setup
   int nfilt = 0, status = 1, iter = 0;
   int whole_skip = 0;  // iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
+  int stagnant = 0, best_it = 0;  // the error has not halved for stag_win iterations at a feasible iterate (sticky)
+  double best_err = INFINITY;
 
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
@@ -1531,6 +1536,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
     // (an iterate that changed the working set counts a quarter: its new rows start with their own violation -- but a solve that
     // changes it at every iterate is cycling and has to end)
+    if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
+    if (sp.stag_win > 0 && !stagnant && cviol <= sp.constr_viol_tol && iter - best_it >= sp.stag_win) stagnant = 1;
     if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
     else if (!ws_changed) ++stall_cnt;
     else if (++stall_ws >= kWsStallDiv) { stall_ws = 0; ++stall_cnt; }
@@ -1650,7 +1657,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             }
             th *= 0.5;
           }
-          if (!use_whole && sp.shift_after > 0 && iter >= sp.shift_after && th < 1.0) {
+          if (!use_whole && sp.shift_after > 0 && (iter >= sp.shift_after || (stagnant && iter >= kShiftStagMin)) && th < 1.0) {
             // late in a long solve the scaled model cycles: whole curvature + the smallest identity shift that keeps the margin
             const double dl = pose_shift(dv.q0 + cxx, dv.q1 + cyy, q2 + cc, cxy, ca, cb);
             h[0] += dl; h[1] += dl; h[2] += dl;

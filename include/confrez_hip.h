@@ -69,7 +69,9 @@ typedef struct cfz_options {
                            *    delta_w = 0), else falls back to the safeguarded model.  Halves the 99th percentile of a scenario's
                            *    iteration chain on the planned-table closed loop, but three instances of the independent-solver
                            *    populations then end with status 5 (docs/notebook.md), so it is off */
-  int32_t reserved1;
+  int32_t shift_stagnation; /* 10: once the scaled optimality error has not halved for this many iterations at a feasible iterate
+                           *    (violation <= constr_viol_tol) the late curvature shift may start at iteration 40 instead of waiting for
+                           *    shift_after; ends the sawtooth of the scaled model 15-20 iterations sooner; 0 = off */
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

@@ -36,6 +36,7 @@ typedef struct {
   int vv_rows; /* 1: vertex-vertex rows (kind 3) in the working set, oracle/mpc_nlp.py MpcSpec.vv_rows */
   int shift_after; /* oracle/ipm.py IpmOptions.shift_after */
   int whole_first; /* oracle/ipm.py IpmOptions.whole_curvature_first */
+  int stag_win;    /* oracle/ipm.py IpmOptions.shift_stagnation */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -129,6 +130,7 @@ static void rk4_sens(const double z[5], const double u[2], double dt, double wb,
 
 /* ---------------------------------------------------------------- separation certificates */
 #define HYST 1e-3 /* m: a block keeps its separating face until another one is better by this much */
+#define SHIFT_STAG_MIN 40 /* oracle/ipm.py SHIFT_STAG_MIN */
 #define WS_STALL_DIV 4 /* iterates that change the working set count 1 / WS_STALL_DIV towards the stall test */
 
 /* signed distances of the 4 vertices of one polygon to face f of the other (+ gradients wrt x,y,psi).
@@ -387,6 +389,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   double mu = sp->mu_init;
   int status = 1, iter = 0;
   int whole_skip = 0; /* iterations left in which the whole row curvature is not tried */
+  int stagnant = 0, best_it = 0; double best_err = INFINITY; /* oracle/ipm.py shift_stagnation */
   static double Ps[MAXN][5][5], ps[MAXN][5];
   double err0 = INFINITY;
   const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb); /* nb counts rows here */
@@ -555,6 +558,8 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
     if (iter == sp->max_iter) break;
+    if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
+    if (sp->stag_win > 0 && !stagnant && cviol <= sp->constr_viol_tol && iter - best_it >= sp->stag_win) stagnant = 1;
     /* infeasibility stall (oracle/ipm.py) */
     /* an iterate that changed the working set counts a quarter (its new rows start with their own violation; but a solve that
      * changes it at EVERY iterate cycles, and must end) */
@@ -635,7 +640,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
           }
           th *= 0.5;
         }
-        if (!use_whole && sp->shift_after > 0 && iter >= sp->shift_after && th < 1.0) {
+        if (!use_whole && sp->shift_after > 0 && (iter >= sp->shift_after || (stagnant && iter >= SHIFT_STAG_MIN)) && th < 1.0) {
           /* late in a long solve the scaled model cycles: whole curvature + smallest identity shift (hess_gn shift=True) */
           const double dl_ = pose_shift(q0 + cxx, q1 + cyy, q2 + cc, cxy, ca, cb);
           H[k][0][0] += dl_; H[k][1][1] += dl_; H[k][2][2] += dl_;

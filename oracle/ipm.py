@@ -84,6 +84,12 @@ class IpmOptions:
     # on the planned-table closed loop the 99th percentile of a scenario's iteration chain halves with it, but three instances of
     # the independent-solver populations then end with status 5 -- parity first, so it stays an experiment switch.
     whole_curvature_first: bool = False
+    # Stagnation shift: once the scaled optimality error has not halved for `shift_stagnation` iterations at a feasible iterate
+    # (cviol <= constr_viol_tol), the late shift of the row curvature (see shift_after) starts as soon as iteration SHIFT_STAG_MIN
+    # is reached instead of waiting for shift_after.  The sawtooth of the scaled model (planned-table closed loop: one vehicle at
+    # 62-65 iterations per solve, every solve) ends 15-20 iterations sooner; solves that make progress are untouched, and the
+    # independent-solver populations keep their outcomes (with a minimum below 40 instance 7 of the first one does not).  0 = off.
+    shift_stagnation: int = 10
     lower_mu_on_failure: bool = False  # a failed line search lowers mu once instead of ending the solve (independent solvers only)
 
 
@@ -132,6 +138,7 @@ def push_to_interior(x, xl, xu, opt: IpmOptions):
 
 
 WS_STALL_DIV = 4
+SHIFT_STAG_MIN = 40  # earliest iteration of a stagnation-triggered curvature shift (IpmOptions.shift_stagnation)
 
 
 def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
@@ -173,6 +180,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
 
     it = 0
     err0 = np.inf
+    stagnant, best_err, best_it = False, np.inf, 0
     mu_forced = False
     whole_skip = 0  # iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
     for it in range(opt.max_iter + 1):
@@ -217,6 +225,10 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             break
         if it == opt.max_iter:
             break
+        if it == 0 or err0 < 0.5 * best_err:
+            best_err, best_it = err0, it
+        if opt.shift_stagnation > 0 and not stagnant and cviol <= opt.constr_viol_tol and it - best_it >= opt.shift_stagnation:
+            stagnant = True
         if it == 0 or cviol <= opt.stall_kappa * stall_ref:
             stall_ref, stall_cnt, stall_ws = cviol, 0, 0
         elif not getattr(nlp, "ws_changed", False):
@@ -252,7 +264,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                         whole_skip = 2
                 whole_skip = max(whole_skip - 1, 0)
                 if H is None:
-                    H = nlp.hess_gn(x, nu, shift=0 < opt.shift_after <= it) + sp.diags(sig + opt.reg_primal)
+                    late = opt.shift_after > 0 and (it >= opt.shift_after or (stagnant and it >= SHIFT_STAG_MIN))
+                    H = nlp.hess_gn(x, nu, shift=late) + sp.diags(sig + opt.reg_primal)
             else:
                 H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")

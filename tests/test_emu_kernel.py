@@ -101,8 +101,9 @@ print('sanitized ok')
 
 def test_late_shift_ends_the_cycle_of_the_scaled_curvature(ospec):
     """tests/golden/mpc_late_shift.npz: solves that run into max_iter while the convexity safeguard scales the row
-    curvature (IpmOptions.shift_after = 0) end within ~80 iterations when, from iteration 60 on, the stage keeps the
-    whole curvature and is shifted instead.  The C port and the kernel source reproduce the full-KKT oracle's iteration
+    curvature (IpmOptions.shift_after = 0) end within ~80 iterations when, from iteration 60 on (from 40 on once the error has
+    stagnated for ten iterations at a feasible iterate, IpmOptions.shift_stagnation), the stage keeps the whole curvature and is
+    shifted instead.  The C port and the kernel source reproduce the full-KKT oracle's iteration
     counts and solutions, and (first instance) the full-KKT oracle itself regenerates the stored vector."""
     import os
 
@@ -116,7 +117,7 @@ def test_late_shift_ends_the_cycle_of_the_scaled_curvature(ospec):
         re_ = emu.solve(ospec, opt, *args, want_duals=False)
         rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
         assert (re_["status"], re_["iters"]) == (0, int(g["iters_shift"][b])) == (rp["status"], rp["iters"]), b
-        assert 60 < re_["iters"] < 100
+        assert 40 < re_["iters"] < 100  # two of the six end at 51: stagnation lets the shift start at iteration 40 (shift_stagnation)
         assert np.abs(re_["zu"] - g["sol"][b]).max() < 1e-6 and np.abs(rp["p"].T - g["sol"][b]).max() < 1e-6
         if b < 2:
             r0 = emu.solve(ospec, off, *args, want_duals=False)
@@ -130,7 +131,7 @@ def test_whole_curvature_first_switch_agrees_across_the_three_implementations(go
     separation rows is tried first and kept when every stage's Huu of the Riccati recursion is positive definite.  The full-KKT
     oracle (which reads the same off the stage structure, oracle/mpc_nlp.py reduced_hessian_pd), the C port and the kernel source
     take the same decisions: equal status and iteration counts, solutions to 1e-7 -- on goldens with active contacts (7, 18, 19:
-    the late-shift fixture's first instance converges in a third of the iterations with it) and on one without."""
+    the late-shift fixture's first instance converges in 38 instead of 66 iterations with it) and on one without."""
     import os
 
     from oracle.mpc_nlp import solve_mpc
@@ -147,4 +148,4 @@ def test_whole_curvature_first_switch_agrees_across_the_three_implementations(go
     args = (g["x0"][0], g["ref"][0], g["nbr"][0], g["zu"][0])
     re_ = emu.solve(ospec, opt, *args, want_duals=False)
     rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
-    assert (re_["status"], re_["iters"]) == (rp["status"], rp["iters"]) and re_["status"] == 0 and re_["iters"] < int(g["iters_shift"][0]) // 2
+    assert (re_["status"], re_["iters"]) == (rp["status"], rp["iters"]) and re_["status"] == 0 and re_["iters"] < 2 * int(g["iters_shift"][0]) // 3
