@@ -93,7 +93,8 @@ struct KSpec {
   int N, n_obs, n_nbr, rk_substeps;
   int max_iter, max_backtrack, filter_cap, stall_iters;
   int row_curvature, vv_rows;  // vv_rows 1: vertex-vertex rows (kind 3) in the working set
-  int stag_win, pad1;            // stag_win: iterations without a halving of the error, at a feasible iterate, after which the late shift may start
+  int stag_win, err_stall;       // err_stall: iterations without a halving of the error after which the solve ends with status 5 (0: never)
+                                 // stag_win: iterations without a halving of the error, at a feasible iterate, after which the late shift may start
                                  // at iteration kShiftStagMin already (0: never; oracle/ipm.py shift_stagnation)
   int shift_after, whole_first;  // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
                                  // whole_first: the whole row curvature is tried first and kept when every stage's Huu is positive definite
@@ -1538,6 +1539,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // changes it at every iterate is cycling and has to end)
     if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
     if (sp.stag_win > 0 && !stagnant && cviol <= sp.constr_viol_tol && iter - best_it >= sp.stag_win) stagnant = 1;
+    if (sp.err_stall > 0 && iter - best_it >= sp.err_stall) { status = 5; break; }  // a cycle below constr_viol_tol: the stall test above never fires
     if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
     else if (!ws_changed) ++stall_cnt;
     else if (++stall_ws >= kWsStallDiv) { stall_ws = 0; ++stall_cnt; }

@@ -72,6 +72,9 @@ typedef struct cfz_options {
   int32_t shift_stagnation; /* 10: once the scaled optimality error has not halved for this many iterations at a feasible iterate
                            *    (violation <= constr_viol_tol) the late curvature shift may start at iteration 40 instead of waiting for
                            *    shift_after; ends the sawtooth of the scaled model 15-20 iterations sooner; 0 = off */
+  int32_t err_stall_iters; /* 150: a solve whose scaled optimality error has not halved for this many iterations ends with status 5
+                           *    instead of running to max_iter (limit cycles below constr_viol_tol escape stall_iters' test); 0 = off */
+  int32_t reserved2;
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

@@ -37,6 +37,7 @@ typedef struct {
   int shift_after; /* oracle/ipm.py IpmOptions.shift_after */
   int whole_first; /* oracle/ipm.py IpmOptions.whole_curvature_first */
   int stag_win;    /* oracle/ipm.py IpmOptions.shift_stagnation */
+  int err_stall;   /* oracle/ipm.py IpmOptions.err_stall_iters */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -560,6 +561,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (iter == sp->max_iter) break;
     if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
     if (sp->stag_win > 0 && !stagnant && cviol <= sp->constr_viol_tol && iter - best_it >= sp->stag_win) stagnant = 1;
+    if (sp->err_stall > 0 && iter - best_it >= sp->err_stall) { status = 5; break; }
     /* infeasibility stall (oracle/ipm.py) */
     /* an iterate that changed the working set counts a quarter (its new rows start with their own violation; but a solve that
      * changes it at EVERY iterate cycles, and must end) */

@@ -90,6 +90,10 @@ class IpmOptions:
     # 62-65 iterations per solve, every solve) ends 15-20 iterations sooner; solves that make progress are untouched, and the
     # independent-solver populations keep their outcomes (with a minimum below 40 instance 7 of the first one does not).  0 = off.
     shift_stagnation: int = 10
+    # A solve whose scaled optimality error has not halved for this many iterations ends with status 5 (stalled) instead of running
+    # to max_iter: limit cycles BELOW constr_viol_tol escape the violation-based stall test (planned-table closed loop: a period-3
+    # cycle at violation 9.6e-3 ran 600 iterations, 50 ms on the critical path of a launch).  0 = off.
+    err_stall_iters: int = 150
     lower_mu_on_failure: bool = False  # a failed line search lowers mu once instead of ending the solve (independent solvers only)
 
 
@@ -229,6 +233,9 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             best_err, best_it = err0, it
         if opt.shift_stagnation > 0 and not stagnant and cviol <= opt.constr_viol_tol and it - best_it >= opt.shift_stagnation:
             stagnant = True
+        if opt.err_stall_iters > 0 and it - best_it >= opt.err_stall_iters:
+            status = STATUS_STALLED
+            break
         if it == 0 or cviol <= opt.stall_kappa * stall_ref:
             stall_ref, stall_cnt, stall_ws = cviol, 0, 0
         elif not getattr(nlp, "ws_changed", False):

@@ -17,7 +17,9 @@ def build(force=False):
     src = os.path.join(_HERE, "cfz_port.c")
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", _LIB, src, "-lm"])
+        tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp, src, "-lm"])
+        os.replace(tmp, _LIB)
     return _LIB
 
 
@@ -30,7 +32,7 @@ class _Spec(C.Structure):
     ] + [(k, C.c_double) for k in (
         "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
-    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("whole_first", C.c_int), ("stag_win", C.c_int)]
+    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("whole_first", C.c_int), ("stag_win", C.c_int), ("err_stall", C.c_int)]
 
 
 def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
@@ -54,6 +56,7 @@ def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
     s.shift_after = int(opt.shift_after)
     s.whole_first = int(opt.whole_curvature_first)
     s.stag_win = int(opt.shift_stagnation)
+    s.err_stall = int(opt.err_stall_iters)
     return s
 
 

@@ -27,7 +27,9 @@ def build(force=False):
                                                                          for f in ("cfz_colloc.inl", "cfz_plan.inl", "cfz_solver.inl")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-Wno-unknown-pragmas", "-Wno-maybe-uninitialized", "-fPIC", "-shared", "-o", _LIB, srcs[0]])
+        tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
+        subprocess.check_call(["g++", "-O2", "-Wno-unknown-pragmas", "-Wno-maybe-uninitialized", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, _LIB)
     return _LIB
 
 

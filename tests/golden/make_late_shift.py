@@ -30,7 +30,7 @@ def main(scenario=477, vehicle=3, keep=6):
     state, pred = seed(table, k0, noise, N)
     carry = [None] * V
     adv = np.minimum(np.arange(N) + 1, N - 1)
-    noshift = ipm.IpmOptions(shift_after=0)
+    noshift = ipm.IpmOptions(shift_after=0, err_stall_iters=0)  # neither the late shift nor the error-stall stop: the cycle runs to max_iter
     out = {k: [] for k in ("x0", "ref", "nbr", "zu", "iters_noshift", "iters_shift", "status_shift", "sol", "step")}
     for t in range(200):
         newp = pred.copy()

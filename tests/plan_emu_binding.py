@@ -22,7 +22,9 @@ def build(force=False):
     srcs = [os.path.join(ROOT, "tests", "emu", "cfz_plan_emu.cpp"), os.path.join(ROOT, "conflict_rez_amd", "csrc", "cfz_plan.inl")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", _LIB, srcs[0]])
+        tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
+        subprocess.check_call(["g++", "-O2", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, _LIB)
     return _LIB
 
 

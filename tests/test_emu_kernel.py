@@ -110,7 +110,7 @@ def test_late_shift_ends_the_cycle_of_the_scaled_curvature(ospec):
     from oracle.mpc_nlp import solve_mpc
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_late_shift.npz"))
-    opt, off = ipm.IpmOptions(), ipm.IpmOptions(shift_after=0)
+    opt, off = ipm.IpmOptions(), ipm.IpmOptions(shift_after=0, err_stall_iters=0)
     assert opt.shift_after == 60
     for b in range(len(g["x0"])):
         args = (g["x0"][b], g["ref"][b], g["nbr"][b], g["zu"][b])
@@ -149,3 +149,17 @@ def test_whole_curvature_first_switch_agrees_across_the_three_implementations(go
     re_ = emu.solve(ospec, opt, *args, want_duals=False)
     rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
     assert (re_["status"], re_["iters"]) == (rp["status"], rp["iters"]) and re_["status"] == 0 and re_["iters"] < 2 * int(g["iters_shift"][0]) // 3
+
+
+def test_error_stall_ends_a_cycle_below_the_violation_tolerance(ospec):
+    """`err_stall_iters` (150): with the late shift off the solves of tests/golden/mpc_late_shift.npz cycle at a violation below
+    constr_viol_tol, where the violation-based stall test never fires; they now end with status 5 once the scaled optimality error has
+    not halved for 150 iterations instead of running to the iteration limit -- in the port and in the kernel source alike."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_late_shift.npz"))
+    opt = ipm.IpmOptions(shift_after=0)
+    args = (g["x0"][0], g["ref"][0], g["nbr"][0], g["zu"][0])
+    re_ = emu.solve(ospec, opt, *args, want_duals=False)
+    rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
+    assert (re_["status"], re_["iters"]) == (rp["status"], rp["iters"]) and re_["status"] == 5 and 150 <= re_["iters"] < 400

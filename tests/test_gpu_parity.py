@@ -549,7 +549,7 @@ def test_late_shift_fixture(eng):
     out = eng.solve(g["x0"], g["ref"], g["nbr"], g["zu"])
     assert out["status"].tolist() == [0] * len(g["x0"]) and out["iters"].tolist() == g["iters_shift"].tolist()
     assert np.abs(out["zu"][:, :5] - g["sol"][:, :5]).max() < 1e-6 and np.abs(out["zu"][:, 5:] - g["sol"][:, 5:]).max() < 1e-4
-    e0 = engine.Engine(eng.spec, max_batch=16, shift_after=0)
+    e0 = engine.Engine(eng.spec, max_batch=16, shift_after=0, err_stall_iters=0)  # no late shift, no error-stall stop: to the limit
     try:
         o0 = e0.solve(g["x0"], g["ref"], g["nbr"], g["zu"])
     finally:
