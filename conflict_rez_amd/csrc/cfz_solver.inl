@@ -50,6 +50,9 @@ constexpr int kMaxN = kNL / kLPS;
 #define CFZ_LANES(tid) { const int tid = (int)threadIdx.x;
 #define CFZ_MID } { const int tid = (int)threadIdx.x;
 #define CFZ_END } __syncthreads();
+// uniform code (every wavefront runs it on its own) that has READ workspace words which a lane is about to overwrite: the
+// wavefronts meet first, or the slower one reads the new words, decides differently and the two fall out of step at the barriers
+#define CFZ_SYNC() __syncthreads()
 #define CFZ_PART(name, n) double name[n]
 #define CFZ_P(name, i) name[i]
 #define CFZ_QSUM(name, i) cfz::quad_sum(name[i])
@@ -63,6 +66,7 @@ constexpr int kMaxN = kNL / kLPS;
 #define CFZ_LANES(tid) for (int tid = 0; tid < cfz::kNL; ++tid) {
 #define CFZ_MID } for (int tid = 0; tid < cfz::kNL; ++tid) {
 #define CFZ_END }
+#define CFZ_SYNC() do { } while (0)
 #define CFZ_PART(name, n) double name[n][cfz::kNL]
 #define CFZ_P(name, i) name[i][tid]
 #define CFZ_QSUM(name, i) cfz::quad_sum_emu(name[i], tid)
@@ -1678,7 +1682,9 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
-    if (use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0) {
+    const bool whole_failed = use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0;
+    if (use_whole) CFZ_SYNC();  // rP[30] is cos of stage 15 once the block below has run: every wavefront reads it first
+    if (whole_failed) {
       use_whole = false; whole_skip = 2;
       CFZ_LANES(tid)  // the sweep's value function sits where the assembly reads cos / sin of the headings (L.rP = L.cs): put them back
         const int k = tid >> 2;
@@ -1767,6 +1773,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     CFZ_STAMP(7);  // line search
     if (!accepted) { status = 2; break; }
     if (!f_type) {
+      // the line search above reads the filter in uniform code: a full filter is shifted below, so the other wavefront must be
+      // through with its comparisons first (found as a GPU memory fault of long closed loops: the wavefront that read a half-shifted
+      // entry rejected the step the other had accepted, ran one more reduction and was a barrier behind from then on)
+      if (nfilt == sp.filter_cap) CFZ_SYNC();
       CFZ_LANES(tid)
         if (tid == 0) {
           int n = nfilt;

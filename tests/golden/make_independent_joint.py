@@ -36,6 +36,12 @@ def plans_of_strategy():
     return {a: ([dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[a]], paths[a]) for a in sorted(hist)}
 
 
+def truncated(plans, agents, sets):
+    """The plans of `agents` cut to their first sets[i] strategy steps (tube and path; the final heading is then the path's heading
+    there): short joint plans on which the independent solver converges also with vehicle 0."""
+    return {a: (plans[a][0][:ns], plans[a][1][: 30 * (ns - 1) + 1]) if ns else plans[a] for a, ns in zip(agents, sets)}
+
+
 def joint_kkt_certificate(nlp, z):
     """Solver-free certificate of a joint plan z = [points of every vehicle | dt] on oracle/independent_joint.py's statement: bounded
     least squares for multipliers (equality rows free; active inequality rows -- every vehicle's own and the pair distances -- and
@@ -114,12 +120,19 @@ if __name__ == "__main__":
     if "--dmin" in args:
         DMIN = float(args[args.index("--dmin") + 1])
         del args[args.index("--dmin"): args.index("--dmin") + 2]
+    SETS = None  # `--sets 5,5`: every vehicle's first five strategy steps only (20 intervals): `vehicle_0 vehicle_2 --dmin 0.2 --sets 5,5`
+    #              -> joint_independent_02_d20_s55.npz, a corner of vehicle 0 against a corner of vehicle 2 at the optimum
+    if "--sets" in args:
+        SETS = [int(x) for x in args[args.index("--sets") + 1].split(",")]
+        del args[args.index("--sets"): args.index("--sets") + 2]
     if len(args) >= 2:
         AGENTS = tuple(args)
     V = len(AGENTS)
-    out_name = "joint_independent.npz" if (AGENTS == ("vehicle_2", "vehicle_3") and DMIN == 0.05) else "joint_independent_%s%s.npz" % (
-        "".join(a[-1] for a in AGENTS), "" if DMIN == 0.05 else "_d%02d" % round(100 * DMIN))
+    out_name = "joint_independent.npz" if (AGENTS == ("vehicle_2", "vehicle_3") and DMIN == 0.05) else "joint_independent_%s%s%s.npz" % (
+        "".join(a[-1] for a in AGENTS), "" if DMIN == 0.05 else "_d%02d" % round(100 * DMIN), "" if SETS is None else "_s" + "".join(map(str, SETS)))
     plans = plans_of_strategy()
+    if SETS is not None:
+        plans = truncated(plans, AGENTS, SETS)
     jn, sp = tc._joint_problem(plans, list(AGENTS), [0] * V, nps=5)
     X0, _ = tc._joint_guess(plans, list(AGENTS), jn, sp, 5)  # the single plans (at the reference's dmin 0.05) on their mean dt
     guesses = [X0[7 * 6 * jn.off[a]: 7 * 6 * jn.off[a + 1]].reshape(-1, 7) for a in range(V)]
