@@ -37,3 +37,14 @@ def test_bench_line_through_torch_distributed(extra):
     assert ("vehicle-sharded" in c["parallelism"]) == bool(extra) and "refs_4v_planned" in c["reference_plan"]
     r = b["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["kernel"] == ("solve_kernel" if extra else "loop_kernel")
+
+
+def test_long_persistent_launch_at_4096_scenarios():
+    """Regression of the round-3 memory fault: 25 closed-loop iterations of 4096 scenarios on the planned table in ONE persistent
+    launch.  Long solves fill the filter; shifting a full filter while the other wavefront still compared against it made the two
+    disagree on a step, run different numbers of reductions and read the work item of the persistent loop out of a reduction's
+    exchange words (a wild instance index: `Memory access fault`, process aborted -- hence the child process).  Also: the launch
+    does the same arithmetic as the stepwise path (equal iteration totals on a smaller batch are tested in test_gpu_parity.py)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fault_probe.py"), "4096", "25"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+    assert "Memory access fault" not in out.stderr
