@@ -610,6 +610,8 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   if (spec->N > cfz::kMaxN) return fail("N exceeds the four-lanes-per-stage kernel");
   if (max_batch < 1) return fail("max_batch must be positive");
   if (opt->filter_cap < 1 || opt->filter_cap > 32) return fail("filter_cap must be in 1..32");
+  if (opt->whole_curvature_first && !cfz::kWholeSwitch)
+    return fail("whole_curvature_first: an experiment switch that is not compiled into this library (build with -DCFZ_WHOLE_FIRST)");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (ndev == 0) return fail("no HIP device: libconfrez_hip has no CPU path");

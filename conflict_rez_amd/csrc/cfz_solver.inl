@@ -372,6 +372,13 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // in the other's normal cone; no face normal certifies their distance, so the row is the Euclidean distance |W_v - V_u| itself,
 // imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
+// The experiment switch `whole_curvature_first` (docs/notebook.md round 3) costs the GPU kernel registers and a test per stage on
+// its serial lane whether it is on or off: compiled in for the CPU builds of this source (tests) and with -DCFZ_WHOLE_FIRST only.
+#if !defined(__HIPCC__) || defined(CFZ_WHOLE_FIRST)
+constexpr bool kWholeSwitch = true;
+#else
+constexpr bool kWholeSwitch = false;
+#endif
 constexpr double kVvInert = 1.0;  // m: margin of the second slot of a vertex-vertex block in the planning kernels (rows_for)
 constexpr int kWsStallDiv = 4;
 constexpr int kShiftStagMin = 40;  // earliest iteration of a stagnation-triggered curvature shift (KSpec::stag_win)  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
@@ -934,7 +941,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const wsp_f64 *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
     wsp_f64 *K = m + o_kk + k * 12;
     const double h10 = h[10], h6 = h[6];
-    if (!(h[5] > 0.0 && h[5] * h6 > 0.0)) pd_ok = 0.0;
+    if (kWholeSwitch && !(h[5] > 0.0 && h[5] * h6 > 0.0)) pd_ok = 0.0;
     const double k53 = -h10 / h6, k10 = -gk[5] / h[5], k11 = -gk[6] / h6;
     P00 = h[0]; P11 = h[1]; P22 = h[2]; P33 = h[3] + h10 * k53; P44 = h[4];
     P01 = h[7]; P02 = h[8]; P12 = h[9];
@@ -1011,7 +1018,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const double H33 = M33 + s01 * M03 + s11 * M13 + s21 * M23 + hc_[3], H34 = M34 + s01 * M04 + s11 * M14 + s21 * M24;
     const double H44 = M44 + s02 * M04 + s12 * M14 + s22 * M24 + hc_[4];
     (void)M43;
-    if (!(a00 > 0.0 && a00 * a11 - a01 * a01 > 0.0)) pd_ok = 0.0;
+    if (kWholeSwitch && !(a00 > 0.0 && a00 * a11 - a01 * a01 > 0.0)) pd_ok = 0.0;
     const double idet = 1.0 / (a00 * a11 - a01 * a01);
     const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
     // t = Huu^-1 [Hux hu]
@@ -1051,7 +1058,7 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
   rP[15] = P03; rP[16] = P13; rP[17] = P23; rP[18] = P33; rP[19] = P34;
   rP[20] = P04; rP[21] = P14; rP[22] = P24; rP[23] = P34; rP[24] = P44;
   rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
-  rP[30] = pd_ok;
+  if (kWholeSwitch) rP[30] = pd_ok;
 }
 
 // ------------------------------------------------------------------------------ forward step and costates as scans
@@ -1581,7 +1588,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // The whole curvature of the separation rows first (oracle/ipm.py whole_curvature_first): kept if the backward sweep finds
     // every stage's Huu positive definite; otherwise the stage-wise safeguarded model below (scaled, late in a solve shifted)
     // is assembled and swept instead, and the next iteration does not try the whole curvature again.
-    bool use_whole = sp.whole_first != 0 && sp.row_curvature != 0 && whole_skip == 0;
+    bool use_whole = kWholeSwitch && sp.whole_first != 0 && sp.row_curvature != 0 && whole_skip == 0;
     for (;;) {
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
@@ -1682,8 +1689,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
-    const bool whole_failed = use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0;
-    if (use_whole) CFZ_SYNC();  // rP[30] is cos of stage 15 once the block below has run: every wavefront reads it first
+    const bool whole_failed = kWholeSwitch && use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0;
+    if (kWholeSwitch && use_whole) CFZ_SYNC();  // rP[30] is cos of stage 15 once the block below has run: every wavefront reads it first
     if (whole_failed) {
       use_whole = false; whole_skip = 2;
       CFZ_LANES(tid)  // the sweep's value function sits where the assembly reads cos / sin of the headings (L.rP = L.cs): put them back
@@ -1694,7 +1701,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     }
     break;
     }
-    if (sp.row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
+    if (kWholeSwitch && sp.row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
     // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_STAMP(9);  // forward step

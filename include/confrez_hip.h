@@ -68,7 +68,8 @@ typedef struct cfz_options {
                            *    recursion finds every stage's Huu positive definite (IPOPT: the first trial of its inertia correction,
                            *    delta_w = 0), else falls back to the safeguarded model.  Halves the 99th percentile of a scenario's
                            *    iteration chain on the planned-table closed loop, but three instances of the independent-solver
-                           *    populations then end with status 5 (docs/notebook.md), so it is off */
+                           *    populations then end with status 5 (docs/notebook.md), so it is off -- and compiled into the library only
+                           *    with -DCFZ_WHOLE_FIRST (it costs the kernel registers even when off): cfz_create refuses 1 otherwise */
   int32_t shift_stagnation; /* 10: once the scaled optimality error has not halved for this many iterations at a feasible iterate
                            *    (violation <= constr_viol_tol) the late curvature shift may start at iteration 40 instead of waiting for
                            *    shift_after; ends the sawtooth of the scaled model 15-20 iterations sooner; 0 = off */

@@ -321,7 +321,7 @@ def solve_ipm(g: GeometricColloc, guess, dt0, opt=None, prune=3.0):
 
     z0 = np.append(np.asarray(guess, float).ravel(), dt0)
     nlp = GeometricCollocIpm(g, z0, prune)
-    opt = opt or ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8, constr_viol_tol=1e-9,
+    opt = opt or ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, err_stall_iters=0, tol=1e-8, constr_viol_tol=1e-9,
                                 compl_inf_tol=1e-9, dual_inf_tol=1e-6, lower_mu_on_failure=True)
     r = ipm.solve(nlp, nlp.initial(z0), opt)
     z = r["X"][: g.n]

@@ -171,7 +171,7 @@ def solve_joint_ipm(gs, pairs, guesses, dt0, opt=None, prune=3.0):
 
     z0 = np.concatenate([np.asarray(g_, float).ravel() for g_ in guesses] + [[dt0]])
     nlp = GeometricJointIpm(gs, pairs, z0, prune)
-    opt = opt or ipm.IpmOptions(max_iter=600, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8, constr_viol_tol=1e-9,
+    opt = opt or ipm.IpmOptions(max_iter=1000, hessian="exact", reg_dual=1e-9, stall_iters=0, err_stall_iters=0, tol=1e-8, constr_viol_tol=1e-9,
                                 compl_inf_tol=1e-9, dual_inf_tol=1e-6, lower_mu_on_failure=True)
     r = ipm.solve(nlp, nlp.initial(z0), opt)
     z = r["X"][: nlp.n0]

@@ -110,7 +110,7 @@ if __name__ == "__main__":
         t0 = time.time()
         from oracle import ipm
 
-        r = solve_ipm(g, X0[:-1].reshape(-1, 7), X0[-1], opt=ipm.IpmOptions(max_iter=800, hessian="exact", reg_dual=1e-9, stall_iters=0, tol=1e-8,
+        r = solve_ipm(g, X0[:-1].reshape(-1, 7), X0[-1], opt=ipm.IpmOptions(max_iter=800, hessian="exact", reg_dual=1e-9, stall_iters=0, err_stall_iters=0, tol=1e-8,
                                                                                constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6))
         z = np.append(r["traj"].ravel(), r["dt"])
         res, lam_eq, lam_act, act = kkt_certificate(g, z)

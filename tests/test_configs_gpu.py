@@ -288,7 +288,7 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     check_plan_against_independent(r2["traj"], r2["dt"], True, agent)
 
 
-@pytest.mark.parametrize("name", ["23", "23_d20", "123_d20"])
+@pytest.mark.parametrize("name", ["23", "23_d20", "123_d20", "02_d20_s66"])
 def test_joint_plan_against_the_independent_solver_on_gpu(name):
     """`cfz_joint_colloc` (HIP, through the C ABI) on the joint plan of vehicles 2 and 3 from the fixture's guess against the optimum
     an INDEPENDENT solver found on an independent statement of `solve_final_problem_obca` (tests/golden/joint_independent.npz:
@@ -299,7 +299,10 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
     test (tests/test_independent_solver.py:check_joint_against_independent).
     `23_d20`, `123_d20` (dmin = 0.2; the latter three vehicles and three pairs, the shape of the reference's `main`,
     multi_vehicle_planner.py:605-642): the bodies of vehicles 2 and 3 are in CONTACT at the optimum -- pair rows active with
-    multipliers 0.35 / 0.28 -- so the vehicle-vehicle rows decide the plan there."""
+    multipliers 0.35 / 0.28 -- so the vehicle-vehicle rows decide the plan there.
+    `02_d20_s66` (vehicles 0 and 2 on their first six strategy steps): a CORNER of one body touches a CORNER of the other at the
+    optimum (vertex-vertex pair rows, multipliers 0.34 / 0.024); there the plan also carries a solver-free KKT certificate on the
+    independent statement (1.8e-12)."""
     from conflict_rez_amd import engine
     from test_independent_solver import _joint_fixture, check_joint_against_independent
 
@@ -310,7 +313,7 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
     args = (scenarios.parking_lot_spec(n_nbr=0, N=2, dmin=d["dmin_"]), [plans[a][1][0] for a in agents], tubes, guesses, float(d["dt0"]),
             [float(plans[a][1][-1, 2]) for a in agents])
     r = engine.joint_colloc(*args, max_iter=400)
-    assert r["status"] == 0 and r["iters"] < 60
+    assert r["status"] == 0 and r["iters"] < (80 if name == "02_d20_s66" else 60)  # (52 on the CPU build for the corner contact)
     check_joint_against_independent(r["traj"], r["dt"], False, name)
     r2 = engine.joint_colloc(*args, max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)
     assert r2["status"] in (0, 1, 2, 3), r2["status"]  # ends AT the optimum with the iteration limit or the line search exhausted

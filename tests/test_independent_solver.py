@@ -483,7 +483,11 @@ JOINT_AGENTS = ("vehicle_2", "vehicle_3")
 # pairs: the shape of the reference's `main`, multi_vehicle_planner.py:605-642) at dmin = 0.2: the bodies of vehicles 2 and 3 are in
 # CONTACT at the optimum (active pair rows, multipliers 0.35 / 0.28; tests/golden/make_independent_joint.py --dmin 0.2)
 JOINT_FIXTURES = {"23": ("joint_independent.npz", JOINT_AGENTS, 0.05), "23_d20": ("joint_independent_23_d20.npz", JOINT_AGENTS, 0.2),
-                  "123_d20": ("joint_independent_123_d20.npz", ("vehicle_1", "vehicle_2", "vehicle_3"), 0.2)}
+                  "123_d20": ("joint_independent_123_d20.npz", ("vehicle_1", "vehicle_2", "vehicle_3"), 0.2),
+                  # vehicles 0 and 2 on their first six strategy steps (25 intervals each), dmin 0.2: at the optimum a corner of one BODY
+                  # touches a corner of the other (vertex-vertex pair rows active at two collocation points, multipliers 0.34 / 0.024)
+                  "02_d20_s66": ("joint_independent_02_d20_s66.npz", ("vehicle_0", "vehicle_2"), 0.2, (6, 6))}
+VV_BODY = "02_d20_s66"
 
 
 def _joint_fixture(name="23"):
@@ -492,15 +496,17 @@ def _joint_fixture(name="23"):
 
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(here, "golden"))
-    from make_independent_joint import plans_of_strategy
+    from make_independent_joint import plans_of_strategy, truncated
     from oracle.independent_colloc import GeometricColloc
 
-    fn, agents, dmin = JOINT_FIXTURES[name]
+    fn, agents, dmin = JOINT_FIXTURES[name][:3]
     f = np.load(os.path.join(here, "golden", fn))
     d = {k: f[k] for k in f.files}
     d.setdefault("value", d["cost"])
     d["agents"], d["dmin_"] = agents, dmin
     plans, sp = plans_of_strategy(), scenarios.parking_lot_spec(dmin=dmin)
+    if len(JOINT_FIXTURES[name]) > 3:
+        plans = truncated(plans, agents, JOINT_FIXTURES[name][3])
     gs = [GeometricColloc(plans[a][1][0], plans[a][0], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=float(plans[a][1][-1, 2]), dmin=dmin) for a in agents]
     return d, gs, plans, sp
 
@@ -524,12 +530,25 @@ def check_joint_against_independent(trajs, dt, tight, name="23"):
     gap = (nlp.f(z) - float(d["value"])) / float(d["value"])
     dpose = max(np.abs(np.asarray(trajs[a])[..., :3] - d[f"traj{a}"][..., :3]).max() for a in range(V))
     ddt = abs(float(dt) - float(d["dt"]))
-    if tight:
+    if tight and name == VV_BODY:
+        # The independent solver stops short of its tolerance on this instance (line search at the rounding floor of its
+        # finite-difference distance gradients: certificate 8.7e-5, rows 2e-8), so the comparison with it is looser (measured: cost
+        # 7e-8, poses 1.1e-4 m, dt 1.5e-6 s) -- and the verdict on the plan handed in is the SOLVER-FREE certificate on the independent
+        # statement: its rows hold and the cost gradient is a combination of the gradients of the equality rows and of the active
+        # inequality rows with multipliers of the right sign (1.8e-12 measured), two of them vertex-vertex contacts of the two bodies.
+        from make_independent_joint import joint_kkt_certificate, vertex_pair_contacts
+
+        assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 1e-6 and dpose < 3e-4 and ddt < 1e-5, (eq, ineq, gap, dpose, ddt)
+        res, _, _, active = joint_kkt_certificate(nlp, z)
+        vv = vertex_pair_contacts(nlp, z, active)
+        assert res < 1e-8 and len(vv) >= 1 and max(lam for _, _, lam in vv) > 0.1, (res, active, vv)
+    elif tight:
         assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 1e-6 and dpose < 5e-5 and ddt < 1e-7, (eq, ineq, gap, dpose, ddt)
     else:
         # (the contact fixtures at dmin = 0.2: three vehicles -1.03 %, 1.35 cm measured -- the tolerance relaxes three plans' rows)
-        lim = (1e-2, 1e-2) if name == "23" else (1.5e-2, 2e-2)
-        assert eq < 1e-2 and ineq > -1e-2 and -lim[0] < gap < 1e-4 and dpose < lim[1] and ddt < 2e-3, (eq, ineq, gap, dpose, ddt)
+        # (the corner-to-corner fixture: -1.16 %, 3.2 cm, 3.6e-3 s measured: the relaxed plan cuts the corner closer)
+        lim = (1e-2, 1e-2, 2e-3) if name == "23" else ((1.5e-2, 5e-2, 5e-3) if name == VV_BODY else (1.5e-2, 2e-2, 2e-3))
+        assert eq < 1e-2 and ineq > -1e-2 and -lim[0] < gap < 1e-4 and dpose < lim[1] and ddt < lim[2], (eq, ineq, gap, dpose, ddt)
     return gap, dpose
 
 
@@ -566,6 +585,32 @@ def test_joint_plan_against_the_independent_solver(tight, name):
     check_joint_against_independent(trajs, r["X"][jn.iDt], tight, name)
 
 
+def test_joint_face_normal_rows_alone_pay_at_a_body_corner_contact():
+    """The corner-to-corner fixture with `vv_rows = 0` (face-normal certificates only: a restriction of the reference's feasible set
+    where two vertices are the closest features of the two bodies): the planning source still returns a feasible plan at the
+    reference's tolerance, but a dearer one -- above the independent optimum (+0.41 % measured; +1.7 % at tight tolerances), where the
+    plan with the vertex-vertex rows lies below it by the relaxation of the tolerance (-1.16 %)."""
+    import colloc_emu_binding as ce
+    import test_colloc as tc
+
+    from oracle.colloc_nlp import JointCollocNlp
+    from oracle.independent_joint import GeometricJointIpm
+
+    d, gs, plans, sp = _joint_fixture(VV_BODY)
+    gaps = {}
+    for vv in (True, False):
+        jn = JointCollocNlp([dict(init_pose=plans[a][1][0], tube=plans[a][0], final_heading=float(plans[a][1][-1, 2])) for a in d["agents"]],
+                            sp.A_obs, sp.b_obs, N_per_set=5, dmin=d["dmin_"], vv=vv)
+        singles = [{k: d[f"guess{a}"][:, c].reshape(gs[a].N, 6) for c, k in enumerate(("x", "y", "psi", "v", "delta", "a", "w"))} for a in range(2)]
+        r = ce.solve(jn, jn.pack(singles, float(d["dt0"])), ipm.IpmOptions(**tc.COLLOC_OPT))
+        assert r["status"] == 0
+        z = r["X"][: jn.iDt + 1]
+        nlp = GeometricJointIpm(gs, [(0, 1)], z)
+        assert nlp.pair_dist(z, 0, 1).min() - nlp.dmin > -1e-2
+        gaps[vv] = nlp.f(z) / float(d["value"]) - 1.0
+    assert gaps[True] < 0.0 and gaps[False] > 1e-3, gaps
+
+
 @pytest.mark.parametrize("name", sorted(JOINT_FIXTURES))
 def test_independent_joint_fixture_is_a_kkt_point(name):
     """Certificate of the joint fixture that needs no solver: at the stored plans the gradient of the cost is a combination of the
@@ -578,6 +623,9 @@ def test_independent_joint_fixture_is_a_kkt_point(name):
 
     d, gs, _, _ = _joint_fixture(name)
     V = len(gs)
+    if name == VV_BODY:  # the independent solver's best point, short of its tolerance; the certificate that counts is taken at the
+        assert float(d["certificate"]) < 2e-4 and len(d["contacts"]) >= 1  # kernel's plan (check_joint_against_independent)
+        return
     if V > 2:  # three vehicles: 2.5 minutes of bounded least squares -- the generator ran the same certificate (make_independent_joint.py
         assert float(d["certificate"]) < 1e-8 and int(d["status"]) in (0, 1, 2)  # joint_kkt_certificate) and stored its residual
         return
