@@ -1,19 +1,3 @@
-    # the product library is built without the switch (it costs the kernel registers and a test per stage on its serial lane even
-    # when off: -12 % on the bench); asking for it is an error, not a silent no-op.  With -DCFZ_WHOLE_FIRST the HIP build takes the
-    # C port's decisions (tools/build_variant.sh; last checked on the GPU in round 3, before the switch left the product build).
-    spec = scenarios.parking_lot_spec()
-    ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
-    try:
-        e2 = engine.Engine(spec, max_batch=8, whole_curvature_first=1)
-    except RuntimeError as e:
-        assert "not compiled into this library" in str(e)
-        return
-    pick = [0, 7, 18, 19]
-    o2 = e2.solve(golden["x0"][pick], golden["ref"][pick], golden["nbr"][pick], golden["zu"][pick], want_duals=False)
-    for i, b in enumerate(pick):
-        r = port.solve(ospec, golden["x0"][b], golden["ref"][b], golden["nbr"][b], golden["zu"][b].T, ipm.IpmOptions(whole_curvature_first=True))
-        assert (r["status"], r["iters"]) == (int(o2["status"][i]), int(o2["iters"][i])) and np.abs(r["p"].T - o2["zu"][i]).max() < 1e-6
-    e2.close()
 """GPU parity tests (`pytest -m gpu`): the HIP path, called through the C ABI, against the oracle.
 
 Tolerances (fp64 everywhere): the kernel and the oracle run the same algorithm, so trajectories
@@ -586,9 +570,16 @@ def test_duplicate_carry_slots_are_refused(eng, golden):
         eng.solve(golden["x0"][a], golden["ref"][a], golden["nbr"][a], golden["zu"][a], want_duals=False, slots=[5, 7, 5])
     out = eng.solve(golden["x0"][a], golden["ref"][a], golden["nbr"][a], golden["zu"][a], want_duals=False, slots=[5, 7, 9])
     assert out["status"].tolist() == golden["meta"][a, 0].astype(int).tolist()
+    # the product library is built without the switch (it costs the kernel registers and a test per stage on its serial lane even
+    # when off: -12 % on the bench); asking for it is an error, not a silent no-op.  With -DCFZ_WHOLE_FIRST the HIP build takes the
+    # C port's decisions (tools/build_variant.sh; last checked on the GPU in round 3, before the switch left the product build).
     spec = scenarios.parking_lot_spec()
-    e2 = engine.Engine(spec, max_batch=8, whole_curvature_first=1)
     ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
+    try:
+        e2 = engine.Engine(spec, max_batch=8, whole_curvature_first=1)
+    except RuntimeError as e:
+        assert "not compiled into this library" in str(e)
+        return
     pick = [0, 7, 18, 19]
     o2 = e2.solve(golden["x0"][pick], golden["ref"][pick], golden["nbr"][pick], golden["zu"][pick], want_duals=False)
     for i, b in enumerate(pick):
