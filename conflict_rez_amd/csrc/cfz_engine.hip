@@ -597,7 +597,7 @@ void cfz_default_options(cfz_options *o) {
   o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
   o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
   o->reg_primal = 1e-8;
-  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1; o->carry_duals = 1; o->vv_rows = 1; o->shift_after = 60; o->whole_curvature_first = 0; o->shift_stagnation = 10; o->err_stall_iters = 150; o->warm_push = 1e-6;
+  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1; o->carry_duals = 1; o->vv_rows = 1; o->shift_after = 60; o->whole_curvature_first = 0; o->shift_stagnation = 10; o->err_stall_iters = 150; o->carry_shift = 1; o->warm_push = 1e-6;
 }
 
 int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out) {
@@ -647,7 +647,7 @@ int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
   k.bound_frac = opt->bound_frac; k.s_max = opt->s_max; k.kappa_sigma = opt->kappa_sigma; k.eta_phi = opt->eta_phi;
   k.gamma_theta = opt->gamma_theta; k.gamma_phi = opt->gamma_phi; k.delta_sw = opt->delta_sw;
   k.s_theta = opt->s_theta; k.s_phi = opt->s_phi; k.reg_primal = opt->reg_primal;
-  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature; k.vv_rows = opt->vv_rows; k.shift_after = opt->shift_after; k.whole_first = opt->whole_curvature_first; k.stag_win = opt->shift_stagnation; k.err_stall = opt->err_stall_iters; k.warm_push = opt->warm_push;
+  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature; k.vv_rows = opt->vv_rows; k.shift_after = opt->shift_after; k.whole_first = opt->whole_curvature_first; k.stag_win = opt->shift_stagnation; k.err_stall = opt->err_stall_iters; k.carry_shift = opt->carry_shift ? 1 : 0; k.pad_ks = 0; k.warm_push = opt->warm_push;
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
   if (const char *pad = std::getenv("CFZ_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(pad);  // occupancy experiments only

@@ -100,6 +100,7 @@ struct KSpec {
   int stag_win, err_stall;       // err_stall: iterations without a halving of the error after which the solve ends with status 5 (0: never)
                                  // stag_win: iterations without a halving of the error, at a feasible iterate, after which the late shift may start
                                  // at iteration kShiftStagMin already (0: never; oracle/ipm.py shift_stagnation)
+  int carry_shift, pad_ks;       // carry_shift: a converged solve that shifted some stage tells its successor to shift from the start (oracle/ipm.py)
   int shift_after, whole_first;  // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
                                  // whole_first: the whole row curvature is tried first and kept when every stage's Huu is positive definite
   double dt, wb, dmin;
@@ -1262,13 +1263,13 @@ static void costate_scan(double *m, int N, int o_ab, int o_hc, int o_gk, int o_k
 struct DualOut { double *l, *mm, *lam_ij, *lam_ji, *s; unsigned long long *stamps; };
 
 // State a converged solve leaves in global memory for the next MPC iteration of the same vehicle
-// (oracle/mpc_nlp.py carry_state), in doubles: z[N][nr] | zl[N][6] | zu[N][6] | pi0[5] | pi[N][5] | mu | valid |
+// (oracle/mpc_nlp.py carry_state), in doubles: z[N][nr] | zl[N][6] | zu[N][6] | pi0[5] | pi[N][5] | mu | valid | shifted |
 // working-set codes, one byte per block.
-struct CarryLay { int z, zl, zu, pi0, pi, mu, valid, sel, stride; };
+struct CarryLay { int z, zl, zu, pi0, pi, mu, valid, shifted, sel, stride; };
 CFZ_FN CarryLay carry_layout(int N, int nb) {
   CarryLay c; int o = 0;
   c.z = o; o += N * 2 * nb; c.zl = o; o += N * 6; c.zu = o; o += N * 6; c.pi0 = o; o += 5; c.pi = o; o += N * 5;
-  c.mu = o; o += 1; c.valid = o; o += 1; c.sel = o; o += (N * nb + 7) / 8;
+  c.mu = o; o += 1; c.valid = o; o += 1; c.shifted = o; o += 1; c.sel = o; o += (N * nb + 7) / 8;
   c.stride = (o + 7) & ~7;
   return c;
 }
@@ -1290,6 +1291,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   (void)xpar;
   CFZ_PART(rd, 6);   // lane partials of the workgroup reductions
   CFZ_PART(qx, 15);  // lane shares that meet in a quad sum
+  CFZ_PART(shf, 1);  // this lane has shifted its stage's curvature in some iteration (-> carry record, carry_shift)
   double ro[6];      // results of a reduction (uniform)
 
   // ---- load parameters, initial point ---------------------------------------------------
@@ -1306,6 +1308,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     }
     if (tid < 5) m[L.pi0 + tid] = 0.0;
     for (int i = tid; i < N * 5; i += kNL) m[L.pi + i] = 0.0;
+    CFZ_P(shf, 0) = 0.0;
   CFZ_END
   // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
   // than 2*constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
@@ -1330,6 +1333,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   }
   const bool warm = wst != nullptr && carry_in != 0 && CFZ_UNIFORM(wst[CL.valid]) != 0.0;
   const double mu0 = CFZ_UNIFORM(warm ? fmin(fmax(CFZ_UNIFORM(wst[CL.mu]), mu_floor), sp.mu_init) : sp.mu_init);
+  const bool shift_hint = warm && sp.carry_shift != 0 && CFZ_UNIFORM(wst[CL.shifted]) != 0.0;  // oracle/ipm.py carry_shift
   CFZ_LANES(tid)
     const int k = tid >> 2, sub = tid & 3;
     if (k < N) {
@@ -1670,7 +1674,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             }
             th *= 0.5;
           }
-          if (!use_whole && sp.shift_after > 0 && (iter >= sp.shift_after || (stagnant && iter >= kShiftStagMin)) && th < 1.0) {
+          if (!use_whole && sp.shift_after > 0 && (iter >= sp.shift_after || (stagnant && iter >= kShiftStagMin) || shift_hint) && th < 1.0) {
+            CFZ_P(shf, 0) = 1.0;
             // late in a long solve the scaled model cycles: whole curvature + the smallest identity shift that keeps the margin
             const double dl = pose_shift(dv.q0 + cxx, dv.q1 + cyy, q2 + cc, cxy, ca, cb);
             h[0] += dl; h[1] += dl; h[2] += dl;
@@ -1937,10 +1942,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         }
       }
     }
-    CFZ_P(rd, 0) = smin;
+    CFZ_P(rd, 0) = CFZ_P(shf, 0); CFZ_P(rd, 1) = smin;
   CFZ_END
-  CFZ_REDUCE(0, 0, 1, rd, ro);
-  out_d[0] = fval_last; out_d[1] = err0; out_d[2] = ro[0];
+  CFZ_REDUCE(0, 1, 1, rd, ro);
+  const bool shifted_any = ro[0] != 0.0;
+  out_d[0] = fval_last; out_d[1] = err0; out_d[2] = ro[1];
   out_i[0] = iter; out_i[1] = status;
   if (wst) {  // leave the multipliers for the next MPC iteration of this vehicle, or say that there are none
     CFZ_LANES(tid)
@@ -1951,7 +1957,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         if (tid < 5) wst[CL.pi0 + tid] = m[L.pi0 + tid];
         unsigned char *ws = reinterpret_cast<unsigned char *>(wst + CL.sel);
         for (int i = tid; i < N * nb; i += kNL) ws[i] = sel_ptr(m, L)[i];
-        if (tid == 0) { wst[CL.mu] = mu; wst[CL.valid] = 1.0; }
+        if (tid == 0) { wst[CL.mu] = mu; wst[CL.valid] = 1.0; wst[CL.shifted] = shifted_any ? 1.0 : 0.0; }
       } else if (tid == 0) {
         wst[CL.valid] = 0.0;
       }

@@ -26,7 +26,7 @@ class _CSpec(C.Structure):
     ]
 
 
-_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "carry_duals", "vv_rows", "shift_after", "whole_curvature_first", "shift_stagnation", "err_stall_iters", "reserved2")
+_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "carry_duals", "vv_rows", "shift_after", "whole_curvature_first", "shift_stagnation", "err_stall_iters", "carry_shift")
 _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
 

@@ -75,7 +75,10 @@ typedef struct cfz_options {
                            *    shift_after; ends the sawtooth of the scaled model 15-20 iterations sooner; 0 = off */
   int32_t err_stall_iters; /* 150: a solve whose scaled optimality error has not halved for this many iterations ends with status 5
                            *    instead of running to max_iter (limit cycles below constr_viol_tol escape stall_iters' test); 0 = off */
-  int32_t reserved2;
+  int32_t carry_shift;    /* 1: a converged solve in which some stage's row curvature had to be shifted tells the next solve of the same
+                           *    carry slot (cfz_mpc_set_carry / the closed loop) to shift from its first iteration instead of waiting for
+                           *    shift_after / shift_stagnation: a cornered vehicle otherwise repeats the 40+ iterations of the scaled
+                           *    model at every MPC iteration.  Solves without carried multipliers are unaffected.  0 = off */
   double tol;             /* :362 1e-2 */
   double constr_viol_tol; /* :363 1e-2 */
   double dual_inf_tol;    /* IPOPT default 1 */

@@ -14,6 +14,7 @@
  * Build: gcc -O2 -fPIC -shared -o oracle/_build/libcfz_port.so oracle/cfz_port.c -lm
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define MAXN 64
@@ -38,6 +39,7 @@ typedef struct {
   int whole_first; /* oracle/ipm.py IpmOptions.whole_curvature_first */
   int stag_win;    /* oracle/ipm.py IpmOptions.shift_stagnation */
   int err_stall;   /* oracle/ipm.py IpmOptions.err_stall_iters */
+  int carry_shift; /* oracle/ipm.py IpmOptions.carry_shift */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -45,6 +47,7 @@ typedef struct {
   int valid;
   int sel[MAXN][MAXB];
   double z[MAXN][MAXR], zl[MAXN][6], zu[MAXN][6], pi0[5], pi[MAXN][5], mu;
+  int shifted, pad; /* the solve that wrote the record shifted some stage's curvature (oracle/mpc_nlp.py carry_state) */
 } cfz_port_carry;
 
 typedef struct {
@@ -372,7 +375,9 @@ static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *
 int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double *ref, const double *nbr, double *p_io,
                          double *sep_out, int *cert_out, int *stats, double *fstats, double *trace, int trace_cap,
                          const cfz_port_carry *cin, cfz_port_carry *cout) {
-  if (cout) cout->valid = 0;
+  if (cout) { cout->valid = 0; cout->shifted = 0; }
+  const int shift_hint = (cin && cin->valid && sp->carry_shift > 0) ? cin->shifted : 0; /* oracle/ipm.py carry_shift */
+  int shift_used = 0;
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
   if (N > MAXN || N < 2 || nblk > MAXB) return -1;
   static iterate it, dt_; /* step stored in an `iterate` too */
@@ -642,7 +647,8 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
           }
           th *= 0.5;
         }
-        if (!use_whole && sp->shift_after > 0 && (iter >= sp->shift_after || (stagnant && iter >= SHIFT_STAG_MIN)) && th < 1.0) {
+        if (!use_whole && sp->shift_after > 0 && (iter >= sp->shift_after || (stagnant && iter >= SHIFT_STAG_MIN) || shift_hint) && th < 1.0) {
+          shift_used = 1;
           /* late in a long solve the scaled model cycles: whole curvature + smallest identity shift (hess_gn shift=True) */
           const double dl_ = pose_shift(q0 + cxx, q1 + cyy, q2 + cc, cxy, ca, cb);
           H[k][0][0] += dl_; H[k][1][1] += dl_; H[k][2][2] += dl_;
@@ -804,6 +810,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   }
   stats[0] = iter; stats[1] = status;
   fstats[0] = fval; fstats[1] = err0; fstats[2] = mu;
+  if (cout) cout->shifted = status == 0 ? shift_used : 0;
   if (cout && status == 0) {
     cout->valid = 1; cout->mu = mu;
     for (int k = 0; k < N; ++k) {

@@ -94,6 +94,12 @@ class IpmOptions:
     # to max_iter: limit cycles BELOW constr_viol_tol escape the violation-based stall test (planned-table closed loop: a period-3
     # cycle at violation 9.6e-3 ran 600 iterations, 50 ms on the critical path of a launch).  0 = off.
     err_stall_iters: int = 150
+    # MPC closed loop: a solve in which some stage's curvature had to be shifted tells the next solve of the same vehicle (with the carried
+    # multipliers, oracle/mpc_nlp.py carry_state) to shift from its first iteration instead of waiting for shift_after / stagnation: a
+    # cornered vehicle otherwise repeats the 40+ iterations of the scaled model at every MPC iteration.  Cold solves are unaffected.
+    # (planned-table closed loop, three sampler seeds: 99th percentile of a scenario's iteration chain 580 -> 370, mean 109 -> 98,
+    # more solves converge; docs/notebook.md round 3.)  0 = off.
+    carry_shift: int = 1
     lower_mu_on_failure: bool = False  # a failed line search lowers mu once instead of ending the solve (independent solvers only)
 
 
@@ -185,6 +191,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
     it = 0
     err0 = np.inf
     stagnant, best_err, best_it = False, np.inf, 0
+    shift_hint = bool(warm is not None and opt.carry_shift and warm.get("shift_hint"))  # IpmOptions.carry_shift
+    shifted = False  # some stage's curvature was shifted in some iteration of this solve
     mu_forced = False
     whole_skip = 0  # iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
     for it in range(opt.max_iter + 1):
@@ -271,8 +279,9 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                         whole_skip = 2
                 whole_skip = max(whole_skip - 1, 0)
                 if H is None:
-                    late = opt.shift_after > 0 and (it >= opt.shift_after or (stagnant and it >= SHIFT_STAG_MIN))
+                    late = opt.shift_after > 0 and (it >= opt.shift_after or (stagnant and it >= SHIFT_STAG_MIN) or shift_hint)
                     H = nlp.hess_gn(x, nu, shift=late) + sp.diags(sig + opt.reg_primal)
+                    shifted = shifted or bool(getattr(nlp, "shift_applied", False))
             else:
                 H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
@@ -373,4 +382,4 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         dl, du = dist(x)
         zl = np.where(hasl, np.clip(zl, mu / (opt.kappa_sigma * dl), opt.kappa_sigma * mu / dl), 0.0)
         zu = np.where(hasu, np.clip(zu, mu / (opt.kappa_sigma * du), opt.kappa_sigma * mu / du), 0.0)
-    return dict(X=x, nu=nu, zl=zl, zu=zu, status=status, iters=it, mu=mu, err=err0, f=nlp.f(x))
+    return dict(X=x, nu=nu, zl=zl, zu=zu, status=status, iters=it, mu=mu, err=err0, f=nlp.f(x), shifted=shifted)

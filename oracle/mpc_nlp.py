@@ -584,6 +584,7 @@ class MpcNlp:
         wt = self.spec.weights
         base = np.arange(N) * ns
         rows, cols, vals = [], [], []
+        self.shift_applied = False  # set below if some stage of THIS evaluation is shifted (oracle/ipm.py carry_shift)
 
         def add(i, j, v):
             rows.append(base + i), cols.append(base + j), vals.append(np.broadcast_to(v, (N,)))
@@ -618,6 +619,7 @@ class MpcNlp:
                             break
                     th *= 0.5
                 if shift and th < 1.0 and not whole:
+                    self.shift_applied = True
                     dl = pose_shift(q0 - m_ + C[k, 0, 0], q1 - m_ + C[k, 1, 1], q2 - m_ + C[k, 2, 2], C[k, 0, 1], a_, b_c)
                     th = 1.0
                     for a in range(3):
@@ -736,7 +738,8 @@ def carry_state(nlp, res):
     Zl, Zu = res["zl"].reshape(N, ns), res["zu"].reshape(N, ns)
     cols = [0, 1, 3, 4, 5, 6]
     return dict(z=Zl[:, NP:].copy(), sel=nlp.sel.copy(), zl=Zl[:, cols].copy(), zu=Zu[:, cols].copy(),
-                pi0=res["nu"][0:5].copy(), pi=res["nu"][5 : nlp.c_blk0].reshape(N - 1, 5).copy(), mu=float(res["mu"]))
+                pi0=res["nu"][0:5].copy(), pi=res["nu"][5 : nlp.c_blk0].reshape(N - 1, 5).copy(), mu=float(res["mu"]),
+                shifted=bool(res.get("shifted", False)))  # some stage's curvature was shifted: the next solve shifts from the start
 
 
 def warm_from_carry(nlp, X, carry, opt):
@@ -787,7 +790,7 @@ def warm_from_carry(nlp, X, carry, opt):
     for k in range(N - 1):
         nu[5 + 5 * k : 10 + 5 * k] = carry["pi"][min(k + 1, N - 2)]
     nu[nlp.c_blk0 :] = NU.ravel()
-    return X.ravel(), dict(zl=Zl.ravel(), zu=Zu.ravel(), nu=nu, mu=mu0)
+    return X.ravel(), dict(zl=Zl.ravel(), zu=Zu.ravel(), nu=nu, mu=mu0, shift_hint=bool(carry.get("shifted", False)))
 
 
 def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None, carry=None):

@@ -32,7 +32,7 @@ class _Spec(C.Structure):
     ] + [(k, C.c_double) for k in (
         "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
-    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("whole_first", C.c_int), ("stag_win", C.c_int), ("err_stall", C.c_int)]
+    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("whole_first", C.c_int), ("stag_win", C.c_int), ("err_stall", C.c_int), ("carry_shift", C.c_int)]
 
 
 def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
@@ -57,6 +57,7 @@ def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
     s.whole_first = int(opt.whole_curvature_first)
     s.stag_win = int(opt.shift_stagnation)
     s.err_stall = int(opt.err_stall_iters)
+    s.carry_shift = int(opt.carry_shift)
     return s
 
 
@@ -78,7 +79,7 @@ class Carry(C.Structure):
     """cfz_port_carry: the state a converged solve hands to the next MPC iteration of the same vehicle."""
     _fields_ = [("valid", C.c_int), ("sel", C.c_int * (MAXN * MAXB)), ("z", C.c_double * (MAXN * MAXR)),
                 ("zl", C.c_double * (MAXN * 6)), ("zu", C.c_double * (MAXN * 6)), ("pi0", C.c_double * 5),
-                ("pi", C.c_double * (MAXN * 5)), ("mu", C.c_double)]
+                ("pi", C.c_double * (MAXN * 5)), ("mu", C.c_double), ("shifted", C.c_int), ("pad", C.c_int)]
 
 
 def solve(spec: MpcSpec, x0, ref, nbr, warm_p, opt: IpmOptions = IpmOptions(), trace_cap=0, carry=None):

@@ -12,7 +12,7 @@ _OPTS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa
 
 
 class KSpec(C.Structure):
-    _fields_ = [(k, C.c_int) for k in "N n_obs n_nbr rk_substeps max_iter max_backtrack filter_cap stall_iters row_curvature vv_rows stag_win err_stall shift_after whole_first".split()] + [
+    _fields_ = [(k, C.c_int) for k in "N n_obs n_nbr rk_substeps max_iter max_backtrack filter_cap stall_iters row_curvature vv_rows stag_win err_stall carry_shift pad_ks shift_after whole_first".split()] + [
         ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
         ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
         ("A_obs", C.c_double * 64), ("b_obs", C.c_double * 32), ("V_obs", C.c_double * 64),
@@ -45,6 +45,7 @@ def make_kspec(spec, opt):
     s.whole_first = int(opt.whole_curvature_first)
     s.stag_win = int(opt.shift_stagnation)
     s.err_stall = int(opt.err_stall_iters)
+    s.carry_shift = int(opt.carry_shift)
     s.dt, s.wb, s.dmin = spec.dt, spec.wb, spec.dmin
     s.g[:] = list(spec.g); s.bounds[:] = list(spec.bounds); s.weights[:] = list(spec.weights)
     A = np.zeros((8, 4, 2)); b = np.zeros((8, 4)); V = np.zeros((8, 4, 2))

@@ -148,7 +148,7 @@ def carry_golden():
     spec = MpcSpec(A_obs=np.stack([o.A for o in obs]), b_obs=np.stack([o.b for o in obs]), n_nbr=3)
     ci = np.load(os.path.join(HERE, "carry_inputs.npz"))
     sol, meta = [], []
-    for seq in range(2):
+    for seq in range(len(ci["x0"]) // 3):
         carry = None
         for t in range(3):
             i = 3 * seq + t

@@ -32,7 +32,7 @@ def test_kernel_source_matches_oracle_on_goldens(golden, ospec):
 
 
 def test_carried_multipliers_port_and_kernel_source_match_oracle(ospec):
-    """Three consecutive MPC iterations of two vehicles, each solve started from the multipliers of the one before
+    """Three consecutive MPC iterations of three vehicles, each solve started from the multipliers of the one before
     (tests/golden/carry_golden.npz from the full-KKT oracle): the C port and the kernel source reproduce status,
     iteration count and solution (tests/golden/make_carry_inputs.py: a vehicle working against active bounds and a neighbour, and
     one that merely tracks its reference -- for the latter carrying takes a third of the cold iterations) and land in the same
@@ -42,7 +42,7 @@ def test_carried_multipliers_port_and_kernel_source_match_oracle(ospec):
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     ci, cg = np.load(os.path.join(here, "carry_inputs.npz")), np.load(os.path.join(here, "carry_golden.npz"))
     opt = ipm.IpmOptions()
-    for seq in range(2):
+    for seq in range(len(ci["x0"]) // 3):
         ce, cp = None, None
         for t in range(3):
             i = 3 * seq + t
@@ -54,6 +54,8 @@ def test_carried_multipliers_port_and_kernel_source_match_oracle(ospec):
             assert np.abs(re_["zu"] - cg["sol"][i]).max() < 1e-6 and np.abs(rp["p"].T - cg["sol"][i]).max() < 1e-6
             if t > 0 and seq == 1:  # the vehicle that merely tracks: a third of the cold iterations; the one working against
                 assert it <= cold_it // 2  # active bounds and a neighbour needs about as many as from cold multipliers
+            if seq == 2:  # a cornered vehicle: the first solve waits for the late curvature shift (45 iterations), its successors
+                assert (it > 40) if t == 0 else (it <= cold_it // 2)  # start shifted (IpmOptions.carry_shift): 10, 14 against 38, 44
 
 
 def test_kernel_source_other_shapes(ospec):

@@ -177,9 +177,10 @@ def test_carried_multipliers_match_oracle(eng):
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     ci, cg = np.load(os.path.join(here, "carry_inputs.npz")), np.load(os.path.join(here, "carry_golden.npz"))
     for t in range(3):
-        idx = [t, 3 + t]  # slot 0 = sequence 0, slot 1 = sequence 1
+        idx = [t, 3 + t, 6 + t]  # slot s = sequence s; the third: a cornered vehicle whose successors start with the curvature
+        #                          shift its first solve needed (cfz_options.carry_shift: 10 and 14 iterations instead of 38 and 44)
         out = eng.solve(ci["x0"][idx], ci["ref"][idx], ci["nbr"][idx], ci["zu"][idx], want_duals=False,
-                        carry=None if t == 0 else [1, 1])
+                        carry=None if t == 0 else [1, 1, 1])
         for slot, i in enumerate(idx):
             assert (out["status"][slot], out["iters"][slot]) == (int(cg["meta"][i, 0]), int(cg["meta"][i, 1])), (t, slot)
             assert np.abs(out["zu"][slot] - cg["sol"][i]).max() < 1e-6
