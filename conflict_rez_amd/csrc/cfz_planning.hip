@@ -78,8 +78,9 @@ struct cfz_plan_ws {
 namespace {
 // the workspace behind the handle-less entry points: one per (thread, device), created on first use, kept for the life of
 // the thread (so that a caller of the plain signatures also stops paying hipMalloc/hipFree per call)
+thread_local std::vector<cfz_plan_ws *> g_default_ws;  // (not destroyed at thread exit: the HIP runtime may be gone by then; cfz_plan_ws_trim(NULL) gives the memory back)
 cfz_plan_ws *default_ws(int device) {
-  thread_local std::vector<cfz_plan_ws *> cache;
+  std::vector<cfz_plan_ws *> &cache = g_default_ws;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fail("no HIP device: libconfrez_hip has no CPU path"); return nullptr; }
   if (device < 0 || device >= ndev) { fail("device index out of range"); return nullptr; }
@@ -101,6 +102,12 @@ int cfz_plan_ws_create(int device, cfz_plan_ws **out) {
   w->device = device;
   if (hipStreamCreate(&w->stream) != hipSuccess) { delete w; return fail("hipStreamCreate"); }
   *out = w;
+  return 0;
+}
+
+int cfz_plan_ws_trim(cfz_plan_ws *w) {
+  if (w) { (void)hipSetDevice(w->device); HIP_OK(hipStreamSynchronize(w->stream)); arena_destroy(w->arena); return 0; }
+  for (cfz_plan_ws *d : g_default_ws) if (d) { (void)hipSetDevice(d->device); HIP_OK(hipStreamSynchronize(d->stream)); arena_destroy(d->arena); }
   return 0;
 }
 
@@ -134,6 +141,7 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   long long nt = 0, nx = 0, ns = 0, npts = 0;
   for (int b = 0; b < B; ++b) {
     if (n_sets[b] < 2 || po->N < 1) return fail("a plan needs at least two strategy steps");
+    if (po->kernel < CFZ_KERNEL_AUTO || po->kernel > CFZ_KERNEL_NARROW) return fail("cfz_plan_options.kernel: 0 (by batch size), 1 (wide) or 2 (narrow)");
     cfzp::PSpec &p = specs[b];
     memset(&p, 0, sizeof p);
     p.N = po->N; p.n_chk = n_sets[b] - 1; p.T = po->N * p.n_chk;
@@ -183,7 +191,8 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
   int cus = 0;
   HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
-  if (B <= 2 * cus && !std::getenv("CFZ_STATE_WS_NARROW")) {  // one plan per CU, faster per plan: up to two rounds of it
+  const bool wide_ws = po->kernel == CFZ_KERNEL_WIDE || (po->kernel == CFZ_KERNEL_AUTO && B <= 2 * cus);
+  if (wide_ws) {  // one plan per CU, faster per plan: by default for up to two rounds of it (cfz_plan_options.kernel)
     const size_t pl_bytes = (size_t)CFZ_PANEL * (cfzp::kKB + CFZ_PANEL) * sizeof(double);
     hipLaunchKernelGGL(state_ws_kernel_wide, dim3(B), dim3(512), pl_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
   } else {
@@ -244,6 +253,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
                       int32_t *iters, double *cost) {
   if (!w) return fail("null workspace");
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
+  if (co->kernel < CFZ_KERNEL_AUTO || co->kernel > CFZ_KERNEL_NARROW) return fail("cfz_colloc_options.kernel: 0 (by batch size), 1 (wide) or 2 (narrow)");
   HIP_OK(hipSetDevice(w->device));
   if (arena_reset(w->arena)) return -1;
   hipStream_t st = w->stream;
@@ -340,9 +350,8 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   if (!wide && !co->one_pivot) {
     int cus = 0;
     HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
-    wide = B <= 2 * cus;
+    wide = co->kernel == CFZ_KERNEL_WIDE || (co->kernel == CFZ_KERNEL_AUTO && B <= 2 * cus);  // cfz_colloc_options.kernel
   }
-  if (std::getenv("CFZ_COLLOC_WIDE")) wide = true;  // experiments: every batch through the wide kernel
   if (!wide) {
     const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
     HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));

@@ -31,8 +31,11 @@ _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps k
              "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
 
 
+KERNEL_AUTO, KERNEL_WIDE, KERNEL_NARROW = 0, 1, 2  # cfz_plan_options.kernel / cfz_colloc_options.kernel (include/confrez_hip.h)
+
+
 class _CPlanOptions(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("N", "max_iter", "bounded_input", "stall_iters")] + [
+    _fields_ = [(k, C.c_int32) for k in ("N", "max_iter", "bounded_input", "stall_iters", "kernel", "reserved0")] + [
         ("dt", C.c_double), ("wb", C.c_double), ("shrink_tube", C.c_double), ("bounds", C.c_double * 12),
         ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
 
@@ -123,6 +126,7 @@ def load_library(path=None):
     lib.cfz_state_ws_w.argtypes = [vp, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
     lib.cfz_plan_ws_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.cfz_plan_ws_destroy.argtypes = [vp]
+    lib.cfz_plan_ws_trim.argtypes = [vp]
     lib.cfz_default_colloc_options.argtypes = [C.POINTER(_CCollocOptions)]
     lib.cfz_colloc.argtypes = [C.c_int, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
     lib.cfz_colloc_w.argtypes = [vp, C.c_int, C.POINTER(_CSpec), C.POINTER(_CCollocOptions)] + [vp] * 11
@@ -153,7 +157,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
+    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -180,6 +184,14 @@ def _f64(a, shape):
     return a
 
 
+def trim_default_workspaces():
+    """`cfz_plan_ws_trim(NULL)`: release the device memory of the calling thread's own workspaces behind `state_ws`, `colloc`,
+    `joint_colloc` called without `ws=` (a 256-plan joint launch leaves 25 GB there)."""
+    lib = load_library()
+    if lib.cfz_plan_ws_trim(None) != 0:
+        raise RuntimeError("cfz_plan_ws_trim: " + lib.cfz_last_error().decode())
+
+
 class PlanWorkspace:
     """`cfz_plan_ws`: a stream and the device buffers of the planning calls, kept between calls.  Pass as `ws=` to
     `state_ws`, `colloc`, `joint_colloc_batch`; without it those use a per-thread workspace inside the library."""
@@ -189,6 +201,11 @@ class PlanWorkspace:
         self._w = C.c_void_p()
         if self.lib.cfz_plan_ws_create(int(device), C.byref(self._w)) != 0:
             raise RuntimeError("cfz_plan_ws_create: " + self.lib.cfz_last_error().decode())
+
+    def trim(self):
+        """`cfz_plan_ws_trim`: give the device memory held between calls back now (the next call allocates again)."""
+        if self.lib.cfz_plan_ws_trim(self._w) != 0:
+            raise RuntimeError("cfz_plan_ws_trim: " + self.lib.cfz_last_error().decode())
 
     def close(self):
         if getattr(self, "_w", None):
@@ -242,7 +259,7 @@ def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=
 
 
 class _CCollocOptions(C.Structure):
-    _fields_ = [("N_per_set", C.c_int32), ("max_iter", C.c_int32), ("exact_rows", C.c_int32), ("one_pivot", C.c_int32), ("vv_rows", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("N_per_set", C.c_int32), ("max_iter", C.c_int32), ("exact_rows", C.c_int32), ("one_pivot", C.c_int32), ("vv_rows", C.c_int32), ("kernel", C.c_int32),
                 ("shrink_tube", C.c_double),
                 ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
 

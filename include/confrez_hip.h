@@ -204,12 +204,22 @@ int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const doub
  *   status, iters, cost   per instance (may be NULL); status as in cfz_mpc_stats, the reference raises on status != 0
  * The solver is the interior point of the MPC path with the exact Hessian of the Lagrangian, IPOPT's delta_w ladder
  * driven by a curvature test, delta_c = 1e-9, on the banded primal-dual system (csrc/cfz_plan.inl). */
+#define CFZ_KERNEL_AUTO 0
+#define CFZ_KERNEL_WIDE 1
+#define CFZ_KERNEL_NARROW 2
+
 typedef struct cfz_plan_options {
   int32_t N;              /* :100 steps per strategy step, 30 */
   int32_t max_iter;       /* :210 500 */
   int32_t bounded_input;  /* :104, :155-167 */
   int32_t stall_iters;    /* 0 (as the reference: an infeasible plan runs to max_iter); n > 0: status 5 after n iterations without
                            *   progress of the constraint violation, as in the MPC step -- a batch then does not wait for such a plan */
+  int32_t kernel;         /* which of the two kernels runs the batch: 0 = by batch size (up to two plans per CU: CFZ_KERNEL_WIDE, else
+                           *   CFZ_KERNEL_NARROW), CFZ_KERNEL_WIDE = 1 (512 threads per plan, one plan per CU: the fastest single plan),
+                           *   CFZ_KERNEL_NARROW = 2 (one wavefront per plan, several plans per CU: the highest throughput).  The two
+                           *   sum in different orders: a plan's iterates are reproducible bit for bit PER KERNEL, and at a marginal
+                           *   tolerance its iteration count can differ between them -- pin the kernel where that matters. */
+  int32_t reserved0;
   double dt;              /* :101 0.1 */
   double wb;              /* wheelbase */
   double shrink_tube;     /* :106 0.5 in the callers */
@@ -230,6 +240,10 @@ void cfz_default_plan_options(cfz_plan_options *opt);
 typedef struct cfz_plan_ws cfz_plan_ws;
 int cfz_plan_ws_create(int device, cfz_plan_ws **out);
 int cfz_plan_ws_destroy(cfz_plan_ws *ws);
+/* Gives the device memory a workspace holds back to the runtime now (it is allocated again by the next call).  ws = NULL: the
+ * calling thread's own workspaces behind the plain entry points, which otherwise live as long as the thread.  A workspace also
+ * shrinks by itself: a call that used less than a quarter of a block above 256 MB releases that block at the start of the next. */
+int cfz_plan_ws_trim(cfz_plan_ws *ws);
 int cfz_state_ws_w(cfz_plan_ws *ws, int B, const cfz_plan_options *opt, const int32_t *n_sets, const double *init_pose,
                    const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
                    int32_t *iters, double *cost);
@@ -261,7 +275,8 @@ typedef struct cfz_colloc_options {
                            *    vertices is constrained by their Euclidean distance -- the reference's OBCA rows admit any unit
                            *    direction (vehicle.py:523-541, multi_vehicle_planner.py:419-451); 0: face-normal certificates only
                            *    (a restriction at corner-to-corner contacts, kept to show the gap) */
-  int32_t reserved0;
+  int32_t kernel;         /* cfz_colloc only (a joint plan always runs on 512 threads): 0 = by batch size, CFZ_KERNEL_WIDE, CFZ_KERNEL_NARROW
+                           *    as in cfz_plan_options.kernel */
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */

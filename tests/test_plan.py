@@ -60,21 +60,20 @@ def test_plan_kernel_source_matches_oracle(plans):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("narrow", [False, True])
-def test_state_ws_on_gpu_matches_oracle(plans, narrow, monkeypatch):
+def test_state_ws_on_gpu_matches_oracle(plans, narrow):
     """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory -- with both
-    kernels: eight wavefronts + panel elimination (what a batch this small gets) and one wavefront + LDS window (larger batches;
-    here forced through the environment switch the library reads at every call)."""
+    kernels: eight wavefronts + panel elimination (what a batch this small gets by default) and one wavefront + LDS window (what
+    larger batches get; here asked for through `cfz_plan_options.kernel`)."""
     from conflict_rez_amd import engine
 
-    if narrow:
-        monkeypatch.setenv("CFZ_STATE_WS_NARROW", "1")
+    kern = dict(kernel=engine.KERNEL_NARROW) if narrow else {}
 
     agents = sorted(plans)
     tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
     opt = ipm.IpmOptions(**PLAN_OPT)
     for with_heading in (False, True):  # the reference's callers fix the terminal heading (vehicle.py:901-912)
         fhs = [float(plans[a][1][-1, 2]) if with_heading else None for a in agents]
-        res = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5)
+        res = engine.state_ws([plans[a][1][0] for a in agents], tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5, **kern)
         for a, fh, r in zip(agents, fhs, res):
             tube, p = plans[a]
             nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
@@ -85,6 +84,42 @@ def test_state_ws_on_gpu_matches_oracle(plans, narrow, monkeypatch):
             assert np.abs(r["traj"] - want).max() < 1e-6 and abs(r["cost"] - ro["f"]) < 1e-7
             if fh is not None:
                 assert abs(r["traj"][-1, 2] - fh) < 1e-6
+
+
+@pytest.mark.gpu
+def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
+    """`cfz_plan_options.kernel` / `cfz_colloc_options.kernel`: by default the batch size picks the kernel (up to two plans per CU:
+    512 threads per plan, else one wavefront per plan) and the two sum in different orders, so a plan's iterates are reproducible
+    bit for bit only per kernel.  Pinned to one kernel, the same plan alone and inside a batch of more than two plans per CU
+    (what the default would send to the other kernel) returns the same status, iteration count and trajectory; and the default
+    choice equals the pinned kernel it names."""
+    from conflict_rez_amd import engine
+
+    cus = 256  # MI355X; only "more than two plans per CU" matters
+    a = "vehicle_1"
+    tube = [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]]
+    fh = float(plans[a][1][-1, 2])
+    B = 2 * cus + 8
+    args1 = ([plans[a][1][0]], [tube], [plans[a][1]], [fh])
+    argsB = ([plans[a][1][0]] * B, [tube] * B, [plans[a][1]] * B, [fh] * B)
+    for kern in (engine.KERNEL_WIDE, engine.KERNEL_NARROW):
+        one = engine.state_ws(*args1, shrink_tube=0.5, kernel=kern)[0]
+        many = engine.state_ws(*argsB, shrink_tube=0.5, kernel=kern)
+        for r in (many[0], many[B // 2], many[-1]):
+            assert (r["status"], r["iters"]) == (one["status"], one["iters"]) and np.array_equal(r["traj"], one["traj"])
+    auto1, autoB = engine.state_ws(*args1, shrink_tube=0.5)[0], engine.state_ws(*argsB, shrink_tube=0.5)[0]
+    assert np.array_equal(auto1["traj"], engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_WIDE)[0]["traj"])
+    assert np.array_equal(autoB["traj"], engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_NARROW)[0]["traj"])
+    with pytest.raises(RuntimeError, match="kernel"):
+        engine.state_ws(*args1, shrink_tube=0.5, kernel=7)
+    # cfz_plan_ws_trim: the memory the batch left in the thread's workspace goes back; the next call allocates again
+    engine.trim_default_workspaces()
+    assert np.array_equal(engine.state_ws(*args1, shrink_tube=0.5)[0]["traj"], auto1["traj"])
+    ws = engine.PlanWorkspace()
+    r1 = engine.state_ws(*args1, shrink_tube=0.5, ws=ws)[0]
+    ws.trim()
+    assert np.array_equal(engine.state_ws(*args1, shrink_tube=0.5, ws=ws)[0]["traj"], r1["traj"])
+    ws.close()
 
 
 @pytest.mark.gpu
