@@ -626,9 +626,9 @@ def test_independent_joint_fixture_is_a_kkt_point(name):
     if name == VV_BODY:  # the independent solver's best point, short of its tolerance; the certificate that counts is taken at the
         assert float(d["certificate"]) < 2e-4 and len(d["contacts"]) >= 1  # kernel's plan (check_joint_against_independent)
         return
-    if V > 2:  # three vehicles: 2.5 minutes of bounded least squares -- the generator ran the same certificate (make_independent_joint.py
-        assert float(d["certificate"]) < 1e-8 and int(d["status"]) in (0, 1, 2)  # joint_kkt_certificate) and stored its residual
-        return
+    if V > 2 or name == "23_d20":  # (three vehicles: 2.5 minutes of bounded least squares; 23_d20: 50 s) the generator ran the same
+        assert float(d["certificate"]) < 1e-8 and int(d["status"]) in (0, 1, 2)  # certificate (make_independent_joint.py
+        return  # joint_kkt_certificate) and stored its residual; the live computation below runs on the first fixture
     z = np.concatenate([d[f"traj{a}"].ravel() for a in range(V)] + [[float(d["dt"])]])
     nlp = GeometricJointIpm(gs, [(a, b) for a in range(V) for b in range(a + 1, V)], z, prune=0.5)
     X = nlp.initial(z)
