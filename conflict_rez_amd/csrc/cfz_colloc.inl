@@ -1509,6 +1509,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
+  double delta_last = 0.0;  // the last nonzero primal perturbation of the inertia correction (Algorithm IC)
+  double delta_floor = 0.0; int delta_retry = 0;  // a failed line search is repeated with a larger perturbation (below)
   bool mu_forced = false;  // the last iteration ended without a step and lowered mu instead
   int status = 1, iter = 0;
   long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
@@ -1564,7 +1566,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       w.g[i] = gphi; w.r1[i] = gphi + w.r1[i]; w.sig[i] = s;
     }
     CFZP_SYNC();
-    double delta = 0.0; bool have = false;
+    double delta = delta_floor; bool have = false;
     tk[0] += tick() - ta;
     for (int tries = 0; tries < 60; ++tries) {
       ta = tick();
@@ -1627,10 +1629,13 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
       }
-      delta = delta == 0.0 ? 1e-4 : delta * 8.0;
+      // IPOPT's Algorithm IC (oracle/ipm.py next_delta_w): after delta = 0 a third of the last perturbation that worked (1e-4 if
+      // there has been none), then x 8
+      delta = delta == 0.0 ? (delta_last == 0.0 ? 1e-4 : fmax(1e-20, delta_last / 3.0)) : delta * 8.0;
       if (delta > 1e20) break;
     }
     if (!have) { status = 3; break; }
+    if (delta > 0.0) delta_last = delta;
     ta = tick();
     double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
@@ -1713,9 +1718,13 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))); mu_forced = true; nfilt = 0; filt_mu = mu;
         continue;
       }
+      // Last resort before status 2: the step passed the curvature test but is no descent direction (seen at mu = mu_floor, a
+      // perturbation of a third of the last one: dphi > 0, theta unchanged) -- the same iterate again with eight times the
+      // perturbation, up to three times.  Only runs that would end here take this path.
+      if (delta_retry < 3 && delta < 1e8) { delta_floor = fmax(8.0 * delta, 1e-4); ++delta_retry; nfilt = 0; continue; }
       status = 2; break;
     }
-    mu_forced = false;
+    mu_forced = false; delta_floor = 0.0; delta_retry = 0;
 #if defined(CFZC_TRACE)  // CPU build only (tests/emu): g++ -DCFZC_TRACE -include stdio.h
     printf("it %3d mu %.2e err %.3e theta %.3e cviol %.2e dinf %.2e cmp %.2e delta %.1e alpha %.3e a_pri %.3e a_dual %.3e ftype %d dt %.5f f %.5f\n", iter, mu, err0, theta, cviol, dual_inf, cmp0, delta, alpha, a_pri, a_dual, (int)f_type, w.x[d.iDt], objective(sp, w.x));
 #endif

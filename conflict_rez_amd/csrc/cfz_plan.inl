@@ -423,6 +423,8 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
   double mu = sp.mu_init, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY;
   const double mu_floor = fmin(sp.tol, sp.compl_inf_tol) / (sp.kappa_eps + 1.0);
   double filt[64][2]; int nfilt = 0;
+  double delta_last = 0.0;  // the last nonzero primal perturbation of the inertia correction (Algorithm IC)
+  double delta_floor = 0.0; int delta_retry = 0;  // a failed line search is repeated with a larger perturbation (below)
   bool mu_forced = false;  // the last iteration ended without a step and lowered mu instead
   double stall_ref = 0.0; int stall_cnt = 0;
   int status = 1, iter = 0;
@@ -470,7 +472,7 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     }
     CFZP_SYNC();
     // Newton step with the curvature test
-    double delta = 0.0; bool have = false;
+    double delta = delta_floor; bool have = false;
     for (int tries = 0; tries < 60; ++tries) {
       assemble(sp, tube, w, sig, delta);
       CFZP_LANE_FOR(i, 0, n - 1) w.rhs[w.posx[i]] = -w.r1[i];
@@ -499,10 +501,16 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
       }
-      delta = delta == 0.0 ? 1e-4 : delta * 8.0;
+      // IPOPT's Algorithm IC (oracle/ipm.py next_delta_w): after delta = 0 a third of the last perturbation that worked (1e-4 if
+      // there has been none), then x 8
+      delta = delta == 0.0 ? (delta_last == 0.0 ? 1e-4 : fmax(1e-20, delta_last / 3.0)) : delta * 8.0;
       if (delta > 1e20) break;
     }
     if (!have) { status = 3; break; }
+#if defined(CFZP_TRACE)  // CPU build only: g++ -DCFZP_TRACE -include stdio.h
+    printf("it %3d mu %.2e delta %.3e (last %.3e)\n", iter, mu, delta, delta_last);
+#endif
+    if (delta > 0.0) delta_last = delta;
     double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
     CFZP_LANE_FOR(i, 0, n - 1) {
       const double dxi = w.dx[i];
@@ -552,9 +560,11 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
         mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))); mu_forced = true; nfilt = 0; filt_mu = mu;
         continue;
       }
+      // last resort, as in cfz_colloc.inl: the same iterate again with eight times the perturbation, up to three times
+      if (delta_retry < 3 && delta < 1e8) { delta_floor = fmax(8.0 * delta, 1e-4); ++delta_retry; nfilt = 0; continue; }
       status = 2; break;
     }
-    mu_forced = false;
+    mu_forced = false; delta_floor = 0.0; delta_retry = 0;
     if (!f_type) {
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;

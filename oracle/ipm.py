@@ -103,6 +103,18 @@ class IpmOptions:
     lower_mu_on_failure: bool = False  # a failed line search lowers mu once instead of ending the solve (independent solvers only)
 
 
+def next_delta_w(delta, last):
+    """IPOPT's inertia correction, Algorithm IC of the paper (sec. 3.1), the primal perturbation: a Newton system that fails the
+    curvature test at delta_w = 0 is tried again with delta_w^0 = 1e-4 if no iteration has needed a perturbation yet, else with a
+    third of the last one that worked (kappa_w^-); every further failure multiplies by kappa_w^+ = 8.  (The paper multiplies by 100
+    while no iteration has needed a perturbation yet; without a restoration phase to fall back on that overshoot -- delta_w = 100
+    where 3 would do -- ends small plans in a failed line search, so the first round climbs by 8 as well.)
+    `last`: the last nonzero perturbation of an earlier iteration (0: none yet)."""
+    if delta == 0.0:
+        return 1e-4 if last == 0.0 else max(1e-20, last / 3.0)
+    return delta * 8.0
+
+
 def kkt_inertia_ok(H, J, n, m):
     """True if [[H, J'], [J, 0]] has n positive and m negative eigenvalues (H's reduced Hessian on the null space of J is positive
     definite): dense LDL' (Bunch-Kaufman), eigenvalue signs of its 1 x 1 and 2 x 2 pivot blocks."""
@@ -300,7 +312,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                 dx, dnu = sol[:n], sol[n:]
                 if float(dx @ (H @ dx)) >= opt.curv_kappa * float(dx @ dx) and np.isfinite(sol).all():
                     break
-                trial_delta = 1e-4 if trial_delta == 0.0 else (max(delta_w_last / 3.0, 1e-4) if trial_delta < 0 else trial_delta * 8.0)
+                trial_delta = next_delta_w(trial_delta, delta_w_last)
                 if trial_delta > 1e20:
                     break
             delta_w_last = trial_delta if trial_delta > 0 else delta_w_last

@@ -39,7 +39,7 @@ def test_plan_kernel_source_matches_oracle(plans):
     opt = ipm.IpmOptions(**PLAN_OPT)
     for a, (tube, p) in plans.items():
         for fh, bounded, exact, seeded in ((None, False, True, False), (None, True, True, True), (float(p[-1, 2]), False, True, True),
-                                           (float(p[-1, 2]), False, a == "vehicle_1", False)):
+                                           (float(p[-1, 2]), False, False, False)):
             nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5, bounded_input=bounded)
             X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt) if seeded else None)
             ro, re_ = ipm.solve(nlp, X0, opt), pe.solve(nlp, X0, opt)

@@ -1,0 +1,32 @@
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_configs_gpu as tcg
+from conflict_rez_amd import engine, scenarios, strategy as strat
+from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
+from conflict_rez_amd.vehicle_types import VehicleBody
+hist = strat.generate_strategy(4)
+with tempfile.TemporaryDirectory() as d:
+    fn = os.path.join(d, "4v_rl_traj"); strat.write_strategy(fn, hist)
+    sets, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
+agents = sorted(hist)
+lot = dict(agents=agents, tubes={a: [((s["back"].A, s["back"].b), (s["front"].A, s["front"].b)) for s in sets[a][1:]] for a in agents}, paths=paths, fh={a: float(paths[a][-1, 2]) for a in agents})
+B = 256
+rng = np.random.default_rng(1)
+who = [a for _ in range(B) for a in agents]
+init = [lot["paths"][a][0] + (np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] if i >= 4 else 0.0) for i, a in enumerate(who)]
+ws, good, plans = tcg._single_plans(lot, who, init)
+ok = [b for b in range(B) if all(4 * b + i in plans and plans[4 * b + i]["status"] == 0 for i in range(4))]
+scen = []
+for b in ok:
+    sing = [plans[4 * b + i] for i in range(4)]
+    scen.append(dict(init_poses=[init[4 * b + i] for i in range(4)], tubes=[lot["tubes"][a] for a in agents], guesses=[s["traj"].reshape(-1, 7) for s in sing], dt0=float(np.mean([s["dt"] for s in sing])), final_headings=[lot["fh"][a] for a in agents]))
+sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+rj = engine.joint_colloc_batch(sp0, scen, max_iter=300)
+bad = [(i, r["status"], r["iters"]) for i, r in enumerate(rj) if r["status"]]
+print("failed:", bad, "iters max", max(r["iters"] for r in rj))
+for i, _, _ in bad[:2] + [(int(np.argmax([r["iters"] for r in rj])), 0, 0)]:
+    np.savez(os.path.join(ROOT, "gpurun_out", f"joint_scen_{i}.npz"), init=np.array(scen[i]["init_poses"]), dt0=scen[i]["dt0"], **{f"g{k}": scen[i]["guesses"][k] for k in range(4)})
+    r1 = engine.joint_colloc(sp0, scen[i]["init_poses"], scen[i]["tubes"], scen[i]["guesses"], scen[i]["dt0"], scen[i]["final_headings"], max_iter=300)
+    print("scenario", i, "alone:", r1["status"], r1["iters"])
