@@ -424,3 +424,28 @@ def test_colloc_fixture_on_gpu(plans):
                             [J0[: 7 * n2].reshape(-1, 7), J0[7 * n2 : -1].reshape(-1, 7)], J0[-1], [fh(a) for a in agents], max_iter=400)
     assert (r["status"], r["iters"]) == (int(st[0]), int(st[1])) and abs(r["cost"] - st[2]) < 1e-8 * st[2]
     assert np.abs(np.concatenate([t.reshape(-1, 7) for t in r["traj"]]) - g["joint_sol"][:-1].reshape(-1, 7)).max() < 1e-6
+
+
+def test_inertia_correction_remembers_and_a_failed_line_search_is_retried(plans):
+    """Two pins of the inertia correction of the planning solvers (IPOPT's Algorithm IC, oracle/ipm.py next_delta_w):
+    * the ladder: delta_w = 0 first; then 1e-4 if no iteration has needed a perturbation yet, else a third of the last one that
+      worked; then x 8 -- not a climb from 1e-4 in every iteration (five factorisations per iteration on the slowest joint plans);
+    * tests/golden/joint_retry_instance.npz (inputs of one four-vehicle joint plan of the 256-plan GPU test, start poses scattered
+      by 3 cm): at mu = mu_floor a perturbation of a third of the last one passes the curvature test but the step is no descent
+      direction and the line search fails -- the solver repeats the iterate with eight times the perturbation instead of ending
+      with status 2 (39 iterations, status 0)."""
+    import os
+
+    import colloc_emu_binding as ce
+
+    assert [ipm.next_delta_w(d, l) for d, l in ((0.0, 0.0), (1e-4, 0.0), (0.0, 0.3), (0.1, 0.3))] == [1e-4, 8e-4, 0.3 / 3.0, 0.8]
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joint_retry_instance.npz"))
+    sp = scenarios.parking_lot_spec()
+    agents = ["vehicle_0", "vehicle_1", "vehicle_2", "vehicle_3"]
+    from oracle.colloc_nlp import JointCollocNlp
+
+    jn = JointCollocNlp([dict(init_pose=w["init"][i], tube=plans[a][0], final_heading=float(plans[a][1][-1, 2])) for i, a in enumerate(agents)],
+                        sp.A_obs, sp.b_obs, N_per_set=5)
+    X0 = np.concatenate([w[f"g{i}"].ravel() for i in range(4)] + [[float(w["dt0"])]])
+    r = ce.solve(jn, X0, ipm.IpmOptions(**COLLOC_OPT))
+    assert r["status"] == 0 and r["iters"] < 60, (r["status"], r["iters"])
