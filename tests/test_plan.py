@@ -112,6 +112,23 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
     assert np.array_equal(autoB["traj"], engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_NARROW)[0]["traj"])
     with pytest.raises(RuntimeError, match="kernel"):
         engine.state_ws(*args1, shrink_tube=0.5, kernel=7)
+    # the same for the collocation refinement (cfz_colloc_options.kernel): wide = 512 threads per plan, narrow = one wavefront
+    from conflict_rez_amd import scenarios
+
+    sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    ws1 = engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_WIDE)[0]["traj"]
+    N = 5 * len(tube)
+    t = 0.1 * np.arange(len(ws1))
+    tau = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])
+    ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
+    guess = np.stack([np.interp(ti, t, ws1[:, c]) for c in range(7)], 1)
+    cargs = lambda B_: (sp0, [plans[a][1][0]] * B_, [tube] * B_, [guess] * B_, [t[-1] / N] * B_, [fh] * B_)
+    for kern in (engine.KERNEL_WIDE, engine.KERNEL_NARROW):
+        one = engine.colloc(*cargs(1), max_iter=400, kernel=kern)[0]
+        many = engine.colloc(*cargs(B), max_iter=400, kernel=kern)
+        assert one["status"] == 0
+        for r in (many[0], many[-1]):
+            assert (r["status"], r["iters"]) == (one["status"], one["iters"]) and np.array_equal(r["traj"], one["traj"]) and r["dt"] == one["dt"]
     # cfz_plan_ws_trim: the memory the batch left in the thread's workspace goes back; the next call allocates again
     engine.trim_default_workspaces()
     assert np.array_equal(engine.state_ws(*args1, shrink_tube=0.5)[0]["traj"], auto1["traj"])
