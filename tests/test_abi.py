@@ -58,3 +58,35 @@ def test_no_cpu_fallback(lib):
     with pytest.raises(RuntimeError, match="cfz_create"):
         engine.Engine(scenarios.parking_lot_spec(), max_batch=4)
     assert b"no CPU path" in lib.cfz_last_error() or b"hipGetDeviceCount" in lib.cfz_last_error()
+
+
+def test_ctypes_mirrors_have_the_headers_layout(tmp_path):
+    """Every field of the four structs that cross the boundary sits at the offset the C header gives it (a C program compiled from
+    include/confrez_hip.h prints sizeof and offsetof; the ctypes mirrors of conflict_rez_amd/engine.py must agree, name by name):
+    the structs grew in every round, and a mirror that drifts reads options from the wrong words without any error."""
+    import subprocess
+
+    from conflict_rez_amd import engine
+
+    pairs = {"cfz_spec": engine._CSpec, "cfz_options": engine._COptions, "cfz_plan_options": engine._CPlanOptions,
+             "cfz_colloc_options": engine._CCollocOptions}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "confrez_hip.h"', "int main(void) {"]
+    for cname, mirror in pairs.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    seen = 0
+    for ln in out:
+        if not ln:
+            continue
+        cname, fname, val = ln.split()
+        mirror = pairs[cname]
+        assert int(val) == (C.sizeof(mirror) if fname == "sizeof" else getattr(mirror, fname).offset), ln
+        seen += 1
+    assert seen == sum(len(m._fields_) + 1 for m in pairs.values())
