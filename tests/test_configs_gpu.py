@@ -320,6 +320,30 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
     check_joint_against_independent(r2["traj"], r2["dt"], True, name)
 
 
+def test_joint_plan_does_not_depend_on_the_order_of_its_vehicles():
+    """A property the reference's joint NLP has by construction (multi_vehicle_planner.py:343-480 loops over the agents and over
+    the pairs; no vehicle is special): listing the vehicles in another order gives the same plans and the same shared dt.  The
+    kernel interleaves the vehicles' unknowns in the band by that order, so the elimination runs differently: equal to the solver's
+    tolerance, not to rounding."""
+    from conflict_rez_amd import engine
+    from test_independent_solver import _joint_fixture
+
+    d, gs, plans, sp = _joint_fixture("123_d20")
+    agents = list(d["agents"])
+    tubes = {a: [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents}
+    guess = {a: d[f"guess{i}"] for i, a in enumerate(agents)}
+    spec = scenarios.parking_lot_spec(n_nbr=0, N=2, dmin=d["dmin_"])
+    res = {}
+    for order in (agents, agents[::-1]):
+        r = engine.joint_colloc(spec, [plans[a][1][0] for a in order], [tubes[a] for a in order], [guess[a] for a in order], float(d["dt0"]),
+                                [float(plans[a][1][-1, 2]) for a in order], max_iter=400)
+        assert r["status"] == 0
+        res[tuple(order)] = (r, {a: r["traj"][i] for i, a in enumerate(order)})
+    (ra, ta), (rb, tb_) = res[tuple(agents)], res[tuple(agents[::-1])]
+    assert abs(ra["cost"] - rb["cost"]) < 2e-3 * ra["cost"] and abs(ra["dt"] - rb["dt"]) < 1e-3
+    assert max(np.abs(ta[a][..., :3] - tb_[a][..., :3]).max() for a in agents) < 2e-2
+
+
 def test_panel_elimination_equals_one_pivot_at_a_time(lot):
     """The joint plan's band is eliminated a panel of sixteen pivots at a time and both right-hand sides are substituted in one
     sweep (cfz_colloc.inl: band_factor_panel, band_substitute_regs); `one_pivot = 1` takes the one-pivot elimination and the
