@@ -135,6 +135,43 @@ def test_order_of_neighbours_and_obstacles_does_not_matter(eng):
         assert abs(int((o["status"] == 0).sum()) - int((base["status"] == 0).sum())) <= 4, name
 
 
+def test_mirror_symmetry(eng):
+    """A third size-independent property at the full batch: the parking lot's NLP is symmetric under the reflection y -> 35 - y
+    (the y bounds [7.5, 27.5] are symmetric about 17.5, the body about its axis): mirror the obstacles (A diag(1, -1), b - 35 A_y),
+    the state, the reference, the neighbours and the warm start (psi, delta, w change sign), solve, mirror back -- the same
+    trajectory.  Every sign in the geometry code (face normals, vertex order, the vertex-vertex cones, dw = d(R b)/dpsi) is on this
+    path twice."""
+    import dataclasses
+
+    from conflict_rez_amd import engine, scenarios
+
+    table, _ = scenarios.load_reference_table(kind="planned")
+    k0, noise = scenarios.sample_scenarios(1024, table, seed=2024, spec=eng.spec)
+    x0, ref, nbr, zu = scenarios.mpc_batch_from_table(eng.spec, table, k0, noise)
+    base = eng.solve(x0, ref, nbr, zu, want_duals=False)
+
+    def mir_pose(a, axis):  # rows (x, y, psi, ...) along `axis`
+        a = np.array(a, float)
+        idx = [slice(None)] * a.ndim
+        idx[axis] = 1; a[tuple(idx)] = 35.0 - a[tuple(idx)]
+        idx[axis] = 2; a[tuple(idx)] = -a[tuple(idx)]
+        return a
+
+    x0m = mir_pose(x0, 1); x0m[:, 4] = -x0m[:, 4]
+    zum = mir_pose(zu, 1); zum[:, 4] = -zum[:, 4]; zum[:, 6] = -zum[:, 6]
+    A, b = eng.spec.A_obs, eng.spec.b_obs
+    spm = dataclasses.replace(eng.spec, A_obs=A * np.array([1.0, -1.0]), b_obs=b - 35.0 * A[:, :, 1])
+    em = engine.Engine(spm, max_batch=len(x0))
+    out = em.solve(x0m, mir_pose(ref, 1), mir_pose(nbr, 2), zum, want_duals=False)
+    em.close()
+    back = mir_pose(out["zu"], 1); back[:, 4] = -back[:, 4]; back[:, 6] = -back[:, 6]
+    same = (out["status"] == base["status"]) & (out["iters"] == base["iters"])
+    assert same.mean() > 0.99, same.mean()
+    ok = same & (base["status"] == 0)
+    dz = np.abs(back[ok] - base["zu"][ok]).reshape(int(ok.sum()), -1).max(1)
+    assert dz.max() < 1e-3 and np.quantile(dz, 0.99) < 1e-6 and np.median(dz) < 1e-10, (dz.max(), np.quantile(dz, 0.99), np.median(dz))
+
+
 def test_closed_loop_on_device(eng, ospec):
     """cfz_loop_step (loop_prep / solve_kernel / loop_post) AND cfz_loop_run (the persistent loop_kernel, what bench.py
     times) against a host replay of the same Jacobi iteration with the oracle's C port: reference-table indexing,
