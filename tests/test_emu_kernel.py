@@ -165,3 +165,32 @@ def test_error_stall_ends_a_cycle_below_the_violation_tolerance(ospec):
     re_ = emu.solve(ospec, opt, *args, want_duals=False)
     rp = port.solve(ospec, args[0], args[1], args[2], args[3].T.copy(), opt)
     assert (re_["status"], re_["iters"]) == (rp["status"], rp["iters"]) and re_["status"] == 5 and 150 <= re_["iters"] < 400
+
+
+def test_mirror_symmetry_on_the_cpu(golden, ospec):
+    """The reflection y -> 35 - y of obstacles, state, reference, neighbours and warm start (psi, delta, w change sign) mirrors the
+    solution: C port and kernel source on goldens with face contacts, a vertex-vertex contact and none (the GPU twin runs the full
+    batch, tests/test_gpu_parity.py::test_mirror_symmetry)."""
+    from oracle.mpc_nlp import MpcSpec
+
+    A, b = np.asarray(ospec.A_obs), np.asarray(ospec.b_obs)
+    mspec = MpcSpec(N=ospec.N, dt=ospec.dt, A_obs=A * np.array([1.0, -1.0]), b_obs=b - 35.0 * A[:, :, 1], n_nbr=ospec.n_nbr)
+
+    def mir(a, axis):
+        a = np.array(a, float)
+        idx = [slice(None)] * a.ndim
+        idx[axis] = 1; a[tuple(idx)] = 35.0 - a[tuple(idx)]
+        idx[axis] = 2; a[tuple(idx)] = -a[tuple(idx)]
+        return a
+
+    opt = ipm.IpmOptions()
+    for i in (0, 7, 18, 19):
+        x0, ref, nbr, zu = golden["x0"][i], golden["ref"][i], golden["nbr"][i], golden["zu"][i]
+        x0m = mir(x0, 0); x0m[4] = -x0m[4]
+        zum = mir(zu, 0); zum[4] = -zum[4]; zum[6] = -zum[6]
+        for solve in (lambda sp, *a: (lambda r: (r["status"], r["iters"], r["p"].T))(port.solve(sp, a[0], a[1], a[2], a[3].T.copy(), opt)),
+                      lambda sp, *a: (lambda r: (r["status"], r["iters"], r["zu"]))(emu.solve(sp, opt, *a, want_duals=False))):
+            s0, it0, z0 = solve(ospec, x0, ref, nbr, zu)
+            s1, it1, z1 = solve(mspec, x0m, mir(ref, 0), mir(nbr, 1), zum)
+            back = mir(z1, 0); back[4] = -back[4]; back[6] = -back[6]
+            assert (s0, it0) == (s1, it1) and np.abs(back - z0).max() < 1e-7, (i, s0, it0, s1, it1)
