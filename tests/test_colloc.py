@@ -449,3 +449,34 @@ def test_inertia_correction_remembers_and_a_failed_line_search_is_retried(plans)
     X0 = np.concatenate([w[f"g{i}"].ravel() for i in range(4)] + [[float(w["dt0"])]])
     r = ce.solve(jn, X0, ipm.IpmOptions(**COLLOC_OPT))
     assert r["status"] == 0 and r["iters"] < 60, (r["status"], r["iters"])
+
+
+def test_mirror_symmetry_of_the_collocation_plan():
+    """The reflection y -> 35 - y of tube, obstacles (the pillar of tests/golden/colloc_independent_vv.npz included: a corner-to-corner
+    contact), start pose, terminal heading and guess mirrors the plan of the planning source: equal status and iteration count, cost
+    to 1e-9, poses to 1e-6 -- every sign of the tube rows, the face rows and the vertex-vertex rows with their second derivatives is
+    on this path twice."""
+    import colloc_emu_binding as ce
+    from test_independent_solver import _colloc_fixture
+
+    def mir_poly(A, b):
+        A = np.asarray(A, float); b = np.asarray(b, float)
+        return A * np.array([1.0, -1.0]), b - 35.0 * A[..., 1]
+
+    for agent in ("vehicle_2_pillar", "vehicle_1"):
+        d, g, (tube, p, fh, sp) = _colloc_fixture(agent)
+        G = d["guess"][:-1].reshape(-1, 7)
+        cols = ("x", "y", "psi", "v", "delta", "a", "w")
+        nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+        r0 = ce.solve(nlp, nlp.pack({k: G[:, c] for c, k in enumerate(cols)}, float(d["guess"][-1])), ipm.IpmOptions(**COLLOC_OPT))
+        tube_m = [dict(front=mir_poly(*s["front"]), back=mir_poly(*s["back"])) for s in tube]
+        Am, bm = mir_poly(sp.A_obs, sp.b_obs)
+        Gm = G * np.array([1.0, -1.0, -1.0, 1.0, -1.0, 1.0, -1.0]) + np.array([0.0, 35.0, 0, 0, 0, 0, 0])
+        p0m = np.array([p[0][0], 35.0 - p[0][1], -p[0][2]])
+        nlm = CollocNlp(p0m, tube_m, Am, bm, N_per_set=5, final_heading=-fh)
+        r1 = ce.solve(nlm, nlm.pack({k: Gm[:, c] for c, k in enumerate(cols)}, float(d["guess"][-1])), ipm.IpmOptions(**COLLOC_OPT))
+        assert (r0["status"], r0["iters"]) == (r1["status"], r1["iters"]) == (0, r0["iters"]), (agent, r0["status"], r0["iters"], r1["status"], r1["iters"])
+        assert abs(r0["f"] - r1["f"]) < 1e-9 * abs(r0["f"])
+        P0, P1 = r0["X"][: nlp.iDt].reshape(-1, 7), r1["X"][: nlm.iDt].reshape(-1, 7)
+        back = P1 * np.array([1.0, -1.0, -1.0, 1.0, -1.0, 1.0, -1.0]) + np.array([0.0, 35.0, 0, 0, 0, 0, 0])
+        assert np.abs(back - P0).max() < 1e-6 and abs(r0["X"][nlp.iDt] - r1["X"][nlm.iDt]) < 1e-9
