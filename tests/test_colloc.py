@@ -480,3 +480,42 @@ def test_mirror_symmetry_of_the_collocation_plan():
         P0, P1 = r0["X"][: nlp.iDt].reshape(-1, 7), r1["X"][: nlm.iDt].reshape(-1, 7)
         back = P1 * np.array([1.0, -1.0, -1.0, 1.0, -1.0, 1.0, -1.0]) + np.array([0.0, 35.0, 0, 0, 0, 0, 0])
         assert np.abs(back - P0).max() < 1e-6 and abs(r0["X"][nlp.iDt] - r1["X"][nlm.iDt]) < 1e-9
+
+
+def test_mirror_symmetry_of_the_joint_plan():
+    """The same reflection on a JOINT plan whose optimum has a corner of one body against a corner of another
+    (tests/golden/joint_independent_02_d20_s66.npz): the vehicle-vehicle rows of all three kinds, their 6 x 6 second derivatives
+    and the handover between working sets mirror too -- equal status and iteration count, cost to 1e-8, poses to 1e-5."""
+    import colloc_emu_binding as ce
+    from test_independent_solver import VV_BODY, _joint_fixture
+
+    from oracle.colloc_nlp import JointCollocNlp
+
+    def mir_poly(A, b):
+        A = np.asarray(A, float); b = np.asarray(b, float)
+        return A * np.array([1.0, -1.0]), b - 35.0 * A[..., 1]
+
+    d, gs, plans, sp = _joint_fixture(VV_BODY)
+    agents = d["agents"]
+    sgn, off = np.array([1.0, -1.0, -1.0, 1.0, -1.0, 1.0, -1.0]), np.array([0.0, 35.0, 0, 0, 0, 0, 0])
+    cols = ("x", "y", "psi", "v", "delta", "a", "w")
+    res = []
+    for mirror in (False, True):
+        vehs, singles = [], []
+        for i, a in enumerate(agents):
+            tube, p = plans[a]
+            p0, fh, G = np.array(p[0], float), float(p[-1, 2]), d[f"guess{i}"]
+            if mirror:
+                tube = [dict(front=mir_poly(*s["front"]), back=mir_poly(*s["back"])) for s in tube]
+                p0, fh, G = np.array([p0[0], 35.0 - p0[1], -p0[2]]), -fh, G * sgn + off
+            vehs.append(dict(init_pose=p0, tube=tube, final_heading=fh))
+            singles.append({k: G[:, c].reshape(gs[i].N, 6) for c, k in enumerate(cols)})
+        A_obs, b_obs = mir_poly(sp.A_obs, sp.b_obs) if mirror else (sp.A_obs, sp.b_obs)
+        jn = JointCollocNlp(vehs, A_obs, b_obs, N_per_set=5, dmin=d["dmin_"])
+        r = ce.solve(jn, jn.pack(singles, float(d["dt0"])), ipm.IpmOptions(**COLLOC_OPT))
+        res.append((r, jn))
+    (r0, j0), (r1, j1) = res
+    assert (r0["status"], r0["iters"]) == (r1["status"], r1["iters"]) == (0, r0["iters"]), (r0["status"], r0["iters"], r1["status"], r1["iters"])
+    assert abs(r0["f"] - r1["f"]) < 1e-8 * abs(r0["f"]) and abs(r0["X"][j0.iDt] - r1["X"][j1.iDt]) < 1e-8
+    P0, P1 = r0["X"][: j0.iDt].reshape(-1, 7), r1["X"][: j1.iDt].reshape(-1, 7)
+    assert np.abs(P1 * sgn + off - P0).max() < 1e-5
