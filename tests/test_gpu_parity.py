@@ -172,6 +172,40 @@ def test_mirror_symmetry(eng):
     assert dz.max() < 1e-3 and np.quantile(dz, 0.99) < 1e-6 and np.median(dz) < 1e-10, (dz.max(), np.quantile(dz, 0.99), np.median(dz))
 
 
+def test_half_turn_symmetry(eng):
+    """And the rotation by pi about the lot's centre (x -> 35 - x, y -> 35 - y, psi -> psi + pi; both box bounds are symmetric about
+    17.5; obstacles -A, b - 35 (A_x + A_y)): the headings leave the range the fixtures cover, every cos / sin changes sign, and the
+    solution turns with the problem."""
+    import dataclasses
+
+    from conflict_rez_amd import engine, scenarios
+
+    table, _ = scenarios.load_reference_table(kind="planned")
+    k0, noise = scenarios.sample_scenarios(1024, table, seed=2025, spec=eng.spec)
+    x0, ref, nbr, zu = scenarios.mpc_batch_from_table(eng.spec, table, k0, noise)
+    base = eng.solve(x0, ref, nbr, zu, want_duals=False)
+
+    def turn(a, axis, sign=1.0):  # rows (x, y, psi, ...) along `axis`
+        a = np.array(a, float)
+        idx = [slice(None)] * a.ndim
+        for r in (0, 1):
+            idx[axis] = r; a[tuple(idx)] = 35.0 - a[tuple(idx)]
+        idx[axis] = 2; a[tuple(idx)] = a[tuple(idx)] + sign * np.pi
+        return a
+
+    A, b = eng.spec.A_obs, eng.spec.b_obs
+    spt = dataclasses.replace(eng.spec, A_obs=-A, b_obs=b - 35.0 * (A[:, :, 0] + A[:, :, 1]))
+    et = engine.Engine(spt, max_batch=len(x0))
+    out = et.solve(turn(x0, 1), turn(ref, 1), turn(nbr, 2), turn(zu, 1), want_duals=False)
+    et.close()
+    back = turn(out["zu"], 1, -1.0)
+    same = (out["status"] == base["status"]) & (out["iters"] == base["iters"])
+    assert same.mean() > 0.99, same.mean()
+    ok = same & (base["status"] == 0)
+    dz = np.abs(back[ok] - base["zu"][ok]).reshape(int(ok.sum()), -1).max(1)
+    assert dz.max() < 1e-3 and np.quantile(dz, 0.99) < 1e-6 and np.median(dz) < 1e-9, (dz.max(), np.quantile(dz, 0.99), np.median(dz))
+
+
 def test_closed_loop_on_device(eng, ospec):
     """cfz_loop_step (loop_prep / solve_kernel / loop_post) AND cfz_loop_run (the persistent loop_kernel, what bench.py
     times) against a host replay of the same Jacobi iteration with the oracle's C port: reference-table indexing,
