@@ -185,3 +185,29 @@ def test_planned_reference_table_reproduces_the_package_data():
     spec = scenarios.parking_lot_spec()
     k0, noise = scenarios.sample_scenarios(256, ref, seed=5, spec=spec)
     assert (scenarios.start_clearances(spec, ref, k0, noise) >= spec.dmin - 0.02).all()
+
+
+def test_mirror_symmetry_of_state_ws(plans):
+    """The reflection y -> 35 - y of tube, start pose, terminal heading and path guess mirrors the warm start `state_ws` computes
+    (planning source, CPU build): equal status and iteration count, cost to 1e-9, trajectory to 1e-6."""
+    import plan_emu_binding as pe
+
+    def mir_poly(A, b):
+        A = np.asarray(A, float); b = np.asarray(b, float)
+        return A * np.array([1.0, -1.0]), b - 35.0 * A[..., 1]
+
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    for a in ("vehicle_1", "vehicle_3"):
+        tube, p = plans[a]
+        fh = float(p[-1, 2])
+        nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
+        r0 = pe.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)), opt)
+        tube_m = [dict(front=mir_poly(*s["front"]), back=mir_poly(*s["back"])) for s in tube]
+        pm = np.stack([p[:, 0], 35.0 - p[:, 1], -p[:, 2]], 1)
+        nlm = StateWsNlp(pm[0], tube_m, final_heading=-fh, shrink_tube=0.5)
+        r1 = pe.solve(nlm, nlm.pack(pm[:, 0], pm[:, 1], pm[:, 2], v=speed_guess(pm, nlm.dt)), opt)
+        assert (r0["status"], r0["iters"]) == (r1["status"], r1["iters"]) == (0, r0["iters"]), (a, r0["status"], r0["iters"], r1["status"], r1["iters"])
+        s0, s1 = nlp.unpack(r0["X"]), nlm.unpack(r1["X"])
+        assert abs(r0["f"] - r1["f"]) < 1e-9 * max(1.0, abs(r0["f"]))
+        assert np.abs(s0["x"] - s1["x"]).max() < 1e-6 and np.abs(s0["y"] - (35.0 - s1["y"])).max() < 1e-6 and np.abs(s0["psi"] + s1["psi"]).max() < 1e-6
+        assert np.abs(s0["delta"] + s1["delta"]).max() < 1e-6 and np.abs(s0["v"] - s1["v"]).max() < 1e-6
