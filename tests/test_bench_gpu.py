@@ -48,3 +48,19 @@ def test_long_persistent_launch_at_4096_scenarios():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fault_probe.py"), "4096", "25"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
     assert "Memory access fault" not in out.stderr
+
+
+def test_planning_extras_of_the_bench_line():
+    """`bench.py`'s `extra` objects (configs[1]: single plans, configs[3]: four-vehicle joint plans) at a small batch: every plan
+    converges, the objects carry their own roofline (band bytes from `cfz_colloc_band_info`) and -- with `cpu=True` in the real run
+    -- a CPU baseline; here the GPU half only (the CPU build of the planning source takes a minute per joint plan set)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    ex = bench.planning_extras(device=0, B=8, cpu=False)
+    c1, c3 = ex["configs[1]"], ex["configs[3]"]
+    assert c1["state_ws_converged"] == 8 and c1["colloc_converged"] == 8 and c1["plans_per_s"] > 1.0
+    assert c3["converged"] == 8 and c3["unknowns"] == 12350 and c3["half_bandwidth"] == 298 and c3["band_bytes"] == 12350 * (3 * 298 + 1) * 8
+    for c in (c1, c3):
+        r = c["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["unit"] == "GB/s"
