@@ -11,8 +11,8 @@
 //                  previous predictions (reference vehicle_follower.py:432-476, 636-637)
 //   loop_post      closed loop: read-back or shift fallback, plant integration, clock
 //                  (reference :484-563)
-// The planning kernels (state_ws, collocation plans) and their entry points live in cfz_planning.hip: a translation unit
-// of its own because the two halves want different optimisation levels on this toolchain (see __graft_entry__.build).
+// The planning kernels (state_ws, collocation plans) and their entry points live in cfz_planning.hip, a translation unit
+// of its own (two units compile in parallel; both at -O3 since round 3, see __graft_entry__.build).
 // Host side: a handle owns all device buffers, one stream and two events.
 
 #include <hip/hip_runtime.h>

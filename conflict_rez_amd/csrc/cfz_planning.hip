@@ -2,7 +2,7 @@
 // the single-vehicle collocation plan (vehicle.py:360-661) and the joint plan of several vehicles
 // (multi_vehicle_planner.py:343-480) as gfx950 kernels, with their C ABI entry points (include/confrez_hip.h).
 // Kernel bodies: cfz_plan.inl, cfz_colloc.inl, cfz_band.inl; the separation-certificate geometry is shared with the MPC
-// step (cfz_solver.inl).  Built at -O3 (the MPC half at -O2, see __graft_entry__.build).
+// step (cfz_solver.inl).  Both translation units are built at -O3 (__graft_entry__.build).
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
