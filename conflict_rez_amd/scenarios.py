@@ -133,12 +133,27 @@ def start_clearances(spec: ProblemSpec, table, k0, noise):
     return out
 
 
-def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0), spec=None, margin=0.02):
+def start_box_excess(spec: ProblemSpec, table, k0, noise):
+    """[S, V]: how far every vehicle's measured start state (table state at k0 + noise) lies OUTSIDE the boxes of the MPC's NLP on
+    x, y, v, delta (vehicle_follower.py:205-240; 0 = inside).  The state of stage 0 is pinned to the measurement (:194-199) and
+    bounded like every other stage, so an excess above constr_viol_tol makes the first NLP infeasible (status 4) -- e.g. a plan that
+    drives at the speed limit, measured with +0.05 m/s of noise."""
+    V = table.shape[0]
+    x = table[np.arange(V)[None, :], np.asarray(k0)[:, None], :5] + noise  # [S, V, 5]
+    b = np.asarray(spec.bounds, float).reshape(6, 2)
+    out = np.zeros(x.shape[:2])
+    for q, c in enumerate((0, 1, 3, 4)):
+        out = np.maximum(out, np.maximum(b[q, 0] - x[..., c], x[..., c] - b[q, 1]))
+    return out
+
+
+def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0), spec=None, margin=0.02, box_tol=1e-2):
     """Start sample k0[S] ~ U[0, T - margin) and state noise [S, V, 5] (sigma_xy 0.05 m,
     sigma_psi 0.02 rad, sigma_v 0.05 m/s).
     spec (optional): only FEASIBLE starts -- a scenario in which some vehicle's measured state is closer than dmin - margin to an
-    obstacle or to another vehicle is drawn again (start time and noise, same generator, up to 50 times): such a state is not
-    one `VehicleFollower` can be in (its first NLP is infeasible, status 4).  Without spec: the draws of rounds 1-2 as they come
+    obstacle or to another vehicle, or outside the NLP's state boxes by more than box_tol (`start_box_excess`: round 4 found the
+    planned table's vehicle 1 at the speed limit, so that half of its noisy starts were), is drawn again (start time and noise,
+    same generator, up to 50 times): such a state is not one `VehicleFollower` can be in (its first NLP is infeasible, status 4).  Without spec: the draws of rounds 1-2 as they come
     (the MPC goldens and the closed-loop tests were generated on those)."""
     rng = np.random.default_rng(seed)
     V, T = table.shape[0], table.shape[1]
@@ -146,7 +161,8 @@ def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 
     nz = rng.normal(0.0, 1.0, size=(S, V, 5)) * np.asarray(noise)
     if spec is not None:
         for _ in range(50):
-            bad = np.flatnonzero(start_clearances(spec, table, k0, nz).min(1) < spec.dmin - margin)
+            bad = np.flatnonzero((start_clearances(spec, table, k0, nz).min(1) < spec.dmin - margin)
+                                 | (start_box_excess(spec, table, k0, nz).max(1) > box_tol))
             if not len(bad):
                 break
             k0[bad] = rng.integers(0, max(T - horizon_margin, 1), size=len(bad)).astype(np.int32)

@@ -40,6 +40,9 @@ typedef struct {
   int stag_win;    /* oracle/ipm.py IpmOptions.shift_stagnation */
   int err_stall;   /* oracle/ipm.py IpmOptions.err_stall_iters */
   int carry_shift; /* oracle/ipm.py IpmOptions.carry_shift */
+  int resto;       /* oracle/ipm.py IpmOptions.restoration */
+  double reg_dual_rows; /* oracle/ipm.py IpmOptions.reg_dual_rows: IPOPT's delta_c on the separation rows */
+  double resto_first;   /* oracle/ipm.py IpmOptions.resto_first */
 } cfz_port_spec;
 
 /* state a converged solve hands to the next MPC iteration of the same vehicle (oracle/mpc_nlp.py carry_state) */
@@ -368,6 +371,258 @@ static void sym2_solve(const double M[2][2], const double *rhs, int nr, double *
   }
 }
 
+/* ---------------------------------------------------------------- work arrays (one solve at a time: not re-entrant) */
+static iterate it, dt_; /* iterate; step stored in an `iterate` too */
+static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cur[MAXN][MAXR][6], cj[MAXN][MAXR];
+static int sel[MAXN][MAXB];
+static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
+static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
+static double Kk[MAXN][2][5], kf[MAXN][2];
+static double pt[MAXN][NP], sgt[MAXN][MAXR];
+static double Ps[MAXN][5][5], ps[MAXN][5];
+static double pinew[MAXN][5], pi0new[5]; /* multipliers of the dynamics / initial-state rows after a full Newton step */
+
+/* ---------------------------------------------------------------- the Newton system's stage recursion */
+/* Riccati backward sweep over the condensed stage problems (H, gk, Ak, Bk, dk): gains Kk, kf and the value function
+ * 0.5 dz'P_k dz + p_k'dz of every stage.  Returns 0 if some stage's Huu is not positive definite. */
+static int riccati_backward(int N) {
+  int ok = 1;
+    {
+      int k = N - 1; /* terminal stage: its inputs a,w are costed but drive no dynamics */
+      double R2[2][2] = {{H[k][5][5], H[k][5][6]}, {H[k][6][5], H[k][6][6]}};
+      if (!(R2[0][0] > 0.0 && R2[0][0] * R2[1][1] - R2[0][1] * R2[1][0] > 0.0)) ok = 0;
+      double rhs[2][6], sol[2][6];
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[k][5 + a][q]; rhs[a][5] = gk[k][5 + a]; }
+      sym2_solve(R2, &rhs[0][0], 6, &sol[0][0]);
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) Ps[k][i][q] = H[k][i][q] + H[k][5][i] * Kk[k][0][q] + H[k][6][i] * Kk[k][1][q];
+        ps[k][i] = gk[k][i] + H[k][5][i] * kf[k][0] + H[k][6][i] * kf[k][1];
+      }
+    }
+    for (int k = N - 2; k >= 0; --k) {
+      double PA[5][5], PB[5][2], Pd[5];
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Ak[k][r][q]; PA[i][q] = s; }
+        for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Bk[k][r][q]; PB[i][q] = s; }
+        double s = ps[k + 1][i]; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * dk[k][r]; Pd[i] = s;
+      }
+      double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
+      for (int a = 0; a < 2; ++a) {
+        for (int b = 0; b < 2; ++b) { double s = H[k][5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PB[r][b]; Huu[a][b] = s; }
+        for (int q = 0; q < 5; ++q) { double s = H[k][5 + a][q]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PA[r][q]; Hux[a][q] = s; }
+        double s = gk[k][5 + a]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * Pd[r]; hu[a] = s;
+      }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) { double s = H[k][i][q]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * PA[r][q]; Hxx[i][q] = s; }
+        double s = gk[k][i]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * Pd[r]; hx[i] = s;
+      }
+      double rhs[2][6], sol[2][6];
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
+      if (!(Huu[0][0] > 0.0 && Huu[0][0] * Huu[1][1] - Huu[0][1] * Huu[1][0] > 0.0)) ok = 0;
+      sym2_solve(Huu, &rhs[0][0], 6, &sol[0][0]);
+      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
+      for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 5; ++q) Ps[k][i][q] = Hxx[i][q] + Hux[0][i] * Kk[k][0][q] + Hux[1][i] * Kk[k][1][q];
+        ps[k][i] = hx[i] + Hux[0][i] * kf[k][0] + Hux[1][i] * kf[k][1];
+      }
+      for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { double s = 0.5 * (Ps[k][i][q] + Ps[k][q][i]); Ps[k][i][q] = Ps[k][q][i] = s; }
+    }
+  return ok;
+}
+
+/* forward sweep: the step dt_.p from dz_0 = x0 - z_0, and the multipliers a full step would leave (pi0new, pinew) */
+static void riccati_forward(int N, const double *x0) {
+  for (int i = 0; i < 5; ++i) dt_.p[0][i] = x0[i] - it.p[0][i];
+  for (int k = 0; k < N; ++k) {
+    for (int a = 0; a < 2; ++a) { double s = kf[k][a]; for (int q = 0; q < 5; ++q) s += Kk[k][a][q] * dt_.p[k][q]; dt_.p[k][5 + a] = s; }
+    if (k + 1 < N)
+      for (int i = 0; i < 5; ++i) {
+        double s = dk[k][i];
+        for (int q = 0; q < 5; ++q) s += Ak[k][i][q] * dt_.p[k][q];
+        for (int q = 0; q < 2; ++q) s += Bk[k][i][q] * dt_.p[k][5 + q];
+        dt_.p[k + 1][i] = s;
+      }
+  }
+  for (int i = 0; i < 5; ++i) { double s = ps[0][i]; for (int q = 0; q < 5; ++q) s += Ps[0][i][q] * dt_.p[0][q]; pi0new[i] = -s; }
+  for (int k = 0; k + 1 < N; ++k)
+    for (int i = 0; i < 5; ++i) { double s = ps[k + 1][i]; for (int q = 0; q < 5; ++q) s += Ps[k + 1][i][q] * dt_.p[k + 1][q]; pinew[k][i] = s; }
+}
+
+/* ---------------------------------------------------------------- feasibility restoration (oracle/ipm.py restore) */
+/* IPOPT answers a failed line search with its restoration phase (paper sec. 3.3): it minimises the constraint violation, staying close
+ * to the point where it was called, and resumes from there.  Here the violation of the separation rows and of the boxes is a sum of
+ * squared hinges -- a nonlinear least-squares problem over the trajectory,
+ *     min  rho / 2 sum_{k >= 1, r} max(0, dmin + eps - sep_kr(p_k))^2  +  rho_b / 2 sum (excess over the boxes shrunk by m_b)^2
+ *          +  zeta / 2 |p - p_R|^2          s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
+ * solved by Gauss-Newton steps on the same stage recursion as the solver's Newton system (H_k = zeta I + rho sum of a a' over the
+ * violated rows + rho_b on the violated boxes), with an Armijo line search on the l1 merit (objective + eta x |dynamics defects|_1).
+ * zeta = sqrt(mu) and p_R = the iterate at entry (paper eq. 30).  No barrier and no multipliers inside: a step is never cut by the
+ * fraction to the boundary (a primal barrier at the solver's small mu crawls from one saturating input to the next).
+ * Returns 1 when every row of stages >= 1 holds with margin eps / 2, every box with margin m_b / 2, and the dynamics defects are
+ * below constr_viol_tol (the iterate is then clipped m_b / 2 inside the boxes); 0 when the iteration stalls before that (a
+ * stationary point of the violation: locally infeasible), when a line search fails, or at the iteration limit.
+ * *iter counts the restoration's iterations on the solve's counter. */
+#define RESTO_RHO 1000.0
+#define RESTO_RHO_BOX 1e5
+#define RESTO_BOX_MARGIN 2e-3
+#define RESTO_MAX_ITER 40
+#define RESTO_STALL 8
+#define RESTO_KAPPA 0.1
+#define RESTO_ARMIJO 1e-4
+#define RESTO_MULT_RESET 1e3
+static double resto_objective(const cfz_port_spec *sp, const double p[][NP], const double pbar[][NP], const double sp_[][MAXR],
+                              double eps, double zeta) {
+  const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
+  double phi = 0.0;
+  for (int k = 0; k < N; ++k) {
+    for (int i = 0; i < NP; ++i) { const double e = p[k][i] - pbar[k][i]; phi += 0.5 * zeta * e * e; }
+    for (int q = (k == 0 ? 4 : 0); q < 6; ++q) {
+      const double el = sp->bounds[2 * q] + RESTO_BOX_MARGIN - p[k][BCOL[q]], eu = p[k][BCOL[q]] - sp->bounds[2 * q + 1] + RESTO_BOX_MARGIN;
+      if (el > 0.0) phi += 0.5 * RESTO_RHO_BOX * el * el;
+      if (eu > 0.0) phi += 0.5 * RESTO_RHO_BOX * eu * eu;
+    }
+    if (k >= 1) for (int j = 0; j < nb; ++j) { const double v = sp->dmin + eps - sp_[k][j]; if (v > 0.0) phi += 0.5 * RESTO_RHO * v * v; }
+  }
+  return phi;
+}
+
+static double pbar[MAXN][NP]; /* the iterate at the restoration's entry */
+static int restore_run(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
+  const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk;
+  const double zeta = sqrt(mu), rho = RESTO_RHO, mb = RESTO_BOX_MARGIN;
+  double eta = 0.0, eps = 0.0, lm = 0.0, vgoal = 0.0, vref = INFINITY, dgoal = 0.0; int ref_it = 0;
+  for (int rit = 0;; ++rit) {
+    if (rit > 0) select_all(sp, nbr, it.p, sel);
+    eval_rows(sp, nbr, it.p, sel, sep, gra, 0);
+    double th_dyn = 0.0, cv_dyn = 0.0, vmax = 0.0, bmax = 0.0;
+    if (rit == 0) { /* the margin the rows are restored with: bound_push, but no more than the worst violation at entry */
+      double v0 = 0.0;
+      for (int k = 1; k < N; ++k) for (int j = 0; j < nb; ++j) v0 = fmax(v0, sp->dmin - sep[k][j]);
+      eps = fmin(sp->bound_push, v0);
+      vgoal = fmax(0.5 * eps, RESTO_KAPPA * (v0 + eps));
+    }
+    for (int i = 0; i < 5; ++i) { double r = it.p[0][i] - x0[i]; th_dyn += fabs(r); cv_dyn = fmax(cv_dyn, fabs(r)); }
+    for (int k = 0; k + 1 < N; ++k) {
+      rk4_sens(it.p[k], it.p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, Fk[k], Ak[k], Bk[k]);
+      for (int i = 0; i < 5; ++i) { dk[k][i] = Fk[k][i] - it.p[k + 1][i]; th_dyn += fabs(dk[k][i]); cv_dyn = fmax(cv_dyn, fabs(dk[k][i])); }
+    }
+    for (int k = 0; k < N; ++k) {
+      memset(H[k], 0, sizeof H[k]);
+      for (int i = 0; i < NP; ++i) { gk[k][i] = zeta * (it.p[k][i] - pbar[k][i]); H[k][i][i] = zeta + lm; }
+      for (int q = (k == 0 ? 4 : 0); q < 6; ++q) { /* the states of stage 0 are the measurement: nothing to restore there */
+        const int c = BCOL[q];
+        const double el = sp->bounds[2 * q] + mb - it.p[k][c], eu = it.p[k][c] - sp->bounds[2 * q + 1] + mb;
+        if (el > 0.0) { gk[k][c] -= RESTO_RHO_BOX * el; H[k][c][c] += RESTO_RHO_BOX; bmax = fmax(bmax, el); }
+        if (eu > 0.0) { gk[k][c] += RESTO_RHO_BOX * eu; H[k][c][c] += RESTO_RHO_BOX; bmax = fmax(bmax, eu); }
+      }
+      if (k >= 1)
+        for (int j = 0; j < nb; ++j) {
+          const double v = sp->dmin + eps - sep[k][j];
+          if (v > 0.0) {
+            vmax = fmax(vmax, v);
+            for (int a = 0; a < 3; ++a) {
+              gk[k][a] -= rho * v * gra[k][j][a];
+              for (int b = 0; b < 3; ++b) H[k][a][b] += rho * gra[k][j][a] * gra[k][j][b];
+            }
+          }
+        }
+      for (int i = 0; i < NP; ++i) gphi[k][i] = gk[k][i];
+    }
+    const double phi = resto_objective(sp, it.p, pbar, sep, eps, zeta);
+    if (rit == 0) dgoal = fmax(sp->constr_viol_tol, cv_dyn); /* dynamics: no worse than at entry */
+    if (vmax <= vgoal && bmax <= 0.5 * mb && cv_dyn <= dgoal) {
+      for (int k = 0; k < N; ++k)
+        for (int q = 0; q < 6; ++q) {
+          const int c = BCOL[q];
+          it.p[k][c] = fmin(fmax(it.p[k][c], sp->bounds[2 * q] + 0.5 * mb), sp->bounds[2 * q + 1] - 0.5 * mb);
+        }
+      return 1;
+    }
+    /* stalled: the worst violation has not dropped by a tenth in RESTO_STALL iterations -> a stationary point of the violation */
+    if (vmax <= 0.9 * vref || vmax <= vgoal) { vref = vmax; ref_it = rit; }
+    if (rit - ref_it >= RESTO_STALL) return 0;
+    if (rit == RESTO_MAX_ITER || *iter >= sp->max_iter) return 0;
+    riccati_backward(N);
+    riccati_forward(N, x0);
+    double dphi = 0.0, pim = 0.0;
+    for (int i = 0; i < 5; ++i) pim = fmax(pim, fabs(pi0new[i]));
+    for (int k = 0; k < N; ++k) {
+      for (int i = 0; i < NP; ++i) dphi += gphi[k][i] * dt_.p[k][i];
+      if (k + 1 < N) for (int i = 0; i < 5; ++i) pim = fmax(pim, fabs(pinew[k][i]));
+    }
+    if (eta < 1.1 * pim) eta = 2.0 * pim;
+    const double M0 = phi + eta * th_dyn, dM = dphi - eta * th_dyn;
+    if (!(dM < -1e-10 * (1.0 + fabs(M0)))) return 0; /* stationary with rows still violated */
+    double alpha = 1.0; int accepted = 0;
+    for (int bt = 0; bt < sp->max_backtrack; ++bt) {
+      double th_t = 0.0;
+      for (int k = 0; k < N; ++k) for (int i = 0; i < NP; ++i) pt[k][i] = it.p[k][i] + alpha * dt_.p[k][i];
+      for (int i = 0; i < 5; ++i) th_t += fabs(pt[0][i] - x0[i]);
+      for (int k = 0; k + 1 < N; ++k) {
+        double F[5];
+        rk4(pt[k], pt[k] + 5, sp->dt, sp->wb, sp->rk_substeps, F);
+        for (int i = 0; i < 5; ++i) th_t += fabs(F[i] - pt[k + 1][i]);
+      }
+      eval_rows(sp, nbr, pt, sel, sgt, 0, 0); /* the working set is held during the line search, as in the solver */
+      const double M_t = resto_objective(sp, pt, pbar, sgt, eps, zeta) + eta * th_t;
+      if (isfinite(M_t) && M_t <= M0 + RESTO_ARMIJO * alpha * dM) { accepted = 1; break; }
+      alpha *= 0.5;
+    }
+    if (!accepted) return 0;
+    if (alpha < 0.2) lm = fmax(4.0 * lm, 1.0); else if (alpha == 1.0) lm *= 0.25;
+    for (int k = 0; k < N; ++k) for (int i = 0; i < NP; ++i) it.p[k][i] = pt[k][i];
+    ++*iter;
+  }
+}
+
+/* a restoration that fails leaves the iterate where it was called */
+static int restore(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
+  memcpy(pbar, it.p, sizeof pbar);
+  if (restore_run(sp, x0, nbr, mu, iter)) return 1;
+  memcpy(it.p, pbar, sizeof pbar);
+  return 0;
+}
+
+/* cold multipliers at the current point (after a restoration): slacks from the rows, z = mu / distance, the equality rows at zero */
+static void cold_multipliers(const cfz_port_spec *sp, const double *nbr, double mu) {
+  const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
+  select_all(sp, nbr, it.p, sel);
+  eval_rows(sp, nbr, it.p, sel, sep, 0, 0);
+  for (int k = 0; k < N; ++k) {
+    for (int j = 0; j < nb; ++j) {
+      it.sg[k][j] = fmax(sep[k][j] - sp->dmin, 0.5 * sp->bound_push);
+      it.zs[k][j] = mu / it.sg[k][j]; it.nuc[k][j] = -it.zs[k][j];
+    }
+    for (int q = 0; q < 6; ++q) {
+      const double dl = it.p[k][BCOL[q]] - sp->bounds[2 * q], du = sp->bounds[2 * q + 1] - it.p[k][BCOL[q]];
+      it.zl[k][q] = mu / dl; it.zu[k][q] = mu / du;
+    }
+    for (int i = 0; i < 5; ++i) it.pi[k][i] = 0.0;
+  }
+  for (int i = 0; i < 5; ++i) it.pi0[i] = 0.0;
+}
+
+/* the restoration phase called from inside the iteration (failed line search, stalled violation), and how the iteration resumes:
+ * the multipliers are kept (the loop's working-set refresh hands them over from the entry's working set) unless they have run away
+ * -- IPOPT's constr_mult_reset_threshold -- in which case the iteration restarts cold at the restored point */
+static int restore_and_resume(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
+  const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
+  static int sel_in[MAXN][MAXB];
+  memcpy(sel_in, sel, sizeof sel);
+  if (!restore(sp, x0, nbr, mu, iter)) return 0;
+  double zmax = 0.0;
+  for (int i = 0; i < 5; ++i) zmax = fmax(zmax, fabs(it.pi0[i]));
+  for (int k = 0; k < N; ++k) {
+    for (int j = 0; j < nb; ++j) zmax = fmax(zmax, fmax(fabs(it.nuc[k][j]), it.zs[k][j]));
+    for (int q = 0; q < 6; ++q) zmax = fmax(zmax, fmax(it.zl[k][q], it.zu[k][q]));
+    if (k + 1 < N) for (int i = 0; i < 5; ++i) zmax = fmax(zmax, fabs(it.pi[k][i]));
+  }
+  if (zmax > RESTO_MULT_RESET) cold_multipliers(sp, nbr, mu);
+  else memcpy(sel, sel_in, sizeof sel);
+  return 1;
+}
+
 /* ---------------------------------------------------------------- the solver */
 /* p_io: [N][7] warm start in (x,y,psi,v,delta,a,w per stage), solution out.
  * stats: [0]=iters [1]=status(0 ok,1 maxiter,2 linesearch,3 nan,4 initial state in collision) ; fstats: [0]=f [1]=err [2]=mu
@@ -380,23 +635,16 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   int shift_used = 0;
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk; /* nb = rows per stage */
   if (N > MAXN || N < 2 || nblk > MAXB) return -1;
-  static iterate it, dt_; /* step stored in an `iterate` too */
-  static double sep[MAXN][MAXR], gra[MAXN][MAXR][3], cur[MAXN][MAXR][6], cj[MAXN][MAXR];
-  static int sel[MAXN][MAXB];
-  static double Fk[MAXN][5], Ak[MAXN][5][5], Bk[MAXN][5][2], dk[MAXN][5];
-  static double H[MAXN][NP][NP], gk[MAXN][NP], gphi[MAXN][NP];
-  static double Kk[MAXN][2][5], kf[MAXN][2];
-  static double pt[MAXN][NP], sgt[MAXN][MAXR];
   double filt[64][2]; int nfilt = 0; double filt_mu = -1.0;
   double theta_min = -1.0, theta_max = -1.0;
   const double mu_floor = fmin(sp->tol, sp->compl_inf_tol) / (sp->kappa_eps + 1.0);
   double stall_ref = 0.0;
   int stall_cnt = 0, stall_ws = 0;
+  int resto_calls = 0, iter0 = 0, locally_infeasible = 0;
   double mu = sp->mu_init;
   int status = 1, iter = 0;
   int whole_skip = 0; /* iterations left in which the whole row curvature is not tried */
   int stagnant = 0, best_it = 0; double best_err = INFINITY; /* oracle/ipm.py shift_stagnation */
-  static double Ps[MAXN][5][5], ps[MAXN][5];
   double err0 = INFINITY;
   const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb); /* nb counts rows here */
 
@@ -429,6 +677,17 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       }
     }
     (void)one;
+  }
+  /* ... and so is a measured state outside the boxes on x, y, v, delta by more than constr_viol_tol (stage 0 is bounded like every
+   * other stage, vehicle_follower.py:205-240, and pinned to the measurement, :194-199) */
+  for (int q = 0; q < 4; ++q) {
+    const double v = x0[BCOL[q]];
+    if (v < sp->bounds[2 * q] - sp->constr_viol_tol || v > sp->bounds[2 * q + 1] + sp->constr_viol_tol) {
+      stats[0] = 0; stats[1] = 4; fstats[0] = 0.0; fstats[1] = INFINITY; fstats[2] = sp->mu_init;
+      if (sep_out) for (int q2 = 0; q2 < N * nblk; ++q2) sep_out[q2] = 0.0;
+      if (cert_out) for (int q2 = 0; q2 < N * nblk; ++q2) cert_out[q2] = 0;
+      return 0;
+    }
   }
   select_all(sp, nbr, it.p, sel);
   eval_rows(sp, nbr, it.p, sel, sep, 0, 0);
@@ -480,10 +739,25 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     for (int k = 0; k + 1 < N; ++k) { const int ko = k + 1 < N - 1 ? k + 1 : N - 2; for (int i = 0; i < 5; ++i) it.pi[k][i] = cin->pi[ko][i]; }
   }
 
-  for (iter = 0; iter <= sp->max_iter; ++iter) {
+  if (sp->resto > 0 && sp->resto_first > 0.0) {
+    /* a start whose rows are violated by more than resto_first goes through the restoration phase first (cold multipliers after it) */
+    double v0 = 0.0;
+    for (int k = 1; k < N; ++k) for (int j = 0; j < nb; ++j) v0 = fmax(v0, sp->dmin - sep[k][j]);
+    if (v0 > sp->resto_first) {
+      int rit = 0;
+      if (restore(sp, x0, nbr, mu, &rit)) {
+        cold_multipliers(sp, nbr, mu);
+      } else {
+        locally_infeasible = 1; /* IPOPT: "converged to a point of local infeasibility" */
+      }
+      iter0 = rit;
+    }
+  }
+  if (locally_infeasible) { status = 5; iter = iter0; }
+  for (iter = iter0; iter <= sp->max_iter && !locally_infeasible; ++iter) {
     /* ---- working set: rows keep slack and multipliers while their (face, vertex) identity lasts */
     int ws_changed = 0;
-    if (iter > 0) {
+    if (iter > iter0) {
       static int old[MAXN][MAXB];
       memcpy(old, sel, sizeof sel);
       select_all(sp, nbr, it.p, sel);
@@ -564,13 +838,13 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp->tol && dual_inf <= sp->dual_inf_tol && cviol <= sp->constr_viol_tol && cmp0 <= sp->compl_inf_tol) { status = 0; break; }
     if (iter == sp->max_iter) break;
-    if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
+    if (iter == iter0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
     if (sp->stag_win > 0 && !stagnant && cviol <= sp->constr_viol_tol && iter - best_it >= sp->stag_win) stagnant = 1;
     if (sp->err_stall > 0 && iter - best_it >= sp->err_stall) { status = 5; break; }
     /* infeasibility stall (oracle/ipm.py) */
     /* an iterate that changed the working set counts a quarter (its new rows start with their own violation; but a solve that
      * changes it at EVERY iterate cycles, and must end) */
-    if (iter == 0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
+    if (iter == iter0 || cviol <= sp->stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
     else if (!ws_changed) ++stall_cnt;
     else if (++stall_ws >= WS_STALL_DIV) { stall_ws = 0; ++stall_cnt; }
     if (sp->stall_iters > 0 && stall_cnt >= sp->stall_iters && cviol > sp->constr_viol_tol) { status = 5; break; }
@@ -615,8 +889,9 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       }
       for (int i = 0; i < NP; ++i) gk[k][i] = gphi[k][i];
       for (int j = 0; j < nb; ++j) {
-        double S = it.zs[k][j] / it.sg[k][j] + sp->reg_primal;
-        double coef = S * cj[k][j] - mu / it.sg[k][j];
+        /* delta_c on the row (IPOPT's dual regularisation, eliminated with the slack): stiffness S0 / (1 + delta_c S0) */
+        const double S0 = it.zs[k][j] / it.sg[k][j] + sp->reg_primal, iD = 1.0 / (1.0 + sp->reg_dual_rows * S0), S = S0 * iD;
+        double coef = S * cj[k][j] - mu / it.sg[k][j] * iD + sp->reg_dual_rows * S * it.nuc[k][j];
         for (int a = 0; a < 3; ++a) {
           gk[k][a] += gra[k][j][a] * coef;
           for (int b = 0; b < 3; ++b) H[k][a][b] += S * gra[k][j][a] * gra[k][j][b];
@@ -658,67 +933,15 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         H[k][0][0] += th * cxx; H[k][1][1] += th * cyy; H[k][0][1] += th * cxy; H[k][1][0] += th * cxy;
       }
     }
-    /* ---- Riccati backward: value function 0.5 dz'P_k dz + p_k'dz kept for every stage ------- */
-    {
-      int k = N - 1; /* terminal stage: its inputs a,w are costed but drive no dynamics */
-      double R2[2][2] = {{H[k][5][5], H[k][5][6]}, {H[k][6][5], H[k][6][6]}};
-      if (!(R2[0][0] > 0.0 && R2[0][0] * R2[1][1] - R2[0][1] * R2[1][0] > 0.0)) pd_ok = 0;
-      double rhs[2][6], sol[2][6];
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[k][5 + a][q]; rhs[a][5] = gk[k][5 + a]; }
-      sym2_solve(R2, &rhs[0][0], 6, &sol[0][0]);
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) Ps[k][i][q] = H[k][i][q] + H[k][5][i] * Kk[k][0][q] + H[k][6][i] * Kk[k][1][q];
-        ps[k][i] = gk[k][i] + H[k][5][i] * kf[k][0] + H[k][6][i] * kf[k][1];
-      }
-    }
-    for (int k = N - 2; k >= 0; --k) {
-      double PA[5][5], PB[5][2], Pd[5];
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Ak[k][r][q]; PA[i][q] = s; }
-        for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Bk[k][r][q]; PB[i][q] = s; }
-        double s = ps[k + 1][i]; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * dk[k][r]; Pd[i] = s;
-      }
-      double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
-      for (int a = 0; a < 2; ++a) {
-        for (int b = 0; b < 2; ++b) { double s = H[k][5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PB[r][b]; Huu[a][b] = s; }
-        for (int q = 0; q < 5; ++q) { double s = H[k][5 + a][q]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PA[r][q]; Hux[a][q] = s; }
-        double s = gk[k][5 + a]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * Pd[r]; hu[a] = s;
-      }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) { double s = H[k][i][q]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * PA[r][q]; Hxx[i][q] = s; }
-        double s = gk[k][i]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * Pd[r]; hx[i] = s;
-      }
-      double rhs[2][6], sol[2][6];
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
-      if (!(Huu[0][0] > 0.0 && Huu[0][0] * Huu[1][1] - Huu[0][1] * Huu[1][0] > 0.0)) pd_ok = 0;
-      sym2_solve(Huu, &rhs[0][0], 6, &sol[0][0]);
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) Ps[k][i][q] = Hxx[i][q] + Hux[0][i] * Kk[k][0][q] + Hux[1][i] * Kk[k][1][q];
-        ps[k][i] = hx[i] + Hux[0][i] * kf[k][0] + Hux[1][i] * kf[k][1];
-      }
-      for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { double s = 0.5 * (Ps[k][i][q] + Ps[k][q][i]); Ps[k][i][q] = Ps[k][q][i] = s; }
-    }
+    if (!riccati_backward(N)) pd_ok = 0;
     if (use_whole && !pd_ok) { use_whole = 0; whole_skip = 2; continue; }
     break;
     }
     if (sp->row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
     /* ---- forward sweep: dp, new multipliers ------------------------------------------------ */
-    for (int i = 0; i < 5; ++i) dt_.p[0][i] = x0[i] - it.p[0][i];
-    for (int k = 0; k < N; ++k) {
-      for (int a = 0; a < 2; ++a) { double s = kf[k][a]; for (int q = 0; q < 5; ++q) s += Kk[k][a][q] * dt_.p[k][q]; dt_.p[k][5 + a] = s; }
-      if (k + 1 < N)
-        for (int i = 0; i < 5; ++i) {
-          double s = dk[k][i];
-          for (int q = 0; q < 5; ++q) s += Ak[k][i][q] * dt_.p[k][q];
-          for (int q = 0; q < 2; ++q) s += Bk[k][i][q] * dt_.p[k][5 + q];
-          dt_.p[k + 1][i] = s;
-        }
-    }
-    for (int i = 0; i < 5; ++i) { double s = ps[0][i]; for (int q = 0; q < 5; ++q) s += Ps[0][i][q] * dt_.p[0][q]; dt_.pi0[i] = -s - it.pi0[i]; }
-    for (int k = 0; k + 1 < N; ++k)
-      for (int i = 0; i < 5; ++i) { double s = ps[k + 1][i]; for (int q = 0; q < 5; ++q) s += Ps[k + 1][i][q] * dt_.p[k + 1][q]; dt_.pi[k][i] = s - it.pi[k][i]; }
+    riccati_forward(N, x0);
+    for (int i = 0; i < 5; ++i) dt_.pi0[i] = pi0new[i] - it.pi0[i];
+    for (int k = 0; k + 1 < N; ++k) for (int i = 0; i < 5; ++i) dt_.pi[k][i] = pinew[k][i] - it.pi[k][i];
     /* ---- slack / multiplier steps, fraction to the boundary ----------------------------------- */
     double a_pri = 1.0, a_dual = 1.0;
     for (int k = 0; k < N; ++k) {
@@ -726,6 +949,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       for (int j = 0; j < nb; ++j) {
         double ds = cj[k][j]; for (int a = 0; a < 3; ++a) ds += gra[k][j][a] * dt_.p[k][a];
         double S = it.zs[k][j] / it.sg[k][j] + sp->reg_primal;
+        ds = (ds + sp->reg_dual_rows * (mu / it.sg[k][j] + it.nuc[k][j])) / (1.0 + sp->reg_dual_rows * S);
         dt_.sg[k][j] = ds;
         dt_.nuc[k][j] = S * ds - mu / it.sg[k][j] - it.nuc[k][j];
         dt_.zs[k][j] = mu / it.sg[k][j] - it.zs[k][j] - it.zs[k][j] / it.sg[k][j] * ds;
@@ -770,7 +994,18 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       if (ok) { accepted = 1; break; }
       alpha *= 0.5;
     }
-    if (!accepted) { status = 2; break; }
+    if (!accepted) {
+      /* IPOPT's answer to a failed line search: the restoration phase, then on with fresh multipliers and an empty filter */
+      if (sp->resto > 0 && resto_calls < sp->resto && cviol > sp->constr_viol_tol) {
+        if (restore_and_resume(sp, x0, nbr, mu, &iter)) {
+          ++resto_calls;
+          nfilt = 0; stall_ref = INFINITY; stall_cnt = 0; stall_ws = 0; best_err = INFINITY; best_it = iter;
+          continue;
+        }
+        status = 5; break; /* the restoration failed: locally infeasible */
+      }
+      status = 2; break;
+    }
     if (!f_type) {
       if (nfilt == sp->filter_cap) { memmove(filt, filt + 1, sizeof(double) * 2 * (nfilt - 1)); nfilt--; }
       filt[nfilt][0] = (1.0 - sp->gamma_theta) * theta; filt[nfilt][1] = phi0 - sp->gamma_phi * theta; nfilt++;

@@ -27,7 +27,7 @@ def seed(table, k0, noise, N):
     return state, pred
 
 
-def replay(ospec: MpcSpec, table, k0, noise, steps, dt=0.1, wb=2.5, carry_duals=True):
+def replay(ospec: MpcSpec, table, k0, noise, steps, dt=0.1, wb=2.5, carry_duals=True, opt=None):
     """Generator: after every iteration yields (state [S,V,5], pred [S,V,7,N], status [S,V], iters [S,V])."""
     S, V, T, N = len(k0), table.shape[0], table.shape[1], ospec.N
     state, pred = seed(table, k0, noise, N)
@@ -41,7 +41,7 @@ def replay(ospec: MpcSpec, table, k0, noise, steps, dt=0.1, wb=2.5, carry_duals=
             for v in range(V):
                 nb = np.stack([pred[s, u][:3][:, adv] for u in range(V) if u != v]) if V > 1 else np.zeros((0, 3, N))
                 w = pred[s, v][:, adv]
-                r = port.solve(ospec, state[s, v], table[v, kr, :3].T, nb, w.T.copy(), carry=carry[s][v] if carry_duals else None)
+                r = port.solve(ospec, state[s, v], table[v, kr, :3].T, nb, w.T.copy(), **({} if opt is None else {"opt": opt}), carry=carry[s][v] if carry_duals else None)
                 carry[s][v] = r["carry"]
                 newp[s, v] = r["p"].T if r["status"] == 0 else w
                 state[s, v] = plant_step(state[s, v], newp[s, v][5:7, 0], dt, wb)

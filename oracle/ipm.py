@@ -77,6 +77,19 @@ class IpmOptions:
     max_backtrack: int = 25
     reg_primal: float = 1e-8
     reg_dual: float = 0.0
+    # IPOPT's dual regularisation delta_c (paper sec. 3.1: -delta_c I in the (2,2) block of the Newton system whenever the Jacobian may
+    # have lost rank), here permanently on the separation rows of a working-set NLP (`nlp.c_blk0`: first of those rows): two rows of a
+    # block, or rows of different blocks of a stage, become dependent at a contact and their multipliers run away along the null space.
+    reg_dual_rows: float = 1e-8
+    # Restoration phase (paper sec. 3.3) of NLPs that provide `restore` (oracle/mpc_nlp.py): at most `restoration` calls per solve,
+    # each after a failed line search at an iterate whose violation exceeds constr_viol_tol; the multipliers are kept unless they
+    # exceed IPOPT's constr_mult_reset_threshold.  A restoration that does not reach its goal ends the solve with status 5
+    # (IPOPT: "converged to a point of local infeasibility").  0 = no restoration phase (a failed line search is status 2).
+    restoration: int = 2
+    # A start whose separation rows are violated by more than this (metres; the warm start of a vehicle whose neighbour's prediction
+    # has moved into its path) goes through the restoration phase BEFORE the first iteration and starts with cold multipliers at the
+    # restored point: the interior-point iteration from half a metre inside a clearance is where the multipliers run away.  0 = never.
+    resto_first: float = 0.3
     hessian: str = "gn"  # "gn" (kernel's choice) or "exact" (needs nlp.hess_exact; planning NLPs)
     curv_kappa: float = 1e-8  # exact Hessian: inertia-free curvature test d'(W+Sigma)d >= kappa d'd
     # True: the whole (unsafeguarded) curvature of the separation rows is tried first and kept when the Newton system has the
@@ -141,7 +154,8 @@ def kkt_inertia_ok(H, J, n, m):
 
 
 STATUS_OK, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NAN = 0, 1, 2, 3
-STATUS_STALLED = 5  # constraint violation stopped decreasing above constr_viol_tol (4 is taken by mpc_nlp)
+STATUS_STALLED = 5  # constraint violation stopped decreasing above constr_viol_tol, or a restoration failed (4 is taken by mpc_nlp)
+RESTO_MULT_RESET = 1e3  # IPOPT's constr_mult_reset_threshold (oracle/mpc_nlp.py restore)
 
 
 def push_to_interior(x, xl, xu, opt: IpmOptions):
@@ -200,6 +214,9 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             return np.inf
         return nlp.f(xx) - mu_ * (np.log(dl[hasl]).sum() + np.log(du[hasu]).sum())
 
+    dual_reg = np.full(m, float(opt.reg_dual))
+    if opt.reg_dual_rows > 0.0 and hasattr(nlp, "c_blk0"):
+        dual_reg[nlp.c_blk0:] += opt.reg_dual_rows
     it = 0
     err0 = np.inf
     stagnant, best_err, best_it = False, np.inf, 0
@@ -207,8 +224,18 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
     shifted = False  # some stage's curvature was shifted in some iteration of this solve
     mu_forced = False
     whole_skip = 0  # iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
-    for it in range(opt.max_iter + 1):
-        if it > 0 and hasattr(nlp, "new_iterate"):  # working-set NLPs refresh their rows here
+    it0 = 0
+    resto_calls = 0
+    can_restore = opt.restoration > 0 and hasattr(nlp, "restore")
+    if can_restore and opt.resto_first > 0.0 and getattr(nlp, "start_viol", 0.0) > opt.resto_first:
+        ok, x, it0 = nlp.restore(x, mu, opt, 0)
+        if not ok:
+            return dict(X=x, nu=nu, zl=zl, zu=zu, status=STATUS_STALLED, iters=it0, mu=mu, err=np.inf, f=nlp.f(x), shifted=False)
+        x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)
+    it = it0 - 1
+    while it < opt.max_iter:
+        it += 1
+        if it > it0 and hasattr(nlp, "new_iterate"):  # working-set NLPs refresh their rows here
             x, zl, nu = nlp.new_iterate(x, zl, nu, mu, opt.bound_push)
         g = nlp.grad(x)
         c, J = nlp._cons_jac(x, True)
@@ -249,14 +276,14 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             break
         if it == opt.max_iter:
             break
-        if it == 0 or err0 < 0.5 * best_err:
+        if it == it0 or err0 < 0.5 * best_err:
             best_err, best_it = err0, it
         if opt.shift_stagnation > 0 and not stagnant and cviol <= opt.constr_viol_tol and it - best_it >= opt.shift_stagnation:
             stagnant = True
         if opt.err_stall_iters > 0 and it - best_it >= opt.err_stall_iters:
             status = STATUS_STALLED
             break
-        if it == 0 or cviol <= opt.stall_kappa * stall_ref:
+        if it == it0 or cviol <= opt.stall_kappa * stall_ref:
             stall_ref, stall_cnt, stall_ws = cviol, 0, 0
         elif not getattr(nlp, "ws_changed", False):
             stall_cnt += 1
@@ -296,7 +323,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                     shifted = shifted or bool(getattr(nlp, "shift_applied", False))
             else:
                 H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
-            K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
+            K = sp.bmat([[H, J.T], [J, -sp.diags(dual_reg)]], format="csc")
             sol = spla.splu(K).solve(rhs)
             dx, dnu = sol[:n], sol[n:]
         else:
@@ -307,7 +334,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             trial_delta = 0.0
             while True:
                 H = W + (trial_delta + opt.reg_primal) * sp.eye(n)
-                K = sp.bmat([[H, J.T], [J, -opt.reg_dual * sp.eye(m)]], format="csc")
+                K = sp.bmat([[H, J.T], [J, -sp.diags(dual_reg)]], format="csc")
                 sol = spla.splu(K).solve(rhs)
                 dx, dnu = sol[:n], sol[n:]
                 if float(dx @ (H @ dx)) >= opt.curv_kappa * float(dx @ dx) and np.isfinite(sol).all():
@@ -369,8 +396,24 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                 accepted = True
                 break
             alpha *= 0.5
+        if not accepted and can_restore and resto_calls < opt.restoration and cviol > opt.constr_viol_tol:
+            # IPOPT's answer to a failed line search: the restoration phase, then on with an empty filter.  The multipliers are kept
+            # (the working-set refresh of the next iteration hands them over from the entry's working set) unless they have run away.
+            sel_in = nlp.sel.copy()
+            ok, x, rit = nlp.restore(x, mu, opt, it)
+            it += rit
+            if not ok:
+                status = STATUS_STALLED
+                break
+            resto_calls += 1
+            if max(np.abs(nu).max(), zl.max(), zu.max()) > RESTO_MULT_RESET:
+                x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)
+            else:
+                nlp.sel[:] = sel_in
+            filt, stall_ref, stall_cnt, stall_ws, best_err, best_it = [], np.inf, 0, 0, np.inf, it
+            continue
         if not accepted:
-            # No restoration phase here.  The independent solvers of oracle/independent_*.py (`lower_mu_on_failure`) give up the
+            # No restoration phase for this NLP (or its calls are used up, or the iterate is feasible).  The independent solvers of oracle/independent_*.py (`lower_mu_on_failure`) give up the
             # barrier problem at hand instead: mu falls, the filter starts afresh, the iterate stays; a second failure in a row
             # (or mu at its floor) ends the solve.  The kernels' oracle path (default) reports status 2 at once, like the kernels.
             if opt.lower_mu_on_failure and mu > mu_floor and not mu_forced:

@@ -44,6 +44,16 @@ import scipy.sparse as sp
 from .dynamics import bicycle_rk4, bicycle_rk4_jac
 
 NP = 7  # x,y,psi,v,delta,a,w
+BCOLS = (0, 1, 3, 4, 5, 6)  # bounded columns of a stage: x y v delta a w
+# constants of the restoration phase (MpcNlp.restore; oracle/cfz_port.c and the kernel carry the same numbers)
+RESTO_RHO = 1000.0        # weight of a squared row violation
+RESTO_RHO_BOX = 1e5       # weight of a squared box excess
+RESTO_BOX_MARGIN = 2e-3   # the boxes are restored with this margin (half of it is kept on return)
+RESTO_MAX_ITER = 40
+RESTO_STALL = 8           # iterations without a drop of the worst violation by a tenth: stationary, locally infeasible
+RESTO_KAPPA = 0.1         # goal: a tenth of the violation at entry (IPOPT's required_infeasibility_reduction is 0.9)
+RESTO_ARMIJO = 1e-4
+RESTO_MULT_RESET = 1e3    # IPOPT's constr_mult_reset_threshold: multipliers above it are not kept after a restoration
 
 
 @dataclass
@@ -494,6 +504,140 @@ class MpcNlp:
                 Xs[k, NP + 2 * j + r], Z[k, NP + 2 * j + r], NU[k, 2 * j + r] = sg, z, nn
         return x, zl, nu
 
+
+    # ---- feasibility restoration (oracle/ipm.py calls it; oracle/cfz_port.c restore_run is the same iteration) ----------------
+    def start_violation(self, X):
+        """Worst violation dmin - sep of the rows of stages >= 1 at X (current working set)."""
+        P = np.asarray(X).reshape(self.spec.N, self.ns)
+        return float(max(0.0, (self.spec.dmin - self.blocks(P)[0][1:]).max()))
+
+    def _resto_objective(self, P, Pbar, sep, eps, zeta):
+        b = self.spec.bounds
+        phi = 0.5 * zeta * float(((P - Pbar) ** 2).sum())
+        for q, c in enumerate(BCOLS):
+            k0 = 1 if q < 4 else 0  # the states of stage 0 are the measurement
+            el = np.maximum(b[2 * q] + RESTO_BOX_MARGIN - P[k0:, c], 0.0)
+            eu = np.maximum(P[k0:, c] - b[2 * q + 1] + RESTO_BOX_MARGIN, 0.0)
+            phi += 0.5 * RESTO_RHO_BOX * float((el**2).sum() + (eu**2).sum())
+        v = np.maximum(self.spec.dmin + eps - sep[1:], 0.0)
+        return phi + 0.5 * RESTO_RHO * float((v**2).sum())
+
+    def restore(self, X, mu, opt, iters_done):
+        """IPOPT's restoration phase (paper sec. 3.3) for this NLP: Gauss-Newton / Levenberg-Marquardt on
+            min rho/2 sum_{k>=1,r} max(0, dmin + eps - sep_kr)^2 + rho_b/2 sum (box excess)^2 + zeta/2 |p - p_R|^2
+            s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
+        (zeta = sqrt(mu), p_R the poses and inputs at entry), Armijo line search on the l1 merit with the dynamics defects.
+        The step comes from the full KKT matrix here and from the stage recursion in oracle/cfz_port.c and the kernel.
+        Returns (ok, X_new, iterations): ok = every row of stages >= 1 within the goal (a tenth of the violation at entry, or
+        half the margin eps), every box with margin, dynamics no worse than at entry; otherwise the caller ends with status 5
+        (a stationary point of the violation: locally infeasible) and X is returned unchanged."""
+        import scipy.sparse.linalg as spla
+
+        sp_, N, ns = self.spec, self.spec.N, self.ns
+        b = sp_.bounds
+        Xs = np.asarray(X, float).reshape(N, ns).copy()
+        P = Xs[:, :NP].copy()
+        Pbar = P.copy()
+        zeta = float(np.sqrt(mu))
+        eta = lm = 0.0
+        vref, ref_it = np.inf, 0
+        sel_entry = self.sel.copy()
+        n, m = NP * N, 5 * N
+        rit = 0
+        while True:
+            if rit > 0:
+                self.select(P)
+            sep, gr = self.blocks(P)
+            F, Fz, Fu = bicycle_rk4_jac(P[:-1, 0:5], P[:-1, 5:7], sp_.dt, sp_.wb, sp_.rk_substeps)
+            c = np.concatenate([P[0, 0:5] - self.x0, (F - P[1:, 0:5]).ravel()])
+            th_dyn, cv_dyn = float(np.abs(c).sum()), float(np.abs(c).max())
+            if rit == 0:
+                v0 = float(max(0.0, (sp_.dmin - sep[1:]).max()))
+                eps = min(opt.bound_push, v0)
+                vgoal = max(0.5 * eps, RESTO_KAPPA * (v0 + eps))
+                dgoal = max(opt.constr_viol_tol, cv_dyn)
+            g = zeta * (P - Pbar)
+            H = np.zeros((N, NP, NP))
+            H[:, range(NP), range(NP)] = zeta + lm
+            bmax = 0.0
+            for q, col in enumerate(BCOLS):
+                k0 = 1 if q < 4 else 0
+                el = np.maximum(b[2 * q] + RESTO_BOX_MARGIN - P[:, col], 0.0)
+                eu = np.maximum(P[:, col] - b[2 * q + 1] + RESTO_BOX_MARGIN, 0.0)
+                el[:k0] = 0.0; eu[:k0] = 0.0
+                g[:, col] += RESTO_RHO_BOX * (eu - el)
+                H[:, col, col] += RESTO_RHO_BOX * ((el > 0.0).astype(float) + (eu > 0.0))
+                bmax = max(bmax, float(el.max()), float(eu.max()))
+            v = np.maximum(sp_.dmin + eps - sep, 0.0)
+            v[0] = 0.0
+            vmax = float(v.max())
+            g[:, 0:3] -= RESTO_RHO * np.einsum("kr,kra->ka", v, gr)
+            H[:, 0:3, 0:3] += RESTO_RHO * np.einsum("kr,kra,krb->kab", (v > 0.0).astype(float), gr, gr)
+            phi = self._resto_objective(P, Pbar, sep, eps, zeta)
+            if vmax <= vgoal and bmax <= 0.5 * RESTO_BOX_MARGIN and cv_dyn <= dgoal:
+                for q, col in enumerate(BCOLS):
+                    P[:, col] = np.minimum(np.maximum(P[:, col], b[2 * q] + 0.5 * RESTO_BOX_MARGIN), b[2 * q + 1] - 0.5 * RESTO_BOX_MARGIN)
+                Xs[:, :NP] = P
+                return True, Xs.ravel(), rit
+            if vmax <= 0.9 * vref or vmax <= vgoal:
+                vref, ref_it = vmax, rit
+            if rit - ref_it >= RESTO_STALL or rit == RESTO_MAX_ITER or iters_done + rit >= opt.max_iter:
+                break
+            # Newton step on [[H, J'], [J, 0]]: J = rows of the initial state and of the dynamics
+            rows, cols, vals = [np.arange(5)], [np.arange(5)], [np.ones(5)]
+            for k in range(N - 1):
+                r0 = 5 + 5 * k
+                for i in range(5):
+                    rows.append(np.full(7, r0 + i)); cols.append(NP * k + np.arange(7)); vals.append(np.concatenate([Fz[k, i], Fu[k, i]]))
+                    rows.append(np.array([r0 + i])); cols.append(np.array([NP * (k + 1) + i])); vals.append(np.array([-1.0]))
+            J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, n))
+            Hs = sp.block_diag([H[k] for k in range(N)], format="csr")
+            K = sp.bmat([[Hs, J.T], [J, None]], format="csc")
+            sol = spla.splu(K).solve(-np.concatenate([g.ravel(), c]))
+            d, pi = sol[:n].reshape(N, NP), sol[n:]
+            dphi = float((g * d).sum())
+            pim = float(np.abs(pi).max())
+            if eta < 1.1 * pim:
+                eta = 2.0 * pim
+            M0, dM = phi + eta * th_dyn, dphi - eta * th_dyn
+            if not (dM < -1e-10 * (1.0 + abs(M0))):
+                break
+            alpha, accepted = 1.0, False
+            for _ in range(opt.max_backtrack):
+                Pt = P + alpha * d
+                Ft = bicycle_rk4(Pt[:-1, 0:5], Pt[:-1, 5:7], sp_.dt, sp_.wb, sp_.rk_substeps)
+                th_t = float(np.abs(Pt[0, 0:5] - self.x0).sum() + np.abs(Ft - Pt[1:, 0:5]).sum())
+                M_t = self._resto_objective(Pt, Pbar, self.blocks(Pt)[0], eps, zeta) + eta * th_t  # working set held
+                if np.isfinite(M_t) and M_t <= M0 + RESTO_ARMIJO * alpha * dM:
+                    accepted = True
+                    break
+                alpha *= 0.5
+            if not accepted:
+                break
+            if alpha < 0.2:
+                lm = max(4.0 * lm, 1.0)
+            elif alpha == 1.0:
+                lm *= 0.25
+            P = Pt
+            rit += 1
+        self.sel[:] = sel_entry
+        return False, np.asarray(X, float).copy(), rit
+
+    def cold_multipliers(self, X, mu, opt):
+        """After a restoration: fresh working set, slacks from the rows (at least half of bound_push), z = mu / distance,
+        multipliers of the equality rows zero.  Returns (X, zl, zu, nu)."""
+        N, ns = self.spec.N, self.ns
+        Xs = np.asarray(X, float).reshape(N, ns).copy()
+        self.select(Xs)
+        Xs[:, NP:] = np.maximum(self.blocks(Xs)[0] - self.spec.dmin, 0.5 * opt.bound_push)
+        x = Xs.ravel()
+        hasl, hasu = np.isfinite(self.xl), np.isfinite(self.xu)
+        zl = np.where(hasl, mu / np.where(hasl, x - np.where(hasl, self.xl, 0.0), 1.0), 0.0)
+        zu = np.where(hasu, mu / np.where(hasu, np.where(hasu, self.xu, 0.0) - x, 1.0), 0.0)
+        nu = np.zeros(self.m)
+        nu[self.c_blk0:] = -zl.reshape(N, ns)[:, NP:].ravel()
+        return x, zl, zu, nu
+
     # ---- packing between reference layout and X ------------------------------------
     def pack(self, sol):
         """Reference-layout dict -> X.  Only the primal arrays are read; warm-start duals are
@@ -727,6 +871,12 @@ def initial_state_in_collision(nlp: "MpcNlp", tol):
         sep, _ = rows_for(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, sel)
         if sep.min() < sp_.dmin - 2.0 * tol:
             return True
+    # ... and so does a measured state outside the boxes on x, y, v, delta by more than tol (stage 0 is bounded like every other
+    # stage, :205-240, and pinned to the measurement, :194-199): e.g. a speed above the limit by the measurement noise
+    b = sp_.bounds
+    for q, c in enumerate((0, 1, 3, 4)):
+        if nlp.x0[c] < b[2 * q] - tol or nlp.x0[c] > b[2 * q + 1] + tol:
+            return True
     return False
 
 
@@ -806,6 +956,7 @@ def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None, carry=None)
         return dict(zu=zu.copy(), status=STATUS_INFEASIBLE_X0, iters=0, f=0.0, sep=None, sol=None, carry=None)
     warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
     X0 = nlp.pack(warm)
+    nlp.start_viol = nlp.start_violation(X0)  # read by ipm.solve (resto_first): the rows at the un-pushed start
     if carry is None:
         res = ipm.solve(nlp, X0, opt, trace=trace)
     else:
