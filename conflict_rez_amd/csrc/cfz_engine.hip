@@ -597,7 +597,8 @@ void cfz_default_options(cfz_options *o) {
   o->bound_push = 1e-2; o->bound_frac = 1e-2; o->s_max = 100.0; o->kappa_sigma = 1e10;
   o->eta_phi = 1e-8; o->gamma_theta = 1e-5; o->gamma_phi = 1e-8; o->delta_sw = 1.0; o->s_theta = 1.1; o->s_phi = 2.3;
   o->reg_primal = 1e-8;
-  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1; o->carry_duals = 1; o->vv_rows = 1; o->shift_after = 60; o->whole_curvature_first = 0; o->shift_stagnation = 10; o->err_stall_iters = 150; o->carry_shift = 1; o->warm_push = 1e-6;
+  o->stall_iters = 10; o->stall_kappa = 0.9; o->row_curvature = 1; o->carry_duals = 1; o->vv_rows = 1; o->shift_after = 60; o->restoration = 2; o->shift_stagnation = 10; o->err_stall_iters = 150; o->carry_shift = 1; o->warm_push = 1e-6;
+  o->reg_dual_rows = 1e-8; o->resto_first = 0.3;
 }
 
 int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max_batch, cfz_handle **out) {
@@ -610,8 +611,7 @@ int cfz_create(const cfz_spec *spec, const cfz_options *opt, int device, int max
   if (spec->N > cfz::kMaxN) return fail("N exceeds the four-lanes-per-stage kernel");
   if (max_batch < 1) return fail("max_batch must be positive");
   if (opt->filter_cap < 1 || opt->filter_cap > 32) return fail("filter_cap must be in 1..32");
-  if (opt->whole_curvature_first && !cfz::kWholeSwitch)
-    return fail("whole_curvature_first: an experiment switch that is not compiled into this library (build with -DCFZ_WHOLE_FIRST)");
+  if (opt->restoration < 0 || !(opt->reg_dual_rows >= 0.0) || !(opt->resto_first >= 0.0)) return fail("restoration, reg_dual_rows, resto_first must not be negative");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (ndev == 0) return fail("no HIP device: libconfrez_hip has no CPU path");
@@ -647,7 +647,7 @@ int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
   k.bound_frac = opt->bound_frac; k.s_max = opt->s_max; k.kappa_sigma = opt->kappa_sigma; k.eta_phi = opt->eta_phi;
   k.gamma_theta = opt->gamma_theta; k.gamma_phi = opt->gamma_phi; k.delta_sw = opt->delta_sw;
   k.s_theta = opt->s_theta; k.s_phi = opt->s_phi; k.reg_primal = opt->reg_primal;
-  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature; k.vv_rows = opt->vv_rows; k.shift_after = opt->shift_after; k.whole_first = opt->whole_curvature_first; k.stag_win = opt->shift_stagnation; k.err_stall = opt->err_stall_iters; k.carry_shift = opt->carry_shift ? 1 : 0; k.pad_ks = 0; k.warm_push = opt->warm_push;
+  k.stall_iters = opt->stall_iters; k.stall_kappa = opt->stall_kappa; k.row_curvature = opt->row_curvature; k.vv_rows = opt->vv_rows; k.shift_after = opt->shift_after; k.resto = opt->restoration; k.stag_win = opt->shift_stagnation; k.err_stall = opt->err_stall_iters; k.carry_shift = opt->carry_shift ? 1 : 0; k.pad_ks = 0; k.warm_push = opt->warm_push; k.reg_dual_rows = opt->reg_dual_rows; k.resto_first = opt->resto_first;
   h->lay = cfz::make_layout(k.N, k.n_obs + k.n_nbr, k.n_nbr);
   h->lds_bytes = (size_t)h->lay.total * sizeof(double);
   if (const char *pad = std::getenv("CFZ_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(pad);  // occupancy experiments only

@@ -101,14 +101,16 @@ struct KSpec {
                                  // stag_win: iterations without a halving of the error, at a feasible iterate, after which the late shift may start
                                  // at iteration kShiftStagMin already (0: never; oracle/ipm.py shift_stagnation)
   int carry_shift, pad_ks;       // carry_shift: a converged solve that shifted some stage tells its successor to shift from the start (oracle/ipm.py)
-  int shift_after, whole_first;  // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
-                                 // whole_first: the whole row curvature is tried first and kept when every stage's Huu is positive definite
+  int shift_after, resto;        // shift_after: iteration from which a stage whose row curvature would be scaled is shifted instead (0: never)
+                                 // resto: restoration phases a solve may go through (0: none; oracle/ipm.py restoration)
   double dt, wb, dmin;
   double g[4], bounds[12], weights[6];
   double A_obs[kMaxObs][4][2], b_obs[kMaxObs][4], V_obs[kMaxObs][4][2];
   double tol, constr_viol_tol, dual_inf_tol, compl_inf_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min,
       bound_push, bound_frac, s_max, kappa_sigma, eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi,
-      reg_primal, stall_kappa, warm_push;
+      reg_primal, stall_kappa, warm_push,
+      reg_dual_rows,  // IPOPT's dual regularisation delta_c on the separation rows (oracle/ipm.py reg_dual_rows)
+      resto_first;    // a start whose rows are violated by more than this goes through the restoration phase first (0: never)
   // static obstacles as the kernel reads them, n_obs x 20 doubles in global memory: A[4][2], b[4], V[4][2]
   // (L1/L2-resident; indexing the arrays above with a lane-varying j would copy this struct to scratch)
   const double *obs_tab;
@@ -373,16 +375,9 @@ CFZ_CALL void rk4_step_h(const double z[5], double a, double w, double h, double
 // in the other's normal cone; no face normal certifies their distance, so the row is the Euclidean distance |W_v - V_u| itself,
 // imposed twice (the block keeps its two slots: twice the barrier weight, same optimum): sel = 192 + u*16 + v*4 + v.
 constexpr double kHyst = 1e-3;  // m: a block keeps its face until another is better by this much
-// The experiment switch `whole_curvature_first` (docs/notebook.md round 3) costs the GPU kernel registers and a test per stage on
-// its serial lane whether it is on or off: compiled in for the CPU builds of this source (tests) and with -DCFZ_WHOLE_FIRST only.
-#if !defined(__HIPCC__) || defined(CFZ_WHOLE_FIRST)
-constexpr bool kWholeSwitch = true;
-#else
-constexpr bool kWholeSwitch = false;
-#endif
 constexpr double kVvInert = 1.0;  // m: margin of the second slot of a vertex-vertex block in the planning kernels (rows_for)
-constexpr int kWsStallDiv = 4;
-constexpr int kShiftStagMin = 40;  // earliest iteration of a stagnation-triggered curvature shift (KSpec::stag_win)  // iterates that change the working set count 1 / kWsStallDiv towards the stall test
+constexpr int kWsStallDiv = 4;     // iterates that change the working set count 1 / kWsStallDiv towards the stall test
+constexpr int kShiftStagMin = 40;  // earliest iteration of a stagnation-triggered curvature shift (KSpec::stag_win)
 
 template <bool GRAD>
 CFZ_FN void vertex_dist(const double A[4][2], const double b[4], const double V[4][2], double x, double y,
@@ -930,10 +925,8 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
 // backward sweep: gains K_k (12 per stage) into kk, value function of stage 0 into rP (25) and rP + 25 (5).
 // P is kept as its upper triangle.  With W = B'P:  Hux = W A,  Huu = R + W B,  hu = g_u + B'(p + P d);  M = P A,
 // Hxx = Q + A'M (upper triangle only);  K = -Huu^-1 [Hux hu];  P <- Hxx - Hux' Huu^-1 Hux,  p <- hx - Hux' Huu^-1 hu.
-// rP[30] = 1 if every stage's Huu is positive definite (the Newton system then has the inertia of a minimisation), else 0.
 CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
   CFZ_SWEEP_GUARD
-  double pd_ok = 1.0;
   // upper triangle of P: P00 P01 P02 P03 P04 | P11 P12 P13 P14 | P22 P23 P24 | P33 P34 | P44
   double P00, P01, P02, P03 = 0.0, P04 = 0.0, P11, P12, P13 = 0.0, P14 = 0.0, P22, P23 = 0.0, P24 = 0.0, P33, P34 = 0.0, P44;
   double p0, p1, p2, p3, p4;
@@ -942,7 +935,6 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const wsp_f64 *h = m + o_hc + k * 11, *gk = m + o_gk + k * kNP;
     wsp_f64 *K = m + o_kk + k * 12;
     const double h10 = h[10], h6 = h[6];
-    if (kWholeSwitch && !(h[5] > 0.0 && h[5] * h6 > 0.0)) pd_ok = 0.0;
     const double k53 = -h10 / h6, k10 = -gk[5] / h[5], k11 = -gk[6] / h6;
     P00 = h[0]; P11 = h[1]; P22 = h[2]; P33 = h[3] + h10 * k53; P44 = h[4];
     P01 = h[7]; P02 = h[8]; P12 = h[9];
@@ -1019,7 +1011,6 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
     const double H33 = M33 + s01 * M03 + s11 * M13 + s21 * M23 + hc_[3], H34 = M34 + s01 * M04 + s11 * M14 + s21 * M24;
     const double H44 = M44 + s02 * M04 + s12 * M14 + s22 * M24 + hc_[4];
     (void)M43;
-    if (kWholeSwitch && !(a00 > 0.0 && a00 * a11 - a01 * a01 > 0.0)) pd_ok = 0.0;
     const double idet = 1.0 / (a00 * a11 - a01 * a01);
     const double i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
     // t = Huu^-1 [Hux hu]
@@ -1059,7 +1050,6 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
   rP[15] = P03; rP[16] = P13; rP[17] = P23; rP[18] = P33; rP[19] = P34;
   rP[20] = P04; rP[21] = P14; rP[22] = P24; rP[23] = P34; rP[24] = P44;
   rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
-  if (kWholeSwitch) rP[30] = pd_ok;
 }
 
 // ------------------------------------------------------------------------------ forward step and costates as scans
@@ -1256,6 +1246,272 @@ static void costate_scan(double *m, int N, int o_ab, int o_hc, int o_gk, int o_k
 }
 #endif
 
+#if defined(CFZ_NO_DELTAC)  // diagnostic builds: what the dual regularisation costs the hot loop
+#define kDeltaC(sp) 0.0
+#else
+#define kDeltaC(sp) (sp).reg_dual_rows
+#endif
+// ------------------------------------------------------------------------------ feasibility restoration
+// IPOPT answers a failed line search with its restoration phase (paper sec. 3.3).  Here (oracle/mpc_nlp.py MpcNlp.restore, oracle/cfz_port.c
+// restore): Levenberg-Marquardt on the squared violations of the separation rows of stages >= 1 and of the boxes,
+//     min  rho / 2 sum max(0, dmin + eps - sep_kr)^2  +  rho_b / 2 sum (excess over the boxes shrunk by m_b)^2     s.t. z_0 = x0, dynamics
+// on the solver's own stage recursion (H_k = (zeta + lambda) I + rho sum a a' over the violated rows + rho_b on the violated boxes,
+// zeta = sqrt(mu)), Armijo line search on the l1 merit (objective + eta |dynamics defects|_1), working set refreshed at every iterate
+// and held inside a line search.  Cold code: a function of its own (registers and instructions of its own), called by every lane.
+constexpr double kRestoRho = 1000.0, kRestoRhoBox = 1e5, kRestoBoxMargin = 2e-3, kRestoKappa = 0.1, kRestoArmijo = 1e-4;
+constexpr int kRestoMaxIter = 40, kRestoStall = 8;
+
+// lane partials at p + alpha dp with the working set held: th |dynamics defects|_1, ph objective
+CFZ_CALL void resto_partials(const KSpec &sp, const KDer &dv, double *m, const Lay &L, double alpha, double eps, int tid, double &th_o,
+                             double &ph_o) {
+  const int N = sp.N, nb = L.nb;
+  const int k = tid >> 2, sub = tid & 3;
+  double th = 0.0, ph = 0.0;
+  if (k < N) {
+    double pt[kNP];
+    for (int i = 0; i < kNP; ++i) pt[i] = m[L.p + k * kNP + i] + alpha * m[L.dp + k * kNP + i];
+    if (k >= 1) {
+      double sn, cn;
+      sincos(pt[2], &sn, &cn);
+      for (int j = sub; j < nb; j += kLPS) {
+        double sep[2];
+        block_sep(sp, m, L, k, j, sel_ptr(m, L)[k * nb + j], pt[0], pt[1], cn, sn, sep);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const double v = sp.dmin + eps - sep[r]; if (v > 0.0) ph += 0.5 * kRestoRho * v * v; }
+      }
+    }
+    if (sub == 0) {
+      for (int q = (k == 0 ? 4 : 0); q < 6; ++q) {
+        const double el = sp.bounds[2 * q] + kRestoBoxMargin - pt[bcol(q)], eu = pt[bcol(q)] - sp.bounds[2 * q + 1] + kRestoBoxMargin;
+        if (el > 0.0) ph += 0.5 * kRestoRhoBox * el * el;
+        if (eu > 0.0) ph += 0.5 * kRestoRhoBox * eu * eu;
+      }
+      if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
+      if (k + 1 < N) {
+        double F[5];
+        rk4_step_h<false>(pt, pt[5], pt[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, F, nullptr);
+        for (int i = 0; i < 5; ++i) th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
+      }
+    }
+  }
+  th_o = th; ph_o = ph;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZ_COLD __device__ __attribute__((noinline, cold))
+#else
+#define CFZ_COLD static
+#endif
+// Returns the solve's iteration counter after the restoration, +1, negated if the restoration failed: positive when the iterate in L.p has
+// been restored (rows of stages >= 1 within the goal, boxes with margin, dynamics no worse than at entry; clipped half the margin inside
+// the boxes), negative when the restoration stalls, fails a line search or reaches its iteration limit (the caller ends with status 5:
+// locally infeasible).  Uses the row-residual array L.cj for the row values; slacks and multipliers are not touched (the caller
+// re-initialises them).  Everything goes in and out by value: a counter of the solver's hot loop whose address is taken lives in scratch.
+// The parity of the reduction exchange (xpar) is 0 at entry and at exit: the caller's is parked while this runs (an even number of
+// reductions is not guaranteed here, so the function realigns with one barrier at its end).
+CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, double *m, const Lay &L, double mu, int iter) {
+  const int N = sp.N, nb = L.nb, nr = L.nr;
+  int xpar = 0;
+  (void)xpar;
+  CFZ_PART(rd, 6);
+  CFZ_PART(qx, 15);
+  double ro[6];
+  const double zeta = CFZ_UNIFORM(sqrt(mu));
+  double eta = 0.0, eps = 0.0, lm = 0.0, vgoal = 0.0, vref = INFINITY, dgoal = 0.0;
+  int ref_it = 0;
+  for (int rit = 0;; ++rit) {
+    // ---- working set (refreshed from the second iteration on), row values into L.cj, dynamics with sensitivities --------------
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      double cmax = 0.0, csum = 0.0, v0 = 0.0;
+      if (k < N) {
+        const double *pk = m + L.p + k * kNP;
+        const double x = pk[0], y = pk[1];
+        double sn, cn;
+        sincos(pk[2], &sn, &cn);
+        if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+        for (int j = sub; j < nb; j += kLPS) {
+          const int t = k * nb + j;
+          double sep[2];
+          const int c0 = sel_ptr(m, L)[t];
+          if (rit > 0) {
+            double A[4][2], b[4], V[4][2];
+            block_polygon(sp, m, L, k, j, A, b, V);
+            const int c1 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, c0, sep, sp.vv_rows);
+            if (c1 != c0) sel_ptr(m, L)[t] = c1;
+          } else {
+            block_sep(sp, m, L, k, j, c0, x, y, cn, sn, sep);
+          }
+          m[L.cj + 2 * t] = sep[0]; m[L.cj + 2 * t + 1] = sep[1];
+          if (k >= 1) v0 = fmax(v0, sp.dmin - fmin(sep[0], sep[1]));
+        }
+        if (tid == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
+        if (k + 1 < N) {
+          double F[5], Sa[3], Sb[3];
+          rk4_sens2(pk, pk[5], pk[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
+          for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
+          if (sub == 0) {
+            for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
+            for (int i = 0; i < 5; ++i) {
+              const double d = F[i] - m[L.p + (k + 1) * kNP + i];
+              m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
+            }
+          }
+        }
+      }
+      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = v0;
+    CFZ_END
+    CFZ_REDUCE(1, 2, 0, rd, ro);
+    const double th_dyn = ro[0], cv_dyn = ro[1];
+    if (rit == 0) {  // the margin the rows are restored with: bound_push, but no more than the worst violation at entry
+      eps = CFZ_UNIFORM(fmin(sp.bound_push, ro[2]));
+      vgoal = CFZ_UNIFORM(fmax(0.5 * eps, kRestoKappa * (ro[2] + eps)));
+      dgoal = CFZ_UNIFORM(fmax(sp.constr_viol_tol, cv_dyn));  // dynamics: no worse than at entry
+    }
+    // ---- stage problems: H_k = (zeta + lambda) I + rho sum a a' (violated rows) + rho_b (violated boxes), g_k the gradient ----
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      double ac[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9
+      double vmax = 0.0, bmax = 0.0, phi = 0.0;
+      if (k >= 1 && k < N) {
+        const double *pk = m + L.p + k * kNP;
+        const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
+        for (int jb = sub; jb < nb; jb += kLPS) {
+          double a0, a1, bap[2];
+          block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cpsi, spsi, a0, a1, bap);
+          for (int r_ = 0; r_ < 2; ++r_) {
+            const double v = sp.dmin + eps - m[L.cj + k * nr + 2 * jb + r_];
+            if (v > 0.0) {
+              const double a2 = bap[r_], w = kRestoRho * v;
+              vmax = fmax(vmax, v); phi += 0.5 * w * v;
+              ac[0] -= w * a0; ac[1] -= w * a1; ac[2] -= w * a2;
+              ac[3] += kRestoRho * a0 * a0; ac[4] += kRestoRho * a1 * a1; ac[5] += kRestoRho * a2 * a2;
+              ac[6] += kRestoRho * a0 * a1; ac[7] += kRestoRho * a0 * a2; ac[8] += kRestoRho * a1 * a2;
+            }
+          }
+        }
+      }
+      for (int i = 0; i < 9; ++i) CFZ_P(qx, i) = ac[i];
+      CFZ_P(rd, 0) = phi; CFZ_P(rd, 1) = vmax; CFZ_P(rd, 2) = bmax;
+    CFZ_MID
+      const int k = tid >> 2, sub = tid & 3;
+      double phi = CFZ_P(rd, 0), bmax = 0.0;
+      if (k < N) {
+        const double *pk = m + L.p + k * kNP;
+        double g[kNP], h[11];
+        for (int i = 0; i < kNP; ++i) { g[i] = 0.0; h[i] = zeta + lm; }
+        h[7] = 0.0; h[8] = 0.0; h[9] = 0.0; h[10] = 0.0;
+        for (int q = (k == 0 ? 4 : 0); q < 6; ++q) {  // the states of stage 0 are the measurement: nothing to restore there
+          const int c = bcol(q);
+          const double el = sp.bounds[2 * q] + kRestoBoxMargin - pk[c], eu = pk[c] - sp.bounds[2 * q + 1] + kRestoBoxMargin;
+          if (el > 0.0) { g[c] -= kRestoRhoBox * el; h[c] += kRestoRhoBox; bmax = fmax(bmax, el); if (sub == 0) phi += 0.5 * kRestoRhoBox * el * el; }
+          if (eu > 0.0) { g[c] += kRestoRhoBox * eu; h[c] += kRestoRhoBox; bmax = fmax(bmax, eu); if (sub == 0) phi += 0.5 * kRestoRhoBox * eu * eu; }
+        }
+        g[0] += CFZ_QSUM(qx, 0); g[1] += CFZ_QSUM(qx, 1); g[2] += CFZ_QSUM(qx, 2);
+        h[0] += CFZ_QSUM(qx, 3); h[1] += CFZ_QSUM(qx, 4); h[2] += CFZ_QSUM(qx, 5);
+        h[7] += CFZ_QSUM(qx, 6); h[8] += CFZ_QSUM(qx, 7); h[9] += CFZ_QSUM(qx, 8);
+        if (sub == 0) {
+          for (int i = 0; i < 11; ++i) m[L.hc + k * 11 + i] = h[i];
+          for (int i = 0; i < kNP; ++i) m[L.gk + k * kNP + i] = g[i];
+        }
+      }
+      CFZ_P(rd, 0) = phi; CFZ_P(rd, 2) = bmax;
+    CFZ_END
+    CFZ_REDUCE(1, 2, 0, rd, ro);
+    const double phi = ro[0], vmax = ro[1], bmax = ro[2];
+    if (vmax <= vgoal && bmax <= 0.5 * kRestoBoxMargin && cv_dyn <= dgoal) {
+      CFZ_LANES(tid)
+        const int k = tid >> 2;
+        if (k < N && (tid & 3) == 0)
+          for (int q = 0; q < 6; ++q) {
+            const int c = bcol(q);
+            m[L.p + k * kNP + c] = fmin(fmax(m[L.p + k * kNP + c], sp.bounds[2 * q] + 0.5 * kRestoBoxMargin), sp.bounds[2 * q + 1] - 0.5 * kRestoBoxMargin);
+          }
+      CFZ_END
+      return iter + 1;
+    }
+    // stalled: the worst violation has not dropped by a tenth in kRestoStall iterations -> a stationary point of the violation
+    if (vmax <= 0.9 * vref || vmax <= vgoal) { vref = vmax; ref_it = rit; }
+    if (rit - ref_it >= kRestoStall) { CFZ_SYNC(); return -(iter + 1); }
+    if (rit == kRestoMaxIter || iter >= sp.max_iter) { CFZ_SYNC(); return -(iter + 1); }
+    // ---- step: the solver's sweeps.  The scans return dpi = pi_new - pi: the multipliers of the equality rows are taken as zero ----
+    CFZ_LANES(tid)
+      if (tid < 5) m[L.pi0 + tid] = 0.0;
+      for (int i = tid; i < N * 5; i += kNL) m[L.pi + i] = 0.0;
+    CFZ_END
+    CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
+    CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
+    CFZ_WAVE0(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
+    CFZ_LANES(tid)
+      const int k = tid >> 2, sub = tid & 3;
+      double dphi = 0.0, pim = 0.0;
+      if (k < N && sub == 0) {
+        for (int i = 0; i < kNP; ++i) dphi += m[L.gk + k * kNP + i] * m[L.dp + k * kNP + i];
+        if (k + 1 < N) for (int i = 0; i < 5; ++i) pim = fmax(pim, fabs(m[L.dpi + k * 5 + i]));
+        if (k == 0) for (int i = 0; i < 5; ++i) pim = fmax(pim, fabs(m[L.dpi0 + i]));
+      }
+      CFZ_P(rd, 0) = dphi; CFZ_P(rd, 1) = pim;
+    CFZ_END
+    CFZ_REDUCE(1, 1, 0, rd, ro);
+    const double dphi = ro[0], pim = ro[1];
+    if (eta < 1.1 * pim) eta = CFZ_UNIFORM(2.0 * pim);
+    const double M0 = CFZ_UNIFORM(phi + eta * th_dyn), dM = CFZ_UNIFORM(dphi - eta * th_dyn);
+    if (!(dM < -1e-10 * (1.0 + fabs(M0)))) { CFZ_SYNC(); return -(iter + 1); }  // stationary with rows still violated
+    double alpha = 1.0;
+    int accepted = 0;
+    for (int bt = 0; bt < sp.max_backtrack; ++bt) {
+      CFZ_LANES(tid)
+        double th_, ph_;
+        resto_partials(sp, dv, m, L, alpha, eps, tid, th_, ph_);
+        CFZ_P(rd, 0) = th_; CFZ_P(rd, 1) = ph_;
+      CFZ_END
+      CFZ_REDUCE(2, 0, 0, rd, ro);
+      const double M_t = CFZ_UNIFORM(ro[1] + eta * ro[0]);
+      if (isfinite(M_t) && M_t <= M0 + kRestoArmijo * alpha * dM) { accepted = 1; break; }
+      alpha = CFZ_UNIFORM(alpha * 0.5);
+    }
+    if (!accepted) { CFZ_SYNC(); return -(iter + 1); }
+    if (alpha < 0.2) lm = fmax(4.0 * lm, 1.0); else if (alpha == 1.0) lm *= 0.25;
+    CFZ_LANES(tid)
+      const int k = tid >> 2;
+      if (k < N && (tid & 3) == 0) for (int i = 0; i < kNP; ++i) m[L.p + k * kNP + i] += alpha * m[L.dp + k * kNP + i];
+    CFZ_END
+    ++iter;
+  }
+}
+
+// Cold multipliers at the point in L.p (after a restoration; IPOPT resets its bound multipliers there and recomputes the others): fresh
+// working set, slacks from the rows (at least half of bound_push), z = mu / distance, the equality rows at zero.
+CFZ_COLD void cold_multipliers(const KSpec &sp, double *m, const Lay &L, double mu) {
+  const int N = sp.N, nb = L.nb;
+  CFZ_LANES(tid)
+    const int k = tid >> 2, sub = tid & 3;
+    if (k < N) {
+      const double *pk = m + L.p + k * kNP;
+      double sn, cn;
+      sincos(pk[2], &sn, &cn);
+      for (int j = sub; j < nb; j += kLPS) {
+        const int t = k * nb + j;
+        double A[4][2], b[4], V[4][2], sep[2];
+        block_polygon(sp, m, L, k, j, A, b, V);
+        sel_ptr(m, L)[t] = select_rows_sep(A, b, V, pk[0], pk[1], cn, sn, sp.g, sel_ptr(m, L)[t], sep, sp.vv_rows);
+        for (int r = 0; r < 2; ++r) {
+          const double sg = fmax(sep[r] - sp.dmin, 0.5 * sp.bound_push), z = mu / sg;
+          m[L.sg + 2 * t + r] = sg; m[L.zs + 2 * t + r] = z; m[L.nuc + 2 * t + r] = -z;
+        }
+      }
+      if (sub == 0) {
+        for (int q = 0; q < 6; ++q) {
+          m[L.zl + k * 6 + q] = mu / (pk[bcol(q)] - sp.bounds[2 * q]);
+          m[L.zu + k * 6 + q] = mu / (sp.bounds[2 * q + 1] - pk[bcol(q)]);
+        }
+        if (k + 1 < N) for (int i = 0; i < 5; ++i) m[L.pi + k * 5 + i] = 0.0;
+      }
+    }
+    if (tid < 5) m[L.pi0 + tid] = 0.0;
+  CFZ_END
+}
+
 // ------------------------------------------------------------------------------ the solver
 // x0[5], ref[3][N], nbr[n_nbr][3][N], zu[7][N] (warm start in, solution out) in global memory;
 // m = this instance's workspace (LDS on the device).  out: iters,status ; cost,err,min_sep.
@@ -1326,7 +1582,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_END
   CFZ_REDUCE(0, 0, 1, rd, ro);
   const CarryLay CL = carry_layout(N, nb);
-  if (ro[0] < sp.dmin - 2.0 * sp.constr_viol_tol) {
+  // ... and so is a measured state outside the boxes on x, y, v, delta by more than constr_viol_tol (stage 0 is bounded like every
+  // other stage, vehicle_follower.py:205-240, and pinned to the measurement, :194-199)
+  bool x0_out = false;
+  for (int q = 0; q < 4; ++q) {
+    const double v = CFZ_UNIFORM(m[L.x0 + bcol(q)]);
+    x0_out = x0_out || v < sp.bounds[2 * q] - sp.constr_viol_tol || v > sp.bounds[2 * q + 1] + sp.constr_viol_tol;
+  }
+  if (ro[0] < sp.dmin - 2.0 * sp.constr_viol_tol || x0_out) {
     out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = ro[0];
     if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
     return;
@@ -1373,6 +1636,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       }
     }
   CFZ_END
+#if defined(CFZ_NO_RESTO)  // diagnostic builds: what the restoration phase's presence costs the hot loop
+  const bool resto_on = false;
+#else
+  const bool resto_on = sp.resto > 0 && L.nr > 0;
+#endif
   CFZ_LANES(tid)
     const int k = tid >> 2, sub = tid & 3;
     if (k < N && sub == 0) {
@@ -1403,16 +1671,22 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   double mu = mu0, filt_mu = -1.0, theta_min = -1.0, theta_max = -1.0, err0 = INFINITY, fval_last = 0.0;
   CFZ_STAMP_DECL
   CFZ_STAMP(0);  // setup
-  int nfilt = 0, status = 1, iter = 0;
-  int whole_skip = 0;  // iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
+  int nfilt = 0, status = 1, iter = 0;  // (iter is set before the loop below)
   int stagnant = 0, best_it = 0;  // the error has not halved for stag_win iterations at a feasible iterate (sticky)
   double best_err = INFINITY;
 
-  for (iter = 0; iter <= sp.max_iter; ++iter) {
-    // ---- working set refresh (iter > 0), rows and dynamics at the current point --------------
+  int iter0 = 0, resto_calls = 0;
+  bool first_checked = false;
+  // The restoration phase is called from OUTSIDE the iteration loop: the loop leaves with `want_resto` set, the phase runs, the loop is
+  // entered again.  (Called from inside, the two call sites cost the hot loop three times its scratch traffic: every value the
+  // register allocator keeps across a call site needs a callee-saved register or a spill slot -- measured 7 % of the throughput.)
+  for (;;) {
+  int want_resto = 0;  // 1: before the first iteration (resto_first), 2: after a failed line search
+  for (; iter <= sp.max_iter; ++iter) {
+    // ---- working set refresh (iter > iter0), rows and dynamics at the current point --------------
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
-      double cmax = 0.0, csum = 0.0, chg = 0.0;  // chg: a block of this lane changed its working set
+      double cmax = 0.0, csum = 0.0, chg = 0.0, v0 = 0.0;  // chg: a block of this lane changed its working set; v0: worst row violation of stages >= 1
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
         const double x = pk[0], y = pk[1];
@@ -1423,7 +1697,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           const int t = k * nb + j;
           double sep[2];
           int c1 = sel_ptr(m, L)[t];
-          if (iter > 0) {
+          if (iter > iter0) {
             const int c0 = c1;
             double A[4][2], b[4], V[4][2];
             block_polygon(sp, m, L, k, j, A, b, V);
@@ -1459,6 +1733,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             m[L.cj + 2 * t + r] = c;
             cmax = fmax(cmax, fabs(c)); csum += fabs(c);
           }
+          if (k >= 1) v0 = fmax(v0, sp.dmin - fmin(sep[0], sep[1]));
         }
         if (tid == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
         if (k + 1 < N) {
@@ -1475,12 +1750,19 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
         }
       }
-      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = chg;
+      CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = chg; CFZ_P(rd, 3) = v0;
     CFZ_END
-    CFZ_REDUCE(1, 2, 0, rd, ro);
+    CFZ_REDUCE(1, 3, 0, rd, ro);
     const double theta = ro[0], cviol = ro[1];
     const bool ws_changed = ro[2] != 0.0;
     CFZ_STAMP(1);  // working set, rows, dynamics
+    // A start whose rows are violated by more than resto_first (a neighbour's prediction has moved into the path) goes through the
+    // restoration phase first and starts again from the restored point with cold multipliers; a restoration that fails ends the solve
+    // with status 5 (IPOPT: "converged to a point of local infeasibility")
+    if (!first_checked) {
+      first_checked = true;
+      if (resto_on && sp.resto_first > 0.0 && ro[3] > sp.resto_first) { want_resto = 1; break; }
+    }
     if (theta_min < 0.0) { theta_min = CFZ_UNIFORM(1e-4 * fmax(1.0, theta)); theta_max = CFZ_UNIFORM(1e4 * fmax(1.0, theta)); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
     CFZ_LANES(tid)
@@ -1552,10 +1834,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // infeasibility stall (oracle/ipm.py): violation stuck above the tolerance -> locally infeasible, status 5
     // (an iterate that changed the working set counts a quarter: its new rows start with their own violation -- but a solve that
     // changes it at every iterate is cycling and has to end)
-    if (iter == 0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
+    if (iter == iter0 || err0 < 0.5 * best_err) { best_err = err0; best_it = iter; }
     if (sp.stag_win > 0 && !stagnant && cviol <= sp.constr_viol_tol && iter - best_it >= sp.stag_win) stagnant = 1;
     if (sp.err_stall > 0 && iter - best_it >= sp.err_stall) { status = 5; break; }  // a cycle below constr_viol_tol: the stall test above never fires
-    if (iter == 0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
+    if (iter == iter0 || cviol <= sp.stall_kappa * stall_ref) { stall_ref = cviol; stall_cnt = 0; stall_ws = 0; }
     else if (!ws_changed) ++stall_cnt;
     else if (++stall_ws >= kWsStallDiv) { stall_ws = 0; ++stall_cnt; }
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
@@ -1583,17 +1865,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     const double tau = CFZ_UNIFORM(fmax(sp.tau_min, 1.0 - mu));
     CFZ_STAMP(3);  // barrier update
     // ---- condensed stage QP: H_k (compact), g_k ---------------------------------------------------
-    // rows: g += a (S c - mu / sigma), H += S a a' and the curvature of the separation rows weighted with their multipliers,
+    // rows: g += a (S c - (mu / sigma) / D + delta_c S nu), H += S a a' with S = S0 / D, D = 1 + delta_c S0, and the curvature of the separation rows weighted with their multipliers,
     // sum_r nu_r d2 sep_r / d(x,y,psi)^2 = [[0,0,ca],[0,0,cb],[ca,cb,cc]] (oracle/mpc_nlp.py row_curvature):
     //   kind 1 (polygon face A_f = (a0,a1), body vertex b_v): d2/dpsi2 = -A_f.(R b_v)
     //   kind 2 (body face normal n = -(a0,a1), polygon vertex): d2/dx dpsi = -a1, d2/dy dpsi = a0, d2/dpsi2 = -(sep + g_f)
     //   kind 3 (distance r of two vertices, n = (a0,a1)): tau tau' / r + kappa e_psi e_psi' with tau = (t, t.dw), t = (-a1, a0)
     //           the unit tangent, dw = d(R b_v)/dpsi, kappa = -n.(R b_v); the only rows that curve x and y (cxx, cyy, cxy)
-    // The whole curvature of the separation rows first (oracle/ipm.py whole_curvature_first): kept if the backward sweep finds
-    // every stage's Huu positive definite; otherwise the stage-wise safeguarded model below (scaled, late in a solve shifted)
-    // is assembled and swept instead, and the next iteration does not try the whole curvature again.
-    bool use_whole = kWholeSwitch && sp.whole_first != 0 && sp.row_curvature != 0 && whole_skip == 0;
-    for (;;) {
     CFZ_LANES(tid)
       const int k = tid >> 2, sub = tid & 3;
       double ac[15] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc | cxx cyy cxy
@@ -1606,8 +1883,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           block_grad(sp, m, L, k, jb, sl, pk[0], pk[1], cpsi, spsi, a0, a1, bap);
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
-            const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
-            const double coef = S * m[L.cj + t] - mu * isg;
+            // delta_c on the row (IPOPT's dual regularisation, eliminated together with the slack): the row's stiffness is
+            // S0 / (1 + delta_c S0) and its right-hand side sees the distance of nu from its centred value -mu / sigma
+            const double isg = 1.0 / m[L.sg + t], S0 = m[L.zs + t] * isg + sp.reg_primal;
+            const double iD = 1.0 / (1.0 + kDeltaC(sp) * S0), S = S0 * iD;
+            const double coef = S * m[L.cj + t] - mu * isg * iD + kDeltaC(sp) * S * m[L.nuc + t];
             const double a2 = bap[r_];
             ac[0] += a0 * coef; ac[1] += a1 * coef; ac[2] += a2 * coef;
             ac[3] += S * a0 * a0; ac[4] += S * a1 * a1; ac[5] += S * a2 * a2;
@@ -1662,7 +1942,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           if (sp.vv_rows) { cxx = CFZ_QSUM(qx, 12); cyy = CFZ_QSUM(qx, 13); cxy = CFZ_QSUM(qx, 14); }
           const bool full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0;  // a vertex-vertex row in this stage
           double th = 1.0;
-          for (int hh = 0; hh < 11 && !use_whole; ++hh) {
+          for (int hh = 0; hh < 11; ++hh) {
             if (hh == 10) { th = 0.0; break; }
             if (!full) {
               if (q2 + th * cc - th * th * quad >= 0.0) break;
@@ -1674,7 +1954,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             }
             th *= 0.5;
           }
-          if (!use_whole && sp.shift_after > 0 && (iter >= sp.shift_after || (stagnant && iter >= kShiftStagMin) || shift_hint) && th < 1.0) {
+          if (sp.shift_after > 0 && (iter >= sp.shift_after || (stagnant && iter >= kShiftStagMin) || shift_hint) && th < 1.0) {
             CFZ_P(shf, 0) = 1.0;
             // late in a long solve the scaled model cycles: whole curvature + the smallest identity shift that keeps the margin
             const double dl = pose_shift(dv.q0 + cxx, dv.q1 + cyy, q2 + cc, cxy, ca, cb);
@@ -1694,19 +1974,6 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
     CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
     CFZ_STAMP(11);  // Riccati backward sweep
-    const bool whole_failed = kWholeSwitch && use_whole && CFZ_UNIFORM(m[L.rP + 30]) == 0.0;
-    if (kWholeSwitch && use_whole) CFZ_SYNC();  // rP[30] is cos of stage 15 once the block below has run: every wavefront reads it first
-    if (whole_failed) {
-      use_whole = false; whole_skip = 2;
-      CFZ_LANES(tid)  // the sweep's value function sits where the assembly reads cos / sin of the headings (L.rP = L.cs): put them back
-        const int k = tid >> 2;
-        if (k < N && (tid & 3) == 0) { double sn, cn; sincos(m[L.p + k * kNP + 2], &sn, &cn); m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
-      CFZ_END
-      continue;
-    }
-    break;
-    }
-    if (kWholeSwitch && sp.row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
     // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_STAMP(9);  // forward step
@@ -1729,7 +1996,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
-            const double ds = m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[r_] * dpk[2];
+            const double ds = (m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[r_] * dpk[2] + kDeltaC(sp) * (mu * isg + m[L.nuc + t])) /
+                              (1.0 + kDeltaC(sp) * (zs * isg + sp.reg_primal));
             m[L.dsg + t] = ds;
             const double dzs = mu * isg - zs - zs * isg * ds;
             dphi -= mu * isg * ds;
@@ -1783,7 +2051,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       alpha = CFZ_UNIFORM(alpha * 0.5);
     }
     CFZ_STAMP(7);  // line search
-    if (!accepted) { status = 2; break; }
+    if (!accepted) {
+      // IPOPT's answer to a failed line search at an infeasible iterate: the restoration phase, then on with cold multipliers and an
+      // empty filter; a restoration that fails ends the solve with status 5
+      if (resto_on && resto_calls < sp.resto && cviol > sp.constr_viol_tol) { want_resto = 2; break; }
+      status = 2; break;
+    }
     if (!f_type) {
       // the line search above reads the filter in uniform code: a full filter is shifted below, so the other wavefront must be
       // through with its comparisons first (found as a GPU memory fault of long closed loops: the wavefront that read a half-shifted
@@ -1833,6 +2106,19 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       }
     CFZ_END
     CFZ_STAMP(8);  // update
+  }
+  if (__builtin_expect(want_resto == 0, 1)) break;
+  {
+    const int r = restore_instance(sp, dv, m, L, mu, iter);
+    if (r < 0) { status = 5; iter = -r - 1; break; }
+    cold_multipliers(sp, m, L, mu);
+    if (want_resto == 1) { iter0 = r - 1; iter = iter0; }  // the first iteration again, from the restored point
+    else {  // the iteration of the failed line search is counted; the filter and the stall tests start afresh
+      iter = r;
+      ++resto_calls;
+      nfilt = 0; stall_ref = INFINITY; stall_cnt = 0; stall_ws = 0; best_err = INFINITY; best_it = r - 1;
+    }
+  }
   }
 
   CFZ_STAMP(10);

@@ -26,9 +26,9 @@ class _CSpec(C.Structure):
     ]
 
 
-_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "carry_duals", "vv_rows", "shift_after", "whole_curvature_first", "shift_stagnation", "err_stall_iters", "carry_shift")
+_OPT_INTS = ("max_iter", "max_backtrack", "filter_cap", "stall_iters", "row_curvature", "carry_duals", "vv_rows", "shift_after", "restoration", "shift_stagnation", "err_stall_iters", "carry_shift")
 _OPT_DBLS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
+             "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push reg_dual_rows resto_first").split()
 
 
 KERNEL_AUTO, KERNEL_WIDE, KERNEL_NARROW = 0, 1, 2  # cfz_plan_options.kernel / cfz_colloc_options.kernel (include/confrez_hip.h)

@@ -63,13 +63,13 @@ typedef struct cfz_options {
   int32_t shift_after;    /* 60: from this iteration on a stage whose row curvature the convexity safeguard would scale keeps it
                            *     whole and is shifted by the smallest multiple of the identity instead (a scaled model can
                            *     cycle for hundreds of iterations on a vehicle pressed into a corner); 0 = never */
-  int32_t whole_curvature_first; /* 0 (default): the stage-wise safeguarded curvature model.  1 (experiment switch): every iteration
-                           *    first takes the WHOLE multiplier-weighted curvature of the separation rows and keeps it when the Riccati
-                           *    recursion finds every stage's Huu positive definite (IPOPT: the first trial of its inertia correction,
-                           *    delta_w = 0), else falls back to the safeguarded model.  Halves the 99th percentile of a scenario's
-                           *    iteration chain on the planned-table closed loop, but three instances of the independent-solver
-                           *    populations then end with status 5 (docs/notebook.md), so it is off -- and compiled into the library only
-                           *    with -DCFZ_WHOLE_FIRST (it costs the kernel registers even when off): cfz_create refuses 1 otherwise */
+  int32_t restoration;    /* 2: restoration phases a solve may go through (IPOPT's answer to a failed line search, paper sec. 3.3):
+                           *    Levenberg-Marquardt on the squared violations of the separation rows and the boxes, on the solver's own
+                           *    stage recursion, until the worst violation is a tenth of what it was; then cold multipliers at the
+                           *    restored point.  Entered after a failed line search at an iterate whose violation exceeds
+                           *    constr_viol_tol, and before the first iteration of a start that resto_first describes.  A restoration
+                           *    that does not reach its goal ends the solve with status 5 (IPOPT: "converged to a point of local
+                           *    infeasibility").  0 = none: a failed line search is status 2 */
   int32_t shift_stagnation; /* 10: once the scaled optimality error has not halved for this many iterations at a feasible iterate
                            *    (violation <= constr_viol_tol) the late curvature shift may start at iteration 40 instead of waiting for
                            *    shift_after; ends the sawtooth of the scaled model 15-20 iterations sooner; 0 = off */
@@ -87,6 +87,12 @@ typedef struct cfz_options {
   double eta_phi, gamma_theta, gamma_phi, delta_sw, s_theta, s_phi, reg_primal;
   double stall_kappa;     /* 0.9: progress = violation below stall_kappa x its last checkpoint */
   double warm_push;       /* 1e-6: distance from a bound kept by a start that carries multipliers */
+  double reg_dual_rows;   /* 1e-8: IPOPT's dual regularisation delta_c (paper sec. 3.1), permanently on the separation rows: two rows of
+                           *    a block, or rows of different blocks of a stage, become dependent at a contact and their multipliers
+                           *    run away along the null space; 0 = off */
+  double resto_first;     /* 0.3 (metres): a start whose separation rows of stages >= 1 are violated by more than this -- the warm
+                           *    start of a vehicle whose neighbour's prediction has moved into its path -- goes through the restoration
+                           *    phase before the first iteration; 0 = never */
 } cfz_options;
 
 typedef struct cfz_handle cfz_handle;

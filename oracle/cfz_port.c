@@ -36,7 +36,6 @@ typedef struct {
   int filter_cap, max_backtrack, stall_iters, row_curvature;
   int vv_rows; /* 1: vertex-vertex rows (kind 3) in the working set, oracle/mpc_nlp.py MpcSpec.vv_rows */
   int shift_after; /* oracle/ipm.py IpmOptions.shift_after */
-  int whole_first; /* oracle/ipm.py IpmOptions.whole_curvature_first */
   int stag_win;    /* oracle/ipm.py IpmOptions.shift_stagnation */
   int err_stall;   /* oracle/ipm.py IpmOptions.err_stall_iters */
   int carry_shift; /* oracle/ipm.py IpmOptions.carry_shift */
@@ -450,18 +449,20 @@ static void riccati_forward(int N, const double *x0) {
 }
 
 /* ---------------------------------------------------------------- feasibility restoration (oracle/ipm.py restore) */
-/* IPOPT answers a failed line search with its restoration phase (paper sec. 3.3): it minimises the constraint violation, staying close
- * to the point where it was called, and resumes from there.  Here the violation of the separation rows and of the boxes is a sum of
- * squared hinges -- a nonlinear least-squares problem over the trajectory,
+/* IPOPT answers a failed line search with its restoration phase (paper sec. 3.3): it minimises the constraint violation and resumes
+ * from the point that reaches.  Here the violation of the separation rows and of the boxes is a sum of squared hinges -- a nonlinear
+ * least-squares problem over the trajectory,
  *     min  rho / 2 sum_{k >= 1, r} max(0, dmin + eps - sep_kr(p_k))^2  +  rho_b / 2 sum (excess over the boxes shrunk by m_b)^2
- *          +  zeta / 2 |p - p_R|^2          s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
- * solved by Gauss-Newton steps on the same stage recursion as the solver's Newton system (H_k = zeta I + rho sum of a a' over the
- * violated rows + rho_b on the violated boxes), with an Armijo line search on the l1 merit (objective + eta x |dynamics defects|_1).
- * zeta = sqrt(mu) and p_R = the iterate at entry (paper eq. 30).  No barrier and no multipliers inside: a step is never cut by the
+ *     s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
+ * solved by Levenberg-Marquardt steps on the same stage recursion as the solver's Newton system (H_k = (zeta + lambda) I + rho sum of
+ * a a' over the violated rows + rho_b on the violated boxes; zeta = sqrt(mu) is IPOPT's proximity weight, paper eq. 30, taken to the
+ * current iterate; lambda grows fourfold after a step the line search cut below 0.2 and falls after a full step), with an Armijo line
+ * search on the l1 merit (objective + eta x |dynamics defects|_1).  No barrier and no multipliers inside: a step is never cut by the
  * fraction to the boundary (a primal barrier at the solver's small mu crawls from one saturating input to the next).
- * Returns 1 when every row of stages >= 1 holds with margin eps / 2, every box with margin m_b / 2, and the dynamics defects are
- * below constr_viol_tol (the iterate is then clipped m_b / 2 inside the boxes); 0 when the iteration stalls before that (a
- * stationary point of the violation: locally infeasible), when a line search fails, or at the iteration limit.
+ * Returns 1 when every row of stages >= 1 is within the goal (a tenth of the violation at entry -- IPOPT asks for nine tenths -- or
+ * half the margin eps), every box holds with margin m_b / 2 and the dynamics defects are no worse than at entry (the iterate is then
+ * clipped m_b / 2 inside the boxes); 0 when the worst violation has not dropped by a tenth in RESTO_STALL iterations (a stationary
+ * point of the violation: locally infeasible), when a line search fails, or at the iteration limit.
  * *iter counts the restoration's iterations on the solve's counter. */
 #define RESTO_RHO 1000.0
 #define RESTO_RHO_BOX 1e5
@@ -470,13 +471,10 @@ static void riccati_forward(int N, const double *x0) {
 #define RESTO_STALL 8
 #define RESTO_KAPPA 0.1
 #define RESTO_ARMIJO 1e-4
-#define RESTO_MULT_RESET 1e3
-static double resto_objective(const cfz_port_spec *sp, const double p[][NP], const double pbar[][NP], const double sp_[][MAXR],
-                              double eps, double zeta) {
+static double resto_objective(const cfz_port_spec *sp, const double p[][NP], const double sp_[][MAXR], double eps) {
   const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
   double phi = 0.0;
   for (int k = 0; k < N; ++k) {
-    for (int i = 0; i < NP; ++i) { const double e = p[k][i] - pbar[k][i]; phi += 0.5 * zeta * e * e; }
     for (int q = (k == 0 ? 4 : 0); q < 6; ++q) {
       const double el = sp->bounds[2 * q] + RESTO_BOX_MARGIN - p[k][BCOL[q]], eu = p[k][BCOL[q]] - sp->bounds[2 * q + 1] + RESTO_BOX_MARGIN;
       if (el > 0.0) phi += 0.5 * RESTO_RHO_BOX * el * el;
@@ -487,8 +485,7 @@ static double resto_objective(const cfz_port_spec *sp, const double p[][NP], con
   return phi;
 }
 
-static double pbar[MAXN][NP]; /* the iterate at the restoration's entry */
-static int restore_run(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
+static int restore(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
   const int N = sp->N, nblk = sp->n_obs + sp->n_nbr, nb = 2 * nblk;
   const double zeta = sqrt(mu), rho = RESTO_RHO, mb = RESTO_BOX_MARGIN;
   double eta = 0.0, eps = 0.0, lm = 0.0, vgoal = 0.0, vref = INFINITY, dgoal = 0.0; int ref_it = 0;
@@ -509,7 +506,7 @@ static int restore_run(const cfz_port_spec *sp, const double *x0, const double *
     }
     for (int k = 0; k < N; ++k) {
       memset(H[k], 0, sizeof H[k]);
-      for (int i = 0; i < NP; ++i) { gk[k][i] = zeta * (it.p[k][i] - pbar[k][i]); H[k][i][i] = zeta + lm; }
+      for (int i = 0; i < NP; ++i) { gk[k][i] = 0.0; H[k][i][i] = zeta + lm; }
       for (int q = (k == 0 ? 4 : 0); q < 6; ++q) { /* the states of stage 0 are the measurement: nothing to restore there */
         const int c = BCOL[q];
         const double el = sp->bounds[2 * q] + mb - it.p[k][c], eu = it.p[k][c] - sp->bounds[2 * q + 1] + mb;
@@ -529,7 +526,7 @@ static int restore_run(const cfz_port_spec *sp, const double *x0, const double *
         }
       for (int i = 0; i < NP; ++i) gphi[k][i] = gk[k][i];
     }
-    const double phi = resto_objective(sp, it.p, pbar, sep, eps, zeta);
+    const double phi = resto_objective(sp, it.p, sep, eps);
     if (rit == 0) dgoal = fmax(sp->constr_viol_tol, cv_dyn); /* dynamics: no worse than at entry */
     if (vmax <= vgoal && bmax <= 0.5 * mb && cv_dyn <= dgoal) {
       for (int k = 0; k < N; ++k)
@@ -565,7 +562,7 @@ static int restore_run(const cfz_port_spec *sp, const double *x0, const double *
         for (int i = 0; i < 5; ++i) th_t += fabs(F[i] - pt[k + 1][i]);
       }
       eval_rows(sp, nbr, pt, sel, sgt, 0, 0); /* the working set is held during the line search, as in the solver */
-      const double M_t = resto_objective(sp, pt, pbar, sgt, eps, zeta) + eta * th_t;
+      const double M_t = resto_objective(sp, pt, sgt, eps) + eta * th_t;
       if (isfinite(M_t) && M_t <= M0 + RESTO_ARMIJO * alpha * dM) { accepted = 1; break; }
       alpha *= 0.5;
     }
@@ -576,15 +573,8 @@ static int restore_run(const cfz_port_spec *sp, const double *x0, const double *
   }
 }
 
-/* a restoration that fails leaves the iterate where it was called */
-static int restore(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
-  memcpy(pbar, it.p, sizeof pbar);
-  if (restore_run(sp, x0, nbr, mu, iter)) return 1;
-  memcpy(it.p, pbar, sizeof pbar);
-  return 0;
-}
-
-/* cold multipliers at the current point (after a restoration): slacks from the rows, z = mu / distance, the equality rows at zero */
+/* cold multipliers at the current point (after a restoration; IPOPT resets its bound multipliers there and recomputes the others):
+ * slacks from the rows, z = mu / distance, the equality rows at zero */
 static void cold_multipliers(const cfz_port_spec *sp, const double *nbr, double mu) {
   const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
   select_all(sp, nbr, it.p, sel);
@@ -601,26 +591,6 @@ static void cold_multipliers(const cfz_port_spec *sp, const double *nbr, double 
     for (int i = 0; i < 5; ++i) it.pi[k][i] = 0.0;
   }
   for (int i = 0; i < 5; ++i) it.pi0[i] = 0.0;
-}
-
-/* the restoration phase called from inside the iteration (failed line search, stalled violation), and how the iteration resumes:
- * the multipliers are kept (the loop's working-set refresh hands them over from the entry's working set) unless they have run away
- * -- IPOPT's constr_mult_reset_threshold -- in which case the iteration restarts cold at the restored point */
-static int restore_and_resume(const cfz_port_spec *sp, const double *x0, const double *nbr, double mu, int *iter) {
-  const int N = sp->N, nb = 2 * (sp->n_obs + sp->n_nbr);
-  static int sel_in[MAXN][MAXB];
-  memcpy(sel_in, sel, sizeof sel);
-  if (!restore(sp, x0, nbr, mu, iter)) return 0;
-  double zmax = 0.0;
-  for (int i = 0; i < 5; ++i) zmax = fmax(zmax, fabs(it.pi0[i]));
-  for (int k = 0; k < N; ++k) {
-    for (int j = 0; j < nb; ++j) zmax = fmax(zmax, fmax(fabs(it.nuc[k][j]), it.zs[k][j]));
-    for (int q = 0; q < 6; ++q) zmax = fmax(zmax, fmax(it.zl[k][q], it.zu[k][q]));
-    if (k + 1 < N) for (int i = 0; i < 5; ++i) zmax = fmax(zmax, fabs(it.pi[k][i]));
-  }
-  if (zmax > RESTO_MULT_RESET) cold_multipliers(sp, nbr, mu);
-  else memcpy(sel, sel_in, sizeof sel);
-  return 1;
 }
 
 /* ---------------------------------------------------------------- the solver */
@@ -643,7 +613,6 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   int resto_calls = 0, iter0 = 0, locally_infeasible = 0;
   double mu = sp->mu_init;
   int status = 1, iter = 0;
-  int whole_skip = 0; /* iterations left in which the whole row curvature is not tried */
   int stagnant = 0, best_it = 0; double best_err = INFINITY; /* oracle/ipm.py shift_stagnation */
   double err0 = INFINITY;
   const int m_eq = 5 + 5 * (N - 1) + nb * N, n_bnd = N * (12 + nb); /* nb counts rows here */
@@ -742,6 +711,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
   if (sp->resto > 0 && sp->resto_first > 0.0) {
     /* a start whose rows are violated by more than resto_first goes through the restoration phase first (cold multipliers after it) */
     double v0 = 0.0;
+    eval_rows(sp, nbr, it.p, sel, sep, 0, 0); /* at the pushed start, working set of the un-pushed one: what the first iteration sees */
     for (int k = 1; k < N; ++k) for (int j = 0; j < nb; ++j) v0 = fmax(v0, sp->dmin - sep[k][j]);
     if (v0 > sp->resto_first) {
       int rit = 0;
@@ -866,14 +836,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     (void)cmpmu;
     double tau = fmax(sp->tau_min, 1.0 - mu);
     /* ---- condensed stage QP ----------------------------------------------------------- */
-    /* The whole curvature of the separation rows first (oracle/ipm.py whole_curvature_first): kept if every stage's Huu of the
-     * Riccati recursion below is positive definite (the Newton system then has the inertia of a minimisation); otherwise the
-     * stage-wise safeguarded model takes its place and the next iteration does not try again. */
     double dphi = 0.0;
-    int use_whole = sp->whole_first && sp->row_curvature && whole_skip == 0;
-    for (;;) {
-    int pd_ok = 1;
-    dphi = 0.0;
     for (int k = 0; k < N; ++k) {
       const double *w = sp->weights; const double *p = it.p[k];
       memset(H[k], 0, sizeof H[k]);
@@ -910,7 +873,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         const double q0 = 2 * w[0] - m_, q1 = 2 * w[1] - m_, q2 = 2 * w[2] - m_;
         const int full = cxx != 0.0 || cyy != 0.0 || cxy != 0.0; /* a vertex-vertex row curves x and y too */
         double th = 1.0;
-        for (int h = 0; h < 11 && !use_whole; ++h) {
+        for (int h = 0; h < 11; ++h) {
           if (h == 10) { th = 0.0; break; }
           if (!full) {
             if (q2 + th * cc - th * th * (ca * ca / q0 + cb * cb / q1) >= 0.0) break;
@@ -922,7 +885,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
           }
           th *= 0.5;
         }
-        if (!use_whole && sp->shift_after > 0 && (iter >= sp->shift_after || (stagnant && iter >= SHIFT_STAG_MIN) || shift_hint) && th < 1.0) {
+        if (sp->shift_after > 0 && (iter >= sp->shift_after || (stagnant && iter >= SHIFT_STAG_MIN) || shift_hint) && th < 1.0) {
           shift_used = 1;
           /* late in a long solve the scaled model cycles: whole curvature + smallest identity shift (hess_gn shift=True) */
           const double dl_ = pose_shift(q0 + cxx, q1 + cyy, q2 + cc, cxy, ca, cb);
@@ -933,11 +896,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         H[k][0][0] += th * cxx; H[k][1][1] += th * cyy; H[k][0][1] += th * cxy; H[k][1][0] += th * cxy;
       }
     }
-    if (!riccati_backward(N)) pd_ok = 0;
-    if (use_whole && !pd_ok) { use_whole = 0; whole_skip = 2; continue; }
-    break;
-    }
-    if (sp->row_curvature) whole_skip = whole_skip > 0 ? whole_skip - 1 : 0;
+    riccati_backward(N);
     /* ---- forward sweep: dp, new multipliers ------------------------------------------------ */
     riccati_forward(N, x0);
     for (int i = 0; i < 5; ++i) dt_.pi0[i] = pi0new[i] - it.pi0[i];
@@ -997,7 +956,8 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
     if (!accepted) {
       /* IPOPT's answer to a failed line search: the restoration phase, then on with fresh multipliers and an empty filter */
       if (sp->resto > 0 && resto_calls < sp->resto && cviol > sp->constr_viol_tol) {
-        if (restore_and_resume(sp, x0, nbr, mu, &iter)) {
+        if (restore(sp, x0, nbr, mu, &iter)) {
+          cold_multipliers(sp, nbr, mu);
           ++resto_calls;
           nfilt = 0; stall_ref = INFINITY; stall_cnt = 0; stall_ws = 0; best_err = INFINITY; best_it = iter;
           continue;

@@ -82,8 +82,8 @@ class IpmOptions:
     # block, or rows of different blocks of a stage, become dependent at a contact and their multipliers run away along the null space.
     reg_dual_rows: float = 1e-8
     # Restoration phase (paper sec. 3.3) of NLPs that provide `restore` (oracle/mpc_nlp.py): at most `restoration` calls per solve,
-    # each after a failed line search at an iterate whose violation exceeds constr_viol_tol; the multipliers are kept unless they
-    # exceed IPOPT's constr_mult_reset_threshold.  A restoration that does not reach its goal ends the solve with status 5
+    # each after a failed line search at an iterate whose violation exceeds constr_viol_tol; the iteration resumes with cold multipliers
+    # at the restored point.  A restoration that does not reach its goal ends the solve with status 5
     # (IPOPT: "converged to a point of local infeasibility").  0 = no restoration phase (a failed line search is status 2).
     restoration: int = 2
     # A start whose separation rows are violated by more than this (metres; the warm start of a vehicle whose neighbour's prediction
@@ -92,11 +92,6 @@ class IpmOptions:
     resto_first: float = 0.3
     hessian: str = "gn"  # "gn" (kernel's choice) or "exact" (needs nlp.hess_exact; planning NLPs)
     curv_kappa: float = 1e-8  # exact Hessian: inertia-free curvature test d'(W+Sigma)d >= kappa d'd
-    # True: the whole (unsafeguarded) curvature of the separation rows is tried first and kept when the Newton system has the
-    # right inertia (see solve).  False (default): always the stage-wise safeguarded model.  Measured in round 3 (docs/notebook.md):
-    # on the planned-table closed loop the 99th percentile of a scenario's iteration chain halves with it, but three instances of
-    # the independent-solver populations then end with status 5 -- parity first, so it stays an experiment switch.
-    whole_curvature_first: bool = False
     # Stagnation shift: once the scaled optimality error has not halved for `shift_stagnation` iterations at a feasible iterate
     # (cviol <= constr_viol_tol), the late shift of the row curvature (see shift_after) starts as soon as iteration SHIFT_STAG_MIN
     # is reached instead of waiting for shift_after.  The sawtooth of the scaled model (planned-table closed loop: one vehicle at
@@ -155,7 +150,6 @@ def kkt_inertia_ok(H, J, n, m):
 
 STATUS_OK, STATUS_MAXITER, STATUS_LINESEARCH, STATUS_NAN = 0, 1, 2, 3
 STATUS_STALLED = 5  # constraint violation stopped decreasing above constr_viol_tol, or a restoration failed (4 is taken by mpc_nlp)
-RESTO_MULT_RESET = 1e3  # IPOPT's constr_mult_reset_threshold (oracle/mpc_nlp.py restore)
 
 
 def push_to_interior(x, xl, xu, opt: IpmOptions):
@@ -223,11 +217,10 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
     shift_hint = bool(warm is not None and opt.carry_shift and warm.get("shift_hint"))  # IpmOptions.carry_shift
     shifted = False  # some stage's curvature was shifted in some iteration of this solve
     mu_forced = False
-    whole_skip = 0  # iterations left in which the whole row curvature is not tried (it has just failed the inertia test)
     it0 = 0
     resto_calls = 0
     can_restore = opt.restoration > 0 and hasattr(nlp, "restore")
-    if can_restore and opt.resto_first > 0.0 and getattr(nlp, "start_viol", 0.0) > opt.resto_first:
+    if can_restore and opt.resto_first > 0.0 and nlp.start_violation(x) > opt.resto_first:  # at the pushed start
         ok, x, it0 = nlp.restore(x, mu, opt, 0)
         if not ok:
             return dict(X=x, nu=nu, zl=zl, zu=zu, status=STATUS_STALLED, iters=it0, mu=mu, err=np.inf, f=nlp.f(x), shifted=False)
@@ -304,23 +297,9 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         rhs = -np.concatenate([gphi + J.T @ nu, c])
         if opt.hessian == "gn":
             if opt.row_curvature and getattr(nlp, "has_row_curvature", False):
-                # The whole curvature of the separation rows first: with it the iteration converges quadratically at an active
-                # contact.  It is kept if the Newton system then has the inertia of a minimisation (n positive, m negative
-                # eigenvalues: the kernels read the same off their Riccati recursion, every stage's Huu positive definite);
-                # otherwise the stage-wise safeguarded model (scaled, from iteration shift_after on shifted) takes its place,
-                # and the next iteration does not try the whole curvature again.
-                H = None
-                if opt.whole_curvature_first and whole_skip == 0:
-                    Hw = nlp.hess_gn(x, nu, whole=True) + sp.diags(sig + opt.reg_primal)
-                    if (nlp.reduced_hessian_pd(Hw, J) if hasattr(nlp, "reduced_hessian_pd") else kkt_inertia_ok(Hw, J, n, m)):
-                        H = Hw
-                    else:
-                        whole_skip = 2
-                whole_skip = max(whole_skip - 1, 0)
-                if H is None:
-                    late = opt.shift_after > 0 and (it >= opt.shift_after or (stagnant and it >= SHIFT_STAG_MIN) or shift_hint)
-                    H = nlp.hess_gn(x, nu, shift=late) + sp.diags(sig + opt.reg_primal)
-                    shifted = shifted or bool(getattr(nlp, "shift_applied", False))
+                late = opt.shift_after > 0 and (it >= opt.shift_after or (stagnant and it >= SHIFT_STAG_MIN) or shift_hint)
+                H = nlp.hess_gn(x, nu, shift=late) + sp.diags(sig + opt.reg_primal)
+                shifted = shifted or bool(getattr(nlp, "shift_applied", False))
             else:
                 H = nlp.hess_gn(x) + sp.diags(sig + opt.reg_primal)
             K = sp.bmat([[H, J.T], [J, -sp.diags(dual_reg)]], format="csc")
@@ -397,19 +376,14 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
                 break
             alpha *= 0.5
         if not accepted and can_restore and resto_calls < opt.restoration and cviol > opt.constr_viol_tol:
-            # IPOPT's answer to a failed line search: the restoration phase, then on with an empty filter.  The multipliers are kept
-            # (the working-set refresh of the next iteration hands them over from the entry's working set) unless they have run away.
-            sel_in = nlp.sel.copy()
+            # IPOPT's answer to a failed line search: the restoration phase, then on with an empty filter and cold multipliers
             ok, x, rit = nlp.restore(x, mu, opt, it)
             it += rit
             if not ok:
                 status = STATUS_STALLED
                 break
             resto_calls += 1
-            if max(np.abs(nu).max(), zl.max(), zu.max()) > RESTO_MULT_RESET:
-                x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)
-            else:
-                nlp.sel[:] = sel_in
+            x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)
             filt, stall_ref, stall_cnt, stall_ws, best_err, best_it = [], np.inf, 0, 0, np.inf, it
             continue
         if not accepted:

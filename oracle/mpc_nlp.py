@@ -53,7 +53,6 @@ RESTO_MAX_ITER = 40
 RESTO_STALL = 8           # iterations without a drop of the worst violation by a tenth: stationary, locally infeasible
 RESTO_KAPPA = 0.1         # goal: a tenth of the violation at entry (IPOPT's required_infeasibility_reduction is 0.9)
 RESTO_ARMIJO = 1e-4
-RESTO_MULT_RESET = 1e3    # IPOPT's constr_mult_reset_threshold: multipliers above it are not kept after a restoration
 
 
 @dataclass
@@ -511,9 +510,9 @@ class MpcNlp:
         P = np.asarray(X).reshape(self.spec.N, self.ns)
         return float(max(0.0, (self.spec.dmin - self.blocks(P)[0][1:]).max()))
 
-    def _resto_objective(self, P, Pbar, sep, eps, zeta):
+    def _resto_objective(self, P, sep, eps):
         b = self.spec.bounds
-        phi = 0.5 * zeta * float(((P - Pbar) ** 2).sum())
+        phi = 0.0
         for q, c in enumerate(BCOLS):
             k0 = 1 if q < 4 else 0  # the states of stage 0 are the measurement
             el = np.maximum(b[2 * q] + RESTO_BOX_MARGIN - P[k0:, c], 0.0)
@@ -523,25 +522,23 @@ class MpcNlp:
         return phi + 0.5 * RESTO_RHO * float((v**2).sum())
 
     def restore(self, X, mu, opt, iters_done):
-        """IPOPT's restoration phase (paper sec. 3.3) for this NLP: Gauss-Newton / Levenberg-Marquardt on
-            min rho/2 sum_{k>=1,r} max(0, dmin + eps - sep_kr)^2 + rho_b/2 sum (box excess)^2 + zeta/2 |p - p_R|^2
-            s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
-        (zeta = sqrt(mu), p_R the poses and inputs at entry), Armijo line search on the l1 merit with the dynamics defects.
-        The step comes from the full KKT matrix here and from the stage recursion in oracle/cfz_port.c and the kernel.
+        """IPOPT's restoration phase (paper sec. 3.3) for this NLP: Levenberg-Marquardt on
+            min rho/2 sum_{k>=1,r} max(0, dmin + eps - sep_kr)^2 + rho_b/2 sum (box excess)^2   s.t. z_0 = x0, z_{k+1} = F(z_k, u_k)
+        with the damping (zeta + lambda) I (zeta = sqrt(mu): IPOPT's proximity weight, taken to the current iterate; lambda adapted
+        to the step lengths) and an Armijo line search on the l1 merit with the dynamics defects.  The step comes from the full
+        KKT matrix here and from the stage recursion in oracle/cfz_port.c and the kernel.
         Returns (ok, X_new, iterations): ok = every row of stages >= 1 within the goal (a tenth of the violation at entry, or
         half the margin eps), every box with margin, dynamics no worse than at entry; otherwise the caller ends with status 5
-        (a stationary point of the violation: locally infeasible) and X is returned unchanged."""
+        (a stationary point of the violation: locally infeasible)."""
         import scipy.sparse.linalg as spla
 
         sp_, N, ns = self.spec, self.spec.N, self.ns
         b = sp_.bounds
         Xs = np.asarray(X, float).reshape(N, ns).copy()
         P = Xs[:, :NP].copy()
-        Pbar = P.copy()
         zeta = float(np.sqrt(mu))
         eta = lm = 0.0
         vref, ref_it = np.inf, 0
-        sel_entry = self.sel.copy()
         n, m = NP * N, 5 * N
         rit = 0
         while True:
@@ -556,7 +553,7 @@ class MpcNlp:
                 eps = min(opt.bound_push, v0)
                 vgoal = max(0.5 * eps, RESTO_KAPPA * (v0 + eps))
                 dgoal = max(opt.constr_viol_tol, cv_dyn)
-            g = zeta * (P - Pbar)
+            g = np.zeros_like(P)
             H = np.zeros((N, NP, NP))
             H[:, range(NP), range(NP)] = zeta + lm
             bmax = 0.0
@@ -573,7 +570,7 @@ class MpcNlp:
             vmax = float(v.max())
             g[:, 0:3] -= RESTO_RHO * np.einsum("kr,kra->ka", v, gr)
             H[:, 0:3, 0:3] += RESTO_RHO * np.einsum("kr,kra,krb->kab", (v > 0.0).astype(float), gr, gr)
-            phi = self._resto_objective(P, Pbar, sep, eps, zeta)
+            phi = self._resto_objective(P, sep, eps)
             if vmax <= vgoal and bmax <= 0.5 * RESTO_BOX_MARGIN and cv_dyn <= dgoal:
                 for q, col in enumerate(BCOLS):
                     P[:, col] = np.minimum(np.maximum(P[:, col], b[2 * q] + 0.5 * RESTO_BOX_MARGIN), b[2 * q + 1] - 0.5 * RESTO_BOX_MARGIN)
@@ -607,7 +604,7 @@ class MpcNlp:
                 Pt = P + alpha * d
                 Ft = bicycle_rk4(Pt[:-1, 0:5], Pt[:-1, 5:7], sp_.dt, sp_.wb, sp_.rk_substeps)
                 th_t = float(np.abs(Pt[0, 0:5] - self.x0).sum() + np.abs(Ft - Pt[1:, 0:5]).sum())
-                M_t = self._resto_objective(Pt, Pbar, self.blocks(Pt)[0], eps, zeta) + eta * th_t  # working set held
+                M_t = self._resto_objective(Pt, self.blocks(Pt)[0], eps) + eta * th_t  # working set held
                 if np.isfinite(M_t) and M_t <= M0 + RESTO_ARMIJO * alpha * dM:
                     accepted = True
                     break
@@ -620,8 +617,8 @@ class MpcNlp:
                 lm *= 0.25
             P = Pt
             rit += 1
-        self.sel[:] = sel_entry
-        return False, np.asarray(X, float).copy(), rit
+        Xs[:, :NP] = P
+        return False, Xs.ravel(), rit
 
     def cold_multipliers(self, X, mu, opt):
         """After a restoration: fresh working set, slacks from the rows (at least half of bound_push), z = mu / distance,
@@ -717,12 +714,12 @@ class MpcNlp:
         Gd[:, 6] = 2 * wt[4] * P[:, 3] ** 2 * P[:, 6]
         return Gd.ravel()
 
-    def hess_gn(self, X, nu=None, shift=False, whole=False):
+    def hess_gn(self, X, nu=None, shift=False):
         """Gauss-Newton Hessian of the Lagrangian: objective curvature with the (v w)^2 term taken as the
         square of the residual r = v*w (PSD); with `nu`, plus the exact curvature of the separation rows
         sum_r nu_r d2 sep_r / d(x,y,psi)^2 (`row_curvature`).  `shift`: a stage whose curvature would be scaled
         keeps it whole and gets the smallest multiple of the identity on (x, y, psi) that restores the margin.
-        `whole`: no safeguard at all -- the caller checks the inertia of the Newton system instead (oracle/ipm.py)."""
+        """
         N, ns = self.spec.N, self.ns
         P = X.reshape(N, ns)
         wt = self.spec.weights
@@ -748,7 +745,7 @@ class MpcNlp:
                 a_, b_c, c_ = C[k, 0, 2], C[k, 1, 2], C[k, 2, 2]
                 full = C[k, 0, 0] != 0.0 or C[k, 1, 1] != 0.0 or C[k, 0, 1] != 0.0  # a vertex-vertex row curves x, y too
                 th = 1.0
-                for h in range(0 if whole else 11):
+                for h in range(11):
                     if h == 10:
                         th = 0.0
                         break
@@ -762,7 +759,7 @@ class MpcNlp:
                         if M[0, 0] > 0.0 and d2 > 0.0 and d3 >= 0.0:
                             break
                     th *= 0.5
-                if shift and th < 1.0 and not whole:
+                if shift and th < 1.0:
                     self.shift_applied = True
                     dl = pose_shift(q0 - m_ + C[k, 0, 0], q1 - m_ + C[k, 1, 1], q2 - m_ + C[k, 2, 2], C[k, 0, 1], a_, b_c)
                     th = 1.0
@@ -776,31 +773,6 @@ class MpcNlp:
         return sp.csr_matrix(
             (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.n, self.n)
         )
-
-    def reduced_hessian_pd(self, H, J):
-        """True if H (Hessian of the Lagrangian + Sigma + reg, [n, n]) is positive definite on the null space of J -- i.e. the
-        Newton system has the inertia of a minimisation -- read off the stage structure the way the kernels do: slack rows
-        condensed into the pose blocks, then the backward Riccati recursion; the answer is "every stage's Huu = R + B'PB is
-        positive definite" (with x0 pinned that is equivalent to the reduced Hessian being positive definite)."""
-        N, ns, nr = self.spec.N, self.ns, self.nr
-        Hd, Jd = H.toarray(), J.toarray()
-        P = None
-        for k in range(N - 1, -1, -1):
-            b = k * ns
-            Hc = Hd[b : b + NP, b : b + NP].copy()
-            for j in range(nr):
-                g = Jd[self.c_blk0 + nr * k + j, b : b + 3]
-                Hc[:3, :3] += Hd[b + NP + j, b + NP + j] * np.outer(g, g)
-            if k == N - 1:  # terminal stage: its inputs are costed but drive no dynamics
-                Hxx, Hux, Huu = Hc[:5, :5], Hc[5:, :5], Hc[5:, 5:]
-            else:
-                A, B = Jd[5 + 5 * k : 10 + 5 * k, b : b + 5], Jd[5 + 5 * k : 10 + 5 * k, b + 5 : b + 7]
-                Hxx, Hux, Huu = Hc[:5, :5] + A.T @ P @ A, Hc[5:, :5] + B.T @ P @ A, Hc[5:, 5:] + B.T @ P @ B
-            if not (Huu[0, 0] > 0.0 and Huu[0, 0] * Huu[1, 1] - Huu[0, 1] * Huu[1, 0] > 0.0):
-                return False
-            P = Hxx - Hux.T @ np.linalg.solve(Huu, Hux)
-            P = 0.5 * (P + P.T)
-        return True
 
     # ---- constraints ---------------------------------------------------------------
     def cons(self, X):
@@ -956,7 +928,6 @@ def solve_mpc(spec: MpcSpec, x0, ref, nbr, zu, opt=None, trace=None, carry=None)
         return dict(zu=zu.copy(), status=STATUS_INFEASIBLE_X0, iters=0, f=0.0, sep=None, sol=None, carry=None)
     warm = dict(zip(("x", "y", "psi", "v", "delta", "a", "w"), zu))
     X0 = nlp.pack(warm)
-    nlp.start_viol = nlp.start_violation(X0)  # read by ipm.solve (resto_first): the rows at the un-pushed start
     if carry is None:
         res = ipm.solve(nlp, X0, opt, trace=trace)
     else:

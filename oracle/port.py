@@ -32,7 +32,7 @@ class _Spec(C.Structure):
     ] + [(k, C.c_double) for k in (
         "tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
-    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("whole_first", C.c_int), ("stag_win", C.c_int), ("err_stall", C.c_int), ("carry_shift", C.c_int), ("resto", C.c_int), ("reg_dual_rows", C.c_double), ("resto_first", C.c_double)]
+    ] + [("filter_cap", C.c_int), ("max_backtrack", C.c_int), ("stall_iters", C.c_int), ("row_curvature", C.c_int), ("vv_rows", C.c_int), ("shift_after", C.c_int), ("stag_win", C.c_int), ("err_stall", C.c_int), ("carry_shift", C.c_int), ("resto", C.c_int), ("reg_dual_rows", C.c_double), ("resto_first", C.c_double)]
 
 
 def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
@@ -54,7 +54,6 @@ def make_spec(spec: MpcSpec, opt: IpmOptions = IpmOptions()):
     s.row_curvature = int(opt.row_curvature)
     s.vv_rows = int(spec.vv_rows)
     s.shift_after = int(opt.shift_after)
-    s.whole_first = int(opt.whole_curvature_first)
     s.stag_win = int(opt.shift_stagnation)
     s.err_stall = int(opt.err_stall_iters)
     s.carry_shift = int(opt.carry_shift)

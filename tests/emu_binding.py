@@ -8,11 +8,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(ROOT, "tests", "_build", "libcfz_emu.so")
 _OPTS = ("tol constr_viol_tol dual_inf_tol compl_inf_tol mu_init kappa_eps kappa_mu theta_mu tau_min bound_push "
-         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push").split()
+         "bound_frac s_max kappa_sigma eta_phi gamma_theta gamma_phi delta_sw s_theta s_phi reg_primal stall_kappa warm_push reg_dual_rows resto_first").split()
 
 
 class KSpec(C.Structure):
-    _fields_ = [(k, C.c_int) for k in "N n_obs n_nbr rk_substeps max_iter max_backtrack filter_cap stall_iters row_curvature vv_rows stag_win err_stall carry_shift pad_ks shift_after whole_first".split()] + [
+    _fields_ = [(k, C.c_int) for k in "N n_obs n_nbr rk_substeps max_iter max_backtrack filter_cap stall_iters row_curvature vv_rows stag_win err_stall carry_shift pad_ks shift_after resto".split()] + [
         ("dt", C.c_double), ("wb", C.c_double), ("dmin", C.c_double),
         ("g", C.c_double * 4), ("bounds", C.c_double * 12), ("weights", C.c_double * 6),
         ("A_obs", C.c_double * 64), ("b_obs", C.c_double * 32), ("V_obs", C.c_double * 64),
@@ -42,7 +42,7 @@ def make_kspec(spec, opt):
     s.row_curvature = int(opt.row_curvature)
     s.vv_rows = int(getattr(spec, "vv_rows", False))
     s.shift_after = int(opt.shift_after)
-    s.whole_first = int(opt.whole_curvature_first)
+    s.resto = int(opt.restoration)
     s.stag_win = int(opt.shift_stagnation)
     s.err_stall = int(opt.err_stall_iters)
     s.carry_shift = int(opt.carry_shift)

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
-PICKS = ((117, 3, 4), (3, 1, 6), (147, 3, 15))  # (scenario, vehicle, first of three consecutive MPC iterations); the third: a cornered
+PICKS = ((117, 3, 4), (3, 1, 6), (3, 0, 0))  # (scenario, vehicle, first of three consecutive MPC iterations); the third: a cornered
 #   vehicle whose first solve needs the late curvature shift (45 iterations) -- its successors start shifted (IpmOptions.carry_shift: 10, 14)
 
 

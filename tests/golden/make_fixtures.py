@@ -124,7 +124,7 @@ def mpc_golden(table):
         SOL.append(res["zu"])
         META.append([res["status"], res["iters"], res["f"], res["sep"].min() if res["sep"] is not None else np.nan])
         print("case", case, "scenario instance", b, "status", res["status"], "iters", res["iters"], "f %.5f" % res["f"])
-        assert res["status"] == 5
+        assert res["status"] in (4, 5)
     # cases 18, 19: a vehicle pushed hard against a separation row (inputs recorded from a closed-loop run of the
     # engine, tools/capture_hard.py -> contact_inputs.npz).  Without the curvature of the separation rows in the
     # Hessian these need 450-600 iterations (period-2 oscillation of the Gauss-Newton iteration); with it about 10.
@@ -195,7 +195,11 @@ def colloc_golden():
 
 
 if __name__ == "__main__":
-    pytypes_fields()
-    mpc_golden(refs_4v())
-    carry_golden()
+    if "--mpc-only" in sys.argv:  # the MPC fixtures again on the committed table (after a change of the MPC algorithm)
+        mpc_golden(np.load(os.path.join(HERE, "refs_4v.npz"))["table"])
+        carry_golden()
+    else:
+        pytypes_fields()
+        mpc_golden(refs_4v())
+        carry_golden()
     colloc_golden()

@@ -57,5 +57,28 @@ def main(scenario=477, vehicle=3, keep=6):
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mpc_late_shift.npz"), A_obs=spec.A_obs, b_obs=spec.b_obs, **out)
 
 
+def resolve():
+    """Round 4: the stored inputs solved again after a change of the MPC algorithm (the closed loop they were recorded from has
+    moved on): `iters_noshift` = iterations without the late shift AND without the dual regularisation of the rows (the cycle:
+    600), `iters_nodc` = default late shift but no dual regularisation (round 3's algorithm), `iters_shift`, `status_shift`, `sol`
+    = the full-KKT oracle at the defaults (delta_c = 1e-8)."""
+    path = os.path.join(ROOT, "tests", "golden", "mpc_late_shift.npz")
+    g = dict(np.load(path))
+    ospec = MpcSpec(N=30, dt=0.1, A_obs=g["A_obs"], b_obs=g["b_obs"], n_nbr=3)
+    cyc = ipm.IpmOptions(shift_after=0, err_stall_iters=0, reg_dual_rows=0.0)
+    nodc = ipm.IpmOptions(reg_dual_rows=0.0)
+    g["iters_nodc"] = np.zeros(len(g["x0"]), int)
+    for b in range(len(g["x0"])):
+        a = (g["x0"][b], g["ref"][b], g["nbr"][b], g["zu"][b])
+        g["iters_noshift"][b] = port.solve(ospec, a[0], a[1], a[2], a[3].T.copy(), opt=cyc)["iters"]
+        g["iters_nodc"][b] = port.solve(ospec, a[0], a[1], a[2], a[3].T.copy(), opt=nodc)["iters"]
+        full = solve_mpc(ospec, *a)
+        cold = port.solve(ospec, a[0], a[1], a[2], a[3].T.copy())
+        assert (full["status"], full["iters"]) == (cold["status"], cold["iters"]), (b, full["iters"], cold["iters"])
+        g["iters_shift"][b], g["status_shift"][b], g["sol"][b] = full["iters"], full["status"], full["zu"]
+    print({k: g[k].tolist() for k in ("iters_noshift", "iters_nodc", "iters_shift", "status_shift")})
+    np.savez_compressed(path, **g)
+
+
 if __name__ == "__main__":
-    main()
+    resolve() if "--resolve" in sys.argv else main()

@@ -586,7 +586,7 @@ def test_population_against_the_independent_solver_on_gpu(prod, fixture):
     e = engine.Engine(scenarios.parking_lot_spec(), max_batch=len(d["x0"]), **opts)
     out = e.solve(d["x0"], d["ref"], d["nbr"], d["zu"], want_duals=False)
     check_against_independent(lambda b, *a: (int(out["status"][b]), out["zu"][b]), 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture][0],
-                              fails=POPULATIONS[fixture][1])
+                              fails=POPULATIONS[fixture][1], stuck=POPULATIONS[fixture][2])
     e.close()
 
 

@@ -202,7 +202,7 @@ def _fixture_file(name):
     return {k: d[k] for k in d.files}, MpcSpec(N=30, dt=0.1, A_obs=d["A_obs"], b_obs=d["b_obs"], n_nbr=3)
 
 
-def check_against_independent(solve, tight_tol, prod, fixture="mpc_independent.npz", better=(), fails=()):
+def check_against_independent(solve, tight_tol, prod, fixture="mpc_independent.npz", better=(), fails=(), stuck=()):
     """Shared by the CPU tests (C port) and the GPU tests (HIP engine): `solve(b, x0, ref, nbr, zu) -> (status, zu [7, N])`.
     Asserted for every instance of the fixture:
       * the engine's trajectory satisfies the GEOMETRIC statement of the reference's constraints (polygon distance >= dmin,
@@ -212,9 +212,15 @@ def check_against_independent(solve, tight_tol, prod, fixture="mpc_independent.n
         (kind 3 rows), with nine active rows (instance 7 of the first fixture), with an intruder's corner in the path;
       * `better`: instances where the engine ends at a DIFFERENT local optimum that is cheaper than the independent solver's
         (the problems are not convex; SLSQP started at the engine's point stays there): only feasibility is asserted;
-      * `fails`: instances the engine does NOT solve (status != 0, so the caller takes the reference's fallback): warm starts
-        0.3-0.5 m inside an obstacle's clearance, which need a restoration phase the engine does not have.  Asserted as
-        failures so that a silent wrong answer cannot hide there.
+      * `fails`: instances the engine does NOT solve (status != 0, so the caller takes the reference's fallback).  Asserted as
+        failures so that a silent wrong answer cannot hide there.  (Round 3 had two: warm starts 0.3-0.5 m inside an obstacle's
+        clearance.  With the dual regularisation of the rows and the restoration phase of round 4 there are none.)
+      * `stuck`: instances where the engine ends at a point that is feasible only WITHIN the production tolerance and dearer than
+        the independent optimum: it converges there (status 0) at constr_viol_tol = 1e-2 and reports local infeasibility (status 5,
+        after a failed restoration) at tight tolerances.  mpc_independent_turn.npz 13: the body's corner passes an obstacle 1.6 mm
+        inside the clearance at stage 4, with the steering rate of the stages before it at its bound -- SLSQP started from that point
+        cannot remove the 1.6 mm either (oracle/independent_mpc.py: status 8, violation unchanged), the independent optimum turns
+        in two stages earlier.  Asserted: status, feasibility within 1e-2, cost within 30 % of the independent optimum.
     Tight mode accepts status 2 (line search exhausted at the rounding floor of the merit function) next to 0: what says
     "optimal" here are the comparisons, not the engine's own verdict."""
     from oracle import independent_mpc as im
@@ -225,6 +231,13 @@ def check_against_independent(solve, tight_tol, prod, fixture="mpc_independent.n
         status, z = solve(b, d["x0"][b], d["ref"][b], d["nbr"][b], d["zu"][b])
         if b in fails:
             assert status != 0, (b, status)
+            continue
+        if b in stuck:
+            assert status == (0 if prod else 5), (b, status)
+            nlp = im.GeometricMpc(ospec, d["x0"][b], d["ref"][b], d["nbr"][b])
+            X = z.T.ravel()
+            assert np.abs(nlp.eq(X)).max() < 1e-2 and -1e-2 < nlp.ineq(X).min() < -1e-4, b
+            assert 0.0 < (nlp.cost(X) - d["cost"][b]) / d["cost"][b] < 0.3, b
             continue
         assert status == 0 or (status == 2 and not prod), (b, status)
         nlp = im.GeometricMpc(ospec, d["x0"][b], d["ref"][b], d["nbr"][b])
@@ -263,9 +276,12 @@ def test_full_size_instances_against_the_independent_solver(prod):
     check_against_independent(solve, 1e-4, prod)
 
 
-# fixture -> (instances where the engine's local optimum is CHEAPER than the independent solver's (0.44 %, 2.7 %),
-#             instances the engine fails on (status 2; no restoration phase))
-POPULATIONS = {"mpc_independent_more.npz": ((18, 25), ()), "mpc_independent_obs.npz": ((), ()), "mpc_independent_turn.npz": ((), (0, 13))}
+# fixture -> (instances where the engine's local optimum is CHEAPER than the independent solver's (0.44 %, 2.7 %; 70 % on the turning
+#             instance whose start is 0.5 m inside a clearance: the restoration phase finds a way round the box that SLSQP does not --
+#             SLSQP started from the engine's optimum stays there),
+#             instances the engine fails on (none since round 4),
+#             instances where it stops at a point feasible only within the production tolerance (see check_against_independent))
+POPULATIONS = {"mpc_independent_more.npz": ((18, 25), (), ()), "mpc_independent_obs.npz": ((), (), ()), "mpc_independent_turn.npz": ((0,), (), (13,))}
 
 
 @pytest.mark.parametrize("fixture", sorted(POPULATIONS))
@@ -278,8 +294,8 @@ def test_population_against_the_independent_solver(prod, fixture):
         parking-lot furniture (static obstacles active);
       mpc_independent_turn.npz (make_independent_turn.py): 24 turning references pushed 0.1-1.6 m sideways (corners swung past
         static boxes, six vertex-vertex contacts with them).
-    76 of 80 are solved to the independent optimum; on two the engine ends at a cheaper local optimum; two (warm starts half a
-    metre inside a clearance) it fails on with status 2.  (The first population is
+    76 of 80 are solved to the independent optimum; on three the engine ends at a cheaper local optimum; on one at a point that is
+    feasible only within the production tolerance (`stuck`).  None fails (round 3: two, warm starts half a metre inside a clearance).  (The first population is
     what found two defects of the first vertex-vertex implementation: the kept vertex pair of a face was compared by its first
     entry instead of its minimum, and the filter kept entries of the previous working set.)"""
     from oracle import port
@@ -291,7 +307,7 @@ def test_population_against_the_independent_solver(prod, fixture):
         r = port.solve(ospec, x0, ref, nbr, zu.T.copy(), opt)
         return r["status"], r["p"].T
 
-    check_against_independent(solve, 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture][0], fails=POPULATIONS[fixture][1])
+    check_against_independent(solve, 1e-4, prod, fixture=fixture, better=POPULATIONS[fixture][0], fails=POPULATIONS[fixture][1], stuck=POPULATIONS[fixture][2])
 
 
 def test_face_normal_certificates_alone_are_a_restriction():
