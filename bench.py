@@ -13,8 +13,11 @@ region.  N GPUs = N independent shards of scenarios (weak scaling, no data-path 
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, `roofline`
 (algorithmic HBM bytes of SURVEY.md 8d / measured solver-kernel time, plus the FP64 and VALU-active fractions),
-`value_converged` (status-0 solves only), `cold_step` (the first MPC iteration, cold multipliers) and `cpu_baseline`
-(oracle/cfz_port.c, the plain-C port, running the SAME closed loop on this host's cores; N=1 only).
+`value` = CONVERGED solves per second (status 0; `value_all` counts every solve of the timed region, also those that did no work:
+`config.status_counts`), `cold_step` (the first MPC iteration, cold multipliers), `extra.seeds` (the same measurement on three sampler
+seeds, outside the timed region: the launch lasts as long as its slowest scenario, a maximum of 1024 draws), `extra.all_moving` (no
+parked vehicle in the sample; `config.parked_fraction` says how many solves of the headline are for one) and `cpu_baseline`
+(oracle/cfz_port.c, the plain-C port, running the SAME closed loop on this host's usable cores; N=1 only).
 """
 import argparse
 import json
@@ -45,7 +48,8 @@ def _cpu_closed_loop_worker(args):
     from oracle.mpc_nlp import MpcSpec
 
     spec = scenarios.parking_lot_spec()
-    table, _ = scenarios.load_reference_table(kind=ref_kind)
+    # ref_kind: "planned" / "state_ws" (package data) or the path of an .npz with the table the GPU run uses (--reference replan)
+    table = np.load(ref_kind)["table"] if ref_kind.endswith(".npz") else scenarios.load_reference_table(kind=ref_kind)[0]
     ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)
     k0, noise = scenarios.sample_scenarios(n_scen, table, seed=seed, spec=spec if feasible else None)
     n = its = ok = 0
@@ -61,6 +65,37 @@ def _cpu_closed_loop_worker(args):
     return n, its, ok, time.perf_counter() - t0, cold
 
 
+def usable_cores():
+    """(cores this job can really use, description): the affinity mask capped by the cgroup's CPU quota (a GPU box shows 256 logical
+    cores to a job whose quota is a fraction of them: 64 processes were measured slower than 16 there), and the CPU model."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n = aff if quota is None else max(1, min(aff, int(np.ceil(quota))))
+    return n, {"logical": os.cpu_count(), "affinity": aff, "cgroup_quota_cores": quota, "model": model}
+
+
 def casadi_probe():
     """the reference's own CPU path is CasADi + IPOPT.  Report what importing it on THIS host does."""
     try:
@@ -71,20 +106,18 @@ def casadi_probe():
         return f"CasADi unavailable on this host: {type(e).__name__}: {e}"
 
 
-def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16, ref_kind="planned", feasible=True):
+def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=64, ref_kind="planned", feasible=True):
     """`cpu_baseline` of the bench line: the oracle's C port ("kind": "port") on the host cores, like for like with the
     GPU's timed region -- the closed loop after `warmup` iterations, carried multipliers -- on a bounded sample of the same
-    scenario sampler (32 scenarios x 4 vehicles per process; about 40 s of CPU time in all).  16 processes: the job's CPU
-    quota on the GPU boxes is about that (measured: 16 processes 17.4 k solves/s, 64 processes 15.6 k).  One process per usable core (the job's CPU
-    quota is usually far below the logical core count: the affinity mask says what is usable), at most `max_cores`."""
+    scenario sampler (about 512 scenarios x 4 vehicles in all, at most 32 per process).  One process per USABLE core (`usable_cores`:
+    affinity mask capped by the cgroup quota; the GPU boxes show 256 logical cores to a job that may use a fraction of them -- 16
+    processes measured 17.4 k solves/s there, 64 processes 15.6 k), at most `max_cores`; the CPU model is reported with it."""
     import concurrent.futures as cf
     import multiprocessing as mp
 
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
+    usable, cpu_info = usable_cores()
     cores = max(1, min(max_cores, usable))
+    n_scen_per_core = max(4, min(n_scen_per_core, 512 // cores))  # the sample stays bounded: about 512 scenarios in all
     jobs = [(2024 + 1000 * i, n_scen_per_core, warmup, steps, ref_kind, feasible) for i in range(cores)]
     t_wall = time.perf_counter()
     try:
@@ -105,7 +138,8 @@ def cpu_baseline(warmup, steps, n_scen_per_core=32, max_cores=16, ref_kind="plan
            "per_core": n / slow / cores,
            "sample": f"closed loop, {cores} processes x {n_scen_per_core} scenarios x 4 vehicles, {warmup} warm-up + {steps} timed MPC "
                      f"iterations with carried multipliers = {n} timed solves, slowest worker {slow:.1f} s (wall incl. start-up {t_wall:.0f} s); "
-                     f"{os.cpu_count()} logical cores on the host, {usable} usable by this job",
+                     f"{os.cpu_count()} logical cores on the host, {usable} usable by this job (affinity mask and cgroup quota)",
+           "cpu": cpu_info,
            "cold_step": {"value": cn / ct, "unit": "solves/s", "mean_ipm_iters": ci / max(cn, 1),
                          "sample": f"first MPC iteration of the same scenarios (cold multipliers), {cn} solves"},
            "casadi": casadi_probe(),
@@ -242,6 +276,18 @@ def planning_extras(device=0, B=256, cpu=True):
         "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg / t_col / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / t_col / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes": "3 x band bytes (nk x (3 kb + 1) x 8: %s) x iterations of every plan" % {a: band[a][2] for a in agents}}}
+    # configs[1] as BASELINE.json words it: FOUR polytope obstacles (0, 1, 3, 4 of the reference's six) -- the same B plans'
+    # collocation refinement again on that map (state_ws does not see the obstacles: the tube keeps the vehicle off them)
+    sp4 = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=4)
+    gs = {k: guess_of(ws[k]["traj"], len(tubes[who[k]]) + 1) for k in good}
+    t0 = time.perf_counter()
+    r4 = engine.colloc(sp4, [init[k] for k in good], [tubes[who[k]] for k in good], [gs[k][0] for k in good], [gs[k][1] for k in good],
+                       [fh[who[k]] for k in good], max_iter=400, device=device)
+    t_col4 = time.perf_counter() - t0
+    out["configs[1]"]["four_obstacles"] = {
+        "workload": f"the same {B} plans with BASELINE.json's 4 polytope obstacles (0, 1, 3, 4 of the reference's six)",
+        "plans_per_s": B / (t_ws + t_col4), "colloc_s": t_col4, "colloc_converged": sum(r["status"] == 0 for r in r4),
+        "colloc_iters_mean": float(np.mean([r["iters"] for r in r4]))}
     # ---- configs[3] ------------------------------------------------------------------------------------------------------------
     idx = list(range(4 * B))
     ws4, good4, plans4, _, _ = single_plans(idx)
@@ -265,6 +311,7 @@ def planning_extras(device=0, B=256, cpu=True):
         "roofline": {"bound": "hbm", "kernel": "colloc_kernel<2>", "achieved": alg4 / t_joint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg4 / t_joint / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes": "3 x band bytes x iterations of every plan"}}
+    engine.trim_default_workspaces()  # a 256-plan joint launch leaves 25 GB in the calling thread's workspace
     if cpu:
         try:
             out["configs[1]"]["cpu_baseline"], out["configs[3]"]["cpu_baseline"] = planning_cpu_baseline(agents, sets, paths, fh)
@@ -336,6 +383,7 @@ def main():
                          "data/refs_4v.npz, the slower state_ws warm-start plans (the table of rounds 1-2); replan: build the planned table "
                          "at start-up with the GPU planning chain instead of loading it")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] planning measurements after the timed region")
+    ap.add_argument("--no-seeds", action="store_true", help="skip the three-seed and all-moving repetitions of the headline after the timed region")
     ap.add_argument("--raw-starts", action="store_true",
                     help="take the sampler's starts as they come (rounds 1-2); default: a scenario whose noisy start state is already "
                          "inside a clearance (an infeasible first NLP, status 4) is drawn again")
@@ -362,7 +410,7 @@ def main():
     spec = scenarios.parking_lot_spec(n_obs=4 if single else args.n_obs, n_nbr=0 if single else 3)
     V = spec.n_nbr + 1
     if args.reference == "replan":
-        table, _, plan_info = scenarios.planned_reference_table(device=local_rank)
+        table, lengths, plan_info = scenarios.planned_reference_table(device=local_rank)
         ref_desc = ("built at start-up by the GPU planning chain (cfz_state_ws -> cfz_colloc, VehicleFollower.plan_single_path): "
                     + ", ".join(f"{a} {i['t_end']:.1f} s" for a, i in plan_info.items()))
     elif args.reference == "planned":
@@ -371,7 +419,7 @@ def main():
                     "cfz_colloc as in VehicleFollower.plan_single_path, free dt), sampled every 0.1 s: "
                     + ", ".join(f"vehicle_{i} {0.1 * (n - 1):.1f} s" for i, n in enumerate(lengths)) + " (SURVEY.md 8d config 3)")
     else:
-        table, _ = scenarios.load_reference_table(kind="state_ws")
+        table, lengths = scenarios.load_reference_table(kind="state_ws")
         ref_desc = ("conflict_rez_amd/data/refs_4v.npz: the four vehicles' Vehicle.state_ws plans of the synthetic strategy "
                     "(tube-constrained warm-start trajectories, 18-30 s)")
     if single:
@@ -379,7 +427,7 @@ def main():
     S = args.scenarios
     fspec = None if (args.raw_starts or single) else spec
     k0, noise = scenarios.sample_scenarios(S, table, seed=args.seed + rank, spec=fspec)
-    infeasible_starts = None if single else int((scenarios.start_clearances(spec, table, k0, noise) < spec.dmin - 0.02).any(1).sum())
+    lengths_v = lengths  # samples of every vehicle's plan (it is parked at its goal after that)
     vehicle_sharded = args.parallelism == "vehicle"
     if vehicle_sharded:
         if dist is None or single:
@@ -389,7 +437,7 @@ def main():
         # scenarios x world in total: every rank steps its vehicles (V / world of them, or one vehicle of a scenario shard when
         # there are more ranks than vehicles) -> the same number of solves per GPU as in scenario sharding
         S_total = args.scenarios * world
-        k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed, spec=fspec)
+        k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed, spec=fspec)  # (every rank holds all scenarios' starts)
         ex = VehicleShardedExchange(V)
         S = len(range(S_total)[ex.scenarios(S_total)])
         eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)
@@ -398,6 +446,18 @@ def main():
     else:
         eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter)
         eng.loop_init(table, k0, noise)
+
+    # what the sampler handed out, counted on the starts that are actually used
+    infeasible_starts = None if single else int(((scenarios.start_clearances(spec, table, k0, noise) < spec.dmin - 0.01).any(1)
+                                                 | (scenarios.start_box_excess(spec, table, k0, noise) > 1e-2).any(1)).sum())
+
+    def parked_fraction(k0_, t_first, t_count):
+        """Share of the (scenario, vehicle, MPC iteration) triples of a closed-loop window whose vehicle has reached the end of its
+        plan (it then holds its goal pose: one or two interior-point iterations per solve)."""
+        if lengths_v is None or single:
+            return None
+        tt = np.arange(t_first, t_first + t_count)
+        return float((np.asarray(k0_)[:, None, None] + tt[None, None, :] >= (np.asarray(lengths_v)[None, :, None] - 1)).mean())
 
     def barrier():
         if dist is not None:
@@ -428,6 +488,7 @@ def main():
     kernel_ms = 0.0
     n_ok = 0
     n_conv = None  # converged solves of the timed region (persistent mode counts them on the device)
+    status_counts = None  # ... and how all of them ended
     if vehicle_sharded:
         ipm_iterations = 0
         for _ in range(args.steps):
@@ -439,6 +500,7 @@ def main():
         ipm_iterations = eng.loop_run(args.steps)  # K iterations of every scenario, one launch
         kernel_ms = eng.last_solve_ms()
         n_conv = eng.loop_last_converged()
+        status_counts = eng.loop_last_status_counts()
         launches = 1
     else:
         ipm_iterations = 0
@@ -465,10 +527,15 @@ def main():
         t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
-        c = torch.tensor([n_ok, -1 if n_conv is None else n_conv], device="cuda", dtype=torch.int64)
+        c = torch.tensor([n_ok, -1 if n_conv is None else n_conv, 1] + ([0] * 6 if status_counts is None else [int(x) for x in status_counts]),
+                         device="cuda", dtype=torch.int64)
         dist.all_reduce(c)
         n_ok = int(c[0])
         n_conv = None if n_conv is None else int(c[1])
+        rccl_ranks = int(c[2])  # an all-reduce of ones over RCCL: the ranks that took part in this measurement
+        status_counts = None if status_counts is None else c[3:9].cpu().numpy()
+    else:
+        rccl_ranks = None
 
     out_line = None
     if rank == 0:
@@ -485,8 +552,10 @@ def main():
         fp64_tflops = (ipm_iterations * FLOP_PER_IPM_ITERATION / (kernel_ms / 1e3) / 1e12) if ipm_iterations else None
         line = {
             "metric": "OBCA MPC-step solves/sec (4 vehicles, N=30)",
-            "value": solves / elapsed,
-            "value_converged": (n_conv / elapsed) if n_conv is not None else None,
+            # converged solves only (status 0); persistent mode counts them on the device over the whole timed region, the other
+            # modes know the last iteration's share only and scale by it
+            "value": (n_conv / elapsed) if n_conv is not None else solves / elapsed * (n_ok / (B * world)),
+            "value_all": solves / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -505,11 +574,18 @@ def main():
                        "parallelism": (f"vehicle-sharded x{world} ({len(ex.owned)} vehicle(s) x 1/{ex.n_shards} of the scenarios per rank), "
                                        f"RCCL all-gather of predictions inside groups of {ex.group_size} ranks per iteration" if vehicle_sharded
                                        else f"scenario-sharded x{world}"),
+                       "rccl_ranks": rccl_ranks,
+                       "status_counts": None if status_counts is None else
+                                        dict(zip(("0 converged", "1 iteration limit", "2 line search", "3 non-finite",
+                                                  "4 measured state infeasible (no iteration)", "5 stalled / locally infeasible"),
+                                                 (int(x) for x in status_counts))),
+                       "parked_fraction": parked_fraction(k0[ex.scenarios(len(k0))] if vehicle_sharded else k0, args.warmup, args.steps),
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
                        "converged_timed_region": (n_conv / solves) if n_conv is not None else None,
                        "reference_plan": ref_desc,
                        "infeasible_starts": infeasible_starts,
-                       "starts": "raw sampler draws" if fspec is None else "scenarios whose noisy start state violates a clearance are drawn again",
+                       "starts": "raw sampler draws" if fspec is None else
+                                 "scenarios whose noisy start state violates a clearance or lies outside the NLP's state boxes (an infeasible first NLP) are drawn again",
                        "ipm_iterations_rank0": ipm_iterations,
                        "mean_ipm_iters_timed_region": (ipm_iterations / (B * args.steps)) if ipm_iterations else None,
                        "mean_ipm_iters_last_step": iters_mean, "scenario_steps_per_s": solves / elapsed / V,
@@ -529,14 +605,50 @@ def main():
         }
         if cold is not None:
             line["cold_step"] = cold
+        if world == 1 and persistent and not single and not vehicle_sharded and not args.no_seeds:
+            # ---- the same measurement on other samples, OUTSIDE the timed region (same process, same engine) ------------------------
+            def closed_loop_sample(k0_, noise_):
+                eng.loop_init(table, k0_, noise_)
+                if args.warmup > 0:
+                    eng.loop_run(args.warmup)
+                t1 = time.perf_counter()
+                its = eng.loop_run(args.steps)
+                dt_ = time.perf_counter() - t1
+                sc, n = eng.loop_last_status_counts(), S * V * args.steps
+                return {"value": float(sc[0] / dt_), "value_all": n / dt_, "ms_per_step": dt_ / args.steps * 1e3, "converged": float(sc[0] / n),
+                        "mean_ipm_iters": its / n, "status_counts": [int(x) for x in sc],
+                        "parked_fraction": parked_fraction(k0_, args.warmup, args.steps)}
+
+            extra = line.setdefault("extra", {})
+            try:
+                seeds = [2024, 2025, 2026]
+                runs = [closed_loop_sample(*scenarios.sample_scenarios(S, table, seed=sd, spec=fspec)) for sd in seeds]
+                vals = sorted(r["value"] for r in runs)
+                extra["seeds"] = {"what": "the headline's measurement (warm-up + timed persistent launch, converged solves per second) on three "
+                                          "sampler seeds: a launch lasts as long as its slowest scenario's chain of interior-point iterations, "
+                                          "the maximum of 1024 draws",
+                                  "seeds": seeds, "median": vals[1], "min": vals[0], "max": vals[2], "runs": runs}
+                if lengths_v is not None:
+                    margin = table.shape[1] - (int(min(lengths_v)) - 30 - (args.warmup + args.steps))
+                    k0m, nzm = scenarios.sample_scenarios(S, table, seed=args.seed, horizon_margin=margin, spec=fspec)
+                    extra["all_moving"] = dict(closed_loop_sample(k0m, nzm),
+                                               what=f"start samples k0 < {table.shape[1] - margin}: no vehicle reaches the end of its plan "
+                                                    f"(the shortest has {int(min(lengths_v))} samples) within the {args.warmup + args.steps} MPC iterations")
+            except Exception as e:  # noqa: BLE001 - the headline must go out whatever happens here
+                extra["seeds_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_extras and not single and not vehicle_sharded:
             try:
-                line["extra"] = planning_extras(device=local_rank, cpu=not args.no_cpu_baseline)
+                line.setdefault("extra", {}).update(planning_extras(device=local_rank, cpu=not args.no_cpu_baseline))
             except Exception as e:  # noqa: BLE001 - the headline must go out whatever happens here
-                line["extra"] = {"error": f"{type(e).__name__}: {e}"}
+                line.setdefault("extra", {})["error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline and not single:
-            line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps, ref_kind="state_ws" if args.reference == "state_ws" else "planned",
-                                                feasible=fspec is not None)
+            ref_kind = args.reference
+            if args.reference == "replan":  # the workers get the table this run built, not the packaged one
+                import tempfile
+
+                ref_kind = os.path.join(tempfile.mkdtemp(), "table.npz")
+                np.savez(ref_kind, table=table)
+            line["cpu_baseline"] = cpu_baseline(max(args.warmup, 1), args.steps, ref_kind=ref_kind, feasible=fspec is not None)
             cb = line["cpu_baseline"]
             if ipm_iterations:  # like for like: IPM iterations per second, GPU : all usable host cores : one core
                 line["gpu_vs_cpu"] = {"ipm_iterations_per_s_gpu": ipm_iterations * world / elapsed,

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
       stats[b * 3] = od[0]; stats[b * 3 + 1] = od[1]; stats[b * 3 + 2] = od[2];
       atomicAdd(iter_sum, oi[0]);
       if (oi[1] == 0) atomicAdd(iter_sum + 1, 1);  // converged solves of this launch
+      atomicAdd(iter_sum + 2 + (oi[1] < 0 ? 0 : (oi[1] > 5 ? 5 : oi[1])), 1);  // ... and how every solve of it ended (status 0..5)
     }
     // release: prediction and state of (s, v, t).  Every storing wavefront drains its stores, the workgroup meets, one
     // lane writes the XCD's L2 back and only then signals (the asm wait keeps the compiler from dropping the drain).
@@ -535,7 +536,7 @@ struct cfz_handle {
   double *pred2 = nullptr, *scratch = nullptr;
   int32_t *queue = nullptr, *ctrl = nullptr, *done = nullptr, *iter_sum = nullptr;
   int queue_cap = 0, grid_blocks = 0, steps_done = 0;
-  long last_iter_sum = 0, last_converged = 0;
+  long last_iter_sum = 0, last_converged = 0, last_status[6] = {0, 0, 0, 0, 0, 0};
   CfzArena arena;  // device buffers of cfz_dual_ws / cfz_joint_dual_ws, kept between calls
 };
 
@@ -983,7 +984,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
   const size_t per_block = 5 + 3 * (size_t)N + (size_t)h->ks.n_nbr * 3 * N + 7 * (size_t)N;
   if (!h->pred2) {
     HIP_OK(hipMalloc(&h->pred2, (size_t)2 * B * 7 * N * 8)); HIP_OK(hipMalloc(&h->ctrl, (4 + 1024) * 4));
-    HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 8));
+    HIP_OK(hipMalloc(&h->done, (size_t)S * 4)); HIP_OK(hipMalloc(&h->iter_sum, 32));
   }
   if (h->grid_blocks < grid) {
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1006,7 +1007,7 @@ int cfz_loop_run(cfz_handle *h, int K) {
     const int32_t ctrl0[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof ctrl0, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipMemsetAsync(h->done, 0, (size_t)S * 4, h->stream));
-    HIP_OK(hipMemsetAsync(h->iter_sum, 0, 8, h->stream));
+    HIP_OK(hipMemsetAsync(h->iter_sum, 0, 32, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));  // `first` and `ctrl0` are host temporaries
   }
   HIP_OK(hipEventRecord(h->ev0, h->stream));
@@ -1048,10 +1049,11 @@ int cfz_loop_run(cfz_handle *h, int K) {
   HIP_OK(hipStreamSynchronize(h->stream));
   HIP_OK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   h->ms_pending = false;
-  int32_t ctrl[4] = {0, 0, 0, 0}, isum[2] = {0, 0};
+  int32_t ctrl[4] = {0, 0, 0, 0}, isum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_OK(hipMemcpy(ctrl, h->ctrl, sizeof ctrl, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(isum, h->iter_sum, 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(isum, h->iter_sum, 32, hipMemcpyDeviceToHost));
   h->last_iter_sum = isum[0]; h->last_converged = isum[1];
+  for (int i = 0; i < 6; ++i) h->last_status[i] = isum[2 + i];
   h->have_order = false;
   if (ctrl[2]) return fail("persistent loop kernel timed out waiting for a work item");
   return 0;
@@ -1059,6 +1061,11 @@ int cfz_loop_run(cfz_handle *h, int K) {
 
 long cfz_loop_last_iterations(const cfz_handle *h) { return h ? h->last_iter_sum : -1; }
 long cfz_loop_last_converged(const cfz_handle *h) { return h ? h->last_converged : -1; }
+int cfz_loop_last_status_counts(const cfz_handle *h, long counts[6]) {
+  if (!h || !counts) return fail("null argument");
+  for (int i = 0; i < 6; ++i) counts[i] = h->last_status[i];
+  return 0;
+}
 
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters) {
   if (!h || !h->pred) return fail("cfz_loop_init has not been called");

@@ -373,9 +373,13 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     const long long avail = ((long long)lds_max - (long long)fa.sharedSizeBytes) / 8;
     const long long pl = kb_max <= cfzc::kWideMaxKb ? (long long)CFZ_PANEL * (kb_max + CFZ_PANEL) : 0;
     const int lds_rhs = nk_max <= avail ? nk_max : 0;
-    const int lds_doubles = (int)std::max<long long>(pl <= avail ? pl : 0, lds_rhs);
-    if (lds_doubles) HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8));
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs);
+    int lds_doubles = (int)std::max<long long>(pl <= avail ? pl : 0, lds_rhs), lds_rhs_ = lds_rhs;
+    if (lds_doubles && hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8) != hipSuccess) {
+      // a runtime whose per-workgroup limit really is the smaller figure: the kernel also runs without dynamic LDS
+      (void)hipGetLastError();
+      lds_doubles = 0; lds_rhs_ = 0;
+    }
+    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs_);
   }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);
@@ -431,7 +435,11 @@ int cfz_joint_colloc_w(cfz_plan_ws *w, int B, int V, const cfz_spec *spec, const
                        int n_pairs, const int32_t *pairs, double *traj, double *dt, int32_t *status, int32_t *iters, double *cost) {
   if (B < 1 || V < 1 || !spec || !co || !n_sets || !init_pose || !tube || !guess || !dt0 || !traj || !dt || n_pairs < 0) return fail("bad argument");
   std::vector<std::pair<int, int>> pr;
-  if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  if (pairs && V < 2) return fail("vehicle pairs need at least two vehicles");
+  if (pairs) for (int e = 0; e < n_pairs; ++e) {
+    if (pairs[2 * e] < 0 || pairs[2 * e] >= pairs[2 * e + 1] || pairs[2 * e + 1] >= V) return fail("bad vehicle pair");  // as colloc_run: 0 <= a < b < V
+    pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  }
   else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});  // :56-58 all pairs
   std::vector<std::vector<std::pair<int, int>>> all((size_t)B, pr);
   std::vector<int32_t> nv((size_t)B, V);
@@ -449,7 +457,11 @@ int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final,
     p.n_chk[a] = n_sets[a] - 1; p.N[a] = N_per_set * p.n_chk[a]; p.has_final[a] = has_final ? (has_final[a] != 0) : 1;
   }
   std::vector<std::pair<int, int>> pr;
-  if (pairs) for (int e = 0; e < n_pairs; ++e) pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  if (pairs && V < 2) return fail("vehicle pairs need at least two vehicles");
+  if (pairs) for (int e = 0; e < n_pairs; ++e) {
+    if (pairs[2 * e] < 0 || pairs[2 * e] >= pairs[2 * e + 1] || pairs[2 * e + 1] >= V) return fail("bad vehicle pair");  // as colloc_run: 0 <= a < b < V
+    pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  }
   else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});
   if ((int)pr.size() > cfzc::kMaxPairs) return fail("problem size outside compiled limits");
   p.n_pairs = (int)pr.size();

@@ -876,7 +876,7 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const double sg = m[L.sg + 2 * t + r] + alpha * m[L.dsg + 2 * t + r];
-        th += fabs(sep[r] - sp.dmin - sg);
+        if (k > 0) th += fabs(sep[r] - sp.dmin - sg);  // (the rows of stage 0 are constants: no part of the violation)
         if (!(sg > 0.0)) bad = 1.0; else lprod *= sg;
       }
     }
@@ -1567,7 +1567,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     CFZ_P(shf, 0) = 0.0;
   CFZ_END
   // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
-  // than 2*constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
+  // than constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
   CFZ_LANES(tid)
     double worst = INFINITY;
     if (tid < nb) {
@@ -1589,7 +1589,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     const double v = CFZ_UNIFORM(m[L.x0 + bcol(q)]);
     x0_out = x0_out || v < sp.bounds[2 * q] - sp.constr_viol_tol || v > sp.bounds[2 * q + 1] + sp.constr_viol_tol;
   }
-  if (ro[0] < sp.dmin - 2.0 * sp.constr_viol_tol || x0_out) {
+  if (ro[0] < sp.dmin - sp.constr_viol_tol || x0_out) {
     out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = ro[0];
     if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
     return;
@@ -1728,8 +1728,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           } else {
             block_sep(sp, m, L, k, j, c1, x, y, cn, sn, sep);
           }
+          // (the rows of stage 0 are constants: its pose is the measurement.  Satisfied, or violated by less than constr_viol_tol --
+          // the pre-check above -- they take no part in the iteration: zero residual here, zero gradient below.  As rows of the variable
+          // z_0 they fought the initial-state row whenever a parked vehicle sat a centimetre inside a clearance.)
           for (int r = 0; r < 2; ++r) {
-            const double c = sep[r] - sp.dmin - m[L.sg + 2 * t + r];
+            const double c = k == 0 ? 0.0 : sep[r] - sp.dmin - m[L.sg + 2 * t + r];
             m[L.cj + 2 * t + r] = c;
             cmax = fmax(cmax, fabs(c)); csum += fabs(c);
           }
@@ -1774,6 +1777,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         for (int jb = sub; jb < nb; jb += kLPS) {
           double a0, a1, ap[2];
           block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cpsi, spsi, a0, a1, ap);
+          if (k == 0) { a0 = 0.0; a1 = 0.0; ap[0] = 0.0; ap[1] = 0.0; }  // the rows of stage 0 are constants
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             const double nu = m[L.nuc + t], zs = m[L.zs + t], sg = m[L.sg + t];
@@ -1881,6 +1885,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           const int sl = sel_ptr(m, L)[k * nb + jb];
           double a0, a1, bap[2];
           block_grad(sp, m, L, k, jb, sl, pk[0], pk[1], cpsi, spsi, a0, a1, bap);
+          if (k == 0) { a0 = 0.0; a1 = 0.0; bap[0] = 0.0; bap[1] = 0.0; }  // the rows of stage 0 are constants
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             // delta_c on the row (IPOPT's dual regularisation, eliminated together with the slack): the row's stiffness is
@@ -1892,7 +1897,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             ac[0] += a0 * coef; ac[1] += a1 * coef; ac[2] += a2 * coef;
             ac[3] += S * a0 * a0; ac[4] += S * a1 * a1; ac[5] += S * a2 * a2;
             ac[6] += S * a0 * a1; ac[7] += S * a0 * a2; ac[8] += S * a1 * a2;
-            if (sp.row_curvature) {
+            if (sp.row_curvature && k > 0) {
               const int f = (sl >> 4) & 3, v = r_ ? (sl & 3) : ((sl >> 2) & 3);
               const double nu = m[L.nuc + t];
               if ((sl >> 6) == 3) {
@@ -1993,6 +1998,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         for (int jb = sub; jb < nb; jb += kLPS) {
           double ba0, ba1, bap[2];
           block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cps, sps, ba0, ba1, bap);
+          if (k == 0) { ba0 = 0.0; ba1 = 0.0; bap[0] = 0.0; bap[1] = 0.0; }  // the rows of stage 0 are constants
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;

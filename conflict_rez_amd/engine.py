@@ -150,6 +150,7 @@ def load_library(path=None):
     lib.cfz_vsl_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cfz_loop_last_converged.argtypes = [vp]
     lib.cfz_loop_last_converged.restype = C.c_long
+    lib.cfz_loop_last_status_counts.argtypes = [vp, vp]
     lib.cfz_loop_get.argtypes = [vp, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -157,7 +158,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_vsl_step "
+    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_loop_last_status_counts cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -513,6 +514,12 @@ class Engine:
     def loop_last_converged(self):
         """Solves of the last `loop_run` that converged (status 0)."""
         return int(self.lib.cfz_loop_last_converged(self._h))
+
+    def loop_last_status_counts(self):
+        """How the solves of the last `loop_run` ended: [6] counts of status 0..5."""
+        c = np.zeros(6, dtype=np.int64)
+        self._ck(self.lib.cfz_loop_last_status_counts(self._h, c.ctypes.data_as(C.c_void_p)), "cfz_loop_last_status_counts")
+        return c
 
     def loop_get(self):
         S, V, N = self._S, self._V, self.spec.N

@@ -112,7 +112,7 @@ def _quad_distance(P, Q):
 
 def start_clearances(spec: ProblemSpec, table, k0, noise):
     """[S, V]: distance of every vehicle's body at its measured start state (table pose at k0 + noise) from the nearest static
-    obstacle or other vehicle (0 = touching or overlapping).  A vehicle that starts closer than dmin - 2 constr_viol_tol has an
+    obstacle or other vehicle (0 = touching or overlapping).  A vehicle that starts closer than dmin - constr_viol_tol has an
     infeasible first NLP (status 4: the pose of stage 0 is pinned to the measured state, vehicle_follower.py:194-199, :280-290)."""
     S, V = len(k0), table.shape[0]
     x = table[np.arange(V)[None, :], np.asarray(k0)[:, None], :3] + noise[..., :3]  # [S, V, 3]
@@ -147,7 +147,7 @@ def start_box_excess(spec: ProblemSpec, table, k0, noise):
     return out
 
 
-def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0), spec=None, margin=0.02, box_tol=1e-2):
+def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 0.02, 0.05, 0.0), spec=None, margin=0.01, box_tol=1e-2):
     """Start sample k0[S] ~ U[0, T - margin) and state noise [S, V, 5] (sigma_xy 0.05 m,
     sigma_psi 0.02 rad, sigma_v 0.05 m/s).
     spec (optional): only FEASIBLE starts -- a scenario in which some vehicle's measured state is closer than dmin - margin to an

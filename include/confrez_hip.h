@@ -147,8 +147,11 @@ int cfz_mpc_get(cfz_handle *h, int B, double *zu, double *l, double *m, double *
 /* sol.stats() (:481): per-instance outcome.  Any pointer may be NULL.
  * status,iters int32[B]; cost, kkt_err (scaled optimality error E_0), min_sep fp64[B].
  * status: 0 converged (IPOPT Solve_Succeeded); 1 iteration limit; 2 line search failed; 3 non-finite iterate;
- *         4 measured state already violates a collision row by more than 2 constr_viol_tol (no iterations);
- *         5 constraint violation stalled above constr_viol_tol (locally infeasible).  Every status != 0 is what
+ *         4 measured state infeasible: it violates a collision row, or a box on x, y, v, delta, by more than constr_viol_tol
+ *           (stage 0 is pinned to the measurement: no iterations; the rows of stage 0 take no part in the iteration otherwise);
+ *         5 locally infeasible: the constraint violation stalled above constr_viol_tol, the scaled optimality error stalled
+ *           (err_stall_iters), or a restoration phase did not reach its goal (IPOPT: "converged to a point of local infeasibility").
+ *         Every status != 0 is what
  *         the reference sees as an exception from opti.solve() and answers with the shift fallback (:501-524). */
 int cfz_mpc_stats(cfz_handle *h, int B, int32_t *status, int32_t *iters, double *cost, double *kkt_err,
                   double *min_sep);
@@ -344,6 +347,9 @@ int cfz_loop_run(cfz_handle *h, int K);
 long cfz_loop_last_iterations(const cfz_handle *h);
 /* solves of that call that converged (status 0); the others took the reference's shift fallback (:501-524) */
 long cfz_loop_last_converged(const cfz_handle *h);
+/* how the solves of that call ended: counts[s] = solves with status s (0 converged, 1 iteration limit, 2 line search, 3 non-finite,
+ * 4 measured state infeasible (in collision or outside the boxes: no iteration), 5 stalled / locally infeasible) */
+int cfz_loop_last_status_counts(const cfz_handle *h, long counts[6]);
 /* state[S][V][5], pred[S][V][7][N], status int32[S][V] of the last step; NULL to skip. */
 int cfz_loop_get(cfz_handle *h, double *state, double *pred, int32_t *status, int32_t *iters);
 

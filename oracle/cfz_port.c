@@ -336,7 +336,7 @@ static int merit_terms(const cfz_port_spec *sp, const double *x0, const double *
     for (int i = 0; i < 5; ++i) th += fabs(F[i] - p[k + 1][i]);
   }
   eval_rows(sp, nbr, p, sel, sep, 0, 0);
-  for (int k = 0; k < N; ++k)
+  for (int k = 1; k < N; ++k) /* the rows of stage 0 are constants: no part of the violation */
     for (int j = 0; j < nb; ++j) th += fabs(sep[k][j] - sp->dmin - sg[k][j]);
   *theta = th; *phi = ph - mu * lg;
   return isfinite(th) && isfinite(*phi);
@@ -638,7 +638,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         vertex_dist(A, b, V, p0[0][0], p0[0][1], p0[0][2], sp->g, c >> 6, (c >> 4) & 3, d, 0, 0);
         r0[0][j] = fmin(d[(c >> 2) & 3], d[c & 3]);
       }
-      if (r0[0][j] < sp->dmin - 2.0 * sp->constr_viol_tol) {
+      if (r0[0][j] < sp->dmin - sp->constr_viol_tol) {
         stats[0] = 0; stats[1] = 4; fstats[0] = 0.0; fstats[1] = INFINITY; fstats[2] = sp->mu_init;
         if (sep_out) for (int q = 0; q < N * nblk; ++q) sep_out[q] = 0.0;
         if (cert_out) for (int q = 0; q < N * nblk; ++q) cert_out[q] = 0;
@@ -760,8 +760,13 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       rk4_sens(it.p[k], it.p[k] + 5, sp->dt, sp->wb, sp->rk_substeps, Fk[k], Ak[k], Bk[k]);
       for (int i = 0; i < 5; ++i) { dk[k][i] = Fk[k][i] - it.p[k + 1][i]; cviol = fmax(cviol, fabs(dk[k][i])); theta += fabs(dk[k][i]); }
     }
+    /* The pose of stage 0 is the measurement (pinned by z_0 = x0): its rows are constants -- either satisfied or violated by less than
+     * constr_viol_tol (the pre-check above) -- and take no part in the iteration: zero residual, zero gradient.  (As rows of the variable
+     * z_0 they fought the initial-state row whenever a parked vehicle sat a centimetre inside a clearance: both multipliers ran away and
+     * every solve of that vehicle ended in a failed line search after 29 iterations.) */
+    for (int j = 0; j < nb; ++j) { for (int a = 0; a < 3; ++a) gra[0][j][a] = 0.0; for (int a = 0; a < 6; ++a) cur[0][j][a] = 0.0; }
     for (int k = 0; k < N; ++k)
-      for (int j = 0; j < nb; ++j) { cj[k][j] = sep[k][j] - sp->dmin - it.sg[k][j]; cviol = fmax(cviol, fabs(cj[k][j])); theta += fabs(cj[k][j]); }
+      for (int j = 0; j < nb; ++j) { cj[k][j] = k == 0 ? 0.0 : sep[k][j] - sp->dmin - it.sg[k][j]; cviol = fmax(cviol, fabs(cj[k][j])); theta += fabs(cj[k][j]); }
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
     /* dual infeasibility, multiplier sums, complementarity */
     double dual_inf = 0.0, sum_nu = 0.0, sum_z = 0.0, fval = 0.0;

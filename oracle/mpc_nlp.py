@@ -468,6 +468,7 @@ class MpcNlp:
                         m = -(dR @ G_BODY[f])
                         C[k, 0, 2] += n_ * m[0]; C[k, 2, 0] += n_ * m[0]
                         C[k, 1, 2] += n_ * m[1]; C[k, 2, 1] += n_ * m[1]
+        C[0] = 0.0  # the rows of stage 0 are constants (see _cons_jac)
         return C
 
     def new_iterate(self, x, zl, nu, mu, bound_push):
@@ -815,9 +816,13 @@ class MpcNlp:
                     add(r, base[1:] + i, -1.0)
         sep, gr = self.blocks(P)
         kk = np.arange(N)
+        # The pose of stage 0 is the measurement (pinned by z_0 = x0): its rows are constants -- satisfied, or violated by less than
+        # constr_viol_tol (`initial_state_in_collision`) -- and take no part in the iteration: zero residual, zero pose gradient.
+        gr[0] = 0.0
         for j in range(self.nr):
             r = self.c_blk0 + self.nr * kk + j
             cvec[r] = sep[:, j] - sp_.dmin - P[:, NP + j]
+            cvec[r[0]] = 0.0
             for q in range(3):
                 add(r, base + q, gr[:, j, q])
             add(r, base + NP + j, -1.0)
@@ -834,14 +839,14 @@ STATUS_INFEASIBLE_X0 = 4
 
 def initial_state_in_collision(nlp: "MpcNlp", tol):
     """The pose of stage 0 is pinned to the measured state (vehicle_follower.py:194-196); if a
-    collision row is violated there by more than 2*tol the NLP has no feasible point (IPOPT
+    collision row is violated there by more than tol the NLP has no point within constr_viol_tol (IPOPT
     would end in restoration failure and `step()` in its fallback, :501-524)."""
     sp_ = nlp.spec
     for j in range(nlp.nb):
         A, b, PV = nlp.polygon(0, j)
         sel = select_rows(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, 0, vv=sp_.vv_rows)
         sep, _ = rows_for(A, b, PV, nlp.x0[0:2], nlp.x0[2], sp_.g, nlp.BV, sel)
-        if sep.min() < sp_.dmin - 2.0 * tol:
+        if sep.min() < sp_.dmin - tol:
             return True
     # ... and so does a measured state outside the boxes on x, y, v, delta by more than tol (stage 0 is bounded like every other
     # stage, :205-240, and pinned to the measurement, :194-199): e.g. a speed above the limit by the measurement noise

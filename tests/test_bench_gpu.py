@@ -28,15 +28,30 @@ def _run(extra):
 
 @pytest.mark.parametrize("extra", [[], ["--parallelism", "vehicle"]])
 def test_bench_line_through_torch_distributed(extra):
+    """The bench line through torch.distributed on one GPU, both sharding modes: the contract's fields and what round 4 added --
+    `value` counts CONVERGED solves (`value_all` every solve), `config.status_counts` says how the timed solves ended,
+    `config.parked_fraction` how many of them are for a vehicle at the end of its plan, `config.rccl_ranks` (an all-reduce of ones)
+    how many RCCL ranks took part, `extra.seeds` the same measurement on three sampler seeds and `extra.all_moving` a sample without
+    parked vehicles (persistent mode)."""
     b = _run(extra)
     assert b["metric"].startswith("OBCA MPC-step solves/sec") and b["unit"] == "solves/s" and b["n_gpus"] == 1 and b["steps"] == 3 and b["warmup"] == 2
     assert b["value"] > 1e3 and b["scaling"] == "weak" and b["dtype"] == "f64" and b["vs_baseline"] is None
-    assert abs(b["value"] - 64 * 4 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value"]  # value = solves / elapsed
+    assert abs(b["value_all"] - 64 * 4 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value_all"]  # value_all = solves / elapsed
+    assert 0.5 * b["value_all"] < b["value"] <= b["value_all"]  # value = converged solves / elapsed
     c = b["config"]
     assert c["scenarios_per_gpu"] == 64 and c["solves_per_step_per_gpu"] == 256 and c["infeasible_starts"] == 0
     assert ("vehicle-sharded" in c["parallelism"]) == bool(extra) and "refs_4v_planned" in c["reference_plan"]
+    assert c["rccl_ranks"] == 1 and 0.2 < c["parked_fraction"] < 0.7
     r = b["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["kernel"] == ("solve_kernel" if extra else "loop_kernel")
+    if not extra:  # persistent launch: counted on the device over the whole timed region
+        sc = c["status_counts"]
+        assert sum(sc.values()) == 64 * 4 * 3 and abs(b["value"] / b["value_all"] - sc["0 converged"] / (64 * 4 * 3)) < 1e-9
+        assert abs(c["converged_timed_region"] - sc["0 converged"] / (64 * 4 * 3)) < 1e-12
+        sd, am = b["extra"]["seeds"], b["extra"]["all_moving"]
+        assert sd["seeds"] == [2024, 2025, 2026] and sd["min"] <= sd["median"] <= sd["max"] and len(sd["runs"]) == 3
+        assert all(sum(r_["status_counts"]) == 64 * 4 * 3 and r_["value"] <= r_["value_all"] for r_ in sd["runs"])
+        assert am["parked_fraction"] == 0.0 and am["value"] > 1e3 and am["mean_ipm_iters"] > sd["runs"][0]["mean_ipm_iters"]
 
 
 def test_long_persistent_launch_at_4096_scenarios():
@@ -60,6 +75,7 @@ def test_planning_extras_of_the_bench_line():
     ex = bench.planning_extras(device=0, B=8, cpu=False)
     c1, c3 = ex["configs[1]"], ex["configs[3]"]
     assert c1["state_ws_converged"] == 8 and c1["colloc_converged"] == 8 and c1["plans_per_s"] > 1.0
+    assert c1["four_obstacles"]["colloc_converged"] == 8 and c1["four_obstacles"]["plans_per_s"] > 1.0  # configs[1] as BASELINE.json words it
     assert c3["converged"] == 8 and c3["unknowns"] == 12350 and c3["half_bandwidth"] == 298 and c3["band_bytes"] == 12350 * (3 * 298 + 1) * 8
     for c in (c1, c3):
         r = c["roofline"]

@@ -24,3 +24,15 @@ def test_cpu_closed_loop_worker_and_probe():
     assert n == 2 * 4 * 2 and 0 < ok <= n and its >= ok and secs > 0.0
     assert cold[0] == 8 and cold[1] >= 8
     assert "casadi" in bench.casadi_probe().lower()
+
+
+def test_cpu_baseline_reports_the_cores_it_used():
+    """`cpu_baseline` of the bench line: one process per usable core (affinity mask capped by the cgroup quota), the CPU model string,
+    a bounded sample of the same closed loop (here 2 + 2 iterations)."""
+    import bench
+
+    n, info = bench.usable_cores()
+    assert 1 <= n <= info["affinity"] <= info["logical"] and isinstance(info["model"], str) and info["model"]
+    cb = bench.cpu_baseline(2, 2, n_scen_per_core=4, max_cores=4)
+    assert cb["kind"] == "port" and cb["unit"] == "solves/s" and 1 <= cb["cores"] <= min(4, n) and cb["value"] > 10.0
+    assert cb["cpu"]["model"] == info["model"] and cb["value_converged"] <= cb["value"] and "usable" in cb["sample"]

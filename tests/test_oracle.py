@@ -65,6 +65,8 @@ def test_nlp_jacobian_fd(golden, ospec):
     J, g = nlp.jac(X).toarray(), nlp.grad(X)
     eps = 1e-6
     for i in rng.choice(nlp.n, 60, replace=False):
+        if 7 <= i < nlp.ns:  # a slack of stage 0: its rows are constants taken out of the iteration (zero residual, zero pose gradient),
+            continue         # the -1 of the slack stays in the Newton system so that the slack's step is zero: not a derivative
         e = np.zeros(nlp.n); e[i] = eps
         assert np.allclose((nlp.cons(X + e) - nlp.cons(X - e)) / (2 * eps), J[:, i], atol=2e-6)
         assert np.isclose((nlp.f(X + e) - nlp.f(X - e)) / (2 * eps), g[i], atol=2e-5)
