@@ -383,6 +383,8 @@ def main():
                          "data/refs_4v.npz, the slower state_ws warm-start plans (the table of rounds 1-2); replan: build the planned table "
                          "at start-up with the GPU planning chain instead of loading it")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] planning measurements after the timed region")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="experiments only: a field of cfz_options for the MPC engine (e.g. carry_duals=0, restoration=0); noted in config.options")
     ap.add_argument("--no-seeds", action="store_true", help="skip the three-seed and all-moving repetitions of the headline after the timed region")
     ap.add_argument("--raw-starts", action="store_true",
                     help="take the sampler's starts as they come (rounds 1-2); default: a scenario whose noisy start state is already "
@@ -428,6 +430,8 @@ def main():
     fspec = None if (args.raw_starts or single) else spec
     k0, noise = scenarios.sample_scenarios(S, table, seed=args.seed + rank, spec=fspec)
     lengths_v = lengths  # samples of every vehicle's plan (it is parked at its goal after that)
+    opts = {kv.split("=", 1)[0]: (float(kv.split("=", 1)[1]) if "." in kv.split("=", 1)[1] or "e" in kv.split("=", 1)[1] else int(kv.split("=", 1)[1]))
+            for kv in args.option}
     vehicle_sharded = args.parallelism == "vehicle"
     if vehicle_sharded:
         if dist is None or single:
@@ -440,11 +444,11 @@ def main():
         k0, noise = scenarios.sample_scenarios(S_total, table, seed=args.seed, spec=fspec)  # (every rank holds all scenarios' starts)
         ex = VehicleShardedExchange(V)
         S = len(range(S_total)[ex.scenarios(S_total)])
-        eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter)
+        eng = engine.Engine(spec, max_batch=S * len(ex.owned), device=local_rank, max_iter=args.max_iter, **opts)
         vloop = VehicleShardedLoop(eng, ex, table, k0, noise, device=f"cuda:{local_rank}")
         args.mode = "step"
     else:
-        eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter)
+        eng = engine.Engine(spec, max_batch=S * V, device=local_rank, max_iter=args.max_iter, **opts)
         eng.loop_init(table, k0, noise)
 
     # what the sampler handed out, counted on the starts that are actually used
@@ -574,7 +578,7 @@ def main():
                        "parallelism": (f"vehicle-sharded x{world} ({len(ex.owned)} vehicle(s) x 1/{ex.n_shards} of the scenarios per rank), "
                                        f"RCCL all-gather of predictions inside groups of {ex.group_size} ranks per iteration" if vehicle_sharded
                                        else f"scenario-sharded x{world}"),
-                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks": rccl_ranks, "options": opts or None,
                        "status_counts": None if status_counts is None else
                                         dict(zip(("0 converged", "1 iteration limit", "2 line search", "3 non-finite",
                                                   "4 measured state infeasible (no iteration)", "5 stalled / locally infeasible"),

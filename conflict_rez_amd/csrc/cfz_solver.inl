@@ -906,7 +906,10 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
 // Structure used: A_k = I + [0 0 s00 s01 s02; 0 0 s10 s11 s12; 0 0 0 s21 s22; 0; 0] (s20 = 1),
 // B_k = [s03 s04; s13 s14; s23 s24; dt 0; 0 dt]; H_k = diag(h0..h6) + pose off-diagonals h7 (0,1), h8 (0,2), h9 (1,2) +
 // the v-w cross term h10 (3,6).  A lane-parallel variant (matrix entries spread over lanes, exchange through LDS) measured
-// 2.2x slower: every exchange is a dependent LDS round trip.
+// 2.2x slower: every exchange is a dependent LDS round trip.  Round 4 built the register-only variant (five lanes, lane j
+// owning column j of P; W, e, three rows of M and the gains' columns broadcast by v_readlane, 40 doubles per stage, no LDS, no
+// barrier): bit-compatible results, 70 k cycles per sweep against 60 k here -- the 80 v_readlane of a stage cost more than the 150
+// multiply-adds they save a lane (docs/notebook.md); taken out again.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(CFZ_SWEEP_INLINE)
 #define CFZ_SWEEP __device__ __forceinline__ void
 #define CFZ_SWEEP_GUARD if (threadIdx.x != 0) return;

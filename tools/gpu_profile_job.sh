@@ -11,14 +11,14 @@ timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | grep -E "pa
 timeout 600 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 1500 $O/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_$tag
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag/trace -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/${tag}_bench_traced.json 2>$O/${tag}_trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag/trace -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-seeds > $O/${tag}_bench_traced.json 2>$O/${tag}_trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/prof_$tag/$c -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras > /dev/null 2>$O/${tag}_$c.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/prof_$tag/$c -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-seeds > /dev/null 2>$O/${tag}_$c.err
 done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof_$tag/SQ -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras > /dev/null 2>$O/${tag}_SQ.err
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof_$tag/SQ -o t -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-seeds > /dev/null 2>$O/${tag}_SQ.err
 cd $R
 # which kernel sources these numbers belong to (bench.py quotes them only on a library with the same hash)
-python -c "import json; from conflict_rez_amd import engine; json.dump({'csrc_sha16': engine.source_hash(), 'command': 'python bench.py --no-cpu-baseline --no-extras'}, open('$O/${tag}_meta.json', 'w'))"
+python -c "import json; from conflict_rez_amd import engine; json.dump({'csrc_sha16': engine.source_hash(), 'command': 'python bench.py --no-cpu-baseline --no-extras --no-seeds'}, open('$O/${tag}_meta.json', 'w'))"
 # ROCm 7.2 writes a rocpd sqlite database; turn it into the CSV summaries kept under profiles/
 python tools/rocpd_summary.py $O/prof_$tag/trace/t_results.db $O/$tag
 for c in FETCH_SIZE WRITE_SIZE SQ; do python tools/rocpd_summary.py $O/prof_$tag/$c/t_results.db $O/$tag $c; done
