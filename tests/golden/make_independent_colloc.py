@@ -18,7 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def problem(agent="vehicle_1"):
-    """(tube, path, final heading, obstacle spec) of one vehicle of the synthetic strategy."""
+    """(tube, path, final heading, obstacle spec) of one vehicle of the synthetic strategy.  `vehicle_0_s6`: the vehicle's first six
+    strategy steps only (tube and path cut there; the final heading is the path's heading at the cut) -- vehicle 0 at full length
+    (N = 50, it waits for 20 intervals) has two local solutions and no tight optimum, docs/notebook.md."""
+    n_sets = None
+    if "_s" in agent:
+        agent, n_sets = agent.rsplit("_s", 1)[0], int(agent.rsplit("_s", 1)[1])
     from conflict_rez_amd import scenarios, strategy as strat
     from conflict_rez_amd.control.compute_sets import compute_sets, interp_along_sets
     from conflict_rez_amd.vehicle_types import VehicleBody
@@ -30,6 +35,8 @@ def problem(agent="vehicle_1"):
         tubes, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
     tube = [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in tubes[agent]]
     p = paths[agent]
+    if n_sets is not None:
+        tube, p = tube[:n_sets], p[: 30 * (n_sets - 1) + 1]
     return tube, p, float(p[-1, 2]), scenarios.parking_lot_spec()
 
 
@@ -42,6 +49,10 @@ if __name__ == "__main__":
     from oracle.independent_colloc import GeometricColloc, solve_ipm
 
     out = {}
+    name = "colloc_independent.npz"
+    if "--truncated" in sys.argv:  # `--truncated vehicle_0_s6` -> colloc_independent_trunc.npz
+        AGENTS = tuple(sys.argv[sys.argv.index("--truncated") + 1:])
+        name = "colloc_independent_trunc.npz"
     for agent in AGENTS:
         tube, p, fh, sp = problem(agent)
         nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
@@ -55,4 +66,4 @@ if __name__ == "__main__":
         assert r["status"] in (0, 2) and r["eq"] < 2e-8 and r["ineq"] > -1e-8
         out.update({f"{agent}_guess": X0[: nlp.iDt + 1], f"{agent}_traj": r["traj"], f"{agent}_dt": r["dt"], f"{agent}_cost": r["cost"],
                     f"{agent}_iters": r["iters"], f"{agent}_status": r["status"]})
-    np.savez_compressed(os.path.join(HERE, "colloc_independent.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, name), **out)

@@ -253,7 +253,7 @@ def test_planner_surface_four_vehicles(tmp_path):
                 assert separated(poly(fr[agents[ia]], i), poly(fr[agents[ib]], i)), (i, ia, ib)
 
 
-@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_2", "vehicle_3", "vehicle_1_pillar", "vehicle_2_pillar", "vehicle_3_pillar"])
+@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_2", "vehicle_3", "vehicle_1_pillar", "vehicle_2_pillar", "vehicle_3_pillar", "vehicle_0_s6"])
 def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     """`cfz_colloc` (HIP, through the C ABI) from the fixture's guess against the optimum an INDEPENDENT solver found on an
     independent statement of the reference's single-vehicle plan (tests/golden/colloc_independent.npz: polygon distances, no
@@ -263,7 +263,9 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     itself.  Assertions shared with the CPU test (tests/test_independent_solver.py:check_plan_against_independent).
     The `_pillar` plans (tests/golden/colloc_independent_vv.npz) carry a seventh obstacle whose corner is in contact with a corner of
     the body at the optimum, multiplier 0.5 ... 23: there the kernel's vertex-vertex rows (`vv_rows`, the default) are what makes
-    its feasible set the reference's (vehicle.py:523-541); with `vv_rows = 0` the same launch ends feasible but dearer."""
+    its feasible set the reference's (vehicle.py:523-541); with `vv_rows = 0` the same launch ends feasible but dearer.
+    `vehicle_0_s6` (tests/golden/colloc_independent_trunc.npz): vehicle 0 on its first six strategy steps -- the longest plan's vehicle
+    (at full length, 50 intervals of which it waits for 20, neither solver has a tight optimum)."""
     import dataclasses
 
     from conflict_rez_amd import engine

@@ -346,6 +346,9 @@ def test_independent_fixture_is_reproducible():
 
 # ---- full size collocation plans (tests/golden/colloc_independent.npz, make_independent_colloc.py) ----------------------------
 COLLOC_AGENTS = ("vehicle_1", "vehicle_2", "vehicle_3")
+# vehicle 0 on its first six strategy steps (25 intervals; tests/golden/colloc_independent_trunc.npz, `make_independent_colloc.py --truncated
+# vehicle_0_s6`): at full length (50 intervals, it waits for 20 of them) the plan has two local solutions and neither solver a tight optimum
+TRUNC_AGENTS = ("vehicle_0_s6",)
 
 
 def _colloc_fixture(agent="vehicle_1"):
@@ -365,7 +368,7 @@ def _colloc_fixture(agent="vehicle_1"):
         tube, p, fh, sp = problem(agent[: -len("_pillar")])
         sp = dataclasses.replace(sp, A_obs=np.concatenate([sp.A_obs, [f[f"{agent}_A"]]]), b_obs=np.concatenate([sp.b_obs, [f[f"{agent}_b"]]]))
     else:
-        f = np.load(os.path.join(here, "golden", "colloc_independent.npz"))
+        f = np.load(os.path.join(here, "golden", "colloc_independent_trunc.npz" if agent in TRUNC_AGENTS else "colloc_independent.npz"))
         d = {k: f[f"{agent}_{k}"] for k in ("guess", "traj", "dt", "cost")}
         d["value"] = d["cost"]
         tube, p, fh, sp = problem(agent)
@@ -388,6 +391,8 @@ def check_plan_against_independent(traj, dt, tight, agent="vehicle_1"):
     if tight:
         lim = (1e-8, 1e-6, 1e-8) if agent == "vehicle_1" else ((1e-6, 1e-4, 1e-6) if agent == "vehicle_1_pillar" else (1e-6, 1e-5, 1e-7))
         assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < lim[0] and dpose < lim[1] and ddt < lim[2], (agent, eq, ineq, gap, dpose, ddt)
+    elif agent in TRUNC_AGENTS:  # (vehicle 0's truncated plan stops earlier on the central path: measured -0.6 %, 1.1 cm, 1.7e-3 s)
+        assert eq < 1e-2 and ineq > -1e-2 and -1e-2 < gap < 1e-4 and dpose < 2e-2 and ddt < 3e-3, (agent, eq, ineq, gap, dpose, ddt)
     else:
         assert eq < 1e-2 and ineq > -1e-2 and -3e-3 < gap < 1e-4 and dpose < 5e-3 and ddt < 1e-3, (agent, eq, ineq, gap, dpose, ddt)
     return gap, dpose
@@ -440,7 +445,7 @@ def test_face_normal_rows_alone_restrict_the_collocation_plan(agent, least):
     assert gap > least, gap
 
 
-@pytest.mark.parametrize("agent", COLLOC_AGENTS)
+@pytest.mark.parametrize("agent", COLLOC_AGENTS + TRUNC_AGENTS)
 @pytest.mark.parametrize("tight", [True, False])
 def test_full_size_collocation_plan_against_the_independent_solver(tight, agent):
     """The planning kernel's source (CPU build) from the fixture's guess against the independent optimum of the geometric
@@ -465,7 +470,7 @@ def test_full_size_collocation_plan_against_the_independent_solver(tight, agent)
     check_plan_against_independent(P, dt, tight, agent)
 
 
-@pytest.mark.parametrize("agent", COLLOC_AGENTS + VV_PLANS)
+@pytest.mark.parametrize("agent", COLLOC_AGENTS + VV_PLANS + TRUNC_AGENTS)
 def test_independent_collocation_fixture_is_a_kkt_point(agent):
     """Certificate of the fixtures that needs no solver: at the stored plan the gradient of the cost is a combination of the
     gradients of the equality rows and of the ACTIVE inequality rows and bounds of the geometric statement with multipliers of
