@@ -1301,7 +1301,11 @@ CFZ_CALL void resto_partials(const KSpec &sp, const KDer &dv, double *m, const L
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(CFZ_RESTO_INLINE)
+#define CFZ_COLD __device__ __forceinline__
+#else
 #define CFZ_COLD __device__ __attribute__((noinline, cold))
+#endif
 #else
 #define CFZ_COLD static
 #endif
