@@ -280,6 +280,8 @@ def planning_extras(device=0, B=256, cpu=True):
     # collocation refinement again on that map (state_ws does not see the obstacles: the tube keeps the vehicle off them)
     sp4 = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=4)
     gs = {k: guess_of(ws[k]["traj"], len(tubes[who[k]]) + 1) for k in good}
+    engine.colloc(sp4, [init[k] for k in good[:8]], [tubes[who[k]] for k in good[:8]], [gs[k][0] for k in good[:8]], [gs[k][1] for k in good[:8]],
+                  [fh[who[k]] for k in good[:8]], max_iter=400, device=device)  # warm-up, as configs[1]'s own launches had
     t0 = time.perf_counter()
     r4 = engine.colloc(sp4, [init[k] for k in good], [tubes[who[k]] for k in good], [gs[k][0] for k in good], [gs[k][1] for k in good],
                        [fh[who[k]] for k in good], max_iter=400, device=device)

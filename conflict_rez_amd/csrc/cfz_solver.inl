@@ -1897,9 +1897,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             const int t = k * nr + 2 * jb + r_;
             // delta_c on the row (IPOPT's dual regularisation, eliminated together with the slack): the row's stiffness is
             // S0 / (1 + delta_c S0) and its right-hand side sees the distance of nu from its centred value -mu / sigma
+#if defined(CFZ_NO_DELTAC)
+            const double isg = 1.0 / m[L.sg + t], S = m[L.zs + t] * isg + sp.reg_primal;
+            const double coef = S * m[L.cj + t] - mu * isg;
+#else
             const double isg = 1.0 / m[L.sg + t], S0 = m[L.zs + t] * isg + sp.reg_primal;
             const double iD = 1.0 / (1.0 + kDeltaC(sp) * S0), S = S0 * iD;
             const double coef = S * m[L.cj + t] - mu * isg * iD + kDeltaC(sp) * S * m[L.nuc + t];
+#endif
             const double a2 = bap[r_];
             ac[0] += a0 * coef; ac[1] += a1 * coef; ac[2] += a2 * coef;
             ac[3] += S * a0 * a0; ac[4] += S * a1 * a1; ac[5] += S * a2 * a2;
@@ -2009,8 +2014,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           for (int r_ = 0; r_ < 2; ++r_) {
             const int t = k * nr + 2 * jb + r_;
             const double sg = m[L.sg + t], zs = m[L.zs + t], isg = 1.0 / sg;
+#if defined(CFZ_NO_DELTAC)
+            const double ds = m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[r_] * dpk[2];
+#else
             const double ds = (m[L.cj + t] + ba0 * dpk[0] + ba1 * dpk[1] + bap[r_] * dpk[2] + kDeltaC(sp) * (mu * isg + m[L.nuc + t])) /
                               (1.0 + kDeltaC(sp) * (zs * isg + sp.reg_primal));
+#endif
             m[L.dsg + t] = ds;
             const double dzs = mu * isg - zs - zs * isg * ds;
             dphi -= mu * isg * ds;

@@ -58,10 +58,10 @@ def _sol_of(traj, dt, eng):
     return sol
 
 
-def _single_plans(lot, who, init):
+def _single_plans(lot, who, init, n_obs=6):
     from conflict_rez_amd import engine
 
-    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=n_obs)
     tubes, paths, fh = lot["tubes"], lot["paths"], lot["fh"]
     ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh[a] for a in who], shrink_tube=0.5)
     good = [i for i, w in enumerate(ws) if w["status"] == 0]
@@ -113,6 +113,35 @@ def test_config1_256_single_vehicle_plans(lot):
         checked += 1
     assert checked == 16
     eng.close()
+
+
+def test_config1_as_baseline_words_it_four_obstacles(lot):
+    """BASELINE.json configs[1] to the letter: B = 256 independent single-vehicle OBCA plans with FOUR polytope obstacles
+    (obstacles 0, 1, 3, 4 of the reference's six) on the planning kernels.  Every plan converges; a sample of 16 goes
+    through the reference's full row list on the four-obstacle map; and since the two dropped boxes are not in any vehicle's way on
+    this strategy, every plan is close to its six-obstacle twin (the rows of the remaining boxes are the same rows)."""
+    from conflict_rez_amd import engine
+
+    B = 256
+    agents = lot["agents"]
+    rng = np.random.default_rng(0)
+    who = [agents[i % 4] for i in range(B)]
+    init = [lot["paths"][a][0] + np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] for a in who]
+    ws, good, plans = _single_plans(lot, who, init, n_obs=4)
+    assert len(good) == B and sum(r["status"] == 0 for r in plans.values()) == B
+    sp4 = scenarios.parking_lot_spec(n_obs=4)
+    assert sp4.n_obs == 4
+    eng = engine.Engine(scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=4), max_batch=1)
+    for i in sorted(plans)[:: B // 16][:16]:
+        a, r = who[i], plans[i]
+        nlp = CollocNlp(init[i], lot["otubes"][a], sp4.A_obs, sp4.b_obs, N_per_set=5, final_heading=lot["fh"][a])
+        rr = reference_residuals(nlp, _sol_of(r["traj"], r["dt"], eng))
+        assert rr["eq"] < 1e-2 and rr["ineq"] < 1e-2 and rr["bound"] <= 1e-9, (i, rr)
+        assert abs(rr["cost"] - r["cost"]) < 1e-8 * max(1.0, r["cost"])
+    eng.close()
+    _, _, plans6 = _single_plans(lot, who[:8], init[:8])
+    for i in range(8):
+        assert abs(plans[i]["cost"] - plans6[i]["cost"]) < 2e-2 * plans6[i]["cost"] and np.abs(plans[i]["traj"][..., :2] - plans6[i]["traj"][..., :2]).max() < 0.1, i
 
 
 def test_config3_four_vehicle_joint_plans(lot):
