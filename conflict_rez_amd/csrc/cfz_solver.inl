@@ -1316,7 +1316,10 @@ CFZ_CALL void resto_partials(const KSpec &sp, const KDer &dv, double *m, const L
 // re-initialises them).  Everything goes in and out by value: a counter of the solver's hot loop whose address is taken lives in scratch.
 // The parity of the reduction exchange (xpar) is 0 at entry and at exit: the caller's is parked while this runs (an even number of
 // reductions is not guaranteed here, so the function realigns with one barrier at its end).
-CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, double *m, const Lay &L, double mu, int iter) {
+// (the workspace comes in as an address-space-3 pointer, like the sweeps': cast back to a generic one here, the compiler then knows where
+// every access of the inlined helpers goes and emits DS instructions instead of FLAT ones)
+CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, const Lay &L, double mu, int iter) {
+  double *m = (double *)mw;
   const int N = sp.N, nb = L.nb, nr = L.nr;
   int xpar = 0;
   (void)xpar;
@@ -1489,7 +1492,8 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, double *m, const 
 
 // Cold multipliers at the point in L.p (after a restoration; IPOPT resets its bound multipliers there and recomputes the others): fresh
 // working set, slacks from the rows (at least half of bound_push), z = mu / distance, the equality rows at zero.
-CFZ_COLD void cold_multipliers(const KSpec &sp, double *m, const Lay &L, double mu) {
+CFZ_COLD void cold_multipliers(const KSpec &sp, wsp_f64 *mw, const Lay &L, double mu) {
+  double *m = (double *)mw;
   const int N = sp.N, nb = L.nb;
   CFZ_LANES(tid)
     const int k = tid >> 2, sub = tid & 3;
@@ -2131,9 +2135,9 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   }
   if (__builtin_expect(want_resto == 0, 1)) break;
   {
-    const int r = restore_instance(sp, dv, m, L, mu, iter);
+    const int r = restore_instance(sp, dv, CFZ_WSP(m), L, mu, iter);
     if (r < 0) { status = 5; iter = -r - 1; break; }
-    cold_multipliers(sp, m, L, mu);
+    cold_multipliers(sp, CFZ_WSP(m), L, mu);
     if (want_resto == 1) { iter0 = r - 1; iter = iter0; }  // the first iteration again, from the restored point
     else {  // the iteration of the failed line search is counted; the filter and the stall tests start afresh
       iter = r;
