@@ -457,6 +457,11 @@ def main():
     infeasible_starts = None if single else int(((scenarios.start_clearances(spec, table, k0, noise) < spec.dmin - 0.01).any(1)
                                                  | (scenarios.start_box_excess(spec, table, k0, noise) > 1e-2).any(1)).sum())
 
+    redrawn = None
+    if fspec is not None and not vehicle_sharded:
+        k0_raw, nz_raw = scenarios.sample_scenarios(len(k0), table, seed=args.seed + rank)
+        redrawn = int(((k0_raw != k0) | (np.abs(nz_raw - noise).max((1, 2)) > 0.0)).sum())  # scenarios of the raw sampler that were drawn again (rounds 1-2 took them as they came)
+
     def parked_fraction(k0_, t_first, t_count):
         """Share of the (scenario, vehicle, MPC iteration) triples of a closed-loop window whose vehicle has reached the end of its
         plan (it then holds its goal pose: one or two interior-point iterations per solve)."""
@@ -589,7 +594,7 @@ def main():
                        "max_iter": args.max_iter, "mode": args.mode, "converged_last_step": n_ok / (B * world),
                        "converged_timed_region": (n_conv / solves) if n_conv is not None else None,
                        "reference_plan": ref_desc,
-                       "infeasible_starts": infeasible_starts,
+                       "infeasible_starts": infeasible_starts, "redrawn_scenarios": redrawn,
                        "starts": "raw sampler draws" if fspec is None else
                                  "scenarios whose noisy start state violates a clearance or lies outside the NLP's state boxes (an infeasible first NLP) are drawn again",
                        "ipm_iterations_rank0": ipm_iterations,

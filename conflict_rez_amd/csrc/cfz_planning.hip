@@ -347,6 +347,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   // the batch is larger than two rounds of the wide kernel (B > 2 CUs), or on request (`one_pivot`, the check of the other).
   bool wide = false;
   for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
+  if (!wide && co->one_pivot && co->kernel == CFZ_KERNEL_WIDE) return fail("one_pivot runs single plans on the one-wavefront kernel: kernel = CFZ_KERNEL_WIDE contradicts it");
   if (!wide && !co->one_pivot) {
     int cus = 0;
     HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));

@@ -285,7 +285,8 @@ typedef struct cfz_colloc_options {
                            *    direction (vehicle.py:523-541, multi_vehicle_planner.py:419-451); 0: face-normal certificates only
                            *    (a restriction at corner-to-corner contacts, kept to show the gap) */
   int32_t kernel;         /* cfz_colloc only (a joint plan always runs on 512 threads): 0 = by batch size, CFZ_KERNEL_WIDE, CFZ_KERNEL_NARROW
-                           *    as in cfz_plan_options.kernel */
+                           *    as in cfz_plan_options.kernel; with one_pivot = 1 single plans always take the narrow kernel
+                           *    (CFZ_KERNEL_WIDE is then refused) */
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */

@@ -389,7 +389,10 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         if not accepted:
             # No restoration phase for this NLP (or its calls are used up, or the iterate is feasible).  The independent solvers of oracle/independent_*.py (`lower_mu_on_failure`) give up the
             # barrier problem at hand instead: mu falls, the filter starts afresh, the iterate stays; a second failure in a row
-            # (or mu at its floor) ends the solve.  The kernels' oracle path (default) reports status 2 at once, like the kernels.
+            # (or mu at its floor) ends the solve.  The MPC kernel's oracle path (default) reports status 2 at once, like the MPC kernel;
+            # the PLANNING kernels (cfz_plan.inl, cfz_colloc.inl) do lower mu once and then retry the iterate with a larger inertia
+            # perturbation -- their parity tests compare against the CPU build of their own source and against the independent solvers,
+            # not against this loop.
             if opt.lower_mu_on_failure and mu > mu_floor and not mu_forced:
                 mu = max(mu_floor, min(opt.kappa_mu * mu, mu**opt.theta_mu))
                 mu_forced, filt, filt_mu = True, [], mu

@@ -130,6 +130,9 @@ if __name__ == "__main__":
     #   point a fixture is the solver-free certificate below, not the path to it; the tests still start the kernel from `guess*`.
     if NEAR:
         args.remove("--start-near")
+    CERTIFY_KERNEL = "--certify-kernel" in args  # also store the planning source's tight plan and its solver-free certificate
+    if CERTIFY_KERNEL:
+        args.remove("--certify-kernel")
     if len(args) >= 2:
         AGENTS = tuple(args)
     V = len(AGENTS)
@@ -164,7 +167,28 @@ if __name__ == "__main__":
     print("certificate %.1e" % res, "active pair rows", active, "vertex-vertex", vc, "value %.9f" % value, flush=True)
     out = dict(dmin=DMIN, dt0=float(X0[jn.iDt]), dt=r["dt"], cost=r["cost"], value=value, iters=r["iters"], status=r["status"], pair=r["pair"],
                contacts=np.array(vc, float).reshape(-1, 3), active=np.array(active, float).reshape(-1, 3), certificate=res)
+    if CERTIFY_KERNEL:
+        # the planning source's own plan at tight tolerances (CPU build) and ITS solver-free certificate on the independent statement:
+        # what the fixture rests on where the independent solver stops short of its tolerance (four vehicles)
+        import colloc_emu_binding as ce
+        from oracle import ipm
+        from oracle.colloc_nlp import JointCollocNlp
+
+        jd = JointCollocNlp([dict(init_pose=plans[a][1][0], tube=plans[a][0], final_heading=float(plans[a][1][-1, 2])) for a in AGENTS],
+                            sp.A_obs, sp.b_obs, N_per_set=5, dmin=DMIN)
+        opt = ipm.IpmOptions(max_iter=800, reg_dual=1e-9, tol=1e-8, constr_viol_tol=1e-9, compl_inf_tol=1e-9, dual_inf_tol=1e-6)
+        opt.no_prox = 1
+        rk = ce.solve(jd, X0, opt)
+        zk = rk["X"][: jd.iDt + 1]
+        nk_ = GeometricJointIpm(gs, pairs, zk)
+        kres, _, _, kact = joint_kkt_certificate(nk_, zk)
+        kvv = vertex_pair_contacts(nk_, zk, kact)
+        print("kernel source: status", rk["status"], "iters", rk["iters"], "cost %.9f" % nk_.f(zk), "certificate %.1e" % kres, "active", len(kact), "vertex-vertex", kvv, flush=True)
+        out.update(kdt=float(zk[-1]), kcost=nk_.f(zk), kcertificate=kres, kactive=np.array(kact, float).reshape(-1, 3), kstatus=rk["status"], kiters=rk["iters"],
+                   kcontacts=np.array(kvv, float).reshape(-1, 3))
+        for a in range(V):
+            out[f"ktraj{a}"] = nk_.z_of(zk, a)[:-1].reshape(-1, 6, 7)
     for a in range(V):
         out[f"guess{a}"], out[f"traj{a}"] = guesses[a], r["trajs"][a]
     np.savez_compressed(os.path.join(HERE, out_name), **out)
-    assert r["status"] in (0, 1, 2) and r["eq"] < 5e-8 and r["ineq"] > -1e-8 and res < 1e-7
+    assert (r["status"] in (0, 1, 2) and r["eq"] < 5e-8 and r["ineq"] > -1e-8 and res < 1e-7) or (CERTIFY_KERNEL and out["kcertificate"] < 1e-8)

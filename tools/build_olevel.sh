@@ -1,6 +1,6 @@
 #!/bin/bash
-# Both translation units at ONE optimisation level (the shipped build takes cfz_engine.hip at -O2 and cfz_planning.hip at -O3, see
-# __graft_entry__.py): tools/build_olevel.sh -O3 tools/_libcfz_o3.so [extra flags]
+# Both translation units at a chosen optimisation level (the shipped build takes both at -O3, see __graft_entry__.py; round 3 checked
+# that the GPU suite passes at -O2 as well): tools/build_olevel.sh -O2 tools/_libcfz_o2.so [extra flags]
 lvl=$1; out=$2; shift; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/conflict_rez_amd/csrc
