@@ -319,7 +319,7 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     check_plan_against_independent(r2["traj"], r2["dt"], True, agent)
 
 
-@pytest.mark.parametrize("name", ["23", "23_d20", "123_d20", "02_d20_s66"])
+@pytest.mark.parametrize("name", ["23", "23_d20", "123_d20", "02_d20_s66", "0123_d20_s5555"])
 def test_joint_plan_against_the_independent_solver_on_gpu(name):
     """`cfz_joint_colloc` (HIP, through the C ABI) on the joint plan of vehicles 2 and 3 from the fixture's guess against the optimum
     an INDEPENDENT solver found on an independent statement of `solve_final_problem_obca` (tests/golden/joint_independent.npz:
@@ -333,7 +333,10 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
     multipliers 0.35 / 0.28 -- so the vehicle-vehicle rows decide the plan there.
     `02_d20_s66` (vehicles 0 and 2 on their first six strategy steps): a CORNER of one body touches a CORNER of the other at the
     optimum (vertex-vertex pair rows, multipliers 0.34 / 0.024); there the plan also carries a solver-free KKT certificate on the
-    independent statement (1.8e-12)."""
+    independent statement (1.8e-12).
+    `0123_d20_s5555` (round 4): ALL FOUR vehicles, six pairs, on their first five strategy steps -- BASELINE configs[3]'s shape -- with
+    two pairs of bodies in contact; both solvers converge tightly to the same cost (1.1e-6) at points that differ in one vehicle's
+    poses (non-unique minimiser), so cost and the solver-free certificate at the kernel's own plan are what is asserted."""
     from conflict_rez_amd import engine
     from test_independent_solver import _joint_fixture, check_joint_against_independent
 

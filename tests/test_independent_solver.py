@@ -507,8 +507,16 @@ JOINT_FIXTURES = {"23": ("joint_independent.npz", JOINT_AGENTS, 0.05), "23_d20":
                   "123_d20": ("joint_independent_123_d20.npz", ("vehicle_1", "vehicle_2", "vehicle_3"), 0.2),
                   # vehicles 0 and 2 on their first six strategy steps (25 intervals each), dmin 0.2: at the optimum a corner of one BODY
                   # touches a corner of the other (vertex-vertex pair rows active at two collocation points, multipliers 0.34 / 0.024)
-                  "02_d20_s66": ("joint_independent_02_d20_s66.npz", ("vehicle_0", "vehicle_2"), 0.2, (6, 6))}
+                  "02_d20_s66": ("joint_independent_02_d20_s66.npz", ("vehicle_0", "vehicle_2"), 0.2, (6, 6)),
+                  # ALL FOUR vehicles (six pairs, one shared dt: the shape of BASELINE configs[3]) on their first five strategy steps, dmin 0.2
+                  # (round 4; `make_independent_joint.py vehicle_0 .. vehicle_3 --dmin 0.2 --sets 5,5,5,5 --start-near --certify-kernel`):
+                  # two pairs of bodies in contact at the optimum, 18 active pair rows, two of them corner against corner.  BOTH solvers
+                  # converge tightly (independent: 413 iterations, certificate 2.3e-11; planning source: 250 iterations, 4.0e-11) to costs
+                  # within 1.1e-6 -- at points up to 0.14 m apart in one vehicle's poses: the minimiser is not unique there (a vehicle may
+                  # wait earlier or later at no cost), so this fixture pins cost and certificate, not poses
+                  "0123_d20_s5555": ("joint_independent_0123_d20_s5555.npz", ("vehicle_0", "vehicle_1", "vehicle_2", "vehicle_3"), 0.2, (5, 5, 5, 5))}
 VV_BODY = "02_d20_s66"
+FOUR = "0123_d20_s5555"
 
 
 def _joint_fixture(name="23"):
@@ -563,8 +571,25 @@ def check_joint_against_independent(trajs, dt, tight, name="23"):
         res, _, _, active = joint_kkt_certificate(nlp, z)
         vv = vertex_pair_contacts(nlp, z, active)
         assert res < 1e-8 and len(vv) >= 1 and max(lam for _, _, lam in vv) > 0.1, (res, active, vv)
+    elif tight and name == FOUR:
+        # cost to 3e-6 of the independent optimum (measured 1.1e-6), dt to 1e-6 s; poses are not compared (non-unique minimiser, see
+        # JOINT_FIXTURES); the verdict on the plan handed in is the solver-free certificate on the independent statement
+        from make_independent_joint import joint_kkt_certificate, vertex_pair_contacts
+
+        assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 3e-6 and ddt < 1e-6 and dpose < 0.3, (eq, ineq, gap, dpose, ddt)
+        # the generator certified the planning source's own tight plan (`ktraj*`, residual 4.0e-11, 15 active pair rows in two pairs, two
+        # of them corner against corner); a plan within 2e-5 m of it shares that certificate, any other gets its own (2.5 minutes of
+        # bounded least squares)
+        dk = max(np.abs(np.asarray(trajs[a])[..., :3] - d[f"ktraj{a}"][..., :3]).max() for a in range(V))
+        assert float(d["kcertificate"]) < 1e-8 and len(d["kactive"]) >= 8 and len(set(d["kactive"][:, 0])) >= 2 and len(d["kcontacts"]) >= 1
+        if not (dk < 2e-5 and abs(nlp.f(z) - float(d["kcost"])) < 1e-8 * float(d["kcost"])):
+            res, _, _, active = joint_kkt_certificate(nlp, z)
+            vv = vertex_pair_contacts(nlp, z, active)
+            assert res < 1e-8 and len(active) >= 8 and len({e_ for e_, _, _ in active}) >= 2 and len(vv) >= 1, (dk, res, active, vv)
     elif tight:
         assert eq < 1e-7 and ineq > -1e-7 and abs(gap) < 1e-6 and dpose < 5e-5 and ddt < 1e-7, (eq, ineq, gap, dpose, ddt)
+    elif name == FOUR:  # measured at the reference's tolerance: -0.31 % (the rows of four plans relaxed by the tolerance)
+        assert eq < 1e-2 and ineq > -1e-2 and -1.5e-2 < gap < 1e-4 and ddt < 5e-3 and dpose < 0.3, (eq, ineq, gap, dpose, ddt)
     else:
         # (the contact fixtures at dmin = 0.2: three vehicles -1.03 %, 1.35 cm measured -- the tolerance relaxes three plans' rows)
         # (the corner-to-corner fixture: -1.16 %, 3.2 cm, 3.6e-3 s measured: the relaxed plan cuts the corner closer)
@@ -646,6 +671,10 @@ def test_independent_joint_fixture_is_a_kkt_point(name):
     V = len(gs)
     if name == VV_BODY:  # the independent solver's best point, short of its tolerance; the certificate that counts is taken at the
         assert float(d["certificate"]) < 2e-4 and len(d["contacts"]) >= 1  # kernel's plan (check_joint_against_independent)
+        return
+    if name == FOUR:  # both solvers' points carry the generator's certificate; the kernel source's is recomputed live in
+        assert float(d["certificate"]) < 1e-8 and float(d["kcertificate"]) < 1e-8 and int(d["status"]) == 0 and int(d["kstatus"]) == 0  # check_joint_against_independent
+        assert abs(float(d["kcost"]) - float(d["value"])) < 3e-6 * float(d["value"]) and len(d["active"]) >= 8 and len(d["contacts"]) >= 1
         return
     if V > 2 or name == "23_d20":  # (three vehicles: 2.5 minutes of bounded least squares; 23_d20: 50 s) the generator ran the same
         assert float(d["certificate"]) < 1e-8 and int(d["status"]) in (0, 1, 2)  # certificate (make_independent_joint.py
