@@ -78,6 +78,37 @@ def test_kernel_source_other_shapes(ospec):
                 assert np.abs(r1["p"].T - r2["zu"]).max() < 1e-7
 
 
+def test_restoration_in_other_shapes():
+    """The restoration phase outside the 4-vehicle shape: a single vehicle (four obstacles, no neighbour: BASELINE.json config 2) and a
+    two-vehicle problem on a short horizon, reference and warm start pushed 0.6-0.9 m sideways into a box's clearance (restoration
+    first) -- equal status and iteration count in the C port and the kernel source, and the phase does its work: the converged
+    plans keep the clearance that the starts violated."""
+    from conflict_rez_amd import scenarios
+    from oracle.mpc_nlp import MpcSpec
+
+    table, _ = scenarios.load_reference_table()
+    opt, off = ipm.IpmOptions(), ipm.IpmOptions(restoration=0)
+    seen = 0
+    for n_obs, n_nbr, N, push in ((4, 0, 30, 0.9), (6, 1, 12, 0.6)):
+        sp = scenarios.parking_lot_spec(n_nbr=n_nbr, N=N, n_obs=n_obs)
+        osp = MpcSpec(N=N, dt=sp.dt, A_obs=sp.A_obs, b_obs=sp.b_obs, n_nbr=n_nbr)
+        k0, noise = scenarios.sample_scenarios(6, table, seed=11)
+        x0, ref, nbr, zu = scenarios.mpc_batch_from_table(sp, table[: n_nbr + 1], k0, noise[:, : n_nbr + 1])
+        for b in range(0, len(x0), n_nbr + 1):
+            # sideways (to the left of the heading) by `push` from stage 3 on: the start state itself stays where it is
+            shift = np.zeros((2, N)); shift[:, 3:] = push * np.array([[-np.sin(ref[b][2, 0])], [np.cos(ref[b][2, 0])]])
+            rf, z0 = ref[b].copy(), zu[b].copy()
+            rf[:2] += shift; z0[:2] += shift
+            r1 = port.solve(osp, x0[b], rf, nbr[b], z0.T, opt)
+            r2 = emu.solve(osp, opt, x0[b], rf, nbr[b], z0)
+            assert (r1["status"], r1["iters"]) == (r2["status"], r2["iters"]), (n_obs, b)
+            if r1["status"] == 0:
+                assert np.abs(r1["p"].T - r2["zu"]).max() < 1e-7 and r1["sep"].min() > osp.dmin - 1e-2
+            r0 = port.solve(osp, x0[b], rf, nbr[b], z0.T, off)
+            seen += (r1["status"] == 0 and r1["iters"] > r0["iters"] + 5) or (r1["status"] == 0 and r0["status"] != 0)
+    assert seen >= 1  # some start went through the phase (more iterations than without it, or a solve that fails without it)
+
+
 def test_kernel_source_under_sanitizers(golden, ospec, tmp_path):
     """AddressSanitizer + UBSan on the CPU build of the kernel source (no GPU sanitizers on this pool)."""
     lib = emu.build(sanitize=True)
