@@ -166,8 +166,7 @@ CFZP_FN CDims cdims(const CSpec &sp) {
 CFZP_FN int veh_of_interval(const CDims &d, int I) { int a = 0; while (a + 1 < d.V && I >= d.off[a + 1]) ++a; return a; }
 CFZP_FN int veh_of_chk(const CDims &d, int T) { int a = 0; while (a + 1 < d.V && T >= d.coff[a + 1]) ++a; return a; }
 // half-bandwidth of the ordering of build_order: the 30 ODE rows of an interval sit between its third and fourth point
-constexpr int kCB = 51, kCLd = 3 * kCB + 1, kCWin = 2 * kCB + 1;
-constexpr int kCLdsDoubles = kCWin * kCLd + 64;  // the window and one spare slot per lane behind it
+constexpr int kCB = 51;  // half-bandwidth of the single-vehicle plan's ordering
 constexpr int kWideMaxKb = 448;  // widest half-bandwidth the eight-wavefront eliminations are compiled for (the host sizes LDS with it)
 // point of tube checkpoint T (global index): start of interval (t+1) Nps of its vehicle, or the vehicle's very last point
 CFZP_FN int chk_point(const CSpec &sp, const CDims &d, int T) {
@@ -806,8 +805,8 @@ __device__ inline int band_factor_wide2(const Band &B, int n, int *ipiv, long lo
   __shared__ int cnt[2];
   if (threadIdx.x == 0) { tks[0] = 0.0; tks[1] = 0.0; tks[2] = 0.0; }
   __syncthreads();
-  const int fail = band_factor_wide2_core((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)ulds, (lds_f64 *)alds, (lds_f64 *)lval, (lds_i32 *)cols, (lds_i32 *)lrow,
-                                          (lds_f64 *)pb, (lds_f64 *)pbv, (lds_i32 *)pj, (lds_i32 *)cnt, (lds_f64 *)tks);
+  const int fail = band_factor_wide2_core((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, cfzb::opaque((lds_f64 *)ulds), cfzb::opaque((lds_f64 *)alds), cfzb::opaque((lds_f64 *)lval), cfzb::opaque((lds_i32 *)cols), cfzb::opaque((lds_i32 *)lrow),
+                                          cfzb::opaque((lds_f64 *)pb), cfzb::opaque((lds_f64 *)pbv), cfzb::opaque((lds_i32 *)pj), cfzb::opaque((lds_i32 *)cnt), cfzb::opaque((lds_f64 *)tks));
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
   return fail;
@@ -1127,8 +1126,8 @@ __device__ inline int band_factor_panel(const Band &B, int n, int *ipiv, long lo
   __syncthreads();
   constexpr int SBIG = (kWideMaxKb + CFZ_PANEL + 63) / 64;
   const int fail = (B.kb + CFZ_PANEL <= 320 && !CFZ_FORCE_SBIG)
-      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks, (glb_f64 *)b1, (glb_f64 *)b2)
-      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, (lds_f64 *)lds, (lds_f64 *)pb, (lds_i32 *)pj, (lds_i32 *)meta, (lds_i32 *)ext, (lds_f64 *)tks, (glb_f64 *)b1, (glb_f64 *)b2);
+      ? band_factor_panel_core<CFZ_PANEL, 5>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, cfzb::opaque((lds_f64 *)lds), cfzb::opaque((lds_f64 *)pb), cfzb::opaque((lds_i32 *)pj), cfzb::opaque((lds_i32 *)meta), cfzb::opaque((lds_i32 *)ext), cfzb::opaque((lds_f64 *)tks), (glb_f64 *)b1, (glb_f64 *)b2)
+      : band_factor_panel_core<CFZ_PANEL, SBIG>((glb_f64 *)B.ab, B.kb, B.ld, n, (glb_i32 *)ipiv, cfzb::opaque((lds_f64 *)lds), cfzb::opaque((lds_f64 *)pb), cfzb::opaque((lds_i32 *)pj), cfzb::opaque((lds_i32 *)meta), cfzb::opaque((lds_i32 *)ext), cfzb::opaque((lds_f64 *)tks), (glb_f64 *)b1, (glb_f64 *)b2);
   __syncthreads();
   for (int i = 0; i < 3; ++i) ptk[i] += (long long)tks[i];
   return fail;
@@ -1332,7 +1331,7 @@ __device__ __attribute__((noinline)) void band_substitute_regs_core(const glb_f6
 __device__ inline void band_substitute_regs(const Band &B, int n, const int *ipiv, double *b, double *b2, bool fwd_done) {
   constexpr int CH = 16;
   __shared__ double slot[4 * CH], stage[2 * (2 * kWideMaxKb + CH)], tri[CH * CH + 4 * CH];
-  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, (lds_f64 *)slot, (lds_f64 *)stage, (lds_f64 *)tri, fwd_done);
+  band_substitute_regs_core<CH>((const glb_f64 *)B.ab, B.kb, B.ld, n, (const glb_i32 *)ipiv, (glb_f64 *)b, (glb_f64 *)b2, cfzb::opaque((lds_f64 *)slot), cfzb::opaque((lds_f64 *)stage), cfzb::opaque((lds_f64 *)tri), fwd_done);
 }
 #endif
 
@@ -1470,10 +1469,10 @@ CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
 
 // X: guess for the 7 variables of every point (vehicles back to back) followed by dt; solution out (same layout).
 // out_i = iterations, status; out_d = cost, err, mu, phase timers.  kb: half-bandwidth the caller sized the slab for
-// (half_bandwidth() of the ordering).  MODE (GPU only; 0 = the generic elimination everywhere): 1 = one wavefront, kb == kCB:
-// the kernel's dynamic LDS (kCLdsDoubles) is the window of cfzb::band_factor_lds / band_substitute_lds; 2 = several
+// (half_bandwidth() of the ordering).  MODE (GPU only; 0 = the generic elimination everywhere, the CPU build): 2 = eight
 // wavefronts: the panel elimination if its multipliers fit the dynamic LDS (lds_doubles), else band_factor_wide2; lds_rhs: doubles
 // of the dynamic LDS a right-hand side may occupy (band_substitute_wide, the fallback substitution), 0 = it does not fit.
+// (MODE 1, one wavefront per single plan with the elimination in an LDS window, was retired in round 4: see cfz_planning.hip.)
 template <int MODE>
 CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles, int lds_rhs = 0) {
   const CDims d = cdims(sp);
@@ -1580,8 +1579,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (MODE == 1 && kb == kCB && blockDim.x == 64) fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, tk + 6);
-      else if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
+      if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];
         fail = band_factor_panel(Bd, d.nk, w.ipiv, tk + 6, wlds, w.rhs, w.rhs2);
         fwd_done = true;
@@ -1591,8 +1589,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (MODE == 1 && kb == kCB && blockDim.x == 64 && 2 * d.nk <= kCWin * kCLd) cfzb::band_substitute_lds<true>(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);
-        else if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2, fwd_done);
+        if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2, fwd_done);
         else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_rhs) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else
 #endif
         band_substitute(Bd, d.nk, w.ipiv, w.rhs, w.rhs2);

@@ -5,17 +5,16 @@
 // rear-axle point inside the back cell and the front point (x + wb cos psi, y + wb sin psi) inside the front cell of
 // strategy step i, both shrunk by `shrink_tube` (:178-192); optional terminal heading (:194-195); cost sum a^2 + w^2
 // (:175-176).  Hundreds of stages, a handful of instances (one per vehicle), solved once: the opposite regime of the
-// MPC step, so this is not a one-wavefront-in-LDS kernel.  One instance per workgroup, workspace in global memory
-// (L2-resident), the interior-point iteration of oracle/ipm.py with the EXACT Hessian of the Lagrangian and the
-// curvature test  dx'(H + delta I)dx >= kappa |dx|^2  (delta: 0, 1e-4, x8 ...), on the full primal-dual system in a
-// stage-interleaved ordering that makes it banded (half-bandwidth <= 40) -- solved by a banded LU with partial
-// pivoting, so terminal and initial equalities, tube rows and indefinite stage Hessians need no special cases.
+// MPC step.  One instance per workgroup (one wavefront), workspace in global memory (L2-resident), the interior-point iteration of
+// oracle/ipm.py with the EXACT Hessian of the Lagrangian and the curvature test  dx'(H + delta I)dx >= kappa |dx|^2  (delta: 0, 1e-4,
+// x8 ...).  The Newton system is a stage recursion (Riccati sweep, below): rounds 1-3 solved it as a banded LU with partial pivoting
+// (half-bandwidth 40, ~3,000 pivots one after the other: 10 ms per iteration); the sweep is T stages of ~200 operations.
 //
 // The same source compiles for the CPU (tests/emu) and is checked iterate for iterate against oracle/plan_nlp.py.
 #pragma once
 #include <math.h>
 
-#include "cfz_band.inl"
+#include "cfz_band.inl"  // (for cfz_colloc.inl, which includes this file)
 
 #if defined(__HIPCC__)
 #define CFZP_FN __host__ __device__ inline
@@ -81,9 +80,6 @@ CFZP_FN double pmax(double v) { return v; }
 CFZP_FN double pmin(double v) { return v; }
 #endif
 
-constexpr int kKB = 40;               // half-bandwidth of the permuted KKT matrix (asserted at set-up)
-constexpr int kLd = 3 * kKB + 1;      // band storage rows (LAPACK gb layout with room for the pivoting fill-in)
-
 struct PSpec {
   int T, N, n_chk, has_final, bounded_input;
   int max_iter, max_backtrack, filter_cap, stall_iters, pad0;
@@ -103,14 +99,16 @@ CFZP_FN PDims dims(const PSpec &sp) {
   return d;
 }
 
-// workspace (doubles unless noted), carved out of one slab by `carve`
+// workspace (doubles), carved out of one slab by `carve`.  st / fb / vf: per stage, what the Riccati sweep reads (kSt), the feedback it
+// leaves for the forward sweep (kFb) and the value function the multipliers are read from (kVf); ce: the tube rows of a checkpoint
+// condensed into its pose block; dx2: the sweep's second solution (the terminal-heading column); flag: the sweep's verdict and eta
+constexpr int kSt = 27, kFb = 14, kVf = 25;
 struct PWork {
-  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *ab, *hd;
-  int *posx, *posc, *ipiv;
+  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *hd, *st, *fb, *vf, *ce, *dx2, *flag;
 };
 CFZP_FN size_t work_doubles(const PSpec &sp) {
   const PDims d = dims(sp);
-  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (1 + kLd) + (size_t)(d.n + d.m + d.nk + 2) / 2 + 64;
+  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)(sp.T + 1) * (kSt + kFb + kVf + 7) + (size_t)sp.n_chk * 6 + 72;
 }
 CFZP_FN PWork carve(const PSpec &sp, double *slab) {
   const PDims d = dims(sp);
@@ -118,8 +116,8 @@ CFZP_FN PWork carve(const PSpec &sp, double *slab) {
   w.x = p; p += d.n; w.xt = p; p += d.n; w.zl = p; p += d.n; w.zu = p; p += d.n; w.dx = p; p += d.n; w.dzl = p; p += d.n;
   w.dzu = p; p += d.n; w.g = p; p += d.n; w.xl = p; p += d.n; w.xu = p; p += d.n; w.r1 = p; p += d.n; w.hd = p; p += d.n;
   w.nu = p; p += d.m; w.dnu = p; p += d.m; w.c = p; p += d.m; w.ct = p; p += d.m;
-  w.rhs = p; p += d.nk; w.ab = p; p += (size_t)d.nk * kLd;
-  w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
+  w.st = p; p += (size_t)(sp.T + 1) * kSt; w.fb = p; p += (size_t)(sp.T + 1) * kFb; w.vf = p; p += (size_t)(sp.T + 1) * kVf;
+  w.dx2 = p; p += (size_t)(sp.T + 1) * 7; w.ce = p; p += (size_t)sp.n_chk * 6; w.flag = p;
   return w;
 }
 
@@ -191,178 +189,256 @@ CFZP_FN void jt_nu(const PSpec &sp, const double *tube, const double *X, const d
   CFZP_SYNC();
 }
 
-// ---- banded storage -----------------------------------------------------------------------------------------
-CFZP_FN double &band(double *ab, int i, int j) { return ab[(size_t)j * kLd + (2 * kKB + i - j)]; }
+// ---- the Newton system as a stage recursion ------------------------------------------------------------------------------------
+// [[W + Sigma + (delta + reg) I, J'], [J, -delta_c on the heading row]] (dx, dnu) = -(r1, c)  is the optimality system of a linear-
+// quadratic control problem over the stages: with the tube slacks eliminated into the pose block of their checkpoint (exactly: their rows
+// carry no delta_c) the unknowns of stage k are dz_k (5) and du_k (2), tied by  dz_{k+1} = A_k dz_k + B du_k + c_k,  A_k = I + dt f_z
+// (six entries off the diagonal), B = dt [e_v e_delta].  Stage 0 is pinned by the initial rows.  The value function  V_k(dz) =
+// dz' P_k dz / 2 + p_k' dz  runs backwards from k = T to 1 (one lane, ~200 dependent FP64 operations per stage); the terminal-heading
+// row is bordered: the sweep carries a second vector p2 for the right-hand side e_psi_T, and  eta = (dpsi_T(1) + c_f) / (dpsi_T(2) +
+// delta_c)  combines the two forward solutions.  Multipliers: dnu_k = P_{k+1} dz_{k+1} + p_{k+1}; the initial rows' from the stationarity
+// of stage 0; the tube rows' from their slacks.  No pivoting: where the reduced Hessian  R + B' P B  of a stage is not positive the
+// curvature test  dx'(H + delta I)dx >= kappa |dx|^2  would not pass either, and the sweep reports failure for a singular one.
+//
+// st[k] (kSt): a02 a03 a12 a13 a23 a24 | q0..q4 q23 q34 | r0 r1 | gz[5] gu[2] | c[5];   fb[k] (kFb): K (2 x 5) kk1[2] kk2[2];
+// vf[k] (kVf): P (upper triangle by rows, 15) p1[5] p2[5];   ce[i]: E00 E01 E02 E11 E12 E22 of checkpoint i
+// FAST: st and fb live in the kernel's dynamic LDS ((kSt + kFb)(T + 1) doubles: 99 KB at T = 300); otherwise (plans too long for the
+// LDS, batches of several plans per CU; the CPU build) in the workspace.  The inlined code names the dynamic LDS directly; the sweeps,
+// functions of their own on the GPU (their registers are allocated apart from the solver's many live scalars), take LDS-typed POINTERS:
+// a non-inlined function that NAMES LDS is broken on this toolchain (gfx950, ROCm 7.2; cfz_colloc.inl's header, cfz_band.inl's `opaque`).
+#if defined(__HIPCC__)
+#define CFZP_SWEEP __host__ __device__ __attribute__((noinline))
+#else
+#define CFZP_SWEEP inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZP_FIRST (threadIdx.x == 0)
+#define CFZP_STAGE_PTRS(w, T) extern __shared__ double cfzp_lds[]; double *const st_ = FAST ? cfzp_lds : (w).st; double *const fb_ = FAST ? cfzp_lds + (size_t)kSt * ((T) + 1) : (w).fb
+typedef cfzb::lds_f64 fast_f64;
+#define CFZP_OPAQUE(p) cfzb::opaque(p)  // cfz_band.inl: the sweeps must not learn WHICH LDS array they work on
+#else
+#define CFZP_OPAQUE(p) (p)
+#define CFZP_FIRST true
+#define CFZP_STAGE_PTRS(w, T) double *const st_ = (w).st; double *const fb_ = (w).fb
+typedef double fast_f64;
+#endif
 
-// stage-interleaved ordering: [init rows | z_0 u_0 | dyn_0 | z_1 u_1 | (slacks, tube rows at checkpoints) | dyn_1 | ...]
-CFZP_FN int build_order(const PSpec &sp, int *posx, int *posc) {
+template <bool FAST>
+CFZP_FN void riccati_prepare(const PSpec &sp, const double *tube, const PWork &w, const double *sig, double delta) {
   const PDims d = dims(sp);
-  int p = 0;
-  for (int k = 0; k <= sp.T; ++k) {
-    if (k == 0) for (int i = 0; i < 7; ++i) posc[i] = p++;
-    const int nv = k < sp.T ? 7 : 5;
-    for (int i = 0; i < nv; ++i) posx[7 * k + i] = p++;
-    if (k > 0 && k % sp.N == 0 && k / sp.N - 1 < sp.n_chk) {
-      const int i = k / sp.N - 1;
-      for (int q = 0; q < 8; ++q) posx[d.s0 + 8 * i + q] = p++;
-      for (int q = 0; q < 8; ++q) posc[d.r0 + 8 * i + q] = p++;
-    }
-    if (k == sp.T && sp.has_final) posc[d.m - 1] = p++;
-    if (k < sp.T) for (int i = 0; i < 5; ++i) posc[7 + 5 * k + i] = p++;
-  }
-  return p;
-}
-
-CFZP_FN void put(double *ab, int i, int j, double v) { band(ab, i, j) += v; if (i != j) band(ab, j, i) += v; }
-
-// KKT matrix [[W + Sigma + (delta + reg) I, J'], [J, 0]] in band storage; hd returns the primal diagonal shift applied
-CFZP_FN void assemble(const PSpec &sp, const double *tube, const PWork &w, const double *sig, double delta) {
-  const PDims d = dims(sp);
-  const int *px = w.posx, *pc = w.posc;
-  CFZP_LANE_FOR(col, 0, d.nk - 1) for (int r = 0; r < kLd; ++r) w.ab[(size_t)col * kLd + r] = 0.0;
-  CFZP_SYNC();
+  CFZP_STAGE_PTRS(w, sp.T); (void)fb_;
   const double *X = w.x, *nu = w.nu;
-  CFZP_LANE_FOR(i, 0, d.n - 1) band(w.ab, px[i], px[i]) += sig[i] + delta + sp.reg_primal;
-  // IPOPT's delta_c: with v = delta = 0 in the guess the heading rows lose rank once the terminal heading is fixed
-  CFZP_LANE_FOR(i, 0, d.m - 1) band(w.ab, pc[i], pc[i]) -= sp.reg_dual;
-  CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, 6) put(w.ab, pc[i], px[i], 1.0);
-  CFZP_LANE_FOR(k, 0, sp.T - 1) {  // every entry written here belongs to stage k alone
-    const double *z = X + 7 * k, *l = nu + 7 + 5 * k;
-    const int b = 7 * k, bn = 7 * (k + 1), r = 7 + 5 * k;
-    const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]), dt = sp.dt, sec2 = 1.0 + tn * tn, v = z[3];
-    // objective and dynamics curvature (multipliers of the x, y, psi rows)
-    band(w.ab, px[b + 5], px[b + 5]) += 2.0; band(w.ab, px[b + 6], px[b + 6]) += 2.0;
-    const double l0 = l[0] * dt, l1 = l[1] * dt, l2 = l[2] * dt;
-    band(w.ab, px[b + 2], px[b + 2]) += l0 * (-v * cs) + l1 * (-v * sn);
-    put(w.ab, px[b + 2], px[b + 3], l0 * (-sn) + l1 * cs);
-    put(w.ab, px[b + 3], px[b + 4], l2 * sec2 / sp.wb);
-    band(w.ab, px[b + 4], px[b + 4]) += l2 * 2.0 * v * tn * sec2 / sp.wb;
-    // Jacobian of the Euler rows
-    for (int i = 0; i < 5; ++i) { put(w.ab, pc[r + i], px[b + i], 1.0); put(w.ab, pc[r + i], px[bn + i], -1.0); }
-    put(w.ab, pc[r + 0], px[b + 2], dt * (-v * sn)); put(w.ab, pc[r + 0], px[b + 3], dt * cs);
-    put(w.ab, pc[r + 1], px[b + 2], dt * (v * cs)); put(w.ab, pc[r + 1], px[b + 3], dt * sn);
-    put(w.ab, pc[r + 2], px[b + 3], dt * tn / sp.wb); put(w.ab, pc[r + 2], px[b + 4], dt * v / sp.wb * sec2);
-    put(w.ab, pc[r + 3], px[b + 5], dt); put(w.ab, pc[r + 4], px[b + 6], dt);
+  const double shift = delta + sp.reg_primal, dt = sp.dt;
+  CFZP_LANE_FOR(k, 0, sp.T) {
+    double *s = st_ + (size_t)kSt * k;
+    const int b = 7 * k;
+    if (k < sp.T) {
+      const double *z = X + b, *l = nu + 7 + 5 * k;
+      const double cs = cos(z[2]), sn = sin(z[2]), tn = tan(z[4]), sec2 = 1.0 + tn * tn, v = z[3];
+      const double l0 = l[0] * dt, l1 = l[1] * dt, l2 = l[2] * dt;
+      s[0] = dt * (-v * sn); s[1] = dt * cs; s[2] = dt * (v * cs); s[3] = dt * sn; s[4] = dt * tn / sp.wb; s[5] = dt * v / sp.wb * sec2;
+      s[6] = sig[b] + shift; s[7] = sig[b + 1] + shift; s[9] = sig[b + 3] + shift;
+      s[8] = sig[b + 2] + shift + l0 * (-v * cs) + l1 * (-v * sn); s[10] = sig[b + 4] + shift + l2 * 2.0 * v * tn * sec2 / sp.wb;
+      s[11] = l0 * (-sn) + l1 * cs; s[12] = l2 * sec2 / sp.wb;
+      s[13] = 2.0 + sig[b + 5] + shift; s[14] = 2.0 + sig[b + 6] + shift;
+      for (int i = 0; i < 7; ++i) s[15 + i] = w.r1[b + i];
+      for (int i = 0; i < 5; ++i) s[22 + i] = w.c[7 + 5 * k + i];
+    } else {
+      for (int i = 0; i < kSt; ++i) s[i] = 0.0;
+      for (int i = 0; i < 5; ++i) { s[6 + i] = sig[b + i] + shift; s[15 + i] = w.r1[b + i]; }
+    }
   }
   CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {
-    const int b = 7 * chk_stage(sp, i), r = d.r0 + 8 * i, s = d.s0 + 8 * i;
+  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {  // tube rows of checkpoint i -> pose block E, pose gradient, heading curvature
+    const int k = chk_stage(sp, i), b = 7 * k, r = d.r0 + 8 * i, sl = d.s0 + 8 * i;
+    double *s = st_ + (size_t)kSt * k, *E = w.ce + 6 * i;
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
     const double *cb = cell(tube, i, 0), *cf = cell(tube, i, 1);
-    double curv = 0.0;
-    for (int q = 0; q < 4; ++q) {
-      put(w.ab, pc[r + q], px[b], cb[2 * q]); put(w.ab, pc[r + q], px[b + 1], cb[2 * q + 1]); put(w.ab, pc[r + q], px[s + q], 1.0);
-      put(w.ab, pc[r + 4 + q], px[b], cf[2 * q]); put(w.ab, pc[r + 4 + q], px[b + 1], cf[2 * q + 1]);
-      put(w.ab, pc[r + 4 + q], px[b + 2], sp.wb * (-cf[2 * q] * sn + cf[2 * q + 1] * cs));
-      put(w.ab, pc[r + 4 + q], px[s + 4 + q], 1.0);
-      curv += nu[r + 4 + q] * sp.wb * (-cf[2 * q] * cs - cf[2 * q + 1] * sn);
+    double e[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, curv = 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const double *cc = q < 4 ? cb : cf; const int qq = q & 3;
+      const double G[3] = {cc[2 * qq], cc[2 * qq + 1], q < 4 ? 0.0 : sp.wb * (-cc[2 * qq] * sn + cc[2 * qq + 1] * cs)};
+      const double S = sig[sl + q] + shift, t = S * w.c[r + q] - w.r1[sl + q];
+      e[0] += S * G[0] * G[0]; e[1] += S * G[0] * G[1]; e[2] += S * G[0] * G[2]; e[3] += S * G[1] * G[1]; e[4] += S * G[1] * G[2]; e[5] += S * G[2] * G[2];
+      for (int j = 0; j < 3; ++j) gp[j] += G[j] * t;
+      if (q >= 4) curv += nu[r + q] * sp.wb * (-cc[2 * qq] * cs - cc[2 * qq + 1] * sn);
     }
-    band(w.ab, px[b + 2], px[b + 2]) += curv;
+    for (int j = 0; j < 6; ++j) E[j] = e[j];
+    for (int j = 0; j < 3; ++j) s[15 + j] += gp[j];
+    s[8] += curv;
   }
-  CFZP_LANE_FOR(one, 0, 0) if (sp.has_final) put(w.ab, pc[d.m - 1], px[7 * sp.T + 2], 1.0);  // (one thread: += is not idempotent)
   CFZP_SYNC();
 }
 
-// LU with partial pivoting of an n x n band matrix (kl = ku = kKB) in LAPACK gb layout, then one solve; 0 = ok
-// `win`: optional fast storage (LDS on the GPU) for the kv+1 = 81 columns the elimination is working on; column q lives
-// in slot q mod 81 while j <= q <= j + kv, enters from `ab` when pivot j = q - kv starts and is written back after
-// its own pivot step.  nullptr: work in `ab` directly.
-constexpr int kWinCols = 2 * kKB + 1;
-template <bool WIN>
-CFZP_FN int band_solve(double *ab, int n, int *ipiv, double *b, double *win) {
-  const int kl = kKB, ku = kKB, kv = kl + ku;
-// WIN is a compile-time switch, and on the GPU the window is named directly (the kernel's dynamic LDS) rather than taken
-// from the argument, so that every access to it is a DS instruction: through a generic pointer most of them became FLAT
-// instructions, which wait on the global-memory counter as well
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ double cfzp_lds[];
-#define CFZP_WIN_BASE cfzp_lds
-#else
-#define CFZP_WIN_BASE win
-#endif
-#define CFZP_COL(q) (WIN ? CFZP_WIN_BASE + (size_t)((q) % kWinCols) * kLd : ab + (size_t)(q) * kLd)
-  if (WIN) {
-    const int last = kv < n - 1 ? kv : n - 1;
-    for (int q = 0; q <= last; ++q) CFZP_LANE_FOR(r, 0, kLd - 1) CFZP_WIN_BASE[(size_t)q * kLd + r] = ab[(size_t)q * kLd + r];
-    CFZP_SYNC();
+// backward sweep (ONE lane calls it); 0 = ok, 1 = a stage's reduced Hessian is singular or not finite.
+// P in symmetric storage (P00 P01 .. P04 P11 .. P44), the products a column at a time: nothing here may spill (a spilled value costs a
+// round trip to memory in a chain of dependent operations).
+template <class SP>
+CFZP_SWEEP int riccati_backward(const PSpec &sp, const PWork &w, SP st_, SP fb_) {
+  const int T = sp.T; const double dt = sp.dt, dt2 = dt * dt;
+  double P00, P01, P02, P03, P04, P11, P12, P13, P14, P22, P23, P24, P33, P34, P44;
+  double p1[5], p2[5] = {0.0, 0.0, sp.has_final ? -1.0 : 0.0, 0.0, 0.0};
+  {
+    const auto *s = st_ + (size_t)kSt * T; const double *E = w.ce + 6 * (sp.n_chk - 1);
+    P00 = s[6] + E[0]; P01 = E[1]; P02 = E[2]; P03 = 0.0; P04 = 0.0; P11 = s[7] + E[3]; P12 = E[4]; P13 = 0.0; P14 = 0.0;
+    P22 = s[8] + E[5]; P23 = 0.0; P24 = 0.0; P33 = s[9]; P34 = 0.0; P44 = s[10];
+    for (int i = 0; i < 5; ++i) p1[i] = s[15 + i];
   }
-  int ju = 0;
-  for (int j = 0; j < n; ++j) {
-    const int km = (kl < n - 1 - j) ? kl : n - 1 - j;
-    double *cj = CFZP_COL(j);
-    int jp = 0; double best;
-#if defined(__HIP_DEVICE_COMPILE__)
-    {  // pivot search: one candidate per lane, butterfly arg-max (first maximum wins, as in the serial loop)
-      const int lane = threadIdx.x;
-      best = lane <= km ? fabs(cj[kv + lane]) : -1.0; jp = lane;
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off); const int oj = __shfl_xor(jp, off);
-        if (ob > best || (ob == best && oj < jp)) { best = ob; jp = oj; }
+#define CFZP_STORE_VF(k)                                                                                                            \
+  {                                                                                                                                 \
+    double *v = w.vf + (size_t)kVf * (k);                                                                                           \
+    v[0] = P00; v[1] = P01; v[2] = P02; v[3] = P03; v[4] = P04; v[5] = P11; v[6] = P12; v[7] = P13; v[8] = P14; v[9] = P22;         \
+    v[10] = P23; v[11] = P24; v[12] = P33; v[13] = P34; v[14] = P44;                                                                \
+    for (int i = 0; i < 5; ++i) { v[15 + i] = p1[i]; v[20 + i] = p2[i]; }                                                           \
+  }
+  CFZP_STORE_VF(T)
+  for (int k = T - 1; k >= 1; --k) {
+    const auto *s = st_ + (size_t)kSt * k;
+    const double a02 = s[0], a03 = s[1], a12 = s[2], a13 = s[3], a23 = s[4], a24 = s[5];
+    // h = p + P c;  g = A' h
+    const double c0 = s[22], c1 = s[23], c2 = s[24], c3 = s[25], c4 = s[26];
+    const double h0 = p1[0] + P00 * c0 + P01 * c1 + P02 * c2 + P03 * c3 + P04 * c4, h1 = p1[1] + P01 * c0 + P11 * c1 + P12 * c2 + P13 * c3 + P14 * c4,
+                 h2 = p1[2] + P02 * c0 + P12 * c1 + P22 * c2 + P23 * c3 + P24 * c4, h3 = p1[3] + P03 * c0 + P13 * c1 + P23 * c2 + P33 * c3 + P34 * c4,
+                 h4 = p1[4] + P04 * c0 + P14 * c1 + P24 * c2 + P34 * c3 + P44 * c4;
+    // columns of P A (A = I + six entries):  col0, col1 are P's;  col2 = P2 + a02 P0 + a12 P1;  col3 = P3 + a03 P0 + a13 P1 + a23 P2;  col4 = P4 + a24 P2
+    const double B02 = P02 + a02 * P00 + a12 * P01, B12 = P12 + a02 * P01 + a12 * P11, B22 = P22 + a02 * P02 + a12 * P12, B32 = P23 + a02 * P03 + a12 * P13,
+                 B42 = P24 + a02 * P04 + a12 * P14;
+    const double B03 = P03 + a03 * P00 + a13 * P01 + a23 * P02, B13 = P13 + a03 * P01 + a13 * P11 + a23 * P12, B23 = P23 + a03 * P02 + a13 * P12 + a23 * P22,
+                 B33 = P33 + a03 * P03 + a13 * P13 + a23 * P23, B43 = P34 + a03 * P04 + a13 * P14 + a23 * P24;
+    const double B04 = P04 + a24 * P02, B14 = P14 + a24 * P12, B24 = P24 + a24 * P22, B34 = P34 + a24 * P23, B44 = P44 + a24 * P24;
+    // reduced Hessian of the stage and its inverse
+    const double R00 = s[13] + dt2 * P33, R01 = dt2 * P34, R11 = s[14] + dt2 * P44;
+    const double det = R00 * R11 - R01 * R01;
+    if (!(det != 0.0) || !isfinite(det)) return 1;
+    const double idet = 1.0 / det, i00 = R11 * idet, i01 = -R01 * idet, i11 = R00 * idet;
+    // Rux = dt (P A)[3:5, :]  (row 3 of P A: P03 P13 B32 B33 B34; row 4: P04 P14 B42 B43 B44)
+    const double x0[5] = {dt * P03, dt * P13, dt * B32, dt * B33, dt * B34}, x1[5] = {dt * P04, dt * P14, dt * B42, dt * B43, dt * B44};
+    double K0[5], K1[5];
+    for (int j = 0; j < 5; ++j) { K0[j] = -(i00 * x0[j] + i01 * x1[j]); K1[j] = -(i01 * x0[j] + i11 * x1[j]); }
+    const double ku0 = s[20] + dt * h3, ku1 = s[21] + dt * h4, kv0 = dt * p2[3], kv1 = dt * p2[4];
+    const double kk0 = -(i00 * ku0 + i01 * ku1), kk1 = -(i01 * ku0 + i11 * ku1), kl0 = -(i00 * kv0 + i01 * kv1), kl1 = -(i01 * kv0 + i11 * kv1);
+    {
+      auto *f = fb_ + (size_t)kFb * k;
+      for (int j = 0; j < 5; ++j) { f[j] = K0[j]; f[5 + j] = K1[j]; }
+      f[10] = kk0; f[11] = kk1; f[12] = kl0; f[13] = kl1;
+    }
+    // p = gz + A' h + Rux' kk
+    const double q0 = p2[0], q1 = p2[1], q2 = p2[2], q3 = p2[3], q4 = p2[4];
+    p1[0] = s[15] + h0 + x0[0] * kk0 + x1[0] * kk1;
+    p1[1] = s[16] + h1 + x0[1] * kk0 + x1[1] * kk1;
+    p1[2] = s[17] + h2 + a02 * h0 + a12 * h1 + x0[2] * kk0 + x1[2] * kk1;
+    p1[3] = s[18] + h3 + a03 * h0 + a13 * h1 + a23 * h2 + x0[3] * kk0 + x1[3] * kk1;
+    p1[4] = s[19] + h4 + a24 * h2 + x0[4] * kk0 + x1[4] * kk1;
+    p2[0] = q0 + x0[0] * kl0 + x1[0] * kl1;
+    p2[1] = q1 + x0[1] * kl0 + x1[1] * kl1;
+    p2[2] = q2 + a02 * q0 + a12 * q1 + x0[2] * kl0 + x1[2] * kl1;
+    p2[3] = q3 + a03 * q0 + a13 * q1 + a23 * q2 + x0[3] * kl0 + x1[3] * kl1;
+    p2[4] = q4 + a24 * q2 + x0[4] * kl0 + x1[4] * kl1;
+    // P <- Q + A' (P A) + Rux' K, upper triangle:  (A' M)_ij = M_ij + (column i of A above the diagonal) . M_:j
+    const double N00 = P00 + x0[0] * K0[0] + x1[0] * K1[0], N01 = P01 + x0[0] * K0[1] + x1[0] * K1[1], N02 = B02 + x0[0] * K0[2] + x1[0] * K1[2],
+                 N03 = B03 + x0[0] * K0[3] + x1[0] * K1[3], N04 = B04 + x0[0] * K0[4] + x1[0] * K1[4];
+    const double N11 = P11 + x0[1] * K0[1] + x1[1] * K1[1], N12 = B12 + x0[1] * K0[2] + x1[1] * K1[2], N13 = B13 + x0[1] * K0[3] + x1[1] * K1[3],
+                 N14 = B14 + x0[1] * K0[4] + x1[1] * K1[4];
+    const double N22 = B22 + a02 * B02 + a12 * B12 + x0[2] * K0[2] + x1[2] * K1[2], N23 = B23 + a02 * B03 + a12 * B13 + x0[2] * K0[3] + x1[2] * K1[3],
+                 N24 = B24 + a02 * B04 + a12 * B14 + x0[2] * K0[4] + x1[2] * K1[4];
+    const double N33 = B33 + a03 * B03 + a13 * B13 + a23 * B23 + x0[3] * K0[3] + x1[3] * K1[3], N34 = B34 + a03 * B04 + a13 * B14 + a23 * B24 + x0[3] * K0[4] + x1[3] * K1[4];
+    const double N44 = B44 + a24 * B24 + x0[4] * K0[4] + x1[4] * K1[4];
+    P00 = N00 + s[6]; P01 = N01; P02 = N02; P03 = N03; P04 = N04; P11 = N11 + s[7]; P12 = N12; P13 = N13; P14 = N14;
+    P22 = N22 + s[8]; P23 = N23 + s[11]; P24 = N24; P33 = N33 + s[9]; P34 = N34 + s[12]; P44 = N44 + s[10];
+    if (k % sp.N == 0) {
+      const double *E = w.ce + 6 * (k / sp.N - 1);
+      P00 += E[0]; P01 += E[1]; P02 += E[2]; P11 += E[3]; P12 += E[4]; P22 += E[5];
+    }
+    CFZP_STORE_VF(k)
+  }
+#undef CFZP_STORE_VF
+  return 0;
+}
+
+// forward sweep (ONE lane): the two solutions' dz, du -> w.dx (right-hand side -(r1, c)) and w.dx2 (e_psi_T)
+template <class SP>
+CFZP_SWEEP void riccati_forward(const PSpec &sp, const PWork &w, SP st_, SP fb_) {
+  const int T = sp.T; const double dt = sp.dt;
+  double z1[5], z2[5] = {0, 0, 0, 0, 0}, u1[2], u2[2] = {0, 0};
+  for (int i = 0; i < 5; ++i) z1[i] = -w.c[i];
+  u1[0] = -w.c[5]; u1[1] = -w.c[6];
+  for (int k = 0; k < T; ++k) {
+    const auto *s = st_ + (size_t)kSt * k;
+    if (k > 0) {
+      const auto *f = fb_ + (size_t)kFb * k;
+      for (int q = 0; q < 2; ++q) {
+        double a = f[10 + q], b = f[12 + q];
+        for (int j = 0; j < 5; ++j) { a += f[5 * q + j] * z1[j]; b += f[5 * q + j] * z2[j]; }
+        u1[q] = a; u2[q] = b;
       }
     }
-#else
-    best = fabs(cj[kv]);
-    for (int i = 1; i <= km; ++i) { const double a = fabs(cj[kv + i]); if (a > best) { best = a; jp = i; } }
-#endif
-    ipiv[j] = j + jp;
-    if (!(best > 0.0)) return 1;
-    const int reach = j + ku + jp; ju = ju > (reach < n - 1 ? reach : n - 1) ? ju : (reach < n - 1 ? reach : n - 1);
-    if (jp != 0) {
-      CFZP_LANE_FOR(q, j, ju) {  // swap rows j and j+jp over columns j..ju
-        double *cq = CFZP_COL(q);
-        double &a = cq[kv + j - q], &c = cq[kv + j + jp - q];
-        const double t = a; a = c; c = t;
-      }
-      CFZP_SYNC();
-    }
-    const double inv = 1.0 / cj[kv];
-    CFZP_SYNC();
-    CFZP_LANE_FOR(i, 1, km) cj[kv + i] *= inv;
-    CFZP_SYNC();
-    CFZP_LANE_FOR(q, j + 1, ju) {  // rank-1 update of the trailing window, one column per lane
-      double *cq = CFZP_COL(q);
-      const double u = cq[kv + j - q];
-      if (u != 0.0) for (int i = 1; i <= km; ++i) cq[kv + j + i - q] -= cj[kv + i] * u;
-    }
-    CFZP_SYNC();
-    if (WIN) {  // column j is final: back to `ab`; its slot takes column j + kv + 1
-      CFZP_LANE_FOR(r, 0, kLd - 1) ab[(size_t)j * kLd + r] = cj[r];
-      CFZP_SYNC();
-      const int qn = j + kv + 1;
-      if (qn < n) { CFZP_LANE_FOR(r, 0, kLd - 1) cj[r] = ab[(size_t)qn * kLd + r]; }
-      CFZP_SYNC();
-    }
+    for (int i = 0; i < 5; ++i) { w.dx[7 * k + i] = z1[i]; w.dx2[7 * k + i] = z2[i]; }
+    w.dx[7 * k + 5] = u1[0]; w.dx[7 * k + 6] = u1[1]; w.dx2[7 * k + 5] = u2[0]; w.dx2[7 * k + 6] = u2[1];
+    const double n1[5] = {z1[0] + s[0] * z1[2] + s[1] * z1[3] + s[22], z1[1] + s[2] * z1[2] + s[3] * z1[3] + s[23], z1[2] + s[4] * z1[3] + s[5] * z1[4] + s[24],
+                          z1[3] + dt * u1[0] + s[25], z1[4] + dt * u1[1] + s[26]};
+    const double n2[5] = {z2[0] + s[0] * z2[2] + s[1] * z2[3], z2[1] + s[2] * z2[2] + s[3] * z2[3], z2[2] + s[4] * z2[3] + s[5] * z2[4], z2[3] + dt * u2[0],
+                          z2[4] + dt * u2[1]};
+    for (int i = 0; i < 5; ++i) { z1[i] = n1[i]; z2[i] = n2[i]; }
   }
-#undef CFZP_COL
-#undef CFZP_WIN_BASE
-  // the swap and the division are not idempotent: ONE thread does them (every thread runs this scalar code; inside one wavefront
-  // the lanes' redundant read-modify-writes happen to coincide, across wavefronts they would repeat -- the bug class that bit
-  // `assemble` when state_ws went to eight wavefronts)
-#if defined(__HIP_DEVICE_COMPILE__)
-  const bool first = threadIdx.x == 0;
-#else
-  const bool first = true;
-#endif
-  for (int j = 0; j < n; ++j) {  // L y = P b
-    const int km = (kl < n - 1 - j) ? kl : n - 1 - j, p = ipiv[j];
-    if (p != j) {
-      if (first) { const double t = b[j]; b[j] = b[p]; b[p] = t; }
-      CFZP_SYNC();
+  for (int i = 0; i < 5; ++i) { w.dx[7 * T + i] = z1[i]; w.dx2[7 * T + i] = z2[i]; }
+}
+
+// The Newton step into w.dx, w.dnu; 0 = ok.  Ends with a barrier.
+template <bool FAST>
+CFZP_FN int newton_step(const PSpec &sp, const double *tube, const PWork &w, const double *sig, double delta) {
+  const PDims d = dims(sp);
+  CFZP_STAGE_PTRS(w, sp.T);
+  const int T = sp.T; const double dt = sp.dt;
+  riccati_prepare<FAST>(sp, tube, w, sig, delta);
+  if (CFZP_FIRST) {
+    int fail;
+    if (FAST) {
+      fast_f64 *const fs = CFZP_OPAQUE((fast_f64 *)st_), *const ff = CFZP_OPAQUE((fast_f64 *)fb_);
+      fail = riccati_backward(sp, w, fs, ff);
+      if (!fail) riccati_forward(sp, w, fs, ff);
+    } else {
+      fail = riccati_backward(sp, w, st_, fb_);
+      if (!fail) riccati_forward(sp, w, st_, fb_);
     }
-    const double bj = b[j];
-    CFZP_SYNC();
-    if (bj != 0.0) CFZP_LANE_FOR(i, 1, km) b[j + i] -= ab[(size_t)j * kLd + kv + i] * bj;
+    double eta = 0.0;
+    if (!fail && sp.has_final) eta = (w.dx[7 * T + 2] + w.c[d.m - 1]) / (w.dx2[7 * T + 2] + sp.reg_dual);
+    w.flag[0] = (double)fail; w.flag[1] = eta;
+  }
+  CFZP_SYNC();
+  if (w.flag[0] != 0.0) return 1;
+  const double eta = w.flag[1];
+  if (sp.has_final) {
+    CFZP_LANE_FOR(i, 0, d.s0 - 1) w.dx[i] -= eta * w.dx2[i];
     CFZP_SYNC();
   }
-  for (int j = n - 1; j >= 0; --j) {  // U x = y
-    const double bj = b[j] / ab[(size_t)j * kLd + kv];
-    CFZP_SYNC();
-    if (first) b[j] = bj;
-    const int lo = j - kv > 0 ? j - kv : 0;
-    if (bj != 0.0) CFZP_LANE_FOR(i, lo, j - 1) b[i] -= ab[(size_t)j * kLd + kv + i - j] * bj;
-    CFZP_SYNC();
+  CFZP_LANE_FOR(k, 0, T - 1) {  // multipliers of the Euler rows; stage 0 also the initial rows'
+    const double *v = w.vf + (size_t)kVf * (k + 1), *zn = w.dx + 7 * (k + 1);
+    double Pm[5][5]; int o = 0;
+    for (int i = 0; i < 5; ++i) for (int j = i; j < 5; ++j) { Pm[i][j] = v[o]; Pm[j][i] = v[o]; ++o; }
+    double l[5];
+    for (int i = 0; i < 5; ++i) { double t = v[15 + i] - eta * v[20 + i]; for (int j = 0; j < 5; ++j) t += Pm[i][j] * zn[j]; l[i] = t; w.dnu[7 + 5 * k + i] = t; }
+    if (k == 0) {
+      const double *s = st_, *z = w.dx;
+      const double At[5] = {l[0], l[1], l[2] + s[0] * l[0] + s[2] * l[1], l[3] + s[1] * l[0] + s[3] * l[1] + s[4] * l[2], l[4] + s[5] * l[2]};
+      const double Qz[5] = {s[6] * z[0], s[7] * z[1], s[8] * z[2] + s[11] * z[3], s[9] * z[3] + s[11] * z[2] + s[12] * z[4], s[10] * z[4] + s[12] * z[3]};
+      for (int i = 0; i < 5; ++i) w.dnu[i] = -(Qz[i] + s[15 + i] + At[i]);
+      w.dnu[5] = -(s[13] * z[5] + s[20] + dt * l[3]); w.dnu[6] = -(s[14] * z[6] + s[21] + dt * l[4]);
+    }
   }
+  CFZP_LANE_FOR(i, 0, sp.n_chk - 1) {  // slacks and multipliers of the tube rows
+    const int b = 7 * chk_stage(sp, i), r = d.r0 + 8 * i, sl = d.s0 + 8 * i;
+    const double cs = cos(w.x[b + 2]), sn = sin(w.x[b + 2]);
+    const double *cb = cell(tube, i, 0), *cf = cell(tube, i, 1);
+    const double shift = delta + sp.reg_primal;
+    for (int q = 0; q < 8; ++q) {
+      const double *cc = q < 4 ? cb : cf; const int qq = q & 3;
+      const double G2 = q < 4 ? 0.0 : sp.wb * (-cc[2 * qq] * sn + cc[2 * qq + 1] * cs);
+      const double ds = -w.c[r + q] - (cc[2 * qq] * w.dx[b] + cc[2 * qq + 1] * w.dx[b + 1] + G2 * w.dx[b + 2]);
+      w.dx[sl + q] = ds; w.dnu[r + q] = -w.r1[sl + q] - (sig[sl + q] + shift) * ds;
+    }
+  }
+  if (sp.has_final && CFZP_FIRST) w.dnu[d.m - 1] = eta;
+  CFZP_SYNC();
   return 0;
 }
 
@@ -377,24 +453,12 @@ CFZP_FN double barrier_obj(const PSpec &sp, const PWork &w, const double *X, dou
   return objective(sp, X) - mu * psum(s);
 }
 
-}  // namespace cfzp
-#if defined(__HIP_DEVICE_COMPILE__)
-namespace cfzc {  // the eight-wavefront elimination and substitution of cfz_colloc.inl (defined there, after this file)
-__device__ inline int band_factor_panel(const cfzb::Band &B, int n, int *ipiv, long long *ptk, double *lds, double *b1, double *b2);
-__device__ inline void band_substitute_regs(const cfzb::Band &B, int n, const int *ipiv, double *b, double *b2, bool fwd_done);
-}
-#endif
-namespace cfzp {
-
-// WIDE: eight wavefronts per plan, band eliminated from global memory a panel at a time (cfz_colloc.inl) -- faster per plan than
-// the one-wavefront LDS window, one plan per CU instead of two.
-template <bool WIN, bool WIDE = false>
-CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d,
-                            double *win) {
+// One plan per workgroup of ONE wavefront (the sweep is one lane's work, everything else is O(n) and shared by the lanes).
+template <bool FAST>
+CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, double *slab, int *out_i, double *out_d) {
   const PDims d = dims(sp);
   const PWork w = carve(sp, slab);
   const int n = d.n, m = d.m;
-  build_order(sp, w.posx, w.posc);
   // bounds
   CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.s0 ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i < d.s0 ? X[i] : 0.0; }
@@ -474,29 +538,10 @@ CFZP_FN void solve_state_ws(const PSpec &sp, const double *tube, double *X, doub
     // Newton step with the curvature test
     double delta = delta_floor; bool have = false;
     for (int tries = 0; tries < 60; ++tries) {
-      assemble(sp, tube, w, sig, delta);
-      CFZP_LANE_FOR(i, 0, n - 1) w.rhs[w.posx[i]] = -w.r1[i];
-      CFZP_LANE_FOR(i, 0, m - 1) w.rhs[w.posc[i]] = -w.c[i];
-      CFZP_SYNC();
-      int fail;
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (WIDE) {
-        const cfzb::Band Bd = {w.ab, kKB, kLd};
-        long long unused[3] = {0, 0, 0};
-        fail = cfzc::band_factor_panel(Bd, d.nk, w.ipiv, unused, win, w.rhs, nullptr);  // the right-hand side rides along
-        if (!fail) cfzc::band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs, true);
-      } else if (WIN && d.nk <= kWinCols * kLd) {  // the batched LDS elimination of cfz_band.inl; the right-hand side follows in LDS
-        const cfzb::Band Bd = {w.ab, kKB, kLd};
-        long long unused[3] = {0, 0, 0};
-        fail = cfzb::band_factor_lds(Bd, d.nk, w.ipiv, unused);
-        if (!fail) cfzb::band_substitute_lds<false>(Bd, d.nk, w.ipiv, w.rhs, nullptr);
-      } else
-#endif
-      fail = band_solve<WIN>(w.ab, d.nk, w.ipiv, w.rhs, win);
-      if (!fail) {
-        double curv = 0.0, dd = 0.0, bad = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - reg_dual |dnu|^2  (from the two block rows of the system)
-        CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.rhs[w.posx[i]]; if (!isfinite(v)) bad = 1.0; w.dx[i] = v; curv -= v * w.r1[i]; dd += v * v; }
-        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.rhs[w.posc[i]]; if (!isfinite(v)) bad = 1.0; w.dnu[i] = v; curv += w.c[i] * v - sp.reg_dual * v * v; }
+      if (!newton_step<FAST>(sp, tube, w, sig, delta)) {
+        double curv = 0.0, dd = 0.0, bad = 0.0;  // dx'(H) dx = -dx.r1 + c.dnu - delta_c eta^2  (from the two block rows of the system)
+        CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.dx[i]; if (!isfinite(v)) bad = 1.0; curv -= v * w.r1[i]; dd += v * v; }
+        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += w.c[i] * v - ((sp.has_final && i == m - 1) ? sp.reg_dual * v * v : 0.0); }
         curv = psum(curv); dd = psum(dd); bad = pmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }

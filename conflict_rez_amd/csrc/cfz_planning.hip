@@ -26,45 +26,32 @@
 
 namespace {
 
-// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup, workspace in global memory; see cfz_plan.inl.
+// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup of one wavefront, workspace in global memory; see cfz_plan.inl.
 // bound 512 = at most 256 VGPRs, no AGPRs: see colloc_kernel
+// FAST: the sweep's per-stage data in dynamic LDS (41 (T + 1) doubles); otherwise in the workspace (plans too long for the LDS).
+template <bool FAST>
 __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
                                 const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
   const int b = blockIdx.x;
-  extern __shared__ double plan_win[];  // the 81 band columns the elimination is working on (cfz_plan.inl)
   if (b >= B) return;
-  // all 64 lanes run the solver redundantly and share the marked loops (cfz_plan.inl)
-  cfzp::solve_state_ws<true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
+  // all 64 lanes run the solver's scalar logic redundantly and share the marked loops; the Riccati sweep is lane 0's (cfz_plan.inl)
+  cfzp::solve_state_ws<FAST>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b);
 }
 
-// the same with eight wavefronts per plan and the panel elimination of cfz_colloc.inl (dynamic LDS: the panel's multipliers)
-__global__ __launch_bounds__(512) void state_ws_kernel_wide(int B, const cfzp::PSpec *specs, const double *tube, const long long *tube_off, double *X,
-                                     const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
-  const int b = blockIdx.x;
-  extern __shared__ double plan_win[];
-  if (b >= B) return;
-  cfzp::solve_state_ws<true, true>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b, plan_win);
-}
-
-// single-vehicle collocation plan (reference vehicle.py:360-661): one NLP per workgroup, workspace in global memory; see
-// cfz_colloc.inl.
-// One wavefront runs it, but the bound is 512: with 64 (or 256) the register allocator may use AGPRs beyond 256 VGPRs, and
-// every such build of this kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950 / ROCm 7.2 while the
-// 256-VGPR builds of the same source run (measured, tools/colloc_timing_one.sh).
+// Collocation plans (reference vehicle.py:360-661 single, multi_vehicle_planner.py:343-480 joint): one NLP per workgroup of 512 threads,
+// workspace in global memory, elimination from global memory a panel at a time; see cfz_colloc.inl.
+// bound 512: with 64 (or 256) the register allocator may use AGPRs beyond 256 VGPRs, and every such build of this kernel died with
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950 / ROCm 7.2 while the 256-VGPR builds of the same source run.
 #ifndef CFZC_BOUNDS
 #define CFZC_BOUNDS 512
 #endif
-// MODE 1: single-vehicle plans, one wavefront each, elimination in the LDS window; MODE 2: joint plans, 512 threads each,
-// elimination from global memory.  Two kernels so that each carries one elimination only (fewer spilled registers).
-template <int MODE>
 __global__ __launch_bounds__(CFZC_BOUNDS) void colloc_kernel(int B, const cfzc::CSpec *specs, double *X, const long long *x_off, double *slab,
                               const long long *slab_off, const int32_t *kbs, int32_t *oi, double *od, int lds_doubles, int lds_rhs) {
   const int b = blockIdx.x;
-  // dynamic LDS (lds_doubles): MODE 1 the 103 band columns the elimination is working on, then the right-hand sides; MODE 2
-  // the multipliers of a panel during the elimination; lds_rhs (<= lds_doubles, 0 = none): room for one right-hand side of the
-  // fallback substitution
+  // dynamic LDS (lds_doubles): the multipliers of a panel during the elimination; lds_rhs (<= lds_doubles, 0 = none): room for one
+  // right-hand side of the fallback substitution
   if (b >= B) return;
-  cfzc::solve_colloc<MODE>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles, lds_rhs);
+  cfzc::solve_colloc<2>(specs[b], X + x_off[b], slab + slab_off[b], kbs[b], oi + 2 * b, od + cfzc::kOutD * b, lds_doubles, lds_rhs);
 }
 
 }  // namespace
@@ -189,17 +176,21 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   HIP_OK(hipMemcpyAsync(doff + B, xoff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(doff + 2 * B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
-  int cus = 0;
+  // cfz_plan_options.kernel: WIDE = the sweep's per-stage data in LDS (one plan per CU at a time, 15 % faster per plan), NARROW = in the
+  // workspace (several plans share a CU: 1024 plans take 0.13 s instead of 0.20 s); by default LDS while the batch fits the CUs in one
+  // round.  A plan too long for the LDS (T > 498) runs from the workspace whatever was asked.
+  int Tmax = 0, lds_max = 0, cus = 0;
+  for (int b = 0; b < B; ++b) Tmax = std::max(Tmax, specs[b].T);
+  const size_t lds_bytes = (size_t)(cfzp::kSt + cfzp::kFb) * (Tmax + 1) * sizeof(double);
+  hipFuncAttributes fa;
+  HIP_OK(hipFuncGetAttributes(&fa, (const void *)state_ws_kernel<true>));
+  HIP_OK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, w->device));
   HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
-  const bool wide_ws = po->kernel == CFZ_KERNEL_WIDE || (po->kernel == CFZ_KERNEL_AUTO && B <= 2 * cus);
-  if (wide_ws) {  // one plan per CU, faster per plan: by default for up to two rounds of it (cfz_plan_options.kernel)
-    const size_t pl_bytes = (size_t)CFZ_PANEL * (cfzp::kKB + CFZ_PANEL) * sizeof(double);
-    hipLaunchKernelGGL(state_ws_kernel_wide, dim3(B), dim3(512), pl_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
-  } else {
-    const size_t win_bytes = ((size_t)cfzp::kWinCols * cfzp::kLd + 64) * sizeof(double);  // window + one spare slot per lane (cfz_band.inl)
-    HIP_OK(hipFuncSetAttribute((const void *)state_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(state_ws_kernel, dim3(B), dim3(64), win_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
-  }
+  const bool want_lds = po->kernel == CFZ_KERNEL_WIDE || (po->kernel == CFZ_KERNEL_AUTO && B <= cus);
+  const bool fast = want_lds && lds_bytes + fa.sharedSizeBytes <= (size_t)lds_max &&
+                    hipFuncSetAttribute((const void *)state_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  if (fast) hipLaunchKernelGGL(state_ws_kernel<true>, dim3(B), dim3(64), lds_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  else { (void)hipGetLastError(); hipLaunchKernelGGL(state_ws_kernel<false>, dim3(B), dim3(64), 0, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod); }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
   HIP_OK(hipMemcpyAsync(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost, st));
@@ -253,7 +244,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
                       int32_t *iters, double *cost) {
   if (!w) return fail("null workspace");
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
-  if (co->kernel < CFZ_KERNEL_AUTO || co->kernel > CFZ_KERNEL_NARROW) return fail("cfz_colloc_options.kernel: 0 (by batch size), 1 (wide) or 2 (narrow)");
+  if (co->kernel < CFZ_KERNEL_AUTO || co->kernel > CFZ_KERNEL_NARROW) return fail("cfz_colloc_options.kernel: 0, 1 or 2 (accepted for compatibility; there is one kernel)");
   HIP_OK(hipSetDevice(w->device));
   if (arena_reset(w->arena)) return -1;
   hipStream_t st = w->stream;
@@ -341,30 +332,21 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   HIP_OK(hipMemcpyAsync(doff + B, soff.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemcpyAsync(dkb, kbs.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
-  // Two kernels.  colloc_kernel<2>: eight wavefronts per plan, band in global memory, panel elimination -- the only one for the
-  // joint plan (its band does not fit LDS) and 2-2.6x faster per plan for single plans too (vehicle 0: 0.96 -> 0.37 s), but one
-  // plan per CU.  colloc_kernel<1>: one wavefront per single plan, elimination in an LDS window, four plans per CU: taken when
-  // the batch is larger than two rounds of the wide kernel (B > 2 CUs), or on request (`one_pivot`, the check of the other).
-  bool wide = false;
-  for (int b = 0; b < B; ++b) if (kbs[b] != cfzc::kCB) wide = true;
-  if (!wide && co->one_pivot && co->kernel == CFZ_KERNEL_WIDE) return fail("one_pivot runs single plans on the one-wavefront kernel: kernel = CFZ_KERNEL_WIDE contradicts it");
-  if (!wide && !co->one_pivot) {
-    int cus = 0;
-    HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
-    wide = co->kernel == CFZ_KERNEL_WIDE || (co->kernel == CFZ_KERNEL_AUTO && B <= 2 * cus);  // cfz_colloc_options.kernel
-  }
-  if (!wide) {
-    const size_t win_bytes = (size_t)cfzc::kCLdsDoubles * sizeof(double);
-    HIP_OK(hipFuncSetAttribute((const void *)colloc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-    hipLaunchKernelGGL(colloc_kernel<1>, dim3(B), dim3(64), win_bytes, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, (int)cfzc::kCLdsDoubles, 0);
-  } else {
+  // One kernel: 512 threads per plan, band in global memory, panel elimination (`one_pivot`: one pivot at a time, the check of the
+  // panel).  Rounds 1-3 also had a one-wavefront kernel with the elimination in an LDS window for batches of more than two plans per CU
+  // (cfz_colloc_options.kernel = CFZ_KERNEL_NARROW).  Round 4 retired it: its 124 KB window let one plan run per CU just as here, so it
+  // was the slower one at every batch size (1024 plans: 3.25 s against 1.83 s, 2048: 5.67 s against 3.80 s), and after a recompile that
+  // left its source untouched it returned, for identical plans of one batch, two or three different results (2e-5 apart in the
+  // trajectory; 7 of 1024 plans no longer converged) -- a race that no placement of barriers in its elimination removed reliably
+  // (docs/notebook.md).  `kernel` is still accepted (0, 1, 2) and means nothing.
+  {
     // Dynamic LDS beside the kernel's static arrays (read from the code object, not assumed): the panel's multipliers
     // (CFZ_PANEL x (kb + CFZ_PANEL) doubles, <= 58 KB) must fit; a right-hand side of the largest instance rides along only if it
     // fits as well (it serves band_substitute_wide, the fallback substitution) -- the panel path does not depend on it.
     int nk_max = 0, kb_max = 0, lds_max = 0;
     for (int b = 0; b < B; ++b) { nk_max = std::max(nk_max, cfzc::cdims(specs[b]).nk); kb_max = std::max(kb_max, (int)kbs[b]); }
     hipFuncAttributes fa;
-    HIP_OK(hipFuncGetAttributes(&fa, (const void *)colloc_kernel<2>));
+    HIP_OK(hipFuncGetAttributes(&fa, (const void *)colloc_kernel));
     HIP_OK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, w->device));
     {  // gfx950: a workgroup may own the whole LDS of its CU (160 KB); some runtimes report the smaller legacy figure per block
       int per_cu = 0;
@@ -375,12 +357,12 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     const long long pl = kb_max <= cfzc::kWideMaxKb ? (long long)CFZ_PANEL * (kb_max + CFZ_PANEL) : 0;
     const int lds_rhs = nk_max <= avail ? nk_max : 0;
     int lds_doubles = (int)std::max<long long>(pl <= avail ? pl : 0, lds_rhs), lds_rhs_ = lds_rhs;
-    if (lds_doubles && hipFuncSetAttribute((const void *)colloc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8) != hipSuccess) {
+    if (lds_doubles && hipFuncSetAttribute((const void *)colloc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8) != hipSuccess) {
       // a runtime whose per-workgroup limit really is the smaller figure: the kernel also runs without dynamic LDS
       (void)hipGetLastError();
       lds_doubles = 0; lds_rhs_ = 0;
     }
-    hipLaunchKernelGGL(colloc_kernel<2>, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs_);
+    hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs_);
   }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * cfzc::kOutD);

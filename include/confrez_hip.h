@@ -211,8 +211,12 @@ int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const doub
  *   guess                 x, y, psi of every point, instances back to back (spline_ws, :199-205); NULL = the initial pose
  *   traj (out)            x, y, psi, v, delta, a, w of every point, instances back to back; the last input is repeated
  *   status, iters, cost   per instance (may be NULL); status as in cfz_mpc_stats, the reference raises on status != 0
- * The solver is the interior point of the MPC path with the exact Hessian of the Lagrangian, IPOPT's delta_w ladder
- * driven by a curvature test, delta_c = 1e-9, on the banded primal-dual system (csrc/cfz_plan.inl). */
+ * The solver is the interior point of the MPC path with the exact Hessian of the Lagrangian and IPOPT's delta_w ladder
+ * driven by a curvature test; the Newton system is solved as a stage recursion (a Riccati sweep over the T stages with
+ * the terminal-heading row, the only one that can lose rank, bordered and regularised: delta_c = 1e-9;
+ * csrc/cfz_plan.inl).  With a terminal heading and a guess that stands still (guess = NULL) the first linearisation
+ * is rank deficient -- the headings cannot move -- and the solve ends with status 2 after a few iterations: give
+ * the spline guess, as the reference's callers do (the speed along it is seeded here). */
 #define CFZ_KERNEL_AUTO 0
 #define CFZ_KERNEL_WIDE 1
 #define CFZ_KERNEL_NARROW 2
@@ -223,11 +227,10 @@ typedef struct cfz_plan_options {
   int32_t bounded_input;  /* :104, :155-167 */
   int32_t stall_iters;    /* 0 (as the reference: an infeasible plan runs to max_iter); n > 0: status 5 after n iterations without
                            *   progress of the constraint violation, as in the MPC step -- a batch then does not wait for such a plan */
-  int32_t kernel;         /* which of the two kernels runs the batch: 0 = by batch size (up to two plans per CU: CFZ_KERNEL_WIDE, else
-                           *   CFZ_KERNEL_NARROW), CFZ_KERNEL_WIDE = 1 (512 threads per plan, one plan per CU: the fastest single plan),
-                           *   CFZ_KERNEL_NARROW = 2 (one wavefront per plan, several plans per CU: the highest throughput).  The two
-                           *   sum in different orders: a plan's iterates are reproducible bit for bit PER KERNEL, and at a marginal
-                           *   tolerance its iteration count can differ between them -- pin the kernel where that matters. */
+  int32_t kernel;         /* where the Riccati sweep keeps its per-stage data: 0 = by batch size (up to one plan per CU: CFZ_KERNEL_WIDE,
+                           *   else CFZ_KERNEL_NARROW), CFZ_KERNEL_WIDE = 1 (in LDS, one plan per CU at a time: the fastest single plan),
+                           *   CFZ_KERNEL_NARROW = 2 (in the workspace, several plans per CU: the highest throughput; also what a plan
+                           *   too long for the LDS, T > 498, gets).  Same arithmetic in the same order: the two agree bit for bit. */
   int32_t reserved0;
   double dt;              /* :101 0.1 */
   double wb;              /* wheelbase */
@@ -284,9 +287,9 @@ typedef struct cfz_colloc_options {
                            *    vertices is constrained by their Euclidean distance -- the reference's OBCA rows admit any unit
                            *    direction (vehicle.py:523-541, multi_vehicle_planner.py:419-451); 0: face-normal certificates only
                            *    (a restriction at corner-to-corner contacts, kept to show the gap) */
-  int32_t kernel;         /* cfz_colloc only (a joint plan always runs on 512 threads): 0 = by batch size, CFZ_KERNEL_WIDE, CFZ_KERNEL_NARROW
-                           *    as in cfz_plan_options.kernel; with one_pivot = 1 single plans always take the narrow kernel
-                           *    (CFZ_KERNEL_WIDE is then refused) */
+  int32_t kernel;         /* 0, CFZ_KERNEL_WIDE or CFZ_KERNEL_NARROW: accepted for compatibility and without effect since round 4 -- there is
+                           *    one collocation kernel (512 threads per plan); the one-wavefront kernel that CFZ_KERNEL_NARROW named was
+                           *    slower at every batch size and is gone (csrc/cfz_planning.hip) */
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */

@@ -209,6 +209,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
         return nlp.f(xx) - mu_ * (np.log(dl[hasl]).sum() + np.log(du[hasu]).sum())
 
     dual_reg = np.full(m, float(opt.reg_dual))
+    if hasattr(nlp, "dual_reg_rows"):  # an NLP that names the only rows able to lose rank takes delta_c on those alone (StateWsNlp)
+        dual_reg = dual_reg * nlp.dual_reg_rows
     if opt.reg_dual_rows > 0.0 and hasattr(nlp, "c_blk0"):
         dual_reg[nlp.c_blk0:] += opt.reg_dual_rows
     it = 0

@@ -53,6 +53,13 @@ class StateWsNlp:
         xl[self.s0 :] = 0.0
         self.xl, self.xu = xl, xu
         self.block_mask = np.zeros(self.n)
+        # IPOPT's delta_c (IpmOptions.reg_dual) on the terminal-heading row alone: the initial rows, the Euler rows (-I on z_{k+1}) and the
+        # tube rows (+I on their slacks) have full row rank at any iterate; the heading row is the one that loses it (with v = delta = 0
+        # the headings are pinned by the initial pose).  This keeps the Newton system a stage recursion: cfz_plan.inl solves it by a Riccati
+        # sweep with that one row bordered.
+        self.dual_reg_rows = np.zeros(self.m)
+        if final_heading is not None:
+            self.dual_reg_rows[-1] = 1.0
 
     def zidx(self, k):
         return 7 * k

@@ -59,9 +59,8 @@ def solve(nlp, X0, opt):
         assert _lib.cfzp_emu_sizeof_spec() == C.sizeof(PSpec)
     s, tube = make_spec(nlp, opt)
     assert _lib.cfzp_emu_n(C.byref(s)) == nlp.n
-    bw = _lib.cfzp_emu_bandwidth(C.byref(s))
     X = np.array(X0, dtype=np.float64)
     oi = np.zeros(2, np.int32); od = np.zeros(3)
     dp = lambda a: a.ctypes.data_as(C.c_void_p)
     assert _lib.cfzp_emu_state_ws(C.byref(s), dp(tube), dp(X), dp(oi), dp(od)) == 0
-    return dict(X=X, iters=int(oi[0]), status=int(oi[1]), f=od[0], err=od[1], mu=od[2], bandwidth=bw)
+    return dict(X=X, iters=int(oi[0]), status=int(oi[1]), f=od[0], err=od[1], mu=od[2])

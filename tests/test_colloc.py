@@ -409,7 +409,7 @@ def test_colloc_fixture_on_gpu(plans):
     tb = lambda a: [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]]
     fh = lambda a: float(plans[a][1][-1, 2])
     X0, st = g["single_guess"], g["single_meta"]
-    for one_pivot in (0, 1):  # both kernels: eight wavefronts + panel elimination (default for a batch this small), one wavefront + LDS window
+    for one_pivot in (0, 1):  # both eliminations of the kernel: a panel of 16 pivots at a time (default), one pivot at a time
         r = engine.colloc(spec, [plans["vehicle_1"][1][0]], [tb("vehicle_1")], [X0[:-1].reshape(-1, 7)], [X0[-1]], [fh("vehicle_1")], max_iter=400,
                           one_pivot=one_pivot)[0]
         assert (r["status"], r["iters"]) == (int(st[0]), int(st[1])) and abs(r["cost"] - st[2]) < 1e-8 * st[2]

@@ -30,10 +30,13 @@ def plans():
 
 
 def test_plan_kernel_source_matches_oracle(plans):
-    """Same iterates as the full-KKT sparse-LU oracle (iteration counts equal, solutions to 1e-8) with the terminal
-    heading free, with bounded inputs, and with a terminal heading when the guess carries the speed along the path (what
-    `cfz_state_ws` does); with a terminal heading and the zero-velocity guess the heading rows are rank deficient, the two
-    linear solvers drift apart and only the outcomes are compared, at the solver's tolerance."""
+    """The kernel source (Newton system as a Riccati sweep over the stages) against the full-KKT sparse-LU oracle: same iteration counts,
+    solutions to 1e-9, with bounded inputs and with a terminal heading when the guess carries the speed along the path (what
+    `cfz_state_ws` does); from the guess that stands still (v = 0: no control authority over the headings in the first linearisations,
+    an ill-conditioned start) the two linear solvers' rounding shows in the iterates, 8e-7 on the longest plan, at equal iteration
+    counts.  With a terminal heading AND the standing guess the first linearisation is rank deficient (the headings cannot move, the
+    terminal row contradicts them; delta_c sits on that row alone, oracle/plan_nlp.py): both give up with status 2 after a few
+    iterations, which is what is compared -- `cfz_state_ws` seeds the speed, the documented way out (include/confrez_hip.h)."""
     import plan_emu_binding as pe
 
     opt = ipm.IpmOptions(**PLAN_OPT)
@@ -43,14 +46,12 @@ def test_plan_kernel_source_matches_oracle(plans):
             nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5, bounded_input=bounded)
             X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt) if seeded else None)
             ro, re_ = ipm.solve(nlp, X0, opt), pe.solve(nlp, X0, opt)
-            assert re_["bandwidth"] <= 40
             assert ro["status"] == re_["status"], (a, fh, bounded)
             if exact:
-                assert ro["iters"] == re_["iters"] and np.abs(ro["X"][: nlp.s0] - re_["X"][: nlp.s0]).max() < 1e-7
-            elif ro["status"] == 0:
-                assert abs(ro["f"] - re_["f"]) < 1e-2 * max(1.0, ro["f"])
-                so, se = nlp.unpack(ro["X"]), nlp.unpack(re_["X"])
-                assert max(np.abs(so[k] - se[k]).max() for k in ("x", "y", "psi")) < 5e-2
+                assert ro["status"] == 0 and ro["iters"] == re_["iters"]
+                assert np.abs(ro["X"][: nlp.s0] - re_["X"][: nlp.s0]).max() < (1e-9 if seeded else 2e-6), (a, fh, bounded)
+            else:
+                assert ro["status"] == 2 and ro["iters"] <= 10 and re_["iters"] <= 10
             if ro["status"] == 0:  # the tube is respected
                 s = nlp.unpack(re_["X"])
                 c = nlp.cons(re_["X"])
@@ -61,9 +62,9 @@ def test_plan_kernel_source_matches_oracle(plans):
 @pytest.mark.gpu
 @pytest.mark.parametrize("narrow", [False, True])
 def test_state_ws_on_gpu_matches_oracle(plans, narrow):
-    """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory -- with both
-    kernels: eight wavefronts + panel elimination (what a batch this small gets by default) and one wavefront + LDS window (what
-    larger batches get; here asked for through `cfz_plan_options.kernel`)."""
+    """cfz_state_ws, all four vehicles in one launch, against the oracle: status, iteration count, trajectory -- with the sweep's
+    per-stage data in LDS (what a batch this small gets by default) and in the workspace (what batches of more than one plan per CU
+    and plans too long for the LDS get; here asked for through `cfz_plan_options.kernel`)."""
     from conflict_rez_amd import engine
 
     kern = dict(kernel=engine.KERNEL_NARROW) if narrow else {}
@@ -88,11 +89,11 @@ def test_state_ws_on_gpu_matches_oracle(plans, narrow):
 
 @pytest.mark.gpu
 def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
-    """`cfz_plan_options.kernel` / `cfz_colloc_options.kernel`: by default the batch size picks the kernel (up to two plans per CU:
-    512 threads per plan, else one wavefront per plan) and the two sum in different orders, so a plan's iterates are reproducible
-    bit for bit only per kernel.  Pinned to one kernel, the same plan alone and inside a batch of more than two plans per CU
-    (what the default would send to the other kernel) returns the same status, iteration count and trajectory; and the default
-    choice equals the pinned kernel it names."""
+    """A plan's iterates do not depend on the batch it is solved in.  `cfz_plan_options.kernel` moves state_ws' sweep data between LDS
+    (default up to one plan per CU) and the workspace (larger batches): same arithmetic, same bits -- the same plan alone and inside a
+    batch of more than two plans per CU returns the same status, iteration count and trajectory, pinned or not.  The collocation plan
+    has one kernel since round 4 (`cfz_colloc_options.kernel` is accepted and without effect): alone or in a batch of 520, bit for bit
+    the same plan -- the check that caught the one-wavefront kernel returning two results for identical plans (docs/notebook.md)."""
     from conflict_rez_amd import engine
 
     cus = 256  # MI355X; only "more than two plans per CU" matters
@@ -110,9 +111,10 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
     auto1, autoB = engine.state_ws(*args1, shrink_tube=0.5)[0], engine.state_ws(*argsB, shrink_tube=0.5)[0]
     assert np.array_equal(auto1["traj"], engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_WIDE)[0]["traj"])
     assert np.array_equal(autoB["traj"], engine.state_ws(*args1, shrink_tube=0.5, kernel=engine.KERNEL_NARROW)[0]["traj"])
+    assert np.array_equal(autoB["traj"], auto1["traj"])  # state_ws: LDS or workspace, the same bits
     with pytest.raises(RuntimeError, match="kernel"):
         engine.state_ws(*args1, shrink_tube=0.5, kernel=7)
-    # the same for the collocation refinement (cfz_colloc_options.kernel): wide = 512 threads per plan, narrow = one wavefront
+    # the same for the collocation refinement
     from conflict_rez_amd import scenarios
 
     sp0 = scenarios.parking_lot_spec(n_nbr=0, N=2)
@@ -123,11 +125,11 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
     ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
     guess = np.stack([np.interp(ti, t, ws1[:, c]) for c in range(7)], 1)
     cargs = lambda B_: (sp0, [plans[a][1][0]] * B_, [tube] * B_, [guess] * B_, [t[-1] / N] * B_, [fh] * B_)
-    for kern in (engine.KERNEL_WIDE, engine.KERNEL_NARROW):
+    for kern in (engine.KERNEL_AUTO, engine.KERNEL_NARROW):  # (accepted, without effect)
         one = engine.colloc(*cargs(1), max_iter=400, kernel=kern)[0]
         many = engine.colloc(*cargs(B), max_iter=400, kernel=kern)
         assert one["status"] == 0
-        for r in (many[0], many[-1]):
+        for r in many:  # every plan of the batch, not a sample: the retired kernel differed on about half of them
             assert (r["status"], r["iters"]) == (one["status"], one["iters"]) and np.array_equal(r["traj"], one["traj"]) and r["dt"] == one["dt"]
     # cfz_plan_ws_trim: the memory the batch left in the thread's workspace goes back; the next call allocates again
     engine.trim_default_workspaces()
