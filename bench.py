@@ -310,7 +310,7 @@ def planning_extras(device=0, B=256, cpu=True):
         "plans_per_s": len(scen) / t_joint, "joint_s": t_joint, "converged": sum(r["status"] == 0 for r in rj),
         "iters_mean": float(np.mean([r["iters"] for r in rj])), "iters_max": int(max(r["iters"] for r in rj)),
         "unknowns": nk4, "half_bandwidth": kb4, "band_bytes": bb4,
-        "roofline": {"bound": "hbm", "kernel": "colloc_kernel<2>", "achieved": alg4 / t_joint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg4 / t_joint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg4 / t_joint / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes": "3 x band bytes x iterations of every plan"}}
     engine.trim_default_workspaces()  # a 256-plan joint launch leaves 25 GB in the calling thread's workspace
@@ -342,7 +342,7 @@ def planning_cpu_baseline(agents, sets, paths, fh):
     for a in agents:
         p = paths[a]
         ws = StateWsNlp(p[0], otubes[a], final_heading=fh[a], shrink_tube=0.5)
-        r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0))
+        r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, mu_init=0.1))
         z = ws.unpack(r["X"])
         nlp = CollocNlp(p[0], otubes[a], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh[a])
         N = nlp.N[0]
@@ -419,8 +419,9 @@ def main():
                     + ", ".join(f"{a} {i['t_end']:.1f} s" for a, i in plan_info.items()))
     elif args.reference == "planned":
         table, lengths = scenarios.load_reference_table(kind="planned")
-        ref_desc = ("conflict_rez_amd/data/refs_4v_planned.npz: the build's own single-vehicle plans of the synthetic strategy (cfz_state_ws -> "
-                    "cfz_colloc as in VehicleFollower.plan_single_path, free dt), sampled every 0.1 s: "
+        ref_desc = ("conflict_rez_amd/data/refs_4v_planned.npz: the package's own single-vehicle plans of the synthetic strategy (cfz_state_ws -> "
+                    "cfz_colloc as in VehicleFollower.plan_single_path, free dt; planned by the round-3 build, kept since so that the workload stays "
+                    "the same: tests/test_plan.py compares today's plans with it), sampled every 0.1 s: "
                     + ", ".join(f"vehicle_{i} {0.1 * (n - 1):.1f} s" for i, n in enumerate(lengths)) + " (SURVEY.md 8d config 3)")
     else:
         table, lengths = scenarios.load_reference_table(kind="state_ws")

@@ -238,7 +238,7 @@ typedef struct cfz_plan_options {
   double bounds[12];      /* lo,hi of x, y, v, delta, a, w */
   double tol;             /* :208 1e-2 */
   double constr_viol_tol; /* :209 1e-2 */
-  double mu_init;         /* 1e-3 */
+  double mu_init;         /* 0.1 (IPOPT's default, what the reference's state_ws runs with; 1e-3 until round 3) */
   double curv_kappa;      /* 1e-8 */
 } cfz_plan_options;
 

@@ -33,7 +33,7 @@ def warm_start(tube, p, fh):
     import plan_emu_binding as pe
 
     ws = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
-    r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0))
+    r = pe.solve(ws, ws.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, ws.dt)), ipm.IpmOptions(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, mu_init=0.1))
     assert r["status"] == 0
     return ws.unpack(r["X"])
 

