@@ -272,7 +272,8 @@ def planning_extras(device=0, B=256, cpu=True):
     out["configs[1]"] = {
         "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5, 6 obstacles)",
         "plans_per_s": B / (t_ws + t_col), "state_ws_s": t_ws, "colloc_s": t_col, "state_ws_converged": len(good), "colloc_converged": ok,
-        "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])),
+        "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])), "colloc_iters_max": int(max(r["iters"] for r in plans.values())),
+        "state_ws_iters_mean": float(np.mean([w_["iters"] for w_ in ws])), "state_ws_iters_max": int(max(w_["iters"] for w_ in ws)),
         "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg / t_col / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / t_col / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes": "3 x band bytes (nk x (3 kb + 1) x 8: %s) x iterations of every plan" % {a: band[a][2] for a in agents}}}
@@ -289,7 +290,7 @@ def planning_extras(device=0, B=256, cpu=True):
     out["configs[1]"]["four_obstacles"] = {
         "workload": f"the same {B} plans with BASELINE.json's 4 polytope obstacles (0, 1, 3, 4 of the reference's six)",
         "plans_per_s": B / (t_ws + t_col4), "colloc_s": t_col4, "colloc_converged": sum(r["status"] == 0 for r in r4),
-        "colloc_iters_mean": float(np.mean([r["iters"] for r in r4]))}
+        "colloc_iters_mean": float(np.mean([r["iters"] for r in r4])), "colloc_iters_max": int(max(r["iters"] for r in r4))}
     # ---- configs[3] ------------------------------------------------------------------------------------------------------------
     idx = list(range(4 * B))
     ws4, good4, plans4, _, _ = single_plans(idx)

@@ -60,7 +60,7 @@ constexpr int kMaxN = kNL / kLPS;
 // the sweeps run on lane 0 of the workgroup, out of line; every lane calls (uniform control flow), lane 0 works
 #define CFZ_SERIAL(call) do { call; __syncthreads(); } while (0)
 #define CFZ_WAVE0(call) do { if (threadIdx.x < cfz::kMaxN) { call; } __syncthreads(); } while (0)  // the lanes that own a stage
-#define CFZ_WSP(p) ((cfz::wsp_f64 *)(p))
+#define CFZ_WSP(p) cfz::opaque_wsp((cfz::wsp_f64 *)(p))
 #define CFZ_UNIFORM(v) cfz::uniform_value(v)
 #else
 #define CFZ_LANES(tid) for (int tid = 0; tid < cfz::kNL; ++tid) {
@@ -190,6 +190,9 @@ template <int OP> CFZ_FN double op2(double a, double b) { return OP == 0 ? a + b
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) double wsp_f64;  // the workspace as the out-of-line sweeps see it: DS instructions, no FLAT
+// ... handed over as a value the compiler cannot see through: otherwise interprocedural constant propagation moves the name of the
+// kernel's dynamic LDS into the sweeps, which then look it up in llvm.amdgcn.dynlds.offset.table at every call (cfz_band.inl: opaque)
+__device__ __forceinline__ wsp_f64 *opaque_wsp(wsp_f64 *p) { asm volatile("" : "+v"(p)); return p; }
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);

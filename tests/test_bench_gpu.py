@@ -76,6 +76,8 @@ def test_planning_extras_of_the_bench_line():
     c1, c3 = ex["configs[1]"], ex["configs[3]"]
     assert c1["state_ws_converged"] == 8 and c1["colloc_converged"] == 8 and c1["plans_per_s"] > 1.0
     assert c1["four_obstacles"]["colloc_converged"] == 8 and c1["four_obstacles"]["plans_per_s"] > 1.0  # configs[1] as BASELINE.json words it
+    assert 5 <= c1["state_ws_iters_mean"] <= c1["state_ws_iters_max"] <= 60 and c1["colloc_iters_mean"] <= c1["colloc_iters_max"] <= 150
+    assert c1["four_obstacles"]["colloc_iters_max"] >= c1["four_obstacles"]["colloc_iters_mean"]
     assert c3["converged"] == 8 and c3["unknowns"] == 12350 and c3["half_bandwidth"] == 298 and c3["band_bytes"] == 12350 * (3 * 298 + 1) * 8
     for c in (c1, c3):
         r = c["roofline"]
