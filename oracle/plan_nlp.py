@@ -44,7 +44,8 @@ class StateWsNlp:
         self.n = 7 * T + 5 + 8 * self.n_chk
         self.s0 = 7 * T + 5
         self.m = 7 + 5 * T + 8 * self.n_chk + (1 if final_heading is not None else 0)
-        b = np.array([2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0]) if bounds is None else bounds
+        b = np.array([2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0]) if bounds is None else np.asarray(bounds, float)
+        self.bounds = b
         xl = np.full(self.n, -np.inf)
         xu = np.full(self.n, np.inf)
         k7 = 7 * np.arange(T)

@@ -37,7 +37,7 @@ def make_spec(nlp, opt):
     s.dt, s.wb, s.shrink = nlp.dt, nlp.wb, nlp.shrink
     s.final_heading = float(nlp.final_heading) if nlp.final_heading is not None else 0.0
     s.init_pose[:] = list(nlp.init_pose)
-    s.bounds[:] = [2.5, 32.5, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0]
+    s.bounds[:] = [float(v) for v in nlp.bounds]
     for k in _OPTS:
         setattr(s, k, getattr(opt, k))
     tube = np.zeros((nlp.n_chk, 2, 12))

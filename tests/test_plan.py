@@ -59,6 +59,57 @@ def test_plan_kernel_source_matches_oracle(plans):
                 assert np.isclose(s["x"][0], p[0, 0]) and np.isclose(s["v"][0], 0.0, atol=1e-9)
 
 
+def _corridor(S, h=1.25, x0=5.0, y0=17.5):
+    """A straight corridor of S strategy steps (2.5 m cells along +x): tube for the oracle, tube for the C ABI, straight-line guess."""
+    A = np.array([[0.0, -1.0], [-1.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    cell = lambda i: (A, np.array([-(y0 - h), -(x0 + 2.5 * i - h), x0 + 2.5 * i + h, y0 + h]))
+    tube = [dict(back=cell(i), front=cell(i + 1)) for i in range(S)]
+    T = 30 * (S - 1)
+    p = np.stack([np.linspace(x0, x0 + 2.5 * (S - 1), T + 1), np.full(T + 1, y0), np.zeros(T + 1)], 1)
+    return tube, [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in tube[1:]], p
+
+
+LONG_BOUNDS = [0.0, 80.0, 7.5, 27.5, -2.5, 2.5, -0.85, 0.85, -1.5, 1.5, -1.0, 1.0]
+
+
+def test_a_plan_of_510_stages(plans):
+    """T = 30 x 17 = 510 Euler stages (the strategy's longest has 300): the Riccati sweep of the kernel source against the sparse-LU
+    oracle on a plan too long for the LDS of a CU (41 doubles per stage: T <= 498) -- same iteration count, trajectory to 1e-9."""
+    import plan_emu_binding as pe
+
+    tube, _, p = _corridor(18)
+    nlp = StateWsNlp(p[0], tube, final_heading=0.0, shrink_tube=0.5, bounds=LONG_BOUNDS)
+    assert nlp.T == 510
+    X0 = nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt))
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    ro, re_ = ipm.solve(nlp, X0, opt), pe.solve(nlp, X0, opt)
+    assert (ro["status"], ro["iters"]) == (re_["status"], re_["iters"]) == (0, ro["iters"]) and ro["iters"] < 30
+    assert np.abs(ro["X"][: nlp.s0] - re_["X"][: nlp.s0]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_a_plan_too_long_for_the_lds_runs_from_the_workspace():
+    """The same 510-stage plan through `cfz_state_ws`: asked for the LDS kernel (`kernel = CFZ_KERNEL_WIDE`) it runs from the workspace
+    (the sweep's per-stage data would take 167 KB), bit for bit what `CFZ_KERNEL_NARROW` returns, and equals the oracle; in one batch
+    with a short plan (the batch's longest plan decides) the short plan is the one it is alone."""
+    from conflict_rez_amd import engine
+
+    tube, ctube, p = _corridor(18)
+    tube6, ctube6, p6 = _corridor(6)
+    kw = dict(shrink_tube=0.5, bounds=LONG_BOUNDS)
+    wide = engine.state_ws([p[0]], [ctube], [p], [0.0], kernel=engine.KERNEL_WIDE, **kw)[0]
+    narrow = engine.state_ws([p[0]], [ctube], [p], [0.0], kernel=engine.KERNEL_NARROW, **kw)[0]
+    assert wide["status"] == 0 and np.array_equal(wide["traj"], narrow["traj"]) and wide["iters"] == narrow["iters"]
+    nlp = StateWsNlp(p[0], tube, final_heading=0.0, shrink_tube=0.5, bounds=LONG_BOUNDS)
+    ro = ipm.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)), ipm.IpmOptions(**PLAN_OPT))
+    so = nlp.unpack(ro["X"])
+    want = np.stack([so["x"], so["y"], so["psi"], so["v"], so["delta"], so["a"], so["w"]], 1)
+    assert wide["iters"] == ro["iters"] and np.abs(wide["traj"] - want).max() < 1e-6
+    short = engine.state_ws([p6[0]], [ctube6], [p6], [0.0], **kw)[0]  # alone: LDS
+    both = engine.state_ws([p[0], p6[0]], [ctube, ctube6], [p, p6], [0.0, 0.0], **kw)
+    assert np.array_equal(both[1]["traj"], short["traj"]) and np.array_equal(both[0]["traj"], wide["traj"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("narrow", [False, True])
 def test_state_ws_on_gpu_matches_oracle(plans, narrow):
