@@ -8,13 +8,13 @@
 // MPC step.  One instance per workgroup (one wavefront), workspace in global memory (L2-resident), the interior-point iteration of
 // oracle/ipm.py with the EXACT Hessian of the Lagrangian and the curvature test  dx'(H + delta I)dx >= kappa |dx|^2  (delta: 0, 1e-4,
 // x8 ...).  The Newton system is a stage recursion (Riccati sweep, below): rounds 1-3 solved it as a banded LU with partial pivoting
-// (half-bandwidth 40, ~3,000 pivots one after the other: 10 ms per iteration); the sweep is T stages of ~200 operations.
+// (half-bandwidth 40, ~3,000 pivots one after the other: 10 ms per iteration); the sweep is T stages of ~350 operations on one lane.
 //
 // The same source compiles for the CPU (tests/emu) and is checked iterate for iterate against oracle/plan_nlp.py.
 #pragma once
 #include <math.h>
 
-#include "cfz_band.inl"  // (for cfz_colloc.inl, which includes this file)
+#include "cfz_band.inl"  // the pointer types the out-of-line sweeps take, `opaque`
 
 #if defined(__HIPCC__)
 #define CFZP_FN __host__ __device__ inline
