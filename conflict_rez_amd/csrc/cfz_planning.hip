@@ -107,6 +107,50 @@ int cfz_plan_ws_destroy(cfz_plan_ws *w) {
   return 0;
 }
 
+// mean of the vertices of the cell A[4][2] p <= b[4] (pairs of non-parallel rows whose intersection satisfies every row)
+static bool cell_centre(const double *cell, double c[2]) {
+  const double *A = cell, *b = cell + 8;
+  double sx = 0.0, sy = 0.0; int nv = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j) {
+      const double det = A[2 * i] * A[2 * j + 1] - A[2 * i + 1] * A[2 * j];
+      if (fabs(det) < 1e-9) continue;
+      const double x = (b[i] * A[2 * j + 1] - A[2 * i + 1] * b[j]) / det, y = (A[2 * i] * b[j] - b[i] * A[2 * j]) / det;
+      bool in = true;
+      for (int r = 0; r < 4; ++r) if (A[2 * r] * x + A[2 * r + 1] * y > b[r] + 1e-9) in = false;
+      if (in) { sx += x; sy += y; ++nv; }
+    }
+  if (!nv) return false;
+  c[0] = sx / nv; c[1] = sy / nv;
+  return true;
+}
+
+int cfz_state_ws_default_guess(int32_t n_sets, int32_t N, const double init_pose[3], double final_heading, const double *tube, double *guess) {
+  if (n_sets < 2 || N < 1 || !init_pose || !tube || !guess) return fail("bad argument");
+  const int S = n_sets;
+  std::vector<double> cx(S), cy(S), hd(S);
+  cx[0] = init_pose[0]; cy[0] = init_pose[1]; hd[0] = init_pose[2];
+  const double two_pi = 6.283185307179586;
+  for (int i = 1; i < S; ++i) {
+    double cb[2], cf[2];
+    const double *cell = tube + (size_t)(i - 1) * 24;
+    const bool okb = cell_centre(cell, cb), okf = cell_centre(cell + 12, cf);
+    cx[i] = okb ? cb[0] : cx[i - 1]; cy[i] = okb ? cb[1] : cy[i - 1];
+    double h = (okb && okf && (cf[0] != cb[0] || cf[1] != cb[1])) ? atan2(cf[1] - cb[1], cf[0] - cb[0]) : hd[i - 1];
+    h += two_pi * nearbyint((hd[i - 1] - h) / two_pi);  // the branch nearest the previous heading
+    hd[i] = h;
+  }
+  if (final_heading == final_heading) hd[S - 1] = final_heading + two_pi * nearbyint((hd[S - 1] - final_heading) / two_pi);
+  const int T = N * (S - 1);
+  for (int k = 0; k <= T; ++k) {
+    const int i = k / N < S - 1 ? k / N : S - 2;
+    const double t = (double)(k - i * N) / N;
+    guess[3 * k] = cx[i] + t * (cx[i + 1] - cx[i]); guess[3 * k + 1] = cy[i] + t * (cy[i + 1] - cy[i]); guess[3 * k + 2] = hd[i] + t * (hd[i + 1] - hd[i]);
+  }
+  // the terminal heading is imposed exactly: the guess ends on it (its branch was chosen above; the NLP takes the value given)
+  return 0;
+}
+
 int cfz_state_ws(int device, int B, const cfz_plan_options *po, const int32_t *n_sets, const double *init_pose,
                  const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
                  int32_t *iters, double *cost) {
@@ -147,10 +191,22 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   }
   // initial guess: x, y, psi of every stage (vehicle.py:199-205), everything else zero
   std::vector<double> X((size_t)nx, 0.0);
+  // no guess from the caller (spline_ws = False): the path through the tube's cells, cfz_state_ws_default_guess -- the standing start
+  // (every stage at the initial pose) is rank deficient once a terminal heading is fixed and failed on every vehicle of the strategy
+  std::vector<double> own;
+  if (!guess) {
+    own.resize((size_t)npts * 3);
+    long long o = 0;
+    for (int b = 0; b < B; ++b) {
+      if (cfz_state_ws_default_guess(n_sets[b], po->N, init_pose + 3 * b, specs[b].has_final ? specs[b].final_heading : NAN, tube + toff[b], own.data() + o * 3)) return -1;
+      o += specs[b].T + 1;
+    }
+    guess = own.data();
+  }
   long long g0 = 0;
   for (int b = 0; b < B; ++b) {
     const int T = specs[b].T;
-    if (guess) {
+    {
       for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = guess[(size_t)(g0 + k) * 3 + c];
       // The reference seeds x, y, psi only.  With v = 0 everywhere the heading rows of the linearisation have no control
       // authority (rank deficient once a terminal heading is fixed); the signed speed along the guessed path costs
@@ -160,7 +216,7 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
         const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], along = dx * cos(p0[2]) + dy * sin(p0[2]);
         X[(size_t)xoff[b] + 7 * k + 3] = (along > 0.0 ? 1.0 : (along < 0.0 ? -1.0 : 0.0)) * sqrt(dx * dx + dy * dy) / po->dt;
       }
-    } else for (int k = 0; k <= T; ++k) for (int c = 0; c < 3; ++c) X[(size_t)xoff[b] + 7 * k + c] = init_pose[b * 3 + c];
+    }
     g0 += T + 1;
   }
   cfzp::PSpec *dspec = nullptr; double *dtube = nullptr, *dX = nullptr, *dslab = nullptr, *dod = nullptr;

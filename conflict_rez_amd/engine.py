@@ -124,6 +124,7 @@ def load_library(path=None):
     lib.cfz_default_plan_options.argtypes = [C.POINTER(_CPlanOptions)]
     lib.cfz_state_ws.argtypes = [C.c_int, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
     lib.cfz_state_ws_w.argtypes = [vp, C.c_int, C.POINTER(_CPlanOptions)] + [vp] * 9
+    lib.cfz_state_ws_default_guess.argtypes = [C.c_int32, C.c_int32, vp, C.c_double, vp, vp]
     lib.cfz_plan_ws_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.cfz_plan_ws_destroy.argtypes = [vp]
     lib.cfz_plan_ws_trim.argtypes = [vp]
@@ -158,7 +159,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_loop_last_status_counts cfz_vsl_step "
+    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_state_ws_default_guess cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_loop_last_status_counts cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -220,10 +221,25 @@ class PlanWorkspace:
             pass
 
 
+def state_ws_default_guess(init_pose, tube, final_heading=None, N=30):
+    """`cfz_state_ws_default_guess`: the path through the tube's cells that `cfz_state_ws` starts from when it is given no guess
+    (host arithmetic, no GPU).  tube as for `state_ws` (one vehicle); returns [N (n_sets - 1) + 1, 3]."""
+    lib = load_library()
+    n_sets = len(tube) + 1
+    t = np.ascontiguousarray(np.concatenate([np.concatenate([np.asarray(A, float).ravel(), np.asarray(b, float).ravel()]) for cellpair in tube for (A, b) in cellpair]))
+    g = np.zeros((N * (n_sets - 1) + 1, 3))
+    p0 = _f64(np.asarray(init_pose, float)[:3], (3,))
+    rc = lib.cfz_state_ws_default_guess(n_sets, N, _ptr(p0), float("nan") if final_heading is None else float(final_heading), _ptr(t), _ptr(g))
+    if rc != 0:
+        raise RuntimeError("cfz_state_ws_default_guess: " + lib.cfz_last_error().decode())
+    return g
+
+
 def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=None, **options):
     """`cfz_state_ws`: the warm-start plans of several vehicles in one launch.
     init_poses [B][3]; tubes: per vehicle a list over strategy steps 1.. of ((A_back, b_back), (A_front, b_front));
-    guesses: per vehicle an array [T+1, 3] of x, y, psi or None; final_headings: per vehicle a float or None.
+    guesses: per vehicle an array [T+1, 3] of x, y, psi, or None (for all: then every vehicle starts from `state_ws_default_guess`);
+    final_headings: per vehicle a float or None.
     options: fields of `cfz_plan_options` (N, dt, wb, shrink_tube, bounded_input, max_iter, tol, ...).
     Returns a list of dict(traj [T+1,7], status, iters, cost)."""
     lib = load_library()

@@ -208,15 +208,16 @@ int cfz_joint_dual_ws(cfz_handle *h, int n, const double *poses_this, const doub
  *   final_heading[B]      psi of the last point (:194-195), NaN = free; the pointer may be NULL
  *   tube                  for every instance, for strategy steps 1..n_sets-1: back cell then front cell, each as
  *                         A[4][2] row-major followed by b[4] (24 doubles per step), instances back to back (:178-192)
- *   guess                 x, y, psi of every point, instances back to back (spline_ws, :199-205); NULL = the initial pose
+ *   guess                 x, y, psi of every point, instances back to back (spline_ws, :199-205); NULL (spline_ws = False, what the
+ *                         reference's scripts configure for vehicle_0: IPOPT then starts from zeros) = cfz_state_ws_default_guess
  *   traj (out)            x, y, psi, v, delta, a, w of every point, instances back to back; the last input is repeated
  *   status, iters, cost   per instance (may be NULL); status as in cfz_mpc_stats, the reference raises on status != 0
  * The solver is the interior point of the MPC path with the exact Hessian of the Lagrangian and IPOPT's delta_w ladder
  * driven by a curvature test; the Newton system is solved as a stage recursion (a Riccati sweep over the T stages with
  * the terminal-heading row, the only one that can lose rank, bordered and regularised: delta_c = 1e-9;
  * csrc/cfz_plan.inl).  With a terminal heading and a guess that stands still (guess = NULL) the first linearisation
- * is rank deficient -- the headings cannot move -- and the solve ends with status 2 after a few iterations: give
- * the spline guess, as the reference's callers do (the speed along it is seeded here). */
+ * is rank deficient -- the headings cannot move -- and the solve ends with status 2 after a few iterations: hence
+ * the default guess through the tube when the caller has none (the speed along any guess is seeded here). */
 #define CFZ_KERNEL_AUTO 0
 #define CFZ_KERNEL_WIDE 1
 #define CFZ_KERNEL_NARROW 2
@@ -262,6 +263,13 @@ int cfz_state_ws_w(cfz_plan_ws *ws, int B, const cfz_plan_options *opt, const in
 int cfz_state_ws(int device, int B, const cfz_plan_options *opt, const int32_t *n_sets, const double *init_pose,
                  const double *final_heading, const double *tube, const double *guess, double *traj, int32_t *status,
                  int32_t *iters, double *cost);
+/* The guess cfz_state_ws takes for an instance when the caller passes none (host arithmetic, no GPU): x, y, psi of the
+ * N (n_sets - 1) + 1 points of the piecewise-linear path from the initial pose through the centres of the back cells of strategy steps
+ * 1 .. n_sets - 1 (centre = mean of the cell's vertices), heading at a step = direction from the back cell's centre to the front
+ * cell's on the branch nearest the previous heading, the terminal heading (NaN = free) at the last step.
+ * tube: (n_sets - 1) x 24 doubles as for cfz_state_ws; guess (out): (N (n_sets - 1) + 1) x 3.  0 = ok, -1 = bad argument. */
+int cfz_state_ws_default_guess(int32_t n_sets, int32_t N, const double init_pose[3], double final_heading, const double *tube,
+                               double *guess);
 
 /* ---- Vehicle.setup_single_final_problem + solve_single_final_problem (confrez/control/vehicle.py:360-661) -------------
  * The single-vehicle collocation plan: N = N_per_set (n_sets - 1) intervals of free length dt, K = 5 Radau points each,

@@ -59,6 +59,60 @@ def test_plan_kernel_source_matches_oracle(plans):
                 assert np.isclose(s["x"][0], p[0, 0]) and np.isclose(s["v"][0], 0.0, atol=1e-9)
 
 
+def test_default_guess_through_the_tube(plans):
+    """`cfz_state_ws_default_guess` (host arithmetic of the library, no GPU): what `cfz_state_ws` starts from when the caller has no guess
+    -- `spline_ws = False`, which the reference's own scripts configure for vehicle_0 (vehicle.py:894-899, vehicle_follower.py:871-876;
+    IPOPT then starts from zeros).  The path goes from the initial pose through the centres of the back cells, heading towards the
+    front cell's centre, and ends on the terminal heading; from it the kernel source converges on every vehicle of the strategy to
+    the optimum it reaches from the reference's spline guess (cost to 1e-3 at the solver's tolerance of 1e-2), where the standing start (every stage at the initial
+    pose: rank deficient under a terminal heading) ends with status 2 on all four."""
+    import plan_emu_binding as pe
+    from conflict_rez_amd import engine
+
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    for a, (tube, p) in plans.items():
+        fh = float(p[-1, 2])
+        ctube = [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in tube[1:]]
+        g = engine.state_ws_default_guess(p[0], ctube, fh)
+        nlp = StateWsNlp(p[0], tube, final_heading=fh, shrink_tube=0.5)
+        assert g.shape == (nlp.T + 1, 3) and np.allclose(g[0], p[0]) and abs(g[-1, 2] - fh) < 1e-12
+        for i in range(1, nlp.S):  # the checkpoints sit inside their (unshrunk) back cells, the headings are continuous
+            A, b = tube[i]["back"]
+            assert (A @ g[30 * i, :2] <= b + 1e-9).all()
+        assert np.abs(np.diff(g[:, 2])).max() < 0.2 and np.hypot(*np.diff(g[:, :2], axis=0).T).max() < 0.2
+        r = pe.solve(nlp, nlp.pack(g[:, 0], g[:, 1], g[:, 2], v=speed_guess(g, nlp.dt)), opt)
+        rs = pe.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)), opt)
+        assert r["status"] == rs["status"] == 0 and r["iters"] <= 30 and abs(r["f"] - rs["f"]) < 1e-3 * rs["f"], a  # (both stop at tol = 1e-2)
+        standing = pe.solve(nlp, nlp.pack(np.full(nlp.T + 1, p[0, 0]), np.full(nlp.T + 1, p[0, 1]), np.full(nlp.T + 1, p[0, 2])), opt)
+        assert standing["status"] == 2
+    lib = engine.load_library()  # a plan needs two strategy steps
+    assert lib.cfz_state_ws_default_guess(1, 30, None, 0.0, None, None) != 0 and b"bad argument" in lib.cfz_last_error()
+
+
+@pytest.mark.gpu
+def test_state_ws_without_a_guess(plans, tmp_path):
+    """`cfz_state_ws` with guess = NULL: all four vehicles converge from the default guess, to the plans they reach from the spline
+    guess (cost to 1e-3, poses to 2 cm: both stop at tol = 1e-2); and `Vehicle.state_ws(spline_ws=False)` of the host mirror -- the reference's configuration for vehicle_0 --
+    returns that plan instead of raising."""
+    from conflict_rez_amd import engine
+    from conflict_rez_amd.control.vehicle import Vehicle
+
+    agents = sorted(plans)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    fhs = [float(plans[a][1][-1, 2]) for a in agents]
+    init = [plans[a][1][0] for a in agents]
+    none = engine.state_ws(init, tubes, None, fhs, shrink_tube=0.5)
+    spl = engine.state_ws(init, tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5)
+    for a, r, s_ in zip(agents, none, spl):
+        assert r["status"] == s_["status"] == 0 and r["iters"] <= 30 and abs(r["cost"] - s_["cost"]) < 1e-3 * s_["cost"], a
+        assert np.abs(r["traj"][:, :3] - s_["traj"][:, :3]).max() < 2e-2
+    fn = str(tmp_path / "4v_rl_traj")
+    strat.write_strategy(fn, strat.generate_strategy(4))
+    v = Vehicle(rl_file_name=fn, agent="vehicle_0", color={"front": (1, 0, 0), "back": (0, 1, 0)})
+    z = v.state_ws(N=30, dt=0.1, final_heading=fhs[0], shrink_tube=0.5, spline_ws=False)
+    assert v.state_ws_stats["status"] == 0 and abs(v.state_ws_stats["cost"] - spl[0]["cost"]) < 1e-3 * spl[0]["cost"] and len(z.x) == len(spl[0]["traj"])
+
+
 def _corridor(S, h=1.25, x0=5.0, y0=17.5):
     """A straight corridor of S strategy steps (2.5 m cells along +x): tube for the oracle, tube for the C ABI, straight-line guess."""
     A = np.array([[0.0, -1.0], [-1.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
