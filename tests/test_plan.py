@@ -248,8 +248,9 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
 
 @pytest.mark.gpu
 def test_plan_single_path_then_follow_on_gpu(tmp_path):
-    """The reference's flow from a strategy file alone: MultiDistributedFollower plans every vehicle (state_ws and
-    dual_ws on the GPU; collocation refinement not built) and runs the distributed MPC on the result."""
+    """The reference's flow from a strategy file alone, with the configuration of its `main` (vehicle_0 without spline guess):
+    MultiDistributedFollower plans every vehicle (state_ws, dual_ws and the collocation refinement on the GPU) and runs the
+    distributed MPC on the result."""
     from conflict_rez_amd.control.vehicle_follower import MultiDistributedFollower
 
     fn = str(tmp_path / "4v_rl_traj")
@@ -257,12 +258,15 @@ def test_plan_single_path_then_follow_on_gpu(tmp_path):
     agents = ["vehicle_%d" % i for i in range(4)]
     colors = {a: {"front": (1.0, 0.0, 0.0), "back": (0.0, 0.0, 1.0)} for a in agents}
     paths = interp_along_sets(fn, VehicleBody(), 30)
-    mdf = MultiDistributedFollower(fn, {a: True for a in agents}, colors, {a: None for a in agents},
-                                   {a: float(paths[a][-1, 2]) for a in agents})
+    # the reference's own configuration (vehicle_follower.py:871-890): no spline guess for vehicle_0, terminal headings 0, 3 pi / 2, pi, pi / 2
+    ws_config = {"vehicle_0": False, "vehicle_1": True, "vehicle_2": True, "vehicle_3": True}
+    heads = {"vehicle_0": 0.0, "vehicle_1": 3 * np.pi / 2, "vehicle_2": np.pi, "vehicle_3": np.pi / 2}
+    assert all(abs(np.angle(np.exp(1j * (heads[a] - paths[a][-1, 2])))) < 1e-9 for a in agents)
+    mdf = MultiDistributedFollower(fn, ws_config, colors, {a: None for a in agents}, heads)
     mdf.setup_multi_vehicles()
     for v in mdf.vehicles:
         assert v.plan_refined is True and v.state_ws_stats["status"] == 0 and v.final_problem_stats["status"] == 0
-        assert abs(v.reference_traj.psi[-1] - v.final_heading) < 1e-2  # the terminal heading of the reference's callers
+        assert abs(np.angle(np.exp(1j * (v.reference_traj.psi[-1] - v.final_heading)))) < 1e-2  # the terminal heading of the reference's callers
         # the collocation plan frees dt: it is faster than the warm start's fixed 0.1 s x 30 steps per strategy step
         assert 2.0 < v.reference_traj.t[-1] < 0.1 * 30 * (v.num_sets - 1) and v.K == 5
         assert v.reference_traj.x.shape == v.reference_traj.psi.shape and np.isfinite(v.reference_xy).all()
