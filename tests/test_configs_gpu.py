@@ -252,7 +252,8 @@ def test_planner_surface_four_vehicles(tmp_path):
     strat.write_strategy(fn, strat.generate_strategy(4))
     agents = ["vehicle_%d" % i for i in range(4)]
     paths = interp_along_sets(fn, VehicleBody(), 30)
-    mvp = MultiVehiclePlanner(fn, {a: True for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
+    # ws_config as in the reference's main (multi_vehicle_planner.py:610-615): no spline guess for vehicle_0
+    mvp = MultiVehiclePlanner(fn, {a: a != "vehicle_0" for a in agents}, {a: {"front": (1, 0, 0), "back": (0, 0, 1)} for a in agents},
                               {a: VehicleState() for a in agents}, {a: float(paths[a][-1, 2]) for a in agents})
     mvp.solve_single_problems()
     mvp.joint_dual_ws(K=5)
