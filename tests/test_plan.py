@@ -142,6 +142,35 @@ def test_a_plan_of_510_stages(plans):
 
 
 @pytest.mark.gpu
+def test_scattered_starts_on_gpu_against_the_cpu_build(plans):
+    """32 plans from start poses scattered by +-3 cm (the bench's configs[1] sample, eight per vehicle) in one launch against the CPU
+    build of the same source, plan by plan: equal status and iteration count, trajectories to 1e-6 -- iteration counts 9 ... 28, not the
+    four nominal plans again."""
+    import plan_emu_binding as pe
+    from conflict_rez_amd import engine
+
+    agents = sorted(plans)
+    rng = np.random.default_rng(0)
+    who = [agents[i % 4] for i in range(32)]
+    init = [plans[a][1][0] + np.r_[rng.uniform(-0.03, 0.03, 2), 0.0] for a in who]
+    tubes = {a: [((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents}
+    fh = {a: float(plans[a][1][-1, 2]) for a in agents}
+    res = engine.state_ws(init, [tubes[a] for a in who], [plans[a][1] for a in who], [fh[a] for a in who], shrink_tube=0.5)
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    its = []
+    for i, (a, r) in enumerate(zip(who, res)):
+        tube, p = plans[a]
+        nlp = StateWsNlp(init[i], tube, final_heading=fh[a], shrink_tube=0.5)
+        re_ = pe.solve(nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)), opt)
+        se = nlp.unpack(re_["X"])
+        want = np.stack([se["x"], se["y"], se["psi"], se["v"], se["delta"], se["a"], se["w"]], 1)
+        assert (r["status"], r["iters"]) == (re_["status"], re_["iters"]) == (0, re_["iters"]), (i, a)
+        assert np.abs(r["traj"] - want).max() < 1e-6, (i, a)
+        its.append(r["iters"])
+    assert min(its) <= 10 and max(its) >= 20
+
+
+@pytest.mark.gpu
 def test_a_plan_too_long_for_the_lds_runs_from_the_workspace():
     """The same 510-stage plan through `cfz_state_ws`: asked for the LDS kernel (`kernel = CFZ_KERNEL_WIDE`) it runs from the workspace
     (the sweep's per-stage data would take 167 KB), bit for bit what `CFZ_KERNEL_NARROW` returns, and equals the oracle; in one batch
