@@ -118,6 +118,46 @@ def test_colloc_source_values_and_derivatives(plans, vv):
     assert bwf <= 51 and Kf.shape[0] == free.n + free.m
 
 
+def test_kkt_matrix_has_the_interval_structure(plans):
+    """What next round's elimination relies on (tools/colloc_condense_study.py, docs/notebook.md): in the matrix the kernel assembles,
+    the interior of a Radau interval (points 1..5 and the interval's 30 ODE rows: 65 unknowns) couples only to its own separator (start
+    point, continuity rows, tube slacks / rows, initial rows) and to the next one; eliminating the interiors independently (dense,
+    pivoted) and then the separator system with the dt border gives the solution of the whole system (1e-7 relative at condition
+    numbers of 1e11) -- at the guess and at an iterate, with barrier terms on every box."""
+    import importlib.util
+
+    import colloc_emu_binding as ce
+
+    spec_ = importlib.util.spec_from_file_location("colloc_condense_study", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "colloc_condense_study.py"))
+    st = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(st)
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tube, p = plans["vehicle_1"]
+    fh = float(p[-1, 2])
+    nlp = CollocNlp(p[0], tube[:4], sp.A_obs, sp.b_obs, N_per_set=5, final_heading=None)  # 15 intervals
+    X0 = colloc_guess(nlp, warm_start(tube[:4], p[: 30 * 3 + 1], None))
+    opt = ipm.IpmOptions(**COLLOC_OPT)
+    rng = np.random.default_rng(1)
+    N = nlp.N[0]
+    for X, mu in ((X0, 0.1), (ce.solve(nlp, X0, ipm.IpmOptions(**{**COLLOC_OPT, "max_iter": 6}))["X"], 2e-2)):
+        Xf = np.zeros(nlp.n)
+        Xf[: len(X)] = X
+        sel = ce.select(nlp, opt, Xf)
+        Xf[nlp.sO :] = np.maximum(Xf[nlp.sO :], 1e-2)
+        K, bw = ce.kkt(nlp, opt, sel, Xf, rng.standard_normal(nlp.m), sig=st.central_sigma(nlp, Xf, mu))
+        grp, live = st.interval_groups(nlp, K)
+        assert st.pattern_violations(K, grp, live) == 0 and (grp[live] != -1).all()
+        assert sorted(set((grp[live][grp[live] >= 0]).tolist())) == list(range(2 * N + 1))
+        sizes = [int((grp[live] == 2 * i + 1).sum()) for i in range(N)]
+        assert sizes[:-1] == [65] * (N - 1) and sizes[-1] == 65 + 16  # (the last interior holds the end point's tube slacks and rows)
+        rhs = rng.standard_normal(K.shape[0])
+        rhs[grp == -1] = 0.0
+        ref = np.zeros(K.shape[0])
+        ref[live] = np.linalg.solve(K[np.ix_(live, live)], rhs[live])
+        sol, info = st.structured_solve(K, grp, live, rhs, N, nlp.iDt)
+        assert np.abs(sol - ref).max() < 1e-7 * np.abs(ref).max() and info["separator_unknowns"] < 25 * (N + 1)
+
+
 @pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_3"])
 def test_colloc_source_solves_reference_problem(plans, agent):
     """Full size (N_per_set = 5, K = 5, six obstacles), from the state_ws warm start: converges at the reference's
