@@ -70,6 +70,67 @@ __device__ int wave_lu(double *M, int lane) {
   return 0;
 }
 
+// ---- the same with the block in REGISTERS: lane r holds row r of [A | B] (N + R doubles), the pivot by a DPP-free butterfly over the
+// candidates, the pivot row broadcast entry by entry with v_readlane; every loop fully unrolled (static register indices).
+__device__ __forceinline__ double lane_get(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int N, int R>
+__device__ __forceinline__ int wave_lu_regs(double (&a)[N + R], int lane, int &ord) {
+  bool done = lane >= N;
+  ord = -1;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double best = done ? -1.0 : fabs(a[k]);
+    double m = best;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if (!(m > 0.0)) return 1;
+    const int pl = (int)__builtin_ctzll(__ballot(best == m));  // first lane holding the largest entry
+    const double inv = 1.0 / lane_get(a[k], pl);
+    const bool mine = lane == pl;
+    const double l = (done || mine) ? 0.0 : a[k] * inv;
+    if (mine) { done = true; ord = k; }
+    if (l != 0.0) a[k] = l;  // rows still to be eliminated keep their multiplier (not needed again here), the pivot row keeps U
+#pragma unroll
+    for (int j = k + 1; j < N + R; ++j) a[j] -= l * lane_get(a[j], pl);
+  }
+  // back substitution: x_k sits in the lane whose row was the k-th pivot
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    const int pl = (int)__builtin_ctzll(__ballot(ord == k));
+    const double inv = 1.0 / lane_get(a[k], pl);
+    const double u = (ord >= 0 && ord < k) ? a[k] : 0.0;  // U entry (row ord, column k) of the rows pivoted before k
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      const double x = lane_get(a[N + c], pl) * inv;
+      a[N + c] = lane == pl ? x : a[N + c] - u * x;
+    }
+  }
+  return 0;
+}
+
+template <int N, int R>
+__global__ __launch_bounds__(512) void lu_regs_kernel(const double *A, const double *B, double *X, int nblocks, int *fail, unsigned long long *cyc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int blk = blockIdx.x * wpb + wave;
+  if (blk >= nblocks) return;
+  double a[N + R];
+  const int r = lane < N ? lane : N - 1;
+#pragma unroll
+  for (int j = 0; j < N + R; ++j) a[j] = j < N ? A[((size_t)blk * N + r) * N + j] : B[((size_t)blk * N + r) * R + (j - N)];
+  int ord;
+  const long long t0 = wall_clock64();
+  const int f = wave_lu_regs<N, R>(a, lane, ord);
+  const long long t1 = wall_clock64();
+  if (lane == 0) atomicAdd(cyc, (unsigned long long)(t1 - t0));
+  if (f && lane == 0) atomicAdd(fail, 1);
+  if (lane < N && ord >= 0) {
+#pragma unroll
+    for (int c = 0; c < R; ++c) X[((size_t)blk * N + ord) * R + c] = a[N + c];
+  }
+}
+
 __global__ void lu_kernel(const double *A, const double *B, double *X, int n, int nrhs, int nblocks, int *fail, unsigned long long *cyc) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, ld = n + nrhs;
@@ -88,6 +149,7 @@ __global__ void lu_kernel(const double *A, const double *B, double *X, int n, in
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 64, nrhs = argc > 2 ? atoi(argv[2]) : 62, nb = argc > 3 ? atoi(argv[3]) : 50 * 256, wpb = argc > 4 ? atoi(argv[4]) : 2;
+  const bool regs = argc > 5;  // any sixth argument: the register version (64 x 64 + 16 only)
   if (!((n == 64 && (nrhs == 16 || nrhs == 62)) || (n == 48 && nrhs == 16))) { fprintf(stderr, "compiled sizes: 64 16, 64 62, 48 16\n"); return 1; }
   std::vector<double> A((size_t)nb * n * n), B((size_t)nb * n * nrhs), X((size_t)nb * n * nrhs);
   srand(1);
@@ -104,7 +166,8 @@ int main(int argc, char **argv) {
   for (int rep = 0; rep < 3; ++rep) {
     OK(hipMemset(dc, 0, 8));
     OK(hipEventRecord(e0));
-    hipLaunchKernelGGL(lu_kernel, dim3(grid), dim3(64 * wpb), lds, 0, dA, dB, dX, n, nrhs, nb, df, dc);
+    if (regs) hipLaunchKernelGGL((lu_regs_kernel<64, 16>), dim3(grid), dim3(64 * wpb), 0, 0, dA, dB, dX, nb, df, dc);
+    else hipLaunchKernelGGL(lu_kernel, dim3(grid), dim3(64 * wpb), lds, 0, dA, dB, dX, n, nrhs, nb, df, dc);
     OK(hipEventRecord(e1)); OK(hipEventSynchronize(e1)); OK(hipEventElapsedTime(&ms, e0, e1));
   }
   OK(hipMemcpy(X.data(), dX, X.size() * 8, hipMemcpyDeviceToHost));
@@ -121,6 +184,7 @@ int main(int argc, char **argv) {
       }
   int cus = 0; OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
   const double per_cu_concurrent = floor(160.0 * 1024 / lds) * wpb;
+  if (regs) printf("REGISTER version: ");
   printf("n %d nrhs %d blocks %d, %d wavefronts per workgroup, LDS %zu B per workgroup: %.3f ms = %.2f us per block per CU-slot (%.0f blocks in flight per CU), "
          "elimination alone %.1f us per block (wall clock inside the kernel), failed %d, worst residual %.2e\n", n, nrhs, nb, wpb, lds, ms,
          ms * 1e3 / ((double)nb / (cus * per_cu_concurrent)), per_cu_concurrent, ticks * 0.01 / nb, fails / 3, worst);
