@@ -156,6 +156,10 @@ def test_kkt_matrix_has_the_interval_structure(plans):
         ref[live] = np.linalg.solve(K[np.ix_(live, live)], rhs[live])
         sol, info = st.structured_solve(K, grp, live, rhs, N, nlp.iDt)
         assert np.abs(sol - ref).max() < 1e-7 * np.abs(ref).max() and info["separator_unknowns"] < 25 * (N + 1)
+        # ... and the separator system itself is a block recursion over the intervals with dt as a second right-hand side
+        xs, _ = st.separator_recursion(info["S"], info["sepidx"], grp, N, info["rs"])
+        xd = np.linalg.solve(info["S"], info["rs"])
+        assert np.abs(xs - xd).max() < 1e-9 * np.abs(xd).max()
 
 
 @pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_3"])
