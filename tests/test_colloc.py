@@ -160,6 +160,14 @@ def test_kkt_matrix_has_the_interval_structure(plans):
         xs, _ = st.separator_recursion(info["S"], info["sepidx"], grp, N, info["rs"])
         xd = np.linalg.solve(info["S"], info["rs"])
         assert np.abs(xs - xd).max() < 1e-9 * np.abs(xd).max()
+        # the partition to build on the GPU: interiors of exactly 64 unknowns (a row per lane), separators of at most 31
+        g64, _ = st.interval_groups(nlp, K, lanes64=True)
+        assert st.pattern_violations(K, g64, live) == 0 and all((g64[live] == 2 * i + 1).sum() == 64 for i in range(N))
+        assert max((g64[live] == 2 * i).sum() for i in range(N + 1)) <= 31
+        sol64, info64 = st.structured_solve(K, g64, live, rhs, N, nlp.iDt)
+        xs64, _ = st.separator_recursion(info64["S"], info64["sepidx"], g64, N, info64["rs"])
+        assert np.abs(sol64 - ref).max() < 1e-7 * np.abs(ref).max()
+        assert np.abs(xs64 - np.linalg.solve(info64["S"], info64["rs"])).max() < 1e-8 * np.abs(xs64).max()
 
 
 @pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_3"])

@@ -22,10 +22,12 @@ from oracle.colloc_nlp import CollocNlp
 from oracle.plan_nlp import StateWsNlp, speed_guess
 
 
-def interval_groups(nlp, K):
+def interval_groups(nlp, K, lanes64=False):
     """Group index of every unknown of the assembled matrix K ([x | c] of a single-vehicle CollocNlp): 2 i = separator i (start point of
     interval i, its continuity rows, tube slacks / rows of a checkpoint, initial rows; 2 N: the terminal rows), 2 i + 1 = interior i
-    (points 1..5 of interval i and its 30 ODE rows), -2 = dt (border), -1 = eliminated before assembly (zero row)."""
+    (points 1..5 of interval i and its 30 ODE rows), -2 = dt (border), -1 = eliminated before assembly (zero row).
+    lanes64: interiors of exactly 64 unknowns and separators of 14 / 15 / 22 / 31 (see the code) -- in the band ordering of
+    cfz_colloc.inl both are still contiguous position ranges."""
     n, N = nlp.n, nlp.N[0]
     nt = n + nlp.m
     live = np.where(np.abs(K).sum(1) > 0)[0]
@@ -45,6 +47,12 @@ def interval_groups(nlp, K):
             if q in liveset and grp[q] < 0:
                 nb = [j for j in np.nonzero(K[q])[0] if grp[j] >= 0]
                 grp[q] = max(grp[j] for j in nb) if nb else -1
+    if lanes64:  # the partition to build: interiors of exactly 64 unknowns (one row per lane of a wavefront)
+        for i in range(N):  # the steering rate of an interval's last point joins the next separator ...
+            grp[7 * (6 * i + 5) + 6] = 2 * (i + 1)
+        for q in live:  # ... and so do the end point's tube slacks and rows
+            if grp[q] == 2 * N - 1 and (nlp.sT <= q < nlp.sP or n + nlp.rT <= q < n + nlp.rF):
+                grp[q] = 2 * N
     grp[nlp.iDt] = -2
     grp[[q for q in range(nt) if q not in liveset]] = -1
     return grp, live
@@ -151,7 +159,7 @@ def main():
         sel = ce.select(nlp, opt, Xf)
         Xf[nlp.sO:] = np.maximum(Xf[nlp.sO:], 1e-2)
         K, bw = ce.kkt(nlp, opt, sel, Xf, nu, sig=central_sigma(nlp, Xf, mu))
-        grp, live = interval_groups(nlp, K)
+        grp, live = interval_groups(nlp, K, lanes64=True)
         rhs = rng.standard_normal(K.shape[0]); rhs[grp == -1] = 0.0
         ref = np.zeros(K.shape[0]); ref[live] = np.linalg.solve(K[np.ix_(live, live)], rhs[live])
         sol, info = structured_solve(K, grp, live, rhs, N, nlp.iDt, want_cond=True)
