@@ -150,7 +150,7 @@ __global__ void lu_kernel(const double *A, const double *B, double *X, int n, in
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 64, nrhs = argc > 2 ? atoi(argv[2]) : 62, nb = argc > 3 ? atoi(argv[3]) : 50 * 256, wpb = argc > 4 ? atoi(argv[4]) : 2;
   const bool regs = argc > 5;  // any sixth argument: the register version (64 x 64 + 16 only)
-  if (!((n == 64 && (nrhs == 16 || nrhs == 62)) || (n == 48 && nrhs == 16))) { fprintf(stderr, "compiled sizes: 64 16, 64 62, 48 16\n"); return 1; }
+  if (!((n == 64 && (nrhs == 16 || nrhs == 62 || (nrhs == 22 && argc > 5))) || (n == 48 && nrhs == 16))) { fprintf(stderr, "compiled sizes: 64 16, 64 62, 48 16\n"); return 1; }
   std::vector<double> A((size_t)nb * n * n), B((size_t)nb * n * nrhs), X((size_t)nb * n * nrhs);
   srand(1);
   for (auto &v : A) v = rand() / (double)RAND_MAX - 0.5;
@@ -159,14 +159,15 @@ int main(int argc, char **argv) {
   OK(hipMalloc(&dA, A.size() * 8)); OK(hipMalloc(&dB, B.size() * 8)); OK(hipMalloc(&dX, X.size() * 8)); OK(hipMalloc(&df, 4)); OK(hipMalloc(&dc, 8));
   OK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); OK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice)); OK(hipMemset(df, 0, 4));
   const size_t lds = (size_t)wpb * n * (n + nrhs) * 8;
-  OK(hipFuncSetAttribute((const void *)lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (!regs) OK(hipFuncSetAttribute((const void *)lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (nb + wpb - 1) / wpb;
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   float ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     OK(hipMemset(dc, 0, 8));
     OK(hipEventRecord(e0));
-    if (regs) hipLaunchKernelGGL((lu_regs_kernel<64, 16>), dim3(grid), dim3(64 * wpb), 0, 0, dA, dB, dX, nb, df, dc);
+    if (regs && nrhs == 22) hipLaunchKernelGGL((lu_regs_kernel<64, 22>), dim3(grid), dim3(64 * wpb), 0, 0, dA, dB, dX, nb, df, dc);
+    else if (regs) hipLaunchKernelGGL((lu_regs_kernel<64, 16>), dim3(grid), dim3(64 * wpb), 0, 0, dA, dB, dX, nb, df, dc);
     else hipLaunchKernelGGL(lu_kernel, dim3(grid), dim3(64 * wpb), lds, 0, dA, dB, dX, n, nrhs, nb, df, dc);
     OK(hipEventRecord(e1)); OK(hipEventSynchronize(e1)); OK(hipEventElapsedTime(&ms, e0, e1));
   }
@@ -183,7 +184,7 @@ int main(int argc, char **argv) {
         worst = fmax(worst, fabs(s));
       }
   int cus = 0; OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-  const double per_cu_concurrent = floor(160.0 * 1024 / lds) * wpb;
+  const double per_cu_concurrent = regs ? 8.0 : floor(160.0 * 1024 / lds) * wpb;  // register version: eight wavefronts of 256 VGPRs per CU
   if (regs) printf("REGISTER version: ");
   printf("n %d nrhs %d blocks %d, %d wavefronts per workgroup, LDS %zu B per workgroup: %.3f ms = %.2f us per block per CU-slot (%.0f blocks in flight per CU), "
          "elimination alone %.1f us per block (wall clock inside the kernel), failed %d, worst residual %.2e\n", n, nrhs, nb, wpb, lds, ms,
