@@ -467,13 +467,14 @@ CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld 
 CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
 
 struct CWork {
-  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond, *condp;
+  double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond, *condp, *sw;
   int *posx, *posc, *ipiv;
   unsigned char *sel;
 };
+CFZP_FN size_t struct_doubles(const CSpec &sp);  // cfz_struct.inl: the structured elimination's own arrays (single plans)
 CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
   const CDims d = cdims(sp);
-  return (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
+  return struct_doubles(sp) + (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
          (size_t)(d.n + d.m + d.nk + 2) / 2 + (size_t)(d.np * sp.n_obs + d.npp + 7) / 8 + 64;
 }
 CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
@@ -488,6 +489,8 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
   w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
   p += (size_t)(d.n + d.m + d.nk + 2) / 2;
   w.sel = reinterpret_cast<unsigned char *>(p);
+  p += (size_t)(d.np * sp.n_obs + d.npp + 7) / 8 + 8;
+  w.sw = p;
   return w;
 }
 
@@ -1473,6 +1476,10 @@ CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
 // wavefronts: the panel elimination if its multipliers fit the dynamic LDS (lds_doubles), else band_factor_wide2; lds_rhs: doubles
 // of the dynamic LDS a right-hand side may occupy (band_substitute_wide, the fallback substitution), 0 = it does not fit.
 // (MODE 1, one wavefront per single plan with the elimination in an LDS window, was retired in round 4: see cfz_planning.hip.)
+}  // namespace cfzc
+#include "cfz_struct.inl"
+namespace cfzc {
+
 template <int MODE>
 CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles, int lds_rhs = 0) {
   const CDims d = cdims(sp);
@@ -1482,6 +1489,10 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
+  // no_prox bit 2: the structured elimination of cfz_struct.inl (single-vehicle plans in the ordering of half-bandwidth kCB)
+  const bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB;
+  SWork SW = {};
+  if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); }
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
   CFZP_SYNC();
   CFZP_LANE_FOR(q, 0, d.np - 1) {
@@ -1578,6 +1589,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       tk[1] += tick() - ta; ta = tick();
       int fail;
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
+      bool solved = false;
+      if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];
@@ -1588,6 +1601,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       fail = band_factor(Bd, d.nk, w.ipiv);
       tk[2] += tick() - ta; ta = tick();
       if (!fail) {
+        if (solved) { } else
 #if defined(__HIP_DEVICE_COMPILE__)
         if (MODE == 2 && (int)blockDim.x >= kb + 16 && 2 * (int)blockDim.x >= 2 * kb + 16 && kb <= kWideMaxKb && !(sp.no_prox & 2)) band_substitute_regs(Bd, d.nk, w.ipiv, w.rhs, w.rhs2, fwd_done);
         else if (MODE == 2 && blockDim.x > kb && 2 * kb <= 2 * (int)blockDim.x && d.nk <= lds_rhs) band_substitute_wide(Bd, d.nk, w.ipiv, w.rhs, w.rhs2); else

@@ -358,7 +358,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
     // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
     // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
+    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | (co->structured ? 4 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);

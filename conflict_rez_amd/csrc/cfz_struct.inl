@@ -1,0 +1,362 @@
+// Structured elimination of the single-vehicle collocation plan's Newton system (included by cfz_colloc.inl; docs/notebook.md, round 4).
+//
+// The band matrix `assemble` fills is eliminated interval by interval instead of pivot by pivot: in the band ordering an interval is
+// [continuity | tube | pt0] [pt1 pt2 | 30 ODE rows | pt3 pt4 pt5]; with the steering rate of pt5 counted to the NEXT interval's head the
+// second bracket is an INTERIOR of exactly 64 unknowns that couples to 7 unknowns on its left (pt0) and at most 14 on its right (that
+// steering rate, the next continuity rows; for the last interval the end point's tube rows and the terminal rows), and what lies
+// between two interiors is a SEPARATOR of 14-31 unknowns.  Phase 1: every interior independently, dense with partial pivoting, with its
+// coupling columns and the two right-hand sides as right-hand sides.  Phase 2: the Schur complements onto the separators.  Phase 3: the
+// separator system is block tridiagonal: a recursion over the intervals (dense, pivoted within a block).  Phase 4: back-substitution.
+// Another elimination ORDER of the same matrix: tools/colloc_condense_study.py and tests/test_colloc.py pin pattern and accuracy.
+#pragma once
+
+namespace cfzc {
+
+constexpr int kSI = 64;             // unknowns of an interior
+constexpr int kSL = 7, kSRt = 14;   // coupling columns on the left / on the right
+constexpr int kSR = 24;             // right-hand sides of an interior: 7 + 14 coupling columns, 2 right-hand sides, 1 spare
+constexpr int kSS = 32;             // separator block, padded (<= 31 unknowns)
+constexpr int kSZ = 16;             // right-hand sides of a separator block: <= 14 coupling columns + 2
+constexpr int kSWi = kSI * (kSL + kSRt) + kSI * kSR;  // doubles per interval: C (64 x 21), W (64 x 24)
+constexpr int kSWs = kSS * kSS + 2 * kSS * kSZ;       // doubles per separator: D (32 x 32), UR (32 x 16), Z (32 x 16)
+
+struct SWork { double *Ci, *Wi, *Ds, *Us, *Zs, *aug, *flag; int *cl, *ps; };
+
+CFZP_FN size_t struct_doubles(const CSpec &sp) {
+  if (sp.V != 1) return 0;
+  const int N = sp.N[0];
+  return (size_t)N * kSWi + (size_t)(N + 1) * kSWs + (size_t)kSI * (kSI + kSR) * 8 + (size_t)(N * 24 + 2 * (N + 2) + 3) / 2 + 16;
+}
+CFZP_FN SWork struct_carve(const CSpec &sp, double *p) {
+  const int N = sp.N[0];
+  SWork s;
+  s.Ci = p; p += (size_t)N * kSI * (kSL + kSRt); s.Wi = p; p += (size_t)N * kSI * kSR;
+  s.Ds = p; p += (size_t)(N + 1) * kSS * kSS; s.Us = p; p += (size_t)(N + 1) * kSS * kSZ; s.Zs = p; p += (size_t)(N + 1) * kSS * kSZ;
+  s.aug = p; p += (size_t)kSI * (kSI + kSR) * 8;  // one staging area per wavefront (eight)
+  s.flag = p; p += 2;
+  s.cl = reinterpret_cast<int *>(p); s.ps = s.cl + N * 24;
+  return s;
+}
+
+// positions: ps[i] = first position of separator i (i = 0..N), ps[N + 1] = nk; the interior of interval i is [pi, pi + 64), pi = ps[i + 1] - 64
+// cl[24 i + q]: q < 7 the positions of pt0 of interval i; 7 <= q < 21 the coupled positions of separator i + 1, -1 = none
+CFZP_FN void struct_setup(const CSpec &sp, const CDims &d, const CWork &w, const SWork &s) {
+  const int N = sp.N[0];
+  CFZP_LANE_FOR(i, 0, N - 1) {
+    const int pe = w.posx[7 * (kPts * i + 5) + 6];  // the steering rate of the interval's last point: first position of separator i + 1
+    s.ps[i + 1] = pe;
+    if (i == 0) { s.ps[0] = 0; s.ps[N + 1] = d.nk; }
+    int *cl = s.cl + 24 * i;
+    for (int c = 0; c < 7; ++c) cl[c] = w.posx[7 * (kPts * i) + c];
+    int q = 7;
+    cl[q++] = pe;
+    if (i + 1 < N) for (int c = 0; c < 7; ++c) cl[q++] = w.posc[d.rC + 7 * i + c];
+    else {
+      for (int T = d.coff[0]; T < d.coff[1]; ++T)
+        if (chk_point(sp, d, T) == kPts * N - 1) for (int r = 0; r < 8; ++r) if (q < 21) cl[q++] = w.posc[d.rT + 8 * T + r];
+      for (int c = 0; c < 5; ++c) if (w.posc[d.rF + c] >= 0 && q < 21) cl[q++] = w.posc[d.rF + c];
+    }
+    while (q < 24) cl[q++] = -1;
+  }
+  CFZP_SYNC();
+}
+
+CFZP_FN double band_at(const Band &B, int n, int i, int j) {
+  const int dd = i - j;
+  return (i >= 0 && j >= 0 && i < n && j < n && dd <= B.kb && -dd <= B.kb) ? B.ab[(size_t)j * B.ld + (2 * B.kb + dd)] : 0.0;
+}
+
+// dense elimination with partial pivoting of the n x n block in aug[n][ld] with nrhs right-hand sides behind it (ld >= n + nrhs);
+// the solution replaces the right-hand sides.  0 = ok.  (The CPU build, and the GPU's reference path: ONE lane runs it.)
+CFZP_FN int block_solve_serial(double *aug, int n, int ld, int nrhs) {
+  for (int k = 0; k < n; ++k) {
+    int p = k; double best = fabs(aug[k * ld + k]);
+    for (int i = k + 1; i < n; ++i) { const double a = fabs(aug[i * ld + k]); if (a > best) { best = a; p = i; } }
+    if (!(best > 0.0)) return 1;
+    if (p != k) for (int j = k; j < n + nrhs; ++j) { const double t = aug[k * ld + j]; aug[k * ld + j] = aug[p * ld + j]; aug[p * ld + j] = t; }
+    const double inv = 1.0 / aug[k * ld + k];
+    for (int i = k + 1; i < n; ++i) {
+      const double l = aug[i * ld + k] * inv;
+      if (l != 0.0) for (int j = k + 1; j < n + nrhs; ++j) aug[i * ld + j] -= l * aug[k * ld + j];
+    }
+  }
+  for (int c = n; c < n + nrhs; ++c)
+    for (int k = n - 1; k >= 0; --k) {
+      double t = aug[k * ld + c];
+      for (int j = k + 1; j < n; ++j) t -= aug[k * ld + j] * aug[j * ld + c];
+      aug[k * ld + c] = t / aug[k * ld + k];
+    }
+  return 0;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The GPU's block elimination: lane r holds row r of [A | B] in registers (NB + RB doubles), every loop unrolled (static register
+// indices), the pivot by a butterfly over the candidates, the pivot row broadcast entry by entry with v_readlane -- no memory inside
+// a pivot step (tools/src/wave_lu_bench.hip: 80-120 us for 64 x 64 with 22 right-hand sides, against 230 us with the block in LDS and
+// 3.4 us per pivot of the band elimination).  Functions of their own (their registers are theirs); they name no LDS.
+__device__ __forceinline__ double struct_lane_get(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int NB, int RB>
+__device__ __forceinline__ int wave_lu_regs(double (&a)[NB + RB], int lane, int &ord) {
+  bool done = lane >= NB;
+  ord = -1;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const double best = done ? -1.0 : fabs(a[k]);
+    double m = best;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if (!(m > 0.0)) return 1;
+    const int pl = (int)__builtin_ctzll(__ballot(best == m));  // the first row holding the largest entry, as the serial search
+    const double inv = 1.0 / struct_lane_get(a[k], pl);
+    const bool mine = lane == pl;
+    const double l = (done || mine) ? 0.0 : a[k] * inv;
+    if (mine) { done = true; ord = k; }
+#pragma unroll
+    for (int j = k + 1; j < NB + RB; ++j) a[j] -= l * struct_lane_get(a[j], pl);
+  }
+#pragma unroll
+  for (int k = NB - 1; k >= 0; --k) {
+    const int pl = (int)__builtin_ctzll(__ballot(ord == k));
+    const double inv = 1.0 / struct_lane_get(a[k], pl);
+    const double u = (ord >= 0 && ord < k) ? a[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c < RB; ++c) {
+      const double x = struct_lane_get(a[NB + c], pl) * inv;
+      a[NB + c] = lane == pl ? x : a[NB + c] - u * x;
+    }
+  }
+  return 0;
+}
+// interior of one interval: rows gathered from the band, coupling columns kept in C, K_II^-1 [C | b1 b2] to W (row = unknown)
+__device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int nk, int pi, const cfzb::glb_i32 *cl,
+                                                         const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W) {
+  const int lane = threadIdx.x & 63, r = pi + lane;
+  double a[kSI + kSR];
+#pragma unroll
+  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0; }
+#pragma unroll
+  for (int q = 0; q < kSL + kSRt; ++q) {
+    const int c = cl[q], dd = r - c;
+    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
+    a[kSI + q] = v; C[lane * (kSL + kSRt) + q] = v;
+  }
+  a[kSI + 21] = b1[r]; a[kSI + 22] = b2[r]; a[kSI + 23] = 0.0;
+  int ord;
+  if (wave_lu_regs<kSI, kSR>(a, lane, ord)) return 1;
+#pragma unroll
+  for (int q = 0; q < kSR; ++q) W[ord * kSR + q] = a[kSI + q];
+  return 0;
+}
+// one separator block: D (32 x 32, identity-padded), [U | r1 r2] (32 x 16) -> Z = D^-1 [U | r]
+__device__ __attribute__((noinline)) int struct_separator(const cfzb::glb_f64 *D, const cfzb::glb_f64 *U, cfzb::glb_f64 *Z) {
+  const int lane = threadIdx.x & 63, r = lane < kSS ? lane : kSS - 1;
+  double a[kSS + kSZ];
+#pragma unroll
+  for (int j = 0; j < kSS; ++j) a[j] = D[r * kSS + j];
+#pragma unroll
+  for (int q = 0; q < kSZ; ++q) a[kSS + q] = U[r * kSZ + q];
+  int ord;
+  if (wave_lu_regs<kSS, kSZ>(a, lane, ord)) return 1;
+  if (lane < kSS) {
+#pragma unroll
+    for (int q = 0; q < kSZ; ++q) Z[ord * kSZ + q] = a[kSS + q];
+  }
+  return 0;
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CFZS_WAVE ((int)(threadIdx.x >> 6))
+#define CFZS_NW ((int)(blockDim.x >> 6))
+#define CFZS_LANE ((int)(threadIdx.x & 63))
+#define CFZS_FIRST_OF_WAVE (CFZS_LANE == 0)
+#else
+#define CFZS_WAVE 0
+#define CFZS_NW 1
+#define CFZS_LANE 0
+#define CFZS_FIRST_OF_WAVE true
+#endif
+
+// The whole solve: on return b1, b2 (band positions) hold the two solutions.  0 = ok, 1 = a block was singular.
+CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const SWork &s, const Band &B, double *b1, double *b2) {
+  double *flag = s.flag;
+  const int N = sp.N[0], nk = d.nk, ldi = kSI + kSR;
+  CFZP_LANE_FOR(one, 0, 0) flag[0] = 0.0;
+  CFZP_SYNC();
+  // ---- phase 1: interiors (a wavefront each) ---------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int i = CFZS_WAVE; i < N; i += CFZS_NW) {
+    const int f = struct_interior((const cfzb::glb_f64 *)B.ab, B.kb, B.ld, nk, s.ps[i + 1] - kSI, (const cfzb::glb_i32 *)(s.cl + 24 * i), (const cfzb::glb_f64 *)b1,
+                                  (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)(s.Ci + (size_t)i * kSI * (kSL + kSRt)), (cfzb::glb_f64 *)(s.Wi + (size_t)i * kSI * kSR));
+    if (f && CFZS_LANE == 0) flag[0] = 1.0;
+  }
+#else
+  for (int i = CFZS_WAVE; i < N; i += CFZS_NW) {
+    const int pi = s.ps[i + 1] - kSI;
+    const int *cl = s.cl + 24 * i;
+    double *aug = s.aug + (size_t)CFZS_WAVE * kSI * ldi, *C = s.Ci + (size_t)i * kSI * (kSL + kSRt), *W = s.Wi + (size_t)i * kSI * kSR;
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int r = CFZS_LANE; r < kSI; r += 64)
+#else
+    for (int r = 0; r < kSI; ++r)
+#endif
+    {
+      for (int j = 0; j < kSI; ++j) aug[r * ldi + j] = band_at(B, nk, pi + r, pi + j);
+      for (int q = 0; q < kSL + kSRt; ++q) { const double v = cl[q] >= 0 ? band_at(B, nk, pi + r, cl[q]) : 0.0; aug[r * ldi + kSI + q] = v; C[r * (kSL + kSRt) + q] = v; }
+      aug[r * ldi + kSI + 21] = b1[pi + r]; aug[r * ldi + kSI + 22] = b2[pi + r]; aug[r * ldi + kSI + 23] = 0.0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+#endif
+    if (CFZS_FIRST_OF_WAVE) { if (block_solve_serial(aug, kSI, ldi, kSR)) flag[0] = 1.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int r = CFZS_LANE; r < kSI; r += 64)
+#else
+    for (int r = 0; r < kSI; ++r)
+#endif
+      for (int q = 0; q < kSR; ++q) W[r * kSR + q] = aug[r * ldi + kSI + q];
+  }
+#endif
+  CFZP_SYNC();
+  if (flag[0] != 0.0) return 1;
+  // ---- phase 2: separator blocks from the band, minus the interiors' Schur complements ------------------------------------------
+  CFZP_LANE_FOR(t, 0, (N + 1) * kSS * kSS - 1) {
+    const int i = t / (kSS * kSS), a = (t / kSS) % kSS, b = t % kSS, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
+    s.Ds[t] = (a < ns && b < ns) ? band_at(B, nk, s.ps[i] + a, s.ps[i] + b) : (a == b ? 1.0 : 0.0);
+  }
+  CFZP_LANE_FOR(t, 0, (N + 1) * kSS * kSZ - 1) {
+    const int i = t / (kSS * kSZ), a = (t / kSZ) % kSS, q = t % kSZ, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
+    s.Us[t] = (q >= 14 && a < ns) ? (q == 14 ? b1[s.ps[i] + a] : b2[s.ps[i] + a]) : 0.0;
+  }
+  CFZP_SYNC();
+  // M = C' W of interval i: rows = coupling columns (7 left, 14 right), columns = W's 24; scattered into D_i, U_i, D_{i+1} and the
+  // right-hand sides.  One (row, column) pair per lane at a time; interval by interval (the targets of neighbours overlap).
+  for (int i = 0; i < N; ++i) {
+    const int *cl = s.cl + 24 * i;
+    const double *C = s.Ci + (size_t)i * kSI * (kSL + kSRt), *W = s.Wi + (size_t)i * kSI * kSR;
+    double *Di = s.Ds + (size_t)i * kSS * kSS, *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Ui = s.Us + (size_t)i * kSS * kSZ, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
+    CFZP_LANE_FOR(t, 0, 21 * 23 - 1) {
+      const int a = t / 23, q = t % 23;  // coupling column a against W's column q (q < 21: coupling column q, 21 / 22: the right-hand sides)
+      if (cl[a] < 0 || (q < 21 && cl[q] < 0)) continue;
+      double m_ = 0.0;
+      for (int r = 0; r < kSI; ++r) m_ += C[r * (kSL + kSRt) + a] * W[r * kSR + q];
+      const int la = a < 7 ? cl[a] - s.ps[i] : cl[a] - s.ps[i + 1];  // local index in its separator
+      if (q >= 21) { (a < 7 ? Ui : Un)[la * kSZ + 14 + (q - 21)] -= m_; continue; }
+      const int lq = q < 7 ? cl[q] - s.ps[i] : cl[q] - s.ps[i + 1];
+      if (a < 7 && q < 7) Di[la * kSS + lq] -= m_;
+      else if (a >= 7 && q >= 7) Dn[la * kSS + lq] -= m_;
+      else if (a < 7 && q >= 7) Ui[la * kSZ + (q - 7)] = -m_;  // coupling of separator i (row la) with separator i + 1 (its q-th coupled unknown)
+    }
+    CFZP_SYNC();
+  }
+  // ---- phase 3: the recursion over the separators (the first wavefront; everybody waits) -------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (CFZS_WAVE == 0) {
+    const int lane = CFZS_LANE;
+    bool bad = false;
+    for (int i = 0; i <= N && !bad; ++i) {
+      const double *Ui = s.Us + (size_t)i * kSS * kSZ;
+      double *Zi = s.Zs + (size_t)i * kSS * kSZ;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+      if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)i * kSS * kSS), (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi)) { bad = true; break; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+      if (i < N) {
+        const int *cl = s.cl + 24 * i;
+        double *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
+        for (int t = lane; t < 14 * kSZ; t += 64) {
+          const int bq = t / kSZ, q = t % kSZ;
+          if (cl[7 + bq] < 0 || (q < 14 && cl[7 + q] < 0)) continue;
+          const int lb = cl[7 + bq] - s.ps[i + 1];
+          double m_ = 0.0;
+          for (int a = 0; a < 7; ++a) { const int la = cl[a] - s.ps[i]; m_ += Ui[la * kSZ + bq] * Zi[la * kSZ + q]; }
+          if (q < 14) Dn[lb * kSS + (cl[7 + q] - s.ps[i + 1])] -= m_; else Un[lb * kSZ + q] -= m_;
+        }
+      }
+    }
+    if (bad) { if (lane == 0) flag[0] = 1.0; }
+    else
+      for (int i = N - 1; i >= 0; --i) {
+        const int *cl = s.cl + 24 * i;
+        double *Zi = s.Zs + (size_t)i * kSS * kSZ; const double *Zn = s.Zs + (size_t)(i + 1) * kSS * kSZ;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+        if (lane < kSS) {
+          double x1 = Zi[lane * kSZ + 14], x2 = Zi[lane * kSZ + 15];
+          for (int bq = 0; bq < 14; ++bq) {
+            if (cl[7 + bq] < 0) continue;
+            const int lb = cl[7 + bq] - s.ps[i + 1];
+            x1 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 14]; x2 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 15];
+          }
+          Zi[lane * kSZ + 14] = x1; Zi[lane * kSZ + 15] = x2;
+        }
+      }
+  }
+#else
+  CFZP_LANE_FOR(one, 0, 0) {
+    double *aug = s.aug;
+    const int lds = kSS + kSZ;
+    for (int i = 0; i <= N; ++i) {
+      const double *Di = s.Ds + (size_t)i * kSS * kSS, *Ui = s.Us + (size_t)i * kSS * kSZ;
+      double *Zi = s.Zs + (size_t)i * kSS * kSZ;
+      for (int a = 0; a < kSS; ++a) { for (int b = 0; b < kSS; ++b) aug[a * lds + b] = Di[a * kSS + b]; for (int q = 0; q < kSZ; ++q) aug[a * lds + kSS + q] = Ui[a * kSZ + q]; }
+      if (block_solve_serial(aug, kSS, lds, kSZ)) { flag[0] = 1.0; break; }
+      for (int a = 0; a < kSS; ++a) for (int q = 0; q < kSZ; ++q) Zi[a * kSZ + q] = aug[a * lds + kSS + q];
+      if (i < N) {  // D_{i+1}[R, R] -= U_i' Z_i[:, U columns];  right-hand sides of separator i + 1 likewise
+        const int *cl = s.cl + 24 * i;
+        double *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
+        for (int bq = 0; bq < 14; ++bq) {
+          if (cl[7 + bq] < 0) continue;
+          const int lb = cl[7 + bq] - s.ps[i + 1];
+          for (int q = 0; q < kSZ; ++q) {
+            if (q < 14 && cl[7 + q] < 0) continue;
+            double m_ = 0.0;
+            for (int a = 0; a < 7; ++a) { const int la = cl[a] - s.ps[i]; m_ += Ui[la * kSZ + bq] * Zi[la * kSZ + q]; }
+            if (q < 14) Dn[lb * kSS + (cl[7 + q] - s.ps[i + 1])] -= m_; else Un[lb * kSZ + q] -= m_;
+          }
+        }
+      }
+    }
+    // backward: x_i = Z_i[:, rhs] - Z_i[:, U columns] x_{i+1}[R]   (x kept in Z's right-hand-side columns)
+    if (flag[0] == 0.0)
+      for (int i = N - 1; i >= 0; --i) {
+        const int *cl = s.cl + 24 * i;
+        double *Zi = s.Zs + (size_t)i * kSS * kSZ; const double *Zn = s.Zs + (size_t)(i + 1) * kSS * kSZ;
+        for (int a = 0; a < kSS; ++a)
+          for (int bq = 0; bq < 14; ++bq) {
+            if (cl[7 + bq] < 0) continue;
+            const int lb = cl[7 + bq] - s.ps[i + 1];
+            Zi[a * kSZ + 14] -= Zi[a * kSZ + bq] * Zn[lb * kSZ + 14]; Zi[a * kSZ + 15] -= Zi[a * kSZ + bq] * Zn[lb * kSZ + 15];
+          }
+      }
+  }
+#endif
+  CFZP_SYNC();
+  if (flag[0] != 0.0) return 1;
+  // ---- phase 4: the separators' and the interiors' unknowns back to band positions ----------------------------------------------
+  CFZP_LANE_FOR(t, 0, (N + 1) * kSS - 1) {
+    const int i = t / kSS, a = t % kSS, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
+    if (a < ns) { b1[s.ps[i] + a] = s.Zs[(size_t)t * kSZ + 14]; b2[s.ps[i] + a] = s.Zs[(size_t)t * kSZ + 15]; }
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(t, 0, N * kSI - 1) {
+    const int i = t / kSI, r = t % kSI, pi = s.ps[i + 1] - kSI;
+    const int *cl = s.cl + 24 * i;
+    const double *W = s.Wi + (size_t)t * kSR;
+    double y1 = W[21], y2 = W[22];
+    for (int q = 0; q < 21; ++q) if (cl[q] >= 0) { y1 -= W[q] * b1[cl[q]]; y2 -= W[q] * b2[cl[q]]; }
+    // (the separators' values were written above: the barrier before this loop orders them)
+    s.Ci[(size_t)t * (kSL + kSRt)] = y1; s.Ci[(size_t)t * (kSL + kSRt) + 1] = y2;  // parked: b1 / b2 at interior positions are still inputs of nobody, but keep reads and writes apart
+    (void)pi; (void)r;
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(t, 0, N * kSI - 1) {
+    const int i = t / kSI, r = t % kSI, pi = s.ps[i + 1] - kSI;
+    b1[pi + r] = s.Ci[(size_t)t * (kSL + kSRt)]; b2[pi + r] = s.Ci[(size_t)t * (kSL + kSRt) + 1];
+  }
+  CFZP_SYNC();
+  return 0;
+}
+
+}  // namespace cfzc

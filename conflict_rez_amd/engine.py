@@ -278,7 +278,8 @@ def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=
 class _CCollocOptions(C.Structure):
     _fields_ = [("N_per_set", C.c_int32), ("max_iter", C.c_int32), ("exact_rows", C.c_int32), ("one_pivot", C.c_int32), ("vv_rows", C.c_int32), ("kernel", C.c_int32),
                 ("shrink_tube", C.c_double),
-                ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double)]
+                ("tol", C.c_double), ("constr_viol_tol", C.c_double), ("mu_init", C.c_double), ("curv_kappa", C.c_double),
+                ("structured", C.c_int32), ("reserved1", C.c_int32)]
 
 
 def colloc(spec, init_poses, tubes, guesses, dt0s, final_headings=None, device=0, ws=None, **options):

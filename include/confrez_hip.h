@@ -303,6 +303,10 @@ typedef struct cfz_colloc_options {
   double constr_viol_tol; /* :651 1e-2 */
   double mu_init;         /* 0.1 (IPOPT's default) */
   double curv_kappa;      /* 1e-8 */
+  int32_t structured;     /* single-vehicle plans (cfz_colloc): 1 = the Newton system is eliminated interval by interval (the interiors of the
+                           *    Radau intervals independently, then a block recursion over the interval starts: csrc/cfz_struct.inl)
+                           *    instead of pivot by pivot along the band; same matrix, same solution to rounding.  Joint plans: ignored */
+  int32_t reserved1;
 } cfz_colloc_options;
 
 void cfz_default_colloc_options(cfz_colloc_options *opt);

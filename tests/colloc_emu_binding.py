@@ -24,7 +24,7 @@ class CSpec(C.Structure):
 
 def build(force=False):
     srcs = [os.path.join(ROOT, "tests", "emu", "cfz_colloc_emu.cpp")] + [os.path.join(ROOT, "conflict_rez_amd", "csrc", f)
-                                                                         for f in ("cfz_colloc.inl", "cfz_plan.inl", "cfz_solver.inl")]
+                                                                         for f in ("cfz_colloc.inl", "cfz_struct.inl", "cfz_plan.inl", "cfz_solver.inl")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library

@@ -118,6 +118,26 @@ def test_colloc_source_values_and_derivatives(plans, vv):
     assert bwf <= 51 and Kf.shape[0] == free.n + free.m
 
 
+@pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_0"])
+def test_structured_elimination_equals_the_band_elimination(plans, agent):
+    """cfz_struct.inl on the CPU build: the single-vehicle plan with its Newton system eliminated interval by interval (CSpec::no_prox
+    bit 2) takes the iterates of the band elimination -- equal status and iteration count, solution to 1e-8: another elimination order
+    of the same matrix (30 and 50 intervals; the 50-interval plan is the one whose batch time the bench's configs[1] is)."""
+    import colloc_emu_binding as ce
+
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tube, p = plans[agent]
+    fh = float(p[-1, 2])
+    nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
+    X0 = colloc_guess(nlp, warm_start(tube, p, fh))
+    band = ce.solve(nlp, X0, ipm.IpmOptions(**COLLOC_OPT))
+    opt = ipm.IpmOptions(**COLLOC_OPT)
+    opt.no_prox = 4
+    st = ce.solve(nlp, X0, opt)
+    assert (st["status"], st["iters"]) == (band["status"], band["iters"]) == (0, band["iters"])
+    assert np.abs(st["X"] - band["X"]).max() < 1e-8 and abs(st["f"] - band["f"]) < 1e-9 * band["f"]
+
+
 def test_kkt_matrix_has_the_interval_structure(plans):
     """What next round's elimination relies on (tools/colloc_condense_study.py, docs/notebook.md): in the matrix the kernel assembles,
     the interior of a Radau interval (points 1..5 and the interval's 30 ODE rows: 65 unknowns) couples only to its own separator (start
@@ -449,6 +469,38 @@ def test_planning_workspace_reuse(plans):
         assert np.array_equal(a["traj"], b["traj"]) and np.array_equal(a["traj"], c["traj"])
     assert np.array_equal(one[0]["traj"], plain[1]["traj"])
     ws.close()
+
+
+@pytest.mark.gpu
+def test_structured_elimination_on_gpu(plans):
+    """`cfz_colloc_options.structured = 1`: the four vehicles' plans from their state_ws warm starts with the Newton system eliminated
+    interval by interval (register-resident dense eliminations of the 64-unknown interiors, eight wavefronts at a time; a block
+    recursion over the separators) against the band elimination: equal status and iteration count, trajectories to 1e-7; and 300
+    copies of one plan in a batch all equal the lone plan bit for bit."""
+    from conflict_rez_amd import engine
+
+    agents = sorted(plans)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    fhs = [float(plans[a][1][-1, 2]) for a in agents]
+    init = [plans[a][1][0] for a in agents]
+    ws = engine.state_ws(init, tubes, [plans[a][1] for a in agents], fhs, shrink_tube=0.5)
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tau = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])
+    gs = []
+    for w_, t_ in zip(ws, tubes):
+        N = 5 * len(t_)
+        t = 0.1 * np.arange(len(w_["traj"]))
+        ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
+        gs.append((np.stack([np.interp(ti, t, w_["traj"][:, c]) for c in range(7)], 1), t[-1] / N))
+    args = (sp, init, tubes, [g[0] for g in gs], [g[1] for g in gs], fhs)
+    band = engine.colloc(*args, max_iter=400)
+    st = engine.colloc(*args, max_iter=400, structured=1)
+    for a, b, s_ in zip(agents, band, st):
+        assert (s_["status"], s_["iters"]) == (b["status"], b["iters"]) == (0, b["iters"]), a
+        assert np.abs(s_["traj"] - b["traj"]).max() < 1e-7 and abs(s_["dt"] - b["dt"]) < 1e-10 and abs(s_["cost"] - b["cost"]) < 1e-8 * b["cost"]
+    B = 300
+    many = engine.colloc(sp, [init[1]] * B, [tubes[1]] * B, [gs[1][0]] * B, [gs[1][1]] * B, [fhs[1]] * B, max_iter=400, structured=1)
+    assert all(r["iters"] == st[1]["iters"] and np.array_equal(r["traj"], st[1]["traj"]) and r["dt"] == st[1]["dt"] for r in many)
 
 
 @pytest.mark.gpu
