@@ -1590,7 +1590,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
       bool solved = false;
-      if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2); solved = true; } else
+      if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];

@@ -140,13 +140,13 @@ __device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab
   for (int q = 0; q < kSL + kSRt; ++q) {
     const int c = cl[q], dd = r - c;
     const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
-    a[kSI + q] = v; C[lane * (kSL + kSRt) + q] = v;
+    a[kSI + q] = v; C[q * kSI + lane] = v;
   }
   a[kSI + 21] = b1[r]; a[kSI + 22] = b2[r]; a[kSI + 23] = 0.0;
   int ord;
   if (wave_lu_regs<kSI, kSR>(a, lane, ord)) return 1;
 #pragma unroll
-  for (int q = 0; q < kSR; ++q) W[ord * kSR + q] = a[kSI + q];
+  for (int q = 0; q < kSR; ++q) W[q * kSI + ord] = a[kSI + q];
   return 0;
 }
 // one separator block: D (32 x 32, identity-padded), [U | r1 r2] (32 x 16) -> Z = D^-1 [U | r]
@@ -180,8 +180,9 @@ __device__ __attribute__((noinline)) int struct_separator(const cfzb::glb_f64 *D
 #endif
 
 // The whole solve: on return b1, b2 (band positions) hold the two solutions.  0 = ok, 1 = a block was singular.
-CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const SWork &s, const Band &B, double *b1, double *b2) {
+CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const SWork &s, const Band &B, double *b1, double *b2, long long *ptk) {
   double *flag = s.flag;
+  long long tp = tick();  // ptk[0..2]: interiors, Schur complements, separator recursion + back-substitution (device clock)
   const int N = sp.N[0], nk = d.nk, ldi = kSI + kSR;
   CFZP_LANE_FOR(one, 0, 0) flag[0] = 0.0;
   CFZP_SYNC();
@@ -204,7 +205,7 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
 #endif
     {
       for (int j = 0; j < kSI; ++j) aug[r * ldi + j] = band_at(B, nk, pi + r, pi + j);
-      for (int q = 0; q < kSL + kSRt; ++q) { const double v = cl[q] >= 0 ? band_at(B, nk, pi + r, cl[q]) : 0.0; aug[r * ldi + kSI + q] = v; C[r * (kSL + kSRt) + q] = v; }
+      for (int q = 0; q < kSL + kSRt; ++q) { const double v = cl[q] >= 0 ? band_at(B, nk, pi + r, cl[q]) : 0.0; aug[r * ldi + kSI + q] = v; C[q * kSI + r] = v; }
       aug[r * ldi + kSI + 21] = b1[pi + r]; aug[r * ldi + kSI + 22] = b2[pi + r]; aug[r * ldi + kSI + 23] = 0.0;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -217,10 +218,11 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
 #else
     for (int r = 0; r < kSI; ++r)
 #endif
-      for (int q = 0; q < kSR; ++q) W[r * kSR + q] = aug[r * ldi + kSI + q];
+      for (int q = 0; q < kSR; ++q) W[q * kSI + r] = aug[r * ldi + kSI + q];
   }
 #endif
   CFZP_SYNC();
+  { const long long t1 = tick(); ptk[0] += t1 - tp; tp = t1; }
   if (flag[0] != 0.0) return 1;
   // ---- phase 2: separator blocks from the band, minus the interiors' Schur complements ------------------------------------------
   CFZP_LANE_FOR(t, 0, (N + 1) * kSS * kSS - 1) {
@@ -232,26 +234,29 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
     s.Us[t] = (q >= 14 && a < ns) ? (q == 14 ? b1[s.ps[i] + a] : b2[s.ps[i] + a]) : 0.0;
   }
   CFZP_SYNC();
-  // M = C' W of interval i: rows = coupling columns (7 left, 14 right), columns = W's 24; scattered into D_i, U_i, D_{i+1} and the
-  // right-hand sides.  One (row, column) pair per lane at a time; interval by interval (the targets of neighbours overlap).
-  for (int i = 0; i < N; ++i) {
+  // M = C' W of interval i: rows = coupling columns (7 left, 14 right), columns = W's first 23; scattered into D_i, U_i, D_{i+1} and the
+  // right-hand sides.  One (interval, row, column) triple per lane at a time, all intervals at once: what two neighbouring intervals
+  // write into the same separator never coincides (interval i: the rows / columns of its right coupling list, interval i + 1: pt0).
+  CFZP_LANE_FOR(tt, 0, N * 21 * 23 - 1) {
+    const int i = tt / (21 * 23), t = tt - i * (21 * 23);
     const int *cl = s.cl + 24 * i;
     const double *C = s.Ci + (size_t)i * kSI * (kSL + kSRt), *W = s.Wi + (size_t)i * kSI * kSR;
     double *Di = s.Ds + (size_t)i * kSS * kSS, *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Ui = s.Us + (size_t)i * kSS * kSZ, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
-    CFZP_LANE_FOR(t, 0, 21 * 23 - 1) {
-      const int a = t / 23, q = t % 23;  // coupling column a against W's column q (q < 21: coupling column q, 21 / 22: the right-hand sides)
-      if (cl[a] < 0 || (q < 21 && cl[q] < 0)) continue;
-      double m_ = 0.0;
-      for (int r = 0; r < kSI; ++r) m_ += C[r * (kSL + kSRt) + a] * W[r * kSR + q];
-      const int la = a < 7 ? cl[a] - s.ps[i] : cl[a] - s.ps[i + 1];  // local index in its separator
-      if (q >= 21) { (a < 7 ? Ui : Un)[la * kSZ + 14 + (q - 21)] -= m_; continue; }
-      const int lq = q < 7 ? cl[q] - s.ps[i] : cl[q] - s.ps[i + 1];
-      if (a < 7 && q < 7) Di[la * kSS + lq] -= m_;
-      else if (a >= 7 && q >= 7) Dn[la * kSS + lq] -= m_;
-      else if (a < 7 && q >= 7) Ui[la * kSZ + (q - 7)] = -m_;  // coupling of separator i (row la) with separator i + 1 (its q-th coupled unknown)
-    }
-    CFZP_SYNC();
+    const int a = t / 23, q = t % 23;  // coupling column a against W's column q (q < 21: coupling column q, 21 / 22: the right-hand sides)
+    if (cl[a] < 0 || (q < 21 && cl[q] < 0)) continue;
+    if (a >= 7 && q < 7) continue;  // (the transpose of a block that is kept)
+    double m_ = 0.0;
+#pragma unroll 16
+    for (int r = 0; r < kSI; ++r) m_ += C[a * kSI + r] * W[q * kSI + r];  // (both stored column by column: contiguous in r)
+    const int la = a < 7 ? cl[a] - s.ps[i] : cl[a] - s.ps[i + 1];  // local index in its separator
+    if (q >= 21) { (a < 7 ? Ui : Un)[la * kSZ + 14 + (q - 21)] -= m_; continue; }
+    const int lq = q < 7 ? cl[q] - s.ps[i] : cl[q] - s.ps[i + 1];
+    if (a < 7 && q < 7) Di[la * kSS + lq] -= m_;
+    else if (a >= 7 && q >= 7) Dn[la * kSS + lq] -= m_;
+    else Ui[la * kSZ + (q - 7)] = -m_;  // coupling of separator i (row la) with separator i + 1 (its q-th coupled unknown)
   }
+  CFZP_SYNC();
+  { const long long t1 = tick(); ptk[1] += t1 - tp; tp = t1; }
   // ---- phase 3: the recursion over the separators (the first wavefront; everybody waits) -------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
   if (CFZS_WAVE == 0) {
@@ -343,19 +348,20 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
   CFZP_LANE_FOR(t, 0, N * kSI - 1) {
     const int i = t / kSI, r = t % kSI, pi = s.ps[i + 1] - kSI;
     const int *cl = s.cl + 24 * i;
-    const double *W = s.Wi + (size_t)t * kSR;
-    double y1 = W[21], y2 = W[22];
-    for (int q = 0; q < 21; ++q) if (cl[q] >= 0) { y1 -= W[q] * b1[cl[q]]; y2 -= W[q] * b2[cl[q]]; }
+    const double *W = s.Wi + (size_t)i * kSI * kSR + r;  // column q of the interval's W at W[q * 64]
+    double y1 = W[21 * kSI], y2 = W[22 * kSI];
+    for (int q = 0; q < 21; ++q) if (cl[q] >= 0) { y1 -= W[q * kSI] * b1[cl[q]]; y2 -= W[q * kSI] * b2[cl[q]]; }
     // (the separators' values were written above: the barrier before this loop orders them)
-    s.Ci[(size_t)t * (kSL + kSRt)] = y1; s.Ci[(size_t)t * (kSL + kSRt) + 1] = y2;  // parked: b1 / b2 at interior positions are still inputs of nobody, but keep reads and writes apart
+    s.Ci[(size_t)i * kSI * (kSL + kSRt) + r] = y1; s.Ci[(size_t)i * kSI * (kSL + kSRt) + kSI + r] = y2;  // parked: b1 / b2 at interior positions are still inputs of nobody, but keep reads and writes apart
     (void)pi; (void)r;
   }
   CFZP_SYNC();
   CFZP_LANE_FOR(t, 0, N * kSI - 1) {
     const int i = t / kSI, r = t % kSI, pi = s.ps[i + 1] - kSI;
-    b1[pi + r] = s.Ci[(size_t)t * (kSL + kSRt)]; b2[pi + r] = s.Ci[(size_t)t * (kSL + kSRt) + 1];
+    b1[pi + r] = s.Ci[(size_t)i * kSI * (kSL + kSRt) + r]; b2[pi + r] = s.Ci[(size_t)i * kSI * (kSL + kSRt) + kSI + r];
   }
   CFZP_SYNC();
+  { const long long t1 = tick(); ptk[2] += t1 - tp; }
   return 0;
 }
 
