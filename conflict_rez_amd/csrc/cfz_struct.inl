@@ -18,9 +18,9 @@ constexpr int kSR = 24;             // right-hand sides of an interior: 7 + 14 c
 constexpr int kSS = 32;             // separator block, padded (<= 31 unknowns)
 constexpr int kSZ = 16;             // right-hand sides of a separator block: <= 14 coupling columns + 2
 constexpr int kSWi = kSI * (kSL + kSRt) + kSI * kSR;  // doubles per interval: C (64 x 21), W (64 x 24)
-constexpr int kSWs = kSS * kSS + 2 * kSS * kSZ;       // doubles per separator: D (32 x 32), UR (32 x 16), Z (32 x 16)
+constexpr int kSWs = kSS * kSS + 4 * kSS * kSZ;       // doubles per separator: D (32 x 32), UR, Z and their bottom-up twins (32 x 16 each)
 
-struct SWork { double *Ci, *Wi, *Ds, *Us, *Zs, *aug, *flag; int *cl, *ps; };
+struct SWork { double *Ci, *Wi, *Ds, *Us, *Zs, *Ub, *Zb, *aug, *flag; int *cl, *ps; };
 
 CFZP_FN size_t struct_doubles(const CSpec &sp) {
   if (sp.V != 1) return 0;
@@ -32,6 +32,7 @@ CFZP_FN SWork struct_carve(const CSpec &sp, double *p) {
   SWork s;
   s.Ci = p; p += (size_t)N * kSI * (kSL + kSRt); s.Wi = p; p += (size_t)N * kSI * kSR;
   s.Ds = p; p += (size_t)(N + 1) * kSS * kSS; s.Us = p; p += (size_t)(N + 1) * kSS * kSZ; s.Zs = p; p += (size_t)(N + 1) * kSS * kSZ;
+  s.Ub = p; p += (size_t)(N + 1) * kSS * kSZ; s.Zb = p; p += (size_t)(N + 1) * kSS * kSZ;
   s.aug = p; p += (size_t)kSI * (kSI + kSR) * 8;  // one staging area per wavefront (eight)
   s.flag = p; p += 2;
   s.cl = reinterpret_cast<int *>(p); s.ps = s.cl + N * 24;
@@ -104,9 +105,7 @@ __device__ __forceinline__ int wave_lu_regs(double (&a)[NB + RB], int lane, int 
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     const double best = done ? -1.0 : fabs(a[k]);
-    double m = best;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    const double m = cfz::wave_reduce<1>(best);  // DPP row operations and four v_readlane: no trip through the LDS crossbar
     if (!(m > 0.0)) return 1;
     const int pl = (int)__builtin_ctzll(__ballot(best == m));  // the first row holding the largest entry, as the serial search
     const double inv = 1.0 / struct_lane_get(a[k], pl);
@@ -259,16 +258,19 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
   { const long long t1 = tick(); ptk[1] += t1 - tp; tp = t1; }
   // ---- phase 3: the recursion over the separators (the first wavefront; everybody waits) -------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (CFZS_WAVE == 0) {
-    const int lane = CFZS_LANE;
-    bool bad = false;
-    for (int i = 0; i <= N && !bad; ++i) {
-      const double *Ui = s.Us + (size_t)i * kSS * kSZ;
-      double *Zi = s.Zs + (size_t)i * kSS * kSZ;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
-      if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)i * kSS * kSS), (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi)) { bad = true; break; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
-      if (i < N) {
+  {
+    // From both ends: wavefront 0 eliminates separators 0 .. mid - 1 downwards (separator i into i + 1), wavefront 1 separators N .. mid + 1
+    // upwards (j into j - 1); then wavefront 0 solves separator mid, which has received both, and the two back-substitute outwards.
+    const int lane = CFZS_LANE, wv = CFZS_WAVE, mid = (N + 1) / 2;
+#define CFZS_WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+    if (wv == 0) {
+      bool bad = false;
+      for (int i = 0; i < mid && !bad; ++i) {
+        const double *Ui = s.Us + (size_t)i * kSS * kSZ;
+        double *Zi = s.Zs + (size_t)i * kSS * kSZ;
+        CFZS_WFENCE();
+        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)i * kSS * kSS), (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi)) { bad = true; break; }
+        CFZS_WFENCE();
         const int *cl = s.cl + 24 * i;
         double *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
         for (int t = lane; t < 14 * kSZ; t += 64) {
@@ -280,23 +282,76 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
           if (q < 14) Dn[lb * kSS + (cl[7 + q] - s.ps[i + 1])] -= m_; else Un[lb * kSZ + q] -= m_;
         }
       }
-    }
-    if (bad) { if (lane == 0) flag[0] = 1.0; }
-    else
-      for (int i = N - 1; i >= 0; --i) {
-        const int *cl = s.cl + 24 * i;
-        double *Zi = s.Zs + (size_t)i * kSS * kSZ; const double *Zn = s.Zs + (size_t)(i + 1) * kSS * kSZ;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
-        if (lane < kSS) {
-          double x1 = Zi[lane * kSZ + 14], x2 = Zi[lane * kSZ + 15];
-          for (int bq = 0; bq < 14; ++bq) {
-            if (cl[7 + bq] < 0) continue;
-            const int lb = cl[7 + bq] - s.ps[i + 1];
-            x1 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 14]; x2 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 15];
-          }
-          Zi[lane * kSZ + 14] = x1; Zi[lane * kSZ + 15] = x2;
+      if (bad && lane == 0) flag[0] = 1.0;
+    } else if (wv == 1) {
+      bool bad = false;
+      for (int j = N; j > mid && !bad; --j) {
+        // right-hand sides of block j for the upward step: columns 0..6 = U_{j-1}' (row R_b of separator j, column a of pt0_{j-1}), 14 / 15 = r_j
+        const int *cl = s.cl + 24 * (j - 1);
+        const double *Up = s.Us + (size_t)(j - 1) * kSS * kSZ;  // coupling of separator j - 1 (rows) with separator j (its coupled unknowns, columns)
+        double *Ubj = s.Ub + (size_t)j * kSS * kSZ, *Zbj = s.Zb + (size_t)j * kSS * kSZ;
+        const double *Uj = s.Us + (size_t)j * kSS * kSZ;
+        CFZS_WFENCE();
+        for (int t = lane; t < kSS * kSZ; t += 64) { const int q = t % kSZ; Ubj[t] = q >= 14 ? Uj[t] : 0.0; }
+        CFZS_WFENCE();
+        for (int t = lane; t < 14 * 7; t += 64) {
+          const int bq = t / 7, a = t % 7;
+          if (cl[7 + bq] < 0) continue;
+          Ubj[(cl[7 + bq] - s.ps[j]) * kSZ + a] = Up[(cl[a] - s.ps[j - 1]) * kSZ + bq];
+        }
+        CFZS_WFENCE();
+        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)j * kSS * kSS), (const cfzb::glb_f64 *)Ubj, (cfzb::glb_f64 *)Zbj)) { bad = true; break; }
+        CFZS_WFENCE();
+        // D_{j-1}[L, L] -= U_{j-1} Zb_j[R, 0:7];  r_{j-1}[L] -= U_{j-1} Zb_j[R, 14:16]
+        double *Dp = s.Ds + (size_t)(j - 1) * kSS * kSS; double *Upw = s.Us + (size_t)(j - 1) * kSS * kSZ;
+        for (int t = lane; t < 7 * 9; t += 64) {
+          const int a = t / 9, q = t % 9, la = cl[a] - s.ps[j - 1];
+          double m_ = 0.0;
+          for (int bq = 0; bq < 14; ++bq) { if (cl[7 + bq] < 0) continue; m_ += Up[la * kSZ + bq] * Zbj[(cl[7 + bq] - s.ps[j]) * kSZ + (q < 7 ? q : 14 + (q - 7))]; }
+          if (q < 7) Dp[la * kSS + (cl[q] - s.ps[j - 1])] -= m_; else Upw[la * kSZ + 14 + (q - 7)] -= m_;
         }
       }
+      if (bad && lane == 0) flag[0] = 1.0;
+    }
+    __syncthreads();
+    if (flag[0] == 0.0 && wv == 0) {  // the middle block: everything above and below has been folded into it
+      double *Zm = s.Zs + (size_t)mid * kSS * kSZ;
+      if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)mid * kSS * kSS), (const cfzb::glb_f64 *)(s.Us + (size_t)mid * kSS * kSZ), (cfzb::glb_f64 *)Zm)) { if (lane == 0) flag[0] = 1.0; }
+      CFZS_WFENCE();
+      if (mid < N) for (int t = lane; t < kSS * 2; t += 64) s.Zb[(size_t)mid * kSS * kSZ + (t / 2) * kSZ + 14 + (t & 1)] = Zm[(t / 2) * kSZ + 14 + (t & 1)];  // x_mid, for the downward pass
+    }
+    __syncthreads();
+    if (flag[0] == 0.0) {
+      if (wv == 0) {  // upwards: x_i = Z_i[:, rhs] - Z_i[:, U columns] x_{i+1}[R]
+        for (int i = mid - 1; i >= 0; --i) {
+          const int *cl = s.cl + 24 * i;
+          double *Zi = s.Zs + (size_t)i * kSS * kSZ; const double *Zn = s.Zs + (size_t)(i + 1) * kSS * kSZ;
+          CFZS_WFENCE();
+          if (lane < kSS) {
+            double x1 = Zi[lane * kSZ + 14], x2 = Zi[lane * kSZ + 15];
+            for (int bq = 0; bq < 14; ++bq) {
+              if (cl[7 + bq] < 0) continue;
+              const int lb = cl[7 + bq] - s.ps[i + 1];
+              x1 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 14]; x2 -= Zi[lane * kSZ + bq] * Zn[lb * kSZ + 15];
+            }
+            Zi[lane * kSZ + 14] = x1; Zi[lane * kSZ + 15] = x2;
+          }
+        }
+      } else if (wv == 1) {  // downwards: x_j = Zb_j[:, rhs] - Zb_j[:, 0:7] x_{j-1}[pt0]; results also into Z (phase 4 reads Z)
+        for (int j = mid + 1; j <= N; ++j) {
+          const int *cl = s.cl + 24 * (j - 1);
+          double *Zbj = s.Zb + (size_t)j * kSS * kSZ; const double *Zbp = s.Zb + (size_t)(j - 1) * kSS * kSZ;
+          CFZS_WFENCE();
+          if (lane < kSS) {
+            double x1 = Zbj[lane * kSZ + 14], x2 = Zbj[lane * kSZ + 15];
+            for (int a = 0; a < 7; ++a) { const int la = cl[a] - s.ps[j - 1]; x1 -= Zbj[lane * kSZ + a] * Zbp[la * kSZ + 14]; x2 -= Zbj[lane * kSZ + a] * Zbp[la * kSZ + 15]; }
+            Zbj[lane * kSZ + 14] = x1; Zbj[lane * kSZ + 15] = x2;
+            s.Zs[(size_t)j * kSS * kSZ + lane * kSZ + 14] = x1; s.Zs[(size_t)j * kSS * kSZ + lane * kSZ + 15] = x2;
+          }
+        }
+      }
+    }
+#undef CFZS_WFENCE
   }
 #else
   CFZP_LANE_FOR(one, 0, 0) {
