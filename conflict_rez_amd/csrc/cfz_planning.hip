@@ -358,7 +358,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
     // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
     // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | (co->structured ? 4 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
+    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | ((co->structured && !co->one_pivot) ? 4 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);
@@ -517,7 +517,7 @@ int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final,
 
 void cfz_default_colloc_options(cfz_colloc_options *o) {
   memset(o, 0, sizeof *o);
-  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5; o->vv_rows = 1;
+  o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5; o->vv_rows = 1; o->structured = 1;
   // mu_init: IPOPT's default; 1e-3 (the MPC step's value) leaves a tail of plans that jam against a bound for 100+ iterations
   o->tol = 1e-2; o->constr_viol_tol = 1e-2; o->mu_init = 0.1; o->curv_kappa = 1e-8;
 }

@@ -473,7 +473,7 @@ def test_planning_workspace_reuse(plans):
 
 @pytest.mark.gpu
 def test_structured_elimination_on_gpu(plans):
-    """`cfz_colloc_options.structured = 1`: the four vehicles' plans from their state_ws warm starts with the Newton system eliminated
+    """`cfz_colloc_options.structured` (1 by default): the four vehicles' plans from their state_ws warm starts with the Newton system eliminated
     interval by interval (register-resident dense eliminations of the 64-unknown interiors, eight wavefronts at a time; a block
     recursion over the separators) against the band elimination: equal status and iteration count, trajectories to 1e-7; and 300
     copies of one plan in a batch all equal the lone plan bit for bit."""
@@ -493,13 +493,13 @@ def test_structured_elimination_on_gpu(plans):
         ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
         gs.append((np.stack([np.interp(ti, t, w_["traj"][:, c]) for c in range(7)], 1), t[-1] / N))
     args = (sp, init, tubes, [g[0] for g in gs], [g[1] for g in gs], fhs)
-    band = engine.colloc(*args, max_iter=400)
-    st = engine.colloc(*args, max_iter=400, structured=1)
+    band = engine.colloc(*args, max_iter=400, structured=0)
+    st = engine.colloc(*args, max_iter=400)  # (structured = 1 is the default)
     for a, b, s_ in zip(agents, band, st):
         assert (s_["status"], s_["iters"]) == (b["status"], b["iters"]) == (0, b["iters"]), a
         assert np.abs(s_["traj"] - b["traj"]).max() < 1e-7 and abs(s_["dt"] - b["dt"]) < 1e-10 and abs(s_["cost"] - b["cost"]) < 1e-8 * b["cost"]
     B = 300
-    many = engine.colloc(sp, [init[1]] * B, [tubes[1]] * B, [gs[1][0]] * B, [gs[1][1]] * B, [fhs[1]] * B, max_iter=400, structured=1)
+    many = engine.colloc(sp, [init[1]] * B, [tubes[1]] * B, [gs[1][0]] * B, [gs[1][1]] * B, [fhs[1]] * B, max_iter=400)
     assert all(r["iters"] == st[1]["iters"] and np.array_equal(r["traj"], st[1]["traj"]) and r["dt"] == st[1]["dt"] for r in many)
 
 

@@ -27,7 +27,7 @@ ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh
 gs = [guess_of(w["traj"], len(tubes[a]) + 1) for w, a in zip(ws, who)]
 args = (sp, init, [tubes[a] for a in who], [g[0] for g in gs], [g[1] for g in gs], [fh[a] for a in who])
 res = {}
-for name, kw in (("band", {}), ("structured", dict(structured=1)), ("band", {}), ("structured", dict(structured=1))):
+for name, kw in (("band", dict(structured=0)), ("structured", dict(structured=1)), ("band", dict(structured=0)), ("structured", dict(structured=1))):
     t0 = time.time(); r = engine.colloc(*args, max_iter=400, **kw); t1 = time.time()
     res[name] = r
     its = np.array([x["iters"] for x in r])
