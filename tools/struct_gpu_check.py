@@ -12,7 +12,7 @@ with tempfile.TemporaryDirectory() as d:
     fn = os.path.join(d, "4v_rl_traj"); strat.write_strategy(fn, hist)
     sets, paths = compute_sets(fn), interp_along_sets(fn, VehicleBody(), 30)
 agents = sorted(hist)
-sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+sp = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=int(os.environ.get("NOBS", 6)))
 tubes = {a: [((s["back"].A, s["back"].b), (s["front"].A, s["front"].b)) for s in sets[a][1:]] for a in agents}
 fh = {a: float(paths[a][-1, 2]) for a in agents}
 tau = np.append(0.0, [0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])
@@ -35,4 +35,5 @@ for name, kw in (("band", dict(structured=0)), ("structured", dict(structured=1)
 a, b = res["band"], res["structured"]
 same = sum(x["iters"] == y["iters"] and x["status"] == y["status"] for x, y in zip(a, b))
 dmax = max(float(np.abs(x["traj"] - y["traj"]).max()) for x, y in zip(a, b) if x["iters"] == y["iters"])
+print("plans with other iteration counts:", [(i, who[i], x["iters"], y["iters"]) for i, (x, y) in enumerate(zip(a, b)) if x["iters"] != y["iters"]][:10])
 print(f"same status and iteration count: {same} of {B}; largest trajectory difference among those {dmax:.2e}; dt difference {max(abs(x['dt'] - y['dt']) for x, y in zip(a, b)):.2e}")
