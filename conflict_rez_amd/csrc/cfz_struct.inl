@@ -128,24 +128,31 @@ __device__ __forceinline__ int wave_lu_regs(double (&a)[NB + RB], int lane, int 
   }
   return 0;
 }
-// interior of one interval: rows gathered from the band, coupling columns kept in C, K_II^-1 [C | b1 b2] to W (row = unknown)
+// interior of one interval: rows gathered from the band, coupling columns kept in C, K_II^-1 [C | b1 b2] to W (row = unknown).
+// NC coupling columns are live (15 for all intervals but the last: pt0, the steering rate, the next continuity rows; 21 for the last);
+// the right-hand sides follow them in the registers and go to W's columns 21 and 22 either way.
+template <int NC>
 __device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int nk, int pi, const cfzb::glb_i32 *cl,
                                                          const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W) {
+  constexpr int RB = NC + 2 + (NC & 1);  // (even, as the elimination's template was measured)
   const int lane = threadIdx.x & 63, r = pi + lane;
-  double a[kSI + kSR];
+  double a[kSI + RB];
 #pragma unroll
   for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0; }
 #pragma unroll
   for (int q = 0; q < kSL + kSRt; ++q) {
-    const int c = cl[q], dd = r - c;
+    const int c = q < NC ? cl[q] : -1, dd = r - c;
     const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
-    a[kSI + q] = v; C[q * kSI + lane] = v;
+    if (q < NC) a[kSI + q] = v;
+    C[q * kSI + lane] = v;
   }
-  a[kSI + 21] = b1[r]; a[kSI + 22] = b2[r]; a[kSI + 23] = 0.0;
+  a[kSI + NC] = b1[r]; a[kSI + NC + 1] = b2[r];
+  if (NC & 1) a[kSI + NC + 2] = 0.0;
   int ord;
-  if (wave_lu_regs<kSI, kSR>(a, lane, ord)) return 1;
+  if (wave_lu_regs<kSI, RB>(a, lane, ord)) return 1;
 #pragma unroll
-  for (int q = 0; q < kSR; ++q) W[q * kSI + ord] = a[kSI + q];
+  for (int q = 0; q < kSL + kSRt; ++q) W[q * kSI + ord] = q < NC ? a[kSI + q] : 0.0;
+  W[21 * kSI + ord] = a[kSI + NC]; W[22 * kSI + ord] = a[kSI + NC + 1];
   return 0;
 }
 // one separator block: D (32 x 32, identity-padded), [U | r1 r2] (32 x 16) -> Z = D^-1 [U | r]
@@ -188,8 +195,11 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
   // ---- phase 1: interiors (a wavefront each) ---------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
   for (int i = CFZS_WAVE; i < N; i += CFZS_NW) {
-    const int f = struct_interior((const cfzb::glb_f64 *)B.ab, B.kb, B.ld, nk, s.ps[i + 1] - kSI, (const cfzb::glb_i32 *)(s.cl + 24 * i), (const cfzb::glb_f64 *)b1,
-                                  (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)(s.Ci + (size_t)i * kSI * (kSL + kSRt)), (cfzb::glb_f64 *)(s.Wi + (size_t)i * kSI * kSR));
+    const cfzb::glb_f64 *ab_ = (const cfzb::glb_f64 *)B.ab, *b1_ = (const cfzb::glb_f64 *)b1, *b2_ = (const cfzb::glb_f64 *)b2;
+    const cfzb::glb_i32 *cl_ = (const cfzb::glb_i32 *)(s.cl + 24 * i);
+    cfzb::glb_f64 *C_ = (cfzb::glb_f64 *)(s.Ci + (size_t)i * kSI * (kSL + kSRt)), *W_ = (cfzb::glb_f64 *)(s.Wi + (size_t)i * kSI * kSR);
+    const int f = i + 1 < N ? struct_interior<15>(ab_, B.kb, B.ld, nk, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_)
+                            : struct_interior<kSL + kSRt>(ab_, B.kb, B.ld, nk, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
