@@ -504,6 +504,35 @@ def test_structured_elimination_on_gpu(plans):
 
 
 @pytest.mark.gpu
+def test_structured_elimination_on_short_plans(plans):
+    """Plans of 5, 10 and 15 intervals (the separator recursion from both ends meets after one to seven steps), with and without a
+    terminal heading: the structured elimination ends where the band elimination ends -- status (a plan that fails its line search
+    among them), iteration count, trajectory to 1e-5."""
+    from conflict_rez_amd import engine
+
+    sp = scenarios.parking_lot_spec(n_nbr=0, N=2)
+    tau = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])
+    seen = set()
+    for a in ("vehicle_1", "vehicle_0"):
+        for S in (2, 3, 4):
+            tube = [((s_["back"][0], s_["back"][1]), (s_["front"][0], s_["front"][1])) for s_ in plans[a][0][1:S]]
+            p = plans[a][1][: 30 * (S - 1) + 1]
+            for fh in (None, float(p[-1, 2])):
+                ws = engine.state_ws([p[0]], [tube], [p], [fh], shrink_tube=0.5)[0]
+                assert ws["status"] == 0
+                N = 5 * len(tube)
+                t = 0.1 * np.arange(len(ws["traj"]))
+                ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
+                g = np.stack([np.interp(ti, t, ws["traj"][:, c]) for c in range(7)], 1)
+                args = (sp, [p[0]], [tube], [g], [t[-1] / N], [fh])
+                b = engine.colloc(*args, max_iter=400, structured=0)[0]
+                s1 = engine.colloc(*args, max_iter=400)[0]
+                assert (s1["status"], s1["iters"]) == (b["status"], b["iters"]) and np.abs(s1["traj"] - b["traj"]).max() < 1e-5, (a, S, fh)
+                seen.add(b["status"])
+    assert 0 in seen
+
+
+@pytest.mark.gpu
 def test_colloc_fixture_on_gpu(plans):
     """The same fixture through the C ABI: cfz_colloc and cfz_joint_colloc from the stored guesses."""
     from conflict_rez_amd import engine
