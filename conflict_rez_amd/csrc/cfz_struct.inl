@@ -155,21 +155,31 @@ __device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab
   W[21 * kSI + ord] = a[kSI + NC]; W[22 * kSI + ord] = a[kSI + NC + 1];
   return 0;
 }
-// one separator block: D (32 x 32, identity-padded), [U | r1 r2] (32 x 16) -> Z = D^-1 [U | r]
-__device__ __attribute__((noinline)) int struct_separator(const cfzb::glb_f64 *D, const cfzb::glb_f64 *U, cfzb::glb_f64 *Z) {
-  const int lane = threadIdx.x & 63, r = lane < kSS ? lane : kSS - 1;
-  double a[kSS + kSZ];
+// one separator block: D (32 x 32 in memory, identity-padded), [U | r1 r2] (32 x 16) -> Z = D^-1 [U | r].  NS = 16 for the separators of
+// at most 15 unknowns (four in five): half the pivot steps
+template <int NS>
+__device__ __attribute__((noinline)) int struct_separator_n(const cfzb::glb_f64 *D, const cfzb::glb_f64 *U, cfzb::glb_f64 *Z) {
+  const int lane = threadIdx.x & 63, r = lane < NS ? lane : NS - 1;
+  double a[NS + kSZ];
 #pragma unroll
-  for (int j = 0; j < kSS; ++j) a[j] = D[r * kSS + j];
+  for (int j = 0; j < NS; ++j) a[j] = D[r * kSS + j];
 #pragma unroll
-  for (int q = 0; q < kSZ; ++q) a[kSS + q] = U[r * kSZ + q];
+  for (int q = 0; q < kSZ; ++q) a[NS + q] = U[r * kSZ + q];
   int ord;
-  if (wave_lu_regs<kSS, kSZ>(a, lane, ord)) return 1;
-  if (lane < kSS) {
+  if (wave_lu_regs<NS, kSZ>(a, lane, ord)) return 1;
+  if (lane < NS) {
 #pragma unroll
-    for (int q = 0; q < kSZ; ++q) Z[ord * kSZ + q] = a[kSS + q];
+    for (int q = 0; q < kSZ; ++q) Z[ord * kSZ + q] = a[NS + q];
   }
   return 0;
+}
+__device__ __forceinline__ int struct_separator(const cfzb::glb_f64 *D, const cfzb::glb_f64 *U, cfzb::glb_f64 *Z, int ns) {
+  if (ns <= 16) {
+    const int f = struct_separator_n<16>(D, U, Z);
+    if (!f) { const int lane = threadIdx.x & 63; if (lane >= 16 && lane < kSS) { for (int q = 0; q < kSZ; ++q) Z[lane * kSZ + q] = 0.0; } }  // the padding rows' (zero) solution
+    return f;
+  }
+  return struct_separator_n<kSS>(D, U, Z);
 }
 #endif
 
@@ -271,15 +281,24 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
   {
     // From both ends: wavefront 0 eliminates separators 0 .. mid - 1 downwards (separator i into i + 1), wavefront 1 separators N .. mid + 1
     // upwards (j into j - 1); then wavefront 0 solves separator mid, which has received both, and the two back-substitute outwards.
-    const int lane = CFZS_LANE, wv = CFZS_WAVE, mid = (N + 1) / 2;
+    const int lane = CFZS_LANE, wv = CFZS_WAVE, mid = (4 * (N + 1)) / 7;  // (an upward step costs more than a downward one)
 #define CFZS_WFENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+    // the upward steps' right-hand sides: columns 0..6 of Ub_j = U_{j-1}' (row = unknown of separator j, column = pt0 unknown of j - 1)
+    for (int t = (int)threadIdx.x; t < (N - mid) * kSS * 14; t += (int)blockDim.x) { const int j = mid + 1 + t / (kSS * 14), e = t % (kSS * 14); s.Ub[(size_t)j * kSS * kSZ + (e / 14) * kSZ + (e % 14)] = 0.0; }
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < (N - mid) * 14 * 7; t += (int)blockDim.x) {
+      const int j = mid + 1 + t / 98, e = t % 98, bq = e / 7, a = e % 7;
+      const int *cl = s.cl + 24 * (j - 1);
+      if (cl[7 + bq] >= 0) s.Ub[(size_t)j * kSS * kSZ + (cl[7 + bq] - s.ps[j]) * kSZ + a] = s.Us[(size_t)(j - 1) * kSS * kSZ + (cl[a] - s.ps[j - 1]) * kSZ + bq];
+    }
+    __syncthreads();
     if (wv == 0) {
       bool bad = false;
       for (int i = 0; i < mid && !bad; ++i) {
         const double *Ui = s.Us + (size_t)i * kSS * kSZ;
         double *Zi = s.Zs + (size_t)i * kSS * kSZ;
         CFZS_WFENCE();
-        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)i * kSS * kSS), (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi)) { bad = true; break; }
+        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)i * kSS * kSS), (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi, s.ps[i + 1] - kSI - s.ps[i])) { bad = true; break; }
         CFZS_WFENCE();
         const int *cl = s.cl + 24 * i;
         double *Dn = s.Ds + (size_t)(i + 1) * kSS * kSS, *Un = s.Us + (size_t)(i + 1) * kSS * kSZ;
@@ -302,15 +321,9 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
         double *Ubj = s.Ub + (size_t)j * kSS * kSZ, *Zbj = s.Zb + (size_t)j * kSS * kSZ;
         const double *Uj = s.Us + (size_t)j * kSS * kSZ;
         CFZS_WFENCE();
-        for (int t = lane; t < kSS * kSZ; t += 64) { const int q = t % kSZ; Ubj[t] = q >= 14 ? Uj[t] : 0.0; }
+        for (int t = lane; t < kSS * 2; t += 64) Ubj[(t >> 1) * kSZ + 14 + (t & 1)] = Uj[(t >> 1) * kSZ + 14 + (t & 1)];  // r_j as it stands now (U' was laid out before the recursion)
         CFZS_WFENCE();
-        for (int t = lane; t < 14 * 7; t += 64) {
-          const int bq = t / 7, a = t % 7;
-          if (cl[7 + bq] < 0) continue;
-          Ubj[(cl[7 + bq] - s.ps[j]) * kSZ + a] = Up[(cl[a] - s.ps[j - 1]) * kSZ + bq];
-        }
-        CFZS_WFENCE();
-        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)j * kSS * kSS), (const cfzb::glb_f64 *)Ubj, (cfzb::glb_f64 *)Zbj)) { bad = true; break; }
+        if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)j * kSS * kSS), (const cfzb::glb_f64 *)Ubj, (cfzb::glb_f64 *)Zbj, (j < N ? s.ps[j + 1] - kSI : nk) - s.ps[j])) { bad = true; break; }
         CFZS_WFENCE();
         // D_{j-1}[L, L] -= U_{j-1} Zb_j[R, 0:7];  r_{j-1}[L] -= U_{j-1} Zb_j[R, 14:16]
         double *Dp = s.Ds + (size_t)(j - 1) * kSS * kSS; double *Upw = s.Us + (size_t)(j - 1) * kSS * kSZ;
@@ -326,7 +339,7 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
     __syncthreads();
     if (flag[0] == 0.0 && wv == 0) {  // the middle block: everything above and below has been folded into it
       double *Zm = s.Zs + (size_t)mid * kSS * kSZ;
-      if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)mid * kSS * kSS), (const cfzb::glb_f64 *)(s.Us + (size_t)mid * kSS * kSZ), (cfzb::glb_f64 *)Zm)) { if (lane == 0) flag[0] = 1.0; }
+      if (struct_separator((const cfzb::glb_f64 *)(s.Ds + (size_t)mid * kSS * kSS), (const cfzb::glb_f64 *)(s.Us + (size_t)mid * kSS * kSZ), (cfzb::glb_f64 *)Zm, (mid < N ? s.ps[mid + 1] - kSI : nk) - s.ps[mid])) { if (lane == 0) flag[0] = 1.0; }
       CFZS_WFENCE();
       if (mid < N) for (int t = lane; t < kSS * 2; t += 64) s.Zb[(size_t)mid * kSS * kSZ + (t / 2) * kSZ + 14 + (t & 1)] = Zm[(t / 2) * kSZ + 14 + (t & 1)];  // x_mid, for the downward pass
     }
