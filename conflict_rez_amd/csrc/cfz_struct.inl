@@ -244,9 +244,10 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
   { const long long t1 = tick(); ptk[0] += t1 - tp; tp = t1; }
   if (flag[0] != 0.0) return 1;
   // ---- phase 2: separator blocks from the band, minus the interiors' Schur complements ------------------------------------------
-  CFZP_LANE_FOR(t, 0, (N + 1) * kSS * kSS - 1) {
-    const int i = t / (kSS * kSS), a = (t / kSS) % kSS, b = t % kSS, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
-    s.Ds[t] = (a < ns && b < ns) ? band_at(B, nk, s.ps[i] + a, s.ps[i] + b) : (a == b ? 1.0 : 0.0);
+  CFZP_LANE_FOR(t, 0, (N + 1) * kSS - 1) {  // one column of a separator block per lane at a time: contiguous in the band
+    const int i = t / kSS, b = t % kSS, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
+    double *Di = s.Ds + (size_t)i * kSS * kSS;
+    for (int a = 0; a < kSS; ++a) Di[a * kSS + b] = (a < ns && b < ns) ? band_at(B, nk, s.ps[i] + a, s.ps[i] + b) : (a == b ? 1.0 : 0.0);
   }
   CFZP_LANE_FOR(t, 0, (N + 1) * kSS * kSZ - 1) {
     const int i = t / (kSS * kSZ), a = (t / kSZ) % kSS, q = t % kSZ, ns = (i < N ? s.ps[i + 1] - kSI : nk) - s.ps[i];
