@@ -58,8 +58,8 @@ namespace cfzc {
 // CSpec::no_prox = 1 switches it off (the exact solution at tight tolerances, tests/test_independent_solver.py).
 
 constexpr int kPts = 6;     // points per interval (K + 1)
-constexpr int kOutD = 12;    // out_d: cost, err, mu, then 100 MHz ticks spent in evaluation, assembly, factorisation, substitution,
-                            // line search, and in total (zero on the CPU)
+constexpr int kOutD = 20;    // out_d: cost, err, mu, then 100 MHz ticks spent in evaluation, assembly, factorisation, substitution,
+                            // line search, and in total, three sub-phases of the elimination, eight of the joint structured elimination (zero on the CPU)
 CFZP_FN long long tick() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (long long)wall_clock64();
@@ -142,6 +142,10 @@ struct CDims {
   int rO, rC, rR, rT, rF, rP;
   int off[kMaxVeh + 1], coff[kMaxVeh + 1], poff[kMaxPairs + 1];
 };
+// The structured elimination of the JOINT plan (cfz_jstruct.inl; CSpec::no_prox bit 2 with V > 1) works on another statement of the same
+// Newton system: positions vehicle-major (build_order), the tube slacks and rows condensed into the pose block they touch like the
+// collision rows (so a vehicle's separators hold at most 15 unknowns), the condensed pair blocks kept beside the band (CWork::pm).
+CFZP_FN bool jstruct_mode(const CSpec &sp) { return (sp.no_prox & 4) != 0 && sp.V > 1; }
 CFZP_FN CDims cdims(const CSpec &sp) {
   CDims d;
   d.V = sp.V; d.off[0] = 0; d.coff[0] = 0;
@@ -161,6 +165,7 @@ CFZP_FN CDims cdims(const CSpec &sp) {
   d.rP = d.rF + 5 * sp.V; d.m = d.rP + 2 * d.npp;
   // dt is bordered, collision slacks and rows (obstacles and pairs) are condensed, dead heading rows are left out
   d.nk = 7 * d.np + 8 * d.nchk + 7 * sp.V + 5 * d.np + 7 * (d.NI - sp.V) + 8 * d.nchk + 4 * sp.V + nfin;
+  if (jstruct_mode(sp)) d.nk -= 16 * d.nchk;
   return d;
 }
 CFZP_FN int veh_of_interval(const CDims &d, int I) { int a = 0; while (a + 1 < d.V && I >= d.off[a + 1]) ++a; return a; }
@@ -409,7 +414,35 @@ CFZC_PIECE void jt_nu(const CSpec &sp, const unsigned char *sel, const double *X
 // (assemble), which leaves a half-bandwidth of 51 whatever the number of obstacles.
 // With several vehicles the interval blocks are interleaved in time (interval t of vehicle 0, of vehicle 1, ...): the pair
 // rows couple the poses of the same (t, k) of two vehicles, which then sit (b - a) blocks apart.
+// Vehicle-major ordering of the joint plan's structured elimination: every vehicle's unknowns in one range, per interval
+// [continuity (initial rows) | pt0 | pt1 pt2 | 30 ODE rows | pt3 pt4 pt5], terminal rows last; no tube positions (condensed).  With the
+// steering rate of pt5 counted to the next separator: separator 0 = 14 unknowns at base, interior t = [base + 79 t + 14, + 64),
+// separator t = [base + 79 t - 1, + 15), the last separator = the steering rate and the terminal rows (cfz_jstruct.inl).
+CFZP_FN int build_order_vm(const CSpec &sp, int *posx, int *posc) {
+  const CDims d = cdims(sp);
+  int p = 0;
+  for (int a = 0; a < sp.V; ++a) {
+    for (int cc = 0; cc < 7; ++cc) posc[7 * a + cc] = p++;
+    for (int t = 0; t < sp.N[a]; ++t) {
+      const int i = d.off[a] + t;
+      if (t >= 1) for (int cc = 0; cc < 7; ++cc) posc[d.rC + 7 * (i - a - 1) + cc] = p++;
+      for (int k = 0; k < kPts; ++k) {
+        const int q = i * kPts + k;
+        if (k == 3) for (int kk = 0; kk < kPts; ++kk) for (int cc = 0; cc < 5; ++cc) posc[d.rO + 5 * (i * kPts + kk) + cc] = p++;
+        for (int cc = 0; cc < 7; ++cc) posx[7 * q + cc] = p++;
+        for (int r = 0; r < d.nr; ++r) { posx[d.sO + q * d.nr + r] = -1; posc[d.rR + q * d.nr + r] = -1; }
+      }
+    }
+    for (int cc = 0; cc < 4; ++cc) posc[d.rF + 5 * a + cc] = p++;
+    posc[d.rF + 5 * a + 4] = sp.has_final[a] ? p++ : -1;
+  }
+  for (int r = 0; r < 8 * d.nchk; ++r) { posx[d.sT + r] = -1; posc[d.rT + r] = -1; }
+  for (int r = 0; r < 2 * d.npp; ++r) { posx[d.sP + r] = -1; posc[d.rP + r] = -1; }
+  posx[d.iDt] = -1;
+  return p;
+}
 CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
+  if (jstruct_mode(sp)) return build_order_vm(sp, posx, posc);
   const CDims d = cdims(sp);
   int p = 0, nmax = 0;
   for (int a = 0; a < sp.V; ++a) nmax = sp.N[a] > nmax ? sp.N[a] : nmax;
@@ -445,6 +478,7 @@ CFZP_FN int build_order(const CSpec &sp, int *posx, int *posc) {
 // half-bandwidth: 51 within an interval block; with several vehicles the continuity rows reach back over the other vehicles'
 // blocks to the previous interval of their own, and the pair rows couple the poses of two vehicles
 CFZP_FN int half_bandwidth(const CSpec &sp, const int *posx, const int *posc) {
+  if (jstruct_mode(sp)) return kCB;  // within a vehicle; the pair blocks are kept beside the band
   const CDims d = cdims(sp);
   int kb = kCB;
   for (int a = 0; a < sp.V; ++a)
@@ -468,13 +502,15 @@ CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if 
 
 struct CWork {
   double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *rhs, *rhs2, *bord, *ab, *sig, *cond, *condp, *sw;
+  double *pm, *condt;  // joint structured elimination: the condensed pair blocks (36 per pair point), the tube rows' gradient, D, t (5 per row)
   int *posx, *posc, *ipiv;
   unsigned char *sel;
 };
 CFZP_FN size_t struct_doubles(const CSpec &sp);  // cfz_struct.inl: the structured elimination's own arrays (single plans)
+CFZP_FN size_t jstruct_doubles(const CSpec &sp);  // cfz_jstruct.inl: ... of the joint plans
 CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
   const CDims d = cdims(sp);
-  return struct_doubles(sp) + (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
+  return struct_doubles(sp) + jstruct_doubles(sp) + (jstruct_mode(sp) ? (size_t)d.npp * 36 + (size_t)d.nchk * 40 : 0) + (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
          (size_t)(d.n + d.m + d.nk + 2) / 2 + (size_t)(d.np * sp.n_obs + d.npp + 7) / 8 + 64;
 }
 CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
@@ -486,6 +522,8 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
   w.rhs = p; p += d.nk; w.rhs2 = p; p += d.nk; w.bord = p; p += d.nk; w.ab = p; p += (size_t)d.nk * (3 * kb + 1);
   w.cond = p; p += (size_t)d.np * d.nr * 5;  // per obstacle row: gradient (3), D, t (assemble)
   w.condp = p; p += (size_t)d.npp * 16;     // per pair row: gradient (6), D, t
+  w.pm = nullptr; w.condt = nullptr;
+  if (jstruct_mode(sp)) { w.pm = p; p += (size_t)d.npp * 36; w.condt = p; p += (size_t)d.nchk * 40; }
   w.posx = reinterpret_cast<int *>(p); w.posc = w.posx + d.n; w.ipiv = w.posc + d.m;
   p += (size_t)(d.n + d.m + d.nk + 2) / 2;
   w.sel = reinterpret_cast<unsigned char *>(p);
@@ -600,6 +638,23 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
     const double cs = cos(X[b + 2]), sn = sin(X[b + 2]);
     const double *cb = chk_cell(sp, d, t, 0), *cf = chk_cell(sp, d, t, 1);
     double curv = 0.0;
+    if (jstruct_mode(sp)) {
+      // condensed like the collision rows (the slack enters its row with +1):  S ds + dnu = -r_s,  g'dp + ds - reg_dual dnu = -c'
+      //   =>  dnu = D (g'dp + t),  ds = -(r_s + dnu) / S,   D = 1 / (1/S + reg_dual),  t = c' - r_s / S
+      double P3[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, rp[3] = {0, 0, 0};
+      for (int rr = 0; rr < 8; ++rr) {
+        const double *cc_ = rr < 4 ? cb : cf; const int q_ = rr & 3;
+        const double gr[3] = {cc_[2 * q_], cc_[2 * q_ + 1], rr < 4 ? 0.0 : sp.wb * (-cc_[2 * q_] * sn + cc_[2 * q_ + 1] * cs)};
+        const double S = w.sig[s + rr] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), tt = w.c[r + rr] - prox * sp.reg_dual * nu[r + rr] - w.r1[s + rr] / S;
+        double *cd = w.condt + (size_t)(8 * t + rr) * 5;
+        cd[0] = gr[0]; cd[1] = gr[1]; cd[2] = gr[2]; cd[3] = D; cd[4] = tt;
+        for (int a = 0; a < 3; ++a) { rp[a] += D * tt * gr[a]; for (int c2 = a; c2 < 3; ++c2) P3[a][c2] += D * gr[a] * gr[c2]; }
+        if (rr >= 4) curv += nu[r + rr] * sp.wb * (-cc_[2 * q_] * cs - cc_[2 * q_ + 1] * sn);
+      }
+      for (int a = 0; a < 3; ++a) { w.rhs[px[b + a]] -= rp[a]; for (int c2 = a; c2 < 3; ++c2) put(Bd, px[b + a], px[b + c2], P3[a][c2]); }
+      bnd(Bd, px[b + 2], px[b + 2]) += curv;
+      continue;
+    }
     for (int rr = 0; rr < 4; ++rr) {
       put(Bd, pc[r + rr], px[b], cb[2 * rr]); put(Bd, pc[r + rr], px[b + 1], cb[2 * rr + 1]); put(Bd, pc[r + rr], px[s + rr], 1.0);
       put(Bd, pc[r + 4 + rr], px[b], cf[2 * rr]); put(Bd, pc[r + 4 + rr], px[b + 1], cf[2 * rr + 1]);
@@ -632,6 +687,14 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
         double *cd = w.condp + (size_t)(2 * pp + rr) * 8;
         for (int a = 0; a < 6; ++a) cd[a] = gr[a];
         cd[6] = D; cd[7] = t;
+        if (w.pm != nullptr) {  // joint structured elimination: the block stays beside the band (cfz_jstruct.inl), complete and symmetric
+          double *pm = w.pm + (size_t)pp * 36;
+          for (int a = 0; a < 6; ++a) {
+            w.rhs[at[a]] -= D * t * gr[a];
+            for (int c2 = 0; c2 < 6; ++c2) { const double v = D * gr[a] * gr[c2] + nr_ * H[a < c2 ? a : c2][a < c2 ? c2 : a]; pm[6 * a + c2] = rr == 0 ? v : pm[6 * a + c2] + v; }
+          }
+          continue;
+        }
         for (int a = 0; a < 6; ++a) {
           w.rhs[at[a]] -= D * t * gr[a];
           for (int c2 = a; c2 < 6; ++c2) { const double v = D * gr[a] * gr[c2] + nr_ * H[a][c2]; if (v != 0.0) put(Bd, at[a], at[c2], v); }
@@ -1478,6 +1541,7 @@ CFZC_PIECE bool refresh_working_set(const CSpec &sp, const CWork &w, double *X, 
 // (MODE 1, one wavefront per single plan with the elimination in an LDS window, was retired in round 4: see cfz_planning.hip.)
 }  // namespace cfzc
 #include "cfz_struct.inl"
+#include "cfz_jstruct.inl"
 namespace cfzc {
 
 template <int MODE>
@@ -1491,8 +1555,11 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   CFZP_SYNC();
   // no_prox bit 2: the structured elimination of cfz_struct.inl (single-vehicle plans in the ordering of half-bandwidth kCB)
   const bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB;
+  const bool jstructured = jstruct_mode(sp);  // (the caller sized the slab with kb = kCB: half_bandwidth())
   SWork SW = {};
+  JWork JW = {};
   if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); }
+  if (jstructured) { JW = jstruct_carve(sp, w.sw); jstruct_setup(sp, d, w, JW); }
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
   CFZP_SYNC();
   CFZP_LANE_FOR(q, 0, d.np - 1) {
@@ -1523,7 +1590,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   double delta_floor = 0.0; int delta_retry = 0;  // a failed line search is repeated with a larger perturbation (below)
   bool mu_forced = false;  // the last iteration ended without a step and lowered mu instead
   int status = 1, iter = 0;
-  long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
+  long long tk[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
     ta = tick();
     // rows of a changed working set belong to another problem: the filter starts afresh (as in the MPC step)
@@ -1591,6 +1658,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
       bool solved = false;
       if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
+      if (jstructured) { fail = jstruct_solve(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];
@@ -1622,6 +1690,12 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
           const double S = w.sig[d.sO + r] + delta + sp.reg_primal;
           const double dn = cd[3] * (cd[0] * dp[0] + cd[1] * dp[1] + cd[2] * dp[2] + cd[4]);
           w.dnu[d.rR + r] = dn; w.dx[d.sO + r] = (dn - w.r1[d.sO + r]) / S;
+        }
+        if (w.condt != nullptr) CFZP_LANE_FOR(r, 0, 8 * d.nchk - 1) {  // the condensed tube rows, from the pose step of their checkpoint
+          const double *cd = w.condt + (size_t)r * 5, *dp = w.dx + 7 * chk_point(sp, d, r / 8);
+          const double S = w.sig[d.sT + r] + delta + sp.reg_primal;
+          const double dn = cd[3] * (cd[0] * dp[0] + cd[1] * dp[1] + cd[2] * dp[2] + cd[4]);
+          w.dnu[d.rT + r] = dn; w.dx[d.sT + r] = -(w.r1[d.sT + r] + dn) / S;
         }
         CFZP_LANE_FOR(r, 0, 2 * d.npp - 1) {  // pair rows: from the pose steps of both vehicles
           int e = 0;
@@ -1754,7 +1828,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   }
   CFZP_SYNC();
   tk[5] = tick() - t0;
-  for (int i = 0; i < 9; ++i) out_d[3 + i] = (double)tk[i];
+  for (int i = 0; i < 17; ++i) out_d[3 + i] = (double)tk[i];
   CFZP_LANE_FOR(i, 0, d.iDt) X[i] = w.x[i];
   out_i[0] = iter; out_i[1] = status;
   out_d[0] = objective(sp, w.x); out_d[1] = err0; out_d[2] = mu;

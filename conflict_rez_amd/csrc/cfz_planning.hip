@@ -439,6 +439,9 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
       const double *t = od.data() + (size_t)cfzc::kOutD * b + 3;
       fprintf(stderr, "cfz_colloc[%d]: %d vehicle(s), half-bandwidth %d, %d iterations, evaluate %.2f assemble %.2f factor %.2f substitute %.2f line search %.2f total %.2f ms (factor: panel / pivot search %.2f test / swap %.2f trailing columns / update %.2f)\n",
               b, specs[b].V, kbs[b], oi[2 * b], t[0] * 1e-5, t[1] * 1e-5, t[2] * 1e-5, t[3] * 1e-5, t[4] * 1e-5, t[5] * 1e-5, t[6] * 1e-5, t[7] * 1e-5, t[8] * 1e-5);
+      if (cfzc::jstruct_mode(specs[b]))
+        fprintf(stderr, "cfz_colloc[%d]: joint structured elimination: interiors %.2f | C'W, pair blocks %.2f capacitance matrices %.2f their solves %.2f Z %.2f separator blocks %.2f Schur complements %.2f | recursion %.2f back-substitution %.2f ms\n",
+                b, t[6] * 1e-5, t[9] * 1e-5, t[10] * 1e-5, t[11] * 1e-5, t[12] * 1e-5, t[13] * 1e-5, t[14] * 1e-5, t[15] * 1e-5, t[16] * 1e-5);
     }
   }
   return 0;

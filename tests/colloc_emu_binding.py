@@ -24,7 +24,7 @@ class CSpec(C.Structure):
 
 def build(force=False):
     srcs = [os.path.join(ROOT, "tests", "emu", "cfz_colloc_emu.cpp")] + [os.path.join(ROOT, "conflict_rez_amd", "csrc", f)
-                                                                         for f in ("cfz_colloc.inl", "cfz_struct.inl", "cfz_plan.inl", "cfz_solver.inl")]
+                                                                         for f in ("cfz_colloc.inl", "cfz_struct.inl", "cfz_jstruct.inl", "cfz_plan.inl", "cfz_solver.inl")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
@@ -131,6 +131,6 @@ def solve(nlp, X0, opt):
     """X0: points and dt (7 np + 1) -> dict(X, iters, status, f, err, mu)."""
     s, keep = make_spec(nlp, opt)
     X = np.array(X0[: nlp.iDt + 1], dtype=np.float64)
-    oi, od = np.zeros(2, np.int32), np.zeros(12)
+    oi, od = np.zeros(2, np.int32), np.zeros(20)
     assert lib().cfzc_emu_solve(C.byref(s), _p(X), _p(oi), _p(od)) == 0
     return dict(X=X, iters=int(oi[0]), status=int(oi[1]), f=od[0], err=od[1], mu=od[2])
