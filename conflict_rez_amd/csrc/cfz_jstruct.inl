@@ -35,8 +35,8 @@ CFZP_FN int jycol(int b, int q) { return 32 * (b >> 1) + kJC * (b & 1) + q; }
 constexpr int kJYrhs = 60;
 
 struct JWork {
-  double *W, *Cc, *CW, *Mt, *Cap, *Yh, *Y, *Z, *Ds, *Us, *Zs, *xs, *aug, *flag;
-  int *cl, *bs;
+  double *W, *Cc, *CW, *Mt, *Z, *zt, *Ds, *Us, *Zs, *xs, *aug, *flag;
+  int *cl, *bs, *ordl, *meta, *cmask;
   int Nmax, NI;
 };
 
@@ -46,8 +46,8 @@ CFZP_FN size_t jstruct_doubles(const CSpec &sp) {
   size_t NI = 0;
   for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
   const size_t Nm = jstruct_nmax(sp);
-  return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + 4 * kJB * kJB) + (Nm + 1) * (kJB * kJB + 2 * kJB * kJU + 2 * kJB) +
-         (size_t)kJB * (kJB + 64) + 8 + (NI * 16 + kMaxVeh + 3) / 2 + 16;
+  return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + kJB * kJB + 2 * kJB) + (Nm + 1) * (kJB * kJB + 2 * kJB * kJU + 2 * kJB) +
+         (size_t)kJB * (kJB + 64) + 2 * kJB * kJB + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
 }
 CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   JWork s;
@@ -56,11 +56,11 @@ CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   const size_t Nm = jstruct_nmax(sp);
   s.Nmax = (int)Nm; s.NI = (int)NI;
   s.W = p; p += NI * kSI * kJR; s.Cc = p; p += NI * kSI * kJC; s.CW = p; p += NI * kJC * kJR;
-  s.Mt = p; p += Nm * kJMt; s.Cap = p; p += Nm * kJB * kJB; s.Yh = p; p += Nm * kJB * kJB; s.Y = p; p += Nm * kJB * kJB; s.Z = p; p += Nm * kJB * kJB;
+  s.Mt = p; p += Nm * kJMt; s.Z = p; p += Nm * kJB * kJB; s.zt = p; p += Nm * 2 * kJB;
   s.Ds = p; p += (Nm + 1) * kJB * kJB; s.Us = p; p += (Nm + 1) * kJB * kJU; s.Zs = p; p += (Nm + 1) * kJB * kJU; s.xs = p; p += (Nm + 1) * 2 * kJB;
-  s.aug = p; p += (size_t)kJB * (kJB + 64);
+  s.aug = p; p += (size_t)kJB * (kJB + 64) + 2 * kJB * kJB;  // (the CPU build's staging: one block with its right-hand sides, a capacitance matrix and its right-hand sides)
   s.flag = p; p += 8;
-  s.cl = reinterpret_cast<int *>(p); s.bs = s.cl + NI * 16;
+  s.cl = reinterpret_cast<int *>(p); s.bs = s.cl + NI * 16; s.ordl = s.bs + kMaxVeh; s.meta = s.ordl + (Nm + 1) * kJB; s.cmask = s.meta + 64;
   return s;
 }
 
@@ -71,7 +71,19 @@ CFZP_FN int jsep_size(const CSpec &sp, int a, int i) { return i == 0 ? 14 : (i <
 // cl[16 it + q], it = off[a] + t: q < 7 the positions of pt0 of the interval, 7 <= q < 14 the coupled positions of separator t + 1
 // (-1 = none); flag[1] != 0: the ordering is not the one this file assumes (the caller falls back on nothing: status 3)
 CFZP_FN void jstruct_setup(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s) {
-  CFZP_LANE_FOR(one, 0, 0) { s.flag[1] = 0.0; for (int a = 0; a < sp.V; ++a) s.bs[a] = w.posc[7 * a]; }
+  CFZP_LANE_FOR(one, 0, 0) {
+    s.flag[1] = 0.0;
+    for (int a = 0; a < sp.V; ++a) { s.bs[a] = w.posc[7 * a]; if (sp.N[a] > 255) s.flag[1] = 1.0; }
+    // what the device functions read instead of the specification: N, first positions, terminal headings, the pair of two vehicles, ...
+    int *m = s.meta;
+    for (int a = 0; a < kMaxVeh; ++a) { m[a] = a < sp.V ? sp.N[a] : 0; m[4 + a] = a < sp.V ? w.posc[7 * a] : 0; m[8 + a] = a < sp.V ? (sp.has_final[a] ? 1 : 0) : 0; }
+    for (int e = 0; e < 16; ++e) m[12 + e] = -1;
+    for (int e = 0; e < sp.n_pairs; ++e) { m[12 + 4 * sp.pair_a[e] + sp.pair_b[e]] = e; m[12 + 4 * sp.pair_b[e] + sp.pair_a[e]] = e; }
+    for (int e = 0; e <= kMaxPairs; ++e) m[28 + e] = d.poff[e];
+    m[35] = sp.V;
+    for (int a = 0; a <= kMaxVeh; ++a) m[36 + a] = d.off[a];
+    m[41] = d.nk; m[42] = s.Nmax;
+  }
   CFZP_SYNC();
   CFZP_LANE_FOR(it, 0, d.NI - 1) {
     const int a = veh_of_interval(d, it), t = it - d.off[a];
@@ -79,12 +91,19 @@ CFZP_FN void jstruct_setup(const CSpec &sp, const CDims &d, const CWork &w, cons
     for (int c = 0; c < 7; ++c) cl[c] = w.posx[7 * (kPts * it) + c];
     int q = 7;
     cl[q++] = w.posx[7 * (kPts * it + 5) + 6];
+    // cl[7 + be] is local unknown be of separator t + 1 (or -1): the steering rate, then six continuity rows -- at the end the terminal
+    // rows of v, delta, a (the steering rate's own row does not touch the interior) and the heading row
     if (t + 1 < sp.N[a]) for (int c = 0; c < 6; ++c) cl[q++] = w.posc[d.rC + 7 * (it - a) + c];
     else {
       for (int c = 0; c < 3; ++c) cl[q++] = w.posc[d.rF + 5 * a + c];
-      if (sp.has_final[a]) cl[q++] = w.posc[d.rF + 5 * a + 4];
+      cl[q++] = -1;
+      cl[q++] = sp.has_final[a] ? w.posc[d.rF + 5 * a + 4] : -1;
     }
     while (q < 16) cl[q++] = -1;
+    for (int be = 0; be < 7; ++be) if (cl[7 + be] >= 0 && cl[7 + be] != w.posx[7 * (kPts * it + 5) + 6] + be) s.flag[1] = 1.0;
+    int cm = 0;
+    for (int c = 0; c < kJC; ++c) if (cl[c] >= 0) cm |= 1 << c;
+    s.cmask[it] = cm;
     // the layout this file computes positions from
     const int pi = w.posc[7 * a] + 79 * t + 14;
     bool ok = w.posx[7 * (kPts * it + 1)] == pi && w.posx[7 * (kPts * it + 5) + 5] == pi + 63 && cl[7] == pi + 64 && cl[0] == pi - 7;
@@ -133,6 +152,352 @@ __device__ __attribute__((noinline)) int jstruct_block(const cfzb::glb_f64 *A, c
   for (int q = 0; q < 32; ++q) Z[q * kJB + ord] = a[kJB + q];
   return 0;
 }
+
+// C'W of one interior on the matrix cores: (14 x 64) (64 x 32) as two 16 x 16 tiles of v_mfma_f64_16x16x4_f64, sixteen k-steps
+// (operands: lane l holds A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15]; result register r of lane l is row (l >> 4) + 4 r,
+// column l & 15).  48 loads, 32 matrix instructions: the 434 dot products of length 64 took 1.3 ms per factorisation as a loop.
+typedef double jstruct_v4 __attribute__((ext_vector_type(4)));
+__device__ __attribute__((noinline)) void jstruct_cw(const cfzb::glb_f64 *C, const cfzb::glb_f64 *W, cfzb::glb_f64 *CW) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  jstruct_v4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double av[16], b0[16], b1[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    av[kk] = lo < kJC ? C[lo * kSI + 4 * kk + hi] : 0.0;
+    b0[kk] = W[lo * kSI + 4 * kk + hi]; b1[kk] = W[(16 + lo) * kSI + 4 * kk + hi];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], b0[kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], b1[kk], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int al = hi + 4 * r;
+    if (al < kJC) { CW[al * kJR + lo] = acc0[r]; CW[al * kJR + 16 + lo] = acc1[r]; }
+  }
+}
+// The capacitance system of interval index t, one half of its right-hand sides: (I + M G) Z = M E'K^-1 [C | b]  (Z = M Y without forming
+// Y = (I + G M)^-1 E'K^-1 [C | b]: M (I + G M)^-1 = (I + M G)^-1 M).  Row (a, i) of matrix and right-hand sides is built in the registers of
+// lane 16 a + i from M's three entries per vehicle for that row and the rows jprow(.) of the interiors' solutions W; nothing but Z is stored.
+// h = 0: the coupling columns of vehicles 0 and 1; h = 1: of vehicles 2 and 3, then b1, b2.
+__device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt, const cfzb::glb_f64 *Wall, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Zt) {
+  const int lane = threadIdx.x & 63, va = lane >> 4, i = lane & 15, V = mt[35];
+  const bool real = va < V && t < mt[va] && i < 15;
+  const int kk = real ? i / 3 : 0, ii = real ? i - 3 * kk : 0;
+  const int pr0 = jprow(3 * kk), pr1 = pr0 + 1, pr2 = pr0 + 2;
+  // M's row of this lane, read from the pair blocks themselves: against another vehicle the cross block of their pair; against its own
+  // vehicle the sum of the diagonal blocks of all its pairs
+  double m[4][3], dg[3] = {0.0, 0.0, 0.0};
+  const cfzb::glb_f64 *Wb[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const bool part = b < V && t < mt[b];
+    Wb[b] = Wall + (size_t)(part ? mt[36 + b] + t : 0) * kSI * kJR;
+    const int e = (real && part && b != va) ? mt[12 + 4 * va + b] : -1;
+    const cfzb::glb_f64 *pe = pm + (size_t)(e >= 0 ? mt[28 + e] + kPts * t + kk + 1 : 0) * 36 + (va < b ? 6 * ii : 6 * (3 + ii));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      m[b][c] = e >= 0 ? pe[va < b ? 3 + c : c] : 0.0;
+      dg[c] += e >= 0 ? pe[va < b ? c : 3 + c] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (b == va) m[b][c] = dg[c];
+  double a[kJB + 32];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double v = lane == 16 * b + j ? 1.0 : 0.0;
+      if (j < 15) v += m[b][0] * Wb[b][(16 + j) * kSI + pr0] + m[b][1] * Wb[b][(16 + j) * kSI + pr1] + m[b][2] * Wb[b][(16 + j) * kSI + pr2];
+      a[16 * b + j] = v;
+    }
+  }
+#pragma unroll
+  for (int lc = 0; lc < 28; ++lc) {
+    const int bl = lc / kJC, q = lc % kJC;
+    const cfzb::glb_f64 *Wv = h ? Wb[2 + bl] : Wb[bl];
+    const double m0 = h ? m[2 + bl][0] : m[bl][0], m1 = h ? m[2 + bl][1] : m[bl][1], m2 = h ? m[2 + bl][2] : m[bl][2];
+    a[kJB + lc] = m0 * Wv[q * kSI + pr0] + m1 * Wv[q * kSI + pr1] + m2 * Wv[q * kSI + pr2];
+  }
+#pragma unroll
+  for (int sr = 0; sr < 2; ++sr) {
+    double v = 0.0;
+    if (h) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v += m[b][0] * Wb[b][(14 + sr) * kSI + pr0] + m[b][1] * Wb[b][(14 + sr) * kSI + pr1] + m[b][2] * Wb[b][(14 + sr) * kSI + pr2];
+    }
+    a[kJB + 28 + sr] = v;
+  }
+  a[kJB + 30] = 0.0; a[kJB + 31] = 0.0;
+  int ord;
+  if (wave_lu_regs<kJB, 32>(a, lane, ord)) return 1;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) Zt[(32 * h + q) * kJB + ord] = a[kJB + q];
+  return 0;
+}
+
+// meta (JWork::meta, filled by jstruct_setup): [0..3] N, [4..7] first position, [8..11] terminal heading, [12..27] pair index of two vehicles
+// (-1: none), [28..34] first pair point of a pair, [35] V, [36..40] first interval of a vehicle, [41] band unknowns, [42] the longest plan
+__device__ __forceinline__ int jsep_size_m(const cfzb::glb_i32 *m, int a, int i) { return i == 0 ? 14 : (i < m[a] ? 15 : 5 + m[8 + a]); }
+// Separator block i before the Schur complements, a wavefront per block, lane = row 16 a + la: band entries of the vehicle's own separator,
+// the pair blocks of pt0 (diagonal and off-diagonal parts), identity padding; right-hand sides: zero coupling columns, b1, b2.
+__device__ __attribute__((noinline)) void jstruct_sep_base(int i, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, const cfzb::glb_f64 *pm,
+                                                           const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Di, cfzb::glb_f64 *Ui) {
+  const int lane = threadIdx.x & 63, a = lane >> 4, la = lane & 15, V = m[35];
+  const bool rowok = a < V && i <= m[a] && la < jsep_size_m(m, a, i);
+  const int p0 = i == 0 ? 7 : 8, ps = i == 0 ? m[4 + a] : m[4 + a] + 79 * i - 1, r = ps + la;
+  const bool rpose = rowok && i < m[a] && la >= p0 && la < p0 + 3;
+  double own[16];  // the vehicle's own columns
+#pragma unroll
+  for (int lb = 0; lb < 16; ++lb) {
+    const int c = ps + lb, dd = r - c;
+    own[lb] = (rowok && lb < jsep_size_m(m, a, i) && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
+  }
+  double x3[4][3];  // the pair blocks' row of this lane: [other vehicle][column], and the diagonal parts summed into x3[a]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { x3[b][0] = 0.0; x3[b][1] = 0.0; x3[b][2] = 0.0; }
+  if (rpose) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int e = b < V && b != a ? m[12 + 4 * a + b] : -1;
+      if (e >= 0 && i < m[b]) {
+        const cfzb::glb_f64 *pe = pm + (size_t)(m[28 + e] + kPts * i) * 36;
+        const int ro = a < b ? 6 * (la - p0) : 6 * (3 + la - p0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double cross = pe[ro + (a < b ? 3 + c : c)], diag = pe[ro + (a < b ? c : 3 + c)];
+          x3[b][c] = cross;
+#pragma unroll
+          for (int b2_ = 0; b2_ < 4; ++b2_) if (b2_ == a) x3[b2_][c] += diag;  // (static register indices)
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const bool colveh = b < V && i <= m[b];
+#pragma unroll
+    for (int lb = 0; lb < 16; ++lb) {
+      double v = lane == 16 * b + lb ? 1.0 : 0.0;
+      if (rowok) {
+        v = b == a ? own[lb] : 0.0;
+        if (!(colveh && lb < jsep_size_m(m, b, i))) v = 0.0;
+        else if (rpose && i < m[b] && lb >= p0 && lb < p0 + 3) v += lb == p0 ? x3[b][0] : (lb == p0 + 1 ? x3[b][1] : x3[b][2]);
+      }
+      Di[(16 * b + lb) * kJB + lane] = v;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 28; ++q) Ui[q * kJB + lane] = 0.0;
+  Ui[28 * kJB + lane] = rowok ? b1[r] : 0.0; Ui[29 * kJB + lane] = rowok ? b2[r] : 0.0;
+}
+// Schur complements of the interiors of interval index t onto separator blocks t and t + 1, a wavefront per t, on the matrix cores: per
+// vehicle a  T = (C_a'K_a^-1 E) Z[(a, .), :]  is (14 x 15) (15 x 62): four k-steps of four 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (the
+// operands' 16th row / column are zero: the spare column of W, the padding row of Z); each lane then adds its results T - [own column] C'W
+// to the entries they belong to (every entry has one owner; blocks t's pt0 entries and block t + 1's right-coupled entries are disjoint).
+__device__ __attribute__((noinline)) void jstruct_schur(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cmask, const cfzb::glb_f64 *CWall, const cfzb::glb_f64 *Zt,
+                                                        cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, V = m[35], p0 = t == 0 ? 7 : 8;
+  cfzb::glb_f64 *D0 = Ds + (size_t)t * kJB * kJB, *D1 = D0 + kJB * kJB, *U0 = Us + (size_t)t * kJB * kJU, *U1 = U0 + kJB * kJU;
+  int cm[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cm[b] = (b < V && t < m[b]) ? cmask[m[36 + b] + t] : 0;
+  for (int a = 0; a < V; ++a) {
+    if (t >= m[a]) continue;
+    const cfzb::glb_f64 *CW = CWall + (size_t)(m[36 + a] + t) * kJC * kJR;
+    const int cma = cmask[m[36 + a] + t];
+    jstruct_v4 acc[4];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) acc[tl] = jstruct_v4{0.0, 0.0, 0.0, 0.0};
+    double av[4], bv[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      av[ks] = lo < kJC ? CW[lo * kJR + 16 + 4 * ks + hi] : 0.0;
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) bv[ks][tl] = Zt[(16 * tl + lo) * kJB + 16 * a + 4 * ks + hi];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks][tl], acc[tl], 0, 0, 0);
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+      const int col = 16 * tl + lo, hh = col >> 5, lc = col & 31;
+      const bool isrhs = col >= kJYrhs && col < kJYrhs + 2, iscol = col < kJYrhs && lc < 2 * kJC;
+      const int b = iscol ? 2 * hh + lc / kJC : a, be = iscol ? lc % kJC : 0;
+      const int cmb = b == 0 ? cm[0] : b == 1 ? cm[1] : b == 2 ? cm[2] : cm[3];
+      const bool colok = isrhs || (iscol && ((cmb >> be) & 1));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int al = hi + 4 * r;
+        if (al >= kJC || !colok || !((cma >> al) & 1)) continue;
+        const bool aleft = al < 7;
+        const int ra = 16 * a + (aleft ? p0 + al : al - 7);
+        if (isrhs) {
+          const double val = acc[tl][r] - CW[al * kJR + 14 + col - kJYrhs];
+          (aleft ? U0 : U1)[(28 + col - kJYrhs) * kJB + ra] += val;
+          continue;
+        }
+        const bool bleft = be < 7;
+        if (!aleft && bleft) continue;  // (the transpose of a block that is kept)
+        const double val = acc[tl][r] - (b == a ? CW[al * kJR + be] : 0.0);
+        const int cb = 16 * b + (bleft ? p0 + be : be - 7);
+        if (aleft && bleft) D0[cb * kJB + ra] += val;
+        else if (!aleft && !bleft) D1[cb * kJB + ra] += val;
+        else U0[(7 * b + be - 7) * kJB + ra] = val;
+      }
+    }
+  }
+}
+
+// back-substitution, a wavefront per task, lane = row, every load of a task issued before the first is used:
+// z = M y of interval index t:  Z[:, b] - Z[:, coupling columns] s  (s: the separators' solutions, already at their positions in b1, b2)
+__device__ __attribute__((noinline)) void jstruct_zt(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *Zt, const cfzb::glb_f64 *b1,
+                                                     const cfzb::glb_f64 *b2, cfzb::glb_f64 *zt) {
+  const int lane = threadIdx.x & 63, V = m[35];
+  double z1 = Zt[kJYrhs * kJB + lane], z2 = Zt[(kJYrhs + 1) * kJB + lane];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b >= V || t >= m[b]) continue;
+    const cfzb::glb_i32 *clb = cl + 16 * (m[36 + b] + t);
+#pragma unroll
+    for (int q = 0; q < kJC; ++q) {
+      const int c = clb[q];
+      const double zc = Zt[jycol(b, q) * kJB + lane];
+      z1 -= zc * (c >= 0 ? b1[c] : 0.0); z2 -= zc * (c >= 0 ? b2[c] : 0.0);
+    }
+  }
+  zt[lane] = z1; zt[kJB + lane] = z2;
+}
+// the interior of (vehicle a, interval t):  x = W[:, b] - W[:, C] s - W[:, E] z
+__device__ __attribute__((noinline)) void jstruct_back(int a, int pos0, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *W, const cfzb::glb_f64 *zt, cfzb::glb_f64 *b1,
+                                                       cfzb::glb_f64 *b2) {
+  const int lane = threadIdx.x & 63;
+  double y1 = W[14 * kSI + lane], y2 = W[15 * kSI + lane];
+#pragma unroll
+  for (int q = 0; q < kJC; ++q) {
+    const int c = cl[q];
+    const double wq = W[q * kSI + lane];
+    y1 -= wq * (c >= 0 ? b1[c] : 0.0); y2 -= wq * (c >= 0 ? b2[c] : 0.0);
+  }
+#pragma unroll
+  for (int j = 0; j < 15; ++j) { const double wq = W[(16 + j) * kSI + lane]; y1 -= wq * zt[16 * a + j]; y2 -= wq * zt[kJB + 16 * a + j]; }
+  b1[pos0 + lane] = y1; b2[pos0 + lane] = y2;  // (interior positions are read by nobody in this phase)
+}
+
+// The recursion over the joint separators, one wavefront per direction, everything between two blocks in registers or in words of
+// global memory that the SAME lane wrote (no hand-off between lanes through memory, no fence): side 0 eliminates blocks i0 .. i1 - 1
+// downwards (block i into i + 1), side 1 blocks i0 .. i1 + 1 upwards (block j into j - 1).  Block i: D_i (column-major), right-hand sides
+// [U_i | b1 b2] with U_i = the coupling of block i's pt0 rows (row 16 a + p0 + c) with block i + 1's rows 16 b + be (column 7 b + be).
+// Z (lane = the row the lane's pivot left it with: ordl) is kept lane-major for the back-substitution.  nv: N[a] packed, 8 bits each.
+__device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1, unsigned nvp, int V, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us,
+                                                       cfzb::glb_f64 *Zl, cfzb::glb_i32 *ordl) {
+  const int lane = threadIdx.x & 63, va = lane >> 4, la = lane & 15;
+  const int cu = la < 7 ? 7 * va + la : -1;  // this lane's row as a right-coupled row of its block: its column of U
+  for (int i = i0; side ? i > i1 : i < i1; i += side ? -1 : 1) {
+    const cfzb::glb_f64 *Di = Ds + (size_t)i * kJB * kJB, *Ui = Us + (size_t)i * kJB * kJU;
+    const int ip = side ? i - 1 : i;                 // the coupling block involved: U_ip couples blocks ip and ip + 1
+    const int p0 = ip == 0 ? 7 : 8;                  // pt0's first local row in block ip
+    const cfzb::glb_f64 *Uc = Us + (size_t)ip * kJB * kJU;
+    double a[kJB + 32];
+#pragma unroll
+    for (int j = 0; j < kJB; ++j) a[j] = Di[j * kJB + lane];
+    if (side == 0) {
+#pragma unroll
+      for (int q = 0; q < 30; ++q) a[kJB + q] = Ui[q * kJB + lane];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 28; ++q) a[kJB + q] = cu >= 0 ? Uc[cu * kJB + 16 * (q / 7) + p0 + (q % 7)] : 0.0;  // U_{i-1}' (zero where a vehicle has no interior i - 1)
+      a[kJB + 28] = Ui[28 * kJB + lane]; a[kJB + 29] = Ui[29 * kJB + lane];
+    }
+    a[kJB + 30] = 0.0; a[kJB + 31] = 0.0;
+    int ord;
+    if (wave_lu_regs<kJB, 32>(a, lane, ord)) return 1;
+    cfzb::glb_f64 *Zi = Zl + (size_t)i * kJB * kJU;
+#pragma unroll
+    for (int q = 0; q < 30; ++q) Zi[q * kJB + lane] = a[kJB + q];
+    ordl[i * kJB + lane] = ord;
+    // the neighbour block's update: acc[q] = sum over the coupled rows r of this block of U[r, this lane's row there] Z[r, q]
+    double acc[30];
+#pragma unroll
+    for (int q = 0; q < 30; ++q) acc[q] = 0.0;
+    if (side == 0) {
+      for (int b = 0; b < V; ++b) {
+        if (i >= (int)((nvp >> (8 * b)) & 255u)) continue;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          const int r = 16 * b + p0 + c, lk = (int)__builtin_ctzll(__ballot(ord == r));
+          const double u = cu >= 0 ? Uc[cu * kJB + r] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 30; ++q) acc[q] += u * struct_lane_get(a[kJB + q], lk);
+        }
+      }
+      if (cu >= 0) {
+        cfzb::glb_f64 *Dn = Ds + (size_t)(i + 1) * kJB * kJB, *Un = Us + (size_t)(i + 1) * kJB * kJU;
+#pragma unroll
+        for (int q = 0; q < 28; ++q) Dn[(16 * (q / 7) + (q % 7)) * kJB + lane] -= acc[q];
+        Un[28 * kJB + lane] -= acc[28]; Un[29 * kJB + lane] -= acc[29];
+      }
+    } else {
+      const bool isl = la >= p0 && la < p0 + 7 && ip < (int)((nvp >> (8 * va)) & 255u);  // this lane's row is a pt0 row of block i - 1
+      for (int b = 0; b < V; ++b) {
+        if (ip >= (int)((nvp >> (8 * b)) & 255u)) continue;
+#pragma unroll
+        for (int be = 0; be < 7; ++be) {
+          const int lk = (int)__builtin_ctzll(__ballot(ord == 16 * b + be));
+          const double u = isl ? Uc[(7 * b + be) * kJB + lane] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 30; ++q) acc[q] += u * struct_lane_get(a[kJB + q], lk);
+        }
+      }
+      if (isl) {
+        cfzb::glb_f64 *Dn = Ds + (size_t)ip * kJB * kJB, *Un = Us + (size_t)ip * kJB * kJU;
+#pragma unroll
+        for (int q = 0; q < 28; ++q) Dn[(16 * (q / 7) + p0 + (q % 7)) * kJB + lane] -= acc[q];
+        Un[28 * kJB + lane] -= acc[28]; Un[29 * kJB + lane] -= acc[29];
+      }
+    }
+  }
+  return 0;
+}
+// the middle block (both neighbours folded in) and the back-substitution outwards: side 0 blocks mid - 1 .. 0, side 1 blocks mid + 1 .. Nm;
+// xs[i][s][row] receives the solutions.  Side 1 takes x_mid from xs (written by side 0 before a workgroup barrier: `phase`)
+__device__ __attribute__((noinline)) int jstruct_chain_mid(int mid, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us, cfzb::glb_f64 *xs) {
+  const int lane = threadIdx.x & 63;
+  const cfzb::glb_f64 *Di = Ds + (size_t)mid * kJB * kJB, *Ui = Us + (size_t)mid * kJB * kJU;
+  double a[kJB + 2];
+#pragma unroll
+  for (int j = 0; j < kJB; ++j) a[j] = Di[j * kJB + lane];
+  a[kJB] = Ui[28 * kJB + lane]; a[kJB + 1] = Ui[29 * kJB + lane];
+  int ord;
+  if (wave_lu_regs<kJB, 2>(a, lane, ord)) return 1;
+  xs[(size_t)mid * 2 * kJB + ord] = a[kJB]; xs[(size_t)mid * 2 * kJB + kJB + ord] = a[kJB + 1];
+  return 0;
+}
+__device__ __attribute__((noinline)) void jstruct_chain_back(int side, int mid, int Nm, const cfzb::glb_f64 *Zl, const cfzb::glb_i32 *ordl, cfzb::glb_f64 *xs) {
+  const int lane = threadIdx.x & 63;
+  double xp1 = xs[(size_t)mid * 2 * kJB + lane], xp2 = xs[(size_t)mid * 2 * kJB + kJB + lane];  // x of the block before, by row held: ordp
+  int ordp = lane;
+  for (int i = side ? mid + 1 : mid - 1; side ? i <= Nm : i >= 0; i += side ? 1 : -1) {
+    const cfzb::glb_f64 *Zi = Zl + (size_t)i * kJB * kJU;
+    const int ip = side ? i - 1 : i, p0 = ip == 0 ? 7 : 8;
+    double x1 = Zi[28 * kJB + lane], x2 = Zi[29 * kJB + lane];
+#pragma unroll
+    for (int q = 0; q < 28; ++q) {
+      const int r = side ? 16 * (q / 7) + p0 + (q % 7) : 16 * (q / 7) + (q % 7);  // the row of the block before that column q stands for
+      const int lk = (int)__builtin_ctzll(__ballot(ordp == r));
+      const double z = Zi[q * kJB + lane];
+      x1 -= z * struct_lane_get(xp1, lk); x2 -= z * struct_lane_get(xp2, lk);
+    }
+    const int ord = ordl[i * kJB + lane];
+    xs[(size_t)i * 2 * kJB + ord] = x1; xs[(size_t)i * 2 * kJB + kJB + ord] = x2;
+    xp1 = x1; xp2 = x2; ordp = ord;
+  }
+}
 #endif
 
 // CPU build (and the definition of what the register eliminations compute): A (n x n, column-major, ld 64), nrhs columns R -> Z
@@ -142,6 +507,25 @@ CFZP_FN int jstruct_block_serial(double *aug, const double *A, const double *R, 
   if (block_solve_serial(aug, kJB, ld, nrhs)) return 1;
   for (int r = 0; r < kJB; ++r) for (int q = 0; q < nrhs; ++q) Z[q * kJB + r] = aug[r * ld + kJB + q];
   return 0;
+}
+
+// n independent items, item tt: store(tt, load(tt)).  The workgroup is alone on its CU with two wavefronts per SIMD: a loop that issues
+// one item's loads and waits for them is bound by the memory latency (1-2 us per item), so four items' loads are issued before the first
+// is used (clamped index instead of a branch: the loads of all four stand in one block).
+template <class L, class S>
+CFZP_FN void jstruct_map(int n, L load, S store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int nt = (int)blockDim.x;
+  for (int t0 = (int)threadIdx.x; t0 < n; t0 += 4 * nt) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int tt = t0 + u * nt; v[u] = load(tt < n ? tt : n - 1); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int tt = t0 + u * nt; if (tt < n) store(tt, v[u]); }
+  }
+#else
+  for (int tt = 0; tt < n; ++tt) store(tt, load(tt));
+#endif
 }
 
 // The whole solve: on return b1, b2 (positions of build_order_vm) hold the two solutions.  0 = ok, 1 = a block was singular.
@@ -181,18 +565,21 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   CFZP_SYNC();
   { const long long t1 = tick(); ptk[0] += t1 - tp; tp = t1; ts = t1; }
   if (flag[0] != 0.0) return 1;
-  // ---- phase 2a: C'W of every interior; the pair blocks and the capacitance matrix of every interval index --------------------------
-  CFZP_LANE_FOR(tt, 0, d.NI * kJC * 31 - 1) {
+  // ---- phase 2a: C'W of every interior; the pair blocks of every interval index ------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int it = CFZS_WAVE; it < d.NI; it += CFZS_NW)
+    jstruct_cw((const cfzb::glb_f64 *)(s.Cc + (size_t)it * kSI * kJC), (const cfzb::glb_f64 *)(s.W + (size_t)it * kSI * kJR), (cfzb::glb_f64 *)(s.CW + (size_t)it * kJC * kJR));
+#else
+  for (int tt = 0; tt < d.NI * kJC * 31; ++tt) {
     const int it = tt / (kJC * 31), e = tt - it * (kJC * 31), al = e / 31, q = e - al * 31;
     const double *C = s.Cc + (size_t)it * kSI * kJC + al * kSI, *W = s.W + (size_t)it * kSI * kJR + q * kSI;
     double m_ = 0.0;
-    if (s.cl[16 * it + al] >= 0) {
-#pragma unroll 16
-      for (int r = 0; r < kSI; ++r) m_ += C[r] * W[r];
-    }
+    for (int r = 0; r < kSI; ++r) m_ += C[r] * W[r];
     s.CW[(size_t)it * kJC * kJR + al * kJR + q] = m_;
   }
-  CFZP_LANE_FOR(tt, 0, Nm * kJMt - 1) {  // Mt[t][a][b][point][i][j]: owner computes (a diagonal block sums over the pairs of its vehicle)
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)  // (the device reads M's rows from the pair blocks themselves: jstruct_cap)
+  jstruct_map(Nm * kJMt, [&](int tt) -> double {  // Mt[t][a][b][point][i][j]: owner computes (a diagonal block sums over the pairs of its vehicle)
     const int t = tt / kJMt, e = tt - t * kJMt, a = e / (kMaxVeh * 45), b = (e / 45) % kMaxVeh, kk = (e / 9) % 5, i = (e / 3) % 3, j = e % 3;
     double v = 0.0;
     if (a < V && b < V && t < sp.N[a] && t < sp.N[b])
@@ -204,145 +591,140 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
         else if (pa == a && pb == b) v += pm[6 * i + 3 + j];
         else if (pa == b && pb == a) v += pm[6 * (3 + i) + j];
       }
-    s.Mt[tt] = v;
-  }
+    return v;
+  }, [&](int tt, double v) { s.Mt[tt] = v; });
+#endif
   CFZP_SYNC();
   CFZJ_TICK(3);
-  CFZP_LANE_FOR(tt, 0, Nm * kJB * kJB - 1) {  // Cap = I + G M (column-major), Yh = E' K^-1 [C | b] (column-major)
-    const int t = tt / (kJB * kJB), e = tt - t * (kJB * kJB), col = e / kJB, row = e - col * kJB;
-    const int a = row >> 4, i = row & 15, b = col >> 4, j = col & 15;
-    double cap = row == col ? 1.0 : 0.0, yh = 0.0;
-    if (a < V && t < sp.N[a] && i < 15) {
-      const double *W = s.W + (size_t)(d.off[a] + t) * kSI * kJR;
-      const int pr = jprow(i);
-      if (b < V && t < sp.N[b] && j < 15) {
-        const int kk = j / 3, jj = j - 3 * kk;
-        const double *M = s.Mt + (size_t)t * kJMt + ((a * kMaxVeh + b) * 5 + kk) * 9;
-        for (int c = 0; c < 3; ++c) cap += W[(16 + 3 * kk + c) * kSI + pr] * M[3 * c + jj];
-      }
-      // column `col` of Yh: coupling column q of vehicle vb, or a right-hand side
-      const int h = col >> 5, lc = col & 31;
-      if (col >= kJYrhs) { if (col < kJYrhs + 2) yh = W[(14 + col - kJYrhs) * kSI + pr]; }
-      else if (lc < 2 * kJC) { const int vb = 2 * h + lc / kJC, q = lc % kJC; if (vb == a) yh = W[q * kSI + pr]; }
-    }
-    s.Cap[tt] = cap; s.Yh[tt] = yh;
-  }
-  CFZP_SYNC();
-  CFZJ_TICK(4);
-  // ---- phase 2b: Y = Cap^-1 Yh ------------------------------------------------------------------------------------------------------
+  // ---- phase 2b: the capacitance systems: (I + M G) Z = M E'K^-1 [C | b] --------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
   for (int k = CFZS_WAVE; k < 2 * Nm; k += CFZS_NW) {
     const int t = k >> 1, h = k & 1;
-    const int f = jstruct_block((const cfzb::glb_f64 *)(s.Cap + (size_t)t * kJB * kJB), (const cfzb::glb_f64 *)(s.Yh + (size_t)t * kJB * kJB + h * 32 * kJB),
-                                (cfzb::glb_f64 *)(s.Y + (size_t)t * kJB * kJB + h * 32 * kJB));
+    const int f = jstruct_cap(t, h, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)w.pm, (cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB));
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
-  for (int t = 0; t < Nm; ++t)
-    if (jstruct_block_serial(s.aug, s.Cap + (size_t)t * kJB * kJB, s.Yh + (size_t)t * kJB * kJB, s.Y + (size_t)t * kJB * kJB, 64)) flag[0] = 1.0;
+  for (int t = 0; t < Nm; ++t) {
+    double *Cap = s.aug + (size_t)kJB * (kJB + 64), *Rh = Cap + kJB * kJB;
+    for (int col = 0; col < kJB; ++col)
+      for (int row = 0; row < kJB; ++row) {
+        const int a = row >> 4, i = row & 15, b = col >> 4, j = col & 15;
+        double cap = row == col ? 1.0 : 0.0, rh = 0.0;
+        if (a < V && t < sp.N[a] && i < 15) {
+          const int kk = i / 3, ii = i - 3 * kk, pr = jprow(3 * kk);
+          if (b < V && t < sp.N[b] && j < 15) {
+            const double *M = s.Mt + (size_t)t * kJMt + ((a * kMaxVeh + b) * 5 + kk) * 9 + 3 * ii, *Wb = s.W + (size_t)(d.off[b] + t) * kSI * kJR;
+            for (int c = 0; c < 3; ++c) cap += M[c] * Wb[(16 + j) * kSI + pr + c];
+          }
+          const int h = col >> 5, lc = col & 31;
+          if (col >= kJYrhs) {
+            if (col < kJYrhs + 2)
+              for (int vb = 0; vb < V; ++vb) {
+                if (t >= sp.N[vb]) continue;
+                const double *M = s.Mt + (size_t)t * kJMt + ((a * kMaxVeh + vb) * 5 + kk) * 9 + 3 * ii, *Wb = s.W + (size_t)(d.off[vb] + t) * kSI * kJR;
+                for (int c = 0; c < 3; ++c) rh += M[c] * Wb[(14 + col - kJYrhs) * kSI + pr + c];
+              }
+          } else if (lc < 2 * kJC) {
+            const int vb = 2 * h + lc / kJC, q = lc % kJC;
+            if (vb < V && t < sp.N[vb]) {
+              const double *M = s.Mt + (size_t)t * kJMt + ((a * kMaxVeh + vb) * 5 + kk) * 9 + 3 * ii, *Wb = s.W + (size_t)(d.off[vb] + t) * kSI * kJR;
+              for (int c = 0; c < 3; ++c) rh += M[c] * Wb[q * kSI + pr + c];
+            }
+          }
+        }
+        Cap[col * kJB + row] = cap; Rh[col * kJB + row] = rh;
+      }
+    if (jstruct_block_serial(s.aug, Cap, Rh, s.Z + (size_t)t * kJB * kJB, 64)) flag[0] = 1.0;
+  }
 #endif
   CFZP_SYNC();
   CFZJ_TICK(5);
   if (flag[0] != 0.0) return 1;
-  // ---- phase 2c: Z = M Y ------------------------------------------------------------------------------------------------------------
-  CFZP_LANE_FOR(tt, 0, Nm * kJB * kJB - 1) {
-    const int t = tt / (kJB * kJB), e = tt - t * (kJB * kJB), col = e / kJB, row = e - col * kJB, a = row >> 4, i = row & 15;
-    double z = 0.0;
-    if (a < V && t < sp.N[a] && i < 15) {
-      const int kk = i / 3, ii = i - 3 * kk;
-      const double *Yc = s.Y + (size_t)t * kJB * kJB + col * kJB;
-      for (int b = 0; b < V; ++b) {
-        if (t >= sp.N[b]) continue;
-        const double *M = s.Mt + (size_t)t * kJMt + ((a * kMaxVeh + b) * 5 + kk) * 9 + 3 * ii;
-        for (int c = 0; c < 3; ++c) z += M[c] * Yc[16 * b + 3 * kk + c];
-      }
-    }
-    s.Z[tt] = z;
-  }
-  CFZP_SYNC();
-  CFZJ_TICK(6);
-  // ---- phase 2d: the joint separator blocks: band entries, pair blocks of pt0, identity padding; right-hand sides ------------------------
-  CFZP_LANE_FOR(tt, 0, (Nm + 1) * kJB * kJB - 1) {
+  // ---- phase 2d: the joint separator blocks, owner computes: band entries, the pair blocks of pt0, identity padding, minus the Schur
+  // complements of the interiors of interval index i (rows / columns of pt0) and i - 1 (the right-coupled unknowns):
+  //   S[(a, al), (b, be)] -= [a == b] C_a'W_a[al, be] - sum_j (C_a'K_a^-1 E)[al, j] Z[(a, j), (b, be)]
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int i = CFZS_WAVE; i <= Nm; i += CFZS_NW)
+    jstruct_sep_base(i, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, (const cfzb::glb_f64 *)w.pm, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
+                     (cfzb::glb_f64 *)(s.Ds + (size_t)i * kJB * kJB), (cfzb::glb_f64 *)(s.Us + (size_t)i * kJB * kJU));
+  __syncthreads();
+  CFZJ_TICK(7);
+  for (int t = CFZS_WAVE; t < Nm; t += CFZS_NW)
+    jstruct_schur(t, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cmask, (const cfzb::glb_f64 *)s.CW, (const cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB), (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us);
+#else
+  auto schur = [&](int t, int a, int al, int b, int be) -> double {  // be >= 14: right-hand side be - 14
+    const double *CW = s.CW + (size_t)(d.off[a] + t) * kJC * kJR + al * kJR;
+    const double *Zc = s.Z + (size_t)t * kJB * kJB + (size_t)(be >= kJC ? kJYrhs + be - kJC : jycol(b, be)) * kJB + 16 * a;
+    double m_ = be >= kJC ? CW[be] : (a == b ? CW[be] : 0.0);
+#pragma unroll
+    for (int j = 0; j < 15; ++j) m_ -= CW[16 + j] * Zc[j];
+    return m_;
+  };
+  jstruct_map((Nm + 1) * kJB * kJB, [&](int tt) -> double {
     const int i = tt / (kJB * kJB), e = tt - i * (kJB * kJB), col = e / kJB, row = e - col * kJB, a = row >> 4, la = row & 15, b = col >> 4, lb = col & 15;
     double v = row == col ? 1.0 : 0.0;
     if (a < V && b < V && i <= sp.N[a] && i <= sp.N[b] && la < jsep_size(sp, a, i) && lb < jsep_size(sp, b, i)) {
-      if (a == b) v = band_at(B, d.nk, jsep_start(s, a, i) + la, jsep_start(s, a, i) + lb);
-      else {
-        v = 0.0;
-        const int p0a = i == 0 ? 7 : 8, p0b = p0a;  // pt0's first local index
-        if (i < sp.N[a] && i < sp.N[b] && la >= p0a && la < p0a + 3 && lb >= p0b && lb < p0b + 3)
-          for (int pe = 0; pe < sp.n_pairs; ++pe) {
-            const int pa = sp.pair_a[pe], pb = sp.pair_b[pe];
-            const double *pm = w.pm + (size_t)(d.poff[pe] + kPts * i) * 36;
-            if (pa == a && pb == b) v += pm[6 * (la - p0a) + 3 + (lb - p0b)];
-            else if (pa == b && pb == a) v += pm[6 * (3 + la - p0a) + (lb - p0b)];
-          }
-      }
-      if (a == b && i < sp.N[a]) {  // the diagonal parts of the pair blocks at pt0
-        const int p0 = i == 0 ? 7 : 8;
-        if (la >= p0 && la < p0 + 3 && lb >= p0 && lb < p0 + 3)
-          for (int pe = 0; pe < sp.n_pairs; ++pe) {
-            const int pa = sp.pair_a[pe], pb = sp.pair_b[pe];
-            if (i >= sp.N[pa] || i >= sp.N[pb]) continue;
-            const double *pm = w.pm + (size_t)(d.poff[pe] + kPts * i) * 36;
-            if (pa == a) v += pm[6 * (la - p0) + (lb - p0)]; else if (pb == a) v += pm[6 * (3 + la - p0) + 3 + (lb - p0)];
-          }
-      }
+      const int p0 = i == 0 ? 7 : 8;  // pt0's first local index
+      const bool inter = i < sp.N[a] && i < sp.N[b];
+      const bool pose = inter && la >= p0 && la < p0 + 3 && lb >= p0 && lb < p0 + 3;
+      v = a == b ? band_at(B, d.nk, jsep_start(s, a, i) + la, jsep_start(s, a, i) + lb) : 0.0;
+      if (pose)
+        for (int pe = 0; pe < sp.n_pairs; ++pe) {
+          const int pa = sp.pair_a[pe], pb = sp.pair_b[pe];
+          if (i >= sp.N[pa] || i >= sp.N[pb]) continue;
+          const double *pm = w.pm + (size_t)(d.poff[pe] + kPts * i) * 36;
+          if (a == b) { if (pa == a) v += pm[6 * (la - p0) + (lb - p0)]; else if (pb == a) v += pm[6 * (3 + la - p0) + 3 + (lb - p0)]; }
+          else if (pa == a && pb == b) v += pm[6 * (la - p0) + 3 + (lb - p0)];
+          else if (pa == b && pb == a) v += pm[6 * (3 + la - p0) + (lb - p0)];
+        }
+      if (inter && la >= p0 && la < p0 + 7 && lb >= p0 && lb < p0 + 7) v -= schur(i, a, la - p0, b, lb - p0);
+      if (i >= 1 && la < 7 && lb < 7 && s.cl[16 * (d.off[a] + i - 1) + 7 + la] >= 0 && s.cl[16 * (d.off[b] + i - 1) + 7 + lb] >= 0) v -= schur(i - 1, a, 7 + la, b, 7 + lb);
     }
-    s.Ds[tt] = v;
-  }
-  CFZP_LANE_FOR(tt, 0, (Nm + 1) * kJB * kJU - 1) {
-    const int i = tt / (kJB * kJU), e = tt - i * (kJB * kJU), col = e / kJB, row = e - col * kJB, a = row >> 4, la = row & 15;
+    return v;
+  }, [&](int tt, double v) { s.Ds[tt] = v; });
+  // right-hand sides of the blocks: columns 0..27 = U_i, the coupling of block i's pt0 rows with block i + 1's rows 16 b + be; 28, 29 = b1, b2
+  jstruct_map((Nm + 1) * kJB * 30, [&](int tt) -> double {
+    const int i = tt / (kJB * 30), e = tt - i * (kJB * 30), col = e / kJB, row = e - col * kJB, a = row >> 4, la = row & 15;
     double v = 0.0;
-    if (col >= 28 && col < 30 && a < V && i <= sp.N[a] && la < jsep_size(sp, a, i)) v = (col == 28 ? b1 : b2)[jsep_start(s, a, i) + la];
-    s.Us[tt] = v;
-  }
-  CFZP_SYNC();
-  CFZJ_TICK(7);
-  // Schur complements of the interiors of interval index t onto separators t (rows / columns of pt0) and t + 1 (the right-coupled
-  // unknowns):  S[(a, al), (b, be)] -= [a == b] C_a'W_a[al, be] - sum_j C_a'K_a^-1 E[al, j] Z[(a, j), (b, be)];  owner computes
-  CFZP_LANE_FOR(tt, 0, Nm * kMaxVeh * kJC * (kMaxVeh * kJC + 2) - 1) {
-    const int per = kMaxVeh * kJC + 2;
-    const int t = tt / (kMaxVeh * kJC * per), e = tt - t * (kMaxVeh * kJC * per), a = e / (kJC * per), al = (e / per) % kJC, tb = e % per;
-    if (a >= V || t >= sp.N[a]) continue;
-    const int it = d.off[a] + t;
-    const int *cl = s.cl + 16 * it;
-    if (cl[al] < 0) continue;
-    const double *CW = s.CW + (size_t)it * kJC * kJR + al * kJR;
-    const double *Zt = s.Z + (size_t)t * kJB * kJB;
-    const bool aleft = al < 7;
-    const int ra = 16 * a + (aleft ? cl[al] - jsep_start(s, a, t) : cl[al] - jsep_start(s, a, t + 1));  // row in separator t (left) or t + 1
-    if (tb >= kMaxVeh * kJC) {  // the right-hand sides
-      const int sr = tb - kMaxVeh * kJC;
-      double m_ = CW[14 + sr];
-      for (int j = 0; j < 15; ++j) m_ -= CW[16 + j] * Zt[(kJYrhs + sr) * kJB + 16 * a + j];
-      s.Us[(size_t)(aleft ? t : t + 1) * kJB * kJU + (28 + sr) * kJB + ra] -= m_;
-      continue;
+    if (a >= V || i > sp.N[a] || la >= jsep_size(sp, a, i)) return v;
+    const int p0 = i == 0 ? 7 : 8;
+    const bool left = i < sp.N[a] && la >= p0 && la < p0 + 7;
+    if (col < 28) {
+      const int b = col / 7, be = col - 7 * b;
+      if (left && b < V && i < sp.N[b] && s.cl[16 * (d.off[b] + i) + 7 + be] >= 0) v = -schur(i, a, la - p0, b, 7 + be);
+      return v;
     }
-    const int b = tb / kJC, be = tb - b * kJC;
-    if (b >= V || t >= sp.N[b]) continue;
-    const int *clb = s.cl + 16 * (d.off[b] + t);
-    if (clb[be] < 0) continue;
-    const bool bleft = be < 7;
-    if (!aleft && bleft) continue;  // (the transpose of a block that is kept)
-    double m_ = a == b ? CW[be] : 0.0;
-    for (int j = 0; j < 15; ++j) m_ -= CW[16 + j] * Zt[jycol(b, be) * kJB + 16 * a + j];
-    const int cb = 16 * b + (bleft ? clb[be] - jsep_start(s, b, t) : clb[be] - jsep_start(s, b, t + 1));
-    if (aleft && bleft) s.Ds[(size_t)t * kJB * kJB + cb * kJB + ra] -= m_;
-    else if (!aleft && !bleft) s.Ds[(size_t)(t + 1) * kJB * kJB + cb * kJB + ra] -= m_;
-    else s.Us[(size_t)t * kJB * kJU + (7 * b + be - 7) * kJB + ra] = -m_;  // coupling of separator t (row) with separator t + 1 (vehicle b's be-th coupled unknown)
-  }
+    v = (col == 28 ? b1 : b2)[jsep_start(s, a, i) + la];
+    if (left) v -= schur(i, a, la - p0, a, kJC + col - 28);
+    if (i >= 1 && la < 7 && s.cl[16 * (d.off[a] + i - 1) + 7 + la] >= 0) v -= schur(i - 1, a, 7 + la, a, kJC + col - 28);
+    return v;
+  }, [&](int tt, double v) { const int i = tt / (kJB * 30), e = tt - i * (kJB * 30); s.Us[(size_t)i * kJB * kJU + e] = v; });
+#endif
   CFZP_SYNC();
   CFZJ_TICK(8);
   { const long long t1 = tick(); ptk[1] += t1 - tp; tp = t1; }
   // ---- phase 3: recursion over the joint separators -------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+  {  // from both ends, a wavefront each; the middle block receives both; back-substitution outwards
+    const int mid = (Nm + 1) / 2, wv = CFZS_WAVE;
+    unsigned nvp = 0;
+    for (int a = 0; a < V; ++a) nvp |= (unsigned)sp.N[a] << (8 * a);
+    int f = 0;
+    if (wv == 0) f = jstruct_chain(0, 0, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_i32 *)s.ordl);
+    else if (wv == 1) f = jstruct_chain(1, Nm, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_i32 *)s.ordl);
+    if (f && CFZS_LANE == 0) flag[0] = 1.0;
+    __syncthreads();
+    if (flag[0] != 0.0) return 1;
+    if (wv == 0 && jstruct_chain_mid(mid, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.xs) && CFZS_LANE == 0) flag[0] = 1.0;
+    __syncthreads();
+    if (flag[0] != 0.0) return 1;
+    if (wv < 2) jstruct_chain_back(wv, mid, Nm, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_i32 *)s.ordl, (cfzb::glb_f64 *)s.xs);
+    __syncthreads();
+  }
+#else
   for (int i = 0; i <= Nm; ++i) {
     double *Di = s.Ds + (size_t)i * kJB * kJB, *Ui = s.Us + (size_t)i * kJB * kJU, *Zi = s.Zs + (size_t)i * kJB * kJU;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (CFZS_WAVE == 0) { if (jstruct_block((const cfzb::glb_f64 *)Di, (const cfzb::glb_f64 *)Ui, (cfzb::glb_f64 *)Zi) && CFZS_LANE == 0) flag[0] = 1.0; }
-#else
     if (jstruct_block_serial(s.aug, Di, Ui, Zi, kJU)) flag[0] = 1.0;
-#endif
     CFZP_SYNC();
     if (flag[0] != 0.0) return 1;
     if (i == Nm) break;
@@ -389,6 +771,7 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
     }
     CFZP_SYNC();
   }
+#endif
   CFZJ_TICK(9);
   // ---- phase 4: the separators' and the interiors' unknowns back to their positions --------------------------------------------------------
   CFZP_LANE_FOR(tt, 0, (Nm + 1) * kJB - 1) {
@@ -396,28 +779,40 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
     if (a < V && i <= sp.N[a] && la < jsep_size(sp, a, i)) { const int p = jsep_start(s, a, i) + la; b1[p] = s.xs[(size_t)i * 2 * kJB + row]; b2[p] = s.xs[(size_t)i * 2 * kJB + kJB + row]; }
   }
   CFZP_SYNC();
-  CFZP_LANE_FOR(tt, 0, Nm * 2 * kJB - 1) {  // z = M y of every interval index: Z[:, b] - Z[:, coupling columns] s   (kept in Yh's first two columns)
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int t = CFZS_WAVE; t < Nm; t += CFZS_NW)
+    jstruct_zt(t, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB), (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
+               (cfzb::glb_f64 *)(s.zt + (size_t)t * 2 * kJB));
+  __syncthreads();
+  for (int it = CFZS_WAVE; it < d.NI; it += CFZS_NW) {
+    const int a = veh_of_interval(d, it), t = it - d.off[a];
+    jstruct_back(a, s.bs[a] + 79 * t + 14, (const cfzb::glb_i32 *)(s.cl + 16 * it), (const cfzb::glb_f64 *)(s.W + (size_t)it * kSI * kJR), (const cfzb::glb_f64 *)(s.zt + (size_t)t * 2 * kJB),
+                 (cfzb::glb_f64 *)b1, (cfzb::glb_f64 *)b2);
+  }
+#else
+  jstruct_map(Nm * 2 * kJB, [&](int tt) -> double {  // z = M y of every interval index: Z[:, b] - Z[:, coupling columns] s
     const int t = tt / (2 * kJB), e = tt - t * (2 * kJB), sr = e / kJB, row = e - sr * kJB;
     const double *Zt = s.Z + (size_t)t * kJB * kJB, *xb = sr ? b2 : b1;
     double z = Zt[(kJYrhs + sr) * kJB + row];
     for (int b = 0; b < V; ++b) {
       if (t >= sp.N[b]) continue;
       const int *clb = s.cl + 16 * (d.off[b] + t);
-      for (int q = 0; q < kJC; ++q) if (clb[q] >= 0) z -= Zt[jycol(b, q) * kJB + row] * xb[clb[q]];
+#pragma unroll
+      for (int q = 0; q < kJC; ++q) { const int c = clb[q]; z -= Zt[jycol(b, q) * kJB + row] * (c >= 0 ? xb[c] : 0.0); }
     }
-    s.Yh[(size_t)t * kJB * kJB + e] = z;
-  }
-  CFZP_SYNC();
+    return z;
+  }, [&](int tt, double z) { s.zt[tt] = z; });
   CFZP_LANE_FOR(tt, 0, d.NI * kSI - 1) {
     const int it = tt / kSI, r = tt - it * kSI, a = veh_of_interval(d, it), t = it - d.off[a];
     const int *cl = s.cl + 16 * it;
-    const double *W = s.W + (size_t)it * kSI * kJR + r, *z = s.Yh + (size_t)t * kJB * kJB;
+    const double *W = s.W + (size_t)it * kSI * kJR + r, *z = s.zt + (size_t)t * 2 * kJB;
     double y1 = W[14 * kSI], y2 = W[15 * kSI];
     for (int q = 0; q < kJC; ++q) if (cl[q] >= 0) { y1 -= W[q * kSI] * b1[cl[q]]; y2 -= W[q * kSI] * b2[cl[q]]; }
     for (int j = 0; j < 15; ++j) { y1 -= W[(16 + j) * kSI] * z[16 * a + j]; y2 -= W[(16 + j) * kSI] * z[kJB + 16 * a + j]; }
     const int p = s.bs[a] + 79 * t + 14 + r;  // (interior positions are read by nobody in this phase)
     b1[p] = y1; b2[p] = y2;
   }
+#endif
   CFZP_SYNC();
   CFZJ_TICK(10);
 #undef CFZJ_TICK
