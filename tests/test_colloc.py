@@ -384,6 +384,40 @@ def test_joint_source_solves_pair(plans):
     assert abs(cost - res["f"]) < 1e-8 * res["f"] and cost >= sum(reference_residuals(jn, singles[a], a)["cost"] for a in range(2)) - 1e-6
 
 
+@pytest.mark.parametrize("agents,nsets", [(["vehicle_2", "vehicle_3"], [0, 0]), (["vehicle_1", "vehicle_2", "vehicle_3"], [0, 0, 0]),
+                                          (["vehicle_0", "vehicle_1", "vehicle_2", "vehicle_3"], [4, 3, 4, 2])])
+def test_joint_structured_elimination_equals_the_band_elimination(plans, agents, nsets):
+    """cfz_jstruct.inl on the CPU build (CSpec::no_prox bit 2 with V > 1): the joint plan's Newton system eliminated interval by interval
+    -- vehicle-major ordering, tube rows condensed, every vehicle's 64-unknown interiors by themselves, the pair-coupled poses of an
+    interval index through a capacitance system, a block recursion over the joint separators -- takes the iterates of the band elimination
+    (half-bandwidth 100-298 across the vehicles): equal status and iteration count, solution to 1e-7.  Two and three vehicles at full
+    length (30 / 50 intervals), four vehicles with plans of DIFFERENT lengths (the shorter vehicles drop out of the later interval indices)
+    and one without a terminal heading."""
+    import colloc_emu_binding as ce
+
+    nps = 5
+    if any(nsets):
+        jn, sp = _joint_problem(plans, agents, nsets, nps=nps, headings=[float(plans[a][1][30 * (ns - 1), 2]) if a != "vehicle_1" else None for a, ns in zip(agents, nsets)])
+        sing = []
+        for a, ns in zip(agents, nsets):
+            tube, p = plans[a]
+            z = warm_start(tube[:ns], p[: 30 * (ns - 1) + 1], None)
+            N = nps * (ns - 1)
+            t_i = np.concatenate([k + jn.tau for k in range(N)]) / N * z["t"][-1]
+            sing.append(({k: interp1d(z["t"], z[k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")}, z["t"][-1] / N))
+        X0 = jn.pack([s[0] for s in sing], float(np.mean([s[1] for s in sing])))
+    else:
+        jn, sp = _joint_problem(plans, agents, nsets, nps=nps)
+        X0, _ = _joint_guess(plans, agents, jn, sp, nps)
+    band = ce.solve(jn, X0, ipm.IpmOptions(**COLLOC_OPT))
+    opt = ipm.IpmOptions(**COLLOC_OPT)
+    opt.no_prox = 4
+    st = ce.solve(jn, X0, opt)
+    assert ce.half_bandwidth(jn, opt) == 51 and ce.half_bandwidth(jn, ipm.IpmOptions(**COLLOC_OPT)) > 90
+    assert (st["status"], st["iters"]) == (band["status"], band["iters"]) == (0, band["iters"])
+    assert np.abs(st["X"] - band["X"]).max() < 1e-7 and abs(st["f"] - band["f"]) < 1e-9 * band["f"]
+
+
 @pytest.mark.gpu
 def test_joint_colloc_on_gpu(plans, tmp_path):
     """cfz_joint_colloc against the CPU build of the same source, and MultiVehiclePlanner.solve_single_problems ->

@@ -392,7 +392,12 @@ def test_panel_elimination_equals_one_pivot_at_a_time(lot):
     assert good == list(range(4))
     args = (scenarios.parking_lot_spec(n_nbr=0, N=2), [lot["paths"][a][0] for a in agents], [lot["tubes"][a] for a in agents],
             [plans[i]["traj"].reshape(-1, 7) for i in range(4)], float(np.mean([plans[i]["dt"] for i in range(4)])), [lot["fh"][a] for a in agents])
-    r = engine.joint_colloc(*args, max_iter=300)
+    r = engine.joint_colloc(*args, max_iter=300, structured=0)
     r1 = engine.joint_colloc(*args, max_iter=300, one_pivot=1)
     assert r["status"] == r1["status"] == 0 and r["iters"] == r1["iters"]
     assert r["cost"] == r1["cost"] and r["dt"] == r1["dt"] and all(np.array_equal(a, b) for a, b in zip(r["traj"], r1["traj"]))
+    # ... and the structured elimination (cfz_jstruct.inl, the default: interval by interval, no band across the vehicles) is another
+    # elimination order of the same Newton systems: same status and iteration count, the plan to rounding
+    rs = engine.joint_colloc(*args, max_iter=300)
+    assert (rs["status"], rs["iters"]) == (r["status"], r["iters"]) and abs(rs["cost"] - r["cost"]) < 1e-9 * r["cost"] and abs(rs["dt"] - r["dt"]) < 1e-9
+    assert max(np.abs(a - b).max() for a, b in zip(rs["traj"], r["traj"])) < 1e-7
