@@ -211,6 +211,37 @@ def profiled_sq(kernel, require_current=True):
     return {"frac": 4.0 * raw, "raw_quotient": raw}, os.path.basename(tags[-1])[: -len("_pmc_SQ.csv")]
 
 
+def profiled_extras(dispatch, kernel="colloc_kernel", require_current=True):
+    """HBM bytes and VALU-active fraction of ONE dispatch of `kernel` from the committed PMC passes of `python bench.py --extras-only`
+    (profiles/<tag>_extras_pmc_*.csv, made by tools/gpu_profile_extras.sh; hash-gated like the headline's): dispatch = the ordinal of the
+    launch among the kernel's dispatches of that command (planning_extras records it).  -> dict(traffic, valu_active_frac, source) or None."""
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    tags = sorted(glob.glob(os.path.join(here, "profiles", "*_extras_pmc_FETCH_SIZE.csv")))
+    if not tags:
+        return None
+    tag = tags[-1][: -len("_pmc_FETCH_SIZE.csv")]
+    if require_current and not profile_is_current(tag):
+        return {"traffic": None, "valu_active_frac": None, "source": os.path.basename(tag) + " (stale: taken on other kernel sources)"}
+
+    def per_dispatch(fn):
+        vals = {}
+        for line in open(fn):
+            f = line.rstrip("\n").split(",")
+            if f[0] == kernel and len(f) >= 5:
+                vals[f[1]] = [float(x) for x in f[4].split()]
+        return vals
+
+    try:
+        tot = sum(per_dispatch(f"{tag}_pmc_{c}.csv")[c][dispatch] for c in ("FETCH_SIZE", "WRITE_SIZE")) * 1024.0
+        sq = per_dispatch(f"{tag}_pmc_SQ.csv")
+        valu = 4.0 * sq["SQ_ACTIVE_INST_VALU"][dispatch] / (sq["GRBM_GUI_ACTIVE"][dispatch] / 8.0 * 1024.0)
+    except (OSError, ValueError, IndexError, KeyError, ZeroDivisionError):
+        return None
+    return {"traffic": tot, "valu_active_frac": valu, "source": os.path.basename(tag)}
+
+
 TAU5 = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])  # Radau-5 nodes
 
 
@@ -249,6 +280,8 @@ def planning_extras(device=0, B=256, cpu=True):
         ti = (np.arange(N)[:, None] + TAU5[None, :]).ravel() / N * t[-1]
         return np.stack([np.interp(ti, t, ws[:, c]) for c in range(7)], 1), t[-1] / N
 
+    launches = {"colloc_kernel": 0}  # ordinal of the next colloc_kernel dispatch of this process (profiled_extras looks it up)
+
     def single_plans(idx):
         t0 = time.perf_counter()
         ws = engine.state_ws([init[i] for i in idx], [tubes[who[i]] for i in idx], [paths[who[i]] for i in idx], [fh[who[i]] for i in idx],
@@ -260,23 +293,31 @@ def planning_extras(device=0, B=256, cpu=True):
         rg = engine.colloc(sp0, [init[idx[k]] for k in good], [tubes[who[idx[k]]] for k in good], [gs[k][0] for k in good],
                            [gs[k][1] for k in good], [fh[who[idx[k]]] for k in good], max_iter=400, device=device)
         t3 = time.perf_counter()
+        launches["colloc_kernel"] += 1
         return ws, good, dict(zip(good, rg)), t1 - t0, t3 - t2
 
     out = {}
     # ---- configs[1] ------------------------------------------------------------------------------------------------------------
     single_plans(list(range(8)))  # warm-up: module load, workspace allocation
     ws, good, plans, t_ws, t_col = single_plans(list(range(B)))
-    band = {a: engine.colloc_band_info([len(tubes[a]) + 1]) for a in agents}
-    alg = sum(3.0 * band[who[k]][2] * plans[k]["iters"] for k in plans)
+    d1 = launches["colloc_kernel"] - 1
+    info1 = {a: engine.colloc_elimination_info([len(tubes[a]) + 1]) for a in agents}
+    alg = float(sum(info1[who[k]]["alg_bytes"] * plans[k]["iters"] for k in plans))
     ok = sum(r["status"] == 0 for r in plans.values())
+
+    def roofline_of(alg_bytes, seconds, dispatch, what):
+        pe = profiled_extras(dispatch)
+        return {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg_bytes / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / seconds / 1e9 / HBM_PEAK_GBS, "alg_bytes": alg_bytes, "alg_bytes_definition": what,
+                "traffic": pe["traffic"] if pe else None, "valu_active_frac": pe["valu_active_frac"] if pe else None,
+                "traffic_source": (pe["source"] + f", colloc_kernel dispatch {dispatch} of `python bench.py --extras-only`") if pe else None}
     out["configs[1]"] = {
         "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5, 6 obstacles)",
         "plans_per_s": B / (t_ws + t_col), "state_ws_s": t_ws, "colloc_s": t_col, "state_ws_converged": len(good), "colloc_converged": ok,
         "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])), "colloc_iters_max": int(max(r["iters"] for r in plans.values())),
         "state_ws_iters_mean": float(np.mean([w_["iters"] for w_ in ws])), "state_ws_iters_max": int(max(w_["iters"] for w_ in ws)),
-        "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg / t_col / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / t_col / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes": "3 x band bytes (nk x (3 kb + 1) x 8: %s) x iterations of every plan" % {a: band[a][2] for a in agents}}}
+        "roofline": roofline_of(alg, t_col, d1, "bytes the structured elimination of one Newton system moves between its phases (cfz_colloc_elimination_info: "
+                                "%s per vehicle) x interior-point iterations of every plan" % {a: info1[a]["alg_bytes"] for a in agents})}
     # configs[1] as BASELINE.json words it: FOUR polytope obstacles (0, 1, 3, 4 of the reference's six) -- the same B plans'
     # collocation refinement again on that map (state_ws does not see the obstacles: the tube keeps the vehicle off them)
     sp4 = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=4)
@@ -287,6 +328,7 @@ def planning_extras(device=0, B=256, cpu=True):
     r4 = engine.colloc(sp4, [init[k] for k in good], [tubes[who[k]] for k in good], [gs[k][0] for k in good], [gs[k][1] for k in good],
                        [fh[who[k]] for k in good], max_iter=400, device=device)
     t_col4 = time.perf_counter() - t0
+    launches["colloc_kernel"] += 2
     out["configs[1]"]["four_obstacles"] = {
         "workload": f"the same {B} plans with BASELINE.json's 4 polytope obstacles (0, 1, 3, 4 of the reference's six)",
         "plans_per_s": B / (t_ws + t_col4), "colloc_s": t_col4, "colloc_converged": sum(r["status"] == 0 for r in r4),
@@ -304,16 +346,24 @@ def planning_extras(device=0, B=256, cpu=True):
     t0 = time.perf_counter()
     rj = engine.joint_colloc_batch(sp0, scen, max_iter=300, device=device)
     t_joint = time.perf_counter() - t0
-    nk4, kb4, bb4 = engine.colloc_band_info([len(tubes[a]) + 1 for a in agents])
-    alg4 = sum(3.0 * bb4 * r["iters"] for r in rj)
+    d3 = launches["colloc_kernel"]
+    launches["colloc_kernel"] += 1
+    info4 = engine.colloc_elimination_info([len(tubes[a]) + 1 for a in agents])
+    nk4, kb4, bb4 = info4["nk"], info4["kb"], info4["band_bytes"]
+    alg4 = float(sum(info4["alg_bytes"] * r["iters"] for r in rj))
     out["configs[3]"] = {
         "workload": f"BASELINE.json configs[3]: {len(scen)} centralised four-vehicle joint plans (six pairs, one shared dt) in one launch, one workgroup each",
         "plans_per_s": len(scen) / t_joint, "joint_s": t_joint, "converged": sum(r["status"] == 0 for r in rj),
         "iters_mean": float(np.mean([r["iters"] for r in rj])), "iters_max": int(max(r["iters"] for r in rj)),
-        "unknowns": nk4, "half_bandwidth": kb4, "band_bytes": bb4,
-        "roofline": {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg4 / t_joint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg4 / t_joint / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes": "3 x band bytes x iterations of every plan"}}
+        "unknowns": nk4, "half_bandwidth": kb4, "band_bytes": bb4, "workspace_bytes_per_plan": info4["workspace_bytes"],
+        "elimination": "structured (cfz_jstruct.inl): vehicle-major ordering, per-vehicle band of half-bandwidth 51, no band across the vehicles",
+        "roofline": roofline_of(alg4, t_joint, d3, f"bytes the structured elimination of one joint Newton system moves between its phases "
+                                f"(cfz_colloc_elimination_info: {info4['alg_bytes']}) x interior-point iterations of every plan")}
+    # BASELINE.md section 4 config 2 as drawn there: lane poses, default_rng(1234), MPC form, four obstacles, no neighbours
+    try:
+        out["configs[1]"]["lane_sampler"] = lane_sampler_line(device)
+    except Exception as e:  # noqa: BLE001 - reporting only
+        out["configs[1]"]["lane_sampler"] = {"error": f"{type(e).__name__}: {e}"}
     engine.trim_default_workspaces()  # a 256-plan joint launch leaves 25 GB in the calling thread's workspace
     if cpu:
         try:
@@ -321,6 +371,44 @@ def planning_extras(device=0, B=256, cpu=True):
         except Exception as e:  # noqa: BLE001 - reporting only
             out["configs[1]"]["cpu_baseline"] = out["configs[3]"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def lane_sampler_line(device=0, B=256):
+    """B = 256 independent single-vehicle OBCA problems in MPC form (N = 30, the four
+    obstacles 0, 1, 3, 4 of the reference's six, no neighbours) at lane poses drawn with default_rng(1234): one cold `cfz_mpc_solve` of the
+    whole batch (host buffers in and out; the kernel time beside it), and the same batch on one host core through the C port."""
+    from conflict_rez_amd import engine, scenarios
+
+    spec = scenarios.parking_lot_spec(n_obs=4, n_nbr=0)
+    x0, ref, zu = scenarios.lane_sampler(spec, B=B, seed=1234)
+    eng = engine.Engine(spec, max_batch=B, device=device)
+    eng.solve(x0, ref, None, zu, want_duals=False)  # warm-up
+    t0 = time.perf_counter()
+    out = eng.solve(x0, ref, None, zu, want_duals=False)
+    wall = time.perf_counter() - t0
+    eng.close()
+    it = out["iters"]
+    line = {"workload": f"BASELINE.md section 4 config 2: {B} single-vehicle MPC-form problems, N = 30, 4 obstacles, lane poses x0~U[5,30], y0~U[15,20], "
+                        "psi0 in {0,pi}+N(0,0.05), v0~U[-1,1], default_rng(1234); one cold solve of the batch",
+            "solves_per_s": B / wall, "solves_per_s_kernel": B / (out["solve_ms"] * 1e-3), "wall_ms": wall * 1e3, "kernel_ms": out["solve_ms"],
+            "converged": int((out["status"] == 0).sum()), "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(out["status"], return_counts=True))}}
+    try:
+        from oracle import port
+        from oracle.mpc_nlp import MpcSpec
+
+        ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=0)
+        t0 = time.perf_counter()
+        same = 0
+        for b in range(B):
+            r = port.solve(ospec, x0[b], ref[b], np.zeros((0, 3, spec.N)), zu[b].T)
+            same += int(r["status"] == out["status"][b] and r["iters"] == out["iters"][b])
+        tc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": B / tc, "unit": "solves/s", "cores": 1, "kind": "port", "sample": f"the same {B} problems, {tc:.2f} s",
+                                "same_status_and_iterations": same}
+    except Exception as e:  # noqa: BLE001
+        line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return line
 
 
 def planning_cpu_baseline(agents, sets, paths, fh):
@@ -354,7 +442,7 @@ def planning_cpu_baseline(agents, sets, paths, fh):
         singles.append(nlp.unpack(ce.solve(nlp, X0, opt1)["X"]))
     t1 = time.perf_counter()
     jn = JointCollocNlp([dict(init_pose=paths[a][0], tube=otubes[a], final_heading=fh[a]) for a in agents], sp.A_obs, sp.b_obs, N_per_set=5)
-    rj = ce.solve(jn, jn.pack(singles, float(np.mean([s["dt"] for s in singles]))), opt)
+    rj = ce.solve(jn, jn.pack(singles, float(np.mean([s["dt"] for s in singles]))), opt1)  # the structured elimination (cfz_jstruct.inl), as on the GPU
     t2 = time.perf_counter()
     return ({"value": 4 / (t1 - t0), "unit": "plans/s", "cores": 1, "kind": "port", "sample": f"the four vehicles' plans (state_ws + collocation), {t1 - t0:.1f} s"},
             {"value": 1 / (t2 - t1), "unit": "plans/s", "cores": 1, "kind": "port",
@@ -371,6 +459,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2024, help="scenario sampler seed of rank 0 (rank r uses seed + r)")
     ap.add_argument("--n-obs", type=int, default=6, help="static obstacles (reference map: 6); fewer = experiments only")
+    ap.add_argument("--extras-only", action="store_true", help="only the planning extras (configs[1], configs[3]): the command tools/gpu_profile_extras.sh profiles")
     ap.add_argument("--workload", choices=["mpc4", "single"], default="mpc4",
                     help="mpc4: BASELINE.json configs[2], 4-vehicle distributed MPC (the metric); single: configs[1] in MPC form, "
                          "independent single-vehicle problems, 4 obstacles, no neighbours (use --scenarios 256)")
@@ -401,6 +490,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.extras_only:  # (one process, one GPU: what tools/gpu_profile_extras.sh profiles; not a bench line)
+        print(json.dumps({"extras_only": True, "extra": planning_extras(device=local_rank, cpu=not args.no_cpu_baseline)}), flush=True)
+        return
 
     dist = None
     # CFZ_BENCH_FORCE_DIST=1: go through torch.distributed even with one rank (exercises the N > 1 code path on one GPU)

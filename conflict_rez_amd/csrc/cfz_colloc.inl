@@ -1741,6 +1741,26 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       }
     }
     a_pri = bmin(a_pri); a_dual = bmin(a_dual); dphi = bsum(dphi);
+#if defined(CFZC_TRACE)
+    {  // which bounds cut the step: the five smallest ratios (kind: p point variable 0..6, o obstacle slack, t tube slack, q pair slack)
+      int bi[5] = {-1, -1, -1, -1, -1}; double bv[5] = {2, 2, 2, 2, 2};
+      for (int i = 0; i < n; ++i) {
+        double r_ = 2.0;
+        if (w.xl[i] > -1e300 && w.dx[i] < 0.0) r_ = fmin(r_, -tau * (w.x[i] - w.xl[i]) / w.dx[i]);
+        if (w.xu[i] < 1e300 && w.dx[i] > 0.0) r_ = fmin(r_, tau * (w.xu[i] - w.x[i]) / w.dx[i]);
+        for (int k = 0; k < 5; ++k) if (r_ < bv[k]) { for (int k2 = 4; k2 > k; --k2) { bv[k2] = bv[k2 - 1]; bi[k2] = bi[k2 - 1]; } bv[k] = r_; bi[k] = i; break; }
+      }
+      printf("   blockers:");
+      for (int k = 0; k < 5 && bi[k] >= 0; ++k) {
+        const int i = bi[k];
+        if (i < d.iDt) printf(" p[pt %d var %d] %.2e (x %.3f dx %.2e z %.1e/%.1e)", i / 7, i % 7, bv[k], w.x[i], w.dx[i], w.zl[i], w.zu[i]);
+        else if (i < d.sT) printf(" o[pt %d row %d] %.2e (s %.2e dx %.2e z %.1e)", (i - d.sO) / d.nr, (i - d.sO) % d.nr, bv[k], w.x[i], w.dx[i], w.zl[i]);
+        else if (i < d.sP) printf(" t[chk %d row %d] %.2e (s %.2e dx %.2e z %.1e)", (i - d.sT) / 8, (i - d.sT) % 8, bv[k], w.x[i], w.dx[i], w.zl[i]);
+        else printf(" q[pp %d row %d] %.2e (s %.2e dx %.2e z %.1e)", (i - d.sP) / 2, (i - d.sP) % 2, bv[k], w.x[i], w.dx[i], w.zl[i]);
+      }
+      printf("\n");
+    }
+#endif
     CFZP_SYNC();
     const double phi0 = barrier_obj(sp, w, w.x, mu);
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }

@@ -49,6 +49,17 @@ CFZP_FN size_t jstruct_doubles(const CSpec &sp) {
   return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + kJB * kJB + 2 * kJB) + (Nm + 1) * (kJB * kJB + 2 * kJB * kJU + 2 * kJB) +
          (size_t)kJB * (kJB + 64) + 2 * kJB * kJB + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
 }
+// doubles the structured elimination of one joint Newton system moves between its phases (bench.py's roofline of configs[3]): the band
+// cleared and gathered once, the pair blocks written and read; W written, read for C'W and by the back-substitution; C and C'W written and
+// read; Z written, read by the Schur complements and by the back-substitution; separator blocks, right-hand sides and solutions written and
+// read once; the two right-hand sides in and out
+CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t npp) {
+  size_t NI = 0;
+  for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
+  const size_t Nm = jstruct_nmax(sp);
+  return 2 * nk * ld + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
+         2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk;
+}
 CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   JWork s;
   size_t NI = 0;

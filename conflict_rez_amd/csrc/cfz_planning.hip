@@ -518,6 +518,48 @@ int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final,
   return 0;
 }
 
+int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs, const int32_t *pairs,
+                                int structured, int32_t *nk, int32_t *kb, int64_t *band_bytes, int64_t *alg_bytes, int64_t *workspace_bytes) {
+  if (V < 1 || V > cfzc::kMaxVeh || !n_sets || N_per_set < 1 || n_obs < 0 || n_obs > cfzc::kMaxObs || n_pairs < 0) return fail("bad argument");
+  cfzc::CSpec p;
+  memset(&p, 0, sizeof p);
+  p.V = V; p.Nps = N_per_set; p.n_obs = n_obs; p.no_prox = structured ? 4 : 0;
+  for (int a = 0; a < V; ++a) {
+    if (n_sets[a] < 2) return fail("a plan needs at least two strategy steps");
+    p.n_chk[a] = n_sets[a] - 1; p.N[a] = N_per_set * p.n_chk[a]; p.has_final[a] = has_final ? (has_final[a] != 0) : 1;
+  }
+  std::vector<std::pair<int, int>> pr;
+  if (pairs && V < 2) return fail("vehicle pairs need at least two vehicles");
+  if (pairs) for (int e = 0; e < n_pairs; ++e) {
+    if (pairs[2 * e] < 0 || pairs[2 * e] >= pairs[2 * e + 1] || pairs[2 * e + 1] >= V) return fail("bad vehicle pair");
+    pr.push_back({pairs[2 * e], pairs[2 * e + 1]});
+  }
+  else for (int a = 0; a < V; ++a) for (int b = a + 1; b < V; ++b) pr.push_back({a, b});
+  if ((int)pr.size() > cfzc::kMaxPairs) return fail("problem size outside compiled limits");
+  p.n_pairs = (int)pr.size();
+  for (int e = 0; e < p.n_pairs; ++e) { p.pair_a[e] = pr[e].first; p.pair_b[e] = pr[e].second; }
+  const cfzc::CDims d = cfzc::cdims(p);
+  std::vector<int> pos((size_t)d.n + d.m);
+  if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
+  const int hb = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
+  const size_t ld = 3 * (size_t)hb + 1;
+  if (nk) *nk = d.nk;
+  if (kb) *kb = hb;
+  if (band_bytes) *band_bytes = (int64_t)d.nk * (int64_t)ld * 8;
+  if (alg_bytes) {
+    // per Newton system: the band elimination clears and assembles the band, then reads and writes it once while it eliminates;
+    // the structured eliminations: struct_alg_doubles / jstruct_alg_doubles
+    size_t dbl = 3 * (size_t)d.nk * ld;
+    if (structured && V == 1 && hb == cfzc::kCB) dbl = cfzc::struct_alg_doubles(p, d.nk, ld);
+    if (cfzc::jstruct_mode(p)) dbl = cfzc::jstruct_alg_doubles(p, d.nk, ld, d.npp);
+    *alg_bytes = (int64_t)dbl * 8;
+  }
+  if (workspace_bytes) *workspace_bytes = (int64_t)cfzc::work_doubles(p, hb) * 8;
+  return 0;
+}
+
+int cfz_abi_version(void) { return CFZ_ABI_VERSION; }
+
 void cfz_default_colloc_options(cfz_colloc_options *o) {
   memset(o, 0, sizeof *o);
   o->N_per_set = 5; o->max_iter = 3000; o->shrink_tube = 0.5; o->vv_rows = 1; o->structured = 1;

@@ -27,6 +27,13 @@ CFZP_FN size_t struct_doubles(const CSpec &sp) {
   const int N = sp.N[0];
   return (size_t)N * kSWi + (size_t)(N + 1) * kSWs + (size_t)kSI * (kSI + kSR) * 8 + (size_t)(N * 24 + 2 * (N + 2) + 3) / 2 + 16;
 }
+// doubles the structured elimination of one single-vehicle Newton system moves between its phases (what bench.py prices the kernel's HBM
+// traffic with): the band cleared and gathered once; C written and read by the Schur products; W written, read by the Schur products and by
+// the back-substitution; the separator blocks, their right-hand sides and solutions written and read once, the upward twins for half of them
+CFZP_FN size_t struct_alg_doubles(const CSpec &sp, size_t nk, size_t ld) {
+  const size_t N = sp.N[0];
+  return 2 * nk * ld + 2 * N * kSI * (kSL + kSRt) + 3 * N * kSI * kSR + 2 * (N + 1) * kSS * kSS + 4 * (N + 1) * kSS * kSZ + (N + 1) * kSS * kSZ + 4 * nk;
+}
 CFZP_FN SWork struct_carve(const CSpec &sp, double *p) {
   const int N = sp.N[0];
   SWork s;

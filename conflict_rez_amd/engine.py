@@ -98,6 +98,9 @@ class ProblemSpec:
 _lib = None
 
 
+ABI_VERSION = 5  # CFZ_ABI_VERSION of include/confrez_hip.h
+
+
 def load_library(path=None):
     """Loads libconfrez_hip.so and declares the prototypes of include/confrez_hip.h."""
     global _lib
@@ -111,6 +114,10 @@ def load_library(path=None):
         )
     lib = C.CDLL(path)
     vp, i32p = C.c_void_p, C.c_void_p
+    # the structs below mirror include/confrez_hip.h at this layout version (a caller compiled against another round's header
+    # would hand over shorter structs)
+    if not hasattr(lib, "cfz_abi_version") or lib.cfz_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: struct layout version {lib.cfz_abi_version() if hasattr(lib, 'cfz_abi_version') else 'none'}, this binding is written against {ABI_VERSION}: rebuild the library")
     lib.cfz_last_error.restype = C.c_char_p
     lib.cfz_default_spec.argtypes = [C.POINTER(_CSpec)]
     lib.cfz_default_options.argtypes = [C.POINTER(_COptions)]
@@ -159,7 +166,7 @@ def load_library(path=None):
 
 EXPORTS = (
     "cfz_default_spec cfz_default_options cfz_create cfz_destroy cfz_max_batch cfz_kernel_info cfz_mpc_set_params cfz_mpc_set_warm "
-    "cfz_source_hash cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_state_ws_default_guess cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_loop_last_status_counts cfz_vsl_step "
+    "cfz_source_hash cfz_abi_version cfz_colloc_elimination_info cfz_colloc_band_info cfz_joint_dual_ws cfz_default_plan_options cfz_state_ws cfz_state_ws_default_guess cfz_default_colloc_options cfz_colloc cfz_joint_colloc cfz_plan_ws_create cfz_plan_ws_destroy cfz_plan_ws_trim cfz_state_ws_w cfz_colloc_w cfz_joint_colloc_w cfz_mpc_set_carry cfz_mpc_set_carry_device cfz_mpc_set_slots cfz_mpc_solve cfz_mpc_get cfz_mpc_stats cfz_last_solve_ms cfz_mpc_solve_device cfz_dual_ws cfz_loop_init cfz_loop_step cfz_loop_run cfz_loop_last_iterations cfz_loop_last_converged cfz_loop_last_status_counts cfz_vsl_step "
     "cfz_loop_get cfz_last_error"
 ).split()
 
@@ -340,6 +347,22 @@ def colloc_band_info(n_sets, N_per_set=5, n_obs=6, pairs=None, has_final=None):
     if rc != 0:
         raise RuntimeError("cfz_colloc_band_info: " + lib.cfz_last_error().decode())
     return int(nk.value), int(kb.value), int(bb.value)
+
+
+def colloc_elimination_info(n_sets, N_per_set=5, n_obs=6, pairs=None, has_final=None, structured=1):
+    """`cfz_colloc_elimination_info`: dict(nk, kb, band_bytes, alg_bytes, workspace_bytes) of the elimination one (joint) collocation plan
+    goes through (host arithmetic, needs no GPU); alg_bytes: bytes per Newton system, bench.py's roofline of the planning kernels."""
+    lib = load_library()
+    ns = np.ascontiguousarray(np.asarray(n_sets, np.int32))
+    hf = None if has_final is None else np.ascontiguousarray(np.asarray(has_final, np.int32))
+    pr = None if pairs is None else np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    nk, kb, bb, ab, wb = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+    lib.cfz_colloc_elimination_info.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    rc = lib.cfz_colloc_elimination_info(len(ns), _ptr(ns), _ptr(hf), int(N_per_set), int(n_obs), 0 if pr is None else len(pr), _ptr(pr), int(structured),
+                                         C.addressof(nk), C.addressof(kb), C.addressof(bb), C.addressof(ab), C.addressof(wb))
+    if rc != 0:
+        raise RuntimeError("cfz_colloc_elimination_info: " + lib.cfz_last_error().decode())
+    return dict(nk=int(nk.value), kb=int(kb.value), band_bytes=int(bb.value), alg_bytes=int(ab.value), workspace_bytes=int(wb.value))
 
 
 def joint_colloc_batch(spec, scenarios, pairs=None, device=0, ws=None, **options):

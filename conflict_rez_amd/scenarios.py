@@ -170,6 +170,32 @@ def sample_scenarios(S, table, seed=2024, horizon_margin=30, noise=(0.05, 0.05, 
     return k0, nz
 
 
+def lane_sampler(spec: ProblemSpec, B=256, seed=1234, speed=1.0, radius=12.0):
+    """BASELINE.md section 4, config 2 (SURVEY.md 8d "Config 2"): B independent single-vehicle MPC-form problems (N stages, no
+    neighbours) in the lane between the two rows of parking spots: x0 ~ U[5, 30], y0 ~ U[15, 20], psi0 in {0, pi} + N(0, 0.05),
+    v0 ~ U[-1, 1], delta0 = 0, `default_rng(seed)`; the reference is a straight segment (even instances) or an arc of `radius` m
+    bending back towards the lane's centre line (odd instances), driven at `speed` m/s along the lane direction from the start
+    position.  Returns x0 [B, 5], ref [B, 3, N], zu [B, 7, N] (warm start = the reference at the measured speed, inputs zero)."""
+    rng = np.random.default_rng(seed)
+    N, dt = spec.N, spec.dt
+    x = rng.uniform(5.0, 30.0, B); y = rng.uniform(15.0, 20.0, B)
+    lane = rng.integers(0, 2, B) * np.pi
+    psi = lane + rng.normal(0.0, 0.05, B)
+    v = rng.uniform(-1.0, 1.0, B)
+    x0 = np.stack([x, y, psi, v, np.zeros(B)], 1)
+    s_ = speed * dt * (np.arange(N) + 1.0)
+    ref = np.zeros((B, 3, N)); zu = np.zeros((B, 7, N))
+    for b in range(B):
+        if b % 2 == 0:
+            ref[b, 0] = x[b] + s_ * np.cos(lane[b]); ref[b, 1] = y[b]; ref[b, 2] = lane[b]
+        else:  # an arc towards the centre line y = 17.5
+            k = (1.0 if y[b] < 17.5 else -1.0) * (1.0 if lane[b] == 0.0 else -1.0) / radius
+            th = lane[b] + k * s_
+            ref[b, 0] = x[b] + (np.sin(th) - np.sin(lane[b])) / k; ref[b, 1] = y[b] - (np.cos(th) - np.cos(lane[b])) / k; ref[b, 2] = th
+        zu[b, :3] = ref[b]; zu[b, 3] = v[b]
+    return x0, ref, zu
+
+
 def mpc_batch_from_table(spec: ProblemSpec, table, k0, noise):
     """Host arrays of one cold MPC step for S scenarios x V vehicles, instance order [s][v]:
     x0 [B,5], ref [B,3,N], nbr [B,V-1,3,N], zu [B,7,N] (the first `step()` of every vehicle:

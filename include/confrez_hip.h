@@ -345,6 +345,19 @@ int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_c
 int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs,
                          const int32_t *pairs, int32_t *nk, int32_t *kb, int64_t *band_bytes);
 
+/* The same for the elimination a plan actually goes through (`structured` as in cfz_colloc_options: 1 = interval by interval, cfz_struct.inl
+ * for one vehicle, cfz_jstruct.inl for several -- vehicle-major ordering, half-bandwidth 51, tube rows condensed; 0 = along the band):
+ * alg_bytes = the bytes one Newton system's elimination moves between its phases (every array written once and read where another phase
+ * consumes it: csrc/cfz_struct.inl struct_alg_doubles, csrc/cfz_jstruct.inl jstruct_alg_doubles; the band path: 3 x the band), what bench.py
+ * prices the planning kernels' HBM traffic with; workspace_bytes = the plan's slab in HBM.  Any output pointer may be NULL. */
+int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs, const int32_t *pairs,
+                                int structured, int32_t *nk, int32_t *kb, int64_t *band_bytes, int64_t *alg_bytes, int64_t *workspace_bytes);
+
+/* Layout version of the structs of this header (cfz_spec, cfz_options, cfz_colloc_options, cfz_plan_options): a binding compares it with the
+ * CFZ_ABI_VERSION it was written against before it passes a struct (conflict_rez_amd/engine.py does).  Round 5: 5. */
+#define CFZ_ABI_VERSION 5
+int cfz_abi_version(void);
+
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------
  * S scenarios x V vehicles (V = n_nbr + 1), B = S*V instances ordered [s][v].
  * ref_table[V][T][7]: each vehicle's planned trajectory (x,y,psi,v,delta,a,w) sampled every dt

@@ -78,7 +78,25 @@ def test_planning_extras_of_the_bench_line():
     assert c1["four_obstacles"]["colloc_converged"] == 8 and c1["four_obstacles"]["plans_per_s"] > 1.0  # configs[1] as BASELINE.json words it
     assert 5 <= c1["state_ws_iters_mean"] <= c1["state_ws_iters_max"] <= 60 and c1["colloc_iters_mean"] <= c1["colloc_iters_max"] <= 150
     assert c1["four_obstacles"]["colloc_iters_max"] >= c1["four_obstacles"]["colloc_iters_mean"]
-    assert c3["converged"] == 8 and c3["unknowns"] == 12350 and c3["half_bandwidth"] == 298 and c3["band_bytes"] == 12350 * (3 * 298 + 1) * 8
+    # configs[3] goes through the structured elimination (cfz_jstruct.inl): vehicle-major ordering, tube rows condensed, half-bandwidth 51,
+    # no band across the vehicles (round 4: 12,350 unknowns in a band of half-bandwidth 298, 88 MB per plan)
+    from conflict_rez_amd import engine
+
+    assert c3["converged"] == 8 and c3["unknowns"] == 12350 - 16 * 30 and c3["half_bandwidth"] == 51 and c3["band_bytes"] == c3["unknowns"] * (3 * 51 + 1) * 8
+    assert c3["iters_max"] <= 120 and "structured" in c3["elimination"] and c3["workspace_bytes_per_plan"] < 60e6
+    info4 = engine.colloc_elimination_info([11, 7, 7, 9])  # the four vehicles' strategy lengths
+    assert (info4["nk"], info4["kb"]) == (c3["unknowns"], 51)
+    band4 = engine.colloc_elimination_info([11, 7, 7, 9], structured=0)
+    assert (band4["nk"], band4["kb"], band4["alg_bytes"]) == (12350, 298, 3 * 12350 * (3 * 298 + 1) * 8) and info4["alg_bytes"] < band4["alg_bytes"] / 4
     for c in (c1, c3):
         r = c["roofline"]
-        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["unit"] == "GB/s"
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["unit"] == "GB/s" and r["kernel"] == "colloc_kernel"
+        # `frac` follows from the line's own numbers: algorithmic bytes of the eliminations run / the launch time / the roof
+        secs = c["colloc_s"] if c is c1 else c["joint_s"]
+        assert abs(r["frac"] - r["alg_bytes"] / secs / 1e9 / 8000.0) < 1e-12 and "cfz_colloc_elimination_info" in r["alg_bytes_definition"]
+        assert "traffic" in r and "valu_active_frac" in r and "traffic_source" in r  # (filled when profiles/<tag>_extras_* of these sources exist)
+    assert abs(c1["roofline"]["alg_bytes"] - sum(engine.colloc_elimination_info([n])["alg_bytes"] for n in (11, 7, 7, 9)) * 2 * c1["colloc_iters_mean"]) < 1e-6 * c1["roofline"]["alg_bytes"]
+    # BASELINE.md section 4's config-2 draw (lane poses, default_rng(1234), MPC form, four obstacles): its own line, checked against the port
+    ls = c1["lane_sampler"]
+    assert "default_rng(1234)" in ls["workload"] and ls["converged"] >= 250 and ls["solves_per_s_kernel"] >= ls["solves_per_s"] > 1e3
+    assert ls["cpu_baseline"]["kind"] == "port" and ls["cpu_baseline"]["same_status_and_iterations"] == 256 and 3 <= ls["iters_mean"] <= ls["iters_max"] <= 200

@@ -36,3 +36,27 @@ def test_cpu_baseline_reports_the_cores_it_used():
     cb = bench.cpu_baseline(2, 2, n_scen_per_core=4, max_cores=4)
     assert cb["kind"] == "port" and cb["unit"] == "solves/s" and 1 <= cb["cores"] <= min(4, n) and cb["value"] > 10.0
     assert cb["cpu"]["model"] == info["model"] and cb["value_converged"] <= cb["value"] and "usable" in cb["sample"]
+
+
+def test_lane_sampler_and_elimination_info():
+    """BASELINE.md section 4's config-2 draw (`scenarios.lane_sampler`): the poses are the stated distributions under default_rng(1234),
+    the references stay in the lane; `cfz_colloc_elimination_info` (host arithmetic) prices the eliminations that are actually run."""
+    import numpy as np
+
+    from conflict_rez_amd import engine, scenarios
+
+    spec = scenarios.parking_lot_spec(n_obs=4, n_nbr=0)
+    x0, ref, zu = scenarios.lane_sampler(spec)
+    assert x0.shape == (256, 5) and ref.shape == (256, 3, 30) and zu.shape == (256, 7, 30)
+    rng = np.random.default_rng(1234)
+    assert np.array_equal(x0[:, 0], rng.uniform(5.0, 30.0, 256)) and np.array_equal(x0[:, 1], rng.uniform(15.0, 20.0, 256))
+    assert 5.0 <= x0[:, 0].min() and x0[:, 0].max() <= 30.0 and np.abs(x0[:, 3]).max() <= 1.0 and np.all(x0[:, 4] == 0.0)
+    off = np.minimum(np.abs(x0[:, 2]), np.abs(x0[:, 2] - np.pi))
+    assert off.max() < 0.25 and 14.9 < ref[:, 1].min() and ref[:, 1].max() < 20.1
+    assert np.allclose(np.hypot(np.diff(ref[:, 0], axis=1), np.diff(ref[:, 1], axis=1)), 0.1, atol=1e-3)  # 1 m/s along the lane
+    one = engine.colloc_elimination_info([11])
+    band = engine.colloc_elimination_info([11], structured=0)
+    assert (one["nk"], one["kb"]) == (band["nk"], band["kb"]) == (engine.colloc_band_info([11])[0], 51) and one["alg_bytes"] < band["alg_bytes"]
+    four = engine.colloc_elimination_info([11, 7, 7, 9])
+    assert four["kb"] == 51 and four["nk"] == engine.colloc_band_info([11, 7, 7, 9])[0] - 16 * 30 and four["workspace_bytes"] < 60e6
+    assert bench.profiled_extras(0, require_current=False) is None or "traffic" in bench.profiled_extras(0, require_current=False)
