@@ -1554,11 +1554,11 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
   // no_prox bit 2: the structured elimination of cfz_struct.inl (single-vehicle plans in the ordering of half-bandwidth kCB)
-  const bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB;
+  bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB;
   const bool jstructured = jstruct_mode(sp);  // (the caller sized the slab with kb = kCB: half_bandwidth())
   SWork SW = {};
   JWork JW = {};
-  if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); }
+  if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); if (SW.flag[1] != 0.0) structured = false; }  // (not the layout cfz_struct.inl assumes: the band elimination)
   if (jstructured) { JW = jstruct_carve(sp, w.sw); jstruct_setup(sp, d, w, JW); }
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
   CFZP_SYNC();

@@ -241,6 +241,10 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   hipFuncAttributes fa;
   HIP_OK(hipFuncGetAttributes(&fa, (const void *)state_ws_kernel<true>));
   HIP_OK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, w->device));
+  {  // gfx950: a workgroup may own the whole LDS of its CU; some runtimes report the smaller legacy figure per block (as in colloc_run)
+    int per_cu = 0;
+    if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, w->device) == hipSuccess) lds_max = std::max(lds_max, per_cu);
+  }
   HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
   const bool want_lds = po->kernel == CFZ_KERNEL_WIDE || (po->kernel == CFZ_KERNEL_AUTO && B <= cus);
   const bool fast = want_lds && lds_bytes + fa.sharedSizeBytes <= (size_t)lds_max &&

@@ -2139,7 +2139,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   if (__builtin_expect(want_resto == 0, 1)) break;
   {
     const int r = restore_instance(sp, dv, CFZ_WSP(m), L, mu, iter);
-    if (r < 0) { status = 5; iter = -r - 1; break; }
+    if (r < 0) { iter = -r - 1; status = iter >= sp.max_iter ? 1 : 5; break; }  // (out of iterations inside the restoration: the limit, not local infeasibility)
     cold_multipliers(sp, CFZ_WSP(m), L, mu);
     if (want_resto == 1) { iter0 = r - 1; iter = iter0; }  // the first iteration again, from the restored point
     else {  // the iteration of the failed line search is counted; the filter and the stall tests start afresh

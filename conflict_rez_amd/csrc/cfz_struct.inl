@@ -50,6 +50,8 @@ CFZP_FN SWork struct_carve(const CSpec &sp, double *p) {
 // cl[24 i + q]: q < 7 the positions of pt0 of interval i; 7 <= q < 21 the coupled positions of separator i + 1, -1 = none
 CFZP_FN void struct_setup(const CSpec &sp, const CDims &d, const CWork &w, const SWork &s) {
   const int N = sp.N[0];
+  CFZP_LANE_FOR(one, 0, 0) s.flag[1] = 0.0;
+  CFZP_SYNC();
   CFZP_LANE_FOR(i, 0, N - 1) {
     const int pe = w.posx[7 * (kPts * i + 5) + 6];  // the steering rate of the interval's last point: first position of separator i + 1
     s.ps[i + 1] = pe;
@@ -65,6 +67,18 @@ CFZP_FN void struct_setup(const CSpec &sp, const CDims &d, const CWork &w, const
       for (int c = 0; c < 5; ++c) if (w.posc[d.rF + c] >= 0 && q < 21) cl[q++] = w.posc[d.rF + c];
     }
     while (q < 24) cl[q++] = -1;
+    // the layout the phases below assume (a changed ordering or row set must not turn into a wrong Newton step): interiors of
+    // exactly 64 unknowns behind pt0, separators of 1..31 unknowns, the right coupling list complete (the loops above stop at 21 entries)
+    bool ok = pe == w.posx[7 * (kPts * i + 1)] + kSI && cl[0] == w.posx[7 * (kPts * i + 1)] - 7 && cl[6] == cl[0] + 6;
+    const int lo = i == 0 ? 0 : w.posx[7 * (kPts * (i - 1) + 5) + 6];  // first position of separator i
+    ok = ok && cl[0] - lo + 7 >= 1 && cl[0] - lo + 7 <= kSS - 1;
+    if (i + 1 == N) {
+      int need = 1;
+      for (int T = d.coff[0]; T < d.coff[1]; ++T) if (chk_point(sp, d, T) == kPts * N - 1) need += 8;
+      for (int c = 0; c < 5; ++c) if (w.posc[d.rF + c] >= 0) ++need;
+      ok = ok && need <= kSRt && d.nk - pe >= 1 && d.nk - pe <= kSS - 1;
+    }
+    if (!ok) s.flag[1] = 1.0;
   }
   CFZP_SYNC();
 }

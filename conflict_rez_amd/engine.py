@@ -245,7 +245,7 @@ def state_ws_default_guess(init_pose, tube, final_heading=None, N=30):
 def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=None, **options):
     """`cfz_state_ws`: the warm-start plans of several vehicles in one launch.
     init_poses [B][3]; tubes: per vehicle a list over strategy steps 1.. of ((A_back, b_back), (A_front, b_front));
-    guesses: per vehicle an array [T+1, 3] of x, y, psi, or None (for all: then every vehicle starts from `state_ws_default_guess`);
+    guesses: per vehicle an array [T+1, 3] of x, y, psi, or None (that vehicle then starts from `state_ws_default_guess`);
     final_headings: per vehicle a float or None.
     options: fields of `cfz_plan_options` (N, dt, wb, shrink_tube, bounded_input, max_iter, tol, ...).
     Returns a list of dict(traj [T+1,7], status, iters, cost)."""
@@ -265,8 +265,12 @@ def state_ws(init_poses, tubes, guesses=None, final_headings=None, device=0, ws=
     init = _f64(np.asarray(init_poses, float), (B, 3))
     fh = np.array([np.nan if (final_headings is None or final_headings[b] is None) else float(final_headings[b]) for b in range(B)])
     guess = None
-    if guesses is not None and all(g is not None for g in guesses):
-        guess = np.ascontiguousarray(np.concatenate([np.asarray(g, float)[: T[b] + 1, :3] for b, g in enumerate(guesses)]))
+    if guesses is not None and any(g is not None for g in guesses):
+        # a mixed batch (the reference's own `spline_ws_config`: vehicle_0 without a spline guess, the others with one): the vehicles
+        # without a guess get the one the library would build for them, the others keep theirs (they used to lose it)
+        gs = [np.asarray(g, float)[: T[b] + 1, :3] if g is not None else
+              state_ws_default_guess(init[b], tubes[b], None if np.isnan(fh[b]) else float(fh[b]), N=po.N) for b, g in enumerate(guesses)]
+        guess = np.ascontiguousarray(np.concatenate(gs))
         assert guess.shape[0] == int((T + 1).sum())
     traj = np.zeros((int((T + 1).sum()), 7))
     status, iters, cost = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B)

@@ -723,7 +723,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
       iter0 = rit;
     }
   }
-  if (locally_infeasible) { status = 5; iter = iter0; }
+  if (locally_infeasible) { status = iter0 >= sp->max_iter ? 1 : 5; iter = iter0; } /* (out of iterations inside the restoration: the limit, not local infeasibility) */
   for (iter = iter0; iter <= sp->max_iter && !locally_infeasible; ++iter) {
     /* ---- working set: rows keep slack and multipliers while their (face, vertex) identity lasts */
     int ws_changed = 0;
@@ -967,7 +967,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
           nfilt = 0; stall_ref = INFINITY; stall_cnt = 0; stall_ws = 0; best_err = INFINITY; best_it = iter;
           continue;
         }
-        status = 5; break; /* the restoration failed: locally infeasible */
+        status = iter >= sp->max_iter ? 1 : 5; break; /* the restoration failed: locally infeasible -- or simply out of iterations */
       }
       status = 2; break;
     }

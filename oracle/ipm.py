@@ -224,8 +224,8 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
     can_restore = opt.restoration > 0 and hasattr(nlp, "restore")
     if can_restore and opt.resto_first > 0.0 and nlp.start_violation(x) > opt.resto_first:  # at the pushed start
         ok, x, it0 = nlp.restore(x, mu, opt, 0)
-        if not ok:
-            return dict(X=x, nu=nu, zl=zl, zu=zu, status=STATUS_STALLED, iters=it0, mu=mu, err=np.inf, f=nlp.f(x), shifted=False)
+        if not ok:  # (a restoration that runs into the solve's iteration limit is the limit, status 1, not local infeasibility: ADVICE r4)
+            return dict(X=x, nu=nu, zl=zl, zu=zu, status=1 if it0 >= opt.max_iter else STATUS_STALLED, iters=it0, mu=mu, err=np.inf, f=nlp.f(x), shifted=False)
         x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)
     it = it0 - 1
     while it < opt.max_iter:
@@ -382,7 +382,7 @@ def solve(nlp, X0, opt: IpmOptions = IpmOptions(), trace=None, warm=None):
             ok, x, rit = nlp.restore(x, mu, opt, it)
             it += rit
             if not ok:
-                status = STATUS_STALLED
+                status = 1 if it >= opt.max_iter else STATUS_STALLED
                 break
             resto_calls += 1
             x, zl, zu, nu = nlp.cold_multipliers(x, mu, opt)

@@ -1,0 +1,65 @@
+"""The Jacobi closed loop of the bench workload, looked at from outside: S scenarios x 4 vehicles, K stepwise MPC iterations on the planned
+table (the bench's sampler), after every iteration the driven states' body polygons.  Prints how many vehicle pairs overlap, by how much, and
+how that relates to the status of the two solves that produced the states.   python tools/closed_loop_separation.py [S=256] [K=25] [seed=2024]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from conflict_rez_amd import engine, scenarios
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 2024
+
+
+def body_polygons(state, g=(3.3, 0.9, 0.6, 0.9)):
+    """state [..., 5] -> vertices [..., 4, 2]."""
+    c, s = np.cos(state[..., 2]), np.sin(state[..., 2])
+    bv = np.array([[g[0], g[1]], [-g[2], g[1]], [-g[2], -g[3]], [g[0], -g[3]]])
+    x = state[..., 0, None] + c[..., None] * bv[:, 0] - s[..., None] * bv[:, 1]
+    y = state[..., 1, None] + s[..., None] * bv[:, 0] + c[..., None] * bv[:, 1]
+    return np.stack([x, y], -1)
+
+
+def separation(P, Q):
+    """Largest gap along the face normals of two batches of convex quadrilaterals [n, 4, 2]: > 0 separated by at least that (a lower bound
+    of the distance), < 0: the polygons overlap (separating-axis theorem)."""
+    best = np.full(len(P), -np.inf)
+    for A, B in ((P, Q), (Q, P)):
+        e = np.roll(A, -1, 1) - A
+        n = np.stack([e[..., 1], -e[..., 0]], -1)
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        pa = np.einsum("nfd,nvd->nfv", n, A).max(-1)
+        pb = np.einsum("nfd,nvd->nfv", n, B).min(-1)
+        best = np.maximum(best, (pb - pa).max(-1))
+    return best
+
+
+def run(S, K, seed):
+    spec = scenarios.parking_lot_spec()
+    table, _ = scenarios.load_reference_table(kind="planned")
+    k0, noise = scenarios.sample_scenarios(S, table, seed=seed, spec=spec)
+    eng = engine.Engine(spec, max_batch=S * 4)
+    eng.loop_init(table, k0, noise)
+    rows = []
+    prev_status = None
+    for t in range(K):
+        eng.loop_step()
+        o = eng.loop_get()
+        pol = body_polygons(o["state"])  # [S, 4, 4, 2]
+        for a in range(4):
+            for b in range(a + 1, 4):
+                sep = separation(pol[:, a], pol[:, b])
+                both = (o["status"][:, a] == 0) & (o["status"][:, b] == 0)
+                rows.append((t, a, b, sep, both))
+        prev_status = o["status"]
+    eng.close()
+    return rows
+
+
+if __name__ == "__main__":
+    rows = run(S, K, seed)
+    sep = np.concatenate([r[3] for r in rows]); both = np.concatenate([r[4] for r in rows])
+    print(f"{S} scenarios x {K} iterations: {len(sep)} vehicle pairs; overlapping {int((sep < 0).sum())} ({(sep < 0).mean():.2e}), of them with both solves converged {int(((sep < 0) & both).sum())}")
+    for thr in (0.0, -0.005, -0.01, -0.02, -0.05):
+        print(f"  separation < {thr:+.3f} m: all {int((sep < thr).sum())}, both converged {int(((sep < thr) & both).sum())}")
+    print(f"  smallest separation with both converged {sep[both].min():+.4f} m, overall {sep.min():+.4f} m; pairs closer than dmin = 0.05 with both converged: {int(((sep < 0.05) & both).sum())}")
