@@ -6,9 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from conflict_rez_amd import engine, scenarios
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-seed = int(sys.argv[3]) if len(sys.argv) > 3 else 2024
 
 
 def body_polygons(state, g=(3.3, 0.9, 0.6, 0.9)):
@@ -57,6 +54,9 @@ def run(S, K, seed):
 
 
 if __name__ == "__main__":
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 2024
     rows = run(S, K, seed)
     sep = np.concatenate([r[3] for r in rows]); both = np.concatenate([r[4] for r in rows])
     print(f"{S} scenarios x {K} iterations: {len(sep)} vehicle pairs; overlapping {int((sep < 0).sum())} ({(sep < 0).mean():.2e}), of them with both solves converged {int(((sep < 0) & both).sum())}")
