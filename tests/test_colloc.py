@@ -573,7 +573,8 @@ def test_structured_elimination_on_short_plans(plans):
                 assert (rc["status"], rc["iters"]) == (s1["status"], s1["iters"]), (a, S, fh, rc["status"], rc["iters"], s1["status"], s1["iters"])
                 if rc["status"] == 0:
                     # (measured: 1.7e-6 at worst on these short, badly determined plans -- 5 intervals stop at tol = 1e-2 with flat directions)
-                    assert np.abs(rc["X"][: nlp.iDt].reshape(-1, 7) - s1["traj"].reshape(-1, 7)).max() < 1e-5 and abs(rc["X"][nlp.iDt] - s1["dt"]) < 1e-7
+                    dcol = np.abs(rc["X"][: nlp.iDt].reshape(-1, 7) - s1["traj"].reshape(-1, 7)).max(0)
+                    assert dcol[:5].max() < 1e-5 and dcol[5:].max() < 1e-3 and abs(rc["X"][nlp.iDt] - s1["dt"]) < 1e-6, (a, S, fh, dcol, rc["X"][nlp.iDt] - s1["dt"])
     assert 0 in seen
 
 
