@@ -5,7 +5,7 @@
 
 namespace cfzb {
 
-struct Band { double *ab; int kb, ld; };
+struct Band { double *ab; int kb, ld, off; };  // entry (i, j) at ab[j * ld + off + i - j]; the band eliminations: off = 2 kb, ld = 3 kb + 1 (room for the fill); the structured ones only read it: off = kb, ld = 2 kb + 1
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // The eliminations are functions of their own (registers of their own: inlined into a solver their loops reloaded spilled values from

@@ -497,7 +497,7 @@ CFZP_FN int half_bandwidth(const CSpec &sp, const int *posx, const int *posc) {
 }
 
 using cfzb::Band;
-CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld + (2 * B.kb + i - j)]; }
+CFZP_FN double &bnd(const Band &B, int i, int j) { return B.ab[(size_t)j * B.ld + (B.off + i - j)]; }
 CFZP_FN void put(const Band &B, int i, int j, double v) { bnd(B, i, j) += v; if (i != j) bnd(B, j, i) += v; }
 
 struct CWork {
@@ -1548,7 +1548,9 @@ template <int MODE>
 CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int *out_i, double *out_d, int lds_doubles, int lds_rhs = 0) {
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
-  const Band Bd = {w.ab, kb, 3 * kb + 1};
+  // the structured eliminations never factor the band in place: no room for fill (a third less to clear and to stream per assembly)
+  const bool compact = (sp.no_prox & 4) && (jstruct_mode(sp) || (sp.V == 1 && kb == kCB));
+  const Band Bd = {w.ab, kb, compact ? 2 * kb + 1 : 3 * kb + 1, compact ? kb : 2 * kb};
   const int n = d.n, m = d.m;
   const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   build_order(sp, w.posx, w.posc);

@@ -126,16 +126,16 @@ CFZP_FN void jstruct_setup(const CSpec &sp, const CDims &d, const CWork &w, cons
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // interior of (vehicle, interval): rows gathered from the band, coupling columns kept in C, K^-1 [C | b1 b2 | E] to W (row = unknown)
-__device__ __attribute__((noinline)) int jstruct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int pi, const cfzb::glb_i32 *cl,
+__device__ __forceinline__ int jstruct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int off, int pi, const cfzb::glb_i32 *cl,
                                                           const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W) {
   const int lane = threadIdx.x & 63, r = pi + lane;
   double a[kSI + kJR];
 #pragma unroll
-  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0; }
+  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
 #pragma unroll
   for (int q = 0; q < kJC; ++q) {
     const int c = cl[q], dd = r - c;
-    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
+    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
     a[kSI + q] = v;
     C[q * kSI + lane] = v;
   }
@@ -168,7 +168,7 @@ __device__ __attribute__((noinline)) int jstruct_block(const cfzb::glb_f64 *A, c
 // (operands: lane l holds A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15]; result register r of lane l is row (l >> 4) + 4 r,
 // column l & 15).  48 loads, 32 matrix instructions: the 434 dot products of length 64 took 1.3 ms per factorisation as a loop.
 typedef double jstruct_v4 __attribute__((ext_vector_type(4)));
-__device__ __attribute__((noinline)) void jstruct_cw(const cfzb::glb_f64 *C, const cfzb::glb_f64 *W, cfzb::glb_f64 *CW) {
+__device__ __forceinline__ void jstruct_cw(const cfzb::glb_f64 *C, const cfzb::glb_f64 *W, cfzb::glb_f64 *CW) {
   const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
   jstruct_v4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double av[16], b0[16], b1[16];
@@ -192,7 +192,7 @@ __device__ __attribute__((noinline)) void jstruct_cw(const cfzb::glb_f64 *C, con
 // Y = (I + G M)^-1 E'K^-1 [C | b]: M (I + G M)^-1 = (I + M G)^-1 M).  Row (a, i) of matrix and right-hand sides is built in the registers of
 // lane 16 a + i from M's three entries per vehicle for that row and the rows jprow(.) of the interiors' solutions W; nothing but Z is stored.
 // h = 0: the coupling columns of vehicles 0 and 1; h = 1: of vehicles 2 and 3, then b1, b2.
-__device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt, const cfzb::glb_f64 *Wall, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Zt) {
+__device__ __forceinline__ int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt, const cfzb::glb_f64 *Wall, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Zt) {
   const int lane = threadIdx.x & 63, va = lane >> 4, i = lane & 15, V = mt[35];
   const bool real = va < V && t < mt[va] && i < 15;
   const int kk = real ? i / 3 : 0, ii = real ? i - 3 * kk : 0;
@@ -218,6 +218,8 @@ __device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::g
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (b == va) m[b][c] = dg[c];
   double a[kJB + 32];
+  // (built a vehicle's 16 columns at a time, the loads of one batch in flight together and no more: left to itself the compiler issues all
+  // 290 loads of a task at once and spills a hundred registers around them)
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -226,6 +228,7 @@ __device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::g
       if (j < 15) v += m[b][0] * Wb[b][(16 + j) * kSI + pr0] + m[b][1] * Wb[b][(16 + j) * kSI + pr1] + m[b][2] * Wb[b][(16 + j) * kSI + pr2];
       a[16 * b + j] = v;
     }
+    asm volatile("" ::: "memory");
   }
 #pragma unroll
   for (int lc = 0; lc < 28; ++lc) {
@@ -233,6 +236,7 @@ __device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::g
     const cfzb::glb_f64 *Wv = h ? Wb[2 + bl] : Wb[bl];
     const double m0 = h ? m[2 + bl][0] : m[bl][0], m1 = h ? m[2 + bl][1] : m[bl][1], m2 = h ? m[2 + bl][2] : m[bl][2];
     a[kJB + lc] = m0 * Wv[q * kSI + pr0] + m1 * Wv[q * kSI + pr1] + m2 * Wv[q * kSI + pr2];
+    if (lc % 7 == 6) asm volatile("" ::: "memory");
   }
 #pragma unroll
   for (int sr = 0; sr < 2; ++sr) {
@@ -256,7 +260,7 @@ __device__ __attribute__((noinline)) int jstruct_cap(int t, int h, const cfzb::g
 __device__ __forceinline__ int jsep_size_m(const cfzb::glb_i32 *m, int a, int i) { return i == 0 ? 14 : (i < m[a] ? 15 : 5 + m[8 + a]); }
 // Separator block i before the Schur complements, a wavefront per block, lane = row 16 a + la: band entries of the vehicle's own separator,
 // the pair blocks of pt0 (diagonal and off-diagonal parts), identity padding; right-hand sides: zero coupling columns, b1, b2.
-__device__ __attribute__((noinline)) void jstruct_sep_base(int i, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, const cfzb::glb_f64 *pm,
+__device__ __forceinline__ void jstruct_sep_base(int i, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off, const cfzb::glb_f64 *pm,
                                                            const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Di, cfzb::glb_f64 *Ui) {
   const int lane = threadIdx.x & 63, a = lane >> 4, la = lane & 15, V = m[35];
   const bool rowok = a < V && i <= m[a] && la < jsep_size_m(m, a, i);
@@ -266,7 +270,7 @@ __device__ __attribute__((noinline)) void jstruct_sep_base(int i, const cfzb::gl
 #pragma unroll
   for (int lb = 0; lb < 16; ++lb) {
     const int c = ps + lb, dd = r - c;
-    own[lb] = (rowok && lb < jsep_size_m(m, a, i) && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
+    own[lb] = (rowok && lb < jsep_size_m(m, a, i) && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
   }
   double x3[4][3];  // the pair blocks' row of this lane: [other vehicle][column], and the diagonal parts summed into x3[a]
 #pragma unroll
@@ -310,7 +314,7 @@ __device__ __attribute__((noinline)) void jstruct_sep_base(int i, const cfzb::gl
 // vehicle a  T = (C_a'K_a^-1 E) Z[(a, .), :]  is (14 x 15) (15 x 62): four k-steps of four 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (the
 // operands' 16th row / column are zero: the spare column of W, the padding row of Z); each lane then adds its results T - [own column] C'W
 // to the entries they belong to (every entry has one owner; blocks t's pt0 entries and block t + 1's right-coupled entries are disjoint).
-__device__ __attribute__((noinline)) void jstruct_schur(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cmask, const cfzb::glb_f64 *CWall, const cfzb::glb_f64 *Zt,
+__device__ __forceinline__ void jstruct_schur(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cmask, const cfzb::glb_f64 *CWall, const cfzb::glb_f64 *Zt,
                                                         cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us) {
   const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, V = m[35], p0 = t == 0 ? 7 : 8;
   cfzb::glb_f64 *D0 = Ds + (size_t)t * kJB * kJB, *D1 = D0 + kJB * kJB, *U0 = Us + (size_t)t * kJB * kJU, *U1 = U0 + kJB * kJU;
@@ -367,7 +371,7 @@ __device__ __attribute__((noinline)) void jstruct_schur(int t, const cfzb::glb_i
 
 // back-substitution, a wavefront per task, lane = row, every load of a task issued before the first is used:
 // z = M y of interval index t:  Z[:, b] - Z[:, coupling columns] s  (s: the separators' solutions, already at their positions in b1, b2)
-__device__ __attribute__((noinline)) void jstruct_zt(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *Zt, const cfzb::glb_f64 *b1,
+__device__ __forceinline__ void jstruct_zt(int t, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *Zt, const cfzb::glb_f64 *b1,
                                                      const cfzb::glb_f64 *b2, cfzb::glb_f64 *zt) {
   const int lane = threadIdx.x & 63, V = m[35];
   double z1 = Zt[kJYrhs * kJB + lane], z2 = Zt[(kJYrhs + 1) * kJB + lane];
@@ -385,7 +389,7 @@ __device__ __attribute__((noinline)) void jstruct_zt(int t, const cfzb::glb_i32 
   zt[lane] = z1; zt[kJB + lane] = z2;
 }
 // the interior of (vehicle a, interval t):  x = W[:, b] - W[:, C] s - W[:, E] z
-__device__ __attribute__((noinline)) void jstruct_back(int a, int pos0, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *W, const cfzb::glb_f64 *zt, cfzb::glb_f64 *b1,
+__device__ __forceinline__ void jstruct_back(int a, int pos0, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *W, const cfzb::glb_f64 *zt, cfzb::glb_f64 *b1,
                                                        cfzb::glb_f64 *b2) {
   const int lane = threadIdx.x & 63;
   double y1 = W[14 * kSI + lane], y2 = W[15 * kSI + lane];
@@ -400,6 +404,61 @@ __device__ __attribute__((noinline)) void jstruct_back(int a, int pos0, const cf
   b1[pos0 + lane] = y1; b2[pos0 + lane] = y2;  // (interior positions are read by nobody in this phase)
 }
 
+// One call per wavefront and phase, the loop over the wavefront's tasks inside: an out-of-line function that uses the whole register file
+// saves and restores the caller's registers in scratch at entry and exit (60-230 dwords per lane), which per TASK was 20 MB of scratch
+// traffic per Newton system -- 40 % of the elimination's own bytes (profiles/r5a_extras_*: 2.05x the algorithmic bytes moved).
+// an argument that is the same in every lane, moved to scalar registers: a pointer kept in vector registers across a task that wants all
+// 256 of them is spilled and reloaded per task
+template <class T>
+__device__ __forceinline__ T *juni(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int juni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int jveh_of(const cfzb::glb_i32 *m, int it) { int a = 0; while (a + 1 < m[35] && it >= m[36 + a + 1]) ++a; return a; }
+__device__ __attribute__((noinline)) int jstruct_interiors_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
+                                                               const cfzb::glb_i32 *cl, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *W) {
+  int f = 0;
+  m = juni(m); ab = juni(ab); cl = juni(cl); b1 = juni(b1); b2 = juni(b2); Cc = juni(Cc); W = juni(W);
+  w0 = juni(w0); nw = juni(nw); kb = juni(kb); ld = juni(ld); off = juni(off);
+  const int NI = m[36 + m[35]];
+  for (int it = w0; it < NI; it += nw) {
+    const int a = jveh_of(m, it), t = it - m[36 + a];
+    f |= jstruct_interior(ab, kb, ld, off, m[4 + a] + 79 * t + 14, cl + 16 * it, b1, b2, Cc + (size_t)it * kSI * kJC, W + (size_t)it * kSI * kJR);
+  }
+  return f;
+}
+__device__ __attribute__((noinline)) void jstruct_cw_all(int w0, int nw, int NI, const cfzb::glb_f64 *Cc, const cfzb::glb_f64 *W, cfzb::glb_f64 *CW) {
+  for (int it = w0; it < NI; it += nw) jstruct_cw(Cc + (size_t)it * kSI * kJC, W + (size_t)it * kSI * kJR, CW + (size_t)it * kJC * kJR);
+}
+__device__ __attribute__((noinline)) int jstruct_cap_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_f64 *W, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Z) {
+  int f = 0;
+  m = juni(m); W = juni(W); pm = juni(pm); Z = juni(Z); w0 = juni(w0); nw = juni(nw); Nm = juni(Nm);
+  for (int k = w0; k < 2 * Nm; k += nw) f |= jstruct_cap(k >> 1, k & 1, m, W, pm, Z + (size_t)(k >> 1) * kJB * kJB);
+  return f;
+}
+__device__ __attribute__((noinline)) void jstruct_sep_base_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
+                                                               const cfzb::glb_f64 *pm, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us) {
+  for (int i = w0; i <= Nm; i += nw) jstruct_sep_base(i, m, ab, kb, ld, off, pm, b1, b2, Ds + (size_t)i * kJB * kJB, Us + (size_t)i * kJB * kJU);
+}
+__device__ __attribute__((noinline)) void jstruct_schur_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cmask, const cfzb::glb_f64 *CW,
+                                                            const cfzb::glb_f64 *Z, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us) {
+  for (int t = w0; t < Nm; t += nw) jstruct_schur(t, m, cmask, CW, Z + (size_t)t * kJB * kJB, Ds, Us);
+}
+__device__ __attribute__((noinline)) void jstruct_zt_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *Z,
+                                                         const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *zt) {
+  for (int t = w0; t < Nm; t += nw) jstruct_zt(t, m, cl, Z + (size_t)t * kJB * kJB, b1, b2, zt + (size_t)t * 2 * kJB);
+}
+__device__ __attribute__((noinline)) void jstruct_back_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl, const cfzb::glb_f64 *W,
+                                                           const cfzb::glb_f64 *zt, cfzb::glb_f64 *b1, cfzb::glb_f64 *b2) {
+  const int NI = m[36 + m[35]];
+  for (int it = w0; it < NI; it += nw) {
+    const int a = jveh_of(m, it), t = it - m[36 + a];
+    jstruct_back(a, m[4 + a] + 79 * t + 14, cl + 16 * it, W + (size_t)it * kSI * kJR, zt + (size_t)t * 2 * kJB, b1, b2);
+  }
+}
+
 // The recursion over the joint separators, one wavefront per direction, everything between two blocks in registers or in words of
 // global memory that the SAME lane wrote (no hand-off between lanes through memory, no fence): side 0 eliminates blocks i0 .. i1 - 1
 // downwards (block i into i + 1), side 1 blocks i0 .. i1 + 1 upwards (block j into j - 1).  Block i: D_i (column-major), right-hand sides
@@ -409,6 +468,7 @@ __device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1,
                                                        cfzb::glb_f64 *Zl, cfzb::glb_i32 *ordl) {
   const int lane = threadIdx.x & 63, va = lane >> 4, la = lane & 15;
   const int cu = la < 7 ? 7 * va + la : -1;  // this lane's row as a right-coupled row of its block: its column of U
+  Ds = juni(Ds); Us = juni(Us); Zl = juni(Zl); ordl = juni(ordl); side = juni(side); i0 = juni(i0); i1 = juni(i1); V = juni(V); nvp = (unsigned)juni((int)nvp);
   for (int i = i0; side ? i > i1 : i < i1; i += side ? -1 : 1) {
     const cfzb::glb_f64 *Di = Ds + (size_t)i * kJB * kJB, *Ui = Us + (size_t)i * kJB * kJU;
     const int ip = side ? i - 1 : i;                 // the coupling block involved: U_ip couples blocks ip and ip + 1
@@ -551,10 +611,9 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   CFZP_SYNC();
   // ---- phase 1: interiors ---------------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int it = CFZS_WAVE; it < d.NI; it += CFZS_NW) {
-    const int a = veh_of_interval(d, it), t = it - d.off[a];
-    const int f = jstruct_interior((const cfzb::glb_f64 *)B.ab, B.kb, B.ld, s.bs[a] + 79 * t + 14, (const cfzb::glb_i32 *)(s.cl + 16 * it), (const cfzb::glb_f64 *)b1,
-                                   (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)(s.Cc + (size_t)it * kSI * kJC), (cfzb::glb_f64 *)(s.W + (size_t)it * kSI * kJR));
+  {
+    const int f = jstruct_interiors_all(CFZS_WAVE, CFZS_NW, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_i32 *)s.cl,
+                                        (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
@@ -578,8 +637,7 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   if (flag[0] != 0.0) return 1;
   // ---- phase 2a: C'W of every interior; the pair blocks of every interval index ------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int it = CFZS_WAVE; it < d.NI; it += CFZS_NW)
-    jstruct_cw((const cfzb::glb_f64 *)(s.Cc + (size_t)it * kSI * kJC), (const cfzb::glb_f64 *)(s.W + (size_t)it * kSI * kJR), (cfzb::glb_f64 *)(s.CW + (size_t)it * kJC * kJR));
+  jstruct_cw_all(CFZS_WAVE, CFZS_NW, d.NI, (const cfzb::glb_f64 *)s.Cc, (const cfzb::glb_f64 *)s.W, (cfzb::glb_f64 *)s.CW);
 #else
   for (int tt = 0; tt < d.NI * kJC * 31; ++tt) {
     const int it = tt / (kJC * 31), e = tt - it * (kJC * 31), al = e / 31, q = e - al * 31;
@@ -609,9 +667,8 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   CFZJ_TICK(3);
   // ---- phase 2b: the capacitance systems: (I + M G) Z = M E'K^-1 [C | b] --------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int k = CFZS_WAVE; k < 2 * Nm; k += CFZS_NW) {
-    const int t = k >> 1, h = k & 1;
-    const int f = jstruct_cap(t, h, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)w.pm, (cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB));
+  {
+    const int f = jstruct_cap_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)w.pm, (cfzb::glb_f64 *)s.Z);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
@@ -655,13 +712,11 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   // complements of the interiors of interval index i (rows / columns of pt0) and i - 1 (the right-coupled unknowns):
   //   S[(a, al), (b, be)] -= [a == b] C_a'W_a[al, be] - sum_j (C_a'K_a^-1 E)[al, j] Z[(a, j), (b, be)]
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int i = CFZS_WAVE; i <= Nm; i += CFZS_NW)
-    jstruct_sep_base(i, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, (const cfzb::glb_f64 *)w.pm, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
-                     (cfzb::glb_f64 *)(s.Ds + (size_t)i * kJB * kJB), (cfzb::glb_f64 *)(s.Us + (size_t)i * kJB * kJU));
+  jstruct_sep_base_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_f64 *)w.pm, (const cfzb::glb_f64 *)b1,
+                       (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us);
   __syncthreads();
   CFZJ_TICK(7);
-  for (int t = CFZS_WAVE; t < Nm; t += CFZS_NW)
-    jstruct_schur(t, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cmask, (const cfzb::glb_f64 *)s.CW, (const cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB), (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us);
+  jstruct_schur_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cmask, (const cfzb::glb_f64 *)s.CW, (const cfzb::glb_f64 *)s.Z, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us);
 #else
   auto schur = [&](int t, int a, int al, int b, int be) -> double {  // be >= 14: right-hand side be - 14
     const double *CW = s.CW + (size_t)(d.off[a] + t) * kJC * kJR + al * kJR;
@@ -791,15 +846,9 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   }
   CFZP_SYNC();
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int t = CFZS_WAVE; t < Nm; t += CFZS_NW)
-    jstruct_zt(t, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)(s.Z + (size_t)t * kJB * kJB), (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
-               (cfzb::glb_f64 *)(s.zt + (size_t)t * 2 * kJB));
+  jstruct_zt_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)s.Z, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)s.zt);
   __syncthreads();
-  for (int it = CFZS_WAVE; it < d.NI; it += CFZS_NW) {
-    const int a = veh_of_interval(d, it), t = it - d.off[a];
-    jstruct_back(a, s.bs[a] + 79 * t + 14, (const cfzb::glb_i32 *)(s.cl + 16 * it), (const cfzb::glb_f64 *)(s.W + (size_t)it * kSI * kJR), (const cfzb::glb_f64 *)(s.zt + (size_t)t * 2 * kJB),
-                 (cfzb::glb_f64 *)b1, (cfzb::glb_f64 *)b2);
-  }
+  jstruct_back_all(CFZS_WAVE, CFZS_NW, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)s.zt, (cfzb::glb_f64 *)b1, (cfzb::glb_f64 *)b2);
 #else
   jstruct_map(Nm * 2 * kJB, [&](int tt) -> double {  // z = M y of every interval index: Z[:, b] - Z[:, coupling columns] s
     const int t = tt / (2 * kJB), e = tt - t * (2 * kJB), sr = e / kJB, row = e - sr * kJB;

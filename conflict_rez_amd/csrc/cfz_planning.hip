@@ -546,7 +546,8 @@ int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has
   std::vector<int> pos((size_t)d.n + d.m);
   if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
   const int hb = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
-  const size_t ld = 3 * (size_t)hb + 1;
+  const bool compact = structured && (cfzc::jstruct_mode(p) || (V == 1 && hb == cfzc::kCB));  // (as solve_colloc: no room for fill where nothing is factored in place)
+  const size_t ld = compact ? 2 * (size_t)hb + 1 : 3 * (size_t)hb + 1;
   if (nk) *nk = d.nk;
   if (kb) *kb = hb;
   if (band_bytes) *band_bytes = (int64_t)d.nk * (int64_t)ld * 8;

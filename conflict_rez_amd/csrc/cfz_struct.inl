@@ -85,7 +85,7 @@ CFZP_FN void struct_setup(const CSpec &sp, const CDims &d, const CWork &w, const
 
 CFZP_FN double band_at(const Band &B, int n, int i, int j) {
   const int dd = i - j;
-  return (i >= 0 && j >= 0 && i < n && j < n && dd <= B.kb && -dd <= B.kb) ? B.ab[(size_t)j * B.ld + (2 * B.kb + dd)] : 0.0;
+  return (i >= 0 && j >= 0 && i < n && j < n && dd <= B.kb && -dd <= B.kb) ? B.ab[(size_t)j * B.ld + (B.off + dd)] : 0.0;
 }
 
 // dense elimination with partial pivoting of the n x n block in aug[n][ld] with nrhs right-hand sides behind it (ld >= n + nrhs);
@@ -153,17 +153,17 @@ __device__ __forceinline__ int wave_lu_regs(double (&a)[NB + RB], int lane, int 
 // NC coupling columns are live (15 for all intervals but the last: pt0, the steering rate, the next continuity rows; 21 for the last);
 // the right-hand sides follow them in the registers and go to W's columns 21 and 22 either way.
 template <int NC>
-__device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int nk, int pi, const cfzb::glb_i32 *cl,
+__device__ __attribute__((noinline)) int struct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int off, int pi, const cfzb::glb_i32 *cl,
                                                          const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W) {
   constexpr int RB = NC + 2 + (NC & 1);  // (even, as the elimination's template was measured)
   const int lane = threadIdx.x & 63, r = pi + lane;
   double a[kSI + RB];
 #pragma unroll
-  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0; }
+  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
 #pragma unroll
   for (int q = 0; q < kSL + kSRt; ++q) {
     const int c = q < NC ? cl[q] : -1, dd = r - c;
-    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (2 * kb + dd)] : 0.0;
+    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
     if (q < NC) a[kSI + q] = v;
     C[q * kSI + lane] = v;
   }
@@ -229,8 +229,8 @@ CFZP_FN int struct_solve(const CSpec &sp, const CDims &d, const CWork &w, const 
     const cfzb::glb_f64 *ab_ = (const cfzb::glb_f64 *)B.ab, *b1_ = (const cfzb::glb_f64 *)b1, *b2_ = (const cfzb::glb_f64 *)b2;
     const cfzb::glb_i32 *cl_ = (const cfzb::glb_i32 *)(s.cl + 24 * i);
     cfzb::glb_f64 *C_ = (cfzb::glb_f64 *)(s.Ci + (size_t)i * kSI * (kSL + kSRt)), *W_ = (cfzb::glb_f64 *)(s.Wi + (size_t)i * kSI * kSR);
-    const int f = i + 1 < N ? struct_interior<15>(ab_, B.kb, B.ld, nk, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_)
-                            : struct_interior<kSL + kSRt>(ab_, B.kb, B.ld, nk, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_);
+    const int f = i + 1 < N ? struct_interior<15>(ab_, B.kb, B.ld, B.off, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_)
+                            : struct_interior<kSL + kSRt>(ab_, B.kb, B.ld, B.off, s.ps[i + 1] - kSI, cl_, b1_, b2_, C_, W_);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else

@@ -52,7 +52,7 @@ int cfzc_emu_kkt(const cfzc::CSpec *sp, const unsigned char *sel, const double *
   cfzc::build_order(*sp, w.posx, w.posc);
   memcpy(w.x, X, sizeof(double) * d.n); memcpy(w.nu, nu, sizeof(double) * d.m); memcpy(w.sig, sig, sizeof(double) * d.n);
   memcpy(w.sel, sel, d.np * sp->n_obs + d.npp);
-  const cfzc::Band Bd = {w.ab, kb, 3 * kb + 1};
+  const cfzc::Band Bd = {w.ab, kb, 3 * kb + 1, 2 * kb};
   const double hdd = cfzc::assemble(*sp, w, Bd, delta);
   const int nt = d.n + d.m;
   int *nat = (int *)malloc(sizeof(int) * d.nk);  // band position -> natural index

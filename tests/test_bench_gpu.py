@@ -82,7 +82,7 @@ def test_planning_extras_of_the_bench_line():
     # no band across the vehicles (round 4: 12,350 unknowns in a band of half-bandwidth 298, 88 MB per plan)
     from conflict_rez_amd import engine
 
-    assert c3["converged"] == 8 and c3["unknowns"] == 12350 - 16 * 30 and c3["half_bandwidth"] == 51 and c3["band_bytes"] == c3["unknowns"] * (3 * 51 + 1) * 8
+    assert c3["converged"] == 8 and c3["unknowns"] == 12350 - 16 * 30 and c3["half_bandwidth"] == 51 and c3["band_bytes"] == c3["unknowns"] * (2 * 51 + 1) * 8
     assert c3["iters_max"] <= 120 and "structured" in c3["elimination"] and c3["workspace_bytes_per_plan"] < 60e6
     info4 = engine.colloc_elimination_info([11, 7, 7, 9])  # the four vehicles' strategy lengths
     assert (info4["nk"], info4["kb"]) == (c3["unknowns"], 51)
