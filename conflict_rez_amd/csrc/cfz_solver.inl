@@ -1058,6 +1058,131 @@ CFZ_SWEEP riccati_backward(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int
   rP[25] = p0; rP[26] = p1; rP[27] = p2; rP[28] = p3; rP[29] = p4;
 }
 
+// Operands of the sweep in homogeneous coordinates (below), as workspace words or constants, and the sweep itself in plain loops with
+// every sum in the order v_mfma_f64_16x16x4_f64 forms it (k ascending, one fused multiply-add per k onto the accumulator): what the CPU
+// build runs, bit for bit what the matrix-core sweep returns (tools/src/riccati_mfma_bench.hip: 0 of 2,880 gains differ); oracle/cfz_port.c
+// has the same loops.
+struct RicEnt { int off, stride; double c; };  // value at stage k: stride ? m[off + k * stride] : c
+CFZ_FN RicEnt ric_T(int r, int j, double dt, int o_ab, int o_d) {  // T[r][j], r < 6, j < 8
+  RicEnt e = {0, 0, 0.0};
+  if (r >= 6 || j >= 8) return e;
+  if (r == 5) { e.c = j == 5 ? 1.0 : 0.0; return e; }
+  if (j < 5) {
+    e.c = r == j ? 1.0 : 0.0;
+    int idx = -1;
+    if (r == 0 && j >= 2) idx = j - 2; else if (r == 1 && j >= 2) idx = 5 + j - 2; else if (r == 2 && j >= 3) idx = 11 + j - 3;
+    if (idx >= 0) { e.off = o_ab + idx; e.stride = 15; }
+    return e;
+  }
+  if (j == 5) { e.off = o_d + r; e.stride = 5; return e; }
+  const int u = j - 6;
+  if (r < 3) { e.off = o_ab + 5 * r + 3 + u; e.stride = 15; } else e.c = (r - 3 == u) ? dt : 0.0;
+  return e;
+}
+CFZ_FN RicEnt ric_H(int a, int b, int o_hc, int o_gk) {  // Ht[a][b], a, b < 8 (variables z0..z4, 1, u0, u1)
+  RicEnt e = {0, 0, 0.0};
+  if (a < 0 || a >= 8 || b >= 8) return e;
+  if (a > b) { const int t = a; a = b; b = t; }
+  const int za = a < 5 ? a : (a == 5 ? -1 : a - 1), zb = b < 5 ? b : (b == 5 ? -1 : b - 1);  // index in (z, u) = 0..6, -1 = the constant
+  if (za < 0 && zb < 0) return e;
+  if (za < 0 || zb < 0) { e.off = o_gk + (za < 0 ? zb : za); e.stride = kNP; return e; }
+  int idx = -1;
+  if (za == zb) idx = za; else if (za == 0 && zb == 1) idx = 7; else if (za == 0 && zb == 2) idx = 8; else if (za == 1 && zb == 2) idx = 9; else if (za == 3 && zb == 6) idx = 10;
+  if (idx >= 0) { e.off = o_hc + idx; e.stride = 11; }
+  return e;
+}
+CFZ_FN double ric_val(const wsp_f64 *m, const RicEnt &e, int k) { return e.stride ? m[e.off + k * e.stride] : e.c; }
+#if !defined(__HIP_DEVICE_COMPILE__)
+static void riccati_backward_dense(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
+  double P[6][6];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) P[i][j] = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    double T[6][8], Ht[8][8], Y[6][8], M[8][8], V[2][6];
+    for (int r = 0; r < 6; ++r) for (int j = 0; j < 8; ++j) T[r][j] = k < N - 1 ? ric_val(m, ric_T(r, j, dt, o_ab, o_d), k) : 0.0;  // (the terminal stage has no dynamics)
+    for (int a = 0; a < 8; ++a) for (int b = 0; b < 8; ++b) Ht[a][b] = ric_val(m, ric_H(a, b, o_hc, o_gk), k);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) { double s_ = 0.0; for (int q = 0; q < 6; ++q) s_ = fma(P[q][i], T[q][j], s_); Y[i][j] = s_; }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) { double s_ = Ht[i][j]; for (int q = 0; q < 6; ++q) s_ = fma(T[q][i], Y[q][j], s_); M[i][j] = s_; }
+    const double idet = 1.0 / fma(M[6][6], M[7][7], -(M[6][7] * M[7][6]));
+    const double i00 = M[7][7] * idet, i01 = -M[6][7] * idet, i10 = -M[7][6] * idet, i11 = M[6][6] * idet;
+    for (int j = 0; j < 6; ++j) { V[0][j] = fma(i00, M[6][j], i01 * M[7][j]); V[1][j] = fma(i10, M[6][j], i11 * M[7][j]); }
+    for (int g = 0; g < 2; ++g) for (int j = 0; j < 6; ++j) m[o_kk + k * 12 + (j < 5 ? 5 * g + j : 10 + g)] = -V[g][j];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) P[i][j] = fma(-M[7][i], V[1][j], fma(-M[6][i], V[0][j], M[i][j]));
+  }
+  for (int i = 0; i < 5; ++i) { for (int j = 0; j < 5; ++j) m[o_rP + 5 * i + j] = P[i][j]; m[o_rP + 25 + i] = P[5][i]; }
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CFZ_RICCATI_SCALAR)
+// The same sweep on the matrix cores (round 5; tools/src/riccati_mfma_bench.hip is the go / no-go measurement: 1,150 cycles per stage
+// against 1,850 for the one-lane sweep above, gains equal to 9e-16).  The first wavefront, all 64 lanes.  Homogeneous coordinates, variables
+// ordered [z (5), 1, u (2)]:  [z+; 1] = T [z; 1; u],  T = [[A d B], [0 1 0]]  (6 x 8),  Pt = [[P p], [p' 0]]  (6 x 6),
+//   M = T' Pt T + Ht  (8 x 8; Ht = the stage's Hessian with its gradient in row / column 5),   Pt <- M_kk - M_ke M_ee^-1 M_ek,  K = -M_ee^-1 M_ek,
+// as five dependent v_mfma_f64_16x16x4_f64 per stage (result register r of lane l = row (l >> 4) + 4 r, column l & 15):
+//   Y = Pt T     two k-steps; the A operand is Pt's accumulator as it stands (Pt is symmetric: register s of lane l is A[l & 15][(l >> 4) + 4 s]);
+//   M = Tt' Y    two k-steps onto an accumulator that starts as Ht; the B operand is Y's accumulator as it stands; Tt' repeats the rows of
+//                u at rows 8, 9 and (crossed) 12, 13, so that the 16-lane groups 0 and 1 hold M's rows of u in their own registers;
+//   Pt <- M - U V   one k-step: A = -M_ke (groups 0, 1: register 2), B = V = M_ee^-1 M_ek (from registers 2 and 3; M_ee by v_readlane).
+// The operands are built on the fly from the stage data the one-lane sweep reads (15 sensitivities, d, 11 Hessian entries, 7 gradient
+// entries): every lane knows once and for all which workspace word (or constant) each of its eight operand entries is.  The terminal
+// stage is the same step from Pt = 0.  (The CPU build and the oracle run the one-lane algebra: same recursion, sums in another order.)
+typedef double ric_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double ric_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __attribute__((noinline)) void riccati_backward_mfma(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, g = lane >> 4;
+  // row i of Tt' / Ht stands for variable: 0..7 themselves, 8 -> u0, 9 -> u1, 12 -> u1, 13 -> u0, the others are zero rows
+  const int vlo = lo < 8 ? lo : (lo == 8 ? 6 : lo == 9 ? 7 : lo == 12 ? 7 : lo == 13 ? 6 : -1);
+  RicEnt eB[2], eA[2], eH[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    eB[s_] = ric_T(g + 4 * s_, lo, dt, o_ab, o_d);
+    eA[s_] = vlo >= 0 ? ric_T(g + 4 * s_, vlo, dt, o_ab, o_d) : RicEnt{0, 0, 0.0};
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = g + 4 * r, vr = row < 8 ? row : (row == 8 ? 6 : row == 9 ? 7 : row == 12 ? 7 : row == 13 ? 6 : -1);
+    eH[r] = ric_H(vr, lo, o_hc, o_gk);
+  }
+  ric_v4d P = {0.0, 0.0, 0.0, 0.0};
+  int k = N - 1;
+  double b0 = 0.0, b1 = 0.0, a0 = 0.0, a1 = 0.0;  // (the terminal stage has no dynamics: T = 0 against Pt = 0)
+  ric_v4d H = {ric_val(m, eH[0], k), ric_val(m, eH[1], k), ric_val(m, eH[2], k), ric_val(m, eH[3], k)};
+  for (; k >= 0; --k) {
+    ric_v4d Y = {0.0, 0.0, 0.0, 0.0};
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Y, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], b1, Y, 0, 0, 0);
+    ric_v4d M = H;
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Y[0], M, 0, 0, 0);
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Y[1], M, 0, 0, 0);
+    // the next stage's operands: requested now, used after this stage's last matrix instruction
+    const int kn = k > 0 ? k - 1 : 0;
+    const double nb0 = ric_val(m, eB[0], kn), nb1 = ric_val(m, eB[1], kn), na0 = ric_val(m, eA[0], kn), na1 = ric_val(m, eA[1], kn);
+    const ric_v4d nH = {ric_val(m, eH[0], kn), ric_val(m, eH[1], kn), ric_val(m, eH[2], kn), ric_val(m, eH[3], kn)};
+    // M_ee: rows 6, 7 = groups 2, 3, register 1; columns 6, 7
+    const double m66 = ric_lane(M[1], 38), m67 = ric_lane(M[1], 39), m76 = ric_lane(M[1], 54), m77 = ric_lane(M[1], 55);
+    const double idet = 1.0 / fma(m66, m77, -(m67 * m76));  // (explicit fused multiply-adds: the CPU mirrors of this sweep use the same)
+    const double i00 = m77 * idet, i01 = -m67 * idet, i10 = -m76 * idet, i11 = m66 * idet;
+    const double m6 = g == 0 ? M[2] : M[3], m7 = g == 0 ? M[3] : M[2];  // rows of u0, u1 in this group's registers (8 / 12, 13 / 9)
+    const double V = g == 0 ? fma(i00, m6, i01 * m7) : (g == 1 ? fma(i10, m6, i11 * m7) : 0.0);
+    const double U = g < 2 ? -M[2] : 0.0;
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(U, V, M, 0, 0, 0);
+    if (g < 2 && lo < 6) m[o_kk + k * 12 + (lo < 5 ? 5 * g + lo : 10 + g)] = -V;
+    P = M; b0 = nb0; b1 = nb1; a0 = na0; a1 = na1; H = nH;
+  }
+  // value function of stage 0: P (5 x 5, rows 0..3 in register 0 of group = row, row 4 in register 1 of group 0), p = row 5 (register 1 of group 1)
+  if (lo < 5) {
+    m[o_rP + 5 * g + lo] = P[0];
+    if (g == 0) m[o_rP + 20 + lo] = P[1];
+    if (g == 1) m[o_rP + 25 + lo] = P[1];
+  }
+}
+#define CFZ_RICCATI(...) do { if (threadIdx.x < 64) { riccati_backward_mfma(__VA_ARGS__); } __syncthreads(); } while (0)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define CFZ_RICCATI(...) CFZ_SERIAL(riccati_backward(__VA_ARGS__))  // (-DCFZ_RICCATI_SCALAR: the one-lane sweep, for comparison)
+#else
+#define CFZ_RICCATI(...) riccati_backward_dense(__VA_ARGS__)
+#endif
+
 // ------------------------------------------------------------------------------ forward step and costates as scans
 // Once the gains are known the forward sweep is a LINEAR recurrence, z_{k+1} = (A_k + B_k K_k) z_k + (B_k k_k + d_k), and
 // so is the costate sweep, lam_{k-1} = q_k + A_k' lam_k.  Both are prefix compositions of affine maps, done here in
@@ -1452,7 +1577,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
       if (tid < 5) m[L.pi0 + tid] = 0.0;
       for (int i = tid; i < N * 5; i += kNL) m[L.pi + i] = 0.0;
     CFZ_END
-    CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
+    CFZ_RICCATI(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP);
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_WAVE0(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
     CFZ_LANES(tid)
@@ -1996,7 +2121,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     CFZ_END
     CFZ_STAMP(4);  // assembly
     // ---- Riccati backward sweep, forward step, costates (lane 0, out of line) -----------------------------
-    CFZ_SERIAL(riccati_backward(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP));
+    CFZ_RICCATI(CFZ_WSP(m), N, sp.dt, L.ab, L.hc, L.gk, L.d, L.kk, L.rP);
     CFZ_STAMP(11);  // Riccati backward sweep
     // forward step and costates: linear recurrences once the gains are known -> two scans by the first wavefront
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));

@@ -383,50 +383,51 @@ static double pinew[MAXN][5], pi0new[5]; /* multipliers of the dynamics / initia
 
 /* ---------------------------------------------------------------- the Newton system's stage recursion */
 /* Riccati backward sweep over the condensed stage problems (H, gk, Ak, Bk, dk): gains Kk, kf and the value function
- * 0.5 dz'P_k dz + p_k'dz of every stage.  Returns 0 if some stage's Huu is not positive definite. */
-static int riccati_backward(int N) {
+ * 0.5 dz'P_k dz + p_k'dz of every stage.  Returns 0 if some stage's Huu is not positive definite.
+ * Since round 5 the sweep mirrors the kernel's, which runs on the matrix cores (cfz_solver.inl riccati_backward_mfma), BIT FOR BIT: the
+ * stage in homogeneous coordinates, variables ordered [z (5), 1, u (2)],
+ *     [z+; 1] = T [z; 1; u],  T = [[A d B], [0 1 0]],   M = T' Pt T + Ht,   Pt <- M_kk - M_ke M_ee^-1 M_ek,   K = -M_ee^-1 M_ek,
+ * every sum in the order v_mfma_f64_16x16x4_f64 forms it -- k ascending, one fused multiply-add per k onto the accumulator, which starts
+ * as Ht for M and as M for the update -- with the operands the instructions get (Pt read transposed, T's structural entries as the
+ * constants 0, 1, dt).  tools/src/riccati_mfma_bench.hip checks this emulation against the instructions: 0 of 2,880 gains differ. */
+static int riccati_backward(int N, double port_dt) {
   int ok = 1;
-    {
-      int k = N - 1; /* terminal stage: its inputs a,w are costed but drive no dynamics */
-      double R2[2][2] = {{H[k][5][5], H[k][5][6]}, {H[k][6][5], H[k][6][6]}};
-      if (!(R2[0][0] > 0.0 && R2[0][0] * R2[1][1] - R2[0][1] * R2[1][0] > 0.0)) ok = 0;
-      double rhs[2][6], sol[2][6];
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = H[k][5 + a][q]; rhs[a][5] = gk[k][5 + a]; }
-      sym2_solve(R2, &rhs[0][0], 6, &sol[0][0]);
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) Ps[k][i][q] = H[k][i][q] + H[k][5][i] * Kk[k][0][q] + H[k][6][i] * Kk[k][1][q];
-        ps[k][i] = gk[k][i] + H[k][5][i] * kf[k][0] + H[k][6][i] * kf[k][1];
-      }
+  double P[6][6];
+  memset(P, 0, sizeof P);
+  for (int k = N - 1; k >= 0; --k) {
+    double T[6][8], Ht[8][8], Y[6][8], M[8][8], V[2][6];
+    memset(T, 0, sizeof T); memset(Ht, 0, sizeof Ht);
+    if (k < N - 1) { /* (the terminal stage's inputs a, w are costed but drive no dynamics: T = 0 against Pt = 0) */
+      for (int r = 0; r < 5; ++r) { T[r][r] = 1.0; T[r][5] = dk[k][r]; }
+      T[0][2] = Ak[k][0][2]; T[0][3] = Ak[k][0][3]; T[0][4] = Ak[k][0][4];
+      T[1][2] = Ak[k][1][2]; T[1][3] = Ak[k][1][3]; T[1][4] = Ak[k][1][4];
+      T[2][3] = Ak[k][2][3]; T[2][4] = Ak[k][2][4];
+      for (int r = 0; r < 3; ++r) { T[r][6] = Bk[k][r][0]; T[r][7] = Bk[k][r][1]; }
+      T[3][6] = port_dt; T[4][7] = port_dt;
+      T[5][5] = 1.0;
     }
-    for (int k = N - 2; k >= 0; --k) {
-      double PA[5][5], PB[5][2], Pd[5];
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Ak[k][r][q]; PA[i][q] = s; }
-        for (int q = 0; q < 2; ++q) { double s = 0; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * Bk[k][r][q]; PB[i][q] = s; }
-        double s = ps[k + 1][i]; for (int r = 0; r < 5; ++r) s += Ps[k + 1][i][r] * dk[k][r]; Pd[i] = s;
-      }
-      double Huu[2][2], Hux[2][5], hu[2], Hxx[5][5], hx[5];
-      for (int a = 0; a < 2; ++a) {
-        for (int b = 0; b < 2; ++b) { double s = H[k][5 + a][5 + b]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PB[r][b]; Huu[a][b] = s; }
-        for (int q = 0; q < 5; ++q) { double s = H[k][5 + a][q]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * PA[r][q]; Hux[a][q] = s; }
-        double s = gk[k][5 + a]; for (int r = 0; r < 5; ++r) s += Bk[k][r][a] * Pd[r]; hu[a] = s;
-      }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) { double s = H[k][i][q]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * PA[r][q]; Hxx[i][q] = s; }
-        double s = gk[k][i]; for (int r = 0; r < 5; ++r) s += Ak[k][r][i] * Pd[r]; hx[i] = s;
-      }
-      double rhs[2][6], sol[2][6];
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) rhs[a][q] = Hux[a][q]; rhs[a][5] = hu[a]; }
-      if (!(Huu[0][0] > 0.0 && Huu[0][0] * Huu[1][1] - Huu[0][1] * Huu[1][0] > 0.0)) ok = 0;
-      sym2_solve(Huu, &rhs[0][0], 6, &sol[0][0]);
-      for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -sol[a][q]; kf[k][a] = -sol[a][5]; }
-      for (int i = 0; i < 5; ++i) {
-        for (int q = 0; q < 5; ++q) Ps[k][i][q] = Hxx[i][q] + Hux[0][i] * Kk[k][0][q] + Hux[1][i] * Kk[k][1][q];
-        ps[k][i] = hx[i] + Hux[0][i] * kf[k][0] + Hux[1][i] * kf[k][1];
-      }
-      for (int i = 0; i < 5; ++i) for (int q = i + 1; q < 5; ++q) { double s = 0.5 * (Ps[k][i][q] + Ps[k][q][i]); Ps[k][i][q] = Ps[k][q][i] = s; }
+    { /* Ht: the stage's Hessian in its pattern (diagonal, the pose block, the v-w cross term), the gradient in row / column 5 */
+      static const int zu[8] = {0, 1, 2, 3, 4, -1, 5, 6};
+      for (int a = 0; a < 8; ++a)
+        for (int b = 0; b < 8; ++b) {
+          const int za = zu[a], zb = zu[b];
+          if (za < 0 && zb < 0) continue;
+          if (za < 0 || zb < 0) { Ht[a][b] = gk[k][za < 0 ? zb : za]; continue; }
+          const int lo = za < zb ? za : zb, hi = za < zb ? zb : za;
+          if (lo == hi || (lo == 0 && hi == 1) || (lo == 0 && hi == 2) || (lo == 1 && hi == 2) || (lo == 3 && hi == 6)) Ht[a][b] = H[k][lo][hi];
+        }
     }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) { double s_ = 0.0; for (int q = 0; q < 6; ++q) s_ = fma(P[q][i], T[q][j], s_); Y[i][j] = s_; }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) { double s_ = Ht[i][j]; for (int q = 0; q < 6; ++q) s_ = fma(T[q][i], Y[q][j], s_); M[i][j] = s_; }
+    const double det = fma(M[6][6], M[7][7], -(M[6][7] * M[7][6]));
+    if (!(M[6][6] > 0.0 && det > 0.0)) ok = 0;
+    const double idet = 1.0 / det;
+    const double i00 = M[7][7] * idet, i01 = -M[6][7] * idet, i10 = -M[7][6] * idet, i11 = M[6][6] * idet;
+    for (int j = 0; j < 6; ++j) { V[0][j] = fma(i00, M[6][j], i01 * M[7][j]); V[1][j] = fma(i10, M[6][j], i11 * M[7][j]); }
+    for (int a = 0; a < 2; ++a) { for (int q = 0; q < 5; ++q) Kk[k][a][q] = -V[a][q]; kf[k][a] = -V[a][5]; }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) P[i][j] = fma(-M[7][i], V[1][j], fma(-M[6][i], V[0][j], M[i][j]));
+    for (int i = 0; i < 5; ++i) { for (int q = 0; q < 5; ++q) Ps[k][i][q] = P[i][q]; ps[k][i] = P[5][i]; }
+  }
   return ok;
 }
 
@@ -540,7 +541,7 @@ static int restore(const cfz_port_spec *sp, const double *x0, const double *nbr,
     if (vmax <= 0.9 * vref || vmax <= vgoal) { vref = vmax; ref_it = rit; }
     if (rit - ref_it >= RESTO_STALL) return 0;
     if (rit == RESTO_MAX_ITER || *iter >= sp->max_iter) return 0;
-    riccati_backward(N);
+    riccati_backward(N, sp->dt);
     riccati_forward(N, x0);
     double dphi = 0.0, pim = 0.0;
     for (int i = 0; i < 5; ++i) pim = fmax(pim, fabs(pi0new[i]));
@@ -901,7 +902,7 @@ int cfz_port_solve_carry(const cfz_port_spec *sp, const double *x0, const double
         H[k][0][0] += th * cxx; H[k][1][1] += th * cyy; H[k][0][1] += th * cxy; H[k][1][0] += th * cxy;
       }
     }
-    riccati_backward(N);
+    riccati_backward(N, sp->dt);
     /* ---- forward sweep: dp, new multipliers ------------------------------------------------ */
     riccati_forward(N, x0);
     for (int i = 0; i < 5; ++i) dt_.pi0[i] = pi0new[i] - it.pi0[i];

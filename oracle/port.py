@@ -18,7 +18,14 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = _LIB + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", tmp, src, "-lm"])
+        # -mfma where the host has it: the Riccati sweep mirrors the kernel's matrix instructions with fma() per term (libm's software fma is
+        # exact too, and fifty times slower); -ffp-contract=off: no other product-sum may be fused behind the source's back
+        has_fma = False
+        try:
+            has_fma = " fma " in open("/proc/cpuinfo").read()
+        except OSError:
+            pass
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off"] + (["-mfma"] if has_fma else []) + ["-fPIC", "-shared", "-o", tmp, src, "-lm"])
         os.replace(tmp, _LIB)
     return _LIB
 

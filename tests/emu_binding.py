@@ -27,7 +27,8 @@ def build(force=False, sanitize=False):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined"] if sanitize else ["-O2"]
         tmp = lib + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
-        subprocess.check_call(["g++", *flags, "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        fma_ = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []  # (the Riccati sweep's fma() per term: hardware where there is one; as oracle/port.py)
+        subprocess.check_call(["g++", *flags, "-ffp-contract=off", *fma_, "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, srcs[0]])
         os.replace(tmp, lib)
     return lib
 
