@@ -113,19 +113,44 @@ __global__ __launch_bounds__(64) void bench(const double *data, double *gains_s,
     double b0 = oB[0] >= 0 ? st[oB[0]] : 0.0, b1 = oB[1] >= 0 ? st[oB[1]] : 0.0, a0 = oA[0] >= 0 ? st[oA[0]] : 0.0, a1 = oA[1] >= 0 ? st[oA[1]] : 0.0;
     v4d H = {oH[0] >= 0 ? st[oH[0]] : 0.0, oH[1] >= 0 ? st[oH[1]] : 0.0, oH[2] >= 0 ? st[oH[2]] : 0.0, oH[3] >= 0 ? st[oH[3]] : 0.0};
     for (int k = NS - 1; k >= 0; --k) {
-      v4d Y = {0.0, 0.0, 0.0, 0.0};
+#ifndef RIC_VARIANT
+#define RIC_VARIANT 0
+#endif
+      const v4d Z4 = {0.0, 0.0, 0.0, 0.0};
+#if RIC_VARIANT == 1
+      const v4d Ya = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Z4, 0, 0, 0);
+      const v4d Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], b1, Z4, 0, 0, 0);
+      const v4d Y = Ya + Yb;
+      const v4d Ma = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Y[0], H, 0, 0, 0);
+      const v4d Mb = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Y[1], Z4, 0, 0, 0);
+      v4d M = Ma + Mb;
+#else
+      v4d Y = Z4;
       Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Y, 0, 0, 0);
       Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], b1, Y, 0, 0, 0);
       v4d M = H;
       M = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Y[0], M, 0, 0, 0);
       M = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Y[1], M, 0, 0, 0);
+#endif
       // the next stage's operands: issued now, used after this stage's last matrix instruction
       const double *sn = sd + (k > 0 ? k - 1 : 0) * 112;
       const double nb0 = oB[0] >= 0 ? sn[oB[0]] : 0.0, nb1 = oB[1] >= 0 ? sn[oB[1]] : 0.0, na0 = oA[0] >= 0 ? sn[oA[0]] : 0.0, na1 = oA[1] >= 0 ? sn[oA[1]] : 0.0;
       const v4d nH = {oH[0] >= 0 ? sn[oH[0]] : 0.0, oH[1] >= 0 ? sn[oH[1]] : 0.0, oH[2] >= 0 ? sn[oH[2]] : 0.0, oH[3] >= 0 ? sn[oH[3]] : 0.0};
       // M_ee: rows 6, 7 = groups 2, 3, register 1; columns 6, 7
+#if RIC_VARIANT == 3
+      const double m66 = 2.0 + M[1] * 1e-300, m67 = 0.1, m76 = 0.1, m77 = 3.0;
+#else
       const double m66 = rl(M[1], 38), m67 = rl(M[1], 39), m76 = rl(M[1], 54), m77 = rl(M[1], 55);
+#endif
+#if RIC_VARIANT == 2
+      const double idet = fma(m66, m77, -(m67 * m76)) * 0.25;
+#elif RIC_VARIANT == 4
+      const double det_ = fma(m66, m77, -(m67 * m76));
+      double idet = __builtin_amdgcn_rcp(det_);
+      idet = fma(fma(-det_, idet, 1.0), idet, idet); idet = fma(fma(-det_, idet, 1.0), idet, idet);
+#else
       const double idet = 1.0 / fma(m66, m77, -(m67 * m76));
+#endif
       const double i00 = m77 * idet, i01 = -m67 * idet, i10 = -m76 * idet, i11 = m66 * idet;
       // groups 0, 1: register 2 = row 8 / 9 (u0 / u1), register 3 = row 12 / 13 (u1 / u0)
       const double m6 = g == 0 ? M[2] : M[3], m7 = g == 0 ? M[3] : M[2];
