@@ -1128,25 +1128,38 @@ typedef double ric_v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double ric_lane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// operand entry without a branch: value at stage k = fma(m[off + k stride], mask, c) -- a data entry has mask 1, c 0 (the product with 1 and
+// the sum with 0 are exact); a constant reads a harmless finite word (the stage's first Hessian entry) with mask 0.  The exec-masked loads the
+// `stride ? .. : ..` form compiled to were a third of the sweep's instructions, and the sweep is bound by their issue, not by the five
+// matrix instructions (tools/src/riccati_mfma_bench.hip: 140 instructions per stage)
+struct RicFetch { int addr, stride; double mask, c; };
+__device__ __forceinline__ RicFetch ric_fetch(const RicEnt &e, int k, int o_hc) {
+  RicFetch f;  // (the harmless word: the stage's first Hessian entry, written for every stage and finite)
+  f.stride = e.stride ? e.stride : 11; f.addr = (e.stride ? e.off : o_hc) + k * f.stride; f.mask = e.stride ? 1.0 : 0.0; f.c = e.stride ? 0.0 : e.c;
+  return f;
+}
+__device__ __forceinline__ double ric_get(const wsp_f64 *m, const RicFetch &f) { return fma(m[f.addr], f.mask, f.c); }
 __device__ __attribute__((noinline)) void riccati_backward_mfma(wsp_f64 *m, int N, double dt, int o_ab, int o_hc, int o_gk, int o_d, int o_kk, int o_rP) {
   const int lane = threadIdx.x & 63, lo = lane & 15, g = lane >> 4;
   // row i of Tt' / Ht stands for variable: 0..7 themselves, 8 -> u0, 9 -> u1, 12 -> u1, 13 -> u0, the others are zero rows
   const int vlo = lo < 8 ? lo : (lo == 8 ? 6 : lo == 9 ? 7 : lo == 12 ? 7 : lo == 13 ? 6 : -1);
-  RicEnt eB[2], eA[2], eH[4];
+  int k = N - 1;
+  RicFetch fB[2], fA[2], fH[4];
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_) {
-    eB[s_] = ric_T(g + 4 * s_, lo, dt, o_ab, o_d);
-    eA[s_] = vlo >= 0 ? ric_T(g + 4 * s_, vlo, dt, o_ab, o_d) : RicEnt{0, 0, 0.0};
+    fB[s_] = ric_fetch(ric_T(g + 4 * s_, lo, dt, o_ab, o_d), k > 0 ? k - 1 : 0, o_hc);  // (T is first needed for stage N - 2)
+    fA[s_] = ric_fetch(vlo >= 0 ? ric_T(g + 4 * s_, vlo, dt, o_ab, o_d) : RicEnt{0, 0, 0.0}, k > 0 ? k - 1 : 0, o_hc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = g + 4 * r, vr = row < 8 ? row : (row == 8 ? 6 : row == 9 ? 7 : row == 12 ? 7 : row == 13 ? 6 : -1);
-    eH[r] = ric_H(vr, lo, o_hc, o_gk);
+    fH[r] = ric_fetch(ric_H(vr, lo, o_hc, o_gk), k, o_hc);
   }
   ric_v4d P = {0.0, 0.0, 0.0, 0.0};
-  int k = N - 1;
   double b0 = 0.0, b1 = 0.0, a0 = 0.0, a1 = 0.0;  // (the terminal stage has no dynamics: T = 0 against Pt = 0)
-  ric_v4d H = {ric_val(m, eH[0], k), ric_val(m, eH[1], k), ric_val(m, eH[2], k), ric_val(m, eH[3], k)};
+  ric_v4d H = {ric_get(m, fH[0]), ric_get(m, fH[1]), ric_get(m, fH[2]), ric_get(m, fH[3])};
+  const int kout = o_kk + (lo < 5 ? 5 * g + lo : 10 + g);  // where this lane's gain goes (groups 0, 1, columns 0..5)
+#pragma unroll 2
   for (; k >= 0; --k) {
     ric_v4d Y = {0.0, 0.0, 0.0, 0.0};
     Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Y, 0, 0, 0);
@@ -1154,19 +1167,27 @@ __device__ __attribute__((noinline)) void riccati_backward_mfma(wsp_f64 *m, int 
     ric_v4d M = H;
     M = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Y[0], M, 0, 0, 0);
     M = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Y[1], M, 0, 0, 0);
-    // the next stage's operands: requested now, used after this stage's last matrix instruction
-    const int kn = k > 0 ? k - 1 : 0;
-    const double nb0 = ric_val(m, eB[0], kn), nb1 = ric_val(m, eB[1], kn), na0 = ric_val(m, eA[0], kn), na1 = ric_val(m, eA[1], kn);
-    const ric_v4d nH = {ric_val(m, eH[0], kn), ric_val(m, eH[1], kn), ric_val(m, eH[2], kn), ric_val(m, eH[3], kn)};
+    // the next stage's operands: requested now, used after this stage's last matrix instruction (the last pass re-reads stage 0: harmless)
+    if (k > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fH[r].addr -= fH[r].stride;
+    }
+    const double nb0 = ric_get(m, fB[0]), nb1 = ric_get(m, fB[1]), na0 = ric_get(m, fA[0]), na1 = ric_get(m, fA[1]);
+    const ric_v4d nH = {ric_get(m, fH[0]), ric_get(m, fH[1]), ric_get(m, fH[2]), ric_get(m, fH[3])};
+    if (k > 1) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) { fB[s_].addr -= fB[s_].stride; fA[s_].addr -= fA[s_].stride; }
+    }
     // M_ee: rows 6, 7 = groups 2, 3, register 1; columns 6, 7
     const double m66 = ric_lane(M[1], 38), m67 = ric_lane(M[1], 39), m76 = ric_lane(M[1], 54), m77 = ric_lane(M[1], 55);
     const double idet = 1.0 / fma(m66, m77, -(m67 * m76));  // (explicit fused multiply-adds: the CPU mirrors of this sweep use the same)
     const double i00 = m77 * idet, i01 = -m67 * idet, i10 = -m76 * idet, i11 = m66 * idet;
     const double m6 = g == 0 ? M[2] : M[3], m7 = g == 0 ? M[3] : M[2];  // rows of u0, u1 in this group's registers (8 / 12, 13 / 9)
-    const double V = g == 0 ? fma(i00, m6, i01 * m7) : (g == 1 ? fma(i10, m6, i11 * m7) : 0.0);
+    const double ia = g == 0 ? i00 : i10, ib = g == 0 ? i01 : i11;
+    const double Vf = fma(ia, m6, ib * m7), V = g < 2 ? Vf : 0.0;
     const double U = g < 2 ? -M[2] : 0.0;
     M = __builtin_amdgcn_mfma_f64_16x16x4f64(U, V, M, 0, 0, 0);
-    if (g < 2 && lo < 6) m[o_kk + k * 12 + (lo < 5 ? 5 * g + lo : 10 + g)] = -V;
+    if (g < 2 && lo < 6) m[kout + k * 12] = -V;
     P = M; b0 = nb0; b1 = nb1; a0 = na0; a1 = na1; H = nH;
   }
   // value function of stage 0: P (5 x 5, rows 0..3 in register 0 of group = row, row 4 in register 1 of group 0), p = row 5 (register 1 of group 1)
