@@ -304,7 +304,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
                       int32_t *iters, double *cost) {
   if (!w) return fail("null workspace");
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
-  if (co->kernel < CFZ_KERNEL_AUTO || co->kernel > CFZ_KERNEL_NARROW) return fail("cfz_colloc_options.kernel: 0, 1 or 2 (accepted for compatibility; there is one kernel)");
+  if (co->kernel != CFZ_KERNEL_AUTO) return fail("cfz_colloc_options.kernel: retired with the one-wavefront collocation kernel (round 4); leave it 0");
   HIP_OK(hipSetDevice(w->device));
   if (arena_reset(w->arena)) return -1;
   hipStream_t st = w->stream;

@@ -1159,7 +1159,6 @@ __device__ __attribute__((noinline)) void riccati_backward_mfma(wsp_f64 *m, int 
   double b0 = 0.0, b1 = 0.0, a0 = 0.0, a1 = 0.0;  // (the terminal stage has no dynamics: T = 0 against Pt = 0)
   ric_v4d H = {ric_get(m, fH[0]), ric_get(m, fH[1]), ric_get(m, fH[2]), ric_get(m, fH[3])};
   const int kout = o_kk + (lo < 5 ? 5 * g + lo : 10 + g);  // where this lane's gain goes (groups 0, 1, columns 0..5)
-#pragma unroll 2
   for (; k >= 0; --k) {
     ric_v4d Y = {0.0, 0.0, 0.0, 0.0};
     Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Y, 0, 0, 0);

@@ -295,9 +295,8 @@ typedef struct cfz_colloc_options {
                            *    vertices is constrained by their Euclidean distance -- the reference's OBCA rows admit any unit
                            *    direction (vehicle.py:523-541, multi_vehicle_planner.py:419-451); 0: face-normal certificates only
                            *    (a restriction at corner-to-corner contacts, kept to show the gap) */
-  int32_t kernel;         /* 0, CFZ_KERNEL_WIDE or CFZ_KERNEL_NARROW: accepted for compatibility and without effect since round 4 -- there is
-                           *    one collocation kernel (512 threads per plan); the one-wavefront kernel that CFZ_KERNEL_NARROW named was
-                           *    slower at every batch size and is gone (csrc/cfz_planning.hip) */
+  int32_t kernel;         /* must be 0: the field named the one-wavefront collocation kernel that round 4 retired (slower at every batch size,
+                           *    and not deterministic: docs/notebook.md); any other value is an error since round 5 (the slot keeps the layout) */
   double shrink_tube;     /* :370; 0.5 in plan_single_path */
   double tol;             /* :650 1e-2 */
   double constr_viol_tol; /* :651 1e-2 */
@@ -306,7 +305,11 @@ typedef struct cfz_colloc_options {
   int32_t structured;     /* single-vehicle plans (cfz_colloc): 1 (default) = the Newton system is eliminated interval by interval (the interiors of the
                            *    Radau intervals independently, then a block recursion over the interval starts: csrc/cfz_struct.inl)
                            *    instead of pivot by pivot along the band (0; also what one_pivot = 1 takes); same matrix, same solution to rounding: 3x
-                           *    faster at 256 plans.  Joint plans: ignored */
+                           *    faster at 256 plans.  Joint plans (cfz_joint_colloc), since round 5: 1 = csrc/cfz_jstruct.inl -- vehicle-major
+                           *    ordering (a band of half-bandwidth 51 per vehicle, the condensed pair blocks beside it), tube rows condensed,
+                           *    every vehicle's interiors by themselves, the pair-coupled poses of an interval index through a 64 x 64
+                           *    capacitance system, a block recursion over joint separators of 4 x 15 unknowns; 0 = the band across the
+                           *    vehicles (half-bandwidth ~300, 88 MB per four-vehicle plan) a panel at a time: 4.5x slower */
   int32_t reserved1;
 } cfz_colloc_options;
 

@@ -226,7 +226,7 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
     """A plan's iterates do not depend on the batch it is solved in.  `cfz_plan_options.kernel` moves state_ws' sweep data between LDS
     (default up to one plan per CU) and the workspace (larger batches): same arithmetic, same bits -- the same plan alone and inside a
     batch of more than two plans per CU returns the same status, iteration count and trajectory, pinned or not.  The collocation plan
-    has one kernel since round 4 (`cfz_colloc_options.kernel` is accepted and without effect): alone or in a batch of 520, bit for bit
+    has one kernel since round 4 (`cfz_colloc_options.kernel` other than 0 is an error since round 5): alone or in a batch of 520, bit for bit
     the same plan -- the check that caught the one-wavefront kernel returning two results for identical plans (docs/notebook.md)."""
     from conflict_rez_amd import engine
 
@@ -259,12 +259,13 @@ def test_a_plan_does_not_depend_on_its_batch_when_the_kernel_is_pinned(plans):
     ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
     guess = np.stack([np.interp(ti, t, ws1[:, c]) for c in range(7)], 1)
     cargs = lambda B_: (sp0, [plans[a][1][0]] * B_, [tube] * B_, [guess] * B_, [t[-1] / N] * B_, [fh] * B_)
-    for kern in (engine.KERNEL_AUTO, engine.KERNEL_NARROW):  # (accepted, without effect)
-        one = engine.colloc(*cargs(1), max_iter=400, kernel=kern)[0]
-        many = engine.colloc(*cargs(B), max_iter=400, kernel=kern)
-        assert one["status"] == 0
-        for r in many:  # every plan of the batch, not a sample: the retired kernel differed on about half of them
-            assert (r["status"], r["iters"]) == (one["status"], one["iters"]) and np.array_equal(r["traj"], one["traj"]) and r["dt"] == one["dt"]
+    one = engine.colloc(*cargs(1), max_iter=400)[0]
+    many = engine.colloc(*cargs(B), max_iter=400)
+    assert one["status"] == 0
+    for r in many:  # every plan of the batch, not a sample: the retired kernel differed on about half of them
+        assert (r["status"], r["iters"]) == (one["status"], one["iters"]) and np.array_equal(r["traj"], one["traj"]) and r["dt"] == one["dt"]
+    with pytest.raises(RuntimeError, match="retired"):  # the field that named the retired kernel is an error now, not a silent no-op
+        engine.colloc(*cargs(1), max_iter=400, kernel=engine.KERNEL_NARROW)
     # cfz_plan_ws_trim: the memory the batch left in the thread's workspace goes back; the next call allocates again
     engine.trim_default_workspaces()
     assert np.array_equal(engine.state_ws(*args1, shrink_tube=0.5)[0]["traj"], auto1["traj"])

@@ -22,8 +22,8 @@ ti = (np.arange(N)[:, None] + tau[None, :]).ravel() / N * t[-1]
 guess = np.stack([np.interp(ti, t, ws1[:, c]) for c in range(7)], 1)
 cargs = lambda B_: (sp0, [paths[a][0]] * B_, [tube] * B_, [guess] * B_, [t[-1] / N] * B_, [fh] * B_)
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    for kern in (engine.KERNEL_WIDE, engine.KERNEL_NARROW):
-        one = engine.colloc(*cargs(1), max_iter=400, kernel=kern)[0]
-        many = engine.colloc(*cargs(B), max_iter=400, kernel=kern)
+    for kern, kw in (("structured", dict(structured=1)), ("band", dict(structured=0))):
+        one = engine.colloc(*cargs(1), max_iter=400, **kw)[0]
+        many = engine.colloc(*cargs(B), max_iter=400, **kw)
         bad = [(i, float(np.abs(r["traj"] - one["traj"]).max()), r["iters"]) for i, r in enumerate(many) if not np.array_equal(r["traj"], one["traj"])]
-        print(rep, "wide" if kern == 1 else "narrow", "one iters", one["iters"], "differing plans", len(bad), bad[:6], flush=True)
+        print(rep, kern, "one iters", one["iters"], "differing plans", len(bad), bad[:6], flush=True)

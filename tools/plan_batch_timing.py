@@ -31,7 +31,7 @@ ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh
 t1 = time.time()
 gs = [guess_of(w["traj"], len(tubes[a]) + 1) for w, a in zip(ws, who)]
 good = [i for i, w in enumerate(ws) if w["status"] == 0]  # a vehicle whose warm start failed is not refined (plan_single_path raises there)
-rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=int(os.environ.get("MAXIT", 150)), kernel=int(os.environ.get("KERN", 0)), **MU)
+rg = engine.colloc(sp, [init[i] for i in good], [tubes[who[i]] for i in good], [gs[i][0] for i in good], [gs[i][1] for i in good], [fh[who[i]] for i in good], max_iter=int(os.environ.get("MAXIT", 150)), **MU)
 t2 = time.time()
 res = [None] * B
 for i, r in zip(good, rg):
