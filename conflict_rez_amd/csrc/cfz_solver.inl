@@ -1312,14 +1312,39 @@ CFZ_SCAN forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk,
   const int k = threadIdx.x;
   Aff5 t;
   aff5_stage(m, k, N, dt, o_ab, o_d, o_kk, t);
+  // One Kogge-Stone step in two halves, the partner's vector first and its matrix after: t.v += t.M s.v needs only the five values of
+  // s.v beside t, so that the step's peak is t (30 doubles) + s.M (25) + a row's temporaries instead of t + all of s -- the function then
+  // fits the 144 caller-saved VGPRs of the calling convention and its prologue no longer saves 37 registers per lane to scratch at every
+  // call (= every interior-point iteration: 3.4 GB written per bench launch, profiles/r5c_pmc_WRITE_SIZE.csv).  Same sums in the same
+  // order as aff5_after (which the CPU build calls).
 #pragma unroll
   for (int dd = 1; dd < 32; dd <<= 1) {
-    Aff5 s;
+    {
+      double sv[5];
 #pragma unroll
-    for (int i = 0; i < 25; ++i) s.M[i] = __shfl_up(t.M[i], dd, 64);
+      for (int i = 0; i < 5; ++i) sv[i] = __shfl_up(t.v[i], dd, 64);
+      if (k >= dd) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) s.v[i] = __shfl_up(t.v[i], dd, 64);
-    if (k >= dd) aff5_after(t, s);
+        for (int i = 0; i < 5; ++i)
+          t.v[i] = t.v[i] + t.M[i * 5 + 0] * sv[0] + t.M[i * 5 + 1] * sv[1] + t.M[i * 5 + 2] * sv[2] + t.M[i * 5 + 3] * sv[3] + t.M[i * 5 + 4] * sv[4];
+      }
+    }
+    asm volatile("" ::: "memory");
+    {
+      double sM[25];
+#pragma unroll
+      for (int i = 0; i < 25; ++i) sM[i] = __shfl_up(t.M[i], dd, 64);
+      if (k >= dd) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const double a0 = t.M[i * 5 + 0], a1 = t.M[i * 5 + 1], a2 = t.M[i * 5 + 2], a3 = t.M[i * 5 + 3], a4 = t.M[i * 5 + 4];
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            t.M[i * 5 + j] = a0 * sM[0 * 5 + j] + a1 * sM[1 * 5 + j] + a2 * sM[2 * 5 + j] + a3 * sM[3 * 5 + j] + a4 * sM[4 * 5 + j];
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
   }
   const double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
                z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
