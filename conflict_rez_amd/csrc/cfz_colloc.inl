@@ -145,7 +145,7 @@ struct CDims {
 // The structured elimination of the JOINT plan (cfz_jstruct.inl; CSpec::no_prox bit 2 with V > 1) works on another statement of the same
 // Newton system: positions vehicle-major (build_order), the tube slacks and rows condensed into the pose block they touch like the
 // collision rows (so a vehicle's separators hold at most 15 unknowns), the condensed pair blocks kept beside the band (CWork::pm).
-CFZP_FN bool jstruct_mode(const CSpec &sp) { return (sp.no_prox & 4) != 0 && sp.V > 1; }
+CFZP_FN bool jstruct_mode(const CSpec &sp) { return (sp.no_prox & 4) != 0 && (sp.V > 1 || (sp.no_prox & 8) != 0); }  // (bit 3: single plans too)
 CFZP_FN CDims cdims(const CSpec &sp) {
   CDims d;
   d.V = sp.V; d.off[0] = 0; d.coff[0] = 0;
@@ -1556,8 +1556,8 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
   // no_prox bit 2: the structured elimination of cfz_struct.inl (single-vehicle plans in the ordering of half-bandwidth kCB)
-  bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB;
   const bool jstructured = jstruct_mode(sp);  // (the caller sized the slab with kb = kCB: half_bandwidth())
+  bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB && !jstructured;  // (the caller sized the slab with kb = kCB: half_bandwidth())
   SWork SW = {};
   JWork JW = {};
   if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); if (SW.flag[1] != 0.0) structured = false; }  // (not the layout cfz_struct.inl assumes: the band elimination)
@@ -1660,6 +1660,9 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
       bool solved = false;
       if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (jstructured && sp.V == 1) { fail = jstruct_solve1(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
+#endif
       if (jstructured) { fail = jstruct_solve(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {

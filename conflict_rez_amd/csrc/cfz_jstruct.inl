@@ -57,6 +57,8 @@ CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t
   size_t NI = 0;
   for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
   const size_t Nm = jstruct_nmax(sp);
+  // one vehicle: no capacitance systems, 16 right-hand sides per interior, 16-row separator blocks with 10 right-hand sides
+  if (sp.V == 1) return 2 * nk * ld + 3 * NI * kSI * 16 + 2 * NI * kSI * kJC + 2 * NI * kJC * 16 + 2 * (Nm + 1) * 256 + 4 * (Nm + 1) * 160 + 4 * nk;
   return 2 * nk * ld + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
          2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk;
 }
@@ -583,6 +585,253 @@ CFZP_FN int jstruct_block_serial(double *aug, const double *A, const double *R, 
 // n independent items, item tt: store(tt, load(tt)).  The workgroup is alone on its CU with two wavefronts per SIMD: a loop that issues
 // one item's loads and waits for them is bound by the memory latency (1-2 us per item), so four items' loads are issued before the first
 // is used (clamped index instead of a branch: the loads of all four stand in one block).
+// ---- one vehicle (cfz_colloc, round 5): the same partition without the pair coupling ------------------------------------------------------------
+// No capacitance systems and no E columns: an interior is K^-1 [C | b1 b2] (64 x 64, 16 right-hand sides), the separators are 16-row blocks
+// (15 unknowns, identity-padded) with 7 coupling columns and b1, b2, and their blocks are written with the Schur complements -C'W in place
+// (owner computes).  Compact storage of its own: D1[i][16 x 16], U1[i][16 x 10] (columns 0..6: the coupling with separator i + 1, 7 / 8:
+// b1 / b2), Z1 likewise, lane-major.  It replaces cfz_struct.inl's path (separators of 14-31 with the tube rows inside, a recursion that
+// handed rows over between the lanes of a wavefront through memory) for the product; that file stays for `structured = 2`.
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int kJ1U = 10;
+__device__ __attribute__((noinline)) int j1_interiors_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
+                                                          const cfzb::glb_i32 *cl_, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *Wc) {
+  int f = 0;
+  m = juni(m); ab = juni(ab); cl_ = juni(cl_); b1 = juni(b1); b2 = juni(b2); Cc = juni(Cc); Wc = juni(Wc);
+  w0 = juni(w0); nw = juni(nw); kb = juni(kb); ld = juni(ld); off = juni(off);
+  const int NI = m[0], lane = threadIdx.x & 63;
+  for (int it = w0; it < NI; it += nw) {
+    const int pi = m[4] + 79 * it + 14, r = pi + lane;
+    const cfzb::glb_i32 *cl = cl_ + 16 * it;
+    cfzb::glb_f64 *C = Cc + (size_t)it * kSI * kJC, *W = Wc + (size_t)it * kSI * kJR;
+    double a[kSI + 16];
+#pragma unroll
+    for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < kJC; ++q) {
+      const int c = cl[q], dd = r - c;
+      const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
+      a[kSI + q] = v;
+      C[q * kSI + lane] = v;
+    }
+    a[kSI + 14] = b1[r]; a[kSI + 15] = b2[r];
+    int ord;
+    if (wave_lu_regs<kSI, 16>(a, lane, ord)) { f = 1; continue; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) W[q * kSI + ord] = a[kSI + q];
+  }
+  return f;
+}
+// C'W (14 x 64 x 16): one tile of the matrix cores per interior
+__device__ __attribute__((noinline)) void j1_cw_all(int w0, int nw, int NI, const cfzb::glb_f64 *Cc, const cfzb::glb_f64 *Wc, cfzb::glb_f64 *CWc) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  for (int it = w0; it < NI; it += nw) {
+    const cfzb::glb_f64 *C = Cc + (size_t)it * kSI * kJC, *W = Wc + (size_t)it * kSI * kJR;
+    jstruct_v4 acc = {0.0, 0.0, 0.0, 0.0};
+    double av[16], bv[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { av[kk] = lo < kJC ? C[lo * kSI + 4 * kk + hi] : 0.0; bv[kk] = W[lo * kSI + 4 * kk + hi]; }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int al = hi + 4 * r; if (al < kJC) CWc[(size_t)it * kJC * kJR + al * kJR + lo] = acc[r]; }
+  }
+}
+// separator blocks with the Schur complements in place: four separators per wavefront (lane = 16 x separator-in-group + row)
+__device__ __attribute__((noinline)) void j1_sep_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cmask, const cfzb::glb_f64 *ab, int kb, int ld, int off,
+                                                     const cfzb::glb_f64 *CWc, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *D1, cfzb::glb_f64 *U1) {
+  const int lane = threadIdx.x & 63, la = lane & 15, N = m[0], hf = m[8];
+  for (int i0 = 4 * w0; i0 <= N; i0 += 4 * nw) {
+    const int i = i0 + (lane >> 4);
+    if (i > N) continue;
+    const int ns = i == 0 ? 14 : (i < N ? 15 : 5 + hf), ps = i == 0 ? m[4] : m[4] + 79 * i - 1, p0 = i == 0 ? 7 : 8, r = ps + la;
+    const bool rowok = la < ns, left = rowok && i < N && la >= p0 && la < p0 + 7;
+    const int cmp = i >= 1 ? cmask[i - 1] : 0, cmi = i < N ? cmask[i] : 0;  // (coupling masks of the interiors on either side)
+    const bool right = rowok && i >= 1 && la < 7 && ((cmp >> (7 + la)) & 1);
+    const cfzb::glb_f64 *CWl = CWc + (size_t)(i < N ? i : 0) * kJC * kJR + (left ? la - p0 : 0) * kJR;      // row al = la - p0 of interior i
+    const cfzb::glb_f64 *CWr = CWc + (size_t)(i >= 1 ? i - 1 : 0) * kJC * kJR + (right ? 7 + la : 0) * kJR;  // row al = 7 + la of interior i - 1
+    cfzb::glb_f64 *D = D1 + (size_t)i * 256, *U = U1 + (size_t)i * 16 * kJ1U;
+#pragma unroll
+    for (int lb = 0; lb < 16; ++lb) {
+      double v = la == lb ? 1.0 : 0.0;
+      if (rowok) {
+        const int c = ps + lb, dd = r - c;
+        v = (lb < ns && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
+        if (left && lb >= p0 && lb < p0 + 7) v -= CWl[lb - p0];
+        if (right && lb < 7 && ((cmp >> (7 + lb)) & 1)) v -= CWr[7 + lb];
+      }
+      D[lb * 16 + la] = v;
+    }
+#pragma unroll
+    for (int be = 0; be < 7; ++be) U[be * 16 + la] = (left && ((cmi >> (7 + be)) & 1)) ? -CWl[7 + be] : 0.0;
+#pragma unroll
+    for (int sr = 0; sr < 2; ++sr) {
+      double v = rowok ? (sr ? b2 : b1)[r] : 0.0;
+      if (left) v -= CWl[14 + sr];
+      if (right) v -= CWr[14 + sr];
+      U[(7 + sr) * 16 + la] = v;
+    }
+    U[9 * 16 + la] = 0.0;
+  }
+}
+// the recursion from one end (as jstruct_chain): 16-row blocks, 10 right-hand sides, lanes 16.. idle
+__device__ __attribute__((noinline)) int j1_chain(int side, int i0, int i1, cfzb::glb_f64 *D1, cfzb::glb_f64 *U1, cfzb::glb_f64 *Z1, cfzb::glb_i32 *ordl) {
+  const int lane = threadIdx.x & 63, la = lane & 15;
+  D1 = juni(D1); U1 = juni(U1); Z1 = juni(Z1); ordl = juni(ordl); side = juni(side); i0 = juni(i0); i1 = juni(i1);
+  for (int i = i0; side ? i > i1 : i < i1; i += side ? -1 : 1) {
+    const cfzb::glb_f64 *Di = D1 + (size_t)i * 256, *Ui = U1 + (size_t)i * 16 * kJ1U;
+    const int ip = side ? i - 1 : i, p0 = ip == 0 ? 7 : 8;
+    const cfzb::glb_f64 *Uc = U1 + (size_t)ip * 16 * kJ1U;
+    double a[16 + kJ1U];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = Di[j * 16 + la];
+    if (side == 0) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) a[16 + q] = Ui[q * 16 + la];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) a[16 + q] = la < 7 ? Uc[la * 16 + p0 + q] : 0.0;  // U_{i-1}' (row la of this block = right-coupled unknown la)
+      a[16 + 7] = Ui[7 * 16 + la]; a[16 + 8] = Ui[8 * 16 + la];
+    }
+    a[16 + 9] = 0.0;
+    int ord;
+    if (wave_lu_regs<16, kJ1U>(a, lane, ord)) return 1;
+    cfzb::glb_f64 *Zi = Z1 + (size_t)i * 16 * kJ1U;
+    if (lane < 16) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Zi[q * 16 + lane] = a[16 + q];
+      ordl[i * 16 + lane] = ord;
+    }
+    double acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+    if (side == 0) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        const int lk = (int)__builtin_ctzll(__ballot(ord == p0 + c));
+        const double u = la < 7 ? Uc[la * 16 + p0 + c] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] += u * struct_lane_get(a[16 + q], lk);
+      }
+      if (lane < 7) {
+        cfzb::glb_f64 *Dn = D1 + (size_t)(i + 1) * 256, *Un = U1 + (size_t)(i + 1) * 16 * kJ1U;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) Dn[q * 16 + lane] -= acc[q];
+        Un[7 * 16 + lane] -= acc[7]; Un[8 * 16 + lane] -= acc[8];
+      }
+    } else {
+      const bool isl = lane < 16 && la >= p0 && la < p0 + 7;
+#pragma unroll
+      for (int be = 0; be < 7; ++be) {
+        const int lk = (int)__builtin_ctzll(__ballot(ord == be));
+        const double u = isl ? Uc[be * 16 + la] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] += u * struct_lane_get(a[16 + q], lk);
+      }
+      if (isl) {
+        cfzb::glb_f64 *Dn = D1 + (size_t)ip * 256, *Un = U1 + (size_t)ip * 16 * kJ1U;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) Dn[(p0 + q) * 16 + la] -= acc[q];
+        Un[7 * 16 + la] -= acc[7]; Un[8 * 16 + la] -= acc[8];
+      }
+    }
+  }
+  return 0;
+}
+__device__ __attribute__((noinline)) int j1_chain_mid(int mid, cfzb::glb_f64 *D1, cfzb::glb_f64 *U1, cfzb::glb_f64 *xs) {
+  const int lane = threadIdx.x & 63, la = lane & 15;
+  const cfzb::glb_f64 *Di = D1 + (size_t)mid * 256, *Ui = U1 + (size_t)mid * 16 * kJ1U;
+  double a[16 + 2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = Di[j * 16 + la];
+  a[16] = Ui[7 * 16 + la]; a[17] = Ui[8 * 16 + la];
+  int ord;
+  if (wave_lu_regs<16, 2>(a, lane, ord)) return 1;
+  if (lane < 16) { xs[(size_t)mid * 32 + ord] = a[16]; xs[(size_t)mid * 32 + 16 + ord] = a[17]; }
+  return 0;
+}
+__device__ __attribute__((noinline)) void j1_chain_back(int side, int mid, int N, const cfzb::glb_f64 *Z1, const cfzb::glb_i32 *ordl, cfzb::glb_f64 *xs) {
+  const int lane = threadIdx.x & 63, la = lane & 15;
+  double xp1 = xs[(size_t)mid * 32 + la], xp2 = xs[(size_t)mid * 32 + 16 + la];
+  int ordp = lane < 16 ? lane : -1;
+  for (int i = side ? mid + 1 : mid - 1; side ? i <= N : i >= 0; i += side ? 1 : -1) {
+    const cfzb::glb_f64 *Zi = Z1 + (size_t)i * 16 * kJ1U;
+    const int ip = side ? i - 1 : i, p0 = ip == 0 ? 7 : 8;
+    double x1 = Zi[7 * 16 + la], x2 = Zi[8 * 16 + la];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int r = side ? p0 + q : q;
+      const int lk = (int)__builtin_ctzll(__ballot(ordp == r));
+      const double z = Zi[q * 16 + la];
+      x1 -= z * struct_lane_get(xp1, lk); x2 -= z * struct_lane_get(xp2, lk);
+    }
+    const int ord = lane < 16 ? ordl[i * 16 + lane] : -1;
+    if (lane < 16) { xs[(size_t)i * 32 + ord] = x1; xs[(size_t)i * 32 + 16 + ord] = x2; }
+    xp1 = x1; xp2 = x2; ordp = ord;
+  }
+}
+__device__ __attribute__((noinline)) void j1_back_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_i32 *cl_, const cfzb::glb_f64 *Wc, cfzb::glb_f64 *b1, cfzb::glb_f64 *b2) {
+  const int NI = m[0], lane = threadIdx.x & 63;
+  for (int it = w0; it < NI; it += nw) {
+    const cfzb::glb_i32 *cl = cl_ + 16 * it;
+    const cfzb::glb_f64 *W = Wc + (size_t)it * kSI * kJR;
+    double y1 = W[14 * kSI + lane], y2 = W[15 * kSI + lane];
+#pragma unroll
+    for (int q = 0; q < kJC; ++q) {
+      const int c = cl[q];
+      const double wq = W[q * kSI + lane];
+      y1 -= wq * (c >= 0 ? b1[c] : 0.0); y2 -= wq * (c >= 0 ? b2[c] : 0.0);
+    }
+    const int p = m[4] + 79 * it + 14 + lane;
+    b1[p] = y1; b2[p] = y2;
+  }
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// the single vehicle's solve on the device (see above); same contract as jstruct_solve
+__device__ inline int jstruct_solve1(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s, const Band &B, double *b1, double *b2, long long *ptk) {
+  double *flag = s.flag;
+  long long tp = tick();
+  const int N = sp.N[0], wv = CFZS_WAVE, nw = CFZS_NW;
+  if (flag[1] != 0.0) return 1;
+  if (threadIdx.x == 0) flag[0] = 0.0;
+  __syncthreads();
+  cfzb::glb_f64 *D1 = (cfzb::glb_f64 *)s.Ds, *U1 = (cfzb::glb_f64 *)s.Us, *Z1 = (cfzb::glb_f64 *)s.Zs, *xs = (cfzb::glb_f64 *)s.xs;
+  const cfzb::glb_i32 *meta = (const cfzb::glb_i32 *)s.meta;
+  if (j1_interiors_all(wv, nw, meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
+                       (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W) && CFZS_LANE == 0) flag[0] = 1.0;
+  __syncthreads();
+  { const long long t1 = tick(); ptk[0] += t1 - tp; tp = t1; }
+  if (flag[0] != 0.0) return 1;
+  j1_cw_all(wv, nw, N, (const cfzb::glb_f64 *)s.Cc, (const cfzb::glb_f64 *)s.W, (cfzb::glb_f64 *)s.CW);
+  __syncthreads();
+  j1_sep_all(wv, nw, meta, (const cfzb::glb_i32 *)s.cmask, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_f64 *)s.CW, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2, D1, U1);
+  __syncthreads();
+  { const long long t1 = tick(); ptk[1] += t1 - tp; tp = t1; }
+  const int mid = (N + 1) / 2;
+  int f = 0;
+  if (wv == 0) f = j1_chain(0, 0, mid, D1, U1, Z1, (cfzb::glb_i32 *)s.ordl);
+  else if (wv == 1) f = j1_chain(1, N, mid, D1, U1, Z1, (cfzb::glb_i32 *)s.ordl);
+  if (f && CFZS_LANE == 0) flag[0] = 1.0;
+  __syncthreads();
+  if (flag[0] != 0.0) return 1;
+  if (wv == 0 && j1_chain_mid(mid, D1, U1, xs) && CFZS_LANE == 0) flag[0] = 1.0;
+  __syncthreads();
+  if (flag[0] != 0.0) return 1;
+  if (wv < 2) j1_chain_back(wv, mid, N, (const cfzb::glb_f64 *)Z1, (const cfzb::glb_i32 *)s.ordl, xs);
+  __syncthreads();
+  for (int t = (int)threadIdx.x; t < (N + 1) * 16; t += (int)blockDim.x) {
+    const int i = t >> 4, la = t & 15, ns = i == 0 ? 14 : (i < N ? 15 : 5 + (sp.has_final[0] ? 1 : 0));
+    if (la < ns) { const int p = (i == 0 ? s.bs[0] : s.bs[0] + 79 * i - 1) + la; b1[p] = s.xs[(size_t)i * 32 + la]; b2[p] = s.xs[(size_t)i * 32 + 16 + la]; }
+  }
+  __syncthreads();
+  j1_back_all(wv, nw, meta, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)s.W, (cfzb::glb_f64 *)b1, (cfzb::glb_f64 *)b2);
+  __syncthreads();
+  { const long long t1 = tick(); ptk[2] += t1 - tp; }
+  return 0;
+}
+#endif
+
 template <class L, class S>
 CFZP_FN void jstruct_map(int n, L load, S store) {
 #if defined(__HIP_DEVICE_COMPILE__)

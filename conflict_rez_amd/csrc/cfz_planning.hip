@@ -362,7 +362,8 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
     // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
     // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | ((co->structured && !co->one_pivot) ? 4 : 0); p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
+    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | ((co->structured && !co->one_pivot) ? 4 : 0) | ((co->structured == 1 && !co->one_pivot) ? 8 : 0);
+    p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;  // (no_prox bit 3: single plans through cfz_jstruct.inl's scheme too; structured = 2: cfz_struct.inl, round 4's)
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);
@@ -527,7 +528,7 @@ int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has
   if (V < 1 || V > cfzc::kMaxVeh || !n_sets || N_per_set < 1 || n_obs < 0 || n_obs > cfzc::kMaxObs || n_pairs < 0) return fail("bad argument");
   cfzc::CSpec p;
   memset(&p, 0, sizeof p);
-  p.V = V; p.Nps = N_per_set; p.n_obs = n_obs; p.no_prox = structured ? 4 : 0;
+  p.V = V; p.Nps = N_per_set; p.n_obs = n_obs; p.no_prox = structured ? (structured == 1 ? 12 : 4) : 0;
   for (int a = 0; a < V; ++a) {
     if (n_sets[a] < 2) return fail("a plan needs at least two strategy steps");
     p.n_chk[a] = n_sets[a] - 1; p.N[a] = N_per_set * p.n_chk[a]; p.has_final[a] = has_final ? (has_final[a] != 0) : 1;

@@ -302,7 +302,9 @@ typedef struct cfz_colloc_options {
   double constr_viol_tol; /* :651 1e-2 */
   double mu_init;         /* 0.1 (IPOPT's default) */
   double curv_kappa;      /* 1e-8 */
-  int32_t structured;     /* single-vehicle plans (cfz_colloc): 1 (default) = the Newton system is eliminated interval by interval (the interiors of the
+  int32_t structured;     /* 1 (default) = csrc/cfz_jstruct.inl's scheme for single plans too since round 5 (tube rows condensed, 16-row separator blocks, a
+                           *    recursion that keeps its hand-offs in registers); 2 = round 4's csrc/cfz_struct.inl, described next, kept for comparison:
+                           *    single-vehicle plans (cfz_colloc): the Newton system is eliminated interval by interval (the interiors of the
                            *    Radau intervals independently, then a block recursion over the interval starts: csrc/cfz_struct.inl)
                            *    instead of pivot by pivot along the band (0; also what one_pivot = 1 takes); same matrix, same solution to rounding: 3x
                            *    faster at 256 plans.  Joint plans (cfz_joint_colloc), since round 5: 1 = csrc/cfz_jstruct.inl -- vehicle-major

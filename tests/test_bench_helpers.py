@@ -56,7 +56,9 @@ def test_lane_sampler_and_elimination_info():
     assert np.allclose(np.hypot(np.diff(ref[:, 0], axis=1), np.diff(ref[:, 1], axis=1)), 0.1, atol=1e-3)  # 1 m/s along the lane
     one = engine.colloc_elimination_info([11])
     band = engine.colloc_elimination_info([11], structured=0)
-    assert (one["nk"], one["kb"]) == (band["nk"], band["kb"]) == (engine.colloc_band_info([11])[0], 51) and one["alg_bytes"] < band["alg_bytes"]
+    r4 = engine.colloc_elimination_info([11], structured=2)   # round 4's scheme (cfz_struct.inl): the band's unknowns, its own sweep
+    assert (r4["nk"], r4["kb"]) == (band["nk"], band["kb"]) == (engine.colloc_band_info([11])[0], 51) and r4["alg_bytes"] < band["alg_bytes"]
+    assert (one["nk"], one["kb"]) == (band["nk"] - 16 * 10, 51) and one["alg_bytes"] < r4["alg_bytes"]   # (tube rows condensed: 16 per strategy step)
     four = engine.colloc_elimination_info([11, 7, 7, 9])
     assert four["kb"] == 51 and four["nk"] == engine.colloc_band_info([11, 7, 7, 9])[0] - 16 * 30 and four["workspace_bytes"] < 60e6
     assert bench.profiled_extras(0, require_current=False) is None or "traffic" in bench.profiled_extras(0, require_current=False)
