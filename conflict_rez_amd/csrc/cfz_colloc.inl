@@ -1661,9 +1661,14 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       bool solved = false;
       if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (jstructured && sp.V == 1) { fail = jstruct_solve1(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
+      if (jstructured) {  // (the dynamic LDS: 8 x kLuLdsWave doubles for the 64-row eliminations, sized by the host)
+        extern __shared__ double wlds[];
+        fail = sp.V == 1 ? jstruct_solve1(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6, wlds) : jstruct_solve(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6, wlds);
+        solved = true;
+      } else
+#else
+      if (jstructured) { fail = jstruct_solve(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6, nullptr); solved = true; } else
 #endif
-      if (jstructured) { fail = jstruct_solve(sp, d, w, JW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (MODE == 2 && blockDim.x >= 512 && blockDim.x >= kb + CFZ_PANEL && kb <= kWideMaxKb && CFZ_PANEL * (kb + CFZ_PANEL) <= lds_doubles && !CFZ_NO_PANEL && !(sp.no_prox & 2)) {
         extern __shared__ double wlds[];

@@ -33,6 +33,10 @@ CFZP_FN int jprow(int j) { const int k = j / 3, c = j - 3 * k; return (k == 0 ? 
 // column of Y / Z: coupling column q of vehicle b, or right-hand side s (two halves of 32: vehicles 0, 1 | vehicles 2, 3, b1, b2)
 CFZP_FN int jycol(int b, int q) { return 32 * (b >> 1) + kJC * (b & 1) + q; }
 constexpr int kJYrhs = 60;
+// JWork::aug: per wavefront the 64 x 96 rows of a capacitance system between their builder and the elimination (the device; column-major,
+// every lane reads back what it wrote); the CPU build stages one block (64 x 128) and a capacitance system (2 x 64 x 64) there
+constexpr int kJRowBuf = (kJB + 32) * kJB, kJRows = 8 * kJRowBuf;
+static_assert(kJRows >= kJB * (kJB + 64) + 2 * kJB * kJB, "the CPU build's staging fits");
 
 struct JWork {
   double *W, *Cc, *CW, *Mt, *Z, *zt, *Ds, *Us, *Zs, *xs, *aug, *flag;
@@ -47,7 +51,7 @@ CFZP_FN size_t jstruct_doubles(const CSpec &sp) {
   for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
   const size_t Nm = jstruct_nmax(sp);
   return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + kJB * kJB + 2 * kJB) + (Nm + 1) * (kJB * kJB + 2 * kJB * kJU + 2 * kJB) +
-         (size_t)kJB * (kJB + 64) + 2 * kJB * kJB + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
+         (size_t)kJRows + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
 }
 // doubles the structured elimination of one joint Newton system moves between its phases (bench.py's roofline of configs[3]): the band
 // cleared and gathered once, the pair blocks written and read; W written, read for C'W and by the back-substitution; C and C'W written and
@@ -71,7 +75,7 @@ CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   s.W = p; p += NI * kSI * kJR; s.Cc = p; p += NI * kSI * kJC; s.CW = p; p += NI * kJC * kJR;
   s.Mt = p; p += Nm * kJMt; s.Z = p; p += Nm * kJB * kJB; s.zt = p; p += Nm * 2 * kJB;
   s.Ds = p; p += (Nm + 1) * kJB * kJB; s.Us = p; p += (Nm + 1) * kJB * kJU; s.Zs = p; p += (Nm + 1) * kJB * kJU; s.xs = p; p += (Nm + 1) * 2 * kJB;
-  s.aug = p; p += (size_t)kJB * (kJB + 64) + 2 * kJB * kJB;  // (the CPU build's staging: one block with its right-hand sides, a capacitance matrix and its right-hand sides)
+  s.aug = p; p += (size_t)kJRows;  // the CPU build's staging (one block with its right-hand sides, a capacitance matrix and its right-hand sides); the device's row buffers
   s.flag = p; p += 8;
   s.cl = reinterpret_cast<int *>(p); s.bs = s.cl + NI * 16; s.ordl = s.bs + kMaxVeh; s.meta = s.ordl + (Nm + 1) * kJB; s.cmask = s.meta + 64;
   return s;
@@ -127,45 +131,38 @@ CFZP_FN void jstruct_setup(const CSpec &sp, const CDims &d, const CWork &w, cons
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// One call per wavefront and phase, the loop over the wavefront's tasks inside: an out-of-line function that uses the whole register file
+// saves and restores the caller's registers in scratch at entry and exit (60-230 dwords per lane), which per TASK was 20 MB of scratch
+// traffic per Newton system -- 40 % of the elimination's own bytes (profiles/r5a_extras_*: 2.05x the algorithmic bytes moved).
+// an argument that is the same in every lane, moved to scalar registers: a pointer kept in vector registers across a task that wants all
+// 256 of them is spilled and reloaded per task
+template <class T>
+__device__ __forceinline__ T *juni(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int juni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ cfzb::lds_f64 *juni_lds(cfzb::lds_f64 *p) { return (cfzb::lds_f64 *)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p); }
 // interior of (vehicle, interval): rows gathered from the band, coupling columns kept in C, K^-1 [C | b1 b2 | E] to W (row = unknown)
 __device__ __forceinline__ int jstruct_interior(const cfzb::glb_f64 *ab, int kb, int ld, int off, int pi, const cfzb::glb_i32 *cl,
-                                                          const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W) {
-  const int lane = threadIdx.x & 63, r = pi + lane;
-  double a[kSI + kJR];
+                                                          const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *C, cfzb::glb_f64 *W, cfzb::lds_f64 *lds) {
+  const int lane = lu_opaque(threadIdx.x & 63), r = pi + lane;
+  return lu64_build<kJR>(lds, W, [&](auto Jc, double (&v)[16]) {  // W[q * kSI + unknown]
+    constexpr int J = decltype(Jc)::value;
 #pragma unroll
-  for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
-#pragma unroll
-  for (int q = 0; q < kJC; ++q) {
-    const int c = cl[q], dd = r - c;
-    const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
-    a[kSI + q] = v;
-    C[q * kSI + lane] = v;
-  }
-  a[kSI + 14] = b1[r]; a[kSI + 15] = b2[r];
-#pragma unroll
-  for (int j = 0; j < 15; ++j) a[kSI + 16 + j] = lane == jprow(j) ? 1.0 : 0.0;
-  a[kSI + 31] = 0.0;
-  int ord;
-  if (wave_lu_regs<kSI, kJR>(a, lane, ord)) return 1;
-#pragma unroll
-  for (int q = 0; q < kJR; ++q) W[q * kSI + ord] = a[kSI + q];
-  return 0;
+    for (int k = 0; k < 16; ++k) {
+      if constexpr (J < 4) { const int c = pi + 16 * J + k, dd = r - c; v[k] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
+      else if constexpr (J == 4) {
+        if (k < kJC) {
+          const int c = cl[k], dd = r - c;
+          v[k] = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
+          C[k * kSI + lane] = v[k];
+        } else v[k] = k == 14 ? b1[r] : b2[r];
+      } else v[k] = (k < 15 && lane == jprow(k)) ? 1.0 : 0.0;
+    }
+  });
 }
-// a 64 x 64 block (column-major in memory) with 32 right-hand sides (column-major, 64 rows): Z = A^-1 R
-__device__ __attribute__((noinline)) int jstruct_block(const cfzb::glb_f64 *A, const cfzb::glb_f64 *R, cfzb::glb_f64 *Z) {
-  const int lane = threadIdx.x & 63;
-  double a[kJB + 32];
-#pragma unroll
-  for (int j = 0; j < kJB; ++j) a[j] = A[j * kJB + lane];
-#pragma unroll
-  for (int q = 0; q < 32; ++q) a[kJB + q] = R[q * kJB + lane];
-  int ord;
-  if (wave_lu_regs<kJB, 32>(a, lane, ord)) return 1;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) Z[q * kJB + ord] = a[kJB + q];
-  return 0;
-}
-
 // C'W of one interior on the matrix cores: (14 x 64) (64 x 32) as two 16 x 16 tiles of v_mfma_f64_16x16x4_f64, sixteen k-steps
 // (operands: lane l holds A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15]; result register r of lane l is row (l >> 4) + 4 r,
 // column l & 15).  48 loads, 32 matrix instructions: the 434 dot products of length 64 took 1.3 ms per factorisation as a loop.
@@ -194,8 +191,9 @@ __device__ __forceinline__ void jstruct_cw(const cfzb::glb_f64 *C, const cfzb::g
 // Y = (I + G M)^-1 E'K^-1 [C | b]: M (I + G M)^-1 = (I + M G)^-1 M).  Row (a, i) of matrix and right-hand sides is built in the registers of
 // lane 16 a + i from M's three entries per vehicle for that row and the rows jprow(.) of the interiors' solutions W; nothing but Z is stored.
 // h = 0: the coupling columns of vehicles 0 and 1; h = 1: of vehicles 2 and 3, then b1, b2.
-__device__ __forceinline__ int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt, const cfzb::glb_f64 *Wall, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Zt) {
-  const int lane = threadIdx.x & 63, va = lane >> 4, i = lane & 15, V = mt[35];
+__device__ __forceinline__ int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt, const cfzb::glb_f64 *Wall, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Zt, cfzb::lds_f64 *lds,
+                                                     cfzb::glb_f64 *S) {
+  const int lane = lu_opaque(threadIdx.x & 63), va = lane >> 4, i = lane & 15, V = mt[35];
   const bool real = va < V && t < mt[va] && i < 15;
   const int kk = real ? i / 3 : 0, ii = real ? i - 3 * kk : 0;
   const int pr0 = jprow(3 * kk), pr1 = pr0 + 1, pr2 = pr0 + 2;
@@ -206,7 +204,7 @@ __device__ __forceinline__ int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const bool part = b < V && t < mt[b];
-    Wb[b] = Wall + (size_t)(part ? mt[36 + b] + t : 0) * kSI * kJR;
+    Wb[b] = juni(Wall + (size_t)(part ? mt[36 + b] + t : 0) * kSI * kJR);  // (scalar base + this lane's 32-bit offset: no 64-bit address per load)
     const int e = (real && part && b != va) ? mt[12 + 4 * va + b] : -1;
     const cfzb::glb_f64 *pe = pm + (size_t)(e >= 0 ? mt[28 + e] + kPts * t + kk + 1 : 0) * 36 + (va < b ? 6 * ii : 6 * (3 + ii));
 #pragma unroll
@@ -219,42 +217,44 @@ __device__ __forceinline__ int jstruct_cap(int t, int h, const cfzb::glb_i32 *mt
   for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (b == va) m[b][c] = dg[c];
-  double a[kJB + 32];
-  // (built a vehicle's 16 columns at a time, the loads of one batch in flight together and no more: left to itself the compiler issues all
-  // 290 loads of a task at once and spills a hundred registers around them)
+  // The rows are built column by column into this wavefront's row buffer (coalesced; eight columns' loads in flight at a time) and read
+  // back by the same lane a column tile at a time: builder and elimination do not compete for registers (built in registers beside the
+  // tiles, two of the six tiles lived in scratch memory).
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      double v = lane == 16 * b + j ? 1.0 : 0.0;
-      if (j < 15) v += m[b][0] * Wb[b][(16 + j) * kSI + pr0] + m[b][1] * Wb[b][(16 + j) * kSI + pr1] + m[b][2] * Wb[b][(16 + j) * kSI + pr2];
-      a[16 * b + j] = v;
+      double x = lane == 16 * b + j ? 1.0 : 0.0;
+      if (j < 15) x += m[b][0] * Wb[b][(16 + j) * kSI + pr0] + m[b][1] * Wb[b][(16 + j) * kSI + pr1] + m[b][2] * Wb[b][(16 + j) * kSI + pr2];
+      S[(16 * b + j) * kJB + lane] = x;
+      if ((j & 7) == 7) asm volatile("" ::: "memory");
     }
-    asm volatile("" ::: "memory");
   }
 #pragma unroll
   for (int lc = 0; lc < 28; ++lc) {
     const int bl = lc / kJC, q = lc % kJC;
     const cfzb::glb_f64 *Wv = h ? Wb[2 + bl] : Wb[bl];
     const double m0 = h ? m[2 + bl][0] : m[bl][0], m1 = h ? m[2 + bl][1] : m[bl][1], m2 = h ? m[2 + bl][2] : m[bl][2];
-    a[kJB + lc] = m0 * Wv[q * kSI + pr0] + m1 * Wv[q * kSI + pr1] + m2 * Wv[q * kSI + pr2];
+    S[(kJB + lc) * kJB + lane] = m0 * Wv[q * kSI + pr0] + m1 * Wv[q * kSI + pr1] + m2 * Wv[q * kSI + pr2];
     if (lc % 7 == 6) asm volatile("" ::: "memory");
   }
 #pragma unroll
   for (int sr = 0; sr < 2; ++sr) {
-    double v = 0.0;
+    double x = 0.0;
     if (h) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v += m[b][0] * Wb[b][(14 + sr) * kSI + pr0] + m[b][1] * Wb[b][(14 + sr) * kSI + pr1] + m[b][2] * Wb[b][(14 + sr) * kSI + pr2];
+      for (int b = 0; b < 4; ++b) x += m[b][0] * Wb[b][(14 + sr) * kSI + pr0] + m[b][1] * Wb[b][(14 + sr) * kSI + pr1] + m[b][2] * Wb[b][(14 + sr) * kSI + pr2];
     }
-    a[kJB + 28 + sr] = v;
+    S[(kJB + 28 + sr) * kJB + lane] = x;
   }
-  a[kJB + 30] = 0.0; a[kJB + 31] = 0.0;
-  int ord;
-  if (wave_lu_regs<kJB, 32>(a, lane, ord)) return 1;
+  S[(kJB + 30) * kJB + lane] = 0.0; S[(kJB + 31) * kJB + lane] = 0.0;
+  asm volatile("" ::: "memory");
+  const cfzb::glb_f64 *Sr = juni((const cfzb::glb_f64 *)S);
+  return lu64_build<32>(lds, Zt + 32 * h * kJB, [&](auto Jc, double (&v)[16]) {  // Zt[(32 h + q) * kJB + unknown]
+    constexpr int J = decltype(Jc)::value;
 #pragma unroll
-  for (int q = 0; q < 32; ++q) Zt[(32 * h + q) * kJB + ord] = a[kJB + q];
-  return 0;
+    for (int k = 0; k < 16; ++k) v[k] = Sr[(16 * J + k) * kJB + lane];
+  });
 }
 
 // meta (JWork::meta, filled by jstruct_setup): [0..3] N, [4..7] first position, [8..11] terminal heading, [12..27] pair index of two vehicles
@@ -406,38 +406,31 @@ __device__ __forceinline__ void jstruct_back(int a, int pos0, const cfzb::glb_i3
   b1[pos0 + lane] = y1; b2[pos0 + lane] = y2;  // (interior positions are read by nobody in this phase)
 }
 
-// One call per wavefront and phase, the loop over the wavefront's tasks inside: an out-of-line function that uses the whole register file
-// saves and restores the caller's registers in scratch at entry and exit (60-230 dwords per lane), which per TASK was 20 MB of scratch
-// traffic per Newton system -- 40 % of the elimination's own bytes (profiles/r5a_extras_*: 2.05x the algorithmic bytes moved).
-// an argument that is the same in every lane, moved to scalar registers: a pointer kept in vector registers across a task that wants all
-// 256 of them is spilled and reloaded per task
-template <class T>
-__device__ __forceinline__ T *juni(T *p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-  return (T *)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ int juni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int jveh_of(const cfzb::glb_i32 *m, int it) { int a = 0; while (a + 1 < m[35] && it >= m[36 + a + 1]) ++a; return a; }
 __device__ __attribute__((noinline)) int jstruct_interiors_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
-                                                               const cfzb::glb_i32 *cl, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *W) {
+                                                               const cfzb::glb_i32 *cl, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *W,
+                                                               cfzb::lds_f64 *lds) {
   int f = 0;
   m = juni(m); ab = juni(ab); cl = juni(cl); b1 = juni(b1); b2 = juni(b2); Cc = juni(Cc); W = juni(W);
+  lds = juni_lds(lds) + (threadIdx.x >> 6) * kLuLdsWave;
   w0 = juni(w0); nw = juni(nw); kb = juni(kb); ld = juni(ld); off = juni(off);
   const int NI = m[36 + m[35]];
   for (int it = w0; it < NI; it += nw) {
     const int a = jveh_of(m, it), t = it - m[36 + a];
-    f |= jstruct_interior(ab, kb, ld, off, m[4 + a] + 79 * t + 14, cl + 16 * it, b1, b2, Cc + (size_t)it * kSI * kJC, W + (size_t)it * kSI * kJR);
+    f |= jstruct_interior(ab, kb, ld, off, m[4 + a] + 79 * t + 14, cl + 16 * it, b1, b2, Cc + (size_t)it * kSI * kJC, W + (size_t)it * kSI * kJR, lds);
   }
   return f;
 }
 __device__ __attribute__((noinline)) void jstruct_cw_all(int w0, int nw, int NI, const cfzb::glb_f64 *Cc, const cfzb::glb_f64 *W, cfzb::glb_f64 *CW) {
   for (int it = w0; it < NI; it += nw) jstruct_cw(Cc + (size_t)it * kSI * kJC, W + (size_t)it * kSI * kJR, CW + (size_t)it * kJC * kJR);
 }
-__device__ __attribute__((noinline)) int jstruct_cap_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_f64 *W, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Z) {
+__device__ __attribute__((noinline)) int jstruct_cap_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_f64 *W, const cfzb::glb_f64 *pm, cfzb::glb_f64 *Z,
+                                                         cfzb::lds_f64 *lds, cfzb::glb_f64 *rows) {
   int f = 0;
   m = juni(m); W = juni(W); pm = juni(pm); Z = juni(Z); w0 = juni(w0); nw = juni(nw); Nm = juni(Nm);
-  for (int k = w0; k < 2 * Nm; k += nw) f |= jstruct_cap(k >> 1, k & 1, m, W, pm, Z + (size_t)(k >> 1) * kJB * kJB);
+  lds = juni_lds(lds) + (threadIdx.x >> 6) * kLuLdsWave;
+  rows = juni(rows) + (size_t)(threadIdx.x >> 6) * kJRowBuf;
+  for (int k = w0; k < 2 * Nm; k += nw) f |= jstruct_cap(k >> 1, k & 1, m, W, pm, Z + (size_t)(k >> 1) * kJB * kJB, lds, rows);
   return f;
 }
 __device__ __attribute__((noinline)) void jstruct_sep_base_all(int w0, int nw, int Nm, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
@@ -461,39 +454,46 @@ __device__ __attribute__((noinline)) void jstruct_back_all(int w0, int nw, const
   }
 }
 
-// The recursion over the joint separators, one wavefront per direction, everything between two blocks in registers or in words of
-// global memory that the SAME lane wrote (no hand-off between lanes through memory, no fence): side 0 eliminates blocks i0 .. i1 - 1
-// downwards (block i into i + 1), side 1 blocks i0 .. i1 + 1 upwards (block j into j - 1).  Block i: D_i (column-major), right-hand sides
-// [U_i | b1 b2] with U_i = the coupling of block i's pt0 rows (row 16 a + p0 + c) with block i + 1's rows 16 b + be (column 7 b + be).
-// Z (lane = the row the lane's pivot left it with: ordl) is kept lane-major for the back-substitution.  nv: N[a] packed, 8 bits each.
-__device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1, unsigned nvp, int V, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us,
-                                                       cfzb::glb_f64 *Zl, cfzb::glb_i32 *ordl) {
+// The recursion over the joint separators, one wavefront per direction: side 0 eliminates blocks i0 .. i1 - 1 downwards (block i into
+// i + 1), side 1 blocks i0 .. i1 + 1 upwards (block j into j - 1).  Block i: D_i (column-major), right-hand sides [U_i | b1 b2] with U_i =
+// the coupling of block i's pt0 rows (row 16 a + p0 + c) with block i + 1's rows 16 b + be (column 7 b + be).  The elimination (lu64_build,
+// on the matrix cores) leaves Z_i = D_i^-1 [..] in LDS, row = unknown (X, 64 x 33); every lane keeps its own row of it in global memory
+// for the back-substitution (read again by the same lane), and accumulates the neighbour block's update for the row it will LOAD there
+// from broadcast reads of X: the words of global memory a lane reads in the next step are words the same lane wrote (no hand-off between
+// lanes through global memory, no fence; the hand-off inside the wavefront goes through LDS).  nvp: N[a] packed, 8 bits each.
+constexpr int kJXld = 33;  // row stride of X (odd: the lane = row reads are conflict-free)
+__device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1, unsigned nvp, int V, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us, cfzb::glb_f64 *Zl,
+                                                       cfzb::lds_f64 *lds, cfzb::lds_f64 *X) {
   const int lane = threadIdx.x & 63, va = lane >> 4, la = lane & 15;
   const int cu = la < 7 ? 7 * va + la : -1;  // this lane's row as a right-coupled row of its block: its column of U
-  Ds = juni(Ds); Us = juni(Us); Zl = juni(Zl); ordl = juni(ordl); side = juni(side); i0 = juni(i0); i1 = juni(i1); V = juni(V); nvp = (unsigned)juni((int)nvp);
+  Ds = juni(Ds); Us = juni(Us); Zl = juni(Zl); lds = juni_lds(lds); X = juni_lds(X); side = juni(side); i0 = juni(i0); i1 = juni(i1); V = juni(V); nvp = (unsigned)juni((int)nvp);
   for (int i = i0; side ? i > i1 : i < i1; i += side ? -1 : 1) {
     const cfzb::glb_f64 *Di = Ds + (size_t)i * kJB * kJB, *Ui = Us + (size_t)i * kJB * kJU;
     const int ip = side ? i - 1 : i;                 // the coupling block involved: U_ip couples blocks ip and ip + 1
     const int p0 = ip == 0 ? 7 : 8;                  // pt0's first local row in block ip
     const cfzb::glb_f64 *Uc = Us + (size_t)ip * kJB * kJU;
-    double a[kJB + 32];
+    if (lu64_build<32, kJXld, 1, cfzb::lds_f64>(lds, X, [&](auto Jc, double (&v)[16]) {
+          constexpr int J = decltype(Jc)::value;
+          if constexpr (J < 4) {
 #pragma unroll
-    for (int j = 0; j < kJB; ++j) a[j] = Di[j * kJB + lane];
-    if (side == 0) {
+            for (int k = 0; k < 16; ++k) v[k] = Di[(16 * J + k) * kJB + lane];
+          } else if (side == 0) {
 #pragma unroll
-      for (int q = 0; q < 30; ++q) a[kJB + q] = Ui[q * kJB + lane];
-    } else {
+            for (int k = 0; k < 16; ++k) { const int q = 16 * (J - 4) + k; v[k] = q < 30 ? Ui[q * kJB + lane] : 0.0; }
+          } else {
+            const int cuc = cu >= 0 ? cu : 0;  // (clamped: the loads of a tile stand in one block, their results masked)
 #pragma unroll
-      for (int q = 0; q < 28; ++q) a[kJB + q] = cu >= 0 ? Uc[cu * kJB + 16 * (q / 7) + p0 + (q % 7)] : 0.0;  // U_{i-1}' (zero where a vehicle has no interior i - 1)
-      a[kJB + 28] = Ui[28 * kJB + lane]; a[kJB + 29] = Ui[29 * kJB + lane];
-    }
-    a[kJB + 30] = 0.0; a[kJB + 31] = 0.0;
-    int ord;
-    if (wave_lu_regs<kJB, 32>(a, lane, ord)) return 1;
+            for (int k = 0; k < 16; ++k) {
+              const int q = 16 * (J - 4) + k;
+              const double x = q < 28 ? Uc[cuc * kJB + 16 * (q / 7) + p0 + (q % 7)] : (q < 30 ? Ui[q * kJB + lane] : 0.0);  // U_{i-1}' (zero where a vehicle has no interior i - 1)
+              v[k] = (q < 28 && cu < 0) ? 0.0 : x;
+            }
+          }
+        })) return 1;
+    lu_wave_sync();
     cfzb::glb_f64 *Zi = Zl + (size_t)i * kJB * kJU;
 #pragma unroll
-    for (int q = 0; q < 30; ++q) Zi[q * kJB + lane] = a[kJB + q];
-    ordl[i * kJB + lane] = ord;
+    for (int q = 0; q < 30; ++q) Zi[q * kJB + lane] = X[lane * kJXld + q];
     // the neighbour block's update: acc[q] = sum over the coupled rows r of this block of U[r, this lane's row there] Z[r, q]
     double acc[30];
 #pragma unroll
@@ -503,10 +503,10 @@ __device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1,
         if (i >= (int)((nvp >> (8 * b)) & 255u)) continue;
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-          const int r = 16 * b + p0 + c, lk = (int)__builtin_ctzll(__ballot(ord == r));
+          const int r = 16 * b + p0 + c;
           const double u = cu >= 0 ? Uc[cu * kJB + r] : 0.0;
 #pragma unroll
-          for (int q = 0; q < 30; ++q) acc[q] += u * struct_lane_get(a[kJB + q], lk);
+          for (int q = 0; q < 30; ++q) acc[q] += u * X[r * kJXld + q];
         }
       }
       if (cu >= 0) {
@@ -521,10 +521,10 @@ __device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1,
         if (ip >= (int)((nvp >> (8 * b)) & 255u)) continue;
 #pragma unroll
         for (int be = 0; be < 7; ++be) {
-          const int lk = (int)__builtin_ctzll(__ballot(ord == 16 * b + be));
+          const int r = 16 * b + be;
           const double u = isl ? Uc[(7 * b + be) * kJB + lane] : 0.0;
 #pragma unroll
-          for (int q = 0; q < 30; ++q) acc[q] += u * struct_lane_get(a[kJB + q], lk);
+          for (int q = 0; q < 30; ++q) acc[q] += u * X[r * kJXld + q];
         }
       }
       if (isl) {
@@ -534,6 +534,7 @@ __device__ __attribute__((noinline)) int jstruct_chain(int side, int i0, int i1,
         Un[28 * kJB + lane] -= acc[28]; Un[29 * kJB + lane] -= acc[29];
       }
     }
+    lu_wave_sync();  // (X is rewritten by the next block's elimination)
   }
   return 0;
 }
@@ -551,24 +552,21 @@ __device__ __attribute__((noinline)) int jstruct_chain_mid(int mid, cfzb::glb_f6
   xs[(size_t)mid * 2 * kJB + ord] = a[kJB]; xs[(size_t)mid * 2 * kJB + kJB + ord] = a[kJB + 1];
   return 0;
 }
-__device__ __attribute__((noinline)) void jstruct_chain_back(int side, int mid, int Nm, const cfzb::glb_f64 *Zl, const cfzb::glb_i32 *ordl, cfzb::glb_f64 *xs) {
+__device__ __attribute__((noinline)) void jstruct_chain_back(int side, int mid, int Nm, const cfzb::glb_f64 *Zl, cfzb::glb_f64 *xs) {
   const int lane = threadIdx.x & 63;
-  double xp1 = xs[(size_t)mid * 2 * kJB + lane], xp2 = xs[(size_t)mid * 2 * kJB + kJB + lane];  // x of the block before, by row held: ordp
-  int ordp = lane;
+  double xp1 = xs[(size_t)mid * 2 * kJB + lane], xp2 = xs[(size_t)mid * 2 * kJB + kJB + lane];  // x of the block before, lane = unknown
   for (int i = side ? mid + 1 : mid - 1; side ? i <= Nm : i >= 0; i += side ? 1 : -1) {
     const cfzb::glb_f64 *Zi = Zl + (size_t)i * kJB * kJU;
     const int ip = side ? i - 1 : i, p0 = ip == 0 ? 7 : 8;
     double x1 = Zi[28 * kJB + lane], x2 = Zi[29 * kJB + lane];
 #pragma unroll
     for (int q = 0; q < 28; ++q) {
-      const int r = side ? 16 * (q / 7) + p0 + (q % 7) : 16 * (q / 7) + (q % 7);  // the row of the block before that column q stands for
-      const int lk = (int)__builtin_ctzll(__ballot(ordp == r));
+      const int r = side ? 16 * (q / 7) + p0 + (q % 7) : 16 * (q / 7) + (q % 7);  // the unknown of the block before that column q stands for
       const double z = Zi[q * kJB + lane];
-      x1 -= z * struct_lane_get(xp1, lk); x2 -= z * struct_lane_get(xp2, lk);
+      x1 -= z * struct_lane_get(xp1, r); x2 -= z * struct_lane_get(xp2, r);
     }
-    const int ord = ordl[i * kJB + lane];
-    xs[(size_t)i * 2 * kJB + ord] = x1; xs[(size_t)i * 2 * kJB + kJB + ord] = x2;
-    xp1 = x1; xp2 = x2; ordp = ord;
+    xs[(size_t)i * 2 * kJB + lane] = x1; xs[(size_t)i * 2 * kJB + kJB + lane] = x2;
+    xp1 = x1; xp2 = x2;
   }
 }
 #endif
@@ -594,30 +592,29 @@ CFZP_FN int jstruct_block_serial(double *aug, const double *A, const double *R, 
 #if defined(__HIP_DEVICE_COMPILE__)
 constexpr int kJ1U = 10;
 __device__ __attribute__((noinline)) int j1_interiors_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,
-                                                          const cfzb::glb_i32 *cl_, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *Wc) {
+                                                          const cfzb::glb_i32 *cl_, const cfzb::glb_f64 *b1, const cfzb::glb_f64 *b2, cfzb::glb_f64 *Cc, cfzb::glb_f64 *Wc,
+                                                          cfzb::lds_f64 *lds) {
   int f = 0;
   m = juni(m); ab = juni(ab); cl_ = juni(cl_); b1 = juni(b1); b2 = juni(b2); Cc = juni(Cc); Wc = juni(Wc);
+  lds = juni_lds(lds) + (threadIdx.x >> 6) * kLuLdsWave;
   w0 = juni(w0); nw = juni(nw); kb = juni(kb); ld = juni(ld); off = juni(off);
-  const int NI = m[0], lane = threadIdx.x & 63;
+  const int NI = m[0], lane0 = threadIdx.x & 63;
   for (int it = w0; it < NI; it += nw) {
-    const int pi = m[4] + 79 * it + 14, r = pi + lane;
+    const int lane = lu_opaque(lane0), pi = m[4] + 79 * it + 14, r = pi + lane;
     const cfzb::glb_i32 *cl = cl_ + 16 * it;
     cfzb::glb_f64 *C = Cc + (size_t)it * kSI * kJC, *W = Wc + (size_t)it * kSI * kJR;
-    double a[kSI + 16];
+    f |= lu64_build<16>(lds, W, [&](auto Jc, double (&v)[16]) {  // W[q * kSI + unknown]
+      constexpr int J = decltype(Jc)::value;
 #pragma unroll
-    for (int j = 0; j < kSI; ++j) { const int c = pi + j, dd = r - c; a[j] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
-#pragma unroll
-    for (int q = 0; q < kJC; ++q) {
-      const int c = cl[q], dd = r - c;
-      const double v = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
-      a[kSI + q] = v;
-      C[q * kSI + lane] = v;
-    }
-    a[kSI + 14] = b1[r]; a[kSI + 15] = b2[r];
-    int ord;
-    if (wave_lu_regs<kSI, 16>(a, lane, ord)) { f = 1; continue; }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) W[q * kSI + ord] = a[kSI + q];
+      for (int k = 0; k < 16; ++k) {
+        if constexpr (J < 4) { const int c = pi + 16 * J + k, dd = r - c; v[k] = (dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0; }
+        else if (k < kJC) {
+          const int c = cl[k], dd = r - c;
+          v[k] = (c >= 0 && dd <= kb && -dd <= kb) ? ab[(size_t)c * ld + (off + dd)] : 0.0;
+          C[k * kSI + lane] = v[k];
+        } else v[k] = k == 14 ? b1[r] : b2[r];
+      }
+    });
   }
   return f;
 }
@@ -789,7 +786,7 @@ __device__ __attribute__((noinline)) void j1_back_all(int w0, int nw, const cfzb
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // the single vehicle's solve on the device (see above); same contract as jstruct_solve
-__device__ inline int jstruct_solve1(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s, const Band &B, double *b1, double *b2, long long *ptk) {
+__device__ inline int jstruct_solve1(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s, const Band &B, double *b1, double *b2, long long *ptk, double *lds) {
   double *flag = s.flag;
   long long tp = tick();
   const int N = sp.N[0], wv = CFZS_WAVE, nw = CFZS_NW;
@@ -799,7 +796,7 @@ __device__ inline int jstruct_solve1(const CSpec &sp, const CDims &d, const CWor
   cfzb::glb_f64 *D1 = (cfzb::glb_f64 *)s.Ds, *U1 = (cfzb::glb_f64 *)s.Us, *Z1 = (cfzb::glb_f64 *)s.Zs, *xs = (cfzb::glb_f64 *)s.xs;
   const cfzb::glb_i32 *meta = (const cfzb::glb_i32 *)s.meta;
   if (j1_interiors_all(wv, nw, meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_i32 *)s.cl, (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2,
-                       (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W) && CFZS_LANE == 0) flag[0] = 1.0;
+                       (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W, cfzb::opaque((cfzb::lds_f64 *)lds)) && CFZS_LANE == 0) flag[0] = 1.0;
   __syncthreads();
   { const long long t1 = tick(); ptk[0] += t1 - tp; tp = t1; }
   if (flag[0] != 0.0) return 1;
@@ -850,7 +847,7 @@ CFZP_FN void jstruct_map(int n, L load, S store) {
 
 // The whole solve: on return b1, b2 (positions of build_order_vm) hold the two solutions.  0 = ok, 1 = a block was singular.
 // ptk[0..2]: interiors; capacitance systems and Schur complements; separator recursion and back-substitution (device clock)
-CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s, const Band &B, double *b1, double *b2, long long *ptk) {
+CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const JWork &s, const Band &B, double *b1, double *b2, long long *ptk, double *lds) {
   double *flag = s.flag;
   long long tp = tick(), ts;
 #define CFZJ_TICK(k) do { const long long t1_ = tick(); ptk[k] += t1_ - ts; ts = t1_; } while (0)  // ptk[3..10]: sub-phases
@@ -862,7 +859,7 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
 #if defined(__HIP_DEVICE_COMPILE__)
   {
     const int f = jstruct_interiors_all(CFZS_WAVE, CFZS_NW, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)B.ab, B.kb, B.ld, B.off, (const cfzb::glb_i32 *)s.cl,
-                                        (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W);
+                                        (const cfzb::glb_f64 *)b1, (const cfzb::glb_f64 *)b2, (cfzb::glb_f64 *)s.Cc, (cfzb::glb_f64 *)s.W, cfzb::opaque((cfzb::lds_f64 *)lds));
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
@@ -917,7 +914,8 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   // ---- phase 2b: the capacitance systems: (I + M G) Z = M E'K^-1 [C | b] --------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
   {
-    const int f = jstruct_cap_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)w.pm, (cfzb::glb_f64 *)s.Z);
+    const int f = jstruct_cap_all(CFZS_WAVE, CFZS_NW, Nm, (const cfzb::glb_i32 *)s.meta, (const cfzb::glb_f64 *)s.W, (const cfzb::glb_f64 *)w.pm, (cfzb::glb_f64 *)s.Z,
+                                  cfzb::opaque((cfzb::lds_f64 *)lds), (cfzb::glb_f64 *)s.aug);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
   }
 #else
@@ -1025,15 +1023,18 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
     unsigned nvp = 0;
     for (int a = 0; a < V; ++a) nvp |= (unsigned)sp.N[a] << (8 * a);
     int f = 0;
-    if (wv == 0) f = jstruct_chain(0, 0, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_i32 *)s.ordl);
-    else if (wv == 1) f = jstruct_chain(1, Nm, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_i32 *)s.ordl);
+    // (LDS: a wavefront's own kLuLdsWave doubles for the elimination; X in the areas of two of the six idle wavefronts)
+    static_assert(2 * kLuLdsWave >= kJB * kJXld, "X fits two areas");
+    cfzb::lds_f64 *lb = cfzb::opaque((cfzb::lds_f64 *)lds);
+    if (wv == 0) f = jstruct_chain(0, 0, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, lb, lb + 2 * kLuLdsWave);
+    else if (wv == 1) f = jstruct_chain(1, Nm, mid, nvp, V, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, lb + kLuLdsWave, lb + 4 * kLuLdsWave);
     if (f && CFZS_LANE == 0) flag[0] = 1.0;
     __syncthreads();
     if (flag[0] != 0.0) return 1;
     if (wv == 0 && jstruct_chain_mid(mid, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.xs) && CFZS_LANE == 0) flag[0] = 1.0;
     __syncthreads();
     if (flag[0] != 0.0) return 1;
-    if (wv < 2) jstruct_chain_back(wv, mid, Nm, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_i32 *)s.ordl, (cfzb::glb_f64 *)s.xs);
+    if (wv < 2) jstruct_chain_back(wv, mid, Nm, (const cfzb::glb_f64 *)s.Zs, (cfzb::glb_f64 *)s.xs);
     __syncthreads();
   }
 #else

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -418,9 +419,18 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     const long long pl = kb_max <= cfzc::kWideMaxKb ? (long long)CFZ_PANEL * (kb_max + CFZ_PANEL) : 0;
     const int lds_rhs = nk_max <= avail ? nk_max : 0;
     int lds_doubles = (int)std::max<long long>(pl <= avail ? pl : 0, lds_rhs), lds_rhs_ = lds_rhs;
+    // the structured eliminations' 64-row blocks on the matrix cores stage their operands in LDS: kLuLdsWave doubles for each of the eight
+    // wavefronts (68 KB); no fallback (gfx950 gives a workgroup the CU's 160 KB)
+    bool any_j = false;
+    for (int b = 0; b < B; ++b) any_j = any_j || cfzc::jstruct_mode(specs[b]);
+    if (any_j) {
+      if (8LL * cfzc::kLuLdsWave > avail) return fail("the structured elimination needs 8 x kLuLdsWave doubles of LDS per workgroup");
+      lds_doubles = std::max(lds_doubles, 8 * cfzc::kLuLdsWave);
+    }
     if (lds_doubles && hipFuncSetAttribute((const void *)colloc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_doubles * 8) != hipSuccess) {
       // a runtime whose per-workgroup limit really is the smaller figure: the kernel also runs without dynamic LDS
       (void)hipGetLastError();
+      if (any_j) return fail("hipFuncSetAttribute: the dynamic LDS of the structured elimination was refused");
       lds_doubles = 0; lds_rhs_ = 0;
     }
     hipLaunchKernelGGL(colloc_kernel, dim3(B), dim3(512), (size_t)lds_doubles * 8, st, B, dspec, dX, doff, dslab, doff + B, dkb, doi, dod, lds_doubles, lds_rhs_);
