@@ -539,6 +539,23 @@ def test_structured_elimination_on_gpu(plans):
 
 
 @pytest.mark.gpu
+def test_block_elimination_on_the_matrix_cores_equals_the_lane_per_row_elimination(tmp_path):
+    """The 64-row eliminations of the structured planning paths (cfz_struct.inl lu64_*: blocked, four pivots a panel, tiles of
+    v_mfma_f64_16x16x4_f64) against the lane = row elimination they replaced (wave_lu_regs: one pivot at a time, v_readlane broadcasts), on
+    2048 random blocks a third of which have a zero diagonal block with a 1e-7 regularisation like a KKT system: the same pivots and the
+    same roundings, so every solution agrees BIT FOR BIT (tools/src/wave_lu_mfma_bench.hip holds both)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_lu_mfma")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(root, "tools", "src", "wave_lu_mfma_bench.hip")])
+    out = subprocess.run([exe, "2048", "8"], check=True, capture_output=True, text=True, timeout=300).stdout
+    assert "solutions that differ in any bit: 0 of" in out and out.count("failed 0,") == 2, out
+
+
+@pytest.mark.gpu
 def test_structured_elimination_on_short_plans(plans):
     """Plans of 5, 10 and 15 intervals (the separator recursion from both ends meets after one to seven steps), with and without a
     terminal heading: the structured elimination ends where the band elimination ends -- status (a plan that fails its line search

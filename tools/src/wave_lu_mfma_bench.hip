@@ -95,52 +95,22 @@ __global__ __launch_bounds__(512) void lu_regs_kernel(const double *A, const dou
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void tile_mfma(v16d &t, int I, double a, double b) {
   v4d c = {t[4 * I], t[4 * I + 1], t[4 * I + 2], t[4 * I + 3]};
-#if defined(LU_E2)
-  c[0] += a * b;
-#else
   c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-#endif
   t[4 * I] = c[0]; t[4 * I + 1] = c[1]; t[4 * I + 2] = c[2]; t[4 * I + 3] = c[3];
 }
-// element e (uniform) of J0 .. J1 - 1 of the column tiles: a scalar branch over the sixteen registers (s_set_gpr_idx_on / off around every
-// dynamic element costs ~200 cycles a pair, measured)
-#if defined(LU_SWITCH)
-template <int NT, int J0, int J1>
-__device__ __forceinline__ void tile_row(const v16d (&T)[NT], int e, double (&u)[NT]) {
-#define CFZ_ROWCASE(E) case E: _Pragma("unroll") for (int J = J0; J < J1; ++J) u[J] = T[J][E]; break;
-  switch (e) {
-    CFZ_ROWCASE(0) CFZ_ROWCASE(1) CFZ_ROWCASE(2) CFZ_ROWCASE(3) CFZ_ROWCASE(4) CFZ_ROWCASE(5) CFZ_ROWCASE(6) CFZ_ROWCASE(7)
-    CFZ_ROWCASE(8) CFZ_ROWCASE(9) CFZ_ROWCASE(10) CFZ_ROWCASE(11) CFZ_ROWCASE(12) CFZ_ROWCASE(13) CFZ_ROWCASE(14) CFZ_ROWCASE(15)
-    default: __builtin_unreachable();
-  }
-#undef CFZ_ROWCASE
-}
-#else
+// element e (uniform) of the column tiles J0 .. J1 - 1: the compiler's s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off.  (A scalar branch over
+// the sixteen registers is turned back into exactly this by the optimiser; with the moves as inline assembly it stays a branch, costs the
+// same 47 us and seven MINUTES of compilation per instantiation.  With the tiles as a [4][NT] array of 4-vectors indexed from a loop over
+// the panels, they live in scratch memory: 143 us.)
 template <int NT, int J0, int J1>
 __device__ __forceinline__ void tile_row(const v16d (&T)[NT], int e, double (&u)[NT]) {
 #pragma unroll
-#if defined(LU_E1)
-  for (int J = J0; J < J1; ++J) u[J] = T[J][3];
-#else
   for (int J = J0; J < J1; ++J) u[J] = T[J][e];
-#endif
 }
-#endif
 __device__ __forceinline__ double uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-template <int N> __device__ __forceinline__ double pick4(const double (&v)[4][N], int j, int rg) {
-  return rg == 0 ? v[0][j] : (rg == 1 ? v[1][j] : (rg == 2 ? v[2][j] : v[3][j]));
-}
 
-#if defined(LU_STAMPS)
-__device__ unsigned long long lu_acc[8];
-#define LU_T0 unsigned long long t_ = __builtin_amdgcn_s_memtime();
-#define LU_T(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) lu_acc[i] += n_ - t_; t_ = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LU_T0
-#define LU_T(i) do {} while (0)
-#endif
 // T: 64 x (64 + RB) in tiles; lds: 2 KB (panel, lane = row) + 4 x 16 (NT) doubles (pivot rows / right-hand sides of a panel).  The solution X
 // (row = unknown) goes to out[k * ostride + c].  0 = ok.  One function per panel (P a template parameter, not a loop variable: a sixteen-
 // trip loop of this size is beyond the unroller's budget, and a tile array indexed by a loop variable stays in scratch memory).
@@ -150,7 +120,6 @@ template <int RB, int P>
 __device__ __forceinline__ int lu_forward_panel(v16d (&T)[4 + RB / 16], lds_f64 *Pb, lds_f64 *Ub, bool &done, int &ord) {
   constexpr int NT = 4 + RB / 16, k0 = 4 * P, Jp = P >> 2, c0 = k0 & 15;
   const int lane = threadIdx.x & 63, cj = lane & 15, rg = lane >> 4;
-  LU_T0
   if (cj >= c0 && cj < c0 + 4) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) Pb[(4 * e + rg) * 4 + (cj - c0)] = T[Jp][e];
@@ -161,7 +130,6 @@ __device__ __forceinline__ int lu_forward_panel(v16d (&T)[4 + RB / 16], lds_f64 
 #pragma unroll
   for (int q = 0; q < 4; ++q) a[q] = Pb[lane * 4 + q];
   wave_sync();
-  LU_T(0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const double best = done ? -1.0 : fabs(a[q]);
@@ -175,7 +143,6 @@ __device__ __forceinline__ int lu_forward_panel(v16d (&T)[4 + RB / 16], lds_f64 
 #pragma unroll
     for (int s = q + 1; s < 4; ++s) a[s] -= l[q] * lane_get(a[s], pl[q]);
   }
-  LU_T(1);
   // the multipliers (negated) and the four pivot rows as they stand (before the panel's own eliminations)
 #pragma unroll
   for (int q = 0; q < 4; ++q) Pb[lane * 4 + q] = -l[q];
@@ -190,7 +157,6 @@ __device__ __forceinline__ int lu_forward_panel(v16d (&T)[4 + RB / 16], lds_f64 
     }
   }
   wave_sync();
-  LU_T(2);
   double Aop[4];
 #pragma unroll
   for (int I = 0; I < 4; ++I) Aop[I] = Pb[(16 * I + cj) * 4 + rg];
@@ -216,7 +182,6 @@ __device__ __forceinline__ int lu_forward_panel(v16d (&T)[4 + RB / 16], lds_f64 
     for (int I = 0; I < 4; ++I) tile_mfma(T[J], I, Aop[I], b);
   }
   wave_sync();
-  LU_T(3);
   return 0;
 }
 // back-substitution, four unknowns at a time
@@ -224,7 +189,6 @@ template <int RB, int P>
 __device__ __forceinline__ void lu_backward_panel(v16d (&T)[4 + RB / 16], lds_f64 *Pb, lds_f64 *Ub, int ord, double *out, int ostride) {
   constexpr int NT = 4 + RB / 16, NR = RB / 16, k0 = 4 * P, Jp = P >> 2, c0 = k0 & 15;
   const int lane = threadIdx.x & 63, cj = lane & 15, rg = lane >> 4;
-  LU_T0
   if (cj >= c0 && cj < c0 + 4) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) Pb[(4 * e + rg) * 4 + (cj - c0)] = T[Jp][e];
@@ -234,7 +198,6 @@ __device__ __forceinline__ void lu_backward_panel(v16d (&T)[4 + RB / 16], lds_f6
 #pragma unroll
   for (int q = 0; q < 4; ++q) a[q] = Pb[lane * 4 + q];
   wave_sync();
-  LU_T(4);
   int pk[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -252,7 +215,6 @@ __device__ __forceinline__ void lu_backward_panel(v16d (&T)[4 + RB / 16], lds_f6
 #pragma unroll
   for (int i = 0; i < 4; ++i) Pb[lane * 4 + i] = early ? -a[3 - i] : 0.0;
   wave_sync();
-  LU_T(5);
   double Aop[4];
 #pragma unroll
   for (int I = 0; I < 4; ++I) Aop[I] = Pb[(16 * I + cj) * 4 + rg];
@@ -260,7 +222,6 @@ __device__ __forceinline__ void lu_backward_panel(v16d (&T)[4 + RB / 16], lds_f6
   const double i3 = uni(Ub[4 * 16 * NT + k0 + 3]), i2 = uni(Ub[4 * 16 * NT + k0 + 2]), i1 = uni(Ub[4 * 16 * NT + k0 + 1]), i0 = uni(Ub[4 * 16 * NT + k0]);
   const double u23 = lane_get(a[3], pk[2]), u13 = lane_get(a[3], pk[1]), u12 = lane_get(a[2], pk[1]);
   const double u03 = lane_get(a[3], pk[0]), u02 = lane_get(a[2], pk[0]), u01 = lane_get(a[1], pk[0]);
-  LU_T(5);
 #pragma unroll
   for (int Jr = 0; Jr < NR; ++Jr) {  // a column tile of right-hand sides at a time (four values live)
     double x0 = Ub[0 * 16 * NT + 16 * Jr + cj], x1 = Ub[1 * 16 * NT + 16 * Jr + cj], x2 = Ub[2 * 16 * NT + 16 * Jr + cj], x3 = Ub[3 * 16 * NT + 16 * Jr + cj];
@@ -276,7 +237,6 @@ __device__ __forceinline__ void lu_backward_panel(v16d (&T)[4 + RB / 16], lds_f6
     }
   }
   wave_sync();
-  LU_T(7);
 }
 template <int RB>
 __device__ __forceinline__ int wave_lu_mfma(v16d (&T)[4 + RB / 16], lds_f64 *lds, double *out, int ostride) {
@@ -361,14 +321,6 @@ int main(int argc, char **argv) {
            "elimination alone %.1f us per block, failed %d, worst residual %.2e\n", variant ? "matrix cores" : "lane = row   ", RB, nb, wpb, ms,
            ms * 1e3 / ((double)nb / (cus * (double)wpb)), cus, wpb, ticks * 0.01 / nb, fails, worst);
   }
-#if defined(LU_STAMPS)
-  {
-    unsigned long long acc[8];
-    OK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(lu_acc), sizeof acc));
-    const char *nm[8] = {"fwd: panel -> lane=row", "fwd: factor", "fwd: rows -> LDS", "fwd: rows up to date + MFMA", "bwd: panel -> lane=row", "bwd: rows -> LDS", "bwd: solve + store", "bwd: MFMA"};
-    for (int i = 0; i < 8; ++i) printf("   %-30s %8.0f ticks (100 MHz) per block of workgroup 0 wave 0, all repetitions\n", nm[i], (double)acc[i]);
-  }
-#endif
   size_t diff = 0;
   double dmax = 0.0;
   for (size_t i = 0; i < X0.size(); ++i) if (memcmp(&X0[i], &X1[i], 8) != 0) { ++diff; dmax = fmax(dmax, fabs(X0[i] - X1[i])); }
