@@ -63,8 +63,9 @@ CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t
   const size_t Nm = jstruct_nmax(sp);
   // one vehicle: no capacitance systems, 16 right-hand sides per interior, 16-row separator blocks with 10 right-hand sides
   if (sp.V == 1) return 2 * nk * ld + 3 * NI * kSI * 16 + 2 * NI * kSI * kJC + 2 * NI * kJC * 16 + 2 * (Nm + 1) * 256 + 4 * (Nm + 1) * 160 + 4 * nk;
+  // (+ the capacitance systems' rows on their way from the builder to the elimination: two halves per interval index, written and read)
   return 2 * nk * ld + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
-         2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk;
+         2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk + 2 * (2 * Nm) * (size_t)kJRowBuf;
 }
 CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   JWork s;

@@ -5,7 +5,7 @@
 // rear-axle point inside the back cell and the front point (x + wb cos psi, y + wb sin psi) inside the front cell of
 // strategy step i, both shrunk by `shrink_tube` (:178-192); optional terminal heading (:194-195); cost sum a^2 + w^2
 // (:175-176).  Hundreds of stages, a handful of instances (one per vehicle), solved once: the opposite regime of the
-// MPC step.  One instance per workgroup (one wavefront), workspace in global memory (L2-resident), the interior-point iteration of
+// MPC step.  One instance per workgroup (four wavefronts since round 5; the sweeps on one lane), workspace in global memory (L2-resident), the interior-point iteration of
 // oracle/ipm.py with the EXACT Hessian of the Lagrangian and the curvature test  dx'(H + delta I)dx >= kappa |dx|^2  (delta: 0, 1e-4,
 // x8 ...).  The Newton system is a stage recursion (Riccati sweep, below): rounds 1-3 solved it as a banded LU with partial pivoting
 // (half-bandwidth 40, ~3,000 pivots one after the other: 10 ms per iteration); the sweep is T stages of ~350 operations on one lane.
@@ -22,7 +22,7 @@
 #define CFZP_FN inline
 #endif
 
-// On the GPU all 64 lanes of the workgroup run the solver redundantly (same scalars, same addresses: one memory
+// On the GPU all lanes of the workgroup (256 since round 5: four wavefronts) run the solver redundantly (same scalars, same addresses: one memory
 // transaction per instruction, so it costs what one lane would); only the loops marked CFZP_LANE_FOR split their
 // iterations over the lanes, with a workgroup barrier before anybody reads what another lane wrote.  On the CPU the
 // marked loops simply run in full.

@@ -27,7 +27,7 @@
 
 namespace {
 
-// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup of one wavefront, workspace in global memory; see cfz_plan.inl.
+// state_ws (reference vehicle.py:99-231): one planning NLP per workgroup of four wavefronts, workspace in global memory; see cfz_plan.inl.
 // bound 512 = at most 256 VGPRs, no AGPRs: see colloc_kernel
 // FAST: the sweep's per-stage data in dynamic LDS (41 (T + 1) doubles); otherwise in the workspace (plans too long for the LDS).
 template <bool FAST>
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void state_ws_kernel(int B, const cfzp::PSpec 
                                 const long long *x_off, double *slab, const long long *slab_off, int32_t *oi, double *od) {
   const int b = blockIdx.x;
   if (b >= B) return;
-  // all 64 lanes run the solver's scalar logic redundantly and share the marked loops; the Riccati sweep is lane 0's (cfz_plan.inl)
+  // all 256 lanes run the solver's scalar logic redundantly and share the marked loops; the Riccati sweep is lane 0's (cfz_plan.inl)
   cfzp::solve_state_ws<FAST>(specs[b], tube + tube_off[b], X + x_off[b], slab + slab_off[b], oi + 2 * b, od + 3 * b);
 }
 
@@ -250,8 +250,12 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   const bool want_lds = po->kernel == CFZ_KERNEL_WIDE || (po->kernel == CFZ_KERNEL_AUTO && B <= cus);
   const bool fast = want_lds && lds_bytes + fa.sharedSizeBytes <= (size_t)lds_max &&
                     hipFuncSetAttribute((const void *)state_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  if (fast) hipLaunchKernelGGL(state_ws_kernel<true>, dim3(B), dim3(64), lds_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
-  else { (void)hipGetLastError(); hipLaunchKernelGGL(state_ws_kernel<false>, dim3(B), dim3(64), 0, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod); }
+  // Four wavefronts per plan in either mode (the same reductions, the same bits): the marked loops split over 256 lanes, the sweeps stay
+  // one lane's.  Measured (wall, 256 / 1024 / 2048 plans): 64 threads 34 / 100 / 115 ms, 128: 30 / 70 / 132, 256: 27 / 101 / 159 -- taken for
+  // BASELINE's batch of 256.
+  const int swt = 256;
+  if (fast) hipLaunchKernelGGL(state_ws_kernel<true>, dim3(B), dim3(swt), lds_bytes, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod);
+  else { (void)hipGetLastError(); hipLaunchKernelGGL(state_ws_kernel<false>, dim3(B), dim3(swt), 0, st, B, dspec, dtube, doff, dX, doff + B, dslab, doff + 2 * B, doi, dod); }
   HIP_OK(hipGetLastError());
   std::vector<int32_t> oi((size_t)B * 2); std::vector<double> od((size_t)B * 3);
   HIP_OK(hipMemcpyAsync(X.data(), dX, (size_t)nx * 8, hipMemcpyDeviceToHost, st));
