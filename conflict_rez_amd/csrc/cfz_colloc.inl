@@ -539,12 +539,37 @@ CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
 //     S dsigma - dnu = -r_sigma,   g'dp - dsigma - reg_dual dnu = -c_r
 //     =>  dnu = D (g'dp + t),  dsigma = (dnu - r_sigma) / S,   D = 1 / (1/S + reg_dual),  t = c_r + r_sigma / S
 // so the pose block gains D g g' and the pose right-hand side loses D t g; g, D, t are kept in w.cond for `recover`.
+// In the joint scheme (jstruct_mode: the band is never factored in place) the band is NOT cleared here: solve_colloc clears it once, and
+// every entry this function ever writes is written by its FIRST writer with a plain store in every assembly -- a point's Hessian entries
+// are summed in registers (in the order the band path adds them: the same bits) and stored once, Jacobian entries and the rows' -reg_dual
+// have one writer each; the tube rows' condensed blocks are added afterwards.  What is never written stays the zero of that one clear.
+// (A third of a single plan's HBM traffic was the clear and the read half of the read-modify-writes.)
+CFZC_PIECE void band_clear(const CSpec &sp, const Band &Bd) {
+  const CDims d = cdims(sp);
+#if defined(__HIP_DEVICE_COMPILE__)
+  {  // 16-byte stores
+    double *z = Bd.ab;
+    const int tot = d.nk * Bd.ld, head = (int)(((size_t)z >> 3) & 1);
+    if (threadIdx.x == 0 && head) z[0] = 0.0;
+    double2 *z2 = reinterpret_cast<double2 *>(z + head);
+    const int n2 = (tot - head) >> 1;
+    for (int t = (int)threadIdx.x; t < n2; t += (int)blockDim.x) z2[t] = make_double2(0.0, 0.0);
+    if (threadIdx.x == 0 && ((tot - head) & 1)) z[tot - 1] = 0.0;
+  }
+#else
+  CFZP_LANE_FOR(t, 0, d.nk * Bd.ld - 1) Bd.ab[t] = 0.0;
+#endif
+  CFZP_SYNC();
+}
+CFZP_FN void set2(const Band &B, int i, int j, double v) { bnd(B, i, j) = v; if (i != j) bnd(B, j, i) = v; }
 CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, double delta) {
   const CDims d = cdims(sp);
   const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   const int *px = w.posx, *pc = w.posc;
   const double *X = w.x, *nu = w.nu;
   const double dt = X[d.iDt];
+  const bool once = jstruct_mode(sp);  // (see above)
+  if (!once) {
 #if defined(__HIP_DEVICE_COMPILE__)
   {  // the band is cleared with 16-byte stores (88 MB per assembly of the four-vehicle plan)
     double *z = Bd.ab;
@@ -558,13 +583,86 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
 #else
   CFZP_LANE_FOR(t, 0, d.nk * Bd.ld - 1) Bd.ab[t] = 0.0;
 #endif
+  }
   CFZP_LANE_FOR(col, 0, d.nk - 1) w.bord[col] = 0.0;
   CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, d.n - 1) if (px[i] >= 0) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
-  CFZP_LANE_FOR(i, 0, d.m - 1) if (pc[i] >= 0) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
-  CFZP_SYNC();
-  CFZP_LANE_FOR(i, 0, 7 * sp.V - 1) put(Bd, pc[i], px[7 * kPts * d.off[i / 7] + i % 7], 1.0);
-  CFZP_LANE_FOR(q, 0, d.np - 1) {  // every entry written here belongs to point q alone
+  if (!once) {
+    CFZP_LANE_FOR(i, 0, d.n - 1) if (px[i] >= 0) bnd(Bd, px[i], px[i]) += w.sig[i] + delta + sp.reg_primal;
+    CFZP_LANE_FOR(i, 0, d.m - 1) if (pc[i] >= 0) bnd(Bd, pc[i], pc[i]) -= sp.reg_dual;
+    CFZP_SYNC();
+    CFZP_LANE_FOR(i, 0, 7 * sp.V - 1) put(Bd, pc[i], px[7 * kPts * d.off[i / 7] + i % 7], 1.0);
+  } else {
+    CFZP_LANE_FOR(i, 0, d.m - 1) if (pc[i] >= 0) bnd(Bd, pc[i], pc[i]) = 0.0 - sp.reg_dual;
+    CFZP_LANE_FOR(i, 0, 7 * sp.V - 1) set2(Bd, pc[i], px[7 * kPts * d.off[i / 7] + i % 7], 1.0);
+  }
+  if (once) CFZP_LANE_FOR(q, 0, d.np - 1) {  // the same entries as the loop below, in the same order, a point's Hessian entries in registers
+    const int i = q / kPts, k = q - i * kPts, b = 7 * q, va = veh_of_interval(d, i), il = i - d.off[va];
+    const double *p = X + b, *l = nu + d.rO + 5 * q;
+    const double cs = cos(p[2]), sn = sin(p[2]), tn = tan(p[4]), sec2 = 1.0 + tn * tn, v = p[3], wv = p[6], bk = sp.B[k];
+    double dg[7], p01 = 0.0, p02 = 0.0, p12 = 0.0;
+    for (int c = 0; c < 7; ++c) dg[c] = 0.0 + (w.sig[b + c] + delta + sp.reg_primal);
+    dg[3] += bk * dt * 2.0 * wv * wv; dg[6] += bk * dt * 2.0 * v * v;
+    set2(Bd, px[b + 3], px[b + 6], 0.0 + bk * dt * 4.0 * v * wv);
+    dg[4] += bk * dt * 2.0; dg[5] += bk * dt * 2.0;
+    const double l0 = -l[0] * dt, l1 = -l[1] * dt, l2 = -l[2] * dt;
+    dg[2] += l0 * (-v * cs) + l1 * (-v * sn);
+    set2(Bd, px[b + 2], px[b + 3], 0.0 + (l0 * (-sn) + l1 * cs));
+    set2(Bd, px[b + 3], px[b + 4], 0.0 + l2 * sec2 / sp.wb);
+    dg[4] += l2 * 2.0 * v * tn * sec2 / sp.wb;
+    w.bord[px[b + 2]] += -(-v * sn * l[0] + v * cs * l[1]);
+    w.bord[px[b + 3]] += bk * 2.0 * v * wv * wv - (cs * l[0] + sn * l[1] + tn / sp.wb * l[2]);
+    w.bord[px[b + 4]] += bk * 2.0 * p[4] - v / sp.wb * sec2 * l[2];
+    w.bord[px[b + 5]] += bk * 2.0 * p[5] - l[3];
+    w.bord[px[b + 6]] += bk * 2.0 * v * v * wv - l[4];
+    double f[5];
+    f_ct(p, sp.wb, f);
+    const int r = d.rO + 5 * q;
+    for (int cc = 0; cc < 5; ++cc) {
+      for (int j = 0; j < kPts; ++j) set2(Bd, pc[r + cc], px[7 * (i * kPts + j) + cc], 0.0 + sp.A[j][k]);
+      w.bord[pc[r + cc]] += -f[cc];
+    }
+    set2(Bd, pc[r + 0], px[b + 2], 0.0 + -dt * (-v * sn)); set2(Bd, pc[r + 0], px[b + 3], 0.0 + -dt * cs);
+    set2(Bd, pc[r + 1], px[b + 2], 0.0 + -dt * (v * cs)); set2(Bd, pc[r + 1], px[b + 3], 0.0 + -dt * sn);
+    set2(Bd, pc[r + 2], px[b + 3], 0.0 + -dt * tn / sp.wb); set2(Bd, pc[r + 2], px[b + 4], 0.0 + -dt * v / sp.wb * sec2);
+    set2(Bd, pc[r + 3], px[b + 5], 0.0 + -dt); set2(Bd, pc[r + 4], px[b + 6], 0.0 + -dt);
+    if (k == 0 && il >= 1) for (int cc = 0; cc < 7; ++cc) { set2(Bd, pc[d.rC + 7 * (i - va - 1) + cc], px[b + cc], 1.0); set2(Bd, pc[d.rC + 7 * (i - va - 1) + cc], px[b - 7 + cc], -1.0); }
+    for (int j = 0; j < sp.n_obs; ++j) {
+      double A[4][2], bb[4], V[4][2], sep[2], gr[2][3];
+      obstacle(sp, j, A, bb, V);
+      const int sl = w.sel[q * sp.n_obs + j], fc = (sl >> 4) & 3;
+      cfz::rows_for<true>(A, bb, V, p[0], p[1], cs, sn, sp.g, sl, sep, gr);
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = d.rR + q * d.nr + 2 * j + rr, sk = d.sO + q * d.nr + 2 * j + rr;
+        const double S = w.sig[sk] + delta + sp.reg_primal, D = 1.0 / (1.0 / S + sp.reg_dual), t = w.c[row] - prox * sp.reg_dual * nu[row] + w.r1[sk] / S;
+        double *cd = w.cond + (size_t)(q * d.nr + 2 * j + rr) * 5;
+        cd[0] = gr[rr][0]; cd[1] = gr[rr][1]; cd[2] = gr[rr][2]; cd[3] = D; cd[4] = t;
+        for (int a = 0; a < 3; ++a) w.rhs[px[b + a]] -= D * t * gr[rr][a];
+        dg[0] += D * gr[rr][0] * gr[rr][0]; p01 += D * gr[rr][0] * gr[rr][1]; p02 += D * gr[rr][0] * gr[rr][2];
+        dg[1] += D * gr[rr][1] * gr[rr][1]; p12 += D * gr[rr][1] * gr[rr][2];
+        dg[2] += D * gr[rr][2] * gr[rr][2];
+        const double nr_ = nu[row];
+        const int vtx = rr == 0 ? ((sl >> 2) & 3) : (sl & 3);
+        if ((sl >> 6) == 3) {
+          const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
+          const double rbx = cs * bx - sn * by, rby = sn * bx + cs * by, a0 = gr[rr][0], a1 = gr[rr][1];
+          const double nq = CFZC_VV_TANGENTIAL * nr_ / sep[0], t2 = a1 * rby + a0 * rbx;
+          dg[0] += nq * a1 * a1; dg[1] += nq * a0 * a0; p01 += -nq * a1 * a0;
+          p02 += -nq * a1 * t2; p12 += nq * a0 * t2;
+          dg[2] += nq * t2 * t2 - nr_ * (a0 * rbx + a1 * rby);
+        } else if ((sl >> 6) == 1) {
+          const double bx = (vtx == 0 || vtx == 3) ? sp.g[0] : -sp.g[2], by = (vtx < 2) ? sp.g[1] : -sp.g[3];
+          dg[2] += nr_ * -(gr[rr][0] * (cs * bx - sn * by) + gr[rr][1] * (sn * bx + cs * by));
+        } else {
+          const double gf = sp.g[fc];
+          p02 += nr_ * -gr[rr][1]; p12 += nr_ * gr[rr][0];
+          dg[2] += nr_ * -(sep[rr] + gf);
+        }
+      }
+    }
+    for (int c = 0; c < 7; ++c) bnd(Bd, px[b + c], px[b + c]) = dg[c];
+    set2(Bd, px[b], px[b + 1], p01); set2(Bd, px[b], px[b + 2], p02); set2(Bd, px[b + 1], px[b + 2], p12);
+  }
+  if (!once) CFZP_LANE_FOR(q, 0, d.np - 1) {  // every entry written here belongs to point q alone
     const int i = q / kPts, k = q - i * kPts, b = 7 * q, va = veh_of_interval(d, i), il = i - d.off[va];
     const double *p = X + b, *l = nu + d.rO + 5 * q;
     const double cs = cos(p[2]), sn = sin(p[2]), tn = tan(p[4]), sec2 = 1.0 + tn * tn, v = p[3], wv = p[6], bk = sp.B[k];
@@ -666,8 +764,8 @@ CFZC_PIECE double assemble(const CSpec &sp, const CWork &w, const Band &Bd, doub
   }
   CFZP_LANE_FOR(a, 0, sp.V - 1) {
     const int bl = 7 * (kPts * d.off[a + 1] - 1);
-    for (int i = 0; i < 4; ++i) put(Bd, pc[d.rF + 5 * a + i], px[bl + 3 + i], 1.0);
-    if (sp.has_final[a]) put(Bd, pc[d.rF + 5 * a + 4], px[bl + 2], 1.0);
+    for (int i = 0; i < 4; ++i) { if (once) set2(Bd, pc[d.rF + 5 * a + i], px[bl + 3 + i], 1.0); else put(Bd, pc[d.rF + 5 * a + i], px[bl + 3 + i], 1.0); }
+    if (sp.has_final[a]) { if (once) set2(Bd, pc[d.rF + 5 * a + 4], px[bl + 2], 1.0); else put(Bd, pc[d.rF + 5 * a + 4], px[bl + 2], 1.0); }
   }
   CFZP_SYNC();
   // pair rows, condensed like the obstacle rows but into the poses of both vehicles (6 x 6: D g g' + nu H); one pair after
@@ -1561,7 +1659,7 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   SWork SW = {};
   JWork JW = {};
   if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); if (SW.flag[1] != 0.0) structured = false; }  // (not the layout cfz_struct.inl assumes: the band elimination)
-  if (jstructured) { JW = jstruct_carve(sp, w.sw); jstruct_setup(sp, d, w, JW); }
+  if (jstructured) { JW = jstruct_carve(sp, w.sw); jstruct_setup(sp, d, w, JW); band_clear(sp, Bd); }  // (the band's only clear: see assemble)
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
   CFZP_SYNC();
   CFZP_LANE_FOR(q, 0, d.np - 1) {

@@ -54,7 +54,7 @@ CFZP_FN size_t jstruct_doubles(const CSpec &sp) {
          (size_t)kJRows + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
 }
 // doubles the structured elimination of one joint Newton system moves between its phases (bench.py's roofline of configs[3]): the band
-// cleared and gathered once, the pair blocks written and read; W written, read for C'W and by the back-substitution; C and C'W written and
+// written where the assembly has entries and gathered once, the pair blocks written and read; W written, read for C'W and by the back-substitution; C and C'W written and
 // read; Z written, read by the Schur complements and by the back-substitution; separator blocks, right-hand sides and solutions written and
 // read once; the two right-hand sides in and out
 CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t npp) {
@@ -62,9 +62,11 @@ CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t
   for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
   const size_t Nm = jstruct_nmax(sp);
   // one vehicle: no capacitance systems, 16 right-hand sides per interior, 16-row separator blocks with 10 right-hand sides
-  if (sp.V == 1) return 2 * nk * ld + 3 * NI * kSI * 16 + 2 * NI * kSI * kJC + 2 * NI * kJC * 16 + 2 * (Nm + 1) * 256 + 4 * (Nm + 1) * 160 + 4 * nk;
+  // (the band: gathered once, nk ld; written where the assembly has entries, about an eighth of it -- it is cleared once per solve, not per
+  // Newton system: cfz_colloc.inl assemble)
+  if (sp.V == 1) return nk * ld + nk * ld / 8 + 3 * NI * kSI * 16 + 2 * NI * kSI * kJC + 2 * NI * kJC * 16 + 2 * (Nm + 1) * 256 + 4 * (Nm + 1) * 160 + 4 * nk;
   // (+ the capacitance systems' rows on their way from the builder to the elimination: two halves per interval index, written and read)
-  return 2 * nk * ld + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
+  return nk * ld + nk * ld / 8 + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
          2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk + 2 * (2 * Nm) * (size_t)kJRowBuf;
 }
 CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {

@@ -315,7 +315,9 @@ def test_collocation_plan_against_the_independent_solver_on_gpu(agent):
     # the same kernel at tight tolerances with IPOPT's form of the dual regularisation (`exact_rows`): the independent optimum
     # itself (vehicle_1: status 0, cost to 1e-8, poses to 1e-6 m; vehicles 2, 3: the unregularised rows lose rank where the vehicle
     # waits and the solve ends with status 2 / 3 at the optimum, cost to 1e-6, poses to 1e-5 m)
-    r2 = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)[0]
+    # (iteration limit 1200: at these tolerances the plans with a waiting vehicle converge linearly -- vehicle_2_pillar takes 780 iterations
+    # with the band elimination, 801 with the structured one, 560 / 654 on the CPU build: tools/pillar_tight.py)
+    r2 = engine.colloc(spec, [p[0]], [tb], [guess], [float(d["guess"][-1])], [fh], max_iter=1200, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)[0]
     assert r2["status"] == 0 or (agent not in ("vehicle_1", "vehicle_1_pillar") and r2["status"] in (2, 3)), (r2["status"], r2["iters"])
     check_plan_against_independent(r2["traj"], r2["dt"], True, agent)
 
