@@ -102,7 +102,7 @@ CFZP_FN PDims dims(const PSpec &sp) {
 // workspace (doubles), carved out of one slab by `carve`.  st / fb / vf: per stage, what the Riccati sweep reads (kSt), the feedback it
 // leaves for the forward sweep (kFb) and the value function the multipliers are read from (kVf); ce: the tube rows of a checkpoint
 // condensed into its pose block; dx2: the sweep's second solution (the terminal-heading column); flag: the sweep's verdict and eta
-constexpr int kSt = 27, kFb = 14, kVf = 25;
+constexpr int kSt = 33, kFb = 14, kVf = 25;
 struct PWork {
   double *x, *xt, *zl, *zu, *nu, *dx, *dnu, *dzl, *dzu, *g, *c, *ct, *xl, *xu, *r1, *hd, *st, *fb, *vf, *ce, *dx2, *flag;
 };
@@ -200,9 +200,10 @@ CFZP_FN void jt_nu(const PSpec &sp, const double *tube, const double *X, const d
 // of stage 0; the tube rows' from their slacks.  No pivoting: where the reduced Hessian  R + B' P B  of a stage is not positive the
 // curvature test  dx'(H + delta I)dx >= kappa |dx|^2  would not pass either, and the sweep reports failure for a singular one.
 //
-// st[k] (kSt): a02 a03 a12 a13 a23 a24 | q0..q4 q23 q34 | r0 r1 | gz[5] gu[2] | c[5];   fb[k] (kFb): K (2 x 5) kk1[2] kk2[2];
+// st[k] (kSt): a02 a03 a12 a13 a23 a24 | q0..q4 q23 q34 | r0 r1 | gz[5] gu[2] | c[5] | for the matrix-core sweep: q0 q1 q2 with the tube block of
+// a checkpoint stage added, E01 E02 E12 (zero elsewhere);   fb[k] (kFb): K (2 x 5) kk1[2] kk2[2];
 // vf[k] (kVf): P (upper triangle by rows, 15) p1[5] p2[5];   ce[i]: E00 E01 E02 E11 E12 E22 of checkpoint i
-// FAST: st and fb live in the kernel's dynamic LDS ((kSt + kFb)(T + 1) doubles: 99 KB at T = 300); otherwise (plans too long for the
+// FAST: st and fb live in the kernel's dynamic LDS ((kSt + kFb)(T + 1) doubles: 113 KB at T = 300); otherwise (plans too long for the
 // LDS, batches of several plans per CU; the CPU build) in the workspace.  The inlined code names the dynamic LDS directly; the sweeps,
 // functions of their own on the GPU (their registers are allocated apart from the solver's many live scalars), take LDS-typed POINTERS:
 // a non-inlined function that NAMES LDS is broken on this toolchain (gfx950, ROCm 7.2; cfz_colloc.inl's header, cfz_band.inl's `opaque`).
@@ -266,6 +267,14 @@ CFZP_FN void riccati_prepare(const PSpec &sp, const double *tube, const PWork &w
     for (int j = 0; j < 6; ++j) E[j] = e[j];
     for (int j = 0; j < 3; ++j) s[15 + j] += gp[j];
     s[8] += curv;
+  }
+  CFZP_SYNC();
+  CFZP_LANE_FOR(k, 0, sp.T) {  // the pose block of the stage's Hessian as the matrix-core sweep reads it: with the tube block where there is one
+    double *s = st_ + (size_t)kSt * k;
+    const bool chk = k >= sp.N && k % sp.N == 0;
+    const double *E = w.ce + 6 * (chk ? k / sp.N - 1 : 0);
+    s[27] = s[6] + (chk ? E[0] : 0.0); s[28] = s[7] + (chk ? E[3] : 0.0); s[29] = s[8] + (chk ? E[5] : 0.0);
+    s[30] = chk ? E[1] : 0.0; s[31] = chk ? E[2] : 0.0; s[32] = chk ? E[4] : 0.0;
   }
   CFZP_SYNC();
 }
@@ -355,6 +364,175 @@ CFZP_SWEEP int riccati_backward(const PSpec &sp, const PWork &w, SP st_, SP fb_)
   return 0;
 }
 
+// The same backward sweep on the matrix cores (round 5; the MPC kernel's sweep, cfz_solver.inl riccati_backward_mfma, is its model: 1,850 ->
+// 1,130 cycles per stage there).  One wavefront, all 64 lanes.  Homogeneous coordinates [z (5), 1, e] with e the coordinate the border vector p2
+// rides on, variables [z, 1, e, -, u0, u1] (index 7 unused: the u rows stand at 8, 9 and, crossed, at 12, 13, so that the lane groups 0 and 1
+// hold M's rows of u in their own registers):  [z+; 1; e] = T [z; 1; e; u],  Pt = [[P p1 p2], [p1' . .], [p2' . .]]  (the entries marked . are
+// constants of the value function that feed nothing),  M = T' Pt T + Ht,  Pt <- M_kk - M_ke M_ee^-1 M_ek,  [K kk kl] = -M_ee^-1 M_ek -- five dependent
+// v_mfma_f64_16x16x4_f64 per stage: Y = Pt T (Pt's accumulator is the first operand as it stands: it is symmetric), M = Tt' Y onto Ht (Y's
+// accumulator is the second operand as it stands), Pt = M - U V.  Operands are read from the stage data with one load each (a constant reads
+// a harmless word with mask 0).  Same recursion as riccati_backward above, the sums in another order.
+struct PlEnt { int off; double c; };  // off >= 0: word off of the stage's data, else the constant c
+CFZP_FN PlEnt pl_T(int r, int j, double dt) {  // T[r][j]: r = 0..6 (z+, 1, e), j a variable
+  PlEnt e = {-1, 0.0};
+  if (r < 0 || r > 6 || j < 0 || j == 7 || j > 9) return e;
+  if (r == 5) { e.c = j == 5 ? 1.0 : 0.0; return e; }
+  if (r == 6) { e.c = j == 6 ? 1.0 : 0.0; return e; }
+  if (j < 5) {
+    e.c = r == j ? 1.0 : 0.0;
+    if (r == 0 && j == 2) e.off = 0; else if (r == 0 && j == 3) e.off = 1; else if (r == 1 && j == 2) e.off = 2; else if (r == 1 && j == 3) e.off = 3;
+    else if (r == 2 && j == 3) e.off = 4; else if (r == 2 && j == 4) e.off = 5;
+    return e;
+  }
+  if (j == 5) { e.off = 22 + r; return e; }
+  if (j == 8) e.c = r == 3 ? dt : 0.0;
+  if (j == 9) e.c = r == 4 ? dt : 0.0;
+  return e;
+}
+CFZP_FN PlEnt pl_H(int a, int b) {  // Ht[a][b] over the variables (gradient in row / column 5)
+  PlEnt e = {-1, 0.0};
+  if (a < 0 || b < 0 || a == 7 || b == 7 || a > 9 || b > 9) return e;
+  if (a > b) { const int t = a; a = b; b = t; }
+  if (a == b) { if (a < 3) e.off = 27 + a; else if (a < 5) e.off = 6 + a; else if (a == 8) e.off = 13; else if (a == 9) e.off = 14; return e; }
+  if (a == 0 && b == 1) e.off = 30; else if (a == 0 && b == 2) e.off = 31; else if (a == 1 && b == 2) e.off = 32;
+  else if (a == 2 && b == 3) e.off = 11; else if (a == 3 && b == 4) e.off = 12;
+  else if (b == 5 && a < 5) e.off = 15 + a;
+  else if (a == 5 && b == 8) e.off = 20; else if (a == 5 && b == 9) e.off = 21;
+  return e;
+}
+// the sweep in homogeneous coordinates as plain loops (the CPU build with -DCFZP_DENSE_SWEEP: the check of the tables above and of the
+// recursion the matrix-core sweep runs, against riccati_backward)
+template <class SP>
+CFZP_FN int riccati_backward_dense(const PSpec &sp, const PWork &w, SP st_, SP fb_) {
+  const int T = sp.T, var[9] = {0, 1, 2, 3, 4, 5, 6, 8, 9};
+  double P[7][7];
+  auto val = [&](const PlEnt &e, int k) -> double { return e.off >= 0 ? (double)st_[(size_t)kSt * k + e.off] : e.c; };
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) P[i][j] = val(pl_H(i, j), T);
+  if (sp.has_final) { P[2][6] = -1.0; P[6][2] = -1.0; }
+  auto store_vf = [&](int k) {
+    double *v = w.vf + (size_t)kVf * k; int o = 0;
+    for (int i = 0; i < 5; ++i) for (int j = i; j < 5; ++j) v[o++] = P[i][j];
+    for (int i = 0; i < 5; ++i) { v[15 + i] = P[5][i]; v[20 + i] = P[6][i]; }
+  };
+  store_vf(T);
+  for (int k = T - 1; k >= 1; --k) {
+    double Tm[7][9], H[9][9], Y[7][9], M[9][9];
+    for (int r = 0; r < 7; ++r) for (int j = 0; j < 9; ++j) Tm[r][j] = val(pl_T(r, var[j], sp.dt), k);
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) H[a][b] = val(pl_H(var[a], var[b]), k);
+#if defined(CFZP_DENSE_TRANSPOSED)  // what the matrix-core sweep does: Pt's accumulator as the first operand "as it stands" = its transpose
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 9; ++j) { double s_ = 0.0; for (int q = 0; q < 7; ++q) s_ += P[q][i] * Tm[q][j]; Y[i][j] = s_; }
+#else
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 9; ++j) { double s_ = 0.0; for (int q = 0; q < 7; ++q) s_ += P[i][q] * Tm[q][j]; Y[i][j] = s_; }
+#endif
+    for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) { double s_ = H[i][j]; for (int q = 0; q < 7; ++q) s_ += Tm[q][i] * Y[q][j]; M[i][j] = s_; }
+    const double det = M[7][7] * M[8][8] - M[7][8] * M[8][7];
+    if (!(det != 0.0) || !isfinite(det)) return 1;
+    const double idet = 1.0 / det, i00 = M[8][8] * idet, i01 = -M[7][8] * idet, i10 = -M[8][7] * idet, i11 = M[7][7] * idet;
+    double V[2][7];
+    for (int j = 0; j < 7; ++j) { V[0][j] = i00 * M[7][j] + i01 * M[8][j]; V[1][j] = i10 * M[7][j] + i11 * M[8][j]; }
+    auto *f = fb_ + (size_t)kFb * k;
+    for (int g = 0; g < 2; ++g) { for (int j = 0; j < 5; ++j) f[5 * g + j] = -V[g][j]; f[10 + g] = -V[g][5]; f[12 + g] = -V[g][6]; }
+#if defined(CFZP_DENSE_TRANSPOSED)
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) P[i][j] = M[i][j] - M[7][i] * V[0][j] - M[8][i] * V[1][j];
+    for (int i = 0; i < 7; ++i) for (int j = i + 1; j < 7; ++j) { const double m_ = 0.5 * (P[i][j] + P[j][i]); P[i][j] = m_; P[j][i] = m_; }  // (see riccati_backward_mfma)
+#else
+    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) P[i][j] = M[i][j] - M[i][7] * V[0][j] - M[i][8] * V[1][j];
+#endif
+    store_vf(k);
+  }
+  return 0;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double pl_v4d __attribute__((ext_vector_type(4)));
+struct PlFetch { int addr; double mask, c; };
+__device__ __forceinline__ PlFetch pl_fetch(const PlEnt &e, int k) { PlFetch f; f.addr = (e.off >= 0 ? e.off : 6) + k * kSt; f.mask = e.off >= 0 ? 1.0 : 0.0; f.c = e.off >= 0 ? 0.0 : e.c; return f; }
+template <class SP> __device__ __forceinline__ double pl_get(SP st_, const PlFetch &f) { return fma((double)st_[f.addr], f.mask, f.c); }
+__device__ __forceinline__ double pl_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double pl_perm(double v, int byte_lane) {  // v of the lane whose index * 4 is byte_lane
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_lane, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_lane, __double2loint(v)));
+}
+template <class SP>
+__device__ __attribute__((noinline)) int riccati_backward_mfma(int T, double dt, int has_final, double *vf_, SP st_, SP fb_) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, g = lane >> 4;
+  cfzb::glb_f64 *vf = (cfzb::glb_f64 *)vf_;
+  // row i of Tt' / Ht stands for variable: 0..6 themselves, 8 -> u0, 9 -> u1, 12 -> u1, 13 -> u0, the others are zero rows
+  const int vlo = lo < 7 ? lo : (lo == 8 ? 8 : lo == 9 ? 9 : lo == 12 ? 9 : lo == 13 ? 8 : -1);
+  int vrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int row = g + 4 * r; vrow[r] = row < 7 ? row : (row == 8 ? 8 : row == 9 ? 9 : row == 12 ? 9 : row == 13 ? 8 : -1); }
+  // where this lane's entries of the value function go: register 0 = row g, register 1 = row 4 + g of Pt, column lo
+  const int v0 = (lo < 5 && lo >= g) ? (g * (11 - g)) / 2 + (lo - g) : -1;
+  const int v1 = lo < 5 ? (g == 0 ? (lo == 4 ? 14 : -1) : g == 1 ? 15 + lo : g == 2 ? 20 + lo : -1) : -1;
+  const int kout = lo < 5 ? 5 * g + lo : (lo == 5 ? 10 + g : 12 + g);  // this lane's gain (groups 0, 1; columns 0..6)
+  pl_v4d P;
+  {
+    PlFetch fH[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fH[r] = pl_fetch(pl_H(vrow[r], lo), T);
+    P = pl_v4d{pl_get(st_, fH[0]), pl_get(st_, fH[1]), pl_get(st_, fH[2]), pl_get(st_, fH[3])};
+    if (has_final) { if (g == 2 && lo == 6) P[0] = -1.0; if (g == 2 && lo == 2) P[1] = -1.0; }  // p2 = -e_psi: Pt[2][6] = Pt[6][2]
+  }
+  if (v0 >= 0) vf[(size_t)kVf * T + v0] = P[0];
+  if (v1 >= 0) vf[(size_t)kVf * T + v1] = P[1];
+  int k = T - 1;
+  PlFetch fB[2], fA[2], fH[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    fB[s_] = pl_fetch(pl_T(g + 4 * s_, (lo < 7 || lo == 8 || lo == 9) ? lo : -1, dt), k);
+    fA[s_] = pl_fetch(pl_T(g + 4 * s_, vlo, dt), k);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) fH[r] = pl_fetch(pl_H(vrow[r], lo), k);
+  double b0 = pl_get(st_, fB[0]), b1 = pl_get(st_, fB[1]), a0 = pl_get(st_, fA[0]), a1 = pl_get(st_, fA[1]);
+  pl_v4d H = {pl_get(st_, fH[0]), pl_get(st_, fH[1]), pl_get(st_, fH[2]), pl_get(st_, fH[3])};
+  for (; k >= 1; --k) {
+    pl_v4d Y = {0.0, 0.0, 0.0, 0.0};
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], b0, Y, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], b1, Y, 0, 0, 0);
+    pl_v4d M = H;
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, Y[0], M, 0, 0, 0);
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Y[1], M, 0, 0, 0);
+    // the next stage's operands: requested now, used after this stage's last matrix instruction (the last pass re-reads stage 1: harmless)
+    if (k > 1) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) { fB[s_].addr -= kSt; fA[s_].addr -= kSt; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fH[r].addr -= kSt;
+    }
+    const double nb0 = pl_get(st_, fB[0]), nb1 = pl_get(st_, fB[1]), na0 = pl_get(st_, fA[0]), na1 = pl_get(st_, fA[1]);
+    const pl_v4d nH = {pl_get(st_, fH[0]), pl_get(st_, fH[1]), pl_get(st_, fH[2]), pl_get(st_, fH[3])};
+    // M_ee: rows 8, 9 = groups 0, 1, register 2; columns 8, 9
+    const double m88 = pl_lane(M[2], 8), m89 = pl_lane(M[2], 9), m98 = pl_lane(M[2], 24), m99 = pl_lane(M[2], 25);
+    const double det = fma(m88, m99, -(m89 * m98));
+    if (!(det != 0.0) || !isfinite(det)) return 1;
+    const double idet = 1.0 / det;
+    const double i00 = m99 * idet, i01 = -m89 * idet, i10 = -m98 * idet, i11 = m88 * idet;
+    const double m6 = g == 0 ? M[2] : M[3], m7 = g == 0 ? M[3] : M[2];  // rows of u0, u1 in this group's registers (8 / 12, 13 / 9)
+    const double ia = g == 0 ? i00 : i10, ib = g == 0 ? i01 : i11;
+    const double Vf = fma(ia, m6, ib * m7), V = g < 2 ? Vf : 0.0;
+    const double U = g < 2 ? -M[2] : 0.0;
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(U, V, M, 0, 0, 0);
+    // Pt <- (Pt + Pt') / 2 on its rows and columns 0..7.  The accumulator serves as the next stage's first operand "as it stands", i.e. as
+    // its TRANSPOSE: what the two triangles differ by in the last bits is an antisymmetric part that this use does not damp -- over 300
+    // stages it grows until the step is wrong in the third digit (vehicle 0's plan: 211 iterations instead of 22; the CPU build's plain
+    // loops reproduce it with -DCFZP_DENSE_TRANSPOSED).  Element (lo, g + 4 r) sits in lane 16 (lo & 3) + g + 4 r, register lo >> 2.
+    {
+      const int l0 = (((lo & 3) << 4) + g) << 2, l1 = l0 + 16;
+      const double t00 = pl_perm(M[0], l0), t01 = pl_perm(M[1], l0), t10 = pl_perm(M[0], l1), t11 = pl_perm(M[1], l1);
+      const double x0 = lo < 4 ? t00 : t01, x1 = lo < 4 ? t10 : t11;
+      if (lo < 8) { M[0] = 0.5 * (M[0] + x0); M[1] = 0.5 * (M[1] + x1); }
+    }
+    if (g < 2 && lo < 7) fb_[(size_t)kFb * k + kout] = -V;
+    if (v0 >= 0) vf[(size_t)kVf * k + v0] = M[0];
+    if (v1 >= 0) vf[(size_t)kVf * k + v1] = M[1];
+    P = M; b0 = nb0; b1 = nb1; a0 = na0; a1 = na1; H = nH;
+  }
+  return 0;
+}
+#endif
+
 // forward sweep (ONE lane): the two solutions' dz, du -> w.dx (right-hand side -(r1, c)) and w.dx2 (e_psi_T)
 template <class SP>
 CFZP_SWEEP void riccati_forward(const PSpec &sp, const PWork &w, SP st_, SP fb_) {
@@ -390,16 +568,30 @@ CFZP_FN int newton_step(const PSpec &sp, const double *tube, const PWork &w, con
   CFZP_STAGE_PTRS(w, sp.T);
   const int T = sp.T; const double dt = sp.dt;
   riccati_prepare<FAST>(sp, tube, w, sig, delta);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (threadIdx.x < 64) {  // the backward sweep on the matrix cores: the first wavefront, all its lanes
+    int fail;
+    if (FAST) fail = riccati_backward_mfma(T, dt, sp.has_final, w.vf, CFZP_OPAQUE((fast_f64 *)st_), CFZP_OPAQUE((fast_f64 *)fb_));
+    else fail = riccati_backward_mfma(T, dt, sp.has_final, w.vf, (cfzb::glb_f64 *)st_, (cfzb::glb_f64 *)fb_);
+    if (threadIdx.x == 0) w.flag[0] = (double)fail;
+  }
+  __syncthreads();
+#endif
   if (CFZP_FIRST) {
     int fail;
-    if (FAST) {
-      fast_f64 *const fs = CFZP_OPAQUE((fast_f64 *)st_), *const ff = CFZP_OPAQUE((fast_f64 *)fb_);
-      fail = riccati_backward(sp, w, fs, ff);
-      if (!fail) riccati_forward(sp, w, fs, ff);
-    } else {
-      fail = riccati_backward(sp, w, st_, fb_);
-      if (!fail) riccati_forward(sp, w, st_, fb_);
+#if defined(__HIP_DEVICE_COMPILE__)
+    fail = w.flag[0] != 0.0;
+    if (!fail) {
+      if (FAST) riccati_forward(sp, w, CFZP_OPAQUE((fast_f64 *)st_), CFZP_OPAQUE((fast_f64 *)fb_));
+      else riccati_forward(sp, w, st_, fb_);
     }
+#elif defined(CFZP_DENSE_SWEEP)
+    fail = riccati_backward_dense(sp, w, st_, fb_);
+    if (!fail) riccati_forward(sp, w, st_, fb_);
+#else
+    fail = riccati_backward(sp, w, st_, fb_);
+    if (!fail) riccati_forward(sp, w, st_, fb_);
+#endif
     double eta = 0.0;
     if (!fail && sp.has_final) eta = (w.dx[7 * T + 2] + w.c[d.m - 1]) / (w.dx2[7 * T + 2] + sp.reg_dual);
     w.flag[0] = (double)fail; w.flag[1] = eta;

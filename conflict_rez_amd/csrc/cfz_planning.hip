@@ -235,7 +235,7 @@ int cfz_state_ws_w(cfz_plan_ws *w, int B, const cfz_plan_options *po, const int3
   HIP_OK(hipMemsetAsync(dslab, 0, (size_t)ns * 8, st));
   // cfz_plan_options.kernel: WIDE = the sweep's per-stage data in LDS (one plan per CU at a time, 15 % faster per plan), NARROW = in the
   // workspace (several plans share a CU: 1024 plans take 0.13 s instead of 0.20 s); by default LDS while the batch fits the CUs in one
-  // round.  A plan too long for the LDS (T > 498) runs from the workspace whatever was asked.
+  // round.  A plan too long for the LDS (376 bytes per stage: T > ~430) runs from the workspace whatever was asked.
   int Tmax = 0, lds_max = 0, cus = 0;
   for (int b = 0; b < B; ++b) Tmax = std::max(Tmax, specs[b].T);
   const size_t lds_bytes = (size_t)(cfzp::kSt + cfzp::kFb) * (Tmax + 1) * sizeof(double);

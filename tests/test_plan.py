@@ -59,6 +59,37 @@ def test_plan_kernel_source_matches_oracle(plans):
                 assert np.isclose(s["x"][0], p[0, 0]) and np.isclose(s["v"][0], 0.0, atol=1e-9)
 
 
+def test_homogeneous_sweep_of_the_matrix_cores_in_plain_loops(plans, tmp_path):
+    """The recursion `riccati_backward_mfma` runs on the GPU (cfz_plan.inl: homogeneous coordinates [z, 1, e], five matrix products per
+    stage, the value function used as its own transpose and symmetrised at every stage) as plain loops in the CPU build
+    (-DCFZP_DENSE_SWEEP -DCFZP_DENSE_TRANSPOSED), against the hand-written one-lane sweep of the default build: the four plans of the
+    strategy take the same iterations to the same cost.  (Without the symmetrisation the transposed use lets an antisymmetric part of P
+    grow over vehicle 0's 300 stages: 220 iterations, status 2 -- docs/notebook.md.)"""
+    import ctypes
+    import subprocess
+
+    import plan_emu_binding as pe
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libplan_dense.so")
+    subprocess.check_call(["g++", "-O2", "-DCFZP_DENSE_SWEEP", "-DCFZP_DENSE_TRANSPOSED", "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", lib,
+                           os.path.join(root, "tests", "emu", "cfz_plan_emu.cpp")])
+    opt = ipm.IpmOptions(**PLAN_OPT)
+    want = {}
+    for a, (tube, p) in plans.items():
+        nlp = StateWsNlp(p[0], tube, final_heading=float(p[-1, 2]), shrink_tube=0.5)
+        want[a] = (nlp, nlp.pack(p[:, 0], p[:, 1], p[:, 2], v=speed_guess(p, nlp.dt)))
+        want[a] += (pe.solve(want[a][0], want[a][1], opt),)
+    default_lib = pe._lib
+    try:
+        pe._lib = ctypes.CDLL(lib)
+        for a, (nlp, X0, r0) in want.items():
+            r = pe.solve(nlp, X0, opt)
+            assert (r["status"], r["iters"]) == (r0["status"], r0["iters"]) == (0, r0["iters"]) and abs(r["f"] - r0["f"]) < 1e-9 * r0["f"], a
+    finally:
+        pe._lib = default_lib
+
+
 def test_default_guess_through_the_tube(plans):
     """`cfz_state_ws_default_guess` (host arithmetic of the library, no GPU): what `cfz_state_ws` starts from when the caller has no guess
     -- `spline_ws = False`, which the reference's own scripts configure for vehicle_0 (vehicle.py:894-899, vehicle_follower.py:871-876;
