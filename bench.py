@@ -315,6 +315,7 @@ def planning_extras(device=0, B=256, cpu=True):
         "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5, 6 obstacles)",
         "plans_per_s": B / (t_ws + t_col), "state_ws_s": t_ws, "colloc_s": t_col, "state_ws_converged": len(good), "colloc_converged": ok,
         "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])), "colloc_iters_max": int(max(r["iters"] for r in plans.values())),
+        "ms_per_iteration_of_the_slowest_plan": 1e3 * t_col / max(1, max(r["iters"] for r in plans.values())),
         "state_ws_iters_mean": float(np.mean([w_["iters"] for w_ in ws])), "state_ws_iters_max": int(max(w_["iters"] for w_ in ws)),
         "roofline": roofline_of(alg, t_col, d1, "bytes the structured elimination of one Newton system moves between its phases (cfz_colloc_elimination_info: "
                                 "%s per vehicle) x interior-point iterations of every plan" % {a: info1[a]["alg_bytes"] for a in agents})}
@@ -334,6 +335,7 @@ def planning_extras(device=0, B=256, cpu=True):
         "plans_per_s": B / (t_ws + t_col4), "colloc_s": t_col4, "colloc_converged": sum(r["status"] == 0 for r in r4),
         "colloc_iters_mean": float(np.mean([r["iters"] for r in r4])), "colloc_iters_max": int(max(r["iters"] for r in r4)),
         "colloc_iters_top3": sorted((int(r["iters"]) for r in r4), reverse=True)[:3],
+        "ms_per_iteration_of_the_slowest_plan": 1e3 * t_col4 / max(1, max(r["iters"] for r in r4)),
         "note": "one plan of the batch has several minimisers: replayed on the CPU build with its guess perturbed by 1e-13 (relative) it takes 61-212 "
                 "iterations and ends at one of three plans (docs/notebook.md); its count here is a draw from that range, the launch lasts as long as it"}
     # ---- configs[3] ------------------------------------------------------------------------------------------------------------
@@ -362,6 +364,10 @@ def planning_extras(device=0, B=256, cpu=True):
         "workload": f"BASELINE.json configs[3]: {len(scen)} centralised four-vehicle joint plans (six pairs, one shared dt) in one launch, one workgroup each",
         "plans_per_s": len(scen) / t_joint, "joint_s": t_joint, "converged": sum(r["status"] == 0 for r in rj),
         "iters_mean": float(np.mean([r["iters"] for r in rj])), "iters_max": int(max(r["iters"] for r in rj)),
+        "iters_top3": sorted((int(r["iters"]) for r in rj), reverse=True)[:3],
+        # the launch lasts as long as its slowest plan, and which plan wanders between minimisers (and for how long) is decided in the last
+        # digits of its guess: the time per iteration of that plan is the figure that compares builds
+        "ms_per_iteration_of_the_slowest_plan": 1e3 * t_joint / max(1, max(r["iters"] for r in rj)),
         "unknowns": nk4, "half_bandwidth": kb4, "band_bytes": bb4, "workspace_bytes_per_plan": info4["workspace_bytes"],
         "elimination": "structured (cfz_jstruct.inl): vehicle-major ordering, per-vehicle band of half-bandwidth 51, no band across the vehicles",
         "roofline": roofline_of(alg4, t_joint, d3, f"bytes the structured elimination of one joint Newton system moves between its phases "
