@@ -107,6 +107,27 @@ CFZP_FN double bmin(double v) {
   return v;
 }
 
+// A marked loop whose items each read several words.  On the GPU a plan has its CU to itself with two wavefronts per SIMD: nothing hides a
+// memory round trip, and an item written as "if (bounded) { load ...; load ... }" costs two or three of them one after the other, nine
+// items per thread.  Here U items' loads -- load(i) is branch-free -- are issued before the first is used, then the items are consumed in
+// ascending order: the order, hence the bits, of CFZP_LANE_FOR.  On the CPU a plain loop.
+struct LV { double v[12]; int k[2]; };
+template <int U, class L, class C>
+CFZP_FN void lane_for_loads(int n, L load, C consume) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int nt = (int)blockDim.x;
+  for (int b = (int)threadIdx.x; b < n; b += U * nt) {
+    LV v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int ii = b + u * nt; v[u] = load(ii < n ? ii : n - 1); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int ii = b + u * nt; if (ii < n) consume(ii, v[u]); }
+  }
+#else
+  for (int i = 0; i < n; ++i) consume(i, load(i));
+#endif
+}
+
 constexpr int kMaxVeh = 4, kMaxPairs = 6;
 
 // V = 1: the single-vehicle plan.  V > 1: the joint plan of the centralised planner (reference
@@ -1533,10 +1554,15 @@ CFZC_PIECE void band_substitute(const Band &B, int n, const int *ipiv, double *b
 CFZC_PIECE double barrier_obj(const CSpec &sp, const CWork &w, const double *X, double mu) {
   const CDims d = cdims(sp);
   double s = 0.0, bad = 0.0;
-  CFZP_LANE_FOR(i, 0, d.n - 1) {
-    if (w.xl[i] > -1e300) { const double dl = X[i] - w.xl[i]; if (!(dl > 0.0)) bad = 1.0; else s += log(dl); }
-    if (w.xu[i] < 1e300) { const double du = w.xu[i] - X[i]; if (!(du > 0.0)) bad = 1.0; else s += log(du); }
-  }
+  lane_for_loads<3>(d.n, [&](int i) { LV q; q.v[0] = w.xl[i]; q.v[1] = w.xu[i]; q.v[2] = X[i]; return q; },
+                    [&](int, const LV &q) {
+                      const bool hl = q.v[0] > -1e300, hu = q.v[1] < 1e300;
+                      const double dl = q.v[2] - q.v[0], du = q.v[1] - q.v[2];
+                      if (hl && !(dl > 0.0)) bad = 1.0;
+                      if (hl && dl > 0.0) s += log(dl);
+                      if (hu && !(du > 0.0)) bad = 1.0;
+                      if (hu && du > 0.0) s += log(du);
+                    });
   if (bmax(bad) > 0.0) return INFINITY;
   return objective(sp, X) - mu * bsum(s);
 }
@@ -1699,29 +1725,39 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     gradient(sp, w.x, w.g);
     jt_nu(sp, w.sel, w.x, w.nu, w.r1);
     double theta = 0.0, cviol = 0.0, sum_nu = 0.0, sum_z = 0.0, dual_inf = 0.0;
-    CFZP_LANE_FOR(i, 0, m - 1) { theta += fabs(w.c[i]); cviol = fmax(cviol, fabs(w.c[i])); sum_nu += fabs(w.nu[i]); }
+    lane_for_loads<4>(m, [&](int i) { LV q; q.v[0] = w.c[i]; q.v[1] = w.nu[i]; return q; },
+                      [&](int, const LV &q) { theta += fabs(q.v[0]); cviol = fmax(cviol, fabs(q.v[0])); sum_nu += fabs(q.v[1]); });
     theta = bsum(theta); cviol = bmax(cviol); sum_nu = bsum(sum_nu);
     if (theta_min < 0.0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
-    CFZP_LANE_FOR(i, 0, n - 1) { sum_z += w.zl[i] + w.zu[i]; dual_inf = fmax(dual_inf, fabs(w.g[i] + w.r1[i] - w.zl[i] + w.zu[i])); }
+    // one pass over the variables: multiplier sum, dual infeasibility, complementarity, and the barrier problem's complementarity at the
+    // present mu (the first pass of the loop below)
+    double cmp0 = 0.0, cm_first = 0.0;
+    lane_for_loads<3>(n, [&](int i) { LV q; q.v[0] = w.zl[i]; q.v[1] = w.zu[i]; q.v[2] = w.g[i]; q.v[3] = w.r1[i]; q.v[4] = w.xl[i]; q.v[5] = w.xu[i]; q.v[6] = w.x[i]; return q; },
+                      [&](int, const LV &q) {
+                        sum_z += q.v[0] + q.v[1]; dual_inf = fmax(dual_inf, fabs(q.v[2] + q.v[3] - q.v[0] + q.v[1]));
+                        if (q.v[4] > -1e300) { cmp0 = fmax(cmp0, fabs((q.v[6] - q.v[4]) * q.v[0])); cm_first = fmax(cm_first, fabs((q.v[6] - q.v[4]) * q.v[0] - mu)); }
+                        if (q.v[5] < 1e300) { cmp0 = fmax(cmp0, fabs((q.v[5] - q.v[6]) * q.v[1])); cm_first = fmax(cm_first, fabs((q.v[5] - q.v[6]) * q.v[1] - mu)); }
+                      });
     sum_z = bsum(sum_z); dual_inf = bmax(dual_inf);
     const double s_d = fmax(sp.s_max, (sum_nu + sum_z) / (double)(m + nb)) / sp.s_max, s_c = fmax(sp.s_max, sum_z / (double)nb) / sp.s_max;
-    double cmp0 = 0.0;
-    CFZP_LANE_FOR(i, 0, n - 1) {
-      if (w.xl[i] > -1e300) cmp0 = fmax(cmp0, fabs((w.x[i] - w.xl[i]) * w.zl[i]));
-      if (w.xu[i] < 1e300) cmp0 = fmax(cmp0, fabs((w.xu[i] - w.x[i]) * w.zu[i]));
-    }
     cmp0 = bmax(cmp0);
     err0 = fmax(dual_inf / s_d, fmax(cviol, cmp0 / s_c));
     if (!isfinite(err0)) { status = 3; break; }
     if (err0 <= sp.tol && dual_inf <= sp.dual_inf_tol && cviol <= sp.constr_viol_tol && cmp0 <= sp.compl_inf_tol) { status = 0; break; }
     if (iter == sp.max_iter) { status = 1; break; }  // (assigned here as well: the GPU build returned 0 for this exit without it)
     bool mu_eased = false;  // at most one such decrease per iteration
+    bool cm_known = true;   // cm_first belongs to the present mu
     while (mu > mu_floor) {
-      double cm = 0.0;
-      CFZP_LANE_FOR(i, 0, n - 1) {
-        if (w.xl[i] > -1e300) cm = fmax(cm, fabs((w.x[i] - w.xl[i]) * w.zl[i] - mu));
-        if (w.xu[i] < 1e300) cm = fmax(cm, fabs((w.xu[i] - w.x[i]) * w.zu[i] - mu));
+      double cm = cm_first;
+      if (!cm_known) {
+        cm = 0.0;
+        lane_for_loads<3>(n, [&](int i) { LV q; q.v[0] = w.zl[i]; q.v[1] = w.zu[i]; q.v[4] = w.xl[i]; q.v[5] = w.xu[i]; q.v[6] = w.x[i]; return q; },
+                          [&](int, const LV &q) {
+                            if (q.v[4] > -1e300) cm = fmax(cm, fabs((q.v[6] - q.v[4]) * q.v[0] - mu));
+                            if (q.v[5] < 1e300) cm = fmax(cm, fabs((q.v[5] - q.v[6]) * q.v[1] - mu));
+                          });
       }
+      cm_known = false;
       cm = bmax(cm);
       if (fmax(dual_inf / s_d, fmax(cviol, cm / s_c)) <= sp.kappa_eps * mu) mu = fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu)));
       else {
@@ -1736,19 +1772,21 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       }
     }
     const double tau = fmax(sp.tau_min, 1.0 - mu);
-    CFZP_LANE_FOR(i, 0, n - 1) {
-      double gphi = w.g[i], s = 0.0;
-      if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; gphi -= mu / dl; s += w.zl[i] / dl; }
-      if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; gphi += mu / du; s += w.zu[i] / du; }
-      w.g[i] = gphi; w.r1[i] = gphi + w.r1[i]; w.sig[i] = s;
-    }
+    lane_for_loads<3>(n, [&](int i) { LV q; q.v[0] = w.zl[i]; q.v[1] = w.zu[i]; q.v[2] = w.g[i]; q.v[3] = w.r1[i]; q.v[4] = w.xl[i]; q.v[5] = w.xu[i]; q.v[6] = w.x[i]; return q; },
+                      [&](int i, const LV &q) {
+                        double gphi = q.v[2], s = 0.0;
+                        if (q.v[4] > -1e300) { const double dl = q.v[6] - q.v[4]; gphi -= mu / dl; s += q.v[0] / dl; }
+                        if (q.v[5] < 1e300) { const double du = q.v[5] - q.v[6]; gphi += mu / du; s += q.v[1] / du; }
+                        w.g[i] = gphi; w.r1[i] = gphi + q.v[3]; w.sig[i] = s;
+                      });
     CFZP_SYNC();
     double delta = delta_floor; bool have = false;
     tk[0] += tick() - ta;
     for (int tries = 0; tries < 60; ++tries) {
       ta = tick();
-      CFZP_LANE_FOR(i, 0, n - 1) if (w.posx[i] >= 0) w.rhs[w.posx[i]] = -w.r1[i];
-      CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.rhs[w.posc[i]] = -w.c[i] + prox * sp.reg_dual * w.nu[i];
+      lane_for_loads<4>(n, [&](int i) { LV q; q.k[0] = w.posx[i]; q.v[0] = w.r1[i]; return q; }, [&](int, const LV &q) { if (q.k[0] >= 0) w.rhs[q.k[0]] = -q.v[0]; });
+      lane_for_loads<4>(m, [&](int i) { LV q; q.k[0] = w.posc[i]; q.v[0] = w.c[i]; q.v[1] = w.nu[i]; return q; },
+                        [&](int, const LV &q) { if (q.k[0] >= 0) w.rhs[q.k[0]] = -q.v[0] + prox * sp.reg_dual * q.v[1]; });
       CFZP_SYNC();
       const double hdd = assemble(sp, w, Bd, delta);
       CFZP_LANE_FOR(i, 0, d.nk - 1) w.rhs2[i] = w.bord[i];
@@ -1786,19 +1824,27 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
         tk[3] += tick() - ta;
         // bordered system: [K b; b' h] [y; s] = [r; r_dt]  ->  s = (r_dt - b'K^-1 r) / (h - b'K^-1 b)
         double bty = 0.0, btw = 0.0;
-        CFZP_LANE_FOR(i, 0, d.nk - 1) { bty += w.bord[i] * w.rhs[i]; btw += w.bord[i] * w.rhs2[i]; }
+        lane_for_loads<4>(d.nk, [&](int i) { LV q; q.v[0] = w.bord[i]; q.v[1] = w.rhs[i]; q.v[2] = w.rhs2[i]; return q; },
+                          [&](int, const LV &q) { bty += q.v[0] * q.v[1]; btw += q.v[0] * q.v[2]; });
         bty = bsum(bty); btw = bsum(btw);
         const double ddt = (-w.r1[d.iDt] - bty) / (hdd - btw);
         double curv = 0.0, dd = 0.0, bad = isfinite(ddt) ? 0.0 : 1.0;
-        CFZP_LANE_FOR(i, 0, n - 1) if (i == d.iDt || w.posx[i] >= 0) w.dx[i] = i == d.iDt ? ddt : w.rhs[w.posx[i]] - w.rhs2[w.posx[i]] * ddt;
-        CFZP_LANE_FOR(i, 0, m - 1) if (w.posc[i] >= 0) w.dnu[i] = w.rhs[w.posc[i]] - w.rhs2[w.posc[i]] * ddt;
+        // (an item is two dependent loads -- its position, then the two right-hand sides there: the positions of U items travel together)
+        lane_for_loads<4>(n, [&](int i) { LV q; const int px_ = w.posx[i]; q.k[0] = px_; q.v[0] = w.rhs[px_ >= 0 ? px_ : 0]; q.v[1] = w.rhs2[px_ >= 0 ? px_ : 0]; return q; },
+                          [&](int i, const LV &q) { if (i == d.iDt || q.k[0] >= 0) w.dx[i] = i == d.iDt ? ddt : q.v[0] - q.v[1] * ddt; });
+        lane_for_loads<4>(m, [&](int i) { LV q; const int pc_ = w.posc[i]; q.k[0] = pc_; q.v[0] = w.rhs[pc_ >= 0 ? pc_ : 0]; q.v[1] = w.rhs2[pc_ >= 0 ? pc_ : 0]; return q; },
+                          [&](int i, const LV &q) { if (q.k[0] >= 0) w.dnu[i] = q.v[0] - q.v[1] * ddt; });
         CFZP_SYNC();
-        CFZP_LANE_FOR(r, 0, d.np * d.nr - 1) {  // the condensed pairs, from the pose step of their point
-          const double *cd = w.cond + (size_t)r * 5, *dp = w.dx + 7 * (r / d.nr);
-          const double S = w.sig[d.sO + r] + delta + sp.reg_primal;
-          const double dn = cd[3] * (cd[0] * dp[0] + cd[1] * dp[1] + cd[2] * dp[2] + cd[4]);
-          w.dnu[d.rR + r] = dn; w.dx[d.sO + r] = (dn - w.r1[d.sO + r]) / S;
-        }
+        lane_for_loads<4>(d.np * d.nr, [&](int r) {  // the condensed pairs, from the pose step of their point
+          LV q; const double *cd = w.cond + (size_t)r * 5, *dp = w.dx + 7 * (r / d.nr);
+          for (int c = 0; c < 5; ++c) q.v[c] = cd[c];
+          q.v[5] = dp[0]; q.v[6] = dp[1]; q.v[7] = dp[2]; q.v[8] = w.sig[d.sO + r]; q.v[9] = w.r1[d.sO + r];
+          return q;
+        }, [&](int r, const LV &q) {
+          const double S = q.v[8] + delta + sp.reg_primal;
+          const double dn = q.v[3] * (q.v[0] * q.v[5] + q.v[1] * q.v[6] + q.v[2] * q.v[7] + q.v[4]);
+          w.dnu[d.rR + r] = dn; w.dx[d.sO + r] = (dn - q.v[9]) / S;
+        });
         if (w.condt != nullptr) CFZP_LANE_FOR(r, 0, 8 * d.nchk - 1) {  // the condensed tube rows, from the pose step of their checkpoint
           const double *cd = w.condt + (size_t)r * 5, *dp = w.dx + 7 * chk_point(sp, d, r / 8);
           const double S = w.sig[d.sT + r] + delta + sp.reg_primal;
@@ -1816,8 +1862,10 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
           w.dnu[d.rP + r] = dn; w.dx[d.sP + r] = (dn - w.r1[d.sP + r]) / S;
         }
         CFZP_SYNC();
-        CFZP_LANE_FOR(i, 0, n - 1) { const double v = w.dx[i]; if (!isfinite(v)) bad = 1.0; curv -= v * w.r1[i]; dd += v * v; }
-        CFZP_LANE_FOR(i, 0, m - 1) { const double v = w.dnu[i]; if (!isfinite(v)) bad = 1.0; curv += (w.c[i] - prox * sp.reg_dual * w.nu[i]) * v - sp.reg_dual * v * v; }
+        lane_for_loads<4>(n, [&](int i) { LV q; q.v[0] = w.dx[i]; q.v[1] = w.r1[i]; return q; },
+                          [&](int, const LV &q) { const double v = q.v[0]; if (!isfinite(v)) bad = 1.0; curv -= v * q.v[1]; dd += v * v; });
+        lane_for_loads<4>(m, [&](int i) { LV q; q.v[0] = w.dnu[i]; q.v[1] = w.c[i]; q.v[2] = w.nu[i]; return q; },
+                          [&](int, const LV &q) { const double v = q.v[0]; if (!isfinite(v)) bad = 1.0; curv += (q.v[1] - prox * sp.reg_dual * q.v[2]) * v - sp.reg_dual * v * v; });
         curv = bsum(curv); dd = bsum(dd); bad = bmax(bad);
         CFZP_SYNC();
         if (bad == 0.0 && curv >= sp.curv_kappa * dd) { have = true; break; }
@@ -1831,23 +1879,25 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     if (delta > 0.0) delta_last = delta;
     ta = tick();
     double a_pri = 1.0, a_dual = 1.0, dphi = 0.0;
-    CFZP_LANE_FOR(i, 0, n - 1) {
-      const double dxi = w.dx[i];
-      dphi += w.g[i] * dxi;
-      w.dzl[i] = 0.0; w.dzu[i] = 0.0;
-      if (w.xl[i] > -1e300) {
-        const double dl = w.x[i] - w.xl[i];
-        w.dzl[i] = mu / dl - w.zl[i] - w.zl[i] / dl * dxi;
-        if (dxi < 0.0) a_pri = fmin(a_pri, -tau * dl / dxi);
-        if (w.dzl[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zl[i] / w.dzl[i]);
-      }
-      if (w.xu[i] < 1e300) {
-        const double du = w.xu[i] - w.x[i];
-        w.dzu[i] = mu / du - w.zu[i] + w.zu[i] / du * dxi;
-        if (dxi > 0.0) a_pri = fmin(a_pri, tau * du / dxi);
-        if (w.dzu[i] < 0.0) a_dual = fmin(a_dual, -tau * w.zu[i] / w.dzu[i]);
-      }
-    }
+    lane_for_loads<3>(n, [&](int i) { LV q; q.v[0] = w.zl[i]; q.v[1] = w.zu[i]; q.v[2] = w.g[i]; q.v[3] = w.dx[i]; q.v[4] = w.xl[i]; q.v[5] = w.xu[i]; q.v[6] = w.x[i]; return q; },
+                      [&](int i, const LV &q) {
+                        const double dxi = q.v[3];
+                        dphi += q.v[2] * dxi;
+                        double dzl = 0.0, dzu = 0.0;
+                        if (q.v[4] > -1e300) {
+                          const double dl = q.v[6] - q.v[4];
+                          dzl = mu / dl - q.v[0] - q.v[0] / dl * dxi;
+                          if (dxi < 0.0) a_pri = fmin(a_pri, -tau * dl / dxi);
+                          if (dzl < 0.0) a_dual = fmin(a_dual, -tau * q.v[0] / dzl);
+                        }
+                        if (q.v[5] < 1e300) {
+                          const double du = q.v[5] - q.v[6];
+                          dzu = mu / du - q.v[1] + q.v[1] / du * dxi;
+                          if (dxi > 0.0) a_pri = fmin(a_pri, tau * du / dxi);
+                          if (dzu < 0.0) a_dual = fmin(a_dual, -tau * q.v[1] / dzu);
+                        }
+                        w.dzl[i] = dzl; w.dzu[i] = dzu;
+                      });
     a_pri = bmin(a_pri); a_dual = bmin(a_dual); dphi = bsum(dphi);
 #if defined(CFZC_TRACE)
     {  // which bounds cut the step: the five smallest ratios (kind: p point variable 0..6, o obstacle slack, t tube slack, q pair slack)
@@ -1874,11 +1924,11 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     double alpha = a_pri; bool accepted = false, f_type = false;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
-      CFZP_LANE_FOR(i, 0, n - 1) w.xt[i] = w.x[i] + alpha * w.dx[i];
+      lane_for_loads<4>(n, [&](int i) { LV q; q.v[0] = w.x[i]; q.v[1] = w.dx[i]; return q; }, [&](int i, const LV &q) { w.xt[i] = q.v[0] + alpha * q.v[1]; });
       CFZP_SYNC();
       constraints(sp, w.sel, w.xt, w.ct);
       double th_t = 0.0;
-      CFZP_LANE_FOR(i, 0, m - 1) th_t += fabs(w.ct[i]);
+      lane_for_loads<4>(m, [&](int i) { LV q; q.v[0] = w.ct[i]; return q; }, [&](int, const LV &q) { th_t += fabs(q.v[0]); });
       th_t = bsum(th_t);
       const double ph_t = barrier_obj(sp, w, w.xt, mu);
       bool ok = isfinite(ph_t) && isfinite(th_t) && th_t <= theta_max && w.xt[d.iDt] > 0.0;
@@ -1945,12 +1995,13 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       if (nfilt == sp.filter_cap) { for (int q = 1; q < nfilt; ++q) { filt[q - 1][0] = filt[q][0]; filt[q - 1][1] = filt[q][1]; } --nfilt; }
       filt[nfilt][0] = (1.0 - sp.gamma_theta) * theta; filt[nfilt][1] = phi0 - sp.gamma_phi * theta; ++nfilt;
     }
-    if (!nu_done) CFZP_LANE_FOR(i, 0, m - 1) w.nu[i] += alpha * w.dnu[i];
-    CFZP_LANE_FOR(i, 0, n - 1) {
-      w.x[i] = w.xt[i];
-      if (w.xl[i] > -1e300) { const double dl = w.x[i] - w.xl[i]; w.zl[i] = fmin(fmax(w.zl[i] + a_dual * w.dzl[i], mu / (sp.kappa_sigma * dl)), sp.kappa_sigma * mu / dl); }
-      if (w.xu[i] < 1e300) { const double du = w.xu[i] - w.x[i]; w.zu[i] = fmin(fmax(w.zu[i] + a_dual * w.dzu[i], mu / (sp.kappa_sigma * du)), sp.kappa_sigma * mu / du); }
-    }
+    if (!nu_done) lane_for_loads<4>(m, [&](int i) { LV q; q.v[0] = w.nu[i]; q.v[1] = w.dnu[i]; return q; }, [&](int i, const LV &q) { w.nu[i] = q.v[0] + alpha * q.v[1]; });
+    lane_for_loads<3>(n, [&](int i) { LV q; q.v[0] = w.zl[i]; q.v[1] = w.zu[i]; q.v[2] = w.dzl[i]; q.v[3] = w.dzu[i]; q.v[4] = w.xl[i]; q.v[5] = w.xu[i]; q.v[6] = w.xt[i]; return q; },
+                      [&](int i, const LV &q) {
+                        w.x[i] = q.v[6];
+                        if (q.v[4] > -1e300) { const double dl = q.v[6] - q.v[4]; w.zl[i] = fmin(fmax(q.v[0] + a_dual * q.v[2], mu / (sp.kappa_sigma * dl)), sp.kappa_sigma * mu / dl); }
+                        if (q.v[5] < 1e300) { const double du = q.v[5] - q.v[6]; w.zu[i] = fmin(fmax(q.v[1] + a_dual * q.v[3], mu / (sp.kappa_sigma * du)), sp.kappa_sigma * mu / du); }
+                      });
     CFZP_SYNC();
     tk[4] += tick() - ta;
   }
