@@ -78,12 +78,19 @@ def test_planning_extras_of_the_bench_line():
     assert c1["four_obstacles"]["colloc_converged"] == 8 and c1["four_obstacles"]["plans_per_s"] > 1.0  # configs[1] as BASELINE.json words it
     assert 5 <= c1["state_ws_iters_mean"] <= c1["state_ws_iters_max"] <= 60 and c1["colloc_iters_mean"] <= c1["colloc_iters_max"] <= 150
     assert c1["four_obstacles"]["colloc_iters_max"] >= c1["four_obstacles"]["colloc_iters_mean"]
+    # the launch lasts as long as its slowest plan, and which plan wanders is decided in the last digits of its guess: the lines carry the
+    # three longest plans and the time per iteration of the slowest one, the figure that compares builds
+    f4 = c1["four_obstacles"]
+    assert f4["colloc_iters_top3"][0] == f4["colloc_iters_max"] and f4["colloc_iters_top3"] == sorted(f4["colloc_iters_top3"], reverse=True)
+    assert abs(f4["ms_per_iteration_of_the_slowest_plan"] - 1e3 * f4["colloc_s"] / f4["colloc_iters_max"]) < 1e-9 and "several minimisers" in f4["note"]
+    assert abs(c1["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c1["colloc_s"] / c1["colloc_iters_max"]) < 1e-9
     # configs[3] goes through the structured elimination (cfz_jstruct.inl): vehicle-major ordering, tube rows condensed, half-bandwidth 51,
     # no band across the vehicles (round 4: 12,350 unknowns in a band of half-bandwidth 298, 88 MB per plan)
     from conflict_rez_amd import engine
 
     assert c3["converged"] == 8 and c3["unknowns"] == 12350 - 16 * 30 and c3["half_bandwidth"] == 51 and c3["band_bytes"] == c3["unknowns"] * (2 * 51 + 1) * 8
     assert c3["iters_max"] <= 120 and "structured" in c3["elimination"] and c3["workspace_bytes_per_plan"] < 60e6
+    assert c3["iters_top3"][0] == c3["iters_max"] and abs(c3["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c3["joint_s"] / c3["iters_max"]) < 1e-9
     info4 = engine.colloc_elimination_info([11, 7, 7, 9])  # the four vehicles' strategy lengths
     assert (info4["nk"], info4["kb"]) == (c3["unknowns"], 51)
     band4 = engine.colloc_elimination_info([11, 7, 7, 9], structured=0)
