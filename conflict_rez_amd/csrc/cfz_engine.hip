@@ -61,7 +61,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void solve_kernel(con
   int oi[2]; double od[3];
   cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 #ifdef CFZ_STAMPS
-  duo.stamps = reinterpret_cast<unsigned long long *>(stats) + (size_t)B * 3 + (size_t)b * 12;  // diagnostic build: stats has room
+  duo.stamps = reinterpret_cast<unsigned long long *>(stats) + (size_t)B * 3 + (size_t)b * 24;  // diagnostic build: stats has room
 #endif
   if (du.l) {
     duo.l = du.l + (size_t)b * N * 4 * no; duo.mm = du.m + (size_t)b * N * 4 * no;
@@ -692,8 +692,8 @@ int create_fill(cfz_handle *h, const cfz_spec *spec, const cfz_options *opt) {
   HIP_OK(hipEventCreate(&h->ev0)); HIP_OK(hipEventCreate(&h->ev1)); HIP_OK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   HIP_OK(hipMalloc(&h->x0, B * 5 * 8)); HIP_OK(hipMalloc(&h->ref, B * 3 * N * 8));
   HIP_OK(hipMalloc(&h->nbr, (B * nn * 3 * N + 1) * 8)); HIP_OK(hipMalloc(&h->zu, B * 7 * N * 8));
-  // stats: 3 doubles per instance (+ 12 phase counters per instance for the -DCFZ_STAMPS diagnostic build)
-  HIP_OK(hipMalloc(&h->stats, B * (3 + 12) * 8)); HIP_OK(hipMalloc(&h->status, B * 4)); HIP_OK(hipMalloc(&h->iters, B * 4));
+  // stats: 3 doubles per instance (+ 24 phase counters per instance for the -DCFZ_STAMPS diagnostic build)
+  HIP_OK(hipMalloc(&h->stats, B * (3 + 24) * 8)); HIP_OK(hipMalloc(&h->status, B * 4)); HIP_OK(hipMalloc(&h->iters, B * 4));
   HIP_OK(hipMalloc(&h->l, (B * N * 4 * no + 1) * 8)); HIP_OK(hipMalloc(&h->m, (B * N * 4 * no + 1) * 8));
   HIP_OK(hipMalloc(&h->lam_ij, (B * nn * N * 4 + 1) * 8)); HIP_OK(hipMalloc(&h->lam_ji, (B * nn * N * 4 + 1) * 8));
   HIP_OK(hipMalloc(&h->s, (B * nn * N * 2 + 1) * 8));
@@ -836,10 +836,10 @@ double cfz_last_solve_ms(const cfz_handle *h_) {
 }
 
 #ifdef CFZ_STAMPS
-// diagnostic build only: the 12 phase counters of every instance of the last solve_kernel launch
+// diagnostic build only: the 24 phase counters of every instance of the last solve_kernel launch
 int cfz_debug_stamps(cfz_handle *h, int B, unsigned long long *out) {
   if (check(h, B)) return -1;
-  HIP_OK(hipMemcpy(out, h->stats + (size_t)B * 3, (size_t)B * 12 * 8, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out, h->stats + (size_t)B * 3, (size_t)B * 24 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 #endif

@@ -40,10 +40,16 @@
 #define CFZ_CALL static inline
 #endif
 
+#ifndef CFZ_LPS
+#define CFZ_LPS 4
+#endif
 namespace cfz {
-constexpr int kNL = 128;  // lanes per instance
-constexpr int kLPS = 4;   // lanes per stage
-constexpr int kMaxN = kNL / kLPS;
+constexpr int kLPS = CFZ_LPS;  // lanes per stage: 4 (a DPP quad, two wavefronts per instance) or 8 (half a DPP row, four wavefronts)
+static_assert(kLPS == 4 || kLPS == 8, "lanes per stage");
+constexpr int kLPSBits = kLPS == 4 ? 2 : 3;
+constexpr int kMaxN = 32;           // stages
+constexpr int kNL = kMaxN * kLPS;   // lanes per instance
+constexpr int kNW = kNL / 64;       // wavefronts per instance
 }  // namespace cfz
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -81,7 +87,7 @@ constexpr int kMaxN = kNL / kLPS;
 // iterations of one instance and written to a debug buffer (never to an output).
 #if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define CFZ_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } while (0)
-#define CFZ_STAMP_DECL unsigned long long stamp_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; const unsigned long long stamp_wall0 = wall_clock64(); unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#define CFZ_STAMP_DECL unsigned long long stamp_acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; const unsigned long long stamp_wall0 = wall_clock64(); unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #else
 #define CFZ_STAMP(i) do {} while (0)
 #define CFZ_STAMP_DECL
@@ -170,7 +176,7 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the current iterate
   L.rP = L.cs;  // value function of stage 0 (30 numbers) between the Riccati sweeps, when cos/sin are not needed
   L.filt = o; o += 32;
-  L.xw = o; o += 24;  // exchange between the two wavefronts of a reduction: [parity 2][wavefront 2][6 values]
+  L.xw = o; o += 12 * kNW;  // exchange between the wavefronts of a reduction: [parity 2][wavefront kNW][6 values]
   L.total = o;  // N = 30, 9 blocks: 5,115 doubles = 40,920 B = 20 LDS granules of 2 KiB: four instances per CU (cfz_create)
   return L;
 }
@@ -198,9 +204,10 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double quad_sum(double v) {
+__device__ __forceinline__ double quad_sum(double v) {  // sum over the kLPS lanes of a stage
   v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+  if (kLPS == 8) v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad's sum
   return v;
 }
 __device__ __forceinline__ double lane_value(double v, int lane) {
@@ -228,22 +235,29 @@ __device__ __forceinline__ void reduce_all(double *m, const Lay &L, int &xpar, c
   double w[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) w[i] = i < NS ? wave_reduce<0>(part[i]) : (i < NS + NX ? wave_reduce<1>(part[i]) : wave_reduce<2>(part[i]));
-  double *x = m + L.xw + xpar * 12;
+  double *x = m + L.xw + xpar * 6 * kNW;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int i = 0; i < n; ++i) x[(threadIdx.x >> 6) * 6 + i] = w[i];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < n; ++i)
-    out[i] = uniform_value(i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i])));
+  for (int i = 0; i < n; ++i) {
+    if (kNW == 2) out[i] = uniform_value(i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i])));
+    else out[i] = uniform_value(i < NS ? op2<0>(op2<0>(x[i], x[6 + i]), op2<0>(x[12 + i], x[18 + i]))
+                                : (i < NS + NX ? op2<1>(op2<1>(x[i], x[6 + i]), op2<1>(x[12 + i], x[18 + i])) : op2<2>(op2<2>(x[i], x[6 + i]), op2<2>(x[12 + i], x[18 + i]))));
+  }
   xpar ^= 1;
 }
 #else
 typedef double wsp_f64;
 static inline double quad_sum_emu(const double *v, int tid) {
   const int q = tid & ~3;
-  return (tid & 2) ? (v[q + 2] + v[q + 3]) + (v[q] + v[q + 1]) : (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+  const double mine = (tid & 2) ? (v[q + 2] + v[q + 3]) + (v[q] + v[q + 1]) : (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+  if (kLPS == 4) return mine;
+  const int o = q ^ 4;  // the other quad of the stage's eight lanes (row_half_mirror: lane i meets lane 7 - i)
+  const double other = (tid & 2) ? (v[o] + v[o + 1]) + (v[o + 2] + v[o + 3]) : (v[o + 2] + v[o + 3]) + (v[o] + v[o + 1]);
+  return mine + other;
 }
 template <int OP> static inline double wave_reduce_emu(const double *v) {
   double a[64], b[64];
@@ -255,9 +269,15 @@ template <int OP> static inline double wave_reduce_emu(const double *v) {
 }
 template <int NS, int NX, int NI> static inline void reduce_all_emu(const double (*part)[kNL], double *out) {
   for (int i = 0; i < NS + NX + NI; ++i) {
-    if (i < NS) out[i] = op2<0>(wave_reduce_emu<0>(part[i]), wave_reduce_emu<0>(part[i] + 64));
-    else if (i < NS + NX) out[i] = op2<1>(wave_reduce_emu<1>(part[i]), wave_reduce_emu<1>(part[i] + 64));
-    else out[i] = op2<2>(wave_reduce_emu<2>(part[i]), wave_reduce_emu<2>(part[i] + 64));
+    if (kNW == 2) {
+      if (i < NS) out[i] = op2<0>(wave_reduce_emu<0>(part[i]), wave_reduce_emu<0>(part[i] + 64));
+      else if (i < NS + NX) out[i] = op2<1>(wave_reduce_emu<1>(part[i]), wave_reduce_emu<1>(part[i] + 64));
+      else out[i] = op2<2>(wave_reduce_emu<2>(part[i]), wave_reduce_emu<2>(part[i] + 64));
+    } else {
+      if (i < NS) out[i] = op2<0>(op2<0>(wave_reduce_emu<0>(part[i]), wave_reduce_emu<0>(part[i] + 64)), op2<0>(wave_reduce_emu<0>(part[i] + 128), wave_reduce_emu<0>(part[i] + 192)));
+      else if (i < NS + NX) out[i] = op2<1>(op2<1>(wave_reduce_emu<1>(part[i]), wave_reduce_emu<1>(part[i] + 64)), op2<1>(wave_reduce_emu<1>(part[i] + 128), wave_reduce_emu<1>(part[i] + 192)));
+      else out[i] = op2<2>(op2<2>(wave_reduce_emu<2>(part[i]), wave_reduce_emu<2>(part[i] + 64)), op2<2>(wave_reduce_emu<2>(part[i] + 128), wave_reduce_emu<2>(part[i] + 192)));
+    }
   }
 }
 #endif
@@ -864,7 +884,7 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double h, double 
 CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg, double *m, const Lay &L, double alpha, int tid,
                              double &th_o, double &ph_o, double &ll_o, double &bad_o) {
   const int N = sp.N, nb = L.nb;
-  const int k = tid >> 2, sub = tid & 3;
+  const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
   // sum of logs taken as the log of a per-lane product (<= 18 factors in [1e-10, 1e2]: no over/underflow)
   double th = 0.0, ph = 0.0, lprod = 1.0, bad = 0.0;
   if (k < N) {
@@ -1441,7 +1461,7 @@ constexpr int kRestoMaxIter = 40, kRestoStall = 8;
 CFZ_CALL void resto_partials(const KSpec &sp, const KDer &dv, double *m, const Lay &L, double alpha, double eps, int tid, double &th_o,
                              double &ph_o) {
   const int N = sp.N, nb = L.nb;
-  const int k = tid >> 2, sub = tid & 3;
+  const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
   double th = 0.0, ph = 0.0;
   if (k < N) {
     double pt[kNP];
@@ -1505,7 +1525,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
   for (int rit = 0;; ++rit) {
     // ---- working set (refreshed from the second iteration on), row values into L.cj, dynamics with sensitivities --------------
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double cmax = 0.0, csum = 0.0, v0 = 0.0;
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
@@ -1532,7 +1552,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
         if (k + 1 < N) {
           double F[5], Sa[3], Sb[3];
           rk4_sens2(pk, pk[5], pk[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
-          for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
+          if (sub < 4) for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
           if (sub == 0) {
             for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
             for (int i = 0; i < 5; ++i) {
@@ -1553,7 +1573,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
     }
     // ---- stage problems: H_k = (zeta + lambda) I + rho sum a a' (violated rows) + rho_b (violated boxes), g_k the gradient ----
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double ac[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9
       double vmax = 0.0, bmax = 0.0, phi = 0.0;
       if (k >= 1 && k < N) {
@@ -1577,7 +1597,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
       for (int i = 0; i < 9; ++i) CFZ_P(qx, i) = ac[i];
       CFZ_P(rd, 0) = phi; CFZ_P(rd, 1) = vmax; CFZ_P(rd, 2) = bmax;
     CFZ_MID
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double phi = CFZ_P(rd, 0), bmax = 0.0;
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
@@ -1604,8 +1624,8 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
     const double phi = ro[0], vmax = ro[1], bmax = ro[2];
     if (vmax <= vgoal && bmax <= 0.5 * kRestoBoxMargin && cv_dyn <= dgoal) {
       CFZ_LANES(tid)
-        const int k = tid >> 2;
-        if (k < N && (tid & 3) == 0)
+        const int k = tid >> kLPSBits;
+        if (k < N && (tid & (kLPS - 1)) == 0)
           for (int q = 0; q < 6; ++q) {
             const int c = bcol(q);
             m[L.p + k * kNP + c] = fmin(fmax(m[L.p + k * kNP + c], sp.bounds[2 * q] + 0.5 * kRestoBoxMargin), sp.bounds[2 * q + 1] - 0.5 * kRestoBoxMargin);
@@ -1626,7 +1646,7 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
     CFZ_WAVE0(forward_scan(CFZ_WSP(m), N, sp.dt, L.ab, L.d, L.kk, L.rP, L.p, L.dp, L.x0, L.pi0, L.dpi0));
     CFZ_WAVE0(costate_scan(CFZ_WSP(m), N, L.ab, L.hc, L.gk, L.kk, L.dp, L.dpi, L.pi));
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double dphi = 0.0, pim = 0.0;
       if (k < N && sub == 0) {
         for (int i = 0; i < kNP; ++i) dphi += m[L.gk + k * kNP + i] * m[L.dp + k * kNP + i];
@@ -1656,8 +1676,8 @@ CFZ_COLD int restore_instance(const KSpec &sp, const KDer &dv, wsp_f64 *mw, cons
     if (!accepted) { CFZ_SYNC(); return -(iter + 1); }
     if (alpha < 0.2) lm = fmax(4.0 * lm, 1.0); else if (alpha == 1.0) lm *= 0.25;
     CFZ_LANES(tid)
-      const int k = tid >> 2;
-      if (k < N && (tid & 3) == 0) for (int i = 0; i < kNP; ++i) m[L.p + k * kNP + i] += alpha * m[L.dp + k * kNP + i];
+      const int k = tid >> kLPSBits;
+      if (k < N && (tid & (kLPS - 1)) == 0) for (int i = 0; i < kNP; ++i) m[L.p + k * kNP + i] += alpha * m[L.dp + k * kNP + i];
     CFZ_END
     ++iter;
   }
@@ -1669,7 +1689,7 @@ CFZ_COLD void cold_multipliers(const KSpec &sp, wsp_f64 *mw, const Lay &L, doubl
   double *m = (double *)mw;
   const int N = sp.N, nb = L.nb;
   CFZ_LANES(tid)
-    const int k = tid >> 2, sub = tid & 3;
+    const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
     if (k < N) {
       const double *pk = m + L.p + k * kNP;
       double sn, cn;
@@ -1782,7 +1802,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   const double mu0 = CFZ_UNIFORM(warm ? fmin(fmax(CFZ_UNIFORM(wst[CL.mu]), mu_floor), sp.mu_init) : sp.mu_init);
   const bool shift_hint = warm && sp.carry_shift != 0 && CFZ_UNIFORM(wst[CL.shifted]) != 0.0;  // oracle/ipm.py carry_shift
   CFZ_LANES(tid)
-    const int k = tid >> 2, sub = tid & 3;
+    const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
     if (k < N) {
       // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
       const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1];
@@ -1826,7 +1846,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   const bool resto_on = sp.resto > 0 && L.nr > 0;
 #endif
   CFZ_LANES(tid)
-    const int k = tid >> 2, sub = tid & 3;
+    const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
     if (k < N && sub == 0) {
       const int ko = k + 1 < N ? k + 1 : N - 1;
       for (int q = 0; q < 6; ++q) {
@@ -1869,7 +1889,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   for (; iter <= sp.max_iter; ++iter) {
     // ---- working set refresh (iter > iter0), rows and dynamics at the current point --------------
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double cmax = 0.0, csum = 0.0, chg = 0.0, v0 = 0.0;  // chg: a block of this lane changed its working set; v0: worst row violation of stages >= 1
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
@@ -1877,7 +1897,9 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         double sn, cn;
         sincos(pk[2], &sn, &cn);
         if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+        CFZ_STAMP(18);
         for (int j = sub; j < nb; j += kLPS) {
+          CFZ_STAMP(19 + (j >= kLPS) + (j >= 2 * kLPS));
           const int t = k * nb + j;
           double sep[2];
           int c1 = sel_ptr(m, L)[t];
@@ -1922,12 +1944,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
           if (k >= 1) v0 = fmax(v0, sp.dmin - fmin(sep[0], sep[1]));
         }
+        CFZ_STAMP(12);  // (diagnostic) working set and rows
         if (tid == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
         if (k + 1 < N) {
           // the quad integrates the stage together: lane sub carries sensitivity column sub, every lane column 4
           double F[5], Sa[3], Sb[3];
           rk4_sens2(pk, pk[5], pk[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
-          for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
+          if (sub < 4) for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
           if (sub == 0) {
             for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
             for (int i = 0; i < 5; ++i) {
@@ -1936,6 +1959,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             }
           }
         }
+        CFZ_STAMP(13);  // (diagnostic) dynamics
       }
       CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = chg; CFZ_P(rd, 3) = v0;
     CFZ_END
@@ -1953,7 +1977,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     if (theta_min < 0.0) { theta_min = CFZ_UNIFORM(1e-4 * fmax(1.0, theta)); theta_max = CFZ_UNIFORM(1e4 * fmax(1.0, theta)); }
     // ---- dual infeasibility, multiplier sums, complementarity, objective, log terms ----------
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double r0 = 0.0, r1 = 0.0, r2 = 0.0, dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, lprod = 1.0;
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
@@ -1971,10 +1995,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
         }
       }
+      CFZ_STAMP(14);  // (diagnostic) residuals: the rows
       CFZ_P(qx, 0) = r0; CFZ_P(qx, 1) = r1; CFZ_P(qx, 2) = r2;
       CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 3) = lprod; CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0;
     CFZ_MID
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double snu = CFZ_P(rd, 0), sz = CFZ_P(rd, 1), lprod = CFZ_P(rd, 3), dinf = CFZ_P(rd, 4), c0 = CFZ_P(rd, 5), fv = 0.0;
       if (k < N) {
         const bool first = sub == 0;  // the stage's own terms enter the sums once, through the quad's first lane
@@ -2032,7 +2057,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
     while (mu > mu_floor) {
       CFZ_LANES(tid)
-        const int k = tid >> 2, sub = tid & 3;
+        const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
         double cm = 0.0;
         if (k < N) {
           for (int jb = sub; jb < nb; jb += kLPS)
@@ -2060,7 +2085,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     //   kind 3 (distance r of two vertices, n = (a0,a1)): tau tau' / r + kappa e_psi e_psi' with tau = (t, t.dw), t = (-a1, a0)
     //           the unit tangent, dw = d(R b_v)/dpsi, kappa = -n.(R b_v); the only rows that curve x and y (cxx, cyy, cxy)
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double ac[15] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // g0 g1 g2 | h0 h1 h2 h7 h8 h9 | ca cb cc | cxx cyy cxy
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
@@ -2108,9 +2133,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           }
         }
       }
+      CFZ_STAMP(15);  // (diagnostic) assembly: the rows
       for (int i = 0; i < 15; ++i) CFZ_P(qx, i) = ac[i];
     CFZ_MID
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
         double g[kNP], h[11];
@@ -2177,7 +2203,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     // The ratio tests keep the largest -d(.)/(.) and divide once at the end; 1/distance is formed once
     // per bound and reused (a DP division is ~12 dependent instructions on this pipe).
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double rpri = 0.0, rdual = 0.0, dphi = 0.0;  // max of -dx/dist and -dz/z
       if (k < N) {
         const double *pk = m + L.p + k * kNP, *dpk = m + L.dp + k * kNP;
@@ -2204,6 +2230,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             rdual = fmax(rdual, -dzs / zs);
           }
         }
+        CFZ_STAMP(16);  // (diagnostic) step: the rows
         if (sub == 0) {
           double g[kNP];
           stage_grad(sp, dv, refg, k, pk, g);
@@ -2272,7 +2299,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     }
     // ---- update ------------------------------------------------------------------------------------------------
     CFZ_LANES(tid)
-      const int k = tid >> 2, sub = tid & 3;
+      const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       if (tid < 5) m[L.pi0 + tid] += alpha * m[L.dpi0 + tid];
       if (k < N) {
         const double ks = sp.kappa_sigma, iks = dv.iks;
@@ -2287,6 +2314,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             m[L.sg + t] = sgn; m[L.nuc + t] += alpha * dnu;
             m[L.zs + t] = fmin(fmax(zs + a_dual * dzs, msn * iks), ks * msn);
           }
+        CFZ_STAMP(17);  // (diagnostic) update: the rows
         if (sub == 0) {
           double *pk = m + L.p + k * kNP; const double *dpk = m + L.dp + k * kNP;
           for (int q = 0; q < 6; ++q) {
@@ -2452,7 +2480,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
 #if defined(CFZ_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
   // slot 0 ("setup", a handful of ticks) carries the wall time of the solve in 10 ns units (constant 100 MHz counter)
   stamp_acc[0] = wall_clock64() - stamp_wall0;
-  if (duo.stamps && threadIdx.x == 0) for (int i = 0; i < 12; ++i) duo.stamps[i] = stamp_acc[i];
+  if (duo.stamps && threadIdx.x == 0) for (int i = 0; i < 24; ++i) duo.stamps[i] = stamp_acc[i];
 #endif
 }
 

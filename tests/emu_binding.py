@@ -23,12 +23,15 @@ def build(force=False, sanitize=False):
     srcs = [os.path.join(ROOT, "tests", "emu", "cfz_emu.cpp"),
             os.path.join(ROOT, "conflict_rez_amd", "csrc", "cfz_solver.inl")]
     lib = _LIB.replace(".so", "_asan.so") if sanitize else _LIB
+    lps = os.environ.get("CFZ_EMU_LPS", "")  # lanes per stage of the emulated kernel (default: the source's)
+    if lps:
+        lib = lib.replace(".so", f"_lps{lps}.so")
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         flags = ["-O1", "-g", "-fsanitize=address,undefined"] if sanitize else ["-O2"]
         tmp = lib + ".%d.tmp" % os.getpid()  # built aside and renamed: parallel test workers never see a half-written library
         fma_ = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []  # (the Riccati sweep's fma() per term: hardware where there is one; as oracle/port.py)
-        subprocess.check_call(["g++", *flags, "-ffp-contract=off", *fma_, "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, srcs[0]])
+        subprocess.check_call(["g++", *flags, *([f"-DCFZ_LPS={lps}"] if lps else []), "-ffp-contract=off", *fma_, "-Wno-unknown-pragmas", "-fPIC", "-shared", "-o", tmp, srcs[0]])
         os.replace(tmp, lib)
     return lib
 
