@@ -34,7 +34,8 @@ ALG_BYTES_PER_SOLVE = 8 * (365 + 2 * 2550)  # parameters + warm 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-FLOP_PER_IPM_ITERATION = 0.75e6  # ~25 kflop per stage and iteration x 30 stages (blocks, RK4 + sensitivities, Riccati)
+FLOP_PER_IPM_ITERATION = 0.75e6  # SURVEY.md 8(d)'s ESTIMATE of the algorithm's flops: ~25 kflop per stage and iteration x 30 stages (blocks,
+                                  # RK4 + sensitivities, Riccati); quoted only when no counter pass of the loaded library is committed -- see profiled_fp64
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
 
@@ -211,6 +212,64 @@ def profiled_sq(kernel, require_current=True):
     return {"frac": 4.0 * raw, "raw_quotient": raw}, os.path.basename(tags[-1])[: -len("_pmc_SQ.csv")]
 
 
+def fp64_from_counters(c):
+    """Counter values of one dispatch (profiles/*_pmc_FP64.csv, *_pmc_MFMA.csv) -> the executed FP64 work.  The SQ_INSTS_VALU_* counters
+    count WAVE-level instructions: flops = (2 FMA + ADD + MUL + TRANS) x 64 lane-slots (an upper bound on useful flops: lanes that an exec
+    mask switches off, and values the four lanes of a stage compute redundantly, are counted) + SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 (the
+    counter's own unit, rocprofv3 -L: MfmaFlopsF64).  mfma_busy_frac: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) over
+    GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs.  valu_useful_frac: FP64 arithmetic instructions (vector and matrix) among
+    all vector instructions issued."""
+    f64 = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    vflop = (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) * 64.0
+    mflop = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512.0
+    out = {"flops": vflop + mflop, "vector_flops": vflop, "mfma_flops": mflop, "mfma_instructions": c.get("SQ_INSTS_VALU_MFMA_F64", 0.0),
+           "valu_instructions": c["SQ_INSTS_VALU"],
+           "valu_useful_frac": (f64 + c.get("SQ_INSTS_VALU_MFMA_F64", 0.0)) / c["SQ_INSTS_VALU"] if c["SQ_INSTS_VALU"] else None,
+           "mfma_busy_frac": None}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE_MFMA"):
+        out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE_MFMA"] / 8.0 * 1024.0)
+    return out
+
+
+def _pmc_rows(fn, kernel):
+    """{counter: [value per dispatch]} of `kernel` from one profiles/*_pmc_*.csv."""
+    vals = {}
+    for line in open(fn):
+        f = line.rstrip("\n").split(",")
+        if f[0] == kernel and len(f) >= 5:
+            vals[f[1]] = [float(x) for x in f[4].split()]
+    return vals
+
+
+def profiled_fp64(kernel="loop_kernel", require_current=True):
+    """Executed FP64 work of the timed (last) dispatch of `kernel` from the committed FP64 / MFMA counter passes of the default command
+    (profiles/<tag>_pmc_FP64.csv, <tag>_pmc_MFMA.csv; tools/gpu_profile_job.sh), with the interior-point iterations of that launch from
+    <tag>_meta.json -> (dict of fp64_from_counters + flop_per_ipm_iteration, tag) or (None, reason)."""
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    tags = sorted(t for t in glob.glob(os.path.join(here, "profiles", "*_pmc_FP64.csv")) if os.path.basename(t).count("_") == 2)
+    if not tags:
+        return None, None
+    tag = tags[-1][: -len("_pmc_FP64.csv")]
+    if require_current and not profile_is_current(tag):
+        return None, os.path.basename(tag) + " (stale: taken on other kernel sources)"
+    try:
+        c = {k: v[-1] for k, v in _pmc_rows(tag + "_pmc_FP64.csv", kernel).items()}
+        try:
+            mf = {k: v[-1] for k, v in _pmc_rows(tag + "_pmc_MFMA.csv", kernel).items()}
+            c["SQ_VALU_MFMA_BUSY_CYCLES"] = mf["SQ_VALU_MFMA_BUSY_CYCLES"]; c["GRBM_GUI_ACTIVE_MFMA"] = mf["GRBM_GUI_ACTIVE"]
+        except (OSError, KeyError, IndexError):
+            pass
+        out = fp64_from_counters(c)
+        its = json.load(open(tag + "_meta.json")).get("ipm_iterations_timed_launch")
+        out["ipm_iterations"] = its
+        out["flop_per_ipm_iteration"] = out["flops"] / its if its else None
+    except (OSError, ValueError, IndexError, KeyError):
+        return None, None
+    return out, os.path.basename(tag)
+
+
 def profiled_extras(dispatch, kernel="colloc_kernel", require_current=True):
     """HBM bytes and VALU-active fraction of ONE dispatch of `kernel` from the committed PMC passes of `python bench.py --extras-only`
     (profiles/<tag>_extras_pmc_*.csv, made by tools/gpu_profile_extras.sh; hash-gated like the headline's): dispatch = the ordinal of the
@@ -224,6 +283,16 @@ def profiled_extras(dispatch, kernel="colloc_kernel", require_current=True):
     tag = tags[-1][: -len("_pmc_FETCH_SIZE.csv")]
     if require_current and not profile_is_current(tag):
         return {"traffic": None, "valu_active_frac": None, "source": os.path.basename(tag) + " (stale: taken on other kernel sources)"}
+    # the dispatch ordinals below are those of THIS file's sequence of planning launches: a profile taken with another bench.py may have
+    # another sequence, so the meta file carries bench.py's hash too and a mismatch is stale like another kernel source
+    try:
+        import hashlib
+
+        want = json.load(open(tag + "_meta.json")).get("bench_sha16")
+        if require_current and want is not None and want != hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]:
+            return {"traffic": None, "valu_active_frac": None, "source": os.path.basename(tag) + " (stale: taken with another bench.py, the dispatch ordinals may differ)"}
+    except (OSError, ValueError):
+        pass
 
     def per_dispatch(fn):
         vals = {}
@@ -239,7 +308,16 @@ def profiled_extras(dispatch, kernel="colloc_kernel", require_current=True):
         valu = 4.0 * sq["SQ_ACTIVE_INST_VALU"][dispatch] / (sq["GRBM_GUI_ACTIVE"][dispatch] / 8.0 * 1024.0)
     except (OSError, ValueError, IndexError, KeyError, ZeroDivisionError):
         return None
-    return {"traffic": tot, "valu_active_frac": valu, "source": os.path.basename(tag)}
+    out = {"traffic": tot, "valu_active_frac": valu, "source": os.path.basename(tag)}
+    try:  # the FP64 / MFMA passes (round 6): executed flops, the matrix pipe's busy fraction, FP64 arithmetic among the vector instructions
+        c = {k: v[dispatch] for k, v in per_dispatch(f"{tag}_pmc_FP64.csv").items()}
+        mf = {k: v[dispatch] for k, v in per_dispatch(f"{tag}_pmc_MFMA.csv").items()}
+        c["SQ_VALU_MFMA_BUSY_CYCLES"] = mf["SQ_VALU_MFMA_BUSY_CYCLES"]; c["GRBM_GUI_ACTIVE_MFMA"] = mf["GRBM_GUI_ACTIVE"]
+        fp = fp64_from_counters(c)
+        out.update(fp64_flops=fp["flops"], mfma_flops=fp["mfma_flops"], mfma_busy_frac=fp["mfma_busy_frac"], valu_useful_frac=fp["valu_useful_frac"])
+    except (OSError, ValueError, IndexError, KeyError, ZeroDivisionError):
+        pass
+    return out
 
 
 TAU5 = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195, 1.0])  # Radau-5 nodes
@@ -300,7 +378,7 @@ def planning_extras(device=0, B=256, cpu=True):
     # ---- configs[1] ------------------------------------------------------------------------------------------------------------
     single_plans(list(range(8)))  # warm-up: module load, workspace allocation
     ws, good, plans, t_ws, t_col = single_plans(list(range(B)))
-    d1 = launches["colloc_kernel"] - 1
+    d6 = launches["colloc_kernel"] - 1
     info1 = {a: engine.colloc_elimination_info([len(tubes[a]) + 1]) for a in agents}
     alg = float(sum(info1[who[k]]["alg_bytes"] * plans[k]["iters"] for k in plans))
     ok = sum(r["status"] == 0 for r in plans.values())
@@ -310,34 +388,56 @@ def planning_extras(device=0, B=256, cpu=True):
         return {"bound": "hbm", "kernel": "colloc_kernel", "achieved": alg_bytes / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes / seconds / 1e9 / HBM_PEAK_GBS, "alg_bytes": alg_bytes, "alg_bytes_definition": what,
                 "traffic": pe["traffic"] if pe else None, "valu_active_frac": pe["valu_active_frac"] if pe else None,
+                "mfma_busy_frac": pe.get("mfma_busy_frac") if pe else None, "valu_useful_frac": pe.get("valu_useful_frac") if pe else None,
+                "fp64_tflops": (pe["fp64_flops"] / seconds / 1e12) if pe and pe.get("fp64_flops") else None,
+                "mfma_flops_share": (pe["mfma_flops"] / pe["fp64_flops"]) if pe and pe.get("fp64_flops") else None,
                 "traffic_source": (pe["source"] + f", colloc_kernel dispatch {dispatch} of `python bench.py --extras-only`") if pe else None}
-    out["configs[1]"] = {
-        "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5, 6 obstacles)",
-        "plans_per_s": B / (t_ws + t_col), "state_ws_s": t_ws, "colloc_s": t_col, "state_ws_converged": len(good), "colloc_converged": ok,
+    what1 = ("bytes the structured elimination of one Newton system moves between its phases (cfz_colloc_elimination_info: "
+             "%s per vehicle) x interior-point iterations of every plan" % {a: info1[a]["alg_bytes"] for a in agents})
+    six = {
+        "workload": f"the same {B} plans on the reference's own map: all SIX obstacles of compute_obstacles (compute_sets.py:259-330)",
+        "plans_per_s": B / (t_ws + t_col), "colloc_s": t_col, "colloc_converged": ok,
         "colloc_iters_mean": float(np.mean([r["iters"] for r in plans.values()])), "colloc_iters_max": int(max(r["iters"] for r in plans.values())),
+        "colloc_iters_top3": sorted((int(r["iters"]) for r in plans.values()), reverse=True)[:3],
         "ms_per_iteration_of_the_slowest_plan": 1e3 * t_col / max(1, max(r["iters"] for r in plans.values())),
-        "state_ws_iters_mean": float(np.mean([w_["iters"] for w_ in ws])), "state_ws_iters_max": int(max(w_["iters"] for w_ in ws)),
-        "roofline": roofline_of(alg, t_col, d1, "bytes the structured elimination of one Newton system moves between its phases (cfz_colloc_elimination_info: "
-                                "%s per vehicle) x interior-point iterations of every plan" % {a: info1[a]["alg_bytes"] for a in agents})}
+        "roofline": roofline_of(alg, t_col, d6, what1)}
     # configs[1] as BASELINE.json words it: FOUR polytope obstacles (0, 1, 3, 4 of the reference's six) -- the same B plans'
-    # collocation refinement again on that map (state_ws does not see the obstacles: the tube keeps the vehicle off them)
+    # collocation refinement on that map (state_ws does not see the obstacles: the tube keeps the vehicle off them).  This is the object's
+    # own line since round 6; the six-obstacle run is nested under it.
     sp4 = scenarios.parking_lot_spec(n_nbr=0, N=2, n_obs=4)
     gs = {k: guess_of(ws[k]["traj"], len(tubes[who[k]]) + 1) for k in good}
-    engine.colloc(sp4, [init[k] for k in good[:8]], [tubes[who[k]] for k in good[:8]], [gs[k][0] for k in good[:8]], [gs[k][1] for k in good[:8]],
-                  [fh[who[k]] for k in good[:8]], max_iter=400, device=device)  # warm-up, as configs[1]'s own launches had
-    t0 = time.perf_counter()
-    r4 = engine.colloc(sp4, [init[k] for k in good], [tubes[who[k]] for k in good], [gs[k][0] for k in good], [gs[k][1] for k in good],
-                       [fh[who[k]] for k in good], max_iter=400, device=device)
-    t_col4 = time.perf_counter() - t0
-    launches["colloc_kernel"] += 2
-    out["configs[1]"]["four_obstacles"] = {
-        "workload": f"the same {B} plans with BASELINE.json's 4 polytope obstacles (0, 1, 3, 4 of the reference's six)",
-        "plans_per_s": B / (t_ws + t_col4), "colloc_s": t_col4, "colloc_converged": sum(r["status"] == 0 for r in r4),
-        "colloc_iters_mean": float(np.mean([r["iters"] for r in r4])), "colloc_iters_max": int(max(r["iters"] for r in r4)),
-        "colloc_iters_top3": sorted((int(r["iters"]) for r in r4), reverse=True)[:3],
-        "ms_per_iteration_of_the_slowest_plan": 1e3 * t_col4 / max(1, max(r["iters"] for r in r4)),
+
+    def colloc4(sel, max_iter=400):
+        t0 = time.perf_counter()
+        r = engine.colloc(sp4, [init[k] for k in sel], [tubes[who[k]] for k in sel], [gs[k][0] for k in sel], [gs[k][1] for k in sel],
+                          [fh[who[k]] for k in sel], max_iter=max_iter, device=device)
+        launches["colloc_kernel"] += 1
+        return r, time.perf_counter() - t0
+    colloc4(good[:8])  # warm-up, as the six-obstacle launches had
+    r4, t_col4 = colloc4(good)
+    d4 = launches["colloc_kernel"] - 1
+    it4 = np.array([r["iters"] for r in r4])
+    # the launch lasts as long as its slowest plan: the same launch stopped at the iteration count that 95 % of the plans need says when
+    # 95 % of the batch was done (a measured time, not an extrapolation; the stragglers end with status 1 there)
+    it95 = int(np.sort(it4)[int(np.ceil(0.95 * len(it4))) - 1])
+    r95, t_col95 = colloc4(good, max_iter=it95)
+    done95 = sum(r["status"] == 0 for r in r95)
+    info4o = {a: engine.colloc_elimination_info([len(tubes[a]) + 1], n_obs=4) for a in agents}
+    alg4o = float(sum(info4o[who[k]]["alg_bytes"] * r["iters"] for k, r in zip(good, r4)))
+    out["configs[1]"] = {
+        "workload": f"BASELINE.json configs[1]: {B} independent single-vehicle OBCA plans (state_ws -> collocation plan, N_per_set 5, K 5) with "
+                    "BASELINE's 4 polytope obstacles (0, 1, 3, 4 of the reference's six)",
+        "plans_per_s": B / (t_ws + t_col4), "state_ws_s": t_ws, "colloc_s": t_col4, "state_ws_converged": len(good),
+        "colloc_converged": sum(r["status"] == 0 for r in r4),
+        "colloc_iters_mean": float(it4.mean()), "colloc_iters_max": int(it4.max()), "colloc_iters_top3": sorted((int(x) for x in it4), reverse=True)[:3],
+        "ms_per_iteration_of_the_slowest_plan": 1e3 * t_col4 / max(1, int(it4.max())),
+        "p95": {"what": f"the same launch with max_iter = {it95}, the iteration count 95 % of the plans need: the rate at which 95 % of the batch is done",
+                "max_iter": it95, "colloc_s": t_col95, "converged": int(done95), "plans_per_s": done95 / (t_ws + t_col95)},
+        "state_ws_iters_mean": float(np.mean([w_["iters"] for w_ in ws])), "state_ws_iters_max": int(max(w_["iters"] for w_ in ws)),
         "note": "one plan of the batch has several minimisers: replayed on the CPU build with its guess perturbed by 1e-13 (relative) it takes 61-212 "
-                "iterations and ends at one of three plans (docs/notebook.md); its count here is a draw from that range, the launch lasts as long as it"}
+                "iterations and ends at one of three plans (docs/notebook.md); its count here is a draw from that range, the launch lasts as long as it",
+        "roofline": roofline_of(alg4o, t_col4, d4, what1.replace("%s per vehicle" % {a: info1[a]["alg_bytes"] for a in agents}, "%s per vehicle" % {a: info4o[a]["alg_bytes"] for a in agents})),
+        "six_obstacles": six}
     # ---- configs[3] ------------------------------------------------------------------------------------------------------------
     idx = list(range(4 * B))
     ws4, good4, plans4, _, _ = single_plans(idx)
@@ -440,7 +540,7 @@ def planning_cpu_baseline(agents, sets, paths, fh):
     otubes = {a: [dict(front=(s["front"].A, s["front"].b), back=(s["back"].A, s["back"].b)) for s in sets[a]] for a in agents}
     opt = ipm.IpmOptions(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2, mu_init=0.1)
     opt1 = ipm.IpmOptions(max_iter=400, reg_dual=1e-7, tol=1e-2, constr_viol_tol=1e-2, mu_init=0.1)
-    opt1.no_prox = 4  # single plans: the structured elimination (cfz_struct.inl), as on the GPU -- also the faster one on the CPU
+    opt1.no_prox = 4  # single plans: the structured elimination (cfz_jstruct.inl's single-vehicle scheme), as on the GPU -- also the faster one on the CPU
     t0 = time.perf_counter()
     singles = []
     for a in agents:
@@ -669,7 +769,13 @@ def main():
         if persistent and not vehicle_sharded and args.steps == 20 and S == 1024 and not single:  # the committed PMC passes are of the default command
             traffic, traffic_src = profiled_traffic("loop_kernel")
             valu_frac, valu_src = profiled_sq("loop_kernel")
-        fp64_tflops = (ipm_iterations * FLOP_PER_IPM_ITERATION / (kernel_ms / 1e3) / 1e12) if ipm_iterations else None
+        # flops per interior-point iteration: MEASURED (FP64 instruction counters of the committed pass of this same command on this same
+        # library: executed lane-slots, an upper bound on useful flops) when there is such a pass, SURVEY's estimate of the algorithm otherwise
+        fp64_pass, fp64_src = (None, None)
+        if persistent and not vehicle_sharded and args.steps == 20 and S == 1024 and not single:
+            fp64_pass, fp64_src = profiled_fp64("loop_kernel")
+        flop_per_it = fp64_pass["flop_per_ipm_iteration"] if fp64_pass and fp64_pass.get("flop_per_ipm_iteration") else FLOP_PER_IPM_ITERATION
+        fp64_tflops = (ipm_iterations * flop_per_it / (kernel_ms / 1e3) / 1e12) if ipm_iterations else None
         line = {
             "metric": "OBCA MPC-step solves/sec (4 vehicles, N=30)",
             # converged solves only (status 0); persistent mode counts them on the device over the whole timed region, the other
@@ -717,7 +823,13 @@ def main():
                          "alg_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                          "fp64_frac": (fp64_tflops / FP64_VECTOR_PEAK_TFLOPS) if fp64_tflops else None,
-                         "flop_per_ipm_iteration": FLOP_PER_IPM_ITERATION,
+                         "flop_per_ipm_iteration": flop_per_it,
+                         "flop_source": (f"measured: FP64 instruction counters x 64 lanes + MFMA operations of {fp64_src} (executed lane-slots)"
+                                         if flop_per_it is not FLOP_PER_IPM_ITERATION else "SURVEY.md 8(d) estimate of the algorithm's flops (no current counter pass)"),
+                         "flop_per_ipm_iteration_estimate": FLOP_PER_IPM_ITERATION,
+                         "mfma_busy_frac": fp64_pass["mfma_busy_frac"] if fp64_pass else None,
+                         "mfma_flops_share": (fp64_pass["mfma_flops"] / fp64_pass["flops"]) if fp64_pass and fp64_pass["flops"] else None,
+                         "valu_useful_frac": fp64_pass["valu_useful_frac"] if fp64_pass else None,
                          "valu_active_frac": valu_frac["frac"] if valu_frac else None,
                          "valu_active_raw_quotient": valu_frac["raw_quotient"] if valu_frac else None, "valu_active_source": valu_src,
                          "note": "latency/FP64-issue bound: the iterate lives in LDS, so algorithmic HBM bytes "

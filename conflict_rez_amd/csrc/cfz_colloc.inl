@@ -166,7 +166,7 @@ struct CDims {
 // The structured elimination of the JOINT plan (cfz_jstruct.inl; CSpec::no_prox bit 2 with V > 1) works on another statement of the same
 // Newton system: positions vehicle-major (build_order), the tube slacks and rows condensed into the pose block they touch like the
 // collision rows (so a vehicle's separators hold at most 15 unknowns), the condensed pair blocks kept beside the band (CWork::pm).
-CFZP_FN bool jstruct_mode(const CSpec &sp) { return (sp.no_prox & 4) != 0 && (sp.V > 1 || (sp.no_prox & 8) != 0); }  // (bit 3: single plans too)
+CFZP_FN bool jstruct_mode(const CSpec &sp) { return (sp.no_prox & 4) != 0; }  // (bit 3 chose between this scheme and round 4's for single plans until round 6: ignored)
 CFZP_FN CDims cdims(const CSpec &sp) {
   CDims d;
   d.V = sp.V; d.off[0] = 0; d.coff[0] = 0;
@@ -527,11 +527,10 @@ struct CWork {
   int *posx, *posc, *ipiv;
   unsigned char *sel;
 };
-CFZP_FN size_t struct_doubles(const CSpec &sp);  // cfz_struct.inl: the structured elimination's own arrays (single plans)
 CFZP_FN size_t jstruct_doubles(const CSpec &sp);  // cfz_jstruct.inl: ... of the joint plans
 CFZP_FN size_t work_doubles(const CSpec &sp, int kb) {
   const CDims d = cdims(sp);
-  return struct_doubles(sp) + jstruct_doubles(sp) + (jstruct_mode(sp) ? (size_t)d.npp * 36 + (size_t)d.nchk * 40 : 0) + (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
+  return jstruct_doubles(sp) + (jstruct_mode(sp) ? (size_t)d.npp * 36 + (size_t)d.nchk * 40 : 0) + (size_t)d.n * 12 + (size_t)d.m * 4 + (size_t)d.nk * (3 + (3 * kb + 1)) + (size_t)d.np * d.nr * 5 + (size_t)d.npp * 16 +
          (size_t)(d.n + d.m + d.nk + 2) / 2 + (size_t)(d.np * sp.n_obs + d.npp + 7) / 8 + 64;
 }
 CFZP_FN CWork carve(const CSpec &sp, int kb, double *slab) {
@@ -1673,18 +1672,15 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   const CDims d = cdims(sp);
   const CWork w = carve(sp, kb, slab);
   // the structured eliminations never factor the band in place: no room for fill (a third less to clear and to stream per assembly)
-  const bool compact = (sp.no_prox & 4) && (jstruct_mode(sp) || (sp.V == 1 && kb == kCB));
+  const bool compact = jstruct_mode(sp);
   const Band Bd = {w.ab, kb, compact ? 2 * kb + 1 : 3 * kb + 1, compact ? kb : 2 * kb};
   const int n = d.n, m = d.m;
   const double prox = (sp.no_prox & 1) ? 0.0 : 1.0;
   build_order(sp, w.posx, w.posc);
   CFZP_SYNC();
-  // no_prox bit 2: the structured elimination of cfz_struct.inl (single-vehicle plans in the ordering of half-bandwidth kCB)
+  // no_prox bit 2: the structured elimination of cfz_jstruct.inl (joint and single plans; a layout it does not know fails with status 3)
   const bool jstructured = jstruct_mode(sp);  // (the caller sized the slab with kb = kCB: half_bandwidth())
-  bool structured = (sp.no_prox & 4) && sp.V == 1 && kb == kCB && !jstructured;  // (the caller sized the slab with kb = kCB: half_bandwidth())
-  SWork SW = {};
   JWork JW = {};
-  if (structured) { SW = struct_carve(sp, w.sw); struct_setup(sp, d, w, SW); if (SW.flag[1] != 0.0) structured = false; }  // (not the layout cfz_struct.inl assumes: the band elimination)
   if (jstructured) { JW = jstruct_carve(sp, w.sw); jstruct_setup(sp, d, w, JW); band_clear(sp, Bd); }  // (the band's only clear: see assemble)
   CFZP_LANE_FOR(i, 0, n - 1) { w.xl[i] = i >= d.sO ? 0.0 : -INFINITY; w.xu[i] = INFINITY; w.x[i] = i <= d.iDt ? X[i] : 0.0; }
   CFZP_SYNC();
@@ -1718,6 +1714,9 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
   int status = 1, iter = 0;
   long long tk[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = tick(), ta;
   for (iter = 0; iter <= sp.max_iter; ++iter) {
+    // a layout the structured elimination does not know (jstruct_setup): every solve would fail and the inertia correction would climb its
+    // whole ladder at every iterate before giving up -- the plan ends at once instead (the host routes what it can foresee to the band path)
+    if (jstructured && JW.flag[1] != 0.0) { status = 3; break; }
     ta = tick();
     // rows of a changed working set belong to another problem: the filter starts afresh (as in the MPC step)
     if (iter > 0 && refresh_working_set(sp, w, w.x, mu, false)) nfilt = 0;
@@ -1795,7 +1794,6 @@ CFZP_FN void solve_colloc(const CSpec &sp, double *X, double *slab, int kb, int 
       int fail;
       bool fwd_done = false;  // the elimination has already applied L^-1 P to both right-hand sides
       bool solved = false;
-      if (structured) { fail = struct_solve(sp, d, w, SW, Bd, w.rhs, w.rhs2, tk + 6); solved = true; } else
 #if defined(__HIP_DEVICE_COMPILE__)
       if (jstructured) {  // (the dynamic LDS: 8 x kLuLdsWave doubles for the 64-row eliminations, sized by the host)
         extern __shared__ double wlds[];

@@ -310,6 +310,7 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
   if (!w) return fail("null workspace");
   if (spec->n_obs < 0 || spec->n_obs > cfzc::kMaxObs || co->N_per_set < 1) return fail("problem size outside compiled limits");
   if (co->kernel != CFZ_KERNEL_AUTO) return fail("cfz_colloc_options.kernel: retired with the one-wavefront collocation kernel (round 4); leave it 0");
+  if (co->structured != 0 && co->structured != 1) return fail("cfz_colloc_options.structured must be 0 (band) or 1 (cfz_jstruct.inl); 2, round 4's scheme, was removed in round 6");
   HIP_OK(hipSetDevice(w->device));
   if (arena_reset(w->arena)) return -1;
   hipStream_t st = w->stream;
@@ -367,8 +368,11 @@ static int colloc_run(cfz_plan_ws *w, int B, const int32_t *nveh, const std::vec
     // and 30 at 3e-6 for the vehicle that waits, and leaves three of the four joint test problems unconverged at any
     // value; the proximal form solves all of them in 26-38 iterations at 1e-7, where the rows are met to ~2e-4 and the
     // cost is 0.65 % below the delta_c = 1e-9 value (constr_viol_tol is 1e-2, vehicle.py:651).
-    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | ((co->structured && !co->one_pivot) ? 4 : 0) | ((co->structured == 1 && !co->one_pivot) ? 8 : 0);
-    p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;  // (no_prox bit 3: single plans through cfz_jstruct.inl's scheme too; structured = 2: cfz_struct.inl, round 4's)
+    p.reg_primal = 1e-8; p.reg_dual = co->exact_rows ? 1e-9 : 1e-7; p.no_prox = (co->exact_rows ? 1 : 0) | (co->one_pivot ? 2 : 0) | ((co->structured && !co->one_pivot) ? 4 : 0);
+    // (the structured elimination packs a vehicle's interval count into eight bits: a longer plan goes through the band elimination,
+    // decided here, where the slab is sized, not discovered on the device -- ADVICE r5)
+    for (int a = 0; a < p.V; ++a) if (p.N[a] > 255) p.no_prox &= ~4;
+    p.vv_rows = co->vv_rows ? 1 : 0; p.curv_kappa = co->curv_kappa;
     p.obs_tab = dtab;
     {  // half-bandwidth of this problem's ordering (51 for one vehicle)
       const cfzc::CDims d = cfzc::cdims(p);
@@ -540,13 +544,15 @@ int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final,
 int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs, const int32_t *pairs,
                                 int structured, int32_t *nk, int32_t *kb, int64_t *band_bytes, int64_t *alg_bytes, int64_t *workspace_bytes) {
   if (V < 1 || V > cfzc::kMaxVeh || !n_sets || N_per_set < 1 || n_obs < 0 || n_obs > cfzc::kMaxObs || n_pairs < 0) return fail("bad argument");
+  if (structured != 0 && structured != 1) return fail("structured must be 0 (band) or 1 (cfz_jstruct.inl)");
   cfzc::CSpec p;
   memset(&p, 0, sizeof p);
-  p.V = V; p.Nps = N_per_set; p.n_obs = n_obs; p.no_prox = structured ? (structured == 1 ? 12 : 4) : 0;
+  p.V = V; p.Nps = N_per_set; p.n_obs = n_obs; p.no_prox = structured ? 4 : 0;
   for (int a = 0; a < V; ++a) {
     if (n_sets[a] < 2) return fail("a plan needs at least two strategy steps");
     p.n_chk[a] = n_sets[a] - 1; p.N[a] = N_per_set * p.n_chk[a]; p.has_final[a] = has_final ? (has_final[a] != 0) : 1;
   }
+  for (int a = 0; a < V; ++a) if (p.N[a] > 255) p.no_prox &= ~4;  // (as colloc_run: such a plan goes through the band elimination)
   std::vector<std::pair<int, int>> pr;
   if (pairs && V < 2) return fail("vehicle pairs need at least two vehicles");
   if (pairs) for (int e = 0; e < n_pairs; ++e) {
@@ -561,16 +567,15 @@ int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has
   std::vector<int> pos((size_t)d.n + d.m);
   if (cfzc::build_order(p, pos.data(), pos.data() + d.n) != d.nk) return fail("internal: ordering does not cover the band system");
   const int hb = cfzc::half_bandwidth(p, pos.data(), pos.data() + d.n);
-  const bool compact = structured && (cfzc::jstruct_mode(p) || (V == 1 && hb == cfzc::kCB));  // (as solve_colloc: no room for fill where nothing is factored in place)
+  const bool compact = cfzc::jstruct_mode(p);  // (as solve_colloc: no room for fill where nothing is factored in place)
   const size_t ld = compact ? 2 * (size_t)hb + 1 : 3 * (size_t)hb + 1;
   if (nk) *nk = d.nk;
   if (kb) *kb = hb;
   if (band_bytes) *band_bytes = (int64_t)d.nk * (int64_t)ld * 8;
   if (alg_bytes) {
     // per Newton system: the band elimination clears and assembles the band, then reads and writes it once while it eliminates;
-    // the structured eliminations: struct_alg_doubles / jstruct_alg_doubles
+    // the structured elimination: jstruct_alg_doubles
     size_t dbl = 3 * (size_t)d.nk * ld;
-    if (structured && V == 1 && hb == cfzc::kCB) dbl = cfzc::struct_alg_doubles(p, d.nk, ld);
     if (cfzc::jstruct_mode(p)) dbl = cfzc::jstruct_alg_doubles(p, d.nk, ld, d.npp);
     *alg_bytes = (int64_t)dbl * 8;
   }

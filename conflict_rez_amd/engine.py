@@ -98,7 +98,7 @@ class ProblemSpec:
 _lib = None
 
 
-ABI_VERSION = 5  # CFZ_ABI_VERSION of include/confrez_hip.h
+ABI_VERSION = 6  # CFZ_ABI_VERSION of include/confrez_hip.h
 
 
 def load_library(path=None):

@@ -302,16 +302,16 @@ typedef struct cfz_colloc_options {
   double constr_viol_tol; /* :651 1e-2 */
   double mu_init;         /* 0.1 (IPOPT's default) */
   double curv_kappa;      /* 1e-8 */
-  int32_t structured;     /* 1 (default) = csrc/cfz_jstruct.inl's scheme for single plans too since round 5 (tube rows condensed, 16-row separator blocks, a
-                           *    recursion that keeps its hand-offs in registers); 2 = round 4's csrc/cfz_struct.inl, described next, kept for comparison:
-                           *    single-vehicle plans (cfz_colloc): the Newton system is eliminated interval by interval (the interiors of the
-                           *    Radau intervals independently, then a block recursion over the interval starts: csrc/cfz_struct.inl)
-                           *    instead of pivot by pivot along the band (0; also what one_pivot = 1 takes); same matrix, same solution to rounding: 3x
-                           *    faster at 256 plans.  Joint plans (cfz_joint_colloc), since round 5: 1 = csrc/cfz_jstruct.inl -- vehicle-major
-                           *    ordering (a band of half-bandwidth 51 per vehicle, the condensed pair blocks beside it), tube rows condensed,
-                           *    every vehicle's interiors by themselves, the pair-coupled poses of an interval index through a 64 x 64
-                           *    capacitance system, a block recursion over joint separators of 4 x 15 unknowns; 0 = the band across the
-                           *    vehicles (half-bandwidth ~300, 88 MB per four-vehicle plan) a panel at a time: 4.5x slower */
+  int32_t structured;     /* 0 or 1 (any other value is an error since round 6).  1 (default): the Newton system is eliminated interval by interval,
+                           *    csrc/cfz_jstruct.inl -- vehicle-major ordering (a band of half-bandwidth 51 per vehicle, the condensed pair blocks of a
+                           *    joint plan beside it), tube rows condensed, every vehicle's interiors (64 unknowns) by themselves on the matrix cores,
+                           *    the pair-coupled poses of an interval index through a 64 x 64 capacitance system, a block recursion over separators of
+                           *    at most 15 unknowns per vehicle that keeps every hand-off in registers; single plans (cfz_colloc) run the same scheme
+                           *    with 16-row blocks.  0 (also what one_pivot = 1 takes, and what a plan of more than 255 intervals per vehicle is routed
+                           *    to): pivot by pivot along the band, for a joint plan the band across the vehicles (half-bandwidth ~300, 88 MB per
+                           *    four-vehicle plan) a panel at a time: same matrix, same solution to rounding, 3-6x slower.  (Round 4's scheme for single
+                           *    plans, 2 until round 5, is gone: its separator recursion handed blocks from wavefront to wavefront through global
+                           *    memory.) */
   int32_t reserved1;
 } cfz_colloc_options;
 
@@ -350,17 +350,18 @@ int cfz_joint_colloc(int device, int B, int V, const cfz_spec *spec, const cfz_c
 int cfz_colloc_band_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs,
                          const int32_t *pairs, int32_t *nk, int32_t *kb, int64_t *band_bytes);
 
-/* The same for the elimination a plan actually goes through (`structured` as in cfz_colloc_options: 1 = interval by interval, cfz_struct.inl
- * for one vehicle, cfz_jstruct.inl for several -- vehicle-major ordering, half-bandwidth 51, tube rows condensed; 0 = along the band):
+/* The same for the elimination a plan actually goes through (`structured` as in cfz_colloc_options: 1 = interval by interval,
+ * cfz_jstruct.inl -- vehicle-major ordering, half-bandwidth 51, tube rows condensed; 0 = along the band):
  * alg_bytes = the bytes one Newton system's elimination moves between its phases (every array written once and read where another phase
- * consumes it: csrc/cfz_struct.inl struct_alg_doubles, csrc/cfz_jstruct.inl jstruct_alg_doubles; the band path: 3 x the band), what bench.py
+ * consumes it: csrc/cfz_jstruct.inl jstruct_alg_doubles; the band path: 3 x the band), what bench.py
  * prices the planning kernels' HBM traffic with; workspace_bytes = the plan's slab in HBM.  Any output pointer may be NULL. */
 int cfz_colloc_elimination_info(int V, const int32_t *n_sets, const int32_t *has_final, int N_per_set, int n_obs, int n_pairs, const int32_t *pairs,
                                 int structured, int32_t *nk, int32_t *kb, int64_t *band_bytes, int64_t *alg_bytes, int64_t *workspace_bytes);
 
 /* Layout version of the structs of this header (cfz_spec, cfz_options, cfz_colloc_options, cfz_plan_options): a binding compares it with the
- * CFZ_ABI_VERSION it was written against before it passes a struct (conflict_rez_amd/engine.py does).  Round 5: 5. */
-#define CFZ_ABI_VERSION 5
+ * CFZ_ABI_VERSION it was written against before it passes a struct (conflict_rez_amd/engine.py does).  Round 5: 5; round 6: 6
+ * (cfz_colloc_options.structured lost its value 2: a caller that still passes it is refused instead of silently taking another path). */
+#define CFZ_ABI_VERSION 6
 int cfz_abi_version(void);
 
 /* ---- batched closed loop of MultiDistributedFollower.solve (:630-663) ---------------------

@@ -44,6 +44,11 @@ def test_bench_line_through_torch_distributed(extra):
     assert c["rccl_ranks"] == 1 and 0.2 < c["parked_fraction"] < 0.7
     r = b["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["kernel"] == ("solve_kernel" if extra else "loop_kernel")
+    # round 6: flops per interior-point iteration from the FP64 instruction counters when a pass of these sources is
+    # committed (otherwise SURVEY's estimate, and the line says which), the matrix pipe's busy fraction and the share of FP64 arithmetic
+    # among the vector instructions
+    assert {"flop_per_ipm_iteration", "flop_source", "flop_per_ipm_iteration_estimate", "mfma_busy_frac", "mfma_flops_share", "valu_useful_frac"} <= set(r)
+    assert r["flop_per_ipm_iteration_estimate"] == 0.75e6 and ("measured" in r["flop_source"] or "estimate" in r["flop_source"])
     if not extra:  # persistent launch: counted on the device over the whole timed region
         sc = c["status_counts"]
         assert sum(sc.values()) == 64 * 4 * 3 and abs(b["value"] / b["value_all"] - sc["0 converged"] / (64 * 4 * 3)) < 1e-9
@@ -74,16 +79,21 @@ def test_planning_extras_of_the_bench_line():
 
     ex = bench.planning_extras(device=0, B=8, cpu=False)
     c1, c3 = ex["configs[1]"], ex["configs[3]"]
+    # configs[1] is BASELINE.json's wording since round 6 (FOUR polytope obstacles); the reference's own six-obstacle map is nested under it
+    assert "4 polytope obstacles" in c1["workload"] and "SIX obstacles" in c1["six_obstacles"]["workload"]
     assert c1["state_ws_converged"] == 8 and c1["colloc_converged"] == 8 and c1["plans_per_s"] > 1.0
-    assert c1["four_obstacles"]["colloc_converged"] == 8 and c1["four_obstacles"]["plans_per_s"] > 1.0  # configs[1] as BASELINE.json words it
-    assert 5 <= c1["state_ws_iters_mean"] <= c1["state_ws_iters_max"] <= 60 and c1["colloc_iters_mean"] <= c1["colloc_iters_max"] <= 150
-    assert c1["four_obstacles"]["colloc_iters_max"] >= c1["four_obstacles"]["colloc_iters_mean"]
+    c6 = c1["six_obstacles"]
+    assert c6["colloc_converged"] == 8 and c6["plans_per_s"] > 1.0
+    assert 5 <= c1["state_ws_iters_mean"] <= c1["state_ws_iters_max"] <= 60 and c6["colloc_iters_mean"] <= c6["colloc_iters_max"] <= 150
+    assert c1["colloc_iters_max"] >= c1["colloc_iters_mean"]
     # the launch lasts as long as its slowest plan, and which plan wanders is decided in the last digits of its guess: the lines carry the
-    # three longest plans and the time per iteration of the slowest one, the figure that compares builds
-    f4 = c1["four_obstacles"]
-    assert f4["colloc_iters_top3"][0] == f4["colloc_iters_max"] and f4["colloc_iters_top3"] == sorted(f4["colloc_iters_top3"], reverse=True)
-    assert abs(f4["ms_per_iteration_of_the_slowest_plan"] - 1e3 * f4["colloc_s"] / f4["colloc_iters_max"]) < 1e-9 and "several minimisers" in f4["note"]
-    assert abs(c1["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c1["colloc_s"] / c1["colloc_iters_max"]) < 1e-9
+    # three longest plans, the time per iteration of the slowest one (the figure that compares builds) and the rate at which 95 % of the
+    # batch was done -- measured: the same launch stopped at the iteration count that 95 % of the plans need
+    assert c1["colloc_iters_top3"][0] == c1["colloc_iters_max"] and c1["colloc_iters_top3"] == sorted(c1["colloc_iters_top3"], reverse=True)
+    assert abs(c1["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c1["colloc_s"] / c1["colloc_iters_max"]) < 1e-9 and "several minimisers" in c1["note"]
+    assert abs(c6["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c6["colloc_s"] / c6["colloc_iters_max"]) < 1e-9
+    p95 = c1["p95"]
+    assert p95["max_iter"] <= c1["colloc_iters_max"] and 0.95 * 8 <= p95["converged"] <= 8 and p95["colloc_s"] <= 1.5 * c1["colloc_s"] and p95["plans_per_s"] > 1.0
     # configs[3] goes through the structured elimination (cfz_jstruct.inl): vehicle-major ordering, tube rows condensed, half-bandwidth 51,
     # no band across the vehicles (round 4: 12,350 unknowns in a band of half-bandwidth 298, 88 MB per plan)
     from conflict_rez_amd import engine
@@ -95,13 +105,14 @@ def test_planning_extras_of_the_bench_line():
     assert (info4["nk"], info4["kb"]) == (c3["unknowns"], 51)
     band4 = engine.colloc_elimination_info([11, 7, 7, 9], structured=0)
     assert (band4["nk"], band4["kb"], band4["alg_bytes"]) == (12350, 298, 3 * 12350 * (3 * 298 + 1) * 8) and info4["alg_bytes"] < band4["alg_bytes"] / 4
-    for c in (c1, c3):
+    for c in (c1, c6, c3):
         r = c["roofline"]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["unit"] == "GB/s" and r["kernel"] == "colloc_kernel"
         # `frac` follows from the line's own numbers: algorithmic bytes of the eliminations run / the launch time / the roof
         secs = c["colloc_s"] if c is c1 else c["joint_s"]
         assert abs(r["frac"] - r["alg_bytes"] / secs / 1e9 / 8000.0) < 1e-12 and "cfz_colloc_elimination_info" in r["alg_bytes_definition"]
         assert "traffic" in r and "valu_active_frac" in r and "traffic_source" in r  # (filled when profiles/<tag>_extras_* of these sources exist)
+        assert {"mfma_busy_frac", "valu_useful_frac", "fp64_tflops", "mfma_flops_share"} <= set(r)  # (round 6: the FP64 / MFMA counter passes)
     # BASELINE.md section 4's config-2 draw (lane poses, default_rng(1234), MPC form, four obstacles): its own line, checked against the port
     ls = c1["lane_sampler"]
     assert "default_rng(1234)" in ls["workload"] and ls["converged"] >= 250 and ls["solves_per_s_kernel"] >= ls["solves_per_s"] > 1e3

@@ -2,6 +2,20 @@
 baseline leg (the same closed loop through the oracle's C port) runs on a tiny sample, the CasADi probe reports a real import
 outcome.  (The GPU leg of bench.py is what the driver runs.)"""
 import bench
+import pytest
+
+
+def test_fp64_counters_to_flops():
+    """`bench.fp64_from_counters`: wave-level FP64 instruction counts x 64 lane-slots (FMA twice) + MFMA operations x 512; the matrix pipe's
+    busy cycles over the SIMD-cycles of the dispatch; FP64 arithmetic among the vector instructions.  And the committed passes parse."""
+    c = {"SQ_INSTS_VALU": 1000.0, "SQ_INSTS_VALU_FMA_F64": 100.0, "SQ_INSTS_VALU_ADD_F64": 50.0, "SQ_INSTS_VALU_MUL_F64": 30.0, "SQ_INSTS_VALU_TRANS_F64": 4.0,
+         "SQ_INSTS_VALU_MFMA_F64": 10.0, "SQ_INSTS_VALU_MFMA_MOPS_F64": 40.0, "SQ_VALU_MFMA_BUSY_CYCLES": 512.0, "GRBM_GUI_ACTIVE_MFMA": 8.0 * 100.0}
+    f = bench.fp64_from_counters(c)
+    assert f["vector_flops"] == (2 * 100 + 50 + 30 + 4) * 64 and f["mfma_flops"] == 40 * 512 and f["flops"] == f["vector_flops"] + f["mfma_flops"]
+    assert abs(f["valu_useful_frac"] - (100 + 50 + 30 + 4 + 10) / 1000.0) < 1e-15 and abs(f["mfma_busy_frac"] - 512.0 / (100.0 * 1024.0)) < 1e-15
+    got, tag = bench.profiled_fp64("loop_kernel", require_current=False)
+    if got is not None:  # (profiles of round 6 on: the FP64 / MFMA passes of tools/gpu_profile_job.sh)
+        assert 0.2e6 < got["flop_per_ipm_iteration"] < 10e6 and 0.0 < got["valu_useful_frac"] < 1.0 and 0.0 < got["mfma_busy_frac"] < 0.5 and tag
 
 
 def test_profile_summaries_parse(monkeypatch):
@@ -56,9 +70,15 @@ def test_lane_sampler_and_elimination_info():
     assert np.allclose(np.hypot(np.diff(ref[:, 0], axis=1), np.diff(ref[:, 1], axis=1)), 0.1, atol=1e-3)  # 1 m/s along the lane
     one = engine.colloc_elimination_info([11])
     band = engine.colloc_elimination_info([11], structured=0)
-    r4 = engine.colloc_elimination_info([11], structured=2)   # round 4's scheme (cfz_struct.inl): the band's unknowns, its own sweep
-    assert (r4["nk"], r4["kb"]) == (band["nk"], band["kb"]) == (engine.colloc_band_info([11])[0], 51) and r4["alg_bytes"] < band["alg_bytes"]
-    assert (one["nk"], one["kb"]) == (band["nk"] - 16 * 10, 51) and one["alg_bytes"] < r4["alg_bytes"]   # (tube rows condensed: 16 per strategy step)
+    assert (band["nk"], band["kb"]) == (engine.colloc_band_info([11])[0], 51)
+    assert (one["nk"], one["kb"]) == (band["nk"] - 16 * 10, 51) and one["alg_bytes"] < band["alg_bytes"]   # (tube rows condensed: 16 per strategy step)
+    with pytest.raises(RuntimeError, match="structured"):   # round 4's scheme (2) left the library in round 6
+        engine.colloc_elimination_info([11], structured=2)
+    # a plan of more than 255 intervals per vehicle does not fit the structured elimination's packed interval counts: the host routes it to
+    # the band elimination where the slab is sized, instead of the device finding out and failing every Newton system
+    long_s, long_b = engine.colloc_elimination_info([53]), engine.colloc_elimination_info([53], structured=0)
+    assert long_s == long_b and long_s["nk"] == engine.colloc_band_info([53])[0]
+    assert engine.colloc_elimination_info([52])["nk"] == engine.colloc_band_info([52])[0] - 16 * 51   # 255 intervals: still structured
     four = engine.colloc_elimination_info([11, 7, 7, 9])
     assert four["kb"] == 51 and four["nk"] == engine.colloc_band_info([11, 7, 7, 9])[0] - 16 * 30 and four["workspace_bytes"] < 60e6
     assert bench.profiled_extras(0, require_current=False) is None or "traffic" in bench.profiled_extras(0, require_current=False)

@@ -120,7 +120,7 @@ def test_colloc_source_values_and_derivatives(plans, vv):
 
 @pytest.mark.parametrize("agent", ["vehicle_1", "vehicle_0"])
 def test_structured_elimination_equals_the_band_elimination(plans, agent):
-    """cfz_struct.inl on the CPU build: the single-vehicle plan with its Newton system eliminated interval by interval (CSpec::no_prox
+    """cfz_jstruct.inl's single-vehicle scheme on the CPU build: the plan with its Newton system eliminated interval by interval (CSpec::no_prox
     bit 2) takes the iterates of the band elimination -- equal status and iteration count, solution to 1e-8: another elimination order
     of the same matrix (30 and 50 intervals; the 50-interval plan is the one whose batch time the bench's configs[1] is)."""
     import colloc_emu_binding as ce
@@ -131,7 +131,7 @@ def test_structured_elimination_equals_the_band_elimination(plans, agent):
     nlp = CollocNlp(p[0], tube, sp.A_obs, sp.b_obs, N_per_set=5, final_heading=fh)
     X0 = colloc_guess(nlp, warm_start(tube, p, fh))
     band = ce.solve(nlp, X0, ipm.IpmOptions(**COLLOC_OPT))
-    for bits in (4, 12):  # 4: cfz_struct.inl (round 4); 12: cfz_jstruct.inl's scheme for one vehicle (round 5, the product's default: tube rows condensed, 16-row separators)
+    for bits in (4, 12):  # bit 2: cfz_jstruct.inl's scheme for one vehicle (the product's default: tube rows condensed, 16-row separators); bit 3 chose it over round 4's scheme until round 6 and is ignored now
         opt = ipm.IpmOptions(**COLLOC_OPT)
         opt.no_prox = bits
         st = ce.solve(nlp, X0, opt)
@@ -582,7 +582,7 @@ def test_structured_elimination_on_short_plans(plans):
                 assert (s1["status"], s1["iters"]) == (b["status"], b["iters"]) and np.abs(s1["traj"] - b["traj"]).max() < 1e-5, (a, S, fh)
                 seen.add(b["status"])
                 # ... and not only HIP against HIP (VERDICT r4 item 2 of "weak"): the CPU build of the solver source with its own, generic
-                # band elimination (one pivot at a time, partial pivoting: none of cfz_struct.inl's code) from the same guess -- status,
+                # band elimination (one pivot at a time, partial pivoting: none of the structured elimination's code) from the same guess -- status,
                 # iteration count, the plan to 1e-5 where it converges
                 import colloc_emu_binding as ce
 

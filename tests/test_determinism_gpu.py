@@ -42,8 +42,10 @@ def _guess(ws, n_sets):
 @pytest.mark.parametrize("structured", [1, 0])
 def test_520_identical_single_plans_twenty_times(lot, structured):
     """520 copies of vehicle 1's collocation plan in one launch (more than two plans per CU), 20 launches: every plan of every launch equals
-    the lone plan bit for bit -- the structured elimination (cfz_struct.inl: register eliminations, the separator recursion with its
-    wavefront-local hand-offs) and the band elimination a panel at a time (eight wavefronts, barriers between panels)."""
+    the lone plan bit for bit -- the structured elimination (cfz_jstruct.inl's single-vehicle scheme `jstruct_solve1`: the interiors on the
+    matrix cores, the separator recursion from both ends with every hand-off in registers; the only structured path since round 6 removed
+    round 4's, whose recursion handed blocks over through global memory behind wavefront fences) and the band elimination a panel at a time
+    (eight wavefronts, barriers between panels)."""
     from conflict_rez_amd import engine
 
     a, B = "vehicle_1", 520

@@ -1,5 +1,6 @@
-"""cfz_colloc's eliminations against each other on the GPU: band (structured = 0), round 4's cfz_struct.inl (2) and cfz_jstruct.inl's scheme
-(1, the default) on the 256-plan launch of configs[1]: status, iterations, trajectories, time.  python tools/struct_gpu_check.py [B]"""
+"""cfz_colloc's eliminations against each other on the GPU: band (structured = 0) and cfz_jstruct.inl's scheme (1, the default) on the
+256-plan launch of configs[1]: status, iterations, trajectories, time.  python tools/struct_gpu_check.py [B]
+(Round 4's cfz_struct.inl scheme, structured = 2, was a third leg until round 6 removed it from the library.)"""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,12 +28,12 @@ ws = engine.state_ws(init, [tubes[a] for a in who], [paths[a] for a in who], [fh
 gs = [guess_of(w["traj"], len(tubes[a]) + 1) for w, a in zip(ws, who)]
 args = (sp, init, [tubes[a] for a in who], [g[0] for g in gs], [g[1] for g in gs], [fh[a] for a in who])
 res = {}
-for name, kw in (("band", dict(structured=0)), ("struct (r4)", dict(structured=2)), ("jstruct", dict(structured=1)), ("struct (r4)", dict(structured=2)), ("jstruct", dict(structured=1))):
+for name, kw in (("band", dict(structured=0)), ("jstruct", dict(structured=1)), ("jstruct", dict(structured=1))):
     t0 = time.time(); r = engine.colloc(*args, max_iter=400, **kw); t1 = time.time()
     res[name] = r
     its = np.array([x["iters"] for x in r])
     print(f"{name}: {B} plans {t1 - t0:.3f} s, converged {sum(x['status'] == 0 for x in r)}, iterations {its.min()}-{its.max()} mean {its.mean():.1f}", flush=True)
-for nm in ("struct (r4)", "jstruct"):
+for nm in ("jstruct",):
     a, b = res["band"], res[nm]
     same = sum(x["iters"] == y["iters"] and x["status"] == y["status"] for x, y in zip(a, b))
     dd = [float(np.abs(x["traj"] - y["traj"]).max()) for x, y in zip(a, b) if x["iters"] == y["iters"]]
