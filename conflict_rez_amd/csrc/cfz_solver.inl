@@ -50,6 +50,7 @@ constexpr int kLPSBits = kLPS == 4 ? 2 : 3;
 constexpr int kMaxN = 32;           // stages
 constexpr int kNL = kMaxN * kLPS;   // lanes per instance
 constexpr int kNW = kNL / 64;       // wavefronts per instance
+constexpr int kXS = 7;              // values one workgroup reduction can carry (slots per wavefront in the exchange area)
 }  // namespace cfz
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -174,10 +175,13 @@ CFZ_FN Lay make_layout(int N, int nb, int n_nbr) {
   L.ref = 0;  // the reference stays in global memory (read-only, L2-resident)
   L.nb4 = o; o += N * n_nbr * 4; L.x0 = o; o += 5;
   L.cs = o; o += (2 * N > 32) ? 2 * N : 32;  // cos, sin of the pose heading of every stage at the current iterate
-  L.rP = L.cs;  // value function of stage 0 (30 numbers) between the Riccati sweeps, when cos/sin are not needed
+  // value function of stage 0 (30 numbers) between the backward sweep and the forward scan: in the step's slots of stages 1.. (dead until the
+  // scan writes them, and the scan reads the value function first); for horizons too short for that it shares the cos / sin slots, whose
+  // readers after the sweeps then form the heading's cosine and sine again (rounds 1-5: always)
+  L.rP = (N - 1) * kNP >= 30 ? L.dp + kNP : L.cs;
   L.filt = o; o += 32;
-  L.xw = o; o += 12 * kNW;  // exchange between the wavefronts of a reduction: [parity 2][wavefront kNW][6 values]
-  L.total = o;  // N = 30, 9 blocks: 5,115 doubles = 40,920 B = 20 LDS granules of 2 KiB: four instances per CU (cfz_create)
+  L.xw = o; o += 2 * kXS * kNW;  // exchange between the wavefronts of a reduction: [parity 2][wavefront kNW][kXS values]
+  L.total = o;  // N = 30, 9 blocks: 5,119 doubles = 40,952 B = 20 LDS granules of 2 KiB (8 bytes to spare): four instances per CU (cfz_create)
   return L;
 }
 
@@ -231,21 +235,22 @@ template <int OP> __device__ __forceinline__ double wave_reduce(double v) {
 template <int NS, int NX, int NI>
 __device__ __forceinline__ void reduce_all(double *m, const Lay &L, int &xpar, const double *part, double *out) {
   constexpr int n = NS + NX + NI;
-  static_assert(n <= 6, "exchange slots");
+  static_assert(n <= kXS, "exchange slots");
   double w[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) w[i] = i < NS ? wave_reduce<0>(part[i]) : (i < NS + NX ? wave_reduce<1>(part[i]) : wave_reduce<2>(part[i]));
-  double *x = m + L.xw + xpar * 6 * kNW;
+  double *x = m + L.xw + xpar * kXS * kNW;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[(threadIdx.x >> 6) * 6 + i] = w[i];
+    for (int i = 0; i < n; ++i) x[(threadIdx.x >> 6) * kXS + i] = w[i];
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    if (kNW == 2) out[i] = uniform_value(i < NS ? op2<0>(x[i], x[6 + i]) : (i < NS + NX ? op2<1>(x[i], x[6 + i]) : op2<2>(x[i], x[6 + i])));
-    else out[i] = uniform_value(i < NS ? op2<0>(op2<0>(x[i], x[6 + i]), op2<0>(x[12 + i], x[18 + i]))
-                                : (i < NS + NX ? op2<1>(op2<1>(x[i], x[6 + i]), op2<1>(x[12 + i], x[18 + i])) : op2<2>(op2<2>(x[i], x[6 + i]), op2<2>(x[12 + i], x[18 + i]))));
+    if (kNW == 2) out[i] = uniform_value(i < NS ? op2<0>(x[i], x[kXS + i]) : (i < NS + NX ? op2<1>(x[i], x[kXS + i]) : op2<2>(x[i], x[kXS + i])));
+    else out[i] = uniform_value(i < NS ? op2<0>(op2<0>(x[i], x[kXS + i]), op2<0>(x[2 * kXS + i], x[3 * kXS + i]))
+                                : (i < NS + NX ? op2<1>(op2<1>(x[i], x[kXS + i]), op2<1>(x[2 * kXS + i], x[3 * kXS + i]))
+                                               : op2<2>(op2<2>(x[i], x[kXS + i]), op2<2>(x[2 * kXS + i], x[3 * kXS + i]))));
   }
   xpar ^= 1;
 }
@@ -881,7 +886,12 @@ CFZ_CALL void rk4_sens2(const double z[5], double a, double w, double h, double 
 // ------------------------------------------------------------------------------ trial-point evaluation
 // theta = |c|_1 and barrier objective at (p + alpha dp, sg + alpha dsg).  Lane partials: part 0 theta, 1 phi without the
 // log terms, 2 sum of logs, 3 = 1 if a bound or a slack is not strictly inside.
-CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg, double *m, const Lay &L, double alpha, int tid,
+// sens (uniform): the trial is expected to be accepted (the first trial of an iteration whose predecessor's first trial was), so the
+// stage's quad integrates the dynamics WITH the sensitivities, as the rows phase of the next iteration would at this very point, and
+// leaves what that phase needs -- the sensitivities in L.ab, the defects in the (dead) Hessian slots L.hc + 5 k, the heading's cosine and
+// sine in L.cs -- so that it can skip its own integration if the trial is accepted (round 6: 14 k of an iteration's 180 k cycles).  The
+// nominal trajectory of rk4_sens2 is rk4_step_h<false>'s, statement for statement.
+CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg, double *m, const Lay &L, double alpha, int tid, int sens,
                              double &th_o, double &ph_o, double &ll_o, double &bad_o) {
   const int N = sp.N, nb = L.nb;
   const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
@@ -903,6 +913,16 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
         if (!(sg > 0.0)) bad = 1.0; else lprod *= sg;
       }
     }
+    double F[5];
+    if (sens) {
+      if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+      if (k + 1 < N) {
+        double Sa[3], Sb[3];
+        rk4_sens2(pt, pt[5], pt[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
+        if (sub < 4) for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + sub] = Sa[r];
+        if (sub == 0) for (int r = 0; r < 3; ++r) m[L.ab + k * 15 + r * 5 + 4] = Sb[r];
+      }
+    }
     if (sub == 0) {
       for (int q = 0; q < 6; ++q) {
         const double dl = pt[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pt[bcol(q)];
@@ -911,10 +931,12 @@ CFZ_CALL void merit_partials(const KSpec &sp, const KDer &dv, const double *refg
       ph += stage_cost(sp, refg, k, pt);
       if (k == 0) for (int i = 0; i < 5; ++i) th += fabs(pt[i] - m[L.x0 + i]);
       if (k + 1 < N) {
-        double F[5];
-        rk4_step_h<false>(pt, pt[5], pt[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, F, nullptr);
-        for (int i = 0; i < 5; ++i)
-          th += fabs(F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]));
+        if (!sens) rk4_step_h<false>(pt, pt[5], pt[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, F, nullptr);
+        for (int i = 0; i < 5; ++i) {
+          const double d = F[i] - (m[L.p + (k + 1) * kNP + i] + alpha * m[L.dp + (k + 1) * kNP + i]);
+          th += fabs(d);
+          if (sens) m[L.hc + k * 5 + i] = d;  // (the defect at the trial point: the next iteration's, if the trial is accepted)
+        }
       }
     }
   }
@@ -1368,6 +1390,13 @@ CFZ_SCAN forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk,
   }
   const double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
                z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
+  // (the value function is read BEFORE the step is stored: it stands in the step's slots of stages 1..5, make_layout; one wavefront,
+  // program order, and a wavefront's DS instructions complete in the order they were issued)
+  if (k < 5) {  // step of the initial-state multiplier from the value function at stage 0
+    const wsp_f64 *rP = m + o_rP;
+    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
+    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
+  }
   if (k + 1 < N) {
     wsp_f64 *zn = m + o_dp + (k + 1) * kNP;
 #pragma unroll
@@ -1375,11 +1404,6 @@ CFZ_SCAN forward_scan(wsp_f64 *m, int N, double dt, int o_ab, int o_d, int o_kk,
       zn[i] = t.v[i] + t.M[i * 5 + 0] * z0 + t.M[i * 5 + 1] * z1 + t.M[i * 5 + 2] * z2 + t.M[i * 5 + 3] * z3 + t.M[i * 5 + 4] * z4;
   }
   if (k == 0) { wsp_f64 *dp = m + o_dp; dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4; }
-  if (k < 5) {  // step of the initial-state multiplier from the value function at stage 0
-    const wsp_f64 *rP = m + o_rP;
-    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
-    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
-  }
 }
 
 CFZ_SCAN costate_scan(wsp_f64 *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
@@ -1414,17 +1438,17 @@ static void forward_scan(double *m, int N, double dt, int o_ab, int o_d, int o_k
   }
   const double z0 = m[o_x0 + 0] - m[o_p + 0], z1 = m[o_x0 + 1] - m[o_p + 1], z2 = m[o_x0 + 2] - m[o_p + 2],
                z3 = m[o_x0 + 3] - m[o_p + 3], z4 = m[o_x0 + 4] - m[o_p + 4];
+  const double *rP = m + o_rP;  // (read before the step is stored: it stands in the step's slots of stages 1..5, make_layout)
+  for (int k = 0; k < 5; ++k) {
+    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
+    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
+  }
   for (int k = 0; k + 1 < N; ++k) {
     double *zn = m + o_dp + (k + 1) * kNP;
     for (int i = 0; i < 5; ++i)
       zn[i] = t[k].v[i] + t[k].M[i * 5 + 0] * z0 + t[k].M[i * 5 + 1] * z1 + t[k].M[i * 5 + 2] * z2 + t[k].M[i * 5 + 3] * z3 + t[k].M[i * 5 + 4] * z4;
   }
   double *dp = m + o_dp; dp[0] = z0; dp[1] = z1; dp[2] = z2; dp[3] = z3; dp[4] = z4;
-  const double *rP = m + o_rP;
-  for (int k = 0; k < 5; ++k) {
-    const double s_ = rP[25 + k] + rP[k * 5 + 0] * z0 + rP[k * 5 + 1] * z1 + rP[k * 5 + 2] * z2 + rP[k * 5 + 3] * z3 + rP[k * 5 + 4] * z4;
-    m[o_dpi0 + k] = -s_ - m[o_pi0 + k];
-  }
 }
 
 static void costate_scan(double *m, int N, int o_ab, int o_hc, int o_gk, int o_kk, int o_dp, int o_dpi, int o_pi) {
@@ -1749,10 +1773,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   int stall_cnt = 0, stall_ws = 0;
   int xpar = 0;  // which half of the wavefront exchange buffer the next reduction uses
   (void)xpar;
-  CFZ_PART(rd, 6);   // lane partials of the workgroup reductions
+  CFZ_PART(rd, 7);   // lane partials of the workgroup reductions
   CFZ_PART(qx, 15);  // lane shares that meet in a quad sum
   CFZ_PART(shf, 1);  // this lane has shifted its stage's curvature in some iteration (-> carry record, carry_shift)
-  double ro[6];      // results of a reduction (uniform)
+  double ro[7];      // results of a reduction (uniform)
 
   // ---- load parameters, initial point ---------------------------------------------------
   CFZ_LANES(tid)
@@ -1881,6 +1905,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
 
   int iter0 = 0, resto_calls = 0;
   bool first_checked = false;
+  int have_dyn = 0;    // the rows phase finds heading, sensitivities and defects of its iterate in place (left by the accepted trial's evaluation)
+  int sens_first = 1;  // the next line search evaluates its first trial with sensitivities: the last one accepted its first trial (or there was none)
   // The restoration phase is called from OUTSIDE the iteration loop: the loop leaves with `want_resto` set, the phase runs, the loop is
   // entered again.  (Called from inside, the two call sites cost the hot loop three times its scratch traffic: every value the
   // register allocator keeps across a call site needs a callee-saved register or a spill slot -- measured 7 % of the throughput.)
@@ -1895,8 +1921,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         const double *pk = m + L.p + k * kNP;
         const double x = pk[0], y = pk[1];
         double sn, cn;
-        sincos(pk[2], &sn, &cn);
-        if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+        // (have_dyn: this iterate is the accepted trial point of a line search that evaluated it with sensitivities -- merit_partials --:
+        // the heading's cosine and sine, the sensitivities and the defects are in place)
+        if (have_dyn) { cn = m[L.cs + 2 * k]; sn = m[L.cs + 2 * k + 1]; }
+        else {
+          sincos(pk[2], &sn, &cn);
+          if (sub == 0) { m[L.cs + 2 * k] = cn; m[L.cs + 2 * k + 1] = sn; }
+        }
         CFZ_STAMP(18);
         for (int j = sub; j < nb; j += kLPS) {
           CFZ_STAMP(19 + (j >= kLPS) + (j >= 2 * kLPS));
@@ -1947,6 +1978,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         CFZ_STAMP(12);  // (diagnostic) working set and rows
         if (tid == 0) for (int i = 0; i < 5; ++i) { const double r = m[L.p + i] - m[L.x0 + i]; cmax = fmax(cmax, fabs(r)); csum += fabs(r); }
         if (k + 1 < N) {
+          if (have_dyn) {
+            if (sub == 0)
+              for (int i = 0; i < 5; ++i) {
+                const double d = m[L.hc + k * 5 + i];
+                m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
+              }
+          } else {
           // the quad integrates the stage together: lane sub carries sensitivity column sub, every lane column 4
           double F[5], Sa[3], Sb[3];
           rk4_sens2(pk, pk[5], pk[6], dv.rk_h, dv.rk_hh, dv.rk_h6, dv.iwb, sp.rk_substeps, sub, F, Sa, Sb);
@@ -1958,12 +1996,14 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
               m[L.d + k * 5 + i] = d; cmax = fmax(cmax, fabs(d)); csum += fabs(d);
             }
           }
+          }
         }
         CFZ_STAMP(13);  // (diagnostic) dynamics
       }
       CFZ_P(rd, 0) = csum; CFZ_P(rd, 1) = cmax; CFZ_P(rd, 2) = chg; CFZ_P(rd, 3) = v0;
     CFZ_END
     CFZ_REDUCE(1, 3, 0, rd, ro);
+    have_dyn = 0;
     const double theta = ro[0], cviol = ro[1];
     const bool ws_changed = ro[2] != 0.0;
     CFZ_STAMP(1);  // working set, rows, dynamics
@@ -1979,6 +2019,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     CFZ_LANES(tid)
       const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
       double r0 = 0.0, r1 = 0.0, r2 = 0.0, dinf = 0.0, snu = 0.0, sz = 0.0, c0 = 0.0, lprod = 1.0;
+      double cm = 0.0;  // complementarity against the current mu: what the barrier update's first test needs (rides along in this phase's reduction)
       if (k < N) {
         const double *pk = m + L.p + k * kNP;
         const double cpsi = m[L.cs + 2 * k], spsi = m[L.cs + 2 * k + 1];
@@ -1992,15 +2033,16 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
             r0 += a0 * nu; r1 += a1 * nu; r2 += ap[r_] * nu;
             dinf = fmax(dinf, fabs(-nu - zs));
             snu += fabs(nu); sz += zs; c0 = fmax(c0, fabs(sg * zs)); lprod *= sg;
+            cm = fmax(cm, fabs(m[L.sg + t] * m[L.zs + t] - mu));
           }
         }
       }
       CFZ_STAMP(14);  // (diagnostic) residuals: the rows
       CFZ_P(qx, 0) = r0; CFZ_P(qx, 1) = r1; CFZ_P(qx, 2) = r2;
-      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 3) = lprod; CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0;
+      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 3) = lprod; CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0; CFZ_P(rd, 6) = cm;
     CFZ_MID
       const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
-      double snu = CFZ_P(rd, 0), sz = CFZ_P(rd, 1), lprod = CFZ_P(rd, 3), dinf = CFZ_P(rd, 4), c0 = CFZ_P(rd, 5), fv = 0.0;
+      double snu = CFZ_P(rd, 0), sz = CFZ_P(rd, 1), lprod = CFZ_P(rd, 3), dinf = CFZ_P(rd, 4), c0 = CFZ_P(rd, 5), cm = CFZ_P(rd, 6), fv = 0.0;
       if (k < N) {
         const bool first = sub == 0;  // the stage's own terms enter the sums once, through the quad's first lane
         const double *pk = m + L.p + k * kNP;
@@ -2026,14 +2068,16 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
           r[bcol(q)] += -zl + zu_;
           const double dl = pk[bcol(q)] - sp.bounds[2 * q], du = sp.bounds[2 * q + 1] - pk[bcol(q)];
           c0 = fmax(c0, fmax(fabs(dl * zl), fabs(du * zu_)));
+          cm = fmax(cm, fmax(fabs((pk[bcol(q)] - sp.bounds[2 * q]) * m[L.zl + k * 6 + q] - mu), fabs((sp.bounds[2 * q + 1] - pk[bcol(q)]) * m[L.zu + k * 6 + q] - mu)));
           if (first) { sz += zl + zu_; lprod *= dl * du; }
         }
         for (int i = 0; i < kNP; ++i) dinf = fmax(dinf, fabs(r[i]));
       }
-      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 2) = fv; CFZ_P(rd, 3) = log(lprod); CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0;
+      CFZ_P(rd, 0) = snu; CFZ_P(rd, 1) = sz; CFZ_P(rd, 2) = fv; CFZ_P(rd, 3) = log(lprod); CFZ_P(rd, 4) = dinf; CFZ_P(rd, 5) = c0; CFZ_P(rd, 6) = cm;
     CFZ_END
-    CFZ_REDUCE(4, 2, 0, rd, ro);
+    CFZ_REDUCE(4, 3, 0, rd, ro);
     const double sum_nu = ro[0], sum_z = ro[1], fval = ro[2], logsum = ro[3], dual_inf = ro[4], cmp0 = ro[5];
+    const double cmp_mu = CFZ_UNIFORM(ro[6]);  // max |slack x multiplier - mu| at the current mu (a maximum: exact whatever the order)
     // scalars every lane computes identically go back to scalar registers: a double computed on the vector pipe lives in a
     // VGPR pair, and two dozen of them live across the whole iteration were what spilled to scratch
     const double s_d = CFZ_UNIFORM(fmax(sp.s_max, (sum_nu + sum_z) / (double)(m_eq + n_bnd)) / sp.s_max);
@@ -2055,7 +2099,13 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     else if (++stall_ws >= kWsStallDiv) { stall_ws = 0; ++stall_cnt; }
     if (sp.stall_iters > 0 && stall_cnt >= sp.stall_iters && cviol > sp.constr_viol_tol) { status = 5; break; }
     // ---- barrier update (monotone, Fiacco-McCormick) ------------------------------------------
+    // (the first pass of this loop used to be a phase of its own -- a sweep over slacks, multipliers and boxes, a reduction, a barrier: 2 % of
+    // an iteration; its maximum now rides along in the residuals' reduction above, and only a mu that has just been lowered is tested by a
+    // sweep of its own)
+    bool mu_same = true;
     while (mu > mu_floor) {
+      double cmv = cmp_mu;
+      if (!mu_same) {
       CFZ_LANES(tid)
         const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
         double cm = 0.0;
@@ -2071,7 +2121,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         CFZ_P(rd, 0) = cm;
       CFZ_END
       CFZ_REDUCE(0, 1, 0, rd, ro);
-      const double emu = fmax(dual_inf / s_d, fmax(cviol, ro[0] / s_c));
+      cmv = ro[0];
+      }
+      mu_same = false;
+      const double emu = fmax(dual_inf / s_d, fmax(cviol, cmv / s_c));
       if (emu <= sp.kappa_eps * mu) mu = CFZ_UNIFORM(fmax(mu_floor, fmin(sp.kappa_mu * mu, pow(mu, sp.theta_mu))));
       else break;
     }
@@ -2207,9 +2260,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
       double rpri = 0.0, rdual = 0.0, dphi = 0.0;  // max of -dx/dist and -dz/z
       if (k < N) {
         const double *pk = m + L.p + k * kNP, *dpk = m + L.dp + k * kNP;
-        // heading of the current iterate again: its cos/sin slots carried the value function through the Riccati sweeps
+        // heading of the current iterate: still in its slots (rounds 1-5: formed again, the slots carried the value function through the
+        // sweeps -- as they still do for horizons of fewer than six stages)
         double sps, cps;
-        sincos(pk[2], &sps, &cps);
+        if (L.rP != L.cs) { cps = m[L.cs + 2 * k]; sps = m[L.cs + 2 * k + 1]; } else sincos(pk[2], &sps, &cps);
         for (int jb = sub; jb < nb; jb += kLPS) {
           double ba0, ba1, bap[2];
           block_grad(sp, m, L, k, jb, sel_ptr(m, L)[k * nb + jb], pk[0], pk[1], cps, sps, ba0, ba1, bap);
@@ -2257,10 +2311,12 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     if (filt_mu != mu) { nfilt = 0; filt_mu = mu; }
     if (ws_changed) nfilt = 0;  // the entries belong to the problem with the previous working set
     double alpha = a_pri; int accepted = 0, f_type = 0;
+    int acc_bt = -1;
     for (int bt = 0; bt < sp.max_backtrack; ++bt) {
+      const int sens_trial = (bt == 0 && sens_first) ? 1 : 0;
       CFZ_LANES(tid)
         double th_, ph_, ll_, bad_;
-        merit_partials(sp, dv, refg, m, L, alpha, tid, th_, ph_, ll_, bad_);
+        merit_partials(sp, dv, refg, m, L, alpha, tid, sens_trial, th_, ph_, ll_, bad_);
         CFZ_P(rd, 0) = th_; CFZ_P(rd, 1) = ph_; CFZ_P(rd, 2) = ll_; CFZ_P(rd, 3) = bad_;
       CFZ_END
       CFZ_REDUCE(3, 1, 0, rd, ro);
@@ -2273,9 +2329,11 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         if (sw) { f_type = 1; ok = ph_t <= phi0 + sp.eta_phi * alpha * dphi; }
         else ok = th_t <= (1.0 - sp.gamma_theta) * theta || ph_t <= phi0 - sp.gamma_phi * theta;
       }
-      if (ok) { accepted = 1; break; }
+      if (ok) { accepted = 1; acc_bt = bt; break; }
       alpha = CFZ_UNIFORM(alpha * 0.5);
     }
+    have_dyn = (acc_bt == 0 && sens_first) ? 1 : 0;
+    sens_first = acc_bt == 0 ? 1 : 0;
     CFZ_STAMP(7);  // line search
     if (!accepted) {
       // IPOPT's answer to a failed line search at an infeasible iterate: the restoration phase, then on with cold multipliers and an
@@ -2339,6 +2397,7 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     const int r = restore_instance(sp, dv, CFZ_WSP(m), L, mu, iter);
     if (r < 0) { iter = -r - 1; status = iter >= sp.max_iter ? 1 : 5; break; }  // (out of iterations inside the restoration: the limit, not local infeasibility)
     cold_multipliers(sp, CFZ_WSP(m), L, mu);
+    have_dyn = 0; sens_first = 1;
     if (want_resto == 1) { iter0 = r - 1; iter = iter0; }  // the first iteration again, from the restored point
     else {  // the iteration of the failed line search is counted; the filter and the stall tests start afresh
       iter = r;
