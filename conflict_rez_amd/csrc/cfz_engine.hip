@@ -306,7 +306,7 @@ __global__ __launch_bounds__(cfz::kNL, CFZ_WAVES_PER_SIMD) void loop_kernel(cons
     CFZ_MARK(3);
     int oi[2]; double od[3];
     cfz::DualOut duo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    cfz::solve_instance(sp, dv, nullptr, ref, nullptr, nullptr, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1, 1);
+    cfz::solve_instance(sp, dv, nullptr, ref, nullptr, nullptr, smem, L, oi, od, duo, wst ? wst + (size_t)b * wst_stride : nullptr, 1, 2);
     __syncthreads();
     CFZ_MARK(4);
     // ---- read-back (the solution is still in the workspace) or shift fallback (:484-524), plant (:528-543) ------------

@@ -2412,7 +2412,10 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_LANES(tid)
     if (!preloaded) for (int i = tid; i < N * kNP; i += kNL) { const int k = i / kNP, c = i - k * kNP; zu[c * N + k] = m[L.p + i]; }
     double smin = INFINITY;
-    for (int t = tid; t < N * nb; t += kNL) {
+    // (preloaded == 2, the persistent closed loop: neither the certificates nor the minimum separation have a reader there -- cfz_loop_get
+    // returns states, predictions, status and iterations --, and the fresh selection of all N x nb blocks this loop runs for them was 4 % of
+    // a 2.5-iteration solve; out_d[2] is then +inf)
+    for (int t = tid; t < (preloaded == 2 ? 0 : N * nb); t += kNL) {
       const int k = t / nb, j = t - k * nb;
       double A[4][2], b[4], V[4][2], sep2[2];
       block_polygon(sp, m, L, k, j, A, b, V);

@@ -109,7 +109,7 @@ def test_planning_extras_of_the_bench_line():
         r = c["roofline"]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and r["unit"] == "GB/s" and r["kernel"] == "colloc_kernel"
         # `frac` follows from the line's own numbers: algorithmic bytes of the eliminations run / the launch time / the roof
-        secs = c["colloc_s"] if c is c1 else c["joint_s"]
+        secs = c["joint_s"] if c is c3 else c["colloc_s"]
         assert abs(r["frac"] - r["alg_bytes"] / secs / 1e9 / 8000.0) < 1e-12 and "cfz_colloc_elimination_info" in r["alg_bytes_definition"]
         assert "traffic" in r and "valu_active_frac" in r and "traffic_source" in r  # (filled when profiles/<tag>_extras_* of these sources exist)
         assert {"mfma_busy_frac", "valu_useful_frac", "fp64_tflops", "mfma_flops_share"} <= set(r)  # (round 6: the FP64 / MFMA counter passes)
