@@ -326,12 +326,17 @@ TAU5 = np.array([0.0, 0.05710419611451768, 0.2768430136381238, 0.583590432368916
 def planning_extras(device=0, B=256, cpu=True):
     """BASELINE.json configs[1] and configs[3], measured OUTSIDE the timed region of the headline (same process, same GPU):
     configs[1]  B single-vehicle plans (`Vehicle.state_ws` -> collocation plan, vehicle.py:99-231, :360-661): the four vehicles of the
-                synthetic strategy in turn, start poses scattered by +-3 cm; one `cfz_state_ws` and one `cfz_colloc` launch;
+                synthetic strategy in turn, start poses scattered by +-3 cm; one `cfz_state_ws` and one `cfz_colloc` launch -- with
+                BASELINE.json's FOUR polytope obstacles (the object's own line), with the reference's six (`six_obstacles`), and stopped
+                at the iteration count 95 % of the plans need (`p95`);
     configs[3]  B four-vehicle joint plans (`solve_final_problem_obca`, multi_vehicle_planner.py:343-480) from those single plans,
                 one `cfz_joint_colloc` launch (one workgroup per plan).
     Times are wall-clock around the C-ABI calls (host buffers in and out: the transfers are megabytes, the launches seconds).
-    `roofline`: algorithmic HBM bytes = 3 x the band (cleared and assembled once, read and written once by the elimination) per
-    interior-point iteration, summed over the plans' iteration counts, over the launch time, against the 8 TB/s roof.
+    `roofline`: algorithmic HBM bytes = what the structured elimination of one Newton system moves between its phases
+    (`cfz_colloc_elimination_info`: every array written once and read where another phase consumes it) per interior-point iteration,
+    summed over the plans' iteration counts, over the launch time, against the 8 TB/s roof; beside it, from the committed counter passes of
+    `python bench.py --extras-only` on the same sources and the same bench.py: measured HBM bytes, VALU-active fraction, executed FP64
+    flops, the matrix pipe's busy fraction.
     `cpu_baseline` ("port": the CPU build of the same kernel source, tests/emu, one core): one plan of every vehicle / one joint plan."""
     import tempfile
 

@@ -351,7 +351,13 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
             [float(plans[a][1][-1, 2]) for a in agents])
     r = engine.joint_colloc(*args, max_iter=400)
     # (52 iterations on the CPU build for the corner contact; the four-vehicle plan with two pairs of bodies in contact: 80 there, 95 here)
-    assert r["status"] == 0 and r["iters"] < {"02_d20_s66": 80, "0123_d20_s5555": 400}.get(name, 60)  # (0123: a plan that wanders between minimisers: 80 - 285 iterations depending on the build, docs/notebook.md)
+    assert r["status"] == 0
+    # iteration counts are asserted where they are a property of the problem (equal on every build so far).  The four-vehicle fixture is a
+    # plan that wanders between two minimisers -- 80 to 285 iterations depending on the build's roundings (docs/notebook.md) -- : there the
+    # count is a draw and NOT asserted (round 5 wrote "< 400" beside max_iter = 400, which asserted nothing: ADVICE r5); what is asserted
+    # for it is what the others get too: convergence within the limit, cost and rows against the independent optimum, the certificate
+    if name != "0123_d20_s5555":
+        assert r["iters"] < {"02_d20_s66": 80}.get(name, 60), r["iters"]
     check_joint_against_independent(r["traj"], r["dt"], False, name)
     r2 = engine.joint_colloc(*args, max_iter=800, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)
     assert r2["status"] in (0, 1, 2, 3), r2["status"]  # ends AT the optimum with the iteration limit or the line search exhausted

@@ -281,7 +281,8 @@ def test_every_solve_of_the_bench_workload_against_the_port(ospec):
                 r = port.solve(ospec, state[s, v], table[v, kr, :3].T, nb, w.T.copy(), carry=carry[s][v])
                 carry[s][v] = r["carry"]
                 assert (r["status"], r["iters"]) == (int(st[s, v]), int(it[s, v])), (t, s, v, r["status"], r["iters"], st[s, v], it[s, v])
-                if r["status"] == 0:  # (measured: 1.9e-6 at worst since the sweep runs on the matrix cores -- port and kernel share its bits, not the reductions')
+                if r["status"] == 0:  # (measured worst case over the 8,192 solves: 1.9e-6, at an input w where v ~ 0 -- TOL_U above; 1e-6 held until the
+                                       # sweep moved to the matrix cores.  Port and kernel share the sweep's bits, not the reductions': DESIGN.md section 5)
                     assert np.abs(r["p"].T - p1[s, v]).max() < 1e-5, (t, s, v)
                 n += 1; seen.add(r["status"])
                 n_resto += r["status"] == 0 and r["iters"] >= 35

@@ -143,6 +143,14 @@ def structured_joint_solve(nlp, K, Kown, rhs, report=None):
     blocks = [[spos[q] for q in s_] for s_ in sep]
     D = [Sfull[np.ix_(b_, b_)].copy() for b_ in blocks]
     Rr = [rs[b_].copy() for b_ in blocks]
+    # 3'. (round 6 study) the same block tridiagonal system by block CYCLIC REDUCTION: every other block eliminated at once, level by level --
+    # what a parallel recursion over all eight wavefronts would do instead of a chain from both ends.  The blocks are eliminated WITHOUT the
+    # neighbours' updates the chain gives them first: their conditioning is what decides whether that is safe.
+    if report is not None and isinstance(report, list):
+        Ul = [Sfull[np.ix_(blocks[i], blocks[i + 1])].copy() for i in range(Nmax)]
+        xb, cb = bcr_solve([d_.copy() for d_ in D], Ul, [r_.copy() for r_ in Rr])
+        conds["bcr_cond"] = cb
+        conds["bcr_x"] = xb
     conds["sep"] = []
     Zs = []
     for i in range(Nmax):
@@ -172,7 +180,63 @@ def structured_joint_solve(nlp, K, Kown, rhs, report=None):
             sol[I] = Ws[j][:, nc] - Ws[j][:, :nc] @ s_a - Ws[j][:, nc + 1:] @ z[o: o + 15]
             o += 15
     ref = np.linalg.solve(K1, r1)
+    if "bcr_x" in conds:  # the separators' solution by cyclic reduction against the chain's and the dense one
+        xb = np.concatenate([conds["bcr_x"][i] for i in range(Nmax + 1)])
+        order = np.concatenate(blocks)
+        conds["bcr_vs_chain"] = float(np.abs(xb - ysep[order]).max() / np.abs(ysep).max())
+        conds["bcr_vs_dense"] = float(np.abs(xb - ref[allsep][order]).max() / np.abs(ref[allsep]).max())
+        conds["chain_vs_dense"] = float(np.abs(ysep - ref[allsep]).max() / np.abs(ref[allsep]).max())
     return sol, ref, conds, (K1, r1)
+
+
+def bcr_solve(D, U, r):
+    """Block tridiagonal [D_i, U_i; U_i', D_{i+1}] x = r by block cyclic reduction (dense LU with partial pivoting inside a block, no
+    pivoting across blocks -- like the chain).  -> (x per block, condition numbers of every block at the moment it is eliminated)."""
+    n = len(D)
+    alive = list(range(n))
+    links = {i: U[i] for i in range(n - 1)}  # links[l] couples block l with the next ALIVE block to its right
+    elim = []  # (j, left, right, G C_l', G C_j, g): what the back-substitution needs
+    conds = []
+    while len(alive) > 1:
+        keep, gone = alive[0::2], alive[1::2]
+        pos = {b: k for k, b in enumerate(alive)}
+        newlinks = {}
+        for j in gone:
+            k = pos[j]
+            l = alive[k - 1]
+            rr = alive[k + 1] if k + 1 < len(alive) else None
+            conds.append(np.linalg.cond(D[j]))
+            lu = sla.lu_factor(D[j])
+            Cl = links[l]                      # rows: block l, columns: block j
+            cols = [Cl.T, r[j][:, None]] + ([links[j]] if rr is not None else [])
+            X = sla.lu_solve(lu, np.hstack(cols))
+            nl = Cl.shape[0]
+            GCl, g = X[:, :nl], X[:, nl]
+            D[l] -= Cl @ GCl
+            r[l] -= Cl @ g
+            if rr is not None:
+                Cj = links[j]
+                GCj = X[:, nl + 1:]
+                D[rr] -= Cj.T @ GCj
+                r[rr] -= Cj.T @ g
+                newlinks[l] = -Cl @ GCj      # block l against block rr
+                # (the lower coupling is its transpose: G is symmetric up to rounding)
+            else:
+                GCj = None
+            elim.append((j, l, rr, GCl, GCj, g))
+        for kk in range(len(keep) - 1):
+            if keep[kk] not in newlinks:
+                raise AssertionError("link lost")
+        links = newlinks
+        alive = keep
+    x = {alive[0]: np.linalg.solve(D[alive[0]], r[alive[0]])}
+    conds.append(np.linalg.cond(D[alive[0]]))
+    for j, l, rr, GCl, GCj, g in reversed(elim):
+        xj = g - GCl @ x[l]
+        if rr is not None:
+            xj = xj - GCj @ x[rr]
+        x[j] = xj
+    return x, conds
 
 
 def central_sigma(nlp, Xf, mu):
@@ -243,6 +307,9 @@ def main():
         rhs = rng.standard_normal(K.shape[0])
         rep = []
         sol, ref, conds, (K1, r1) = structured_joint_solve(jn, K, Kown, rhs, rep)
+        if "bcr_vs_dense" in conds:
+            print(f"   separators by cyclic reduction: blocks' condition at elimination max {max(conds['bcr_cond']):.1e} (chain: {max(conds['sep']):.1e}); "
+                  f"solution against the chain's {conds['bcr_vs_chain']:.1e}, against the dense solve {conds['bcr_vs_dense']:.1e} (chain against dense {conds['chain_vs_dense']:.1e})")
         print(f"{label}: unknowns {len(ref)}; interiors cond max {max(conds['interior']):.1e}; capacitance dims {sorted(set(conds['capdim']))} cond max {max(conds['cap']):.1e}; "
               f"separator dims {sorted(set(conds['sepdim']))} cond max {max(conds['sep']):.1e}; cond K {np.linalg.cond(K1):.1e}; "
               f"difference to the dense solve {np.abs(sol - ref).max() / np.abs(ref).max():.1e}; residual structured {np.abs(K1 @ sol - r1).max():.1e} dense {np.abs(K1 @ ref - r1).max():.1e}; "
