@@ -38,8 +38,9 @@ constexpr int kJYrhs = 60;
 constexpr int kJRowBuf = (kJB + 32) * kJB, kJRows = 8 * kJRowBuf;
 static_assert(kJRows >= kJB * (kJB + 64) + 2 * kJB * kJB, "the CPU build's staging fits");
 
+constexpr int kJL = 28;   // unknowns on either side of a link between two joint separators: 7 per vehicle
 struct JWork {
-  double *W, *Cc, *CW, *Mt, *Z, *zt, *Ds, *Us, *Zs, *xs, *aug, *flag;
+  double *W, *Cc, *CW, *Mt, *Z, *zt, *Ds, *Us, *Zs, *Zb, *Lc, *xs, *aug, *flag;  // Zb, Lc: the cyclic reduction's second inverse columns and link copies
   int *cl, *bs, *ordl, *meta, *cmask;
   int Nmax, NI;
 };
@@ -50,7 +51,7 @@ CFZP_FN size_t jstruct_doubles(const CSpec &sp) {
   size_t NI = 0;
   for (int a = 0; a < sp.V; ++a) NI += sp.N[a];
   const size_t Nm = jstruct_nmax(sp);
-  return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + kJB * kJB + 2 * kJB) + (Nm + 1) * (kJB * kJB + 2 * kJB * kJU + 2 * kJB) +
+  return NI * (kSI * kJR + kSI * kJC + kJC * kJR) + Nm * (kJMt + kJB * kJB + 2 * kJB) + (Nm + 1) * (kJB * kJB + 3 * kJB * kJU + kJL * kJL + 2 * kJB) +
          (size_t)kJRows + 8 + (NI * 16 + kMaxVeh + (Nm + 1) * kJB + 64 + NI + 3) / 2 + 16;
 }
 // doubles the structured elimination of one joint Newton system moves between its phases (bench.py's roofline of configs[3]): the band
@@ -67,7 +68,7 @@ CFZP_FN size_t jstruct_alg_doubles(const CSpec &sp, size_t nk, size_t ld, size_t
   if (sp.V == 1) return nk * ld + nk * ld / 8 + 3 * NI * kSI * 16 + 2 * NI * kSI * kJC + 2 * NI * kJC * 16 + 2 * (Nm + 1) * 256 + 4 * (Nm + 1) * 160 + 4 * nk;
   // (+ the capacitance systems' rows on their way from the builder to the elimination: two halves per interval index, written and read)
   return nk * ld + nk * ld / 8 + 2 * npp * 36 + 3 * NI * kSI * kJR + 2 * NI * kSI * kJC + 2 * NI * kJC * kJR + 3 * Nm * kJB * kJB + 2 * (Nm + 1) * kJB * kJB +
-         2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 4 * nk + 2 * (2 * Nm) * (size_t)kJRowBuf;
+         2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * 30 + 2 * (Nm + 1) * kJB * kJL + 2 * (Nm + 1) * kJL * kJL + 4 * nk + 2 * (2 * Nm) * (size_t)kJRowBuf;
 }
 CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   JWork s;
@@ -78,6 +79,7 @@ CFZP_FN JWork jstruct_carve(const CSpec &sp, double *p) {
   s.W = p; p += NI * kSI * kJR; s.Cc = p; p += NI * kSI * kJC; s.CW = p; p += NI * kJC * kJR;
   s.Mt = p; p += Nm * kJMt; s.Z = p; p += Nm * kJB * kJB; s.zt = p; p += Nm * 2 * kJB;
   s.Ds = p; p += (Nm + 1) * kJB * kJB; s.Us = p; p += (Nm + 1) * kJB * kJU; s.Zs = p; p += (Nm + 1) * kJB * kJU; s.xs = p; p += (Nm + 1) * 2 * kJB;
+  s.Zb = p; p += (Nm + 1) * kJB * kJU; s.Lc = p; p += (Nm + 1) * kJL * kJL;
   s.aug = p; p += (size_t)kJRows;  // the CPU build's staging (one block with its right-hand sides, a capacitance matrix and its right-hand sides); the device's row buffers
   s.flag = p; p += 8;
   s.cl = reinterpret_cast<int *>(p); s.bs = s.cl + NI * 16; s.ordl = s.bs + kMaxVeh; s.meta = s.ordl + (Nm + 1) * kJB; s.cmask = s.meta + 64;
@@ -572,6 +574,170 @@ __device__ __attribute__((noinline)) void jstruct_chain_back(int side, int mid, 
     xp1 = x1; xp2 = x2;
   }
 }
+
+// ---- the recursion over the joint separators by block CYCLIC REDUCTION (round 6) ------------------------------------------
+// The chain above keeps two of the workgroup's eight wavefronts busy for 26 dependent steps each.  The separator system is block
+// tridiagonal with a special coupling: block i and its right neighbour meet only in 28 x 28 entries -- the pt0 rows of block i (row
+// 16 a + p0 + c, p0 = 7 for block 0 and 8 otherwise) against the right-coupled rows of the neighbour (row 16 b + be) -- and eliminating a
+// block leaves exactly such a coupling between ITS two neighbours:
+//   D_l[P, P] -= C_l G_FF C_l',   D_r[F, F] -= C_i' G_PP C_i,   C_l <- -C_l G_FP C_i     (G = D_i^-1; F, P: the block's right-coupled / pt0 rows)
+// so every other block can leave at once, level by level (strides 1, 2, 4, ..: 25 + 13 + 6 + 3 + 2 + 1 blocks for 51), each needing the
+// columns F and P of its inverse: two 64-row eliminations on the matrix cores with 30 and 28 right-hand sides (unit vectors and the two
+// right-hand sides), all eight wavefronts at work.  tools/joint_condense_study.py: as accurate as the chain (the blocks are as well
+// conditioned without their neighbours' updates as with them: 1e12-6e15 either way, solutions equal to 5e-14 .. 2e-9).
+// Per block: Za = G [E_F | r] (64 x 30), Zb = G E_P (64 x 28), Lc = the left link as it stood (28 x 28), all for the back-substitution
+//   x_i = g - G[:, F] (C_l' x_l[P]) - G[:, P] (C_i x_r[F]).
+__device__ __forceinline__ int jrowF(int q) { return 16 * (q / 7) + (q % 7); }              // right-coupled unknown q = 7 b + be of a block
+__device__ __forceinline__ int jrowP(int q, int p0) { return 16 * (q / 7) + p0 + (q % 7); }  // pt0 unknown q = 7 a + c of a block
+__device__ __forceinline__ int jbcr_count(int st, int Nm) { return (Nm / st + 1) / 2; }      // blocks st, 3 st, 5 st, .. <= Nm
+
+// a level's eliminations: task t = (block st (2 (t >> 1) + 1), half t & 1); half 0: Za = D^-1 [E_F | r], half 1: Zb = D^-1 [E_P | 0]
+__device__ __attribute__((noinline)) int jbcr_lu_all(int w0, int nw, int st, int Nm, const cfzb::glb_f64 *Ds, const cfzb::glb_f64 *Us, cfzb::glb_f64 *Za, cfzb::glb_f64 *Zb,
+                                                     cfzb::lds_f64 *lds) {
+  Ds = juni(Ds); Us = juni(Us); Za = juni(Za); Zb = juni(Zb); w0 = juni(w0); nw = juni(nw); st = juni(st); Nm = juni(Nm);
+  lds = juni_lds(lds) + (threadIdx.x >> 6) * kLuLdsWave;
+  const int cnt = jbcr_count(st, Nm), lane0 = threadIdx.x & 63;
+  int f = 0;
+  for (int t = w0; t < 2 * cnt; t += nw) {
+    const int i = st * (2 * (t >> 1) + 1), half = t & 1, lane = lu_opaque(lane0);
+    const cfzb::glb_f64 *Di = Ds + (size_t)i * kJB * kJB, *Ui = Us + (size_t)i * kJB * kJU;
+    cfzb::glb_f64 *out = (half ? Zb : Za) + (size_t)i * kJB * kJU;
+    f |= lu64_build<32>(lds, out, [&](auto Jc, double (&v)[16]) {
+      constexpr int J = decltype(Jc)::value;
+      if constexpr (J < 4) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Di[(16 * J + k) * kJB + lane];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int q = 16 * (J - 4) + k;
+          if (q < kJL) v[k] = lane == (half ? jrowP(q, 8) : jrowF(q)) ? 1.0 : 0.0;  // (a block that leaves is never block 0: p0 = 8)
+          else if (q < 30) v[k] = half ? 0.0 : Ui[q * kJB + lane];
+          else v[k] = 0.0;
+        }
+      }
+    });
+  }
+  return f;
+}
+// X = A (G B) for operands of at most 28 x 28 given as element functions (indices run to 32: the functions return zeros beyond 28), on the
+// matrix cores: T = G B as 2 x 2 tiles of v_mfma_f64_16x16x4_f64 (eight k-steps each), whose accumulators ARE the B operands of the second
+// product as they stand (register r of a tile holds row (lane >> 4) + 4 r: the rows a k-step r asks of this lane); vec(i, s): two more
+// columns (28, 29) put into T before the second product (X[:, 28 + s] = A vec[:, s]); out(i, j, X[i][j]) for every entry this lane holds.
+typedef double jbcr_v4 __attribute__((ext_vector_type(4)));
+template <bool VEC, class FA, class FG, class FB, class FV, class FO>
+__device__ __forceinline__ void jbcr_triple(FA a, FG g, FB b, FV vec, FO out) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+  double ga[2][8], gb[2][8], aa[2][2][4];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ga[I][k] = g(16 * I + lo, 4 * k + hi); gb[I][k] = b(4 * k + hi, 16 * I + lo); }
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) aa[I][Ip][r] = a(16 * I + lo, 16 * Ip + 4 * r + hi);
+  jbcr_v4 T[2][2];
+#pragma unroll
+  for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+      jbcr_v4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[Ip][k], gb[J][k], t, 0, 0, 0);
+      T[Ip][J] = t;
+    }
+  if (VEC) {
+    if (lo == 12 || lo == 13) {
+#pragma unroll
+      for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[Ip][1][r] = vec(16 * Ip + hi + 4 * r, lo - 12);
+    }
+  }
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+      jbcr_v4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[I][Ip][r], T[Ip][J][r], x, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out(16 * I + hi + 4 * r, 16 * J + lo, x[r]);
+    }
+}
+// a level's updates: one wavefront per leaving block, three triple products of 28 x 28 operands read where they lie (the links in Us, the
+// inverse's columns in Za / Zb): no LDS.
+__device__ __attribute__((noinline)) void jbcr_update_all(int w0, int nw, int st, int Nm, cfzb::glb_f64 *Ds, cfzb::glb_f64 *Us, const cfzb::glb_f64 *Za, const cfzb::glb_f64 *Zb,
+                                                          cfzb::glb_f64 *Lc) {
+  Ds = juni(Ds); Us = juni(Us); Za = juni(Za); Zb = juni(Zb); Lc = juni(Lc); w0 = juni(w0); nw = juni(nw); st = juni(st); Nm = juni(Nm);
+  const int cnt = jbcr_count(st, Nm);
+  for (int t = w0; t < cnt; t += nw) {
+    const int i = st * (2 * t + 1), l = i - st, r = i + st <= Nm ? i + st : -1, p0l = l == 0 ? 7 : 8;
+    cfzb::glb_f64 *Dl = Ds + (size_t)l * kJB * kJB, *Ul = Us + (size_t)l * kJB * kJU, *Lci = Lc + (size_t)i * kJL * kJL;
+    const cfzb::glb_f64 *Ui = Us + (size_t)i * kJB * kJU, *Zai = Za + (size_t)i * kJB * kJU, *Zbi = Zb + (size_t)i * kJB * kJU;
+    // (every element function clamps its indices to 27 for the load and masks the value: the loads of a product stand in one block)
+    auto in = [](int x) { return x < kJL ? x : kJL - 1; };
+    auto CL = [&](int rho, int f) { const double v = Ul[in(f) * kJB + jrowP(in(rho), p0l)]; return (rho < kJL && f < kJL) ? v : 0.0; };  // the left link
+    auto CR = [&](int p, int fr) { const double v = Ui[in(fr) * kJB + jrowP(in(p), 8)]; return (p < kJL && fr < kJL) ? v : 0.0; };        // the right link
+    // D_l[P, P] -= CL GFF CL',  r_l[P] -= CL gF; the link as it stands is kept for the back-substitution
+    jbcr_triple<true>([&](int rho, int f) { const double v = CL(rho, f); if (rho < kJL && f < kJL) Lci[rho * kJL + f] = v; return v; },
+                      [&](int f, int f2) { const double v = Zai[in(f2) * kJB + jrowF(in(f))]; return (f < kJL && f2 < kJL) ? v : 0.0; },
+                      [&](int f2, int rho) { return CL(rho, f2); },
+                      [&](int f, int s_) { const double v = Zai[(28 + s_) * kJB + jrowF(in(f))]; return f < kJL ? v : 0.0; },
+                      [&](int rho, int j, double v) {
+                        if (rho >= kJL || j >= 30) return;
+                        if (j < kJL) Dl[jrowP(j, p0l) * kJB + jrowP(rho, p0l)] -= v; else Ul[j * kJB + jrowP(rho, p0l)] -= v;
+                      });
+    if (r < 0) continue;  // (the last block of its level may have no right neighbour: block l's link is never read again)
+    cfzb::glb_f64 *Dr = Ds + (size_t)r * kJB * kJB, *Ur = Us + (size_t)r * kJB * kJU;
+    // D_r[F, F] -= CR' GPP CR,  r_r[F] -= CR' gP
+    jbcr_triple<true>([&](int fr, int p) { return CR(p, fr); },
+                      [&](int p, int p2) { const double v = Zbi[in(p2) * kJB + jrowP(in(p), 8)]; return (p < kJL && p2 < kJL) ? v : 0.0; },
+                      [&](int p2, int fr) { return CR(p2, fr); },
+                      [&](int p, int s_) { const double v = Zai[(28 + s_) * kJB + jrowP(in(p), 8)]; return p < kJL ? v : 0.0; },
+                      [&](int fr, int j, double v) {
+                        if (fr >= kJL || j >= 30) return;
+                        if (j < kJL) Dr[jrowF(j) * kJB + jrowF(fr)] -= v; else Ur[j * kJB + jrowF(fr)] -= v;
+                      });
+    // the new link of block l (with block r): -CL GFP CR -- last: it overwrites CL
+    jbcr_triple<false>([&](int rho, int f) { return CL(rho, f); },
+                       [&](int f, int p) { const double v = Zbi[in(p) * kJB + jrowF(in(f))]; return (f < kJL && p < kJL) ? v : 0.0; },
+                       [&](int p, int fr) { return CR(p, fr); },
+                       [&](int, int) { return 0.0; },
+                       [&](int rho, int fr, double v) { if (rho < kJL && fr < kJL) Ul[fr * kJB + jrowP(rho, p0l)] = -v; });
+  }
+}
+// a level's back-substitution (levels in reverse): x_i = g - G[:, F] (CL' x_l[P]) - G[:, P] (CR x_r[F]), lane = row of block i
+__device__ __attribute__((noinline)) void jbcr_back_all(int w0, int nw, int st, int Nm, const cfzb::glb_f64 *Us, const cfzb::glb_f64 *Za, const cfzb::glb_f64 *Zb, const cfzb::glb_f64 *Lc,
+                                                        cfzb::glb_f64 *xs) {
+  Us = juni(Us); Za = juni(Za); Zb = juni(Zb); Lc = juni(Lc); xs = juni(xs); w0 = juni(w0); nw = juni(nw); st = juni(st); Nm = juni(Nm);
+  const int cnt = jbcr_count(st, Nm), lane = threadIdx.x & 63;
+  const bool on = lane < kJL;
+  const int q = on ? lane : 0, rP = jrowP(q, 8);
+  for (int t = w0; t < cnt; t += nw) {
+    const int i = st * (2 * t + 1), l = i - st, r = i + st <= Nm ? i + st : -1, p0l = l == 0 ? 7 : 8;
+    const cfzb::glb_f64 *Ui = Us + (size_t)i * kJB * kJU, *Zai = Za + (size_t)i * kJB * kJU, *Zbi = Zb + (size_t)i * kJB * kJU, *Lci = Lc + (size_t)i * kJL * kJL;
+    const cfzb::glb_f64 *xl = xs + (size_t)l * 2 * kJB, *xr = xs + (size_t)(r >= 0 ? r : l) * 2 * kJB;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;  // lane f: (CL' x_l[P])[f]; lane p: (CR x_r[F])[p]
+#pragma unroll
+    for (int rho = 0; rho < kJL; ++rho) { const double c = Lci[rho * kJL + q]; a0 += c * xl[jrowP(rho, p0l)]; a1 += c * xl[kJB + jrowP(rho, p0l)]; }
+    if (r >= 0) {
+#pragma unroll
+      for (int fr = 0; fr < kJL; ++fr) { const double c = Ui[fr * kJB + rP]; b0 += c * xr[jrowF(fr)]; b1 += c * xr[kJB + jrowF(fr)]; }
+    }
+    double x0 = Zai[28 * kJB + lane], x1 = Zai[29 * kJB + lane];
+#pragma unroll
+    for (int f = 0; f < kJL; ++f) { const double z = Zai[f * kJB + lane]; x0 -= z * struct_lane_get(a0, f); x1 -= z * struct_lane_get(a1, f); }
+#pragma unroll
+    for (int p = 0; p < kJL; ++p) { const double z = Zbi[p * kJB + lane]; x0 -= z * struct_lane_get(b0, p); x1 -= z * struct_lane_get(b1, p); }
+    xs[(size_t)i * 2 * kJB + lane] = x0; xs[(size_t)i * 2 * kJB + kJB + lane] = x1;
+  }
+}
 #endif
 
 // CPU build (and the definition of what the register eliminations compute): A (n x n, column-major, ld 64), nrhs columns R -> Z
@@ -1021,6 +1187,29 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
   { const long long t1 = tick(); ptk[1] += t1 - tp; tp = t1; }
   // ---- phase 3: recursion over the joint separators -------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(CFZ_JCHAIN)
+  {  // block cyclic reduction (round 6): levels of stride 1, 2, 4, ..; per level the leaving blocks' eliminations on all eight wavefronts, then
+     // their neighbours' updates; block 0 is what remains; the back-substitution runs through the levels in reverse
+    const int wv = CFZS_WAVE, nwv = CFZS_NW;
+    cfzb::lds_f64 *lb = cfzb::opaque((cfzb::lds_f64 *)lds);
+    int top = 1;
+    for (int st = 1; st <= Nm; st *= 2) {
+      top = st;
+      if (jbcr_lu_all(wv, nwv, st, Nm, (const cfzb::glb_f64 *)s.Ds, (const cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_f64 *)s.Zb, lb) && CFZS_LANE == 0) flag[0] = 1.0;
+      __syncthreads();
+      if (flag[0] != 0.0) return 1;
+      jbcr_update_all(wv, nwv, st, Nm, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_f64 *)s.Zb, (cfzb::glb_f64 *)s.Lc);
+      __syncthreads();
+    }
+    if (wv == 0 && jstruct_chain_mid(0, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.xs) && CFZS_LANE == 0) flag[0] = 1.0;
+    __syncthreads();
+    if (flag[0] != 0.0) return 1;
+    for (int st = top; st >= 1; st /= 2) {
+      jbcr_back_all(wv, nwv, st, Nm, (const cfzb::glb_f64 *)s.Us, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_f64 *)s.Zb, (const cfzb::glb_f64 *)s.Lc, (cfzb::glb_f64 *)s.xs);
+      __syncthreads();
+    }
+  }
+#else
   {  // from both ends, a wavefront each; the middle block receives both; back-substitution outwards
     const int mid = (Nm + 1) / 2, wv = CFZS_WAVE;
     unsigned nvp = 0;
@@ -1040,6 +1229,7 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
     if (wv < 2) jstruct_chain_back(wv, mid, Nm, (const cfzb::glb_f64 *)s.Zs, (cfzb::glb_f64 *)s.xs);
     __syncthreads();
   }
+#endif
 #else
   for (int i = 0; i <= Nm; ++i) {
     double *Di = s.Ds + (size_t)i * kJB * kJB, *Ui = s.Us + (size_t)i * kJB * kJU, *Zi = s.Zs + (size_t)i * kJB * kJU;
