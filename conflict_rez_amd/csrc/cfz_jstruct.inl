@@ -596,9 +596,10 @@ __device__ __attribute__((noinline)) int jbcr_lu_all(int w0, int nw, int st, int
                                                      cfzb::lds_f64 *lds) {
   Ds = juni(Ds); Us = juni(Us); Za = juni(Za); Zb = juni(Zb); w0 = juni(w0); nw = juni(nw); st = juni(st); Nm = juni(Nm);
   lds = juni_lds(lds) + (threadIdx.x >> 6) * kLuLdsWave;
-  const int cnt = jbcr_count(st, Nm), lane0 = threadIdx.x & 63;
+  // (st = 0: the block that remains, block 0, with its two right-hand sides: one task)
+  const int cnt = st ? jbcr_count(st, Nm) : 0, ntask = st ? 2 * cnt : 1, lane0 = threadIdx.x & 63;
   int f = 0;
-  for (int t = w0; t < 2 * cnt; t += nw) {
+  for (int t = w0; t < ntask; t += nw) {
     const int i = st * (2 * (t >> 1) + 1), half = t & 1, lane = lu_opaque(lane0);
     const cfzb::glb_f64 *Di = Ds + (size_t)i * kJB * kJB, *Ui = Us + (size_t)i * kJB * kJU;
     cfzb::glb_f64 *out = (half ? Zb : Za) + (size_t)i * kJB * kJU;
@@ -1201,9 +1202,13 @@ CFZP_FN int jstruct_solve(const CSpec &sp, const CDims &d, const CWork &w, const
       jbcr_update_all(wv, nwv, st, Nm, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_f64 *)s.Zb, (cfzb::glb_f64 *)s.Lc);
       __syncthreads();
     }
-    if (wv == 0 && jstruct_chain_mid(0, (cfzb::glb_f64 *)s.Ds, (cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.xs) && CFZS_LANE == 0) flag[0] = 1.0;
+    // block 0 remains: the same elimination with its two right-hand sides (the unit columns ride along unused); its solution is copied to xs
+    // after a workgroup barrier (the elimination stores in tile layout: another lane's words)
+    if (jbcr_lu_all(wv, nwv, 0, Nm, (const cfzb::glb_f64 *)s.Ds, (const cfzb::glb_f64 *)s.Us, (cfzb::glb_f64 *)s.Zs, (cfzb::glb_f64 *)s.Zb, lb) && CFZS_LANE == 0) flag[0] = 1.0;
     __syncthreads();
     if (flag[0] != 0.0) return 1;
+    if (wv < 2) s.xs[wv * kJB + CFZS_LANE] = s.Zs[(28 + wv) * kJB + CFZS_LANE];
+    __syncthreads();
     for (int st = top; st >= 1; st /= 2) {
       jbcr_back_all(wv, nwv, st, Nm, (const cfzb::glb_f64 *)s.Us, (const cfzb::glb_f64 *)s.Zs, (const cfzb::glb_f64 *)s.Zb, (const cfzb::glb_f64 *)s.Lc, (cfzb::glb_f64 *)s.xs);
       __syncthreads();
