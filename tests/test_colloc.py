@@ -419,6 +419,26 @@ def test_joint_structured_elimination_equals_the_band_elimination(plans, agents,
     assert np.abs(st["X"] - band["X"]).max() < 1e-7 and abs(st["f"] - band["f"]) < 1e-9 * band["f"]
 
 
+def test_cyclic_reduction_of_the_joint_separators_equals_the_chain():
+    """What the GPU's recursion over the joint separators relies on since round 6 (cfz_jstruct.inl `jbcr_*`; tools/joint_condense_study.py
+    `bcr_solve`, numpy, on the separator system of the matrix the CPU build assembles; three vehicles, plans of different lengths): the
+    system is block tridiagonal, every other block can be eliminated at once level by level WITHOUT its neighbours' updates -- the blocks are
+    as well conditioned then as the chain finds them -- and the solution is the chain's: to 1e-11 at the guess, to 1e-8 with half of the
+    pair rows made active (condition 6e15, where the chain itself is 3e-6 from a dense solve)."""
+    import importlib.util
+
+    spec_ = importlib.util.spec_from_file_location("joint_condense_study", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "joint_condense_study.py"))
+    st = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(st)
+    jn, opt, X0 = st.study_problem(3, 4)
+    rng = np.random.default_rng(0)
+    for nu, mu, act, tol in ((np.zeros(jn.m), 0.1, 0.0, 1e-11), (rng.standard_normal(jn.m) * 0.3, 1e-4, 0.5, 1e-8)):
+        K, Kown = st.matrices(jn, opt, X0, nu, mu, act, rng)
+        sol, ref, conds, _ = st.structured_joint_solve(jn, K, Kown, rng.standard_normal(K.shape[0]), [])
+        assert conds["bcr_vs_chain"] < tol and conds["bcr_vs_dense"] < 10.0 * max(conds["chain_vs_dense"], 1e-12), (conds["bcr_vs_chain"], conds["bcr_vs_dense"], conds["chain_vs_dense"])
+        assert max(conds["bcr_cond"]) < 100.0 * max(conds["sep"])  # eliminated without their neighbours' updates, the blocks are no worse
+
+
 @pytest.mark.gpu
 def test_joint_colloc_on_gpu(plans, tmp_path):
     """cfz_joint_colloc against the CPU build of the same source, and MultiVehiclePlanner.solve_single_problems ->

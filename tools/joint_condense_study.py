@@ -268,10 +268,10 @@ def matrices(nlp, opt, X, nu, mu, active_pairs=0.0, rng=None):
     return K, Kown
 
 
-def main():
+def study_problem(nv=3, ns=4):
+    """(joint NLP, options, guess along the vehicles' spline paths) of nv vehicles on their first ns (+ 1 for every other vehicle) strategy
+    steps: plans of different lengths, as tests/test_colloc.py builds them."""
     import test_colloc as tc
-    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    ns = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     plans = tc.plans.__wrapped__() if hasattr(tc.plans, "__wrapped__") else None
     if plans is None:
         from conflict_rez_amd import strategy as strat
@@ -286,7 +286,6 @@ def main():
     nsets = [ns + (i % 2) for i in range(nv)]  # plans of different lengths
     jn, sp = tc._joint_problem(plans, agents, nsets, nps=5)
     opt = ipm.IpmOptions(**tc.COLLOC_OPT)
-    rng = np.random.default_rng(0)
     # a guess: every vehicle along its spline path
     from scipy.interpolate import interp1d
     zs = []
@@ -300,6 +299,14 @@ def main():
         t_i = np.concatenate([k + jn.tau for k in range(N)]) / N * zs[j]["t"][-1]
         sing.append({k: interp1d(zs[j]["t"], zs[j][k])(t_i) for k in ("x", "y", "psi", "v", "delta", "a", "w")})
     X0 = jn.pack(sing, float(np.mean([z["t"][-1] / N for z, N in zip(zs, jn.N)])))
+    return jn, opt, X0
+
+
+def main():
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    ns = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    jn, opt, X0 = study_problem(nv, ns)
+    rng = np.random.default_rng(0)
     for label, X, nu, mu, act in (("guess, mu 0.1", X0, np.zeros(jn.m), 0.1, 0.0),
                                   ("guess, random multipliers, 10 % of the pair rows active", X0, rng.standard_normal(jn.m) * 0.3, 1e-3, 0.1),
                                   ("guess, random multipliers, 50 % of the pair rows active", X0, rng.standard_normal(jn.m) * 0.3, 1e-4, 0.5)):
