@@ -1796,20 +1796,29 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   CFZ_END
   // The pose of stage 0 is pinned to the measured state: a collision row violated there by more
   // than constr_viol_tol cannot be repaired (status 4; reference: IPOPT fails, step() falls back).
-  CFZ_LANES(tid)
-    double worst = INFINITY;
-    if (tid < nb) {
-      double A[4][2], b[4], V[4][2], sep[2];
-      block_polygon(sp, m, L, 0, tid, A, b, V);
-      double s0, c0_;
-      sincos(m[L.x0 + 2], &s0, &c0_);
-      select_rows_sep(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0, sep, sp.vv_rows);
-      worst = fmin(sep[0], sep[1]);
-    }
-    CFZ_P(rd, 0) = worst;
-  CFZ_END
-  CFZ_REDUCE(0, 0, 1, rd, ro);
+  // Its nb blocks are checked by the lanes of the stage slots BEYOND the horizon (kMaxN - N slots: eight lanes at N = 30), inside the
+  // passes of the first working-set selection below, where they would idle -- until round 6 the check was a selection pass and a reduction
+  // of its own in front of it (2 % of a 2.5-iteration solve).  Horizons that leave fewer spare lanes than a stage has check first, as before.
   const CarryLay CL = carry_layout(N, nb);
+  const int nspare = kNL - N * kLPS;
+  const bool merged = nspare >= kLPS;
+  double worst0 = INFINITY;
+  if (!merged) {
+    CFZ_LANES(tid)
+      double worst = INFINITY;
+      if (tid < nb) {
+        double A[4][2], b[4], V[4][2], sep[2];
+        block_polygon(sp, m, L, 0, tid, A, b, V);
+        double s0, c0_;
+        sincos(m[L.x0 + 2], &s0, &c0_);
+        select_rows_sep(A, b, V, m[L.x0], m[L.x0 + 1], c0_, s0, sp.g, 0, sep, sp.vv_rows);
+        worst = fmin(sep[0], sep[1]);
+      }
+      CFZ_P(rd, 0) = worst;
+    CFZ_END
+    CFZ_REDUCE(0, 0, 1, rd, ro);
+    worst0 = ro[0];
+  }
   // ... and so is a measured state outside the boxes on x, y, v, delta by more than constr_viol_tol (stage 0 is bounded like every
   // other stage, vehicle_follower.py:205-240, and pinned to the measurement, :194-199)
   bool x0_out = false;
@@ -1817,8 +1826,8 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
     const double v = CFZ_UNIFORM(m[L.x0 + bcol(q)]);
     x0_out = x0_out || v < sp.bounds[2 * q] - sp.constr_viol_tol || v > sp.bounds[2 * q + 1] + sp.constr_viol_tol;
   }
-  if (ro[0] < sp.dmin - sp.constr_viol_tol || x0_out) {
-    out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = ro[0];
+  if (!merged && (worst0 < sp.dmin - sp.constr_viol_tol || x0_out)) {
+    out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = worst0;
     if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
     return;
   }
@@ -1827,16 +1836,20 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
   const bool shift_hint = warm && sp.carry_shift != 0 && CFZ_UNIFORM(wst[CL.shifted]) != 0.0;  // oracle/ipm.py carry_shift
   CFZ_LANES(tid)
     const int k = tid >> kLPSBits, sub = tid & (kLPS - 1);
-    if (k < N) {
+    const bool pre = merged && k >= N;  // a lane beyond the horizon: the check of stage 0 at the measured state
+    double worst = INFINITY;
+    if (k < N || pre) {
       // working set and slacks from the un-pushed warm start (IPOPT: s = g(x0)), then pushed inside
-      const double x = m[L.p + k * kNP], y = m[L.p + k * kNP + 1];
+      const int ks = pre ? 0 : k;
+      const double x = pre ? m[L.x0] : m[L.p + k * kNP], y = pre ? m[L.x0 + 1] : m[L.p + k * kNP + 1];
       double sn, cn;
-      sincos(m[L.p + k * kNP + 2], &sn, &cn);
-      for (int j = sub; j < nb; j += kLPS) {
-        const int t = k * nb + j;
+      sincos(pre ? m[L.x0 + 2] : m[L.p + k * kNP + 2], &sn, &cn);
+      for (int j = pre ? tid - N * kLPS : sub; j < nb; j += pre ? nspare : kLPS) {
+        const int t = ks * nb + j;
         double A[4][2], b[4], V[4][2], sep[2];
-        block_polygon(sp, m, L, k, j, A, b, V);
+        block_polygon(sp, m, L, ks, j, A, b, V);
         const int c0 = select_rows_sep(A, b, V, x, y, cn, sn, sp.g, 0, sep, sp.vv_rows);
+        if (pre) { worst = fmin(worst, fmin(sep[0], sep[1])); continue; }
         sel_ptr(m, L)[t] = c0;
         if (!warm) {
           for (int r = 0; r < 2; ++r) {
@@ -1863,7 +1876,17 @@ CFZ_FN void solve_instance(const KSpec &sp, const KDer &dv, const double *x0g, c
         }
       }
     }
+    CFZ_P(rd, 0) = worst;
   CFZ_END
+  if (merged) {
+    CFZ_REDUCE(0, 0, 1, rd, ro);
+    worst0 = ro[0];
+    if (worst0 < sp.dmin - sp.constr_viol_tol || x0_out) {
+      out_i[0] = 0; out_i[1] = 4; out_d[0] = 0.0; out_d[1] = INFINITY; out_d[2] = worst0;
+      if (wst) { CFZ_LANES(tid) if (tid == 0) wst[CL.valid] = 0.0; CFZ_END }
+      return;
+    }
+  }
 #if defined(CFZ_NO_RESTO)  // diagnostic builds: what the restoration phase's presence costs the hot loop
   const bool resto_on = false;
 #else
