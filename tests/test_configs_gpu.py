@@ -364,6 +364,50 @@ def test_joint_plan_against_the_independent_solver_on_gpu(name):
     check_joint_against_independent(r2["traj"], r2["dt"], True, name)
 
 
+def test_full_length_four_vehicle_plan_ends_at_a_certified_optimum():
+    """BASELINE configs[3]'s problem at FULL length (50 / 30 / 30 / 40 intervals, six pairs, dmin = 0.2: two pairs of bodies in contact) --
+    the one problem of this path no independent solver converges on.  The fixture
+    (tests/golden/make_joint_full_certificate.py from a dump of tools/joint_full_tight.py) holds the kernel's plan at TIGHT tolerances and
+    what a solver-free check on the INDEPENDENT statement (oracle/independent_joint.py: polygon distances, no working sets) says about it:
+    every row holds (equalities 2.4e-7, inequalities 4e-12) and the cost gradient is a combination of the gradients of the equality rows
+    and of the ACTIVE inequality rows with multipliers of the right sign to 1.8e-7 (relative) -- eight active pair rows in three pairs, two
+    of them corner against corner.  Here: the kernel, from the fixture's guess, ends at that cost again (1e-7 relative; rows to 1e-6 on the
+    independent statement; the line search exhausted or the iteration limit AT the optimum, as in the other tight runs), and at the
+    reference's tolerance at a plan whose rows hold to 1e-2 and whose cost lies within 1.5 % below (the rows relaxed by the tolerance)."""
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from conflict_rez_amd import engine
+    from make_independent_joint import plans_of_strategy
+    from make_joint_full_certificate import rows_of, statement
+    from oracle.independent_joint import GeometricJointIpm
+
+    d = np.load(os.path.join(here, "golden", "joint_kernel_0123_d20_full.npz"))
+    assert float(d["kcertificate"]) < 1e-6 and d["keq"] < 1e-6 and d["kineq"] > -1e-7 and len(d["kactive"]) >= 6 and len(set(d["kactive"][:, 0])) >= 2 and int(d["kcontacts"]) >= 1
+    assert (d["kactive"][:, 2] >= 0.0).all() and (d["kactive"][:, 2] > 0.1).sum() >= 6  # multipliers of the right sign, seven of the eight rows really pushing
+    dmin = float(d["dmin"])
+    plans = plans_of_strategy()
+    agents = sorted(plans)
+    tubes = [[((s["back"][0], s["back"][1]), (s["front"][0], s["front"][1])) for s in plans[a][0][1:]] for a in agents]
+    args = (scenarios.parking_lot_spec(n_nbr=0, N=2, dmin=dmin), [plans[a][1][0] for a in agents], tubes, [d[f"guess{a}"] for a in range(4)], float(d["dt0"]),
+            [float(plans[a][1][-1, 2]) for a in agents])
+    gs, pairs = statement(dmin)
+
+    def on_the_independent_statement(r):
+        z = np.concatenate([np.asarray(t, float).ravel() for t in r["traj"]] + [[float(r["dt"])]])
+        nlp = GeometricJointIpm(gs, pairs, z)
+        return float(nlp.f(z)), rows_of(nlp, gs, pairs, z)
+
+    r1 = engine.joint_colloc(*args, max_iter=400)
+    f1, (eq1, ineq1) = on_the_independent_statement(r1)
+    assert r1["status"] == 0 and eq1 < 1e-2 and ineq1 > -1e-2 and -1.5e-2 < (f1 - float(d["kcost"])) / float(d["kcost"]) < 1e-4, (r1["status"], eq1, ineq1, f1)
+    r2 = engine.joint_colloc(*args, max_iter=3000, tol=1e-8, constr_viol_tol=1e-9, exact_rows=1)
+    f2, (eq2, ineq2) = on_the_independent_statement(r2)
+    assert r2["status"] in (0, 1, 2) and eq2 < 1e-6 and ineq2 > -1e-6 and abs(f2 - float(d["kcost"])) < 1e-7 * float(d["kcost"]), (r2["status"], r2["iters"], eq2, ineq2, f2, float(d["kcost"]))
+
+
 def test_joint_plan_does_not_depend_on_the_order_of_its_vehicles():
     """A property the reference's joint NLP has by construction (multi_vehicle_planner.py:343-480 loops over the agents and over
     the pairs; no vehicle is special): listing the vehicles in another order gives the same plans and the same shared dt.  The
