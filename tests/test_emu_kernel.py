@@ -235,3 +235,29 @@ def test_mirror_symmetry_on_the_cpu(golden, ospec):
             s1, it1, z1 = solve(mspec, x0m, mir(ref, 0), mir(nbr, 1), zum)
             back = mir(z1, 0); back[4] = -back[4]; back[6] = -back[6]
             assert (s0, it0) == (s1, it1) and np.abs(back - z0).max() < 1e-7, (i, s0, it0, s1, it1)
+
+
+def test_eight_lanes_per_stage_build_of_the_kernel_source():
+    """`-DCFZ_LPS=8` (round 6's go / no-go: 256-lane instances, four wavefronts, the stage sum a `row_half_mirror` longer, the reductions over
+    four wavefronts) is a diagnostic build, not the product -- but the switch must not rot: the CPU build of the same source with eight
+    lanes per stage solves the goldens with the oracle's status and iteration counts (other lane partials, the same algorithm).  Run in a
+    child process: the binding caches one library per process."""
+    import os
+
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import emu_binding as emu\n"
+            "from oracle import ipm\n"
+            "from oracle.mpc_nlp import MpcSpec\n"
+            "from conflict_rez_amd import scenarios\n"
+            "spec = scenarios.parking_lot_spec()\n"
+            "ospec = MpcSpec(N=spec.N, dt=spec.dt, A_obs=spec.A_obs, b_obs=spec.b_obs, n_nbr=spec.n_nbr)\n"
+            "g = np.load(%r)\n"
+            "assert emu.build().endswith('_lps8.so')\n"
+            "for b in (0, 5, 9, 17, 19):\n"
+            "    r = emu.solve(ospec, ipm.IpmOptions(), g['x0'][b], g['ref'][b], g['nbr'][b], g['zu'][b], want_duals=False)\n"
+            "    assert (r['status'], r['iters']) == (int(g['meta'][b, 0]), int(g['meta'][b, 1])), (b, r['status'], r['iters'])\n"
+            "    assert r['status'] != 0 or np.abs(r['zu'] - g['sol'][b]).max() < 1e-7\n"
+            "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+                                os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_golden.npz"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFZ_EMU_LPS="8"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
