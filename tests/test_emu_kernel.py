@@ -261,3 +261,29 @@ def test_eight_lanes_per_stage_build_of_the_kernel_source():
                                 os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_golden.npz"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CFZ_EMU_LPS="8"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+def test_horizons_at_the_edges_of_the_lane_map():
+    """Horizons where round 6's layout tricks switch over, CPU build of the kernel source against the C port (status, iteration count,
+    solution): N = 32 leaves no spare stage slot and N = 31 exactly one stage's worth of lanes for the stage-0 feasibility check (it runs
+    in the lanes beyond the horizon when there are at least as many as a stage has, and as a pass of its own otherwise); N = 4 is too short
+    for the value function of stage 0 to stand in the step's slots of stages 1-5 (it shares the cos / sin slots then, and the step phase
+    forms the headings' sine and cosine again)."""
+    from conflict_rez_amd import scenarios
+    from oracle.mpc_nlp import MpcSpec
+
+    table, _ = scenarios.load_reference_table()
+    seen = set()
+    for N, n_nbr, seed in ((32, 3, 4), (31, 3, 5), (4, 1, 6)):
+        sp = scenarios.parking_lot_spec(n_nbr=n_nbr, N=N)
+        osp = MpcSpec(N=N, dt=sp.dt, A_obs=sp.A_obs, b_obs=sp.b_obs, n_nbr=n_nbr)
+        k0, noise = scenarios.sample_scenarios(2, table, seed=seed)  # raw draws: an infeasible measured state may be among them
+        x0, ref, nbr, zu = scenarios.mpc_batch_from_table(sp, table[: n_nbr + 1], k0, noise[:, : n_nbr + 1])
+        for b in range(min(len(x0), 4)):
+            r = emu.solve(osp, ipm.IpmOptions(), x0[b], ref[b], nbr[b], zu[b], want_duals=False)
+            q = port.solve(osp, x0[b], ref[b], nbr[b], zu[b].T.copy())
+            assert (r["status"], r["iters"]) == (q["status"], q["iters"]), (N, b, r["status"], r["iters"], q["status"], q["iters"])
+            seen.add(r["status"])
+            if r["status"] == 0:
+                assert np.abs(r["zu"][:5] - q["p"].T[:5]).max() < 1e-6, (N, b)
+    assert 0 in seen

@@ -411,7 +411,9 @@ def test_other_shapes_and_error_paths():
     from oracle.mpc_nlp import MpcSpec
 
     table, _ = scenarios.load_reference_table()
-    for n_obs, n_nbr, N, B in ((4, 0, 30, 5), (6, 1, 12, 3), (0, 2, 8, 1)):
+    # (round 6: N = 32 / 31 -- no / exactly one stage's worth of spare lanes for the stage-0 check -- and N = 4, too short for the value
+    # function to leave the cos / sin slots alone: the horizons where the kernel's layout switches over, tests/test_emu_kernel.py)
+    for n_obs, n_nbr, N, B in ((4, 0, 30, 5), (6, 1, 12, 3), (0, 2, 8, 1), (6, 3, 32, 4), (6, 3, 31, 4), (6, 1, 4, 4)):
         sp = scenarios.parking_lot_spec(n_nbr=n_nbr, N=N, n_obs=n_obs)
         osp = MpcSpec(N=N, dt=sp.dt, A_obs=sp.A_obs, b_obs=sp.b_obs, n_nbr=n_nbr)
         k0, noise = scenarios.sample_scenarios(B, table, seed=4)
