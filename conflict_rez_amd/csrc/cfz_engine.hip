@@ -2,7 +2,7 @@
 //
 // Kernels
 //   solve_kernel   one 128-lane workgroup (two wavefronts; four lanes of a DPP quad per stage) per MPC-step NLP; iterate,
-//                  stage data and reduction scratch in LDS (cfz_solver.inl: 40,920 B per instance, four instances per CU);
+//                  stage data and reduction scratch in LDS (cfz_solver.inl: 40,952 B per instance, four instances per CU);
 //                  parameters, warm start and solution are the only algorithmic global-memory traffic
 //                  (8*(5 + 3N + 3N n_nbr + 2*7N) B per instance) beside the carry record of the slot (8.8 KB)
 //   loop_kernel    the persistent closed loop (cfz_loop_run): the same solver body fed from per-iteration ticket queues of

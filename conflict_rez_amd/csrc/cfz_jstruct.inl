@@ -758,7 +758,9 @@ CFZP_FN int jstruct_block_serial(double *aug, const double *A, const double *R, 
 // (15 unknowns, identity-padded) with 7 coupling columns and b1, b2, and their blocks are written with the Schur complements -C'W in place
 // (owner computes).  Compact storage of its own: D1[i][16 x 16], U1[i][16 x 10] (columns 0..6: the coupling with separator i + 1, 7 / 8:
 // b1 / b2), Z1 likewise, lane-major.  It replaces cfz_struct.inl's path (separators of 14-31 with the tube rows inside, a recursion that
-// handed rows over between the lanes of a wavefront through memory) for the product; that file stays for `structured = 2`.
+// handed rows over between the lanes of a wavefront through memory), which left the library in round 6.  (The separators of ONE vehicle stay a
+// chain from both ends: their cyclic reduction -- 16-row blocks, 7 x 7 couplings, sixteen right-hand sides per leaving block -- was built in
+// round 6 and measured slower, a 16-row elimination being too small for the fixed costs of a level: docs/notebook.md.)
 #if defined(__HIP_DEVICE_COMPILE__)
 constexpr int kJ1U = 10;
 __device__ __attribute__((noinline)) int j1_interiors_all(int w0, int nw, const cfzb::glb_i32 *m, const cfzb::glb_f64 *ab, int kb, int ld, int off,

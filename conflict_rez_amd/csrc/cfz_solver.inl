@@ -15,8 +15,11 @@
 //   dynamics  all four lanes integrate the stage (RK4, identical instruction stream, so the redundancy costs no time) and
 //             each propagates its own columns of the sensitivities: lane sub column sub, every lane column 4
 //   stage     condensed H_k, g_k, bound multipliers, costs: computed by the whole quad, written by sub 0
-//   Riccati   backward sweep: 30 dependent stages on lane 0, out of line (registers of its own); forward step and
-//             costates: linear recurrences once the gains are known -> Kogge-Stone scans, one stage per lane of wavefront 0
+//   Riccati   backward sweep: 30 dependent stages, out of line (registers of its own) -- since round 5 on the matrix cores, the first
+//             wavefront's 64 lanes holding the stage's 16 x 16 tiles (riccati_backward_mfma; the one-lane sweep remains as
+//             -DCFZ_RICCATI_SCALAR); forward step and costates: linear recurrences once the gains are known -> Kogge-Stone scans,
+//             one stage per lane of wavefront 0
+// (CFZ_LPS = 8: eight lanes per stage, four wavefronts per instance -- round 6's go / no-go, a diagnostic build; the product is 4.)
 // Reductions over the workgroup run on registers: DPP butterflies inside a row of 16 lanes, v_readlane across the four
 // rows of a wavefront, one 16-double LDS exchange between the two wavefronts.
 //
