@@ -101,6 +101,7 @@ def test_planning_extras_of_the_bench_line():
     assert c3["converged"] == 8 and c3["unknowns"] == 12350 - 16 * 30 and c3["half_bandwidth"] == 51 and c3["band_bytes"] == c3["unknowns"] * (2 * 51 + 1) * 8
     assert c3["iters_max"] <= 120 and "structured" in c3["elimination"] and c3["workspace_bytes_per_plan"] < 60e6
     assert c3["iters_top3"][0] == c3["iters_max"] and abs(c3["ms_per_iteration_of_the_slowest_plan"] - 1e3 * c3["joint_s"] / c3["iters_max"]) < 1e-9
+    assert c3["p95"]["max_iter"] <= c3["iters_max"] and 0.95 * 8 <= c3["p95"]["converged"] <= 8 and c3["p95"]["plans_per_s"] > 0.5
     info4 = engine.colloc_elimination_info([11, 7, 7, 9])  # the four vehicles' strategy lengths
     assert (info4["nk"], info4["kb"]) == (c3["unknowns"], 51)
     band4 = engine.colloc_elimination_info([11, 7, 7, 9], structured=0)
